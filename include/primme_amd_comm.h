@@ -1,0 +1,48 @@
+/* primme_amd_comm.h — C-ABI of the communicator and of the distributed operator
+ * handle behind the ready-made callbacks of primme_amd.h.
+ *
+ * Replaces what every application of the reference writes by hand around
+ * MPI: the globalSumReal callback (reference include/primme_eigs.h:192-195,
+ * examples/ex_eigs_mpi.c:209-218) and the row-partitioned matvec with its
+ * neighbour exchange (examples/ex_eigs_mpi.c:150-207).
+ */
+#ifndef PRIMME_AMD_COMM_H
+#define PRIMME_AMD_COMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "primme_amd_kernels.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct primme_amd_comm primme_amd_comm;
+
+/* rank 0 creates the 128-byte id; the launcher distributes it to all ranks */
+int primme_amd_comm_unique_id(void *id128);
+int primme_amd_comm_create(primme_amd_comm **comm, const void *id128, int rank, int nranks);
+int primme_amd_comm_destroy(primme_amd_comm *comm);
+int primme_amd_comm_rank(const primme_amd_comm *comm);
+int primme_amd_comm_size(const primme_amd_comm *comm);
+int primme_amd_comm_halo(primme_amd_comm *c, void *hip_stream, const void *x, int64_t ldx,
+      int64_t nrows, int ncols, size_t elem, int64_t send_lo_cnt, int64_t send_hi_cnt, void *lo,
+      int64_t recv_lo_cnt, void *hi, int64_t recv_hi_cnt);
+int primme_amd_comm_allgather(primme_amd_comm *c, void *hip_stream, const void *send, void *recv,
+      size_t bytes_per_rank);
+int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n, int64_t *all);
+
+/* Operator handle for primme->matrix / primme->preconditioner: a local sparse
+ * operator plus (optionally) the communicator that feeds its halo. */
+typedef struct primme_amd_operator primme_amd_operator;
+int primme_amd_operator_create(primme_amd_operator **op, hipk_csr *A, primme_amd_comm *comm_or_null);
+int primme_amd_operator_destroy(primme_amd_operator *op);
+hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op);
+/* y = A x on `hip_stream` including the halo exchange */
+int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stream, const void *x, int64_t ldx,
+      void *y, int64_t ldy, int ncols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

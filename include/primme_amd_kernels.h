@@ -1,0 +1,164 @@
+/* primme_amd_kernels.h — C-ABI of the device layer ("hip_wrapper") under the solver.
+ *
+ * This is boundary B2 of SURVEY.md §8(b): the numerical backend the reference
+ * resolves at compile time to src/linalg/blaslapack.c (CPU), cublas_wrapper.c
+ * (cuBLAS/hipBLAS) or magma_wrapper.c.  Each entry point below names the
+ * reference backend routine(s) or fused solver step it replaces (file:line in
+ * /root/reference).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Conventions
+ *   - "panel" = tall-skinny column-major matrix with m local rows (10^5..10^7)
+ *     and a few (<= 64+64) columns, resident in HBM for the whole solve.
+ *   - all launches go to the stream owned by the hipk_ctx; nothing synchronises
+ *     unless the name says so (hipk_sync, *_to_host).
+ *   - small operands (coefficients, Ritz values, reduction results) live in
+ *     DEVICE memory too, so that chains like dots -> all-reduce -> update run
+ *     without a host round trip (the reference's GPU backend syncs on every
+ *     Num_set_matrix/Num_get_matrix, cublas_wrapper.c:335-395).
+ *   - dtype: element type of the panels.  Reductions accumulate and are returned
+ *     in double (real) / double complex (complex), laid out as doubles.
+ *   - return 0 on success, PRIMME-style negative code otherwise.
+ */
+#ifndef PRIMME_AMD_KERNELS_H
+#define PRIMME_AMD_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hipk_ctx hipk_ctx;
+
+typedef enum { HIPK_F64 = 0, HIPK_F32 = 1, HIPK_C64 = 2 /* double complex */,
+               HIPK_C32 = 3 /* float complex */ } hipk_dtype;
+
+/* A column range of one panel; kernels take up to HIPK_MAX_SEGS of them so that
+ * [locked evecs | V] is streamed in one launch (reference ortho.c:236-246 issues
+ * one gemv per array). */
+#define HIPK_MAX_SEGS 3
+typedef struct { const void *base; int64_t ld; int ncols; } hipk_seg;
+
+/* ---- context, memory, copies ------------------------------------------------
+ * replaces Num_malloc/free_Sprimme (cublas_wrapper.c:187-233), Num_set_matrix /
+ * Num_get_matrix (:335-395), Num_copy_matrix (:739), Num_zero_matrix (:768). */
+int  hipk_ctx_create(hipk_ctx **ctx, void *hip_stream_or_null);
+int  hipk_ctx_destroy(hipk_ctx *ctx);
+void *hipk_ctx_stream(hipk_ctx *ctx);                 /* the hipStream_t            */
+int  hipk_malloc(hipk_ctx *ctx, size_t bytes, void **dptr);
+int  hipk_free(hipk_ctx *ctx, void *dptr);
+int  hipk_host_alloc(hipk_ctx *ctx, size_t bytes, void **hptr); /* pinned          */
+int  hipk_host_free(hipk_ctx *ctx, void *hptr);
+int  hipk_h2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async  */
+int  hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async  */
+int  hipk_d2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async  */
+int  hipk_memset0(hipk_ctx *ctx, void *dst, size_t bytes);
+int  hipk_sync(hipk_ctx *ctx);
+int  hipk_is_device_ptr(const void *p);  /* Num_check_pointer, cublas_wrapper.c:162 */
+/* events around a region on the ctx stream; ms returned by hipk_timer_stop (syncs) */
+int  hipk_timer_start(hipk_ctx *ctx);
+int  hipk_timer_stop(hipk_ctx *ctx, float *ms);
+
+/* ---- TN panel: inner products ------------------------------------------------
+ * out[j + c*ldout] = sum_i conj(col_j(i)) * X(i,c),  j over all segment columns.
+ * `out` is a DEVICE array of accumulator scalars (double / double complex).
+ * If upper_from >= 0 only entries with j <= upper_from + c are guaranteed
+ * (Hermitian projection: H(:,k+c), reference update_projection.c:99-122).
+ * Replaces Num_gemm_ddh (cublas_wrapper.c:479-499, blaslapack.c:610-661),
+ * Num_gemv_ddh (:566), Num_dot (:647), Num_compute_gramm(_ddh) (:898-987). */
+int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
+      const void *X, int64_t ldX, int nx, double *out_dev, int ldout);
+
+/* ---- NN panel: X(:,c) -= [segs] * coef(:,c), then nrm2[c] = ||X(:,c)||^2 -------
+ * coef: DEVICE array of accumulator scalars, ldcoef rows stride.  nrm2 (DEVICE,
+ * nx doubles) may be NULL.  One fused pass over the basis: the CGS update
+ * (reference ortho.c:262-291: two Num_gemv_dhd + Num_dot) and the projector of
+ * ortho_single_iteration (ortho.c:894-925). */
+int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
+      const double *coef_dev, int ldcoef, void *X, int64_t ldX, int nx, double *nrm2_dev);
+
+/* ---- fused Ritz / residual / restart update ----------------------------------
+ * The multi-output panel op of reference auxiliary_eigs_normal.c:155-388
+ * (Num_update_VWXR) and restart.c:1233-1294.  V, W: m x k panels (ld ldVW).
+ * h: DEVICE k x nh coefficients (accumulator scalars, leading dim ldh);
+ * theta: DEVICE nh Ritz values (doubles).
+ * jobs[]: what to produce, executed row-wise so destinations may alias V / W
+ * columns (in-place restart) — all inputs of a row are read before any output
+ * of that row is written.
+ *   HIPK_JOB_XV  : dst = V*h(:,col)
+ *   HIPK_JOB_XW  : dst = W*h(:,col)
+ *   HIPK_JOB_RES : dst = W*h(:,col) - theta[col]*V*h(:,col)   (dst may be NULL)
+ *                  and nrm2_dev[slot] = ||that||^2  when slot >= 0
+ */
+typedef enum { HIPK_JOB_XV = 0, HIPK_JOB_XW = 1, HIPK_JOB_RES = 2 } hipk_job_kind;
+typedef struct { int kind; int col; void *dst; int slot; } hipk_job;
+#define HIPK_MAX_JOBS 160
+int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
+      int64_t ldVW, int k, const double *h_dev, int ldh, const double *theta_dev,
+      const hipk_job *jobs, int njobs, double *nrm2_dev);
+
+/* ---- column utilities ---------------------------------------------------------
+ * Num_scal (cublas_wrapper.c:678), Num_axpy (:616), Num_copy_matrix (:739),
+ * permute_vecs / Num_compact_vecs on device columns (auxiliary.c:716, :897). */
+int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx,
+      const double *alpha_host /* nx real scale factors */);
+int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
+      const void *X, int64_t ldX, void *Y, int64_t ldY, int nx);
+int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
+      void *Y, int64_t ldY, int nx);
+/* Y(:,i) = X(:,perm[i]) for i < n, X and Y distinct panels */
+int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
+      const int *perm_host, int n, void *Y, int64_t ldY);
+/* out_dev[c] = ||X(:,c)||^2 */
+int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
+      int nx, double *out_dev);
+/* residual columns r_c = w_c - theta_host[c]*x_c (in place into W) and their
+ * squared norms (verify_norms, reference main_iter.c:1864-1879). */
+int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
+      void *Wr, int64_t ldW, int nx, const double *theta_host, double *nrm2_dev);
+
+/* ---- sparse operator: the user matvec ------------------------------------------
+ * Replaces the hipsparseSpMM-based callback of examples/ex_eigs_dhipblas.c:239-264
+ * and the SPARSKIT amux of tests/COMMON/mat.c:64-90.
+ * CSR, 0-based int32 indices, row-partitioned: this rank owns rows [row0,row0+m).
+ * Column indices are GLOBAL; columns outside the owned range are served from the
+ * halo set up by primme_amd_comm (single rank: none). */
+typedef struct hipk_csr hipk_csr;
+int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local, int64_t ncols_global,
+      int64_t row0, const int32_t *rowptr_host, const int32_t *colind_host,
+      const void *values_host, hipk_csr **A);
+int hipk_csr_destroy(hipk_csr *A);
+/* launches on `hip_stream` (a hipStream_t passed by value as void*), or on the stream of
+ * the creating context when NULL */
+int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int64_t ldx, void *y, int64_t ldy,
+      int ncols);
+/* diagonal of A (device array of nrows_local elements of dtype) */
+const void *hipk_csr_diag(hipk_csr *A);
+int64_t hipk_csr_nnz(const hipk_csr *A);
+/* Matrix-free Laplacian stencil on an nx x ny x nz grid (nz = 1: 5-point),
+ * diag = 2*dims, off = -1, Dirichlet; rows [row0, row0+m) in lexicographic order
+ * (x fastest).  Same handle type so primme_amd_matvec dispatches on it. */
+int hipk_stencil_create(hipk_ctx *ctx, hipk_dtype dt, int nx, int ny, int nz, int64_t row0,
+      int64_t nrows_local, hipk_csr **A);
+/* rows below/above the owned slab that the operator reads (0 for block-diagonal) */
+int64_t hipk_csr_halo_lo(const hipk_csr *A);
+int64_t hipk_csr_halo_hi(const hipk_csr *A);
+/* halo buffers (device, halo_lo / halo_hi elements per column, column stride =
+ * halo length) the communicator fills before each matvec */
+int hipk_csr_set_halo(hipk_csr *A, const void *lo, const void *hi);
+
+/* y(:,c) = x(:,c) / (d - shift[c])  (Jacobi), shifts on host */
+int hipk_jacobi_apply(void *hip_stream, hipk_dtype dt, int64_t m, const void *diag,
+      const double *shift_host, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols);
+hipk_dtype hipk_csr_dtype(const hipk_csr *A);
+int64_t hipk_csr_nrows(const hipk_csr *A);
+
+/* ---- measurement helpers ------------------------------------------------------- */
+/* device copy bandwidth probe: copies `bytes` src->dst `reps` times, returns GB/s (read+write) */
+int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRIMME_AMD_KERNELS_H */

@@ -1,0 +1,30 @@
+/* oracle/hostcheck_glue.c — TEST INFRASTRUCTURE.  Host-memory stand-ins for the
+ * product's HIP-side callbacks (primme_amd/csrc/amd_operator.hip, comm_rccl.hip)
+ * so that libprimme_hostcheck.so (product host solver + oracle/hipk_cpu.c) links
+ * and the solver's control flow can run in `-m "not gpu"` tests.  Multi-rank
+ * reductions in those tests go through a user globalSumReal callback (gloo). */
+#include <stdlib.h>
+#include "primme_amd.h"
+#include "primme_amd_comm.h"
+
+struct primme_amd_operator { hipk_csr *A; };
+int primme_amd_operator_create(primme_amd_operator **op, hipk_csr *A, primme_amd_comm *c) {
+   (void)c; *op = calloc(1, sizeof(**op)); (*op)->A = A; return 0;
+}
+int primme_amd_operator_destroy(primme_amd_operator *op) { free(op); return 0; }
+hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op) { return op->A; }
+int primme_amd_operator_apply(primme_amd_operator *op, void *st, const void *x, int64_t ldx, void *y, int64_t ldy, int nc) {
+   return hipk_csr_matvec(op->A, st, x, ldx, y, ldy, nc);
+}
+void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
+   *ierr = primme_amd_operator_apply((primme_amd_operator *)p->matrix, NULL, x, *ldx, y, *ldy, *bs);
+}
+void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
+   primme_amd_operator *op = (primme_amd_operator *)p->preconditioner;
+   *ierr = hipk_jacobi_apply(NULL, hipk_csr_dtype(op->A), hipk_csr_nrows(op->A), hipk_csr_diag(op->A),
+         p->ShiftsForPreconditioner, x, *ldx, y, *ldy, *bs);
+}
+void primme_amd_global_sum(void *s, void *r, int *c, struct primme_params *p, int *ierr) {
+   (void)s; (void)r; (void)c; (void)p; *ierr = 1; /* RCCL only exists in the product library */
+}
+int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) { (void)ci; (void)d; (void)n; (void)st; return -43; }

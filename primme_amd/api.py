@@ -1,0 +1,242 @@
+"""Thin Python driver over the C ABI (plumbing only: memory, handles, parameter block).
+
+`eigsh(...)` runs hip_dprimme / hip_sprimme of the product library on `cuda:0`
+(device memory through torch).  The same parameter plumbing can target the two
+CHECKER back ends used by tests and by bench.py's cpu_baseline leg:
+   backend="hostcheck"  product host solver over oracle/hipk_cpu.c (host memory)
+   backend="reference"  the real reference library oracle/_ref/libprimme_ref.so
+The product path (backend="hip") never touches either of them.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _ffi as F
+
+
+class Operator:
+    """A sparse operator: CSR arrays (global column indices) or a Laplacian stencil."""
+
+    def __init__(self, n, csr=None, stencil=None, row0=0, nrows=None):
+        self.n = int(n)
+        self.csr = csr            # (rowptr int32, colind int32, values)
+        self.stencil = stencil    # (nx, ny, nz)
+        self.row0 = int(row0)
+        self.nrows = int(nrows if nrows is not None else (len(csr[0]) - 1 if csr is not None else n))
+
+    def apply_numpy(self, x):
+        from .problems import csr_matvec_numpy, laplacian_csr
+        if self.csr is None:
+            dims = tuple(d for d in self.stencil if d and d > 0)
+            self.csr = laplacian_csr(dims, self.row0, self.nrows)[:3]
+        assert self.nrows == self.n, "numpy apply is single-rank only"
+        return csr_matvec_numpy(self.csr[0], self.csr[1], self.csr[2], x)
+
+    def diagonal(self):
+        if self.csr is None:
+            d = len([x for x in self.stencil if x and x > 1])
+            return np.full(self.nrows, 2.0 * max(d, 1))
+        rp, ci, va = self.csr
+        rows = np.repeat(np.arange(self.nrows), np.diff(rp))
+        dg = np.zeros(self.nrows)
+        m = ci == rows + self.row0
+        dg[rows[m]] = va[m]
+        return dg
+
+
+def _fill_params(lib, p, op, numEvals, target, method, eps, aNorm, maxBlockSize, maxBasisSize,
+                 minRestartSize, maxPrevRetain, locking, maxMatvecs, maxOuterIterations, targetShifts,
+                 initSize, initBasisMode, printLevel, numProcs, procID, nLocal, orth, iseed, keep):
+    lib.primme_initialize(C.byref(p))
+    p.n = op.n
+    p.numEvals = numEvals
+    p.target = F.TARGETS[target] if isinstance(target, str) else target
+    p.eps = eps
+    p.aNorm = aNorm
+    p.printLevel = printLevel
+    p.outputFile = None
+    if maxBlockSize: p.maxBlockSize = maxBlockSize
+    if maxBasisSize: p.maxBasisSize = maxBasisSize
+    if minRestartSize: p.minRestartSize = minRestartSize
+    if maxPrevRetain is not None: p.restartingParams.maxPrevRetain = maxPrevRetain
+    if locking is not None: p.locking = locking
+    if maxMatvecs: p.maxMatvecs = maxMatvecs
+    if maxOuterIterations: p.maxOuterIterations = maxOuterIterations
+    if orth is not None: p.orth = orth
+    if iseed is not None:
+        for i in range(4): p.iseed[i] = iseed[i]
+    if targetShifts is not None:
+        ts = (C.c_double * len(targetShifts))(*targetShifts)
+        keep.append(ts)
+        p.targetShifts = ts
+        p.numTargetShifts = len(targetShifts)
+    p.initSize = initSize
+    if initBasisMode is not None: p.initBasisMode = initBasisMode
+    p.numProcs = numProcs
+    p.procID = procID
+    p.nLocal = nLocal
+    return F.METHODS[method] if isinstance(method, str) else method
+
+
+class Result:
+    def __init__(self, ret, evals, evecs, resNorms, params):
+        self.ret, self.evals, self.evecs, self.resNorms = ret, evals, evecs, resNorms
+        self.initSize = params.initSize
+        s = params.stats
+        self.stats = {k: getattr(s, k) for k, _ in F.PrimmeStats._fields_}
+        self.params = {k: getattr(params, k) for k in ("maxBasisSize", "minRestartSize", "maxBlockSize",
+                                                       "locking", "orth", "aNorm", "eps", "initSize")}
+        self.params["maxPrevRetain"] = params.restartingParams.maxPrevRetain
+
+
+def eigsh(op, numEvals=1, target="smallest", method="GD_plusK", eps=1e-8, aNorm=0.0, v0=None,
+          maxBlockSize=0, maxBasisSize=0, minRestartSize=0, maxPrevRetain=None, locking=None,
+          maxMatvecs=0, maxOuterIterations=0, targetShifts=None, precond=None, dtype=np.float64,
+          backend="hip", printLevel=0, initBasisMode=None, comm=None, global_sum=None,
+          numProcs=1, procID=0, orth=None, iseed=None, profile=False, return_evecs=True,
+          monitor=None):
+    """Compute a few eigenpairs of the symmetric operator `op`.
+
+    v0: optional (nLocal x initSize) initial guesses -> initBasisMode defaults to
+    primme_init_user so that no random numbers enter (parity runs).
+    precond: None | "jacobi".
+    """
+    dtype = np.dtype(dtype)
+    dt = F.HIPK_F64 if dtype == np.float64 else F.HIPK_F32
+    keep = []
+    p = F.PrimmeParams()
+    nLocal = op.nrows
+    v0 = None if v0 is None else np.asarray(v0, dtype=dtype).reshape(nLocal, -1)
+    initSize = 0 if v0 is None else v0.shape[1]
+    if initBasisMode is None and v0 is not None:
+        initBasisMode = F.primme_init_user
+
+    if backend == "hip":
+        lib = F.load_product()
+    elif backend == "hostcheck":
+        lib = F.load_hostcheck()
+    elif backend == "reference":
+        lib = F.load_reference()
+    else:
+        raise ValueError(backend)
+
+    m = _fill_params(lib, p, op, numEvals, target, method, eps, aNorm, maxBlockSize, maxBasisSize,
+                     minRestartSize, maxPrevRetain, locking, maxMatvecs, maxOuterIterations,
+                     targetShifts, initSize, initBasisMode, printLevel, numProcs, procID, nLocal, orth,
+                     iseed, keep)
+    ncols = max(numEvals, initSize)
+    handles = []
+
+    if backend == "reference":
+        def mv(x, ldx, y, ldy, bs, pp, ierr):
+            nb, lx, ly = bs[0], ldx[0], ldy[0]
+            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double if dtype == np.float64 else C.c_float)), shape=(nb, lx))
+            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double if dtype == np.float64 else C.c_float)), shape=(nb, ly))
+            Y[:, :nLocal] = op.apply_numpy(X[:, :nLocal].T.astype(np.float64)).T
+            ierr[0] = 0
+        cb = F.BLOCK_OP(mv)
+        keep.append(cb)
+        p.matrixMatvec = C.cast(cb, C.c_void_p)
+        if precond == "jacobi":
+            dg = op.diagonal()
+            def pc(x, ldx, y, ldy, bs, pp, ierr):
+                nb, lx, ly = bs[0], ldx[0], ldy[0]
+                ct = C.c_double if dtype == np.float64 else C.c_float
+                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ct)), shape=(nb, lx))
+                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ct)), shape=(nb, ly))
+                sh = pp[0].ShiftsForPreconditioner
+                for c in range(nb):
+                    d = dg - (sh[c] if sh else 0.0)
+                    d[np.abs(d) < 1e-300] = 1e-300
+                    Y[c, :nLocal] = X[c, :nLocal] / d
+                ierr[0] = 0
+            pcb = F.BLOCK_OP(pc)
+            keep.append(pcb)
+            p.applyPreconditioner = C.cast(pcb, C.c_void_p)
+            p.correctionParams.precondition = 1
+        evecs = np.zeros((ncols, nLocal), dtype=dtype)   # row-major (ncols x n) == col-major n x ncols
+        if v0 is not None:
+            evecs[:initSize] = v0.T
+        evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
+        solver = lib.dprimme if dtype == np.float64 else lib.sprimme
+    else:
+        ctx = C.c_void_p()
+        if lib.hipk_ctx_create(C.byref(ctx), None):
+            raise RuntimeError("hipk_ctx_create failed (no GPU?)")
+        handles.append(("ctx", ctx))
+        A = C.c_void_p()
+        if op.csr is not None:
+            rp, ci, va = op.csr
+            rp = np.ascontiguousarray(rp, dtype=np.int32)
+            ci = np.ascontiguousarray(ci, dtype=np.int32)
+            va = np.ascontiguousarray(va, dtype=dtype)
+            rc = lib.hipk_csr_create(ctx, dt, nLocal, op.n, op.row0, rp.ctypes.data_as(C.c_void_p),
+                                     ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), C.byref(A))
+        else:
+            nx, ny, nz = (list(op.stencil) + [1, 1])[:3]
+            rc = lib.hipk_stencil_create(ctx, dt, nx, ny or 1, nz or 1, op.row0, nLocal, C.byref(A))
+        if rc:
+            raise RuntimeError(f"operator creation failed: {rc}")
+        handles.append(("csr", A))
+        oph = C.c_void_p()
+        if lib.primme_amd_operator_create(C.byref(oph), A, comm):
+            raise RuntimeError("operator handle creation failed")
+        handles.append(("op", oph))
+        p.matrix = oph
+        p.matrixMatvec = C.cast(lib.primme_amd_matvec, C.c_void_p)
+        if precond == "jacobi":
+            p.preconditioner = oph
+            p.applyPreconditioner = C.cast(lib.primme_amd_jacobi_precond, C.c_void_p)
+            p.correctionParams.precondition = 1
+        if comm is not None:
+            p.commInfo = comm
+            p.globalSumReal = C.cast(lib.primme_amd_global_sum, C.c_void_p)
+        if profile:
+            p.profile = b"phases"
+        if backend == "hip":
+            import torch
+            tdt = torch.float64 if dtype == np.float64 else torch.float32
+            evecs_t = torch.zeros((ncols, nLocal), dtype=tdt, device="cuda")
+            if v0 is not None:
+                evecs_t[:initSize] = torch.from_numpy(np.ascontiguousarray(v0.T)).to("cuda")
+            torch.cuda.synchronize()
+            evecs_ptr = C.c_void_p(evecs_t.data_ptr())
+            keep.append(evecs_t)
+        else:
+            evecs = np.zeros((ncols, nLocal), dtype=dtype)
+            if v0 is not None:
+                evecs[:initSize] = v0.T
+            evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
+        solver = lib.hip_dprimme if dtype == np.float64 else lib.hip_sprimme
+
+    if global_sum is not None:
+        def gs(send, recv, count, pp, ierr):
+            n_ = count[0]
+            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(n_,)).copy()
+            out = global_sum(a)
+            np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(n_,))[:] = out
+            ierr[0] = 0
+        gcb = F.GLOBAL_SUM(gs)
+        keep.append(gcb)
+        p.globalSumReal = C.cast(gcb, C.c_void_p)
+
+    if monitor is not None:
+        mcb = F.MONITOR(monitor)
+        keep.append(mcb)
+        p.monitorFun = C.cast(mcb, C.c_void_p)
+
+    if lib.primme_set_method(m, C.byref(p)):
+        raise ValueError("unknown method")
+    evals = np.zeros(numEvals, dtype=dtype)
+    resNorms = np.zeros(numEvals, dtype=dtype)
+    ret = solver(evals.ctypes.data_as(C.c_void_p), evecs_ptr, resNorms.ctypes.data_as(C.c_void_p), C.byref(p))
+
+    if backend == "hip":
+        import torch
+        torch.cuda.synchronize()
+        evecs = evecs_t.cpu().numpy() if return_evecs else None
+    res = Result(ret, evals, None if evecs is None else evecs[:numEvals].T.copy(), resNorms, p)
+    for kind, h in reversed(handles):
+        if kind == "op": lib.primme_amd_operator_destroy(h)
+        elif kind == "csr": lib.hipk_csr_destroy(h)
+        elif kind == "ctx": lib.hipk_ctx_destroy(h)
+    return res

@@ -1,0 +1,135 @@
+/* amd_operator.hip — the ready-made matrixMatvec / applyPreconditioner callbacks
+ * (include/primme_amd.h) over a device sparse operator, with the halo exchange of
+ * the row-partitioned case.  Replaces the per-application callback code of
+ * reference examples/ex_eigs_dhipblas.c:239-264 and examples/ex_eigs_mpi.c:150-207.
+ */
+#include "hipk_internal.h"
+#include "primme_amd.h"
+#include "primme_amd_comm.h"
+
+struct primme_amd_operator {
+   hipk_csr *A;
+   primme_amd_comm *comm;
+   int mode;                 /* 0 local, 1 neighbour halo, 2 all-gather */
+   int64_t lo, hi;           /* rows needed from below / above */
+   int64_t send_lo, send_hi; /* rows the neighbours need from me */
+   void *buf_lo, *buf_hi;    /* device halo buffers (grown on demand) */
+   size_t cap_lo, cap_hi;
+   void *xfull;              /* all-gather buffer */
+   size_t cap_full;
+   int64_t row0, nrows, n;
+};
+
+static size_t op_elem(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : dt == HIPK_F32 ? 4 : 16; }
+
+extern "C" int primme_amd_operator_create(primme_amd_operator **out, hipk_csr *A, primme_amd_comm *comm) {
+   primme_amd_operator *op = (primme_amd_operator *)calloc(1, sizeof(*op));
+   if (!op) return -2;
+   op->A = A; op->comm = comm;
+   op->lo = hipk_csr_halo_lo(A); op->hi = hipk_csr_halo_hi(A);
+   op->nrows = hipk_csr_nrows(A);
+   if ((op->lo > 0 || op->hi > 0) && !comm) {
+      fprintf(stderr, "primme_amd: operator references rows outside the local slab but no communicator was given\n");
+      free(op);
+      return -1;
+   }
+   if (comm && primme_amd_comm_size(comm) > 1) {
+      const int P = primme_amd_comm_size(comm), r = primme_amd_comm_rank(comm);
+      int64_t mine[3] = {op->lo, op->hi, op->nrows};
+      int64_t *all = (int64_t *)malloc((size_t)P * 3 * sizeof(int64_t));
+      if (primme_amd_comm_allgather_i64(comm, mine, 3, all)) { free(all); free(op); return -43; }
+      int neighbour_ok = 1, any = 0, equal = 1;
+      for (int q = 0; q < P; q++) {
+         if (all[3 * q] > 0 || all[3 * q + 1] > 0) any = 1;
+         if (q > 0 && all[3 * q] > all[3 * (q - 1) + 2]) neighbour_ok = 0;     /* needs more than rank q-1 owns */
+         if (q < P - 1 && all[3 * q + 1] > all[3 * (q + 1) + 2]) neighbour_ok = 0;
+         if (all[3 * q + 2] != all[2]) equal = 0;
+      }
+      if (!any) op->mode = 0;
+      else if (neighbour_ok) {
+         op->mode = 1;
+         op->send_hi = (r < P - 1) ? all[3 * (r + 1)] : 0;     /* what rank r+1 needs from below = my last rows */
+         op->send_lo = (r > 0) ? all[3 * (r - 1) + 1] : 0;     /* what rank r-1 needs from above = my first rows */
+      } else {
+         if (!equal) {
+            fprintf(stderr, "primme_amd: all-gather matvec needs equal slabs per rank\n");
+            free(all); free(op);
+            return -1;
+         }
+         op->mode = 2;
+      }
+      int64_t r0 = 0, n = 0;
+      for (int q = 0; q < P; q++) { if (q < r) r0 += all[3 * q + 2]; n += all[3 * q + 2]; }
+      op->row0 = r0; op->n = n;
+      free(all);
+   }
+   *out = op;
+   return 0;
+}
+
+extern "C" int primme_amd_operator_destroy(primme_amd_operator *op) {
+   if (!op) return 0;
+   if (op->buf_lo) hipFree(op->buf_lo);
+   if (op->buf_hi) hipFree(op->buf_hi);
+   if (op->xfull) hipFree(op->xfull);
+   free(op);
+   return 0;
+}
+
+extern "C" hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op) { return op->A; }
+
+static int grow(void **buf, size_t *cap, size_t need) {
+   if (need <= *cap) return 0;
+   if (*buf) HIPK_CHECK(hipFree(*buf));
+   HIPK_CHECK(hipMalloc(buf, need));
+   *cap = need;
+   return 0;
+}
+
+extern "C" int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stream, const void *x,
+      int64_t ldx, void *y, int64_t ldy, int ncols) {
+   const size_t es = op_elem(hipk_csr_dtype(op->A));
+   if (op->mode == 1) {
+      if (grow(&op->buf_lo, &op->cap_lo, (size_t)(op->lo > 0 ? op->lo : 1) * ncols * es)) return -2;
+      if (grow(&op->buf_hi, &op->cap_hi, (size_t)(op->hi > 0 ? op->hi : 1) * ncols * es)) return -2;
+      int rc = primme_amd_comm_halo(op->comm, hip_stream, x, ldx, op->nrows, ncols, es, op->send_lo,
+            op->send_hi, op->buf_lo, op->lo, op->buf_hi, op->hi);
+      if (rc) return rc;
+      hipk_csr_set_halo(op->A, op->buf_lo, op->buf_hi);
+      return hipk_csr_matvec(op->A, hip_stream, x, ldx, y, ldy, ncols);
+   } else if (op->mode == 2) {
+      /* gather the whole vector once per column; lo = everything below my slab,
+       * hi = everything above */
+      if (grow(&op->xfull, &op->cap_full, (size_t)op->n * es)) return -2;
+      for (int c = 0; c < ncols; c++) {
+         int rc = primme_amd_comm_allgather(op->comm, hip_stream, (const char *)x + (size_t)c * ldx * es,
+               op->xfull, (size_t)op->nrows * es);
+         if (rc) return rc;
+         /* halo buffers are addressed relative to (row0 - lo) and (row0 + nrows) */
+         hipk_csr_set_halo(op->A, (const char *)op->xfull + (size_t)(op->row0 - op->lo) * es,
+               (const char *)op->xfull + (size_t)(op->row0 + op->nrows) * es);
+         rc = hipk_csr_matvec(op->A, hip_stream, (const char *)x + (size_t)c * ldx * es, ldx,
+               (char *)y + (size_t)c * ldy * es, ldy, 1);
+         if (rc) return rc;
+      }
+      return 0;
+   }
+   return hipk_csr_matvec(op->A, hip_stream, x, ldx, y, ldy, ncols);
+}
+
+/* ---- the callbacks ---------------------------------------------------------- */
+extern "C" void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
+      struct primme_params *primme, int *ierr) {
+   primme_amd_operator *op = (primme_amd_operator *)primme->matrix;
+   void *stream = primme->queue ? (void *)*(hipStream_t *)primme->queue : NULL;
+   *ierr = op ? primme_amd_operator_apply(op, stream, x, *ldx, y, *ldy, *blockSize) : 1;
+}
+
+extern "C" void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy,
+      int *blockSize, struct primme_params *primme, int *ierr) {
+   primme_amd_operator *op = (primme_amd_operator *)primme->preconditioner;
+   void *stream = primme->queue ? (void *)*(hipStream_t *)primme->queue : NULL;
+   if (!op) { *ierr = 1; return; }
+   *ierr = hipk_jacobi_apply(stream, hipk_csr_dtype(op->A), hipk_csr_nrows(op->A), hipk_csr_diag(op->A),
+         primme->ShiftsForPreconditioner, x, *ldx, y, *ldy, *blockSize);
+}

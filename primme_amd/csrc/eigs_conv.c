@@ -1,0 +1,266 @@
+/* eigs_conv.c — convergence tests and candidate selection (host control flow that
+ * decides when iterations stop; restated exactly so convergence histories follow
+ * the reference).
+ *   pa_check_convergence   <- reference src/eigs/convergence.c:85-204, :238-281
+ *   pa_project_once        <- reference src/eigs/ortho.c:825-934 (B = I)
+ *   pa_map_vecs            <- reference src/eigs/solve_projection.c:1009-1065
+ *   pa_prepare_candidates  <- reference src/eigs/main_iter.c:1470-1709
+ */
+#include "eigs_solver.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+double pa_problem_norm(int overrideUser, const primme_params *p);
+int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
+int pa_ritz_update(pa_solver *s, int basisSize, const hipk_job *jobs, int njobs, double *norms_out,
+      int nslots, int64_t flop_cols);
+int pa_push_coefficients(pa_solver *s, int basisSize, int ldh);
+
+/* default convTestFun (reference src/eigs/primme_c.c:555-570) */
+void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv,
+      primme_params *p, int *ierr) {
+   (void)eval; (void)evec;
+   /* machine epsilon of the working precision is kept in convtest when we install it */
+   double meps = p->convtest ? *(double *)p->convtest : PA_EPS;
+   *isConv = *rNorm < PA_MAX(p->eps, meps * 2) * pa_problem_norm(0, p);
+   *ierr = 0;
+}
+
+static int call_conv_test(pa_solver *s, double eval, void *evec, double rnorm, int *isconv) {
+   primme_params *p = s->p;
+   int ierr = 0;
+   if (p->convTestFun == pa_conv_test_absolute) {
+      *isconv = rnorm < PA_MAX(p->eps, s->mach_eps * 2) * pa_problem_norm(0, p);
+      return 0;
+   }
+   p->convTestFun(&eval, evec, &rnorm, isconv, p, &ierr);
+   return ierr ? PRIMME_UNEXPECTED_FAILURE : 0;
+}
+
+/* X(:,inX) <- (I - Q Q') X(:,inX), norms of the result (one projector pass) */
+int pa_project_once(pa_solver *s, char *Q, int64_t ldQ, int nQ, char *X, int64_t ldX,
+      const int *inX, int nX, double *norms) {
+   primme_params *p = s->p;
+   double t0 = pa_wtime();
+   for (int c = 0; c < nX; c++) {
+      char *x = PCOL(s, X, ldX, inX ? inX[c] : c);
+      hipk_seg seg = {Q, ldQ, nQ};
+      CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, x, ldX, 1, s->d_red, nQ));
+      CHK(pa_reduce(s, s->d_red, nQ, 1, (p->numProcs > 1 && !s->dev_comm) ? 0 : 1));
+      CHK(hipk_panel_project(s->ctx, s->dt, s->m, &seg, 1, s->d_red, nQ, x, ldX, 1, s->d_red + nQ));
+      CHK(pa_reduce(s, s->d_red + nQ, 1, 0, 0));
+      if (norms) norms[c] = sqrt(s->h_red[nQ]);
+      p->stats.numOrthoInnerProds += nQ + 1;
+   }
+   p->stats.timeOrtho += pa_wtime() - t0;
+   return 0;
+}
+
+/* flags[left..right) from blockNorms (indexed from 0), hVals indexed like flags. */
+int pa_check_convergence(pa_solver *s, char *X, int64_t ldX, int givenX, char *R, int64_t ldR,
+      int givenR, int numLocked, int left, int right, int *flags, double *blockNorms,
+      const double *hVals, int *reset, int practConvCheck) {
+   primme_params *p = s->p;
+   const int nb = right - left;
+   if (nb <= 0) return 0;
+   int *toProject = (int *)malloc((size_t)nb * sizeof(int));
+   if (!toProject) return PRIMME_MALLOC_FAILURE;
+   int numToProject = 0;
+   const double tol = PA_MAX(s->mach_eps * pa_problem_norm(1, p), p->stats.maxConvTol);
+   const double attainableTol = p->locking ? sqrt((double)(p->numOrthoConst + numLocked)) * tol : 0.0;
+
+   for (int i = left; i < right; i++) {
+      const double bn = blockNorms[i - left];
+      const double targetShift = p->numTargetShifts > 0
+            ? p->targetShifts[PA_MIN(p->initSize, p->numTargetShifts - 1)] : 0.0;
+      if ((p->target == primme_closest_leq && hVals[i] - bn > targetShift) ||
+            (p->target == primme_closest_geq && hVals[i] + bn < targetShift)) {
+         flags[i] = UNCONV;
+         continue;
+      }
+      if (bn <= p->stats.maxConvTol) { flags[i] = CONV; continue; }
+      int isConv = 0;
+      int rc = call_conv_test(s, hVals[i], (X && givenX) ? PCOL(s, X, ldX, i - left) : NULL, bn, &isConv);
+      if (rc) { free(toProject); return rc; }
+      if (isConv) {
+         flags[i] = CONV;
+      } else if (bn <= p->stats.estimateResidualError && reset) {
+         flags[i] = SKIP_RESTART;
+         *reset = 1;
+      } else if (p->locking && numLocked > 0 && practConvCheck >= 0) {
+         if (givenR && bn < attainableTol) toProject[numToProject++] = i - left;
+         else if (flags[i] != PRACT_CONV) flags[i] = UNCONV;
+      } else {
+         flags[i] = UNCONV;
+      }
+   }
+
+   if (numToProject > 0) {
+      /* practical convergence: || (I - QQ') r || <= tol with Q the locked vectors
+       * (reference convergence.c:238-281; R loses its Q components as a side effect) */
+      double *norms = (double *)malloc((size_t)numToProject * sizeof(double));
+      int rc = pa_project_once(s, s->evecs, s->ldevecs, p->numOrthoConst + numLocked, R, ldR,
+            toProject, numToProject, norms);
+      if (rc) { free(norms); free(toProject); return rc; }
+      for (int i = 0; i < numToProject; i++) {
+         blockNorms[toProject[i]] = norms[i];
+         flags[left + toProject[i]] = (norms[i] <= tol) ? PRACT_CONV : UNCONV;
+      }
+      free(norms);
+   }
+   free(toProject);
+   return 0;
+}
+
+/* p[i] = column of Vp (m x nV) closest in angle to column i of Wn (m x n), i in [n0,n) */
+void pa_map_vecs(const double *Vp, int mrows, int nV, int ldV, const double *Wn, int n0, int n,
+      int ldW, int *pm) {
+   double *vn = (double *)malloc((size_t)(nV > 0 ? nV : 1) * sizeof(double));
+   double *ip = (double *)malloc((size_t)(nV > 0 ? nV : 1) * sizeof(double));
+   for (int j = 0; j < nV; j++) {
+      double t = 0;
+      for (int r = 0; r < mrows; r++) t += Vp[r + (size_t)j * ldV] * Vp[r + (size_t)j * ldV];
+      vn[j] = sqrt(t);
+   }
+   for (int i = n0; i < n; i++) {
+      for (int j = 0; j < nV; j++) {
+         double t = 0;
+         for (int r = 0; r < mrows; r++) t += Vp[r + (size_t)j * ldV] * Wn[r + (size_t)i * ldW];
+         ip[j] = t;
+      }
+      int jmax = -1;
+      double ipmax = -1;
+      for (int j = 0; j < nV; j++) {
+         double ipij = fabs(ip[j]);
+         if (ipij > ipmax * vn[j]) {
+            int k;
+            for (k = 0; k < i && pm[k] != j; k++) ;
+            if (k < i) continue;
+            ipmax = fabs(ipij / vn[j]);
+            jmax = j;
+         }
+      }
+      if (jmax < 0) jmax = i;
+      pm[i] = jmax;
+   }
+   free(vn);
+   free(ip);
+}
+
+void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags, int *iblock,
+      int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
+      int *lockedFlags, double *lockedNorms, primme_event event) {
+   primme_params *p = s->p;
+   if (!p->monitorFun) return;
+   int err = 0;
+   double time = 0.0;
+   p->stats.elapsedTime = pa_wtime() - s->startTime;
+   p->monitorFun(basisEvals, &basisSize, basisFlags, iblock, &blockSize, basisNorms, &numConverged,
+         lockedEvals, &numLocked, lockedFlags, lockedNorms, NULL, NULL, NULL, &time, &event, p, &err);
+}
+
+/* Put the first unconverged Ritz pairs in the block, computing X, R and the
+ * residual norms for them; flag converged pairs on the way. */
+int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int computeXR,
+      int *flags, int remainedEvals, double *blockNorms, int blockNormsSize, int maxBlockSize,
+      int numLocked, double *evals, double *resNorms, int *iev, int *blockSize,
+      int *recentlyConverged, double *smallestResNorm, int numConverged, double *basisNorms,
+      int *reset, int nprevhVecs, int practConvChecking, int *map) {
+   primme_params *p = s->p;
+   const int ldh = basisSize;
+   int lasti = -1;
+   *blockSize = 0;
+   int *flagsBlock = (int *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(int));
+   double *hValsBlock = (double *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(double));
+   hipk_job *jobs = (hipk_job *)malloc((size_t)(2 * maxBlockSize + 2) * sizeof(hipk_job));
+   if (!flagsBlock || !hValsBlock || !jobs) return PRIMME_MALLOC_FAILURE;
+   int rc = 0;
+
+   for (int i = 0; i < blockNormsSize; i++) hValsBlock[i] = s->hVals[iev[*blockSize + i]];
+   if (blockNormsSize > 0) {
+      *smallestResNorm = HUGE_VAL;
+      for (int i = 0; i < blockNormsSize; i++) *smallestResNorm = PA_MIN(*smallestResNorm, blockNorms[i]);
+   }
+   /* pair each Ritz vector with the closest one of the previous iteration and
+    * carry the flags over */
+   pa_map_vecs(s->prevhVecs, basisSize, nprevhVecs, s->K, s->hVecs, 0, basisSize, ldh, map);
+   pa_permute_ints(flags, basisSize, map);
+
+   *recentlyConverged = 0;
+   for (;;) {
+      for (int i = *blockSize; i < *blockSize + blockNormsSize; i++) flagsBlock[i - *blockSize] = flags[iev[i]];
+      rc = pa_check_convergence(s, X ? PCOL(s, X, s->ld, *blockSize) : NULL, s->ld, computeXR,
+            R ? PCOL(s, R, s->ld, *blockSize) : NULL, s->ld, computeXR, numLocked, 0, blockNormsSize,
+            flagsBlock, blockNorms ? &blockNorms[*blockSize] : NULL, hValsBlock, reset, practConvChecking);
+      if (rc) goto out;
+
+      int blki = *blockSize;
+      for (int i = 0; i < blockNormsSize && *blockSize < maxBlockSize; i++, blki++) {
+         flags[iev[blki]] = flagsBlock[i];
+         basisNorms[iev[blki]] = blockNorms[blki];
+         const double targetShift = p->targetShifts ? p->targetShifts[s->targetShiftIndex] : 0.0;
+         if ((p->target == primme_closest_leq && s->hVals[iev[blki]] - blockNorms[blki] > targetShift) ||
+               (p->target == primme_closest_geq && s->hVals[iev[blki]] + blockNorms[blki] < targetShift)) {
+            /* value +- residual entirely outside the wanted side: ignore */
+         } else if (flagsBlock[i] != UNCONV && *recentlyConverged < remainedEvals &&
+               (iev[blki] < p->numEvals - numLocked || p->target == primme_closest_geq ||
+                     p->target == primme_closest_leq)) {
+            if (!p->locking) {
+               evals[iev[blki]] = s->hVals[iev[blki]];
+               resNorms[iev[blki]] = blockNorms[blki];
+               if (flagsBlock[i] == CONV)
+                  p->stats.maxConvTol = PA_MAX(p->stats.maxConvTol, blockNorms[blki]);
+            }
+            (*recentlyConverged)++;
+            if (*blockSize == 0) *smallestResNorm = HUGE_VAL;
+            maxBlockSize = PA_MIN(maxBlockSize, p->numEvals + 1 - (*recentlyConverged) - numConverged);
+            pa_monitor(s, s->hVals, basisSize, flags, &iev[blki], 1, basisNorms,
+                  numConverged + *recentlyConverged, NULL, 0, NULL, NULL, primme_event_converged);
+         } else if (flagsBlock[i] == UNCONV) {
+            if (*blockSize == 0) *smallestResNorm = HUGE_VAL;
+            *smallestResNorm = PA_MIN(*smallestResNorm, blockNorms[blki]);
+            blockNorms[*blockSize] = blockNorms[blki];
+            iev[*blockSize] = iev[blki];
+            if (computeXR && blki != *blockSize) {
+               if ((rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, X, s->ld, blki), s->ld, PCOL(s, X, s->ld, *blockSize), s->ld, 1))) goto out;
+               if ((rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, R, s->ld, blki), s->ld, PCOL(s, R, s->ld, *blockSize), s->ld, 1))) goto out;
+            }
+            (*blockSize)++;
+         }
+         lasti = iev[blki];
+      }
+
+      /* next candidates after the last visited pair */
+      blki = *blockSize;
+      for (int i = lasti + 1; i < basisSize && blki < maxBlockSize; i++)
+         if (flags[i] == UNCONV) iev[blki++] = i;
+      if (blki == *blockSize || *recentlyConverged >= remainedEvals) break;
+      blockNormsSize = blki - *blockSize;
+      for (int i = 0; i < blockNormsSize; i++) hValsBlock[i] = s->hVals[iev[*blockSize + i]];
+
+      /* X = V h, R = W h - X theta, norms — one fused pass over V and W */
+      if ((rc = pa_push_coefficients(s, basisSize, ldh))) goto out;
+      int nj = 0;
+      for (int c = 0; c < blockNormsSize; c++) {
+         const int col = iev[*blockSize + c];
+         if (computeXR) {
+            jobs[nj++] = (hipk_job){HIPK_JOB_XV, col, PCOL(s, X, s->ld, *blockSize + c), -1};
+            jobs[nj++] = (hipk_job){HIPK_JOB_RES, col, PCOL(s, R, s->ld, *blockSize + c), c};
+         } else {
+            jobs[nj++] = (hipk_job){HIPK_JOB_RES, col, NULL, c};
+         }
+      }
+      if ((rc = pa_ritz_update(s, basisSize, jobs, nj, &blockNorms[*blockSize], blockNormsSize,
+                 (int64_t)2 * blockNormsSize))) goto out;
+      /* do not trust residual norms below the error already accumulated in V, W.
+       * (the reference's loop bounds, main_iter.c:1686-1688, are kept literally) */
+      for (int i = *blockSize; i < blockNormsSize; i++)
+         blockNorms[i] = PA_MAX(blockNorms[i], p->stats.estimateResidualError);
+   }
+out:
+   free(flagsBlock);
+   free(hValsBlock);
+   free(jobs);
+   return rc;
+}

@@ -1,0 +1,290 @@
+/* eigs_dense.c — the small dense kernels of the projected problem, on the host.
+ *
+ * The reference hands these to LAPACK/BLAS (src/linalg/blaslapack.c:1024-1289:
+ * xHEEVX / xHEGVX / xPOTRF / xTRSM), which is an external dependency that does
+ * not travel.  Everything here works on matrices of order <= maxBasisSize
+ * (15..41) + numEvals, so plain loops are the right tool; what matters is
+ * latency (one call per outer iteration sits between two GPU phases).
+ *
+ * Symmetric eigensolver: Householder tridiagonalisation with accumulated
+ * transformations followed by implicit-shift QL sweeps (the classic
+ * EISPACK tred2/tql2 pair, restated).  Columns are sorted ascending.
+ */
+#include "eigs_internal.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* A: n x n, column-major, leading dim lda, symmetric, UPPER triangle referenced.
+ * On exit evals[0..n) ascending and Z (ldz) the orthonormal eigenvectors. */
+int pa_sym_eig(int n, const double *A, int lda, double *evals, double *Z, int ldz) {
+   if (n <= 0) return 0;
+   double *z = (double *)malloc((size_t)n * n * sizeof(double)); /* row-major work z[i*n+j] */
+   double *e = (double *)malloc((size_t)n * sizeof(double));
+   double *d = evals;
+   if (!z || !e) { free(z); free(e); return PRIMME_MALLOC_FAILURE; }
+   for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) z[i * n + j] = (i <= j) ? A[i + (size_t)j * lda] : A[j + (size_t)i * lda];
+
+   /* ---- Householder reduction, last row first ---- */
+   for (int i = n - 1; i >= 1; i--) {
+      const int l = i - 1;
+      double h = 0.0, scale = 0.0;
+      if (l > 0) {
+         for (int k = 0; k <= l; k++) scale += fabs(z[i * n + k]);
+         if (scale == 0.0) {
+            e[i] = z[i * n + l];
+         } else {
+            for (int k = 0; k <= l; k++) { z[i * n + k] /= scale; h += z[i * n + k] * z[i * n + k]; }
+            double f = z[i * n + l];
+            double g = (f >= 0.0) ? -sqrt(h) : sqrt(h);
+            e[i] = scale * g;
+            h -= f * g;
+            z[i * n + l] = f - g;
+            f = 0.0;
+            for (int j = 0; j <= l; j++) {
+               z[j * n + i] = z[i * n + j] / h;
+               g = 0.0;
+               for (int k = 0; k <= j; k++) g += z[j * n + k] * z[i * n + k];
+               for (int k = j + 1; k <= l; k++) g += z[k * n + j] * z[i * n + k];
+               e[j] = g / h;
+               f += e[j] * z[i * n + j];
+            }
+            const double hh = f / (h + h);
+            for (int j = 0; j <= l; j++) {
+               f = z[i * n + j];
+               e[j] = g = e[j] - hh * f;
+               for (int k = 0; k <= j; k++) z[j * n + k] -= f * e[k] + g * z[i * n + k];
+            }
+         }
+      } else {
+         e[i] = z[i * n + l];
+      }
+      d[i] = h;
+   }
+   d[0] = 0.0;
+   e[0] = 0.0;
+   for (int i = 0; i < n; i++) {
+      const int l = i - 1;
+      if (d[i] != 0.0) {
+         for (int j = 0; j <= l; j++) {
+            double g = 0.0;
+            for (int k = 0; k <= l; k++) g += z[i * n + k] * z[k * n + j];
+            for (int k = 0; k <= l; k++) z[k * n + j] -= g * z[k * n + i];
+         }
+      }
+      d[i] = z[i * n + i];
+      z[i * n + i] = 1.0;
+      for (int j = 0; j <= l; j++) z[j * n + i] = z[i * n + j] = 0.0;
+   }
+
+   /* ---- implicit QL on the tridiagonal (d, e) ---- */
+   for (int i = 1; i < n; i++) e[i - 1] = e[i];
+   e[n - 1] = 0.0;
+   for (int l = 0; l < n; l++) {
+      int iter = 0, m;
+      do {
+         for (m = l; m < n - 1; m++) {
+            const double dd = fabs(d[m]) + fabs(d[m + 1]);
+            if (fabs(e[m]) <= DBL_EPSILON * dd) break;
+         }
+         if (m != l) {
+            if (iter++ == 200) { free(z); free(e); return PRIMME_LAPACK_FAILURE; }
+            double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+            double r = hypot(g, 1.0);
+            g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+            double s = 1.0, c = 1.0, p = 0.0;
+            int i;
+            for (i = m - 1; i >= l; i--) {
+               double f = s * e[i];
+               const double b = c * e[i];
+               e[i + 1] = (r = hypot(f, g));
+               if (r == 0.0) {
+                  d[i + 1] -= p;
+                  e[m] = 0.0;
+                  break;
+               }
+               s = f / r;
+               c = g / r;
+               g = d[i + 1] - p;
+               r = (d[i] - g) * s + 2.0 * c * b;
+               d[i + 1] = g + (p = s * r);
+               g = c * r - b;
+               for (int k = 0; k < n; k++) {
+                  f = z[k * n + i + 1];
+                  z[k * n + i + 1] = s * z[k * n + i] + c * f;
+                  z[k * n + i] = c * z[k * n + i] - s * f;
+               }
+            }
+            if (r == 0.0 && i >= l) continue;
+            d[l] -= p;
+            e[l] = g;
+            e[m] = 0.0;
+         }
+      } while (m != l);
+   }
+
+   /* ---- ascending order (selection sort on columns) and copy out ---- */
+   int *ord = (int *)malloc((size_t)n * sizeof(int));
+   if (!ord) { free(z); free(e); return PRIMME_MALLOC_FAILURE; }
+   for (int i = 0; i < n; i++) ord[i] = i;
+   for (int i = 0; i < n - 1; i++) {
+      int k = i;
+      for (int j = i + 1; j < n; j++)
+         if (d[ord[j]] < d[ord[k]]) k = j;
+      int t = ord[i]; ord[i] = ord[k]; ord[k] = t;
+   }
+   for (int j = 0; j < n; j++) {
+      e[j] = d[ord[j]];
+      for (int i = 0; i < n; i++) Z[i + (size_t)j * ldz] = z[i * n + ord[j]];
+   }
+   memcpy(d, e, (size_t)n * sizeof(double));
+   free(ord);
+   free(z);
+   free(e);
+   return 0;
+}
+
+/* Upper Cholesky A = U'U in place (upper triangle of A referenced/overwritten).
+ * Returns 0, or j+1 if the leading minor of order j+1 is not positive definite. */
+int pa_potrf_upper(int n, double *A, int lda) {
+   for (int j = 0; j < n; j++) {
+      double s = A[j + (size_t)j * lda];
+      for (int k = 0; k < j; k++) s -= A[k + (size_t)j * lda] * A[k + (size_t)j * lda];
+      if (!(s > 0.0) || !isfinite(s)) return j + 1;
+      const double ujj = sqrt(s);
+      A[j + (size_t)j * lda] = ujj;
+      for (int c = j + 1; c < n; c++) {
+         double t = A[j + (size_t)c * lda];
+         for (int k = 0; k < j; k++) t -= A[k + (size_t)j * lda] * A[k + (size_t)c * lda];
+         A[j + (size_t)c * lda] = t / ujj;
+      }
+   }
+   return 0;
+}
+
+/* B <- U^-T B  (U upper n x n, B n x nb) */
+void pa_trsm_left_upper_trans(int n, int nb, const double *U, int ldu, double *B, int ldb) {
+   for (int c = 0; c < nb; c++) {
+      double *b = B + (size_t)c * ldb;
+      for (int i = 0; i < n; i++) {
+         double t = b[i];
+         for (int k = 0; k < i; k++) t -= U[k + (size_t)i * ldu] * b[k];
+         b[i] = t / U[i + (size_t)i * ldu];
+      }
+   }
+}
+
+/* B <- U^-1 B */
+void pa_trsm_left_upper(int n, int nb, const double *U, int ldu, double *B, int ldb) {
+   for (int c = 0; c < nb; c++) {
+      double *b = B + (size_t)c * ldb;
+      for (int i = n - 1; i >= 0; i--) {
+         double t = b[i];
+         for (int k = i + 1; k < n; k++) t -= U[i + (size_t)k * ldu] * b[k];
+         b[i] = t / U[i + (size_t)i * ldu];
+      }
+   }
+}
+
+/* B <- B U^-1  (B mb x n) */
+void pa_trsm_right_upper(int mb, int n, const double *U, int ldu, double *B, int ldb) {
+   for (int j = 0; j < n; j++) {
+      for (int k = 0; k < j; k++) {
+         const double u = U[k + (size_t)j * ldu];
+         for (int i = 0; i < mb; i++) B[i + (size_t)j * ldb] -= B[i + (size_t)k * ldb] * u;
+      }
+      const double inv = 1.0 / U[j + (size_t)j * ldu];
+      for (int i = 0; i < mb; i++) B[i + (size_t)j * ldb] *= inv;
+   }
+}
+
+/* Generalised symmetric-definite problem H x = lambda G x, upper triangles of
+ * H and G referenced; G == NULL means identity.  Eigenvectors G-orthonormal. */
+int pa_sym_eig_gen(int n, const double *H, int ldh, const double *G, int ldg, double *evals,
+      double *Z, int ldz) {
+   if (!G) return pa_sym_eig(n, H, ldh, evals, Z, ldz);
+   if (n <= 0) return 0;
+   double *U = (double *)malloc((size_t)n * n * sizeof(double));
+   double *C = (double *)malloc((size_t)n * n * sizeof(double));
+   if (!U || !C) { free(U); free(C); return PRIMME_MALLOC_FAILURE; }
+   for (int j = 0; j < n; j++)
+      for (int i = 0; i < n; i++) {
+         U[i + (size_t)j * n] = (i <= j) ? G[i + (size_t)j * ldg] : 0.0;
+         C[i + (size_t)j * n] = (i <= j) ? H[i + (size_t)j * ldh] : H[j + (size_t)i * ldh];
+      }
+   if (pa_potrf_upper(n, U, n)) { free(U); free(C); return PRIMME_LAPACK_FAILURE; }
+   /* C <- U^-T C U^-1 */
+   pa_trsm_left_upper_trans(n, n, U, n, C, n);
+   pa_trsm_right_upper(n, n, U, n, C, n);
+   /* symmetrise the round-off */
+   for (int j = 0; j < n; j++)
+      for (int i = 0; i < j; i++) {
+         double s = 0.5 * (C[i + (size_t)j * n] + C[j + (size_t)i * n]);
+         C[i + (size_t)j * n] = C[j + (size_t)i * n] = s;
+      }
+   int rc = pa_sym_eig(n, C, n, evals, Z, ldz);
+   if (!rc) pa_trsm_left_upper(n, n, U, n, Z, ldz);
+   free(U);
+   free(C);
+   return rc;
+}
+
+/* new column i = old column perm[i]  (reference src/linalg/auxiliary.c:716 semantics) */
+void pa_permute_cols(double *A, int mrows, int n, int lda, const int *perm) {
+   if (n <= 0 || mrows <= 0) return;
+   double *tmp = (double *)malloc((size_t)mrows * n * sizeof(double));
+   for (int j = 0; j < n; j++) memcpy(tmp + (size_t)j * mrows, A + (size_t)perm[j] * lda, (size_t)mrows * sizeof(double));
+   for (int j = 0; j < n; j++) memcpy(A + (size_t)j * lda, tmp + (size_t)j * mrows, (size_t)mrows * sizeof(double));
+   free(tmp);
+}
+void pa_permute_ints(int *a, int n, const int *perm) {
+   if (n <= 0) return;
+   int *tmp = (int *)malloc((size_t)n * sizeof(int));
+   for (int j = 0; j < n; j++) tmp[j] = a[perm[j]];
+   memcpy(a, tmp, (size_t)n * sizeof(int));
+   free(tmp);
+}
+
+/* R = X' * Hsym * X with Hsym given by its upper triangle (order nh), X nh x nx.
+ * (reference src/linalg/auxiliary.c:598-625 compute_submatrix) */
+void pa_submatrix(const double *X, int nx, int ldx, const double *H, int nh, int ldh, double *R,
+      int ldr) {
+   if (nx <= 0 || nh <= 0) return;
+   double *t = (double *)calloc((size_t)nh * nx, sizeof(double));
+   for (int c = 0; c < nx; c++)
+      for (int j = 0; j < nh; j++) {
+         const double xj = X[j + (size_t)c * ldx];
+         for (int i = 0; i < nh; i++) {
+            const double hij = (i <= j) ? H[i + (size_t)j * ldh] : H[j + (size_t)i * ldh];
+            t[i + (size_t)c * nh] += hij * xj;
+         }
+      }
+   for (int c = 0; c < nx; c++)
+      for (int r = 0; r < nx; r++) {
+         double s = 0.0;
+         for (int i = 0; i < nh; i++) s += X[i + (size_t)r * ldx] * t[i + (size_t)c * nh];
+         R[r + (size_t)c * ldr] = s;
+      }
+   free(t);
+}
+
+/* LAPACK xLARNV(idist = 2) stream, restated: 48-bit multiplicative congruential
+ * generator x <- a*x mod 2^48, a = 33952834046453, uniform(-1,1) = 2*x/2^48 - 1.
+ * iseed holds the state as four base-4096 digits (updated on exit).  Verified
+ * bit-for-bit against the LAPACK in this image (tests/test_dense_host.py).
+ * The reference calls this through Num_larnv_Sprimme (blaslapack.c:938-988). */
+void pa_larnv_uniform11(int64_t iseed[4], int64_t n, double *x) {
+   const uint64_t A = 33952834046453ULL, MASK = (1ULL << 48) - 1;
+   uint64_t s = ((((uint64_t)iseed[0] * 4096 + (uint64_t)iseed[1]) * 4096 + (uint64_t)iseed[2]) * 4096 +
+                 (uint64_t)iseed[3]) & MASK;
+   for (int64_t i = 0; i < n; i++) {
+      s = (s * A) & MASK;
+      x[i] = 2.0 * ((double)s / 281474976710656.0) - 1.0;
+   }
+   iseed[0] = (int64_t)((s >> 36) & 4095);
+   iseed[1] = (int64_t)((s >> 24) & 4095);
+   iseed[2] = (int64_t)((s >> 12) & 4095);
+   iseed[3] = (int64_t)(s & 4095);
+}

@@ -1,0 +1,36 @@
+/* eigs_internal.h — declarations shared by the host side of the solver. */
+#ifndef EIGS_INTERNAL_H
+#define EIGS_INTERNAL_H
+
+#include <stdint.h>
+#include "primme_amd.h"
+#include "primme_amd_kernels.h"
+
+#define PA_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define PA_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define PA_EPS 2.220446049250313e-16 /* double */
+
+/* dense helpers (eigs_dense.c) */
+int  pa_sym_eig(int n, const double *A, int lda, double *evals, double *Z, int ldz);
+int  pa_sym_eig_gen(int n, const double *H, int ldh, const double *G, int ldg, double *evals,
+      double *Z, int ldz);
+int  pa_potrf_upper(int n, double *A, int lda);
+void pa_trsm_left_upper_trans(int n, int nb, const double *U, int ldu, double *B, int ldb);
+void pa_trsm_left_upper(int n, int nb, const double *U, int ldu, double *B, int ldb);
+void pa_trsm_right_upper(int mb, int n, const double *U, int ldu, double *B, int ldb);
+void pa_permute_cols(double *A, int mrows, int n, int lda, const int *perm);
+void pa_permute_ints(int *a, int n, const int *perm);
+void pa_submatrix(const double *X, int nx, int ldx, const double *H, int nh, int ldh, double *R,
+      int ldr);
+void pa_larnv_uniform11(int64_t iseed[4], int64_t n, double *x);
+
+/* parameter handling (eigs_params.c) */
+int pa_check_input(const void *evals, const void *evecs, const void *resNorms,
+      const primme_params *primme, double machine_eps);
+
+/* communicator (comm_rccl.c): device all-reduce used when primme->globalSumReal ==
+ * primme_amd_global_sum */
+int pa_comm_allreduce_device(void *commInfo, double *dbuf, int count, void *hip_stream);
+
+/* the matvec handle understands the communicator for halo exchange */
+#endif

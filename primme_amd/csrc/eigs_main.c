@@ -1,0 +1,721 @@
+/* eigs_main.c — hip_?primme entry points and the outer block-Davidson loop.
+ *
+ *   hip_dprimme / front end   <- reference src/eigs/primme_c.c:103-108, :277-422
+ *   main loop                 <- reference src/eigs/main_iter.c:175-1414
+ *   init_basis / block Krylov <- reference src/eigs/init.c:125-323
+ *   GD correction             <- reference src/eigs/correction.c:335-381
+ *   verify_norms              <- reference src/eigs/main_iter.c:1864-1897
+ *   copy_back_candidates      <- reference src/eigs/main_iter.c:1743-1832
+ *
+ * Scope of this translation unit: Hermitian standard problem, Rayleigh-Ritz
+ * extraction, Generalized-Davidson family (maxInnerIterations == 0: GD, GD+k,
+ * GD_Olsen+k, LOBPCG-like presets), hard and soft locking, all targets.
+ * The control flow is the reference's; every n-length operation is a launch of
+ * the device layer on panels that stay in HBM for the whole solve.
+ */
+#include "eigs_solver.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+double pa_problem_norm(int overrideUser, const primme_params *p);
+int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
+int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0, int nc);
+int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc);
+int pa_random_col(pa_solver *s, char *col);
+int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
+      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int *b2_out);
+int pa_update_projection(pa_solver *s, int numCols, int blockSize);
+int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged);
+int pa_push_coefficients(pa_solver *s, int basisSize, int ldh);
+int pa_ritz_update(pa_solver *s, int basisSize, const hipk_job *jobs, int njobs, double *norms_out,
+      int nslots, int64_t flop_cols);
+void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv,
+      primme_params *p, int *ierr);
+int pa_check_convergence(pa_solver *s, char *X, int64_t ldX, int givenX, char *R, int64_t ldR,
+      int givenR, int numLocked, int left, int right, int *flags, double *blockNorms,
+      const double *hVals, int *reset, int practConvCheck);
+void pa_map_vecs(const double *Vp, int mrows, int nV, int ldV, const double *Wn, int n0, int n,
+      int ldW, int *pm);
+void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags, int *iblock,
+      int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
+      int *lockedFlags, double *lockedNorms, primme_event event);
+int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int computeXR,
+      int *flags, int remainedEvals, double *blockNorms, int blockNormsSize, int maxBlockSize,
+      int numLocked, double *evals, double *resNorms, int *iev, int *blockSize,
+      int *recentlyConverged, double *smallestResNorm, int numConverged, double *basisNorms,
+      int *reset, int nprevhVecs, int practConvChecking, int *map);
+int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, double *blockNorms,
+      int *evecsPerm, double *evals, double *resNorms, int *numConverged, int *numLocked,
+      int *lockedFlags, int nprevhVecs, int numGuesses, int *restartSizeOutput,
+      int *restartsSinceReset);
+
+/* ---- block orthogonalisation dispatcher (reference ortho.c:429-439, :522-530):
+ *      implicit_I -> vector-by-vector CGS. ----------------------------------------- */
+static int ortho_block(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
+      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int *b2_out) {
+   if (b2 < b1) { *b2_out = b2 + 1; return 0; }
+   return pa_ortho_cgs(s, Vp, ldV, b1, b2, locked, ldLocked, numLocked, RLocked, ldRLocked, b2_out);
+}
+
+/* ---- initial basis ------------------------------------------------------------- */
+static int init_block_krylov(pa_solver *s, int dv1, int dv2) {
+   primme_params *p = s->p;
+   const int numNew = dv2 - dv1 + 1;
+   if (numNew <= 0) return 0;
+   const int blockSize = numNew <= p->maxBlockSize ? 1 : p->maxBlockSize;
+   for (int i = dv1; i < dv1 + blockSize; i++) CHK(pa_random_col(s, VCOL(s, i)));
+   int nV = 0;
+   CHK(ortho_block(s, s->V, s->ld, dv1, dv1 + blockSize - 1, s->evecs, s->ldevecs, p->numOrthoConst, NULL, 0, &nV));
+   if (nV != dv1 + blockSize) return PRIMME_UNEXPECTED_FAILURE;
+   int mm = blockSize;
+   for (int i = dv1 + blockSize; i <= dv2; i += mm) {
+      mm = PA_MIN(mm, dv2 - i + 1);
+      /* V(:,i..) = A V(:,i-bs..), also stored as W(:,i-bs..) */
+      CHK(pa_matvec(s, s->V, s->ld, s->V + (size_t)blockSize * s->ld * s->es, s->ld, i - blockSize, mm));
+      CHK(hipk_copy_cols(s->ctx, s->dt, s->m, VCOL(s, i), s->ld, WCOL(s, i - blockSize), s->ld, mm));
+      CHK(ortho_block(s, s->V, s->ld, i, i + mm - 1, s->evecs, s->ldevecs, p->numOrthoConst, NULL, 0, &nV));
+      for (int j = nV; j < i + mm; j++) CHK(pa_random_col(s, VCOL(s, j)));
+      CHK(ortho_block(s, s->V, s->ld, nV, i + mm - 1, s->evecs, s->ldevecs, p->numOrthoConst, NULL, 0, &nV));
+      if (nV != i + mm) return PRIMME_UNEXPECTED_FAILURE;
+   }
+   CHK(pa_matvec(s, s->V, s->ld, s->W, s->ld, dv2 - blockSize + 1, blockSize));
+   return 0;
+}
+
+static int init_basis(pa_solver *s, int *basisSize, int *nextGuess, int *numGuesses) {
+   primme_params *p = s->p;
+   if (p->numOrthoConst > 0) {
+      int nV = 0;
+      CHK(ortho_block(s, s->evecs, s->ldevecs, 0, p->numOrthoConst - 1, NULL, 0, 0, NULL, 0, &nV));
+      if (nV != p->numOrthoConst) return PRIMME_ORTHO_CONST_FAILURE;
+   }
+   int initSize = p->locking ? PA_MIN(p->minRestartSize, p->initSize) : PA_MIN(p->maxBasisSize, p->initSize);
+   initSize = (int)PA_MAX(0, PA_MIN(p->n - p->numOrthoConst, (int64_t)initSize));
+   *numGuesses = p->initSize - initSize;
+   *nextGuess = p->numOrthoConst + initSize;
+   CHK(hipk_copy_cols(s->ctx, s->dt, s->m, ECOL(s, p->numOrthoConst), s->ldevecs, s->V, s->ld, initSize));
+
+   int nrandom = 0;
+   switch (p->initBasisMode) {
+   case primme_init_krylov: nrandom = 0; break;
+   case primme_init_random: nrandom = PA_MAX(0, p->minRestartSize - initSize); break;
+   case primme_init_user: nrandom = PA_MAX(p->maxBlockSize - initSize, 0); break;
+   default: return PRIMME_UNEXPECTED_FAILURE;
+   }
+   nrandom = (int)PA_MAX(0, PA_MIN(p->n - p->numOrthoConst - initSize, (int64_t)nrandom));
+   for (int i = 0; i < nrandom; i++) CHK(pa_random_col(s, VCOL(s, initSize + i)));
+   *basisSize = initSize + nrandom;
+   CHK(ortho_block(s, s->V, s->ld, 0, *basisSize - 1, s->evecs, s->ldevecs, p->numOrthoConst, NULL, 0, basisSize));
+   CHK(pa_matvec(s, s->V, s->ld, s->W, s->ld, 0, *basisSize));
+   if (p->initBasisMode == primme_init_krylov) {
+      int minRestartSize = (int)PA_MIN((int64_t)p->minRestartSize, p->n - p->numOrthoConst);
+      CHK(init_block_krylov(s, *basisSize, minRestartSize - 1));
+      *basisSize = minRestartSize;
+   }
+   return 0;
+}
+
+/* merge the sorted locked values with the current Ritz values (reference
+ * correction.c:700-760 mergeSort): sortedRitzVals and, for each block vector, its
+ * position ilev in the merged list. */
+static void merge_sort(const double *lockedEvals, int numLocked, const double *ritzVals,
+      const int *flags, int basisSize, double *sorted, int *ilev, int blockSize,
+      const primme_params *p) {
+   int li = 0, ri = 0, si = 0, bi = 0;
+   while (li < numLocked || ri < basisSize) {
+      int takeRitz;
+      if (li >= numLocked) takeRitz = 1;
+      else if (ri >= basisSize) takeRitz = 0;
+      else if (p->target == primme_smallest) takeRitz = ritzVals[ri] <= lockedEvals[li];
+      else takeRitz = ritzVals[ri] >= lockedEvals[li];
+      if (takeRitz) {
+         sorted[si] = ritzVals[ri];
+         if (bi < blockSize && flags[ri] == UNCONV) ilev[bi++] = si;
+         ri++;
+      } else {
+         sorted[si] = lockedEvals[li++];
+      }
+      si++;
+   }
+}
+
+/* GD correction: t = K^-1 (r - eps x) (approximate Olsen when RightX) or K^-1 r;
+ * without a preconditioner a device copy.  Writes the correction over X. */
+static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numLocked, int *flags,
+      int basisSize, double *blockNorms, int *iev, int blockSize) {
+   primme_params *p = s->p;
+   if (blockSize <= 0) return 0;
+   double *shifts = (double *)malloc((size_t)blockSize * sizeof(double));
+   double *olsen = (double *)malloc((size_t)blockSize * sizeof(double));
+   double *sorted = s->hVals;
+   int *ilev = iev, own = 0;
+   if (!shifts || !olsen) return PRIMME_MALLOC_FAILURE;
+   const int extremal = (p->target == primme_smallest || p->target == primme_largest);
+   if (p->locking && extremal) {
+      sorted = (double *)malloc((size_t)(numLocked + basisSize) * sizeof(double));
+      ilev = (int *)malloc((size_t)blockSize * sizeof(int));
+      own = 1;
+      for (int b = 0; b < blockSize; b++) ilev[b] = 0;
+      merge_sort(lockedEvals, numLocked, s->hVals, flags, basisSize, sorted, ilev, blockSize, p);
+   }
+   if (!extremal) {
+      const double targetShift = p->numTargetShifts > 0
+            ? p->targetShifts[PA_MIN(p->numTargetShifts - 1, numLocked)] : 0.0;
+      for (int b = 0; b < blockSize; b++) {
+         const int si = ilev[b];
+         const double bn = blockNorms[b] * sqrt(p->stats.estimateInvBNorm);
+         if (fabs(sorted[si] - targetShift) < bn) shifts[b] = targetShift;
+         else shifts[b] = sorted[si] + bn * (targetShift - sorted[si]) / fabs(targetShift - sorted[si]);
+         olsen[b] = (si < s->numPrevRitzVals) ? fabs(s->prevRitzVals[si] - sorted[si]) : bn;
+      }
+      s->numPrevRitzVals = basisSize;
+      memcpy(s->prevRitzVals, sorted, (size_t)basisSize * sizeof(double));
+   } else {
+      for (int b = 0; b < blockSize; b++) {
+         const int si = ilev[b];
+         if (p->correctionParams.robustShifts) {
+            /* robust shift from the Davis-Kahan bounds (reference correction.c:525-613) */
+            const int nS = numLocked + basisSize;
+            const double rn = blockNorms[b];
+            double eps1;
+            if (p->stats.numOuterIterations <= 1) {
+               eps1 = olsen[b] = rn * sqrt(p->stats.estimateInvBNorm);
+            } else {
+               double gap, lowerGap, delta;
+               if (si == 0 && nS >= 2) {
+                  lowerGap = 1.79769313486231571e+308;
+                  gap = fabs(sorted[1] - sorted[0]);
+               } else if (si > 0 && nS >= 2 && si + 1 < nS) {
+                  lowerGap = fabs(sorted[si] - sorted[si - 1]);
+                  gap = PA_MIN(lowerGap, fabs(sorted[si + 1] - sorted[si]));
+               } else {
+                  lowerGap = (si > 0) ? fabs(sorted[si] - sorted[si - 1]) : 1.79769313486231571e+308;
+                  gap = lowerGap;
+               }
+               delta = (si < s->numPrevRitzVals) ? fabs(s->prevRitzVals[si] - sorted[si]) : 1.79769313486231571e+308;
+               if (gap > rn) eps1 = PA_MIN(delta, PA_MIN(rn * rn * p->stats.estimateInvBNorm / gap, lowerGap));
+               else eps1 = PA_MIN(rn * sqrt(p->stats.estimateInvBNorm), lowerGap);
+               olsen[b] = PA_MIN(delta, eps1);
+            }
+            double sh = (p->target == primme_smallest) ? sorted[si] - eps1 : sorted[si] + eps1;
+            if (si > 0) sh = (p->target == primme_smallest) ? PA_MAX(sh, sorted[si - 1]) : PA_MIN(sh, sorted[si - 1]);
+            shifts[b] = sh;
+         } else {
+            shifts[b] = s->hVals[iev[b]];
+            olsen[b] = (si < s->numPrevRitzVals) ? fabs(s->prevRitzVals[si] - sorted[si])
+                                                 : blockNorms[b] * sqrt(p->stats.estimateInvBNorm);
+         }
+      }
+      s->numPrevRitzVals = numLocked + basisSize;
+      memcpy(s->prevRitzVals, sorted, (size_t)s->numPrevRitzVals * sizeof(double));
+   }
+   p->ShiftsForPreconditioner = shifts;
+
+   char *r = WCOL(s, basisSize), *x = VCOL(s, basisSize);
+   int rc = 0;
+   if (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX) {
+      rc = PRIMME_FUNCTION_UNAVAILABLE; /* exact Olsen projector: not on this path */
+   } else {
+      if (p->correctionParams.projectors.RightX &&
+            ((p->correctionParams.precondition && p->applyPreconditioner) ||
+                  (p->locking && p->orth == primme_orth_implicit_I))) {
+         for (int b = 0; b < blockSize; b++) olsen[b] = -olsen[b];
+         rc = hipk_axpy_cols(s->ctx, s->dt, s->m, olsen, x, s->ld, r, s->ld, blockSize);
+      }
+      if (!rc) rc = pa_precond(s, r, s->ld, x, s->ld, blockSize);
+   }
+   p->ShiftsForPreconditioner = NULL;
+   if (own) { free(sorted); free(ilev); }
+   free(shifts);
+   free(olsen);
+   return rc;
+}
+
+/* residual norms of the first nb basis vectors taken as Ritz vectors (soft locking,
+ * just after a restart: V holds Ritz vectors, W = A V) */
+static int verify_norms(pa_solver *s, int nb, double *resNorms, int *flags, int *numConverged) {
+   if (nb > 0) {
+      CHK(hipk_residual_cols(s->ctx, s->dt, s->m, s->V, s->ld, s->W, s->ld, nb, s->hVals, s->d_red));
+      CHK(pa_reduce(s, s->d_red, nb, 0, 0));
+      for (int i = 0; i < nb; i++) resNorms[i] = sqrt(s->h_red[i]);
+      CHK(pa_check_convergence(s, s->V, s->ld, 1, s->W, s->ld, 1, 0, 0, nb, flags, resNorms, s->hVals, NULL, 0));
+   }
+   int i;
+   for (i = 0; i < nb && flags[i] != UNCONV; i++) ;
+   *numConverged = i;
+   return 0;
+}
+
+static int copy_back_candidates(pa_solver *s, int basisSize, double *evals, double *resNorms,
+      int numConverged, int *numRet) {
+   primme_params *p = s->p;
+   if (numConverged >= p->numEvals || basisSize <= 0) return 0;
+   int i = 0;
+   CHK(pa_push_coefficients(s, basisSize, basisSize));
+   while (i < basisSize && numConverged < p->numEvals) {
+      int blockSize = PA_MAX(0, PA_MIN(p->numEvals - numConverged, basisSize - i));
+      blockSize = PA_MIN(blockSize, 8);
+      hipk_job jobs[16];
+      double norms[8];
+      int nj = 0;
+      for (int c = 0; c < blockSize; c++) {
+         jobs[nj++] = (hipk_job){HIPK_JOB_XV, i + c, ECOL(s, p->numOrthoConst + numConverged + c), -1};
+         jobs[nj++] = (hipk_job){HIPK_JOB_RES, i + c, NULL, c};
+      }
+      CHK(pa_ritz_update(s, basisSize, jobs, nj, norms, blockSize, 2 * blockSize));
+      const int nc0 = numConverged;
+      const double targetShift = p->targetShifts ? p->targetShifts[s->targetShiftIndex < 0 ? 0 : s->targetShiftIndex] : 0.0;
+      for (int b = 0; b < blockSize; b++, i++) {
+         if ((p->target == primme_closest_leq && s->hVals[i] - norms[b] > targetShift) ||
+               (p->target == primme_closest_geq && s->hVals[i] + norms[b] < targetShift)) continue;
+         evals[numConverged] = s->hVals[i];
+         resNorms[numConverged] = norms[b];
+         if (nc0 + b != numConverged)
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, ECOL(s, p->numOrthoConst + nc0 + b), s->ldevecs,
+                  ECOL(s, p->numOrthoConst + numConverged), s->ldevecs, 1));
+         numConverged++;
+      }
+   }
+   for (i = numConverged; i < p->numEvals; i++) resNorms[i] = -1;
+   *numRet = numConverged;
+   return 0;
+}
+
+/* in-place column permutation of a device panel: new column i = old column perm[i] */
+static int permute_dev_cols(pa_solver *s, char *base, int64_t ldb, int n, const int *perm) {
+   int moved = 0;
+   for (int i = 0; i < n; i++) if (perm[i] != i) moved = 1;
+   if (!moved) return 0;
+   if (n > s->nT) return PRIMME_UNEXPECTED_FAILURE;
+   for (int i = 0; i < n; i++)
+      CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, perm[i]), ldb, TCOL(s, i), s->ld, 1));
+   CHK(hipk_copy_cols(s->ctx, s->dt, s->m, s->T, s->ld, base, ldb, n));
+   return 0;
+}
+
+/* ================================ main iteration ================================ */
+static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, int *numRet) {
+   primme_params *p = s->p;
+   int i, blockSize = 0, availableBlockSize = 0, basisSize = 0, numLocked = 0, numGuesses = 0,
+       nextGuess = 0, numConverged = 0, recentlyConverged = 0, maxRecentlyConverged = 0,
+       restartLimitReached, nprevhVecs = 0, reset = 0, restartsSinceReset = 0, wholeSpace = 0;
+   const int maxNumRandoms = 10;
+   double smallestResNorm = HUGE_VAL;
+   int *flags = s->flags, *map = s->map, *iev = s->iev, *perm = s->perm;
+   const int gdNoPrecondLocking = p->locking && !p->correctionParams.precondition &&
+                                  p->correctionParams.maxInnerIterations == 0;
+
+   *ret = PRIMME_MAIN_ITER_FAILURE;
+   *numRet = 0;
+   memset(&p->stats, 0, sizeof(p->stats));
+   p->stats.estimateMinEVal = HUGE_VAL;
+   p->stats.estimateMaxEVal = -HUGE_VAL;
+   p->stats.estimateLargestSVal = -HUGE_VAL;
+   p->stats.estimateBNorm = 1.0;
+   p->stats.estimateInvBNorm = 1.0;
+   for (i = 0; i < p->numEvals; i++) perm[i] = i;
+   for (i = 0; i < p->maxBasisSize; i++) { map[i] = i; s->basisNorms[i] = 0.0; }
+   s->targetShiftIndex = 0;
+
+   if (p->numEvals == 0) { p->initSize = 0; *ret = 0; goto clean; }
+
+   CHK(init_basis(s, &basisSize, &nextGuess, &numGuesses));
+   p->initSize = 0;
+
+#define OUTER_LIMITS_OK() (p->stats.numMatvecs < p->maxMatvecs && \
+      (p->maxOuterIterations == 0 || p->stats.numOuterIterations < p->maxOuterIterations))
+
+   while (OUTER_LIMITS_OK()) {
+      p->initSize = numConverged = numLocked;
+      reset = 0;
+      for (i = 0; i < p->maxBasisSize; i++) flags[i] = UNCONV;
+      s->targetShiftIndex = 0;
+      CHK(pa_update_projection(s, 0, basisSize));
+      CHK(pa_solve_H(s, basisSize, numLocked, numConverged));
+      maxRecentlyConverged = availableBlockSize = blockSize = 0;
+      smallestResNorm = HUGE_VAL;
+      p->stats.estimateResidualError = 0.0;
+      if (!p->locking) p->stats.maxConvTol = 0.0;
+      restartsSinceReset = 0;
+
+      while (numConverged < p->numEvals && OUTER_LIMITS_OK() && !wholeSpace) {
+         nprevhVecs = 0;
+         int candidates_prepared = 0;
+
+         /* ------------------ main block Davidson loop ------------------ */
+         while (basisSize < p->maxBasisSize && OUTER_LIMITS_OK()) {
+            p->stats.numOuterIterations++;
+            availableBlockSize = p->maxBlockSize;
+            maxRecentlyConverged = PA_MAX(0, p->numEvals - numConverged);
+            availableBlockSize = PA_MIN(availableBlockSize, p->maxBasisSize - basisSize);
+            availableBlockSize = PA_MIN(availableBlockSize, maxRecentlyConverged + 1);
+
+            if (availableBlockSize > 0) {
+               int practConvCheck = 0;
+               if (p->n <= basisSize + numLocked + p->numOrthoConst) practConvCheck = 1;
+               else if (gdNoPrecondLocking) practConvCheck = -1;
+               CHK(pa_prepare_candidates(s, basisSize, VCOL(s, basisSize), WCOL(s, basisSize), 1, flags,
+                     maxRecentlyConverged, s->blockNorms, blockSize, availableBlockSize, numLocked, evals,
+                     resNorms, iev, &blockSize, &recentlyConverged, &smallestResNorm, numConverged,
+                     s->basisNorms, &reset, nprevhVecs, practConvCheck, map));
+               candidates_prepared = 1;
+            } else {
+               blockSize = recentlyConverged = 0;
+            }
+            numConverged += recentlyConverged;
+            pa_monitor(s, s->hVals, basisSize, flags, iev, blockSize, s->basisNorms, numConverged, evals,
+                  numLocked, s->lockedFlags, resNorms, primme_event_outer_iteration);
+
+            if (numConverged >= p->numEvals ||
+                  (p->locking && numConverged > numLocked && p->target != primme_smallest &&
+                        p->target != primme_largest) ||
+                  s->targetShiftIndex < 0 || (blockSize == 0 && recentlyConverged > 0) ||
+                  (numConverged >= nextGuess - p->numOrthoConst && numGuesses > 0))
+               break;
+
+            if (blockSize > 0)
+               CHK(solve_correction_gd(s, evals, numLocked, flags, basisSize, s->blockNorms, iev, blockSize));
+
+            /* orthogonalise the corrections; when GD runs with locking and no
+             * preconditioner keep Q'r for the practical-convergence test below */
+            double *Rlocked = NULL;
+            const int ldRlocked = p->numOrthoConst + numLocked;
+            const int blockSize0 = blockSize;
+            if (gdNoPrecondLocking) {
+               Rlocked = (double *)calloc((size_t)(ldRlocked > 0 ? ldRlocked : 1) * (blockSize > 0 ? blockSize : 1), sizeof(double));
+               if (!Rlocked) return PRIMME_MALLOC_FAILURE;
+            }
+            for (i = 0; i < maxNumRandoms; i++) {
+               int basisSizeOut = basisSize;
+               int rc = ortho_block(s, s->V, s->ld, basisSize, basisSize + blockSize - 1, s->evecs, s->ldevecs,
+                     p->numOrthoConst + numLocked, i == 0 ? Rlocked : NULL, ldRlocked, &basisSizeOut);
+               if (rc) { free(Rlocked); return rc; }
+               blockSize = basisSizeOut - basisSize;
+               if (blockSize > 0 || availableBlockSize <= 0) break;
+               rc = pa_random_col(s, VCOL(s, basisSize));
+               if (rc) { free(Rlocked); return rc; }
+               blockSize = 1;
+            }
+            if (i >= maxNumRandoms) {
+               if (availableBlockSize > 0 && blockSize0 <= 0 && reset == 0) wholeSpace = 1;
+               else reset = 2;
+               blockSize = 0;
+               free(Rlocked);
+               break;
+            }
+
+            if (gdNoPrecondLocking) {
+               /* practical convergence: sqrt(|r|^2 - |Q'r|^2) against the criterion
+                * (reference main_iter.c:721-797) */
+               if (numLocked > 0) {
+                  for (i = 0; i < blockSize0 && numConverged < p->numEvals; i++) {
+                     double nR = 0.0;
+                     for (int j = 0; j < ldRlocked; j++) nR += Rlocked[j + (size_t)i * ldRlocked] * Rlocked[j + (size_t)i * ldRlocked];
+                     double newBlockNorm = sqrt(PA_MAX(s->blockNorms[i] * s->blockNorms[i] - nR, 0.0));
+                     int rc = pa_check_convergence(s, VCOL(s, basisSize + i), s->ld, 1, NULL, 0, 0, numLocked, 0, 1,
+                           &flags[iev[i]], &newBlockNorm, &s->hVals[iev[i]], &reset, -1);
+                     if (rc) { free(Rlocked); return rc; }
+                     s->basisNorms[iev[i]] = newBlockNorm;
+                     if (flags[iev[i]] == CONV) {
+                        flags[iev[i]] = PRACT_CONV;
+                        numConverged++;
+                        pa_monitor(s, s->hVals, basisSize, flags, &iev[i], 1, s->basisNorms, numConverged, NULL, 0,
+                              NULL, NULL, primme_event_converged);
+                     }
+                  }
+               }
+               free(Rlocked);
+               Rlocked = NULL;
+               if (numConverged > numLocked && p->target != primme_smallest && p->target != primme_largest)
+                  break;
+            }
+
+            CHK(pa_matvec(s, s->V, s->ld, s->W, s->ld, basisSize, blockSize));
+            CHK(pa_update_projection(s, basisSize, blockSize));
+
+            /* remember the coefficient vectors of this step (the +k directions) */
+            for (int j = 0; j < basisSize; j++) {
+               memcpy(s->prevhVecs + (size_t)j * s->K, s->hVecs + (size_t)j * basisSize, (size_t)basisSize * sizeof(double));
+               memset(s->prevhVecs + (size_t)j * s->K + basisSize, 0, (size_t)(s->K - basisSize) * sizeof(double));
+            }
+            nprevhVecs = basisSize;
+            basisSize += blockSize;
+            blockSize = 0;
+            CHK(pa_solve_H(s, basisSize, numLocked, numConverged));
+            candidates_prepared = 0;
+         } /* main block Davidson loop */
+
+         if (basisSize >= p->n - p->numOrthoConst - numLocked) {
+            if (p->stats.maxConvTol < p->stats.estimateResidualError) reset = 1;
+         }
+         if (reset > 0) break;
+
+         /* ---- make sure there are candidates (X, R) for after the restart ---- */
+         if (!candidates_prepared) {
+            if (blockSize > 0) {
+               availableBlockSize = blockSize;
+               maxRecentlyConverged = 0;
+            } else if (p->numTargetShifts > numConverged + 1) {
+               maxRecentlyConverged = p->locking
+                     ? PA_MAX(PA_MIN(p->numEvals, numLocked + 1) - numConverged, 0)
+                     : PA_MAX(PA_MIN(p->numEvals, numConverged + 1) - numConverged, 0);
+               availableBlockSize = maxRecentlyConverged;
+            } else {
+               maxRecentlyConverged = PA_MAX(0, p->numEvals - numConverged);
+               availableBlockSize = PA_MAX(0, PA_MIN(p->maxBlockSize, p->maxBasisSize - (numConverged - numLocked)));
+               availableBlockSize = PA_MIN(availableBlockSize, maxRecentlyConverged + 1);
+            }
+            availableBlockSize = (int)PA_MAX(0, PA_MIN((int64_t)availableBlockSize, p->n - numLocked - p->numOrthoConst));
+
+            if (availableBlockSize <= 0 ||
+                  p->minRestartSize + p->restartingParams.maxPrevRetain + availableBlockSize < p->maxBasisSize ||
+                  p->numOrthoConst + numLocked + basisSize >= p->n) {
+               double dummyZero = 0.0;
+               double *srn = (p->target == primme_closest_abs || p->target == primme_largest_abs)
+                                   ? &dummyZero : &smallestResNorm;
+               CHK(pa_prepare_candidates(s, basisSize, NULL, NULL, 0, flags, maxRecentlyConverged, s->blockNorms,
+                     blockSize, availableBlockSize, numLocked, evals, resNorms, iev, &blockSize,
+                     &recentlyConverged, srn, numConverged, s->basisNorms, &reset, nprevhVecs, 0, map));
+
+               for (i = 0, numConverged = numLocked; i < basisSize; i++)
+                  if (flags[i] != UNCONV && numConverged < p->numEvals &&
+                        (i < p->numEvals - numLocked || p->target == primme_closest_geq ||
+                              p->target == primme_closest_leq))
+                     numConverged++;
+
+               /* converged pairs and the block first */
+               int *iwork = (int *)malloc((size_t)basisSize * sizeof(int));
+               if (!iwork) return PRIMME_MALLOC_FAILURE;
+               int j, k, l, mm;
+               for (i = k = l = mm = 0; i < basisSize; i++) {
+                  int inIev = 0;
+                  for (j = 0; j < blockSize; j++) if (iev[j] == i) inIev = 1;
+                  if ((flags[i] != UNCONV && mm++ < numConverged - numLocked) || inIev) iwork[k++] = i;
+                  else iwork[numConverged - numLocked + blockSize + l++] = i;
+               }
+               pa_permute_cols(s->hVals, 1, basisSize, 1, iwork);
+               pa_permute_cols(s->hVecs, basisSize, basisSize, basisSize, iwork);
+               pa_permute_ints(flags, basisSize, iwork);
+               s->coef_valid_k = -1;
+               free(iwork);
+            } else {
+               blockSize = availableBlockSize;
+               for (i = 0; i < blockSize; i++) iev[i] = i;
+               pa_map_vecs(s->prevhVecs, basisSize, nprevhVecs, s->K, s->hVecs, 0, basisSize, basisSize, map);
+            }
+         }
+         if (reset > 0) break;
+
+         pa_permute_cols(s->prevhVecs, basisSize, nprevhVecs, s->K, map);
+
+         /* ------------------------------ restart ------------------------------ */
+         CHK(pa_restart(s, basisSize, flags, iev, &blockSize, s->blockNorms, perm, evals, resNorms,
+               &numConverged, &numLocked, s->lockedFlags, nprevhVecs, numGuesses, &basisSize,
+               &restartsSinceReset));
+         restartsSinceReset++;
+
+         if (numGuesses > 0) {
+            /* feed remaining initial guesses into the restarted basis */
+            int numNew = PA_MAX(0, PA_MIN(p->minRestartSize + numConverged - (nextGuess - p->numOrthoConst), numGuesses));
+            numNew = PA_MAX(0, PA_MIN(basisSize + numNew, p->maxBasisSize) - basisSize);
+            numNew = (int)PA_MAX(0, PA_MIN((int64_t)(basisSize + numNew + p->numOrthoConst + numLocked), p->n) -
+                                          p->numOrthoConst - numLocked - basisSize);
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, ECOL(s, nextGuess), s->ldevecs, VCOL(s, basisSize), s->ld, numNew));
+            nextGuess += numNew;
+            numGuesses -= numNew;
+            int basisSizeOut = basisSize;
+            CHK(ortho_block(s, s->V, s->ld, basisSize, basisSize + numNew - 1, s->evecs, s->ldevecs,
+                  numLocked + p->numOrthoConst, NULL, 0, &basisSizeOut));
+            numNew = basisSizeOut - basisSize;
+            CHK(pa_matvec(s, s->V, s->ld, s->W, s->ld, basisSize, numNew));
+            /* the block's X, R slots were overwritten: no candidates carried over */
+            blockSize = 0;
+            /* H must be dense again for the new columns: rebuild coefficient layout */
+            {
+               /* hVecs currently has leading dimension basisSize; H is K x K already */
+            }
+            CHK(pa_update_projection(s, basisSize, numNew));
+            basisSize += numNew;
+            CHK(pa_solve_H(s, basisSize, numLocked, numConverged));
+         }
+
+         p->stats.numRestarts++;
+         p->initSize = numConverged;
+         for (i = 0; i < p->maxBasisSize; i++) map[i] = i;
+      } /* restarting loop */
+
+      if (reset > 0) {
+         /* V and W accumulated too much error: re-orthogonalise and recompute W
+          * (reference: `continue` with reset set re-enters the outer loop) */
+         continue;
+      }
+
+      if (p->locking) {
+         CHK(copy_back_candidates(s, basisSize, evals, resNorms, numConverged, numRet));
+         if (*numRet < numConverged) *numRet = numConverged;
+         p->stats.lockingIssue = 0;
+         *ret = (numConverged == p->numEvals || wholeSpace) ? 0 : PRIMME_MAIN_ITER_FAILURE;
+         goto clean;
+      } else {
+         restartLimitReached = OUTER_LIMITS_OK() ? 0 : 1;
+         CHK(verify_norms(s, restartLimitReached ? PA_MIN(p->numEvals, basisSize) : numConverged, resNorms, flags, &numConverged));
+         if (restartLimitReached || numConverged >= p->numEvals || wholeSpace) {
+            for (i = 0; i < p->numEvals; i++) { evals[i] = s->hVals[i]; perm[i] = i; }
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, s->V, s->ld, ECOL(s, p->numOrthoConst), s->ldevecs, p->numEvals));
+            *numRet = p->numEvals;
+            p->initSize = numConverged;
+            *ret = (numConverged >= p->numEvals) ? 0 : PRIMME_MAIN_ITER_FAILURE;
+            goto clean;
+         }
+         /* some pairs lost convergence in the restart: re-orthogonalise, recompute W */
+         CHK(ortho_block(s, s->V, s->ld, 0, basisSize - 1, s->evecs, s->ldevecs, p->numOrthoConst, NULL, 0, &basisSize));
+         CHK(pa_matvec(s, s->V, s->ld, s->W, s->ld, 0, basisSize));
+         restartsSinceReset = 0;
+         reset = 0;
+         p->stats.estimateResidualError = 0.0;
+         numConverged = 0;
+      }
+   }
+   /* limits reached before entering / while re-entering the outer loop */
+   if (p->locking) {
+      CHK(copy_back_candidates(s, basisSize, evals, resNorms, numConverged, numRet));
+      if (*numRet < numConverged) *numRet = numConverged;
+   }
+
+clean:
+   if (p->aNorm <= 0.0) p->aNorm = p->stats.estimateLargestSVal;
+   /* locked vectors are stored in convergence order: sort them like evals */
+   CHK(permute_dev_cols(s, ECOL(s, p->numOrthoConst), s->ldevecs, p->initSize, perm));
+   CHK(hipk_sync(s->ctx));
+   return 0;
+}
+
+/* ================================ front end ===================================== */
+static void free_solver(pa_solver *s) {
+   if (!s) return;
+   if (s->ctx) {
+      hipk_sync(s->ctx);
+      hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T);
+      hipk_free(s->ctx, s->d_red); hipk_free(s->ctx, s->d_coef); hipk_free(s->ctx, s->d_theta);
+      hipk_host_free(s->ctx, s->h_red); hipk_host_free(s->ctx, s->h_coef); hipk_host_free(s->ctx, s->h_theta);
+      hipk_ctx_destroy(s->ctx);
+   }
+   free(s->H); free(s->hVecs); free(s->prevhVecs); free(s->hVals); free(s->prevRitzVals);
+   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms);
+   free(s->flags); free(s->map); free(s->iev); free(s->perm); free(s->lockedFlags);
+   free(s);
+}
+
+extern void primme_amd_global_sum(void *, void *, int *, struct primme_params *, int *);
+
+static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt) {
+   const double t0 = pa_wtime();
+   if (!p) return -4;
+   const int real_out_is_float = (dt == HIPK_F32 || dt == HIPK_C32);
+   const double mach_eps = real_out_is_float ? 1.1920928955078125e-07 : PA_EPS;
+
+   if (p->numProcs <= 1 && evals_out && evecs && resNorms_out) { p->nLocal = p->n; p->procID = 0; }
+   primme_set_defaults(p);
+   if (p->orth == primme_orth_default)
+      p->orth = (real_out_is_float || p->maxBlockSize > 1) ? primme_orth_explicit_I : primme_orth_implicit_I;
+   if (p->ldOPs == -1) p->ldOPs = p->nLocal;
+   if (!evals_out && !evecs && !resNorms_out) return 0;
+   if (p->iseed[0] < 0 || p->iseed[0] > 4095) p->iseed[0] = p->procID % 4096;
+   if (p->iseed[1] < 0 || p->iseed[1] > 4095) p->iseed[1] = (int)(p->procID / 4096 + 1) % 4096;
+   if (p->iseed[2] < 0 || p->iseed[2] > 4095) p->iseed[2] = (int)((p->procID / 4096) / 4096 + 2) % 4096;
+   if (p->iseed[3] < 0 || p->iseed[3] > 4095) p->iseed[3] = (2 * (int)(((p->procID / 4096) / 4096) / 4096) + 1) % 4096;
+   if (!p->convTestFun) {
+      p->convTestFun = pa_conv_test_absolute;
+      p->convTestFun_type = (dt == HIPK_F32 || dt == HIPK_C32) ? primme_op_float : primme_op_double;
+      if (p->eps == 0.0) p->eps = mach_eps * 1e4;
+   }
+   int rc = pa_check_input(evals_out, evecs, resNorms_out, p, mach_eps);
+   if (rc) return rc;
+
+   /* what this build of the path covers; anything else must fail loudly */
+   if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
+   if (p->massMatrixMatvec || p->projectionParams.projection != primme_proj_RR ||
+         p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0 ||
+         p->orth != primme_orth_implicit_I) {
+      if (p->printLevel > 0 && p->outputFile)
+         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / non-RR projection / "
+               "JDQMR inner solver / dynamic method / explicit_I orthogonalisation) is not on the device path yet\n");
+      return PRIMME_FUNCTION_UNAVAILABLE;
+   }
+
+   pa_solver *s = (pa_solver *)calloc(1, sizeof(pa_solver));
+   if (!s) return PRIMME_MALLOC_FAILURE;
+   s->p = p; s->dt = dt; s->es = (dt == HIPK_F64) ? 8 : 4; s->mach_eps = mach_eps;
+   s->m = p->nLocal; s->ld = p->ldOPs; s->K = p->maxBasisSize;
+   s->evecs = (char *)evecs; s->ldevecs = p->ldevecs;
+   s->startTime = t0;
+   s->phase_timing = p->profile != NULL;
+   s->dev_comm = (p->numProcs > 1 && p->globalSumReal == primme_amd_global_sum);
+   s->coef_valid_k = -1;
+   s->maxRank = p->numOrthoConst + (p->locking ? p->numEvals : 0) + p->maxBasisSize;
+   if (hipk_ctx_create(&s->ctx, p->queue)) { free(s); return PRIMME_UNEXPECTED_FAILURE; }
+   /* callbacks find the solver's stream in primme->queue (reference: the queue/handle
+    * field carries the device queue, examples/ex_eigs_dhipblas.c:177-179) */
+   void *user_queue = p->queue;
+   void *own_stream = hipk_ctx_stream(s->ctx);
+   if (!p->queue) p->queue = &own_stream;
+
+   const int K = s->K, nev = p->numEvals, b = p->maxBlockSize;
+   s->nT = K + 2 * b + 2;
+   s->red_cap = (s->maxRank + 16) * (b + 8) + 64;
+   const size_t colBytes = (size_t)(s->ld > 0 ? s->ld : 1) * s->es;
+   rc = hipk_malloc(s->ctx, colBytes * K, (void **)&s->V) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W) ||
+        hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
+        hipk_malloc(s->ctx, (size_t)s->red_cap * 8, (void **)&s->d_red) ||
+        hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
+        hipk_host_alloc(s->ctx, (size_t)s->red_cap * 8, (void **)&s->h_red) ||
+        hipk_host_alloc(s->ctx, (size_t)K * K * 8, (void **)&s->h_coef) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta);
+   s->H = (double *)calloc((size_t)K * K, 8); s->hVecs = (double *)calloc((size_t)K * K, 8);
+   s->prevhVecs = (double *)calloc((size_t)K * K, 8); s->hVals = (double *)calloc((size_t)K, 8);
+   s->prevRitzVals = (double *)calloc((size_t)K + nev, 8);
+   s->blockNorms = (double *)calloc((size_t)K + b, 8); s->basisNorms = (double *)calloc((size_t)K, 8);
+   s->flags = (int *)calloc((size_t)K, sizeof(int)); s->map = (int *)calloc((size_t)K, sizeof(int));
+   s->iev = (int *)calloc((size_t)K + b, sizeof(int)); s->perm = (int *)calloc((size_t)nev + 1, sizeof(int));
+   s->lockedFlags = (int *)calloc((size_t)nev + 1, sizeof(int));
+   if (rc || !s->H || !s->hVecs || !s->prevhVecs || !s->hVals || !s->prevRitzVals || !s->blockNorms ||
+         !s->basisNorms || !s->flags || !s->map || !s->iev || !s->perm || !s->lockedFlags) {
+      free_solver(s);
+      p->queue = user_queue;
+      return PRIMME_MALLOC_FAILURE;
+   }
+
+   /* evals / resNorms are kept in double inside and narrowed on exit */
+   double *evals = (double *)calloc((size_t)nev + 1, 8), *resNorms = (double *)calloc((size_t)nev + 1, 8);
+   int ret = 0, numRet = 0;
+   rc = main_iter(s, evals, resNorms, &ret, &numRet);
+   if (!rc) {
+      for (int i = 0; i < numRet; i++) {
+         if (real_out_is_float) { ((float *)evals_out)[i] = (float)evals[i]; ((float *)resNorms_out)[i] = (float)resNorms[i]; }
+         else { ((double *)evals_out)[i] = evals[i]; ((double *)resNorms_out)[i] = resNorms[i]; }
+      }
+      rc = ret;
+   }
+   free(evals);
+   free(resNorms);
+   if (p->convTestFun == pa_conv_test_absolute) { /* leave the struct as the reference does: default installed */ }
+   free_solver(s);
+   p->queue = user_queue;
+   p->stats.elapsedTime = pa_wtime() - t0;
+   return rc;
+}
+
+int hip_dprimme(double *evals, double *evecs, double *resNorms, primme_params *primme) {
+   return solve(evals, evecs, resNorms, primme, HIPK_F64);
+}
+int hip_sprimme(float *evals, float *evecs, float *resNorms, primme_params *primme) {
+   return solve(evals, evecs, resNorms, primme, HIPK_F32);
+}
+int hip_zprimme(double *evals, void *evecs, double *resNorms, primme_params *primme) {
+   return solve(evals, evecs, resNorms, primme, HIPK_C64);
+}
+int hip_cprimme(float *evals, void *evecs, float *resNorms, primme_params *primme) {
+   return solve(evals, evecs, resNorms, primme, HIPK_C32);
+}

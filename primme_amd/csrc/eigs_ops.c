@@ -1,0 +1,440 @@
+/* eigs_ops.c — solver steps that touch the HBM-resident basis: the matvec wrapper,
+ * reductions (with the optional all-reduce), classical Gram-Schmidt with Daniel's
+ * reorthogonalisation test, the projection update and the Rayleigh-Ritz solve.
+ *
+ * Each function names the reference routine whose behaviour it restates; the
+ * structure differs because the basis never leaves the device and only the few
+ * scalars the control flow needs come back to the host (one synchronisation per
+ * CGS pass instead of the reference GPU backend's one per BLAS call).
+ */
+#include "eigs_solver.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+double pa_wtime(void) {
+   struct timespec ts;
+   clock_gettime(CLOCK_MONOTONIC, &ts);
+   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ---- problem norm / machine epsilons (reference auxiliary_eigs.c:498-591) ------ */
+double pa_problem_norm(int overrideUser, const primme_params *p) {
+   if (!overrideUser) return p->aNorm > 0.0 ? p->aNorm : p->stats.estimateLargestSVal;
+   return PA_MAX(p->aNorm > 0.0 ? p->aNorm : 0.0, p->stats.estimateLargestSVal);
+}
+
+/* ---- reductions -----------------------------------------------------------------
+ * d_buf (device) holds `count` local partial sums.  On return s->h_red[0..count)
+ * holds the global sums; if keep_dev, d_buf holds them as well (the next kernel
+ * uses them as coefficients).  Restates globalSum_Tprimme (reference
+ * auxiliary_eigs.c:391-427) for device-resident partials.
+ * When defer_sync is set and no host callback is involved, the device->host copy
+ * is only enqueued; the caller must hipk_sync before reading h_red. */
+int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync) {
+   primme_params *p = s->p;
+   if (count <= 0) return 0;
+   const int parallel = (p->numProcs > 1 && p->globalSumReal);
+   double t0 = parallel ? pa_wtime() : 0.0;
+   if (parallel && s->dev_comm) {
+      CHK(pa_comm_allreduce_device(p->commInfo, d_buf, count, hipk_ctx_stream(s->ctx)));
+      CHK(hipk_d2h(s->ctx, s->h_red + (d_buf - s->d_red), d_buf, (size_t)count * sizeof(double)));
+      if (!defer_sync) CHK(hipk_sync(s->ctx));
+   } else {
+      CHK(hipk_d2h(s->ctx, s->h_red + (d_buf - s->d_red), d_buf, (size_t)count * sizeof(double)));
+      if (parallel) {
+         CHK(hipk_sync(s->ctx));
+         int ierr = 0, cnt = count;
+         double *hb = s->h_red + (d_buf - s->d_red);
+         p->globalSumReal(hb, hb, &cnt, p, &ierr);
+         if (ierr) return PRIMME_USER_FAILURE;
+         if (keep_dev) CHK(hipk_h2d(s->ctx, d_buf, hb, (size_t)count * sizeof(double)));
+      } else if (!defer_sync) {
+         CHK(hipk_sync(s->ctx));
+      }
+   }
+   if (parallel) {
+      p->stats.numGlobalSum++;
+      p->stats.volumeGlobalSum += count;
+      p->stats.timeGlobalSum += pa_wtime() - t0;
+   }
+   return 0;
+}
+
+/* ---- W(:,c0:c0+nc) = A * V(:,c0:c0+nc)  (reference auxiliary_eigs.c:183-230) ---- */
+int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0, int nc) {
+   primme_params *p = s->p;
+   if (nc <= 0) return 0;
+   double t0 = pa_wtime();
+   int ierr = 0;
+   PRIMME_INT ldx = ldV, ldy = ldW;
+   p->matrixMatvec(PCOL(s, Vp, ldV, c0), &ldx, PCOL(s, Wp, ldW, c0), &ldy, &nc, p, &ierr);
+   if (ierr) return PRIMME_USER_FAILURE;
+   if (s->phase_timing) CHK(hipk_sync(s->ctx));
+   p->stats.timeMatvec += pa_wtime() - t0;
+   p->stats.numMatvecs += nc;
+   return 0;
+}
+
+/* ---- y = K^-1 x or copy (reference auxiliary_eigs.c:317-364) -------------------- */
+int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc) {
+   primme_params *p = s->p;
+   if (nc <= 0) return 0;
+   double t0 = pa_wtime();
+   if (p->correctionParams.precondition) {
+      int ierr = 0;
+      PRIMME_INT ldx = ldX, ldy = ldY;
+      p->applyPreconditioner(X, &ldx, Y, &ldy, &nc, p, &ierr);
+      if (ierr) return PRIMME_USER_FAILURE;
+      p->stats.numPreconds += nc;
+   } else {
+      CHK(hipk_copy_cols(s->ctx, s->dt, s->m, X, ldX, Y, ldY, nc));
+   }
+   if (s->phase_timing) CHK(hipk_sync(s->ctx));
+   p->stats.timePrecond += pa_wtime() - t0;
+   return 0;
+}
+
+/* random column (reference blaslapack.c:938-988 Num_larnv: host xLARNV then upload) */
+int pa_random_col(pa_solver *s, char *col) {
+   double *tmp = (double *)malloc((size_t)(s->m > 0 ? s->m : 1) * sizeof(double));
+   if (!tmp) return PRIMME_MALLOC_FAILURE;
+   pa_larnv_uniform11(s->p->iseed, s->m, tmp);
+   int rc;
+   if (s->dt == HIPK_F64) {
+      rc = hipk_h2d(s->ctx, col, tmp, (size_t)s->m * 8);
+   } else {
+      float *f = (float *)tmp; /* in-place narrowing, front to back */
+      for (int64_t i = 0; i < s->m; i++) f[i] = (float)tmp[i];
+      rc = hipk_h2d(s->ctx, col, tmp, (size_t)s->m * 4);
+   }
+   if (!rc) rc = hipk_sync(s->ctx);
+   free(tmp);
+   return rc;
+}
+
+/* ---- classical Gram-Schmidt with reorthogonalisation ---------------------------
+ * Restates Bortho_gen_Sprimme (reference src/eigs/ortho.c:123-360) for B = I:
+ * orthonormalise columns b1..b2 of Vp against its columns 0..b1-1, against
+ * `locked` (numLocked columns) and among themselves.  Daniel's test with
+ * threshold sqrt(2)/2, at most 3 passes before the column is replaced by a random
+ * vector, at most 10 replacements.  RLocked (host, optional) accumulates
+ * locked' * v of the first passes (used by the practical-convergence test,
+ * reference main_iter.c:742-775).
+ *
+ * Per pass one fused chain runs on the device with no host round trip in between:
+ *    dots([Vp(0:i) | locked | v]' v) -> (all-reduce) -> v -= [Vp locked]*overlaps,
+ *    |v|^2 -> (all-reduce) -> copy back
+ * and the host synchronises once to apply the test.
+ */
+int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
+      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int *b2_out) {
+   primme_params *p = s->p;
+   const int maxNumOrthos = 3, maxNumRandoms = 10;
+   const double tol = sqrt(2.0) / 2.0;
+   const double eps_orth = s->mach_eps;
+   const int parallel = (p->numProcs > 1 && p->globalSumReal);
+   double t0 = pa_wtime();
+
+   if (RLocked)
+      for (int c = 0; c <= b2 - b1; c++)
+         for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)c * ldRLocked] = 0.0;
+   if (b2_out) *b2_out = b1;
+
+   for (int i = b1; i <= b2; i++) {
+      int nOrth = 0, randomizations = 0, updateR = RLocked ? 1 : 0;
+      double s0 = 0.0, s02 = 0.0, s1 = 0.0, s12 = 0.0;
+      char *v = PCOL(s, Vp, ldV, i);
+      for (;;) {
+         if (nOrth >= maxNumOrthos) {
+            updateR = 0;
+            if (randomizations >= maxNumRandoms) goto done;
+            CHK(pa_random_col(s, v));
+            randomizations++;
+            nOrth = 0;
+         }
+         nOrth++;
+         const int first = (nOrth == 1);
+         const int nov = i + numLocked;           /* overlaps proper                  */
+         const int ndot = nov + (first ? 1 : 0);  /* + |v|^2 on the first pass        */
+         hipk_seg segs[3] = {{Vp, ldV, i}, {locked, ldLocked, numLocked}, {v, ldV, first ? 1 : 0}};
+         double *d_ov = s->d_red, *d_s1 = s->d_red + nov + 1;
+         CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segs, 3, v, ldV, 1, d_ov, ndot));
+         p->stats.numOrthoInnerProds += ndot;
+         if (parallel && !s->dev_comm) {
+            CHK(pa_reduce(s, d_ov, ndot, 1, 0));
+         } else if (parallel) {
+            CHK(pa_reduce(s, d_ov, ndot, 1, 1));
+         } else {
+            CHK(hipk_d2h(s->ctx, s->h_red, d_ov, (size_t)ndot * sizeof(double)));
+         }
+         CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, d_ov, nov > 0 ? nov : 1, v, ldV, 1, d_s1));
+         p->stats.numOrthoInnerProds += nov + 1;
+         CHK(pa_reduce(s, d_s1, 1, 0, 0)); /* synchronises: h_red now has overlaps, s02, s12 */
+
+         if (updateR)
+            for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += s->h_red[i + j];
+         if (first) { s02 = s->h_red[nov]; s0 = sqrt(s02); }
+         s12 = s->h_red[nov + 1];
+         s1 = sqrt(s12);
+
+         if (!isfinite(s0) || !isfinite(s1) || s1 <= eps_orth * s0) {
+            nOrth = maxNumOrthos;             /* lost all significant digits: randomise */
+         } else if (s1 <= tol * s0) {
+            s0 = s1; s02 = s12;               /* another pass */
+         } else {
+            double inv = 1.0 / s1;
+            if (isfinite(inv)) {
+               CHK(hipk_scale_cols(s->ctx, s->dt, s->m, v, ldV, 1, &inv));
+               break;
+            }
+            nOrth = maxNumOrthos;
+         }
+      }
+      if (b2_out) *b2_out = i + 1;
+   }
+done:
+   if (s->phase_timing) CHK(hipk_sync(s->ctx));
+   p->stats.timeOrtho += pa_wtime() - t0;
+   return 0;
+}
+
+/* Host-only variant for the k x k coefficient vectors (reference ortho.c:395-415
+ * Bortho_local with primme == NULL: up to 7 passes, always reorthogonalise).
+ * Orthonormalises the single vector x (length n) against Q (n x nQ, ldQ) in the
+ * G inner product (G upper-stored n x n, or NULL for identity).  *R receives the
+ * norm left after projection (0 if the vector had to be randomised). */
+int pa_ortho_local_vec(double *x, int n, const double *Q, int ldQ, int nQ, const double *G,
+      int ldG, double *R, int64_t iseed[4]) {
+   const int maxNumOrthos = 7, maxNumRandoms = 10;
+   const double tol = sqrt(2.0) / 2.0;
+   double *ov = (double *)malloc((size_t)(nQ + 1) * sizeof(double));
+   double *Bx = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+   if (!ov || !Bx) { free(ov); free(Bx); return PRIMME_MALLOC_FAILURE; }
+   int nOrth = 0, randomizations = 0, updateR = 1, rc = -3;
+   double s0 = 0, s02 = 0, s1 = 0, s12 = 0;
+   *R = 0.0;
+#define APPLY_G(dst, src)                                                           \
+   do {                                                                             \
+      if (!G) memcpy(dst, src, (size_t)n * sizeof(double));                         \
+      else for (int i_ = 0; i_ < n; i_++) {                                         \
+         double t_ = 0;                                                             \
+         for (int j_ = 0; j_ < n; j_++)                                             \
+            t_ += ((i_ <= j_) ? G[i_ + (size_t)j_ * ldG] : G[j_ + (size_t)i_ * ldG]) * (src)[j_]; \
+         (dst)[i_] = t_;                                                            \
+      }                                                                             \
+   } while (0)
+   for (;;) {
+      if (nOrth >= maxNumOrthos) {
+         if (updateR) { *R = 0.0; updateR = 0; }
+         if (randomizations >= maxNumRandoms) break;
+         pa_larnv_uniform11(iseed, n, x);
+         randomizations++;
+         nOrth = 0;
+      }
+      nOrth++;
+      APPLY_G(Bx, x);
+      if (nOrth == 1) { s02 = 0; for (int i = 0; i < n; i++) s02 += x[i] * Bx[i]; s0 = sqrt(s02); }
+      for (int j = 0; j < nQ; j++) {
+         double t = 0;
+         for (int i = 0; i < n; i++) t += Q[i + (size_t)j * ldQ] * Bx[i];
+         ov[j] = t;
+      }
+      for (int j = 0; j < nQ; j++)
+         for (int i = 0; i < n; i++) x[i] -= Q[i + (size_t)j * ldQ] * ov[j];
+      APPLY_G(Bx, x);
+      s12 = 0;
+      for (int i = 0; i < n; i++) s12 += x[i] * Bx[i];
+      s1 = sqrt(s12);
+      if (!isfinite(s0) || !isfinite(s1) || s1 <= PA_EPS * s0) {
+         nOrth = maxNumOrthos;
+      } else if (s1 <= tol * s0 || nOrth < maxNumOrthos) {
+         s0 = s1; s02 = s12;
+      } else {
+         if (updateR) *R = s1;
+         double inv = 1.0 / s1;
+         if (isfinite(inv)) { for (int i = 0; i < n; i++) x[i] *= inv; rc = 0; break; }
+         nOrth = maxNumOrthos;
+      }
+   }
+#undef APPLY_G
+   (void)s02;
+   free(ov);
+   free(Bx);
+   return rc;
+}
+
+/* ---- H(:, k:k+b) = V(:,0:k+b)' W(:,k:k+b)  (reference update_projection.c:80-165) - */
+int pa_update_projection(pa_solver *s, int numCols, int blockSize) {
+   if (blockSize <= 0) return 0;
+   const int mrows = numCols + blockSize;
+   hipk_seg seg = {s->V, s->ld, mrows};
+   CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, WCOL(s, numCols), s->ld, blockSize, s->d_red, mrows));
+   CHK(pa_reduce(s, s->d_red, mrows * blockSize, 0, 0));
+   for (int c = 0; c < blockSize; c++)
+      for (int i = 0; i < mrows; i++)
+         s->H[i + (size_t)(numCols + c) * s->K] = s->h_red[i + (size_t)c * mrows];
+   return 0;
+}
+
+/* ---- Rayleigh-Ritz on the projected matrix (reference solve_projection.c:94-154,
+ *      :188-331): eigenpairs of H (upper) ordered by primme->target, then the
+ *      running estimates of the spectrum edges. --------------------------------- */
+int pa_solve_H_RR(pa_solver *s, const double *H, int ldH, const double *VtBV, int ldVtBV,
+      double *hVecs, int ldhVecs, double *hVals, int n, int numConverged) {
+   primme_params *p = s->p;
+   if (n == 0) return 0;
+   if (p->target == primme_largest) {
+      double *Hn = (double *)malloc((size_t)n * n * sizeof(double));
+      if (!Hn) return PRIMME_MALLOC_FAILURE;
+      for (int j = 0; j < n; j++)
+         for (int i = 0; i <= j; i++) Hn[i + (size_t)j * n] = -H[i + (size_t)j * ldH];
+      int rc = pa_sym_eig_gen(n, Hn, n, VtBV, ldVtBV, hVals, hVecs, ldhVecs);
+      free(Hn);
+      if (rc) return rc;
+      for (int i = 0; i < n; i++) hVals[i] = -hVals[i];
+      return 0;
+   }
+   CHK(pa_sym_eig_gen(n, H, ldH, VtBV, ldVtBV, hVals, hVecs, ldhVecs));
+   if (p->target == primme_smallest) return 0;
+
+   /* interior targets: permutation by closeness to the first unlocked shift */
+   int *permu = (int *)malloc((size_t)n * sizeof(int));
+   if (!permu) return PRIMME_MALLOC_FAILURE;
+   const double shift = p->targetShifts[PA_MIN(p->numTargetShifts - 1, numConverged)];
+   int idx = 0, i, j;
+   if (p->target == primme_closest_geq) {
+      for (j = 0; j < n; j++) if (hVals[j] >= shift) break;
+      for (i = j; i < n; i++) permu[idx++] = i;
+      for (i = 0; i < j; i++) permu[idx++] = i;
+   } else if (p->target == primme_closest_leq) {
+      for (j = n - 1; j >= 0; j--) if (hVals[j] <= shift) break;
+      for (i = j; i >= 0; i--) permu[idx++] = i;
+      for (i = n - 1; i > j; i--) permu[idx++] = i;
+   } else if (p->target == primme_closest_abs) {
+      for (j = 0; j < n; j++) if (hVals[j] >= shift) break;
+      i = j - 1;
+      while (i >= 0 && j < n) {
+         if (fabs(hVals[i] - shift) < fabs(hVals[j] - shift)) permu[idx++] = i--;
+         else permu[idx++] = j++;
+      }
+      if (i < 0) { for (i = j; i < n; i++) permu[idx++] = i; }
+      else if (j >= n) { for (j = i; j >= 0; j--) permu[idx++] = j; }
+   } else { /* primme_largest_abs */
+      j = 0; i = n - 1;
+      while (i >= j) {
+         if (fabs(hVals[i] - shift) > fabs(hVals[j] - shift)) permu[idx++] = i--;
+         else permu[idx++] = j++;
+      }
+   }
+   pa_permute_cols(hVals, 1, n, 1, permu);
+   pa_permute_cols(hVecs, n, n, ldhVecs, permu);
+   free(permu);
+   return 0;
+}
+
+int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged) {
+   primme_params *p = s->p;
+   const int off = p->numOrthoConst + numLocked;
+   const double *G = s->VtBV ? s->VtBV + (size_t)off * s->ldVtBV + off : NULL;
+   CHK(pa_solve_H_RR(s, s->H, s->K, G, s->ldVtBV, s->hVecs, basisSize, s->hVals, basisSize, numConverged));
+   for (int i = 0; i < basisSize; i++) {
+      p->stats.estimateMinEVal = PA_MIN(p->stats.estimateMinEVal, s->hVals[i]);
+      p->stats.estimateMaxEVal = PA_MAX(p->stats.estimateMaxEVal, s->hVals[i]);
+      p->stats.estimateLargestSVal = PA_MAX(p->stats.estimateLargestSVal, fabs(s->hVals[i]));
+   }
+   s->coef_valid_k = -1;
+   return 0;
+}
+
+/* upload the current coefficient vectors / Ritz values once per solve_H */
+int pa_push_coefficients(pa_solver *s, int basisSize, int ldh) {
+   if (s->coef_valid_k == basisSize) return 0;
+   for (int j = 0; j < basisSize; j++)
+      memcpy(s->h_coef + (size_t)j * s->K, s->hVecs + (size_t)j * ldh, (size_t)basisSize * sizeof(double));
+   memcpy(s->h_theta, s->hVals, (size_t)basisSize * sizeof(double));
+   CHK(hipk_h2d(s->ctx, s->d_coef, s->h_coef, (size_t)s->K * basisSize * sizeof(double)));
+   CHK(hipk_h2d(s->ctx, s->d_theta, s->h_theta, (size_t)basisSize * sizeof(double)));
+   s->coef_valid_k = basisSize;
+   return 0;
+}
+
+/* ---- fused Ritz / residual update with the reference's bookkeeping -------------
+ * Wraps hipk_ritz_update: uploads coefficients if stale, splits norm-only
+ * residual jobs into read-only pre-passes when more than 16 residual columns
+ * are requested, reduces the squared norms and returns their square roots in
+ * norms_out[slot] (clamped from below by estimateResidualError when asked, as
+ * reference restart.c:1266-1270 / main_iter.c:1686-1690 do). */
+int pa_ritz_update(pa_solver *s, int basisSize, const hipk_job *jobs, int njobs, double *norms_out,
+      int nslots, int64_t flop_cols) {
+   primme_params *p = s->p;
+   double t0 = pa_wtime();
+   if (njobs <= 0) return 0;
+   /* count residual jobs */
+   int nres = 0;
+   for (int q = 0; q < njobs; q++) if (jobs[q].kind == HIPK_JOB_RES) nres++;
+   hipk_job *work = (hipk_job *)malloc((size_t)njobs * sizeof(hipk_job));
+   if (!work) return PRIMME_MALLOC_FAILURE;
+   double *d_n = s->d_red;
+   int slot_base = 0;
+   if (nres > 16) {
+      /* norm-only jobs first, 16 at a time (pure reads, so splitting is safe) */
+      int cnt = 0;
+      for (int q = 0; q < njobs; q++) {
+         if (jobs[q].kind == HIPK_JOB_RES && jobs[q].dst == NULL) {
+            work[cnt] = jobs[q];
+            work[cnt].slot = cnt;
+            cnt++;
+            if (cnt == 16) {
+               int rc = hipk_ritz_update(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef, s->K, s->d_theta, work, cnt, d_n + slot_base);
+               if (rc) { free(work); return rc; }
+               /* remember where each original slot landed */
+               slot_base += cnt; cnt = 0;
+            }
+         }
+      }
+      if (cnt) {
+         int rc = hipk_ritz_update(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef, s->K, s->d_theta, work, cnt, d_n + slot_base);
+         if (rc) { free(work); return rc; }
+         slot_base += cnt;
+      }
+   }
+   /* main launch: everything that writes, plus norm-only jobs not yet done */
+   int cnt = 0, nmain_slots = 0;
+   int *slot_of = (int *)malloc((size_t)(nslots > 0 ? nslots : 1) * sizeof(int)); /* slot -> position in d_n */
+   for (int i = 0; i < nslots; i++) slot_of[i] = -1;
+   if (nres > 16) {
+      int pos = 0;
+      for (int q = 0; q < njobs; q++)
+         if (jobs[q].kind == HIPK_JOB_RES && jobs[q].dst == NULL) { if (jobs[q].slot >= 0) slot_of[jobs[q].slot] = pos; pos++; }
+   }
+   for (int q = 0; q < njobs; q++) {
+      if (nres > 16 && jobs[q].kind == HIPK_JOB_RES && jobs[q].dst == NULL) continue;
+      work[cnt] = jobs[q];
+      if (jobs[q].kind == HIPK_JOB_RES) {
+         if (jobs[q].slot >= 0) slot_of[jobs[q].slot] = slot_base + nmain_slots;
+         work[cnt].slot = nmain_slots++;
+      }
+      cnt++;
+   }
+   if (cnt) {
+      int rc = hipk_ritz_update(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef, s->K, s->d_theta, work, cnt, d_n + slot_base);
+      if (rc) { free(work); free(slot_of); return rc; }
+   }
+   const int total_slots = slot_base + nmain_slots;
+   if (total_slots > 0) {
+      int rc = pa_reduce(s, d_n, total_slots, 0, 0);
+      if (rc) { free(work); free(slot_of); return rc; }
+      for (int i = 0; i < nslots; i++)
+         if (slot_of[i] >= 0 && norms_out) norms_out[i] = sqrt(s->h_red[slot_of[i]]);
+   } else if (s->phase_timing) {
+      hipk_sync(s->ctx);
+   }
+   free(work);
+   free(slot_of);
+   p->stats.timeDense += pa_wtime() - t0;
+   p->stats.flopsDense += (double)s->m * (double)flop_cols * basisSize;
+   return 0;
+}

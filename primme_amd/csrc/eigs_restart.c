@@ -1,0 +1,493 @@
+/* eigs_restart.c — thick restart with +k retained directions, soft and hard locking.
+ *
+ *   pa_restart               <- reference src/eigs/restart.c:200-494  (restart_Sprimme)
+ *   restart_soft_locking     <- reference :598-722
+ *   restart_locking          <- reference :832-1187
+ *   restart_RR               <- reference :1614-1735
+ *   ortho_coefficient_vectors<- reference :2347-2408
+ *   insertion_sort           <- reference src/eigs/auxiliary_eigs_normal.c:543-638
+ *
+ * The host part is integer/permutation logic on k-vectors, restated literally.
+ * The n-length work of a restart is ONE fused pass over V and W (pa_ritz_update):
+ * V <- V*h, W <- W*h in place, the next block's X and R, the vectors to lock
+ * into evecs and their residual norms.
+ */
+#include "eigs_solver.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <assert.h>
+
+double pa_problem_norm(int overrideUser, const primme_params *p);
+int pa_ritz_update(pa_solver *s, int basisSize, const hipk_job *jobs, int njobs, double *norms_out,
+      int nslots, int64_t flop_cols);
+int pa_push_coefficients(pa_solver *s, int basisSize, int ldh);
+int pa_check_convergence(pa_solver *s, char *X, int64_t ldX, int givenX, char *R, int64_t ldR,
+      int givenR, int numLocked, int left, int right, int *flags, double *blockNorms,
+      const double *hVals, int *reset, int practConvCheck);
+int pa_ortho_local_vec(double *x, int n, const double *Q, int ldQ, int nQ, const double *G,
+      int ldG, double *R, int64_t iseed[4]);
+int pa_solve_H_RR(pa_solver *s, const double *H, int ldH, const double *VtBV, int ldVtBV,
+      double *hVecs, int ldhVecs, double *hVals, int n, int numConverged);
+void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags, int *iblock,
+      int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
+      int *lockedFlags, double *lockedNorms, primme_event event);
+
+/* Lock newVal by insertion into the sorted evals (smallest/largest) or in
+ * convergence order within equal shifts (interior). perm remembers arrival order. */
+static int insertion_sort(double newVal, double *evals, double newNorm, double *resNorms,
+      int newFlag, int *flags, int *perm, int n, int initialShift, const primme_params *p) {
+   int i;
+   if (p->target == primme_smallest) {
+      for (i = n; i > 0; i--) if (newVal >= evals[i - 1]) break;
+   } else if (p->target == primme_largest) {
+      for (i = n; i > 0; i--) if (newVal <= evals[i - 1]) break;
+   } else {
+      const double cur = p->targetShifts[PA_MIN(p->numTargetShifts - 1, initialShift + n)];
+      for (i = n; i > 0; i--) {
+         const double ith = p->targetShifts[PA_MIN(p->numTargetShifts - 1, initialShift + i - 1)];
+         int stop;
+         if (p->target == primme_closest_geq) stop = (newVal - cur >= evals[i - 1] - cur);
+         else if (p->target == primme_closest_leq) stop = (cur - newVal >= cur - evals[i - 1]);
+         else if (p->target == primme_closest_abs) stop = (fabs(newVal - cur) >= fabs(evals[i - 1] - cur));
+         else if (p->target == primme_largest_abs) stop = (fabs(newVal - cur) <= fabs(evals[i - 1] - cur));
+         else return PRIMME_FUNCTION_UNAVAILABLE;
+         if (ith != cur || stop) break;
+      }
+   }
+   for (int c = n - 1; c >= i; c--) {
+      evals[c + 1] = evals[c];
+      if (resNorms) resNorms[c + 1] = resNorms[c];
+      if (perm) perm[c + 1] = perm[c];
+      if (flags) flags[c + 1] = flags[c];
+   }
+   evals[i] = newVal;
+   if (resNorms) resNorms[i] = newNorm;
+   if (perm) perm[i] = n;
+   if (flags) flags[i] = newFlag;
+   return 0;
+}
+
+/* Orthogonalise up to *numPrevRetained previous coefficient vectors against the
+ * first indexOfPreviousVecs (+ already retained) current ones and append them. */
+static int ortho_coefficient_vectors(pa_solver *s, int basisSize, int ldh, int indexOfPreviousVecs,
+      const double *G, int ldG, int nprevhVecs, const int *flags, int *numPrevRetained) {
+   primme_params *p = s->p;
+   int retained = 0;
+   for (int i = 0; i < nprevhVecs && retained < *numPrevRetained &&
+                   indexOfPreviousVecs + retained < basisSize; i++) {
+      if (p->locking == 0 && flags[i] != UNCONV) continue;
+      double R = 0.0;
+      double *x = s->prevhVecs + (size_t)i * s->K;
+      pa_ortho_local_vec(x, basisSize, s->hVecs, ldh, indexOfPreviousVecs + retained, G, ldG, &R, p->iseed);
+      if (fabs(R) < PA_EPS * sqrt(retained + 1.0)) continue;
+      memcpy(s->hVecs + (size_t)(indexOfPreviousVecs + retained) * ldh, x, (size_t)basisSize * sizeof(double));
+      retained++;
+   }
+   *numPrevRetained = retained;
+   return 0;
+}
+
+/* H = diag(theta) with the dense +k block, coefficient vectors = unit vectors
+ * except inside that block (implicit_I); with explicit_I, H and VtBV were
+ * recomputed from the data by the fused update and only the block solve remains. */
+static int restart_RR(pa_solver *s, int ldh, int newldh, int restartSize, int basisSize,
+      int numConverged, int numPrevRetained, int indexOfPreviousVecs, const int *hVecsPerm) {
+   primme_params *p = s->p;
+   const int K = s->K;
+   double *H = s->H;
+   const double aNorm = PA_MAX(p->aNorm, p->stats.estimateLargestSVal);
+
+   if (p->orth == primme_orth_implicit_I) {
+      double *blk = (double *)malloc((size_t)(numPrevRetained > 0 ? numPrevRetained * numPrevRetained : 1) * sizeof(double));
+      if (!blk) return PRIMME_MALLOC_FAILURE;
+      pa_submatrix(s->hVecs + (size_t)indexOfPreviousVecs * ldh, numPrevRetained, ldh, H, basisSize, K,
+            blk, numPrevRetained);
+      for (int j = 0; j < restartSize; j++)
+         for (int i = 0; i < restartSize; i++) H[i + (size_t)j * K] = 0.0;
+      for (int j = 0; j < numPrevRetained; j++)
+         for (int i = 0; i < numPrevRetained; i++)
+            H[(indexOfPreviousVecs + i) + (size_t)(indexOfPreviousVecs + j) * K] = blk[i + (size_t)j * numPrevRetained];
+      for (int j = 0; j < indexOfPreviousVecs; j++) H[j + (size_t)j * K] = s->hVals[j];
+      for (int j = indexOfPreviousVecs + numPrevRetained; j < restartSize; j++) H[j + (size_t)j * K] = s->hVals[j];
+      free(blk);
+   }
+
+   const int nLocked = p->numOrthoConst + (p->locking ? numConverged : 0);
+   const double *G = s->VtBV ? s->VtBV + (size_t)nLocked * s->ldVtBV + nLocked : NULL;
+   if (p->targetShifts &&
+         (s->targetShiftIndex < 0 ||
+               fabs(p->targetShifts[s->targetShiftIndex] -
+                     p->targetShifts[PA_MIN(p->numTargetShifts - 1, numConverged)]) > s->mach_eps * aNorm)) {
+      /* the target moved: solve the whole restarted problem */
+      s->targetShiftIndex = PA_MIN(p->numTargetShifts - 1, numConverged);
+      CHK(pa_solve_H_RR(s, H, K, G, s->ldVtBV, s->hVecs, newldh, s->hVals, restartSize, numConverged));
+      for (int i = 0; i < restartSize; i++) {
+         p->stats.estimateMinEVal = PA_MIN(p->stats.estimateMinEVal, s->hVals[i]);
+         p->stats.estimateMaxEVal = PA_MAX(p->stats.estimateMaxEVal, s->hVals[i]);
+         p->stats.estimateLargestSVal = PA_MAX(p->stats.estimateLargestSVal, fabs(s->hVals[i]));
+      }
+      return 0;
+   }
+
+   int ordered = restartSize;
+   for (int i = 0; i < restartSize; i++)
+      if (hVecsPerm[i] == indexOfPreviousVecs) { ordered = i; break; }
+
+   for (int j = 0; j < restartSize; j++) {
+      for (int i = 0; i < restartSize; i++) s->hVecs[i + (size_t)j * newldh] = 0.0;
+      s->hVecs[hVecsPerm[j] + (size_t)j * newldh] = 1.0;
+   }
+   pa_permute_cols(s->hVals, 1, restartSize, 1, hVecsPerm);
+
+   if (numPrevRetained > 0) {
+      const double *Gb = G ? G + (size_t)indexOfPreviousVecs * s->ldVtBV + indexOfPreviousVecs : NULL;
+      CHK(pa_solve_H_RR(s, H + (size_t)indexOfPreviousVecs * K + indexOfPreviousVecs, K, Gb, s->ldVtBV,
+            s->hVecs + (size_t)ordered * newldh + indexOfPreviousVecs, newldh, s->hVals + ordered,
+            numPrevRetained, numConverged));
+      for (int i = 0; i < numPrevRetained; i++) {
+         const double v = s->hVals[ordered + i];
+         p->stats.estimateMinEVal = PA_MIN(p->stats.estimateMinEVal, v);
+         p->stats.estimateMaxEVal = PA_MAX(p->stats.estimateMaxEVal, v);
+         p->stats.estimateLargestSVal = PA_MAX(p->stats.estimateLargestSVal, fabs(v));
+      }
+   }
+   return 0;
+}
+
+/* column shuffles on the device: dst_k <- src_k for k < n, executed through the
+ * scratch panel so overlapping source/destination ranges are safe */
+static int move_cols(pa_solver *s, char *base, const int *src, const int *dst, int n) {
+   for (int c0 = 0; c0 < n; c0 += s->nT) {
+      int nn = PA_MIN(s->nT, n - c0);
+      for (int c = 0; c < nn; c++)
+         CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, s->ld, src[c0 + c]), s->ld, TCOL(s, c), s->ld, 1));
+      for (int c = 0; c < nn; c++)
+         CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, c), s->ld, PCOL(s, base, s->ld, dst[c0 + c]), s->ld, 1));
+   }
+   return 0;
+}
+
+static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, int ldh,
+      int *restartPerm, int *flags, int *iev, int *ievSize, double *blockNorms, double *evals,
+      double *resNorms, int *numConverged, int numPrevRetained, int *indexOfPreviousVecs,
+      int *hVecsPerm) {
+   primme_params *p = s->p;
+   int i, j, k;
+
+   /* a previously converged pair whose Ritz value drifted more than its residual
+    * norm is targeted again */
+   *numConverged = 0;
+   for (i = 0; i < p->numEvals; i++) {
+      if (flags[i] != UNCONV && fabs(s->hVals[i] - evals[i]) > resNorms[i]) {
+         flags[i] = UNCONV;
+      } else if (flags[i] != UNCONV) {
+         if (flags[i] == CONV) {
+            if (*numConverged == 0) p->stats.maxConvTol = 0.0;
+            p->stats.maxConvTol = PA_MAX(p->stats.maxConvTol, resNorms[i]);
+         }
+         (*numConverged)++;
+      }
+   }
+
+   *indexOfPreviousVecs = *restartSize;
+   *restartSize += numPrevRetained;
+   *ievSize = PA_MAX(0, PA_MIN(PA_MIN(PA_MIN(PA_MIN(PA_MIN(*ievSize, p->maxBlockSize),
+                                                p->numEvals - *numConverged + 1),
+                                         p->maxBasisSize - *restartSize),
+                                  basisSize - *numConverged),
+                           p->minRestartSize - *numConverged));
+
+   for (i = j = k = 0; i < basisSize; i++) {
+      if (k >= *numConverged || flags[i] == UNCONV) restartPerm[*numConverged + j++] = i;
+      else restartPerm[k++] = i;
+   }
+   pa_permute_cols(s->hVals, 1, basisSize, 1, restartPerm);
+   pa_permute_cols(s->hVecs, basisSize, basisSize, ldh, restartPerm);
+   s->coef_valid_k = -1;
+   CHK(pa_push_coefficients(s, basisSize, ldh));
+
+   /* one pass: V, W <- V h, W h (in place); X, R for the next block; converged
+    * Ritz vectors copied out to evecs */
+   const int rs = *restartSize, nc = *numConverged, nb = *ievSize;
+   hipk_job *jobs = (hipk_job *)malloc((size_t)(2 * rs + 2 * nb + nc + 4) * sizeof(hipk_job));
+   if (!jobs) return PRIMME_MALLOC_FAILURE;
+   int nj = 0;
+   for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, VCOL(s, c), -1};
+   for (int c = 0; c < nb; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, nc + c, VCOL(s, rs + c), -1};
+   for (int c = 0; c < nc; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, ECOL(s, p->numOrthoConst + c), -1};
+   for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
+   for (int c = 0; c < nb; c++) jobs[nj++] = (hipk_job){HIPK_JOB_RES, nc + c, WCOL(s, rs + c), c};
+   int rc = pa_ritz_update(s, basisSize, jobs, nj, blockNorms, nb, (int64_t)2 * rs + 2 * nb + nc);
+   free(jobs);
+   if (rc) return rc;
+
+   for (i = 0; i < basisSize; i++) hVecsPerm[restartPerm[i]] = i;
+   for (i = 0; i < *ievSize; i++)
+      for (j = 0; j < *restartSize; j++)
+         if (hVecsPerm[j] == *numConverged + i) iev[i] = j;
+   return 0;
+}
+
+static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ldh,
+      int *restartPerm, int *flags, int *iev, int *ievSize, double *blockNorms, double *evals,
+      int *numConverged, int *numLocked, double *resNorms, int *lockedFlags, int *evecsperm,
+      int numPrevRetained, int *indexOfPreviousVecs, int *hVecsPerm) {
+   primme_params *p = s->p;
+   int i, j, k, numPacked, failed;
+   const int numLocked0 = *numLocked;
+   const int nOC = p->numOrthoConst;
+
+   int maxBlockSize = PA_MAX(0, PA_MIN(PA_MIN(*restartSize, p->maxBlockSize), p->numEvals - *numConverged + 1));
+   int sizeBlockNorms = PA_MAX(0, PA_MIN(maxBlockSize,
+         p->maxBasisSize - *restartSize - numPrevRetained - *numConverged + *numLocked));
+   *indexOfPreviousVecs = *restartSize;
+   const int left = *restartSize + numPrevRetained;
+
+   for (i = k = numPacked = 0; i < basisSize; i++) {
+      if (flags[i] != UNCONV && numPacked < p->numEvals - *numLocked &&
+            (i < p->numEvals - *numLocked || p->target == primme_closest_geq ||
+                  p->target == primme_closest_leq)) {
+         restartPerm[left + numPacked++] = i;
+      } else if (k < left) {
+         restartPerm[k++] = i;
+      } else {
+         restartPerm[PA_MIN(*numConverged, p->numEvals) - *numLocked + k++] = i;
+      }
+   }
+   *restartSize = left + numPacked;
+
+   pa_permute_cols(s->hVals, 1, basisSize, 1, restartPerm);
+   pa_permute_cols(s->hVecs, basisSize, basisSize, ldh, restartPerm);
+   s->coef_valid_k = -1;
+   CHK(pa_push_coefficients(s, basisSize, ldh));
+
+   /* one fused pass over V and W */
+   double *lockedResNorms = &resNorms[*numLocked];
+   const int rs = *restartSize;
+   char *X = VCOL(s, rs), *R = WCOL(s, rs);
+   hipk_job *jobs = (hipk_job *)malloc((size_t)(2 * rs + 2 * sizeBlockNorms + 2 * numPacked + 4) * sizeof(hipk_job));
+   double *norms = (double *)malloc((size_t)(sizeBlockNorms + numPacked + 1) * sizeof(double));
+   if (!jobs || !norms) return PRIMME_MALLOC_FAILURE;
+   int nj = 0;
+   for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, VCOL(s, c), -1};
+   for (int c = 0; c < sizeBlockNorms; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, X, s->ld, c), -1};
+   for (int c = 0; c < numPacked; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, left + c, ECOL(s, *numLocked + nOC + c), -1};
+   for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
+   for (int c = 0; c < sizeBlockNorms; c++) jobs[nj++] = (hipk_job){HIPK_JOB_RES, c, PCOL(s, R, s->ld, c), c};
+   for (int c = 0; c < numPacked; c++) jobs[nj++] = (hipk_job){HIPK_JOB_RES, left + c, NULL, sizeBlockNorms + c};
+   int rc = pa_ritz_update(s, basisSize, jobs, nj, norms, sizeBlockNorms + numPacked,
+         (int64_t)2 * rs + 2 * sizeBlockNorms + 2 * numPacked);
+   free(jobs);
+   if (rc) { free(norms); return rc; }
+   for (int c = 0; c < sizeBlockNorms; c++) blockNorms[c] = norms[c];
+   for (int c = 0; c < numPacked; c++)
+      lockedResNorms[c] = PA_MAX(norms[sizeBlockNorms + c], p->stats.estimateResidualError);
+   free(norms);
+
+   /* re-test the pairs about to be locked with their true residual norms */
+   pa_permute_ints(flags, basisSize, restartPerm);
+   CHK(pa_check_convergence(s, VCOL(s, left), s->ld, 1, NULL, 0, 0, *numLocked, left, left + numPacked,
+         flags, lockedResNorms, s->hVals, NULL, 0));
+
+   for (i = left, j = 0; i < left + numPacked; i++) {
+      if (flags[i] != UNCONV && *numLocked + j < p->numEvals) evals[*numLocked + j++] = s->hVals[i];
+      else flags[i] = UNCONV;
+   }
+
+   /* pairs that failed the re-test go back into the basis right after the
+    * restarted vectors and take part in the next block */
+   int *ifailed = (int *)malloc((size_t)(numPacked > 0 ? numPacked : 1) * sizeof(int));
+   if (!ifailed) return PRIMME_MALLOC_FAILURE;
+   for (i = left, failed = 0; i < left + numPacked; i++) if (flags[i] == UNCONV) ifailed[failed++] = i - left;
+   for (i = left, j = 0; i < left + numPacked; i++) if (flags[i] != UNCONV) ifailed[failed + j++] = i - left;
+
+   maxBlockSize = PA_MAX(0, PA_MIN(maxBlockSize,
+         p->maxBasisSize - *restartSize - numPrevRetained - *numConverged + *numLocked));
+   {
+      double *bn0 = (double *)malloc((size_t)(sizeBlockNorms > 0 ? sizeBlockNorms : 1) * sizeof(double));
+      for (i = 0; i < sizeBlockNorms; i++) bn0[i] = blockNorms[i];
+      for (i = j = k = 0; i < *indexOfPreviousVecs || j < failed; k++) {
+         if (i < *indexOfPreviousVecs && (j >= failed || restartPerm[i] < restartPerm[left + ifailed[j]])) {
+            if (k < maxBlockSize && i < sizeBlockNorms) blockNorms[k] = bn0[i];
+            hVecsPerm[k] = i++;
+         } else {
+            if (k < maxBlockSize) blockNorms[k] = resNorms[numLocked0 + ifailed[j]];
+            hVecsPerm[k] = left + j++;
+         }
+      }
+      free(bn0);
+      for (i = 0; i < numPrevRetained; i++) hVecsPerm[k++] = i + *indexOfPreviousVecs;
+      for (; k < basisSize; k++) hVecsPerm[k] = -1;
+   }
+
+   /* Build the next block's X and R from the candidate columns (xo, ro: already
+    * computed above) merged in original order with the failed ones (their X is
+    * the Ritz vector, R = W - theta*V), and compact the failed columns to
+    * V(:,left..left+failed) / W(...).  (reference restart.c:1047-1052,
+    * compute_residual_columns :2464-2538) */
+   {
+      const int nd = maxBlockSize;
+      /* stage the merged block in the scratch panel: X in T[0..nd), R in T[nd..2nd) */
+      int io = 0, ifl = 0;
+      for (int id = 0; id < nd; id++) {
+         if (io < sizeBlockNorms && hVecsPerm[id] == io) {
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, X, s->ld, io), s->ld, TCOL(s, id), s->ld, 1));
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, R, s->ld, io), s->ld, TCOL(s, nd + id), s->ld, 1));
+            io++;
+         } else if (ifl < failed) {
+            const int src = left + ifailed[ifl];
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, VCOL(s, src), s->ld, TCOL(s, id), s->ld, 1));
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, WCOL(s, src), s->ld, TCOL(s, nd + id), s->ld, 1));
+            double th = s->hVals[src];
+            CHK(hipk_residual_cols(s->ctx, s->dt, s->m, VCOL(s, src), s->ld, TCOL(s, nd + id), s->ld, 1, &th, s->d_red));
+            ifl++;
+         } else {
+            break;
+         }
+      }
+      const int nbuilt = io + ifl < nd ? io + ifl : nd;
+      /* compact failed columns (ascending, sources are never below destinations) */
+      for (i = 0; i < failed; i++) {
+         if (ifailed[i] != i) {
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, VCOL(s, left + ifailed[i]), s->ld, VCOL(s, left + i), s->ld, 1));
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, WCOL(s, left + ifailed[i]), s->ld, WCOL(s, left + i), s->ld, 1));
+         }
+      }
+      if (nbuilt > 0) {
+         CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, VCOL(s, left + failed), s->ld, nbuilt));
+         CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, nd), s->ld, WCOL(s, left + failed), s->ld, nbuilt));
+      }
+   }
+
+   /* the same compaction on the host-side coefficient data */
+   {
+      double *tmp = (double *)malloc((size_t)basisSize * (failed > 0 ? failed : 1) * sizeof(double));
+      double *tv = (double *)malloc((size_t)(failed > 0 ? failed : 1) * sizeof(double));
+      for (i = 0; i < failed; i++) {
+         memcpy(tmp + (size_t)i * basisSize, s->hVecs + (size_t)(left + ifailed[i]) * ldh, (size_t)basisSize * sizeof(double));
+         tv[i] = s->hVals[left + ifailed[i]];
+      }
+      for (i = 0; i < failed; i++) {
+         memcpy(s->hVecs + (size_t)(left + i) * ldh, tmp + (size_t)i * basisSize, (size_t)basisSize * sizeof(double));
+         s->hVals[left + i] = tv[i];
+      }
+      free(tmp);
+      free(tv);
+      pa_permute_ints(&restartPerm[left], numPacked, ifailed);
+   }
+   /* (explicit_I: VtBV and H rows/columns follow the same shuffle — see pa_restart) */
+
+   /* lock: pack the accepted vectors in evecs and insertion-sort their values */
+   for (i = left; i < left + numPacked; i++) {
+      if (flags[i] != UNCONV && *numLocked < p->numEvals) {
+         const double resNorm = resNorms[*numLocked] = lockedResNorms[i - left];
+         const double eval = evals[*numLocked];
+         if (numLocked0 + i - left != *numLocked)
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, ECOL(s, numLocked0 + i - left + nOC), s->ldevecs,
+                  ECOL(s, *numLocked + nOC), s->ldevecs, 1));
+         (*numLocked)++;
+         lockedFlags[*numLocked - 1] = flags[i];
+         pa_monitor(s, NULL, 0, NULL, NULL, 0, NULL, 0, evals, *numLocked, lockedFlags, resNorms, primme_event_locked);
+         CHK(insertion_sort(eval, evals, resNorm, resNorms, flags[i], lockedFlags, evecsperm, *numLocked - 1, 0, p));
+         if (flags[i] == CONV) p->stats.maxConvTol = PA_MAX(p->stats.maxConvTol, resNorm);
+      }
+   }
+   free(ifailed);
+
+   *restartSize = left + failed;
+   *ievSize = PA_MIN(maxBlockSize, sizeBlockNorms + failed);
+   *numConverged = *numLocked;
+   for (i = 0; i < *ievSize; i++) iev[i] = i;
+   for (i = 0; i < basisSize; i++) flags[i] = UNCONV;
+   return 0;
+}
+
+int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, double *blockNorms,
+      int *evecsPerm, double *evals, double *resNorms, int *numConverged, int *numLocked,
+      int *lockedFlags, int nprevhVecs, int numGuesses, int *restartSizeOutput,
+      int *restartsSinceReset) {
+   primme_params *p = s->p;
+   const int ldh = basisSize;
+   int i, restartSize;
+
+   for (i = 0, *numConverged = *numLocked; i < basisSize; i++) {
+      if (flags[i] == SKIP_RESTART) flags[i] = UNCONV;
+      else if (flags[i] != UNCONV && *numConverged < p->numEvals &&
+               (i < p->numEvals - *numLocked || p->target == primme_closest_geq ||
+                     p->target == primme_closest_leq))
+         (*numConverged)++;
+   }
+
+   int numPrevRetained = p->restartingParams.maxPrevRetain;
+   if (!p->locking && basisSize + *numLocked + p->numOrthoConst >= p->n) {
+      restartSize = basisSize;
+      numPrevRetained = 0;
+   } else if (basisSize <= p->maxBasisSize - p->maxBlockSize) {
+      restartSize = basisSize;
+      numPrevRetained = 0;
+   } else {
+      restartSize = PA_MIN(basisSize, p->minRestartSize);
+   }
+   restartSize -= PA_MIN(PA_MIN(numGuesses, *numConverged - *numLocked), restartSize);
+   if (p->locking) restartSize = PA_MIN(restartSize, basisSize - (*numConverged - *numLocked));
+   numPrevRetained = PA_MAX(0, PA_MIN(PA_MIN(numPrevRetained, p->maxBasisSize - restartSize - 1),
+                                 (int)(p->n - restartSize - *numConverged - p->numOrthoConst)));
+
+   int indexOfPreviousVecs = p->locking ? restartSize + *numConverged - *numLocked : restartSize;
+   const int nLocked = p->numOrthoConst + *numLocked;
+   const double *G = s->VtBV ? s->VtBV + (size_t)nLocked * s->ldVtBV + nLocked : NULL;
+   CHK(ortho_coefficient_vectors(s, basisSize, ldh, indexOfPreviousVecs, G, s->ldVtBV, nprevhVecs, flags,
+         &numPrevRetained));
+
+   int *restartPerm = (int *)malloc((size_t)basisSize * sizeof(int));
+   int *hVecsPerm = (int *)malloc((size_t)basisSize * sizeof(int));
+   if (!restartPerm || !hVecsPerm) return PRIMME_MALLOC_FAILURE;
+   int rc;
+   if (!p->locking)
+      rc = restart_soft_locking(s, &restartSize, basisSize, ldh, restartPerm, flags, iev, ievSize,
+            blockNorms, evals, resNorms, numConverged, numPrevRetained, &indexOfPreviousVecs, hVecsPerm);
+   else
+      rc = restart_locking(s, &restartSize, basisSize, ldh, restartPerm, flags, iev, ievSize, blockNorms,
+            evals, numConverged, numLocked, resNorms, lockedFlags, evecsPerm, numPrevRetained,
+            &indexOfPreviousVecs, hVecsPerm);
+   if (rc) { free(restartPerm); free(hVecsPerm); return rc; }
+
+   /* previous Ritz values follow the basis (only used by interior-target shifts) */
+   if (p->target != primme_smallest && p->target != primme_largest) {
+      if (s->numPrevRitzVals > 0) {
+         for (i = s->numPrevRitzVals; i < basisSize; i++) s->prevRitzVals[i] = s->prevRitzVals[s->numPrevRitzVals - 1];
+         pa_permute_cols(s->prevRitzVals, 1, basisSize, 1, restartPerm);
+      }
+      for (i = 0; i < restartSize; i++)
+         if (restartPerm[i] >= s->numPrevRitzVals) s->prevRitzVals[i] = s->hVals[i];
+      pa_permute_cols(s->prevRitzVals, 1, restartSize, 1, hVecsPerm);
+      s->numPrevRitzVals = restartSize;
+   }
+
+   rc = restart_RR(s, ldh, restartSize, restartSize, basisSize, *numConverged, numPrevRetained,
+         indexOfPreviousVecs, hVecsPerm);
+   free(restartPerm);
+   if (rc) { free(hVecsPerm); return rc; }
+   s->coef_valid_k = -1;
+
+   if (*numConverged >= p->numEvals && !p->locking) {
+      /* all wanted pairs converged: bring them to the front of V and W */
+      int *inv = (int *)malloc((size_t)restartSize * sizeof(int));
+      int *ident = (int *)malloc((size_t)restartSize * sizeof(int));
+      for (i = 0; i < restartSize; i++) { inv[i] = hVecsPerm[i]; ident[i] = i; }
+      rc = move_cols(s, s->V, inv, ident, restartSize);
+      if (!rc) rc = move_cols(s, s->W, inv, ident, restartSize);
+      free(inv);
+      free(ident);
+      if (rc) { free(hVecsPerm); return rc; }
+   }
+   free(hVecsPerm);
+   *restartSizeOutput = restartSize;
+
+   /* bound on the error accumulated in V and W (implicit_I branch of reference
+    * restart.c:418-451; the explicit_I estimate from VtBV is added with that path) */
+   p->stats.estimateResidualError =
+         2 * sqrt((double)*restartsSinceReset) * s->mach_eps * pa_problem_norm(1, p);
+   return 0;
+}

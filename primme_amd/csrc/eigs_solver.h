@@ -1,0 +1,60 @@
+/* eigs_solver.h — state of one hip_?primme solve (host side). */
+#ifndef EIGS_SOLVER_H
+#define EIGS_SOLVER_H
+
+#include "eigs_internal.h"
+
+enum { UNCONV = PRIMME_AMD_UNCONVERGED, SKIP_RESTART = PRIMME_AMD_SKIP_UNTIL_RESTART,
+       CONV = PRIMME_AMD_CONVERGED, PRACT_CONV = PRIMME_AMD_PRACTICALLY_CONVERGED };
+
+typedef struct pa_solver {
+   primme_params *p;
+   hipk_ctx *ctx;
+   hipk_dtype dt;
+   size_t es;              /* bytes per panel element */
+   double mach_eps;        /* of the panel type */
+   int64_t m, ld;          /* nLocal, ldOPs */
+   int K;                  /* maxBasisSize */
+   int maxRank;
+
+   /* HBM-resident panels */
+   char *V, *W;            /* m x K */
+   char *T;                /* scratch, m x nT */
+   int nT;
+   char *evecs;            /* caller's device array: constraints | locked | guesses */
+   int64_t ldevecs;
+
+   /* small device buffers */
+   double *d_red;          /* reduction results / projection coefficients */
+   double *d_coef;         /* K x K Ritz coefficient vectors */
+   double *d_theta;        /* K Ritz values */
+   int red_cap;
+   /* pinned host mirrors */
+   double *h_red, *h_coef, *h_theta;
+
+   /* projected problem (host) */
+   double *H, *hVecs, *prevhVecs, *hVals, *prevRitzVals;
+   double *VtBV, *fVtBV;   /* explicit_I only */
+   int ldVtBV;
+   double *blockNorms, *basisNorms;
+   int *flags, *map, *iev, *perm, *lockedFlags;
+   int numPrevRitzVals;
+   int targetShiftIndex;
+
+   int dev_comm;           /* reductions run on the device through RCCL */
+   int phase_timing;       /* primme->profile != NULL: sync after phases to time them */
+   int coef_valid_k;       /* d_coef/d_theta currently hold hVecs/hVals of this size, or -1 */
+   double startTime;
+} pa_solver;
+
+#define PCOL(s, base, ldc, j) ((char *)(base) + (size_t)(j) * (size_t)(ldc) * (s)->es)
+#define VCOL(s, j) PCOL(s, (s)->V, (s)->ld, j)
+#define WCOL(s, j) PCOL(s, (s)->W, (s)->ld, j)
+#define TCOL(s, j) PCOL(s, (s)->T, (s)->ld, j)
+#define ECOL(s, j) PCOL(s, (s)->evecs, (s)->ldevecs, j)
+
+#define CHK(call) do { int rc_ = (call); if (rc_) return rc_ < 0 ? rc_ : PRIMME_UNEXPECTED_FAILURE; } while (0)
+
+double pa_wtime(void);
+
+#endif

@@ -1,0 +1,175 @@
+/* hipk_core.hip — context, HBM/pinned memory, stream-ordered copies, the
+ * deterministic second stage of every reduction, and the bandwidth probe.
+ * See include/primme_amd_kernels.h for the reference routines each entry replaces. */
+#include "hipk_internal.h"
+
+extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      fprintf(stderr, "primme_amd: no HIP device available (this library has no CPU path)\n");
+      return -1;
+   }
+   hipk_ctx *ctx = (hipk_ctx *)calloc(1, sizeof(hipk_ctx));
+   if (!ctx) return -2;
+   HIPK_CHECK(hipGetDevice(&ctx->device));
+   hipDeviceProp_t prop;
+   HIPK_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+   if (stream_or_null) {
+      ctx->stream = *(hipStream_t *)stream_or_null;
+      ctx->own_stream = 0;
+   } else {
+      HIPK_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = 1;
+   }
+   HIPK_CHECK(hipEventCreate(&ctx->ev0));
+   HIPK_CHECK(hipEventCreate(&ctx->ev1));
+   ctx->partials = NULL;
+   ctx->partials_cap = 0;
+   if (hipk_reserve_partials(ctx, (size_t)1 << 20)) return -2;
+   *out = ctx;
+   return 0;
+}
+
+extern "C" int hipk_ctx_destroy(hipk_ctx *ctx) {
+   if (!ctx) return 0;
+   hipStreamSynchronize(ctx->stream);
+   if (ctx->partials) hipFree(ctx->partials);
+   hipEventDestroy(ctx->ev0);
+   hipEventDestroy(ctx->ev1);
+   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+   free(ctx);
+   return 0;
+}
+
+extern "C" void *hipk_ctx_stream(hipk_ctx *ctx) { return (void *)ctx->stream; }
+
+int hipk_reserve_partials(hipk_ctx *ctx, size_t n) {
+   if (n <= ctx->partials_cap) return 0;
+   /* growing while work is in flight: drain first (rare; sizes settle immediately) */
+   HIPK_CHECK(hipStreamSynchronize(ctx->stream));
+   if (ctx->partials) HIPK_CHECK(hipFree(ctx->partials));
+   HIPK_CHECK(hipMalloc((void **)&ctx->partials, n * sizeof(double)));
+   ctx->partials_cap = n;
+   return 0;
+}
+
+extern "C" int hipk_malloc(hipk_ctx *ctx, size_t bytes, void **dptr) {
+   (void)ctx;
+   if (bytes == 0) bytes = 8;
+   hipError_t e = hipMalloc(dptr, bytes);
+   if (e != hipSuccess) { *dptr = NULL; return -2; }
+   return 0;
+}
+extern "C" int hipk_free(hipk_ctx *ctx, void *dptr) {
+   (void)ctx;
+   if (dptr) HIPK_CHECK(hipFree(dptr));
+   return 0;
+}
+extern "C" int hipk_host_alloc(hipk_ctx *ctx, size_t bytes, void **hptr) {
+   (void)ctx;
+   if (bytes == 0) bytes = 8;
+   hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocDefault);
+   if (e != hipSuccess) { *hptr = NULL; return -2; }
+   return 0;
+}
+extern "C" int hipk_host_free(hipk_ctx *ctx, void *hptr) {
+   (void)ctx;
+   if (hptr) HIPK_CHECK(hipHostFree(hptr));
+   return 0;
+}
+extern "C" int hipk_h2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+   if (bytes) HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+   return 0;
+}
+extern "C" int hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+   if (bytes) HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+   return 0;
+}
+extern "C" int hipk_d2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+   if (bytes) HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+   return 0;
+}
+extern "C" int hipk_memset0(hipk_ctx *ctx, void *dst, size_t bytes) {
+   if (bytes) HIPK_CHECK(hipMemsetAsync(dst, 0, bytes, ctx->stream));
+   return 0;
+}
+extern "C" int hipk_sync(hipk_ctx *ctx) {
+   HIPK_CHECK(hipStreamSynchronize(ctx->stream));
+   return 0;
+}
+extern "C" int hipk_is_device_ptr(const void *p) {
+   hipPointerAttribute_t attr;
+   if (!p) return 0;
+   if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+      (void)hipGetLastError(); /* plain host memory: clear the sticky error */
+      return 0;
+   }
+   return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+extern "C" int hipk_timer_start(hipk_ctx *ctx) {
+   HIPK_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+   return 0;
+}
+extern "C" int hipk_timer_stop(hipk_ctx *ctx, float *ms) {
+   HIPK_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+   HIPK_CHECK(hipEventSynchronize(ctx->ev1));
+   HIPK_CHECK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+   return 0;
+}
+
+/* ---- stage 2 of every reduction: one block per output, fixed summation order -- */
+__global__ void __launch_bounds__(HIPK_BLOCK)
+hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
+      double *__restrict__ out) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int o = blockIdx.x;
+   double s = 0.0;
+   for (int b = threadIdx.x; b < nblocks; b += HIPK_BLOCK) s += partials[(size_t)b * nout + o];
+   s = hipk_wave_sum(s);
+   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+   __syncthreads();
+   if (threadIdx.x == 0) out[o] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, int nout,
+      double *out_dev) {
+   if (nout <= 0) return 0;
+   hipLaunchKernelGGL(hipk_finalize_kernel, dim3(nout), dim3(HIPK_BLOCK), 0, ctx->stream,
+         partials, nblocks, nout, out_dev);
+   HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
+/* ---- attainable-HBM probe (device copy, 16 B per lane) ------------------------ */
+__global__ void __launch_bounds__(HIPK_BLOCK)
+hipk_copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n16) {
+   size_t i = (size_t)blockIdx.x * HIPK_BLOCK + threadIdx.x;
+   const size_t stride = (size_t)gridDim.x * HIPK_BLOCK;
+   for (; i + 3 * stride < n16; i += 4 * stride) {
+      double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+      dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+   }
+   for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+extern "C" int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps) {
+   void *a = NULL, *b = NULL;
+   if (hipk_malloc(ctx, bytes, &a) || hipk_malloc(ctx, bytes, &b)) return -2;
+   HIPK_CHECK(hipMemsetAsync(a, 1, bytes, ctx->stream));
+   size_t n16 = bytes / 16;
+   int grid = ctx->num_cu * 8;
+   for (int w = 0; w < 2; w++)
+      hipLaunchKernelGGL(hipk_copy16_kernel, dim3(grid), dim3(HIPK_BLOCK), 0, ctx->stream,
+            (const double2 *)a, (double2 *)b, n16);
+   float ms = 0;
+   hipk_timer_start(ctx);
+   for (int r = 0; r < reps; r++)
+      hipLaunchKernelGGL(hipk_copy16_kernel, dim3(grid), dim3(HIPK_BLOCK), 0, ctx->stream,
+            (const double2 *)a, (double2 *)b, n16);
+   if (hipk_timer_stop(ctx, &ms)) return -1;
+   *gbps = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;
+   hipk_free(ctx, a);
+   hipk_free(ctx, b);
+   return 0;
+}

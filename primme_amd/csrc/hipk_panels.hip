@@ -1,0 +1,583 @@
+/* hipk_panels.hip — tall-skinny panel kernels of the Davidson inner loop (gfx950).
+ *
+ * All of these are HBM-bound streaming kernels: every basis column is read once
+ * per launch with unit-stride wave accesses (64 lanes x 8 B = 512 B per
+ * instruction, NC independent loads in flight per lane), reductions go
+ * lane -> wave (DPP shuffles) -> workgroup (LDS) -> per-block partial, and a tiny
+ * second launch adds the partials in a fixed order so results are bit-reproducible
+ * run to run and identical on every rank.
+ *
+ * What each kernel replaces in the reference is listed in
+ * include/primme_amd_kernels.h.
+ */
+#include "hipk_internal.h"
+
+struct SegArgs {
+   const void *base[HIPK_MAX_SEGS];
+   int64_t ld[HIPK_MAX_SEGS];
+   int n[HIPK_MAX_SEGS];
+   int total;
+};
+
+static int pack_segs(const hipk_seg *segs, int nseg, SegArgs *a) {
+   if (nseg < 0 || nseg > HIPK_MAX_SEGS) return -1;
+   a->total = 0;
+   for (int s = 0; s < HIPK_MAX_SEGS; s++) {
+      if (s < nseg && segs[s].ncols > 0) {
+         a->base[s] = segs[s].base; a->ld[s] = segs[s].ld; a->n[s] = segs[s].ncols;
+      } else {
+         a->base[s] = NULL; a->ld[s] = 0; a->n[s] = 0;
+      }
+      a->total += a->n[s];
+   }
+   return 0;
+}
+
+template <typename T>
+__device__ __forceinline__ const T *seg_col(const SegArgs &s, int j) {
+   int q = 0;
+   if (j >= s.n[0]) { j -= s.n[0]; q = 1; if (j >= s.n[1]) { j -= s.n[1]; q = 2; } }
+   return (const T *)s.base[q] + (size_t)j * (size_t)s.ld[q];
+}
+
+/* finalize with an output leading dimension: out[(o % nrows) + (o / nrows)*ldout] */
+__global__ void __launch_bounds__(HIPK_BLOCK)
+finalize_ld_kernel(const double *__restrict__ partials, int nblocks, int nout, int nrows,
+      int ldout, double *__restrict__ out) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int o = blockIdx.x;
+   double s = 0.0;
+   for (int b = threadIdx.x; b < nblocks; b += HIPK_BLOCK) s += partials[(size_t)b * nout + o];
+   s = hipk_wave_sum(s);
+   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+   __syncthreads();
+   if (threadIdx.x == 0) out[(o % nrows) + (size_t)(o / nrows) * ldout] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+/* ============================ TN: inner products ============================== */
+template <typename T, int NC, int NX>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+dots_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int64_t m,
+      double *__restrict__ partials) {
+   const int j0 = blockIdx.y * NC;             /* first basis column of this chunk */
+   const int c0 = blockIdx.z * NX;             /* first right-hand column          */
+   const int ncv = min(NC, segs.total - j0);
+   const int nxv = min(NX, nx - c0);
+   const T *cp[NC];
+#pragma unroll
+   for (int jj = 0; jj < NC; jj++) cp[jj] = seg_col<T>(segs, jj < ncv ? j0 + jj : j0);
+   const T *xp = X + (size_t)c0 * (size_t)ldX;
+
+   double acc[NC][NX];
+#pragma unroll
+   for (int jj = 0; jj < NC; jj++)
+#pragma unroll
+      for (int c = 0; c < NX; c++) acc[jj][c] = 0.0;
+
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      double xv[NX], a[NC];
+#pragma unroll
+      for (int c = 0; c < NX; c++) xv[c] = (c < nxv) ? (double)xp[i + (size_t)c * ldX] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < NC; jj++) a[jj] = (jj < ncv) ? (double)cp[jj][i] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < NC; jj++)
+#pragma unroll
+         for (int c = 0; c < NX; c++) acc[jj][c] = fma(a[jj], xv[c], acc[jj][c]);
+   }
+
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NC * NX];
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+   for (int jj = 0; jj < NC; jj++)
+#pragma unroll
+      for (int c = 0; c < NX; c++) {
+         double v = hipk_wave_sum(acc[jj][c]);
+         if (lane == 0) sm[wv][jj * NX + c] = v;
+      }
+   __syncthreads();
+   if (threadIdx.x < NC * NX) {
+      const int jj = threadIdx.x / NX, c = threadIdx.x % NX;
+      if (jj < ncv && c < nxv) {
+         double v = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+         partials[(size_t)blockIdx.x * ((size_t)segs.total * nx) + (size_t)(j0 + jj) +
+                  (size_t)(c0 + c) * segs.total] = v;
+      }
+   }
+}
+
+template <typename T>
+static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X, int64_t ldX,
+      int nx, double *out_dev, int ldout) {
+   const int NC = 8;
+   int nxt = nx <= 1 ? 1 : nx <= 2 ? 2 : nx <= 4 ? 4 : 8;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   int gy = (sa.total + NC - 1) / NC;
+   int gz = (nx + nxt - 1) / nxt;
+   /* keep the chip full when the chunk grid is already wide */
+   while (gx > 1 && (int64_t)gx * gy * gz > (int64_t)ctx->num_cu * 8) gx = (gx + 1) / 2;
+   size_t nout = (size_t)sa.total * nx;
+   if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
+   dim3 grid(gx, gy, gz), block(HIPK_BLOCK);
+   switch (nxt) {
+   case 1: hipLaunchKernelGGL((dots_kernel<T, 8, 1>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
+   case 2: hipLaunchKernelGGL((dots_kernel<T, 8, 2>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
+   case 4: hipLaunchKernelGGL((dots_kernel<T, 8, 4>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
+   default: hipLaunchKernelGGL((dots_kernel<T, 8, 8>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
+   }
+   HIPK_CHECK(hipGetLastError());
+   hipLaunchKernelGGL(finalize_ld_kernel, dim3((unsigned)nout), dim3(HIPK_BLOCK), 0, ctx->stream,
+         ctx->partials, gx, (int)nout, sa.total, ldout, out_dev);
+   HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
+extern "C" int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs,
+      int nseg, const void *X, int64_t ldX, int nx, double *out_dev, int ldout) {
+   SegArgs sa;
+   if (pack_segs(segs, nseg, &sa)) return -1;
+   if (sa.total == 0 || nx <= 0) return 0;
+   if (ldout < sa.total) return -1;
+   switch (dt) {
+   case HIPK_F64: return panel_dots_t<double>(ctx, m, sa, (const double *)X, ldX, nx, out_dev, ldout);
+   case HIPK_F32: return panel_dots_t<float>(ctx, m, sa, (const float *)X, ldX, nx, out_dev, ldout);
+   default: return -44;
+   }
+}
+
+/* ===================== NN-accumulate: project + norms ========================= */
+#define PROJ_MAXCOLS 192
+template <typename T, int NX>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__restrict__ X,
+      int64_t ldX, int nx, int c0, int64_t m, double *__restrict__ partials) {
+   __shared__ double scoef[PROJ_MAXCOLS * NX];
+   __shared__ const T *sptr[PROJ_MAXCOLS];
+   const int total = segs.total;
+   const int nxv = min(NX, nx - c0);
+   for (int t = threadIdx.x; t < total * NX; t += HIPK_BLOCK) {
+      int j = t / NX, c = t % NX;
+      scoef[t] = (c < nxv) ? coef[j + (size_t)(c0 + c) * ldcoef] : 0.0;
+   }
+   for (int j = threadIdx.x; j < total; j += HIPK_BLOCK) sptr[j] = seg_col<T>(segs, j);
+   __syncthreads();
+
+   T *xp = X + (size_t)c0 * (size_t)ldX;
+   double n2[NX];
+#pragma unroll
+   for (int c = 0; c < NX; c++) n2[c] = 0.0;
+
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      double xv[NX];
+#pragma unroll
+      for (int c = 0; c < NX; c++) xv[c] = (c < nxv) ? (double)xp[i + (size_t)c * ldX] : 0.0;
+      int j = 0;
+      for (; j + 8 <= total; j += 8) {
+         double a[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) a[u] = (double)sptr[j + u][i];
+#pragma unroll
+         for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int c = 0; c < NX; c++) xv[c] = fma(-a[u], scoef[(j + u) * NX + c], xv[c]);
+      }
+      for (; j < total; j++) {
+         double a = (double)sptr[j][i];
+#pragma unroll
+         for (int c = 0; c < NX; c++) xv[c] = fma(-a, scoef[j * NX + c], xv[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < NX; c++)
+         if (c < nxv) {
+            T out = (T)xv[c];
+            xp[i + (size_t)c * ldX] = out;
+            n2[c] = fma((double)out, (double)out, n2[c]);
+         }
+   }
+   if (partials) {
+      __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NX];
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+      for (int c = 0; c < NX; c++) {
+         double v = hipk_wave_sum(n2[c]);
+         if (lane == 0) sm[wv][c] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < nxv)
+         partials[(size_t)blockIdx.x * nx + c0 + threadIdx.x] =
+               (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+   }
+}
+
+template <typename T>
+static int panel_project_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const double *coef,
+      int ldcoef, T *X, int64_t ldX, int nx, double *nrm2_dev) {
+   if (sa.total > PROJ_MAXCOLS) return -1;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (nrm2_dev && hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   double *part = nrm2_dev ? ctx->partials : NULL;
+   dim3 block(HIPK_BLOCK);
+   for (int c0 = 0; c0 < nx;) {
+      int rem = nx - c0;
+      int step;
+      if (rem >= 8) { step = 8; hipLaunchKernelGGL((project_kernel<T, 8>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      else if (rem >= 4) { step = 4; hipLaunchKernelGGL((project_kernel<T, 4>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      else if (rem >= 2) { step = 2; hipLaunchKernelGGL((project_kernel<T, 2>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      else { step = 1; hipLaunchKernelGGL((project_kernel<T, 1>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      HIPK_CHECK(hipGetLastError());
+      c0 += step;
+   }
+   if (nrm2_dev) return hipk_finalize_partials(ctx, ctx->partials, gx, nx, nrm2_dev);
+   return 0;
+}
+
+extern "C" int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs,
+      int nseg, const double *coef_dev, int ldcoef, void *X, int64_t ldX, int nx,
+      double *nrm2_dev) {
+   SegArgs sa;
+   if (pack_segs(segs, nseg, &sa)) return -1;
+   if (nx <= 0) return 0;
+   switch (dt) {
+   case HIPK_F64: return panel_project_t<double>(ctx, m, sa, coef_dev, ldcoef, (double *)X, ldX, nx, nrm2_dev);
+   case HIPK_F32: return panel_project_t<float>(ctx, m, sa, coef_dev, ldcoef, (float *)X, ldX, nx, nrm2_dev);
+   default: return -44;
+   }
+}
+
+/* ================= fused Ritz / residual / restart update ===================== */
+#define RITZ_MAXOUT 80   /* per list (XV, XW) */
+#define RITZ_MAXRES 16
+struct RitzArgs {
+   int nxv, nxw, nres;
+   unsigned char xv_col[RITZ_MAXOUT], xw_col[RITZ_MAXOUT], res_col[RITZ_MAXRES];
+   short res_slot[RITZ_MAXRES];
+   void *xv_dst[RITZ_MAXOUT], *xw_dst[RITZ_MAXOUT], *res_dst[RITZ_MAXRES];
+};
+
+template <typename T, int NK, int NR>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
+      const double *__restrict__ h, int ldh, int nh, const double *__restrict__ theta,
+      RitzArgs ja, int64_t m, double *__restrict__ partials, int nslots) {
+   extern __shared__ double hs[];   /* hs[c*NK + j], zero padded rows j >= k */
+   for (int t = threadIdx.x; t < NK * nh; t += HIPK_BLOCK) {
+      int c = t / NK, j = t % NK;
+      hs[t] = (j < k) ? h[j + (size_t)c * ldh] : 0.0;
+   }
+   __syncthreads();
+   double th[NR];
+#pragma unroll
+   for (int r = 0; r < NR; r++) th[r] = (r < ja.nres) ? theta[ja.res_col[r]] : 0.0;
+   double n2[NR];
+#pragma unroll
+   for (int r = 0; r < NR; r++) n2[r] = 0.0;
+
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      double row[NK];
+      double xres[NR];
+      /* phase A: the V row */
+#pragma unroll
+      for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)V[i + (size_t)j * ld] : 0.0;
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+         xres[r] = 0.0;
+         if (r < ja.nres) {
+            const double *hc = hs + (int)ja.res_col[r] * NK;
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < NK; j++) s = fma(row[j], hc[j], s);
+            xres[r] = s;
+         }
+      }
+      for (int o = 0; o < ja.nxv; o++) {
+         const double *hc = hs + (int)ja.xv_col[o] * NK;
+         double s = 0.0;
+#pragma unroll
+         for (int j = 0; j < NK; j++) s = fma(row[j], hc[j], s);
+         ((T *)ja.xv_dst[o])[i] = (T)s;
+      }
+      /* phase B: the W row (only if something needs it) */
+      if (ja.nxw > 0 || ja.nres > 0) {
+#pragma unroll
+         for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+         for (int o = 0; o < ja.nxw; o++) {
+            const double *hc = hs + (int)ja.xw_col[o] * NK;
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < NK; j++) s = fma(row[j], hc[j], s);
+            ((T *)ja.xw_dst[o])[i] = (T)s;
+         }
+#pragma unroll
+         for (int r = 0; r < NR; r++)
+            if (r < ja.nres) {
+               const double *hc = hs + (int)ja.res_col[r] * NK;
+               double s = 0.0;
+#pragma unroll
+               for (int j = 0; j < NK; j++) s = fma(row[j], hc[j], s);
+               T res = (T)fma(-th[r], xres[r], s);
+               if (ja.res_dst[r]) ((T *)ja.res_dst[r])[i] = res;
+               n2[r] = fma((double)res, (double)res, n2[r]);
+            }
+      }
+   }
+   if (nslots > 0) {
+      __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NR];
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+         double v = hipk_wave_sum(n2[r]);
+         if (lane == 0) sm[wv][r] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < ja.nres && ja.res_slot[threadIdx.x] >= 0)
+         partials[(size_t)blockIdx.x * nslots + ja.res_slot[threadIdx.x]] =
+               (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+   }
+}
+
+template <typename T, int NK>
+static int ritz_launch_nk(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
+      const double *h, int ldh, int nh, const double *theta, const RitzArgs &ja, int gx,
+      int nslots) {
+   size_t shm = (size_t)NK * nh * sizeof(double);
+   if (ja.nres <= 4)
+      hipLaunchKernelGGL((ritz_kernel<T, NK, 4>), dim3(gx), dim3(HIPK_BLOCK), shm, ctx->stream, V, W, ld, k, h, ldh, nh, theta, ja, m, ctx->partials, nslots);
+   else
+      hipLaunchKernelGGL((ritz_kernel<T, NK, RITZ_MAXRES>), dim3(gx), dim3(HIPK_BLOCK), shm, ctx->stream, V, W, ld, k, h, ldh, nh, theta, ja, m, ctx->partials, nslots);
+   HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
+template <typename T>
+static int ritz_update_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
+      const double *h, int ldh, const double *theta, const hipk_job *jobs, int njobs,
+      double *nrm2_dev) {
+   RitzArgs ja;
+   memset(&ja, 0, sizeof(ja));
+   int nh = 0, nslots = 0;
+   for (int q = 0; q < njobs; q++) {
+      const hipk_job &jb = jobs[q];
+      if (jb.col < 0 || jb.col > 255) return -1;
+      if (jb.col + 1 > nh) nh = jb.col + 1;
+      if (jb.kind == HIPK_JOB_XV) {
+         if (ja.nxv >= RITZ_MAXOUT) return -1;
+         ja.xv_col[ja.nxv] = (unsigned char)jb.col; ja.xv_dst[ja.nxv++] = jb.dst;
+      } else if (jb.kind == HIPK_JOB_XW) {
+         if (ja.nxw >= RITZ_MAXOUT) return -1;
+         ja.xw_col[ja.nxw] = (unsigned char)jb.col; ja.xw_dst[ja.nxw++] = jb.dst;
+      } else if (jb.kind == HIPK_JOB_RES) {
+         if (ja.nres >= RITZ_MAXRES) return -1;
+         ja.res_col[ja.nres] = (unsigned char)jb.col; ja.res_dst[ja.nres] = jb.dst;
+         ja.res_slot[ja.nres++] = (short)jb.slot;
+         if (jb.slot + 1 > nslots) nslots = jb.slot + 1;
+      } else return -1;
+   }
+   if (k <= 0 || njobs <= 0) return 0;
+   if (nslots > 0 && !nrm2_dev) return -1;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4);
+   if (nslots > 0) {
+      /* every block writes every slot; slots must be 0..nslots-1, each used once */
+      if (hipk_reserve_partials(ctx, (size_t)gx * nslots)) return -2;
+   }
+   int rc;
+   if (k <= 8) rc = ritz_launch_nk<T, 8>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   else if (k <= 16) rc = ritz_launch_nk<T, 16>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   else if (k <= 24) rc = ritz_launch_nk<T, 24>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   else if (k <= 32) rc = ritz_launch_nk<T, 32>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   else if (k <= 48) rc = ritz_launch_nk<T, 48>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   else if (k <= 64) rc = ritz_launch_nk<T, 64>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   else return -1;
+   if (rc) return rc;
+   if (nslots > 0) return hipk_finalize_partials(ctx, ctx->partials, gx, nslots, nrm2_dev);
+   return 0;
+}
+
+extern "C" int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
+      const void *W, int64_t ldVW, int k, const double *h_dev, int ldh,
+      const double *theta_dev, const hipk_job *jobs, int njobs, double *nrm2_dev) {
+   switch (dt) {
+   case HIPK_F64: return ritz_update_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev);
+   case HIPK_F32: return ritz_update_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev);
+   default: return -44;
+   }
+}
+
+/* ============================ column utilities ================================ */
+#define UTIL_MAXCOLS 64
+struct ColScal { double a[UTIL_MAXCOLS]; };
+struct ColPerm { int p[UTIL_MAXCOLS]; };
+
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+scale_kernel(T *__restrict__ X, int64_t ldX, int nx, ColScal sc, int64_t m) {
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      T *x = X + (size_t)c * ldX;
+      const double a = sc.a[c];
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride)
+         x[i] = (T)(a * (double)x[i]);
+   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+axpy_kernel(ColScal sc, const T *__restrict__ X, int64_t ldX, T *__restrict__ Y, int64_t ldY,
+      int nx, int64_t m) {
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *x = X + (size_t)c * ldX;
+      T *y = Y + (size_t)c * ldY;
+      const double a = sc.a[c];
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride)
+         y[i] = (T)fma(a, (double)x[i], (double)y[i]);
+   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+gather_kernel(const T *__restrict__ X, int64_t ldX, ColPerm pm, int n, T *__restrict__ Y,
+      int64_t ldY, int64_t m) {
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < n; c++) {
+      const T *x = X + (size_t)pm.p[c] * ldX;
+      T *y = Y + (size_t)c * ldY;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride)
+         y[i] = x[i];
+   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+norms2_kernel(const T *__restrict__ X, int64_t ldX, int nx, int64_t m,
+      double *__restrict__ partials) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *x = X + (size_t)c * ldX;
+      double s = 0.0;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+         double v = (double)x[i];
+         s = fma(v, v, s);
+      }
+      s = hipk_wave_sum(s);
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * nx + c] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      __syncthreads();
+   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+residual_kernel(const T *__restrict__ X, int64_t ldX, T *__restrict__ Wr, int64_t ldW, int nx,
+      ColScal th, int64_t m, double *__restrict__ partials) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *x = X + (size_t)c * ldX;
+      T *w = Wr + (size_t)c * ldW;
+      const double t = th.a[c];
+      double s = 0.0;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+         T r = (T)fma(-t, (double)x[i], (double)w[i]);
+         w[i] = r;
+         s = fma((double)r, (double)r, s);
+      }
+      s = hipk_wave_sum(s);
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * nx + c] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      __syncthreads();
+   }
+}
+
+#define DISPATCH_RT(dt, CALL_D, CALL_F)         \
+   switch (dt) {                                \
+   case HIPK_F64: { typedef double T; CALL_D; } break; \
+   case HIPK_F32: { typedef float T; CALL_F; } break;  \
+   default: return -44;                         \
+   }
+
+extern "C" int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX,
+      int nx, const double *alpha_host) {
+   for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
+      int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
+      ColScal sc;
+      for (int c = 0; c < n; c++) sc.a[c] = alpha_host[c0 + c];
+      int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
+      DISPATCH_RT(dt,
+            hipLaunchKernelGGL(scale_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (T *)X + (size_t)c0 * ldX, ldX, n, sc, m),
+            hipLaunchKernelGGL(scale_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (T *)X + (size_t)c0 * ldX, ldX, n, sc, m));
+      HIPK_CHECK(hipGetLastError());
+   }
+   return 0;
+}
+
+extern "C" int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
+      const void *X, int64_t ldX, void *Y, int64_t ldY, int nx) {
+   for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
+      int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
+      ColScal sc;
+      for (int c = 0; c < n; c++) sc.a[c] = alpha_host[c0 + c];
+      int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
+      DISPATCH_RT(dt,
+            hipLaunchKernelGGL(axpy_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sc, (const T *)X + (size_t)c0 * ldX, ldX, (T *)Y + (size_t)c0 * ldY, ldY, n, m),
+            hipLaunchKernelGGL(axpy_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sc, (const T *)X + (size_t)c0 * ldX, ldX, (T *)Y + (size_t)c0 * ldY, ldY, n, m));
+      HIPK_CHECK(hipGetLastError());
+   }
+   return 0;
+}
+
+extern "C" int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
+      int64_t ldX, void *Y, int64_t ldY, int nx) {
+   size_t es = (dt == HIPK_F64) ? 8 : (dt == HIPK_F32) ? 4 : (dt == HIPK_C64) ? 16 : 8;
+   if (nx <= 0 || m <= 0) return 0;
+   HIPK_CHECK(hipMemcpy2DAsync(Y, (size_t)ldY * es, X, (size_t)ldX * es, (size_t)m * es, (size_t)nx,
+         hipMemcpyDeviceToDevice, ctx->stream));
+   return 0;
+}
+
+extern "C" int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
+      int64_t ldX, const int *perm_host, int n, void *Y, int64_t ldY) {
+   for (int c0 = 0; c0 < n; c0 += UTIL_MAXCOLS) {
+      int nn = n - c0 < UTIL_MAXCOLS ? n - c0 : UTIL_MAXCOLS;
+      ColPerm pm;
+      for (int c = 0; c < nn; c++) pm.p[c] = perm_host[c0 + c];
+      int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
+      DISPATCH_RT(dt,
+            hipLaunchKernelGGL(gather_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, pm, nn, (T *)Y + (size_t)c0 * ldY, ldY, m),
+            hipLaunchKernelGGL(gather_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, pm, nn, (T *)Y + (size_t)c0 * ldY, ldY, m));
+      HIPK_CHECK(hipGetLastError());
+   }
+   return 0;
+}
+
+extern "C" int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
+      int64_t ldX, int nx, double *out_dev) {
+   if (nx <= 0) return 0;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(norms2_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, nx, m, ctx->partials),
+         hipLaunchKernelGGL(norms2_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, nx, m, ctx->partials));
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, out_dev);
+}
+
+extern "C" int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
+      int64_t ldX, void *Wr, int64_t ldW, int nx, const double *theta_host, double *nrm2_dev) {
+   if (nx <= 0) return 0;
+   if (nx > UTIL_MAXCOLS) return -1;
+   ColScal th;
+   for (int c = 0; c < nx; c++) th.a[c] = theta_host[c];
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(residual_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (T *)Wr, ldW, nx, th, m, ctx->partials),
+         hipLaunchKernelGGL(residual_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (T *)Wr, ldW, nx, th, m, ctx->partials));
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, nrm2_dev);
+}

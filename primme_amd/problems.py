@@ -1,0 +1,130 @@
+"""Deterministic synthetic inputs of the benchmark configurations.
+
+Everything is generated from integers and closed-form expressions, so the same
+bytes are produced in this container and on the GPU box.
+"""
+import numpy as np
+
+
+def laplacian_csr(dims, row0=0, nrows=None, dtype=np.float64):
+    """CSR (int32 indices, global column numbers) of the 1/2/3-D Dirichlet Laplacian
+    (diag 2*d, off-diagonals -1) on a grid dims = (nx,), (nx, ny) or (nx, ny, nz), x fastest.
+    Returns rows [row0, row0+nrows)."""
+    dims = tuple(int(d) for d in dims)
+    nx = dims[0]
+    ny = dims[1] if len(dims) > 1 else 1
+    nz = dims[2] if len(dims) > 2 else 1
+    n = nx * ny * nz
+    if nrows is None:
+        nrows = n - row0
+    g = np.arange(row0, row0 + nrows, dtype=np.int64)
+    ix = g % nx
+    iy = (g // nx) % ny
+    iz = g // (nx * ny)
+    d = len([x for x in (nx, ny, nz) if x > 1]) if n > 1 else 1
+    if len(dims) == 1:
+        d = 1
+    cols = []
+    vals = []
+    # ascending column order inside each row: -plane, -nx, -1, diag, +1, +nx, +plane
+    cand = []
+    if nz > 1:
+        cand.append((g - nx * ny, iz > 0))
+    if ny > 1:
+        cand.append((g - nx, iy > 0))
+    cand.append((g - 1, ix > 0))
+    cand.append((g, np.ones_like(g, dtype=bool)))
+    cand.append((g + 1, ix < nx - 1))
+    if ny > 1:
+        cand.append((g + nx, iy < ny - 1))
+    if nz > 1:
+        cand.append((g + nx * ny, iz < nz - 1))
+    mask = np.stack([c[1] for c in cand], axis=1)
+    col = np.stack([c[0] for c in cand], axis=1)
+    diag_pos = [i for i, c in enumerate(cand) if c[0] is g][0]
+    val = -np.ones(col.shape, dtype=dtype)
+    val[:, diag_pos] = 2.0 * d
+    counts = mask.sum(axis=1)
+    rowptr = np.zeros(nrows + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    cols = col[mask].astype(np.int32)
+    vals = val[mask].astype(dtype)
+    assert rowptr[-1] < 2**31
+    return rowptr.astype(np.int32), cols, vals, n
+
+
+def laplacian_eigenvalues(dims, k):
+    """k smallest analytic eigenvalues: sum_d 2 - 2cos(i_d pi/(n_d+1))."""
+    axes = [2.0 - 2.0 * np.cos(np.arange(1, d + 1) * np.pi / (d + 1)) for d in dims if d >= 1]
+    # only the low end of each axis can contribute to the k smallest sums
+    axes = [a[: min(len(a), k + 2)] for a in axes]
+    tot = axes[0]
+    for a in axes[1:]:
+        tot = np.add.outer(tot, a).ravel()
+    return np.sort(tot)[:k]
+
+
+def start_vector(n, row0=0, nrows=None, j=0, dtype=np.float64):
+    """Deterministic initial guess v_i = sin(1 + i*0.6180339887 + j) (removes RNG dependence)."""
+    if nrows is None:
+        nrows = n - row0
+    i = np.arange(row0, row0 + nrows, dtype=np.float64)
+    return np.sin(1.0 + i * 0.6180339887498949 + 0.37 * j).astype(dtype)
+
+
+def read_matrix_market(path):
+    """Minimal Matrix-Market coordinate reader (real / symmetric / general), returns scipy-free
+    CSR (rowptr int32, colind int32, values float64, nrows, ncols).  Restates what the
+    reference's test driver does with tests/COMMON/mmio.c + csr.c:46-265 (COO -> CSR,
+    symmetric expansion)."""
+    with open(path) as f:
+        header = f.readline().lower().split()
+        symmetric = "symmetric" in header
+        pattern = "pattern" in header
+        line = f.readline()
+        while line.startswith("%"):
+            line = f.readline()
+        nr, nc, nnz = (int(t) for t in line.split())
+        data = np.loadtxt(f, ndmin=2)
+    r = data[:, 0].astype(np.int64) - 1
+    c = data[:, 1].astype(np.int64) - 1
+    v = np.ones(len(r)) if pattern else data[:, 2].astype(np.float64)
+    if symmetric:
+        off = r != c
+        r, c, v = np.concatenate([r, c[off]]), np.concatenate([c, r[off]]), np.concatenate([v, v[off]])
+    order = np.lexsort((c, r))
+    r, c, v = r[order], c[order], v[order]
+    rowptr = np.zeros(nr + 1, dtype=np.int64)
+    np.add.at(rowptr, r + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return rowptr.astype(np.int32), c.astype(np.int32), v, nr, nc
+
+
+def tile_block_diagonal(rowptr, colind, values, ntiles, scale_fn=None, row0_tile=0):
+    """Block-diagonal tiling of a square CSR matrix: tile t (global index row0_tile + t) is
+    the matrix scaled by scale_fn(t) so that the spectrum stays simple."""
+    n0 = len(rowptr) - 1
+    nnz0 = len(values)
+    rp = np.zeros(n0 * ntiles + 1, dtype=np.int64)
+    ci = np.empty(nnz0 * ntiles, dtype=np.int64)
+    va = np.empty(nnz0 * ntiles, dtype=values.dtype)
+    base = rowptr.astype(np.int64)
+    for t in range(ntiles):
+        gt = row0_tile + t
+        s = 1.0 if scale_fn is None else scale_fn(gt)
+        rp[t * n0 + 1:(t + 1) * n0 + 1] = base[1:] + t * nnz0
+        ci[t * nnz0:(t + 1) * nnz0] = colind.astype(np.int64) + gt * n0
+        va[t * nnz0:(t + 1) * nnz0] = values * s
+    assert ci.max() < 2**31 and rp[-1] < 2**31
+    return rp.astype(np.int32), ci.astype(np.int32), va
+
+
+def csr_matvec_numpy(rowptr, colind, values, x):
+    """y = A x for a CSR matrix with numpy (reference tests/COMMON/mat.c:64-90 amux)."""
+    x = np.asarray(x)
+    prod = values[:, None] * x[colind].reshape(len(colind), -1)
+    y = np.add.reduceat(prod, rowptr[:-1].astype(np.int64), axis=0)
+    empty = rowptr[1:] == rowptr[:-1]
+    if empty.any():
+        y[empty] = 0
+    return y.reshape((len(rowptr) - 1,) + x.shape[1:])
