@@ -187,7 +187,13 @@ def load_product():
             raise RuntimeError(
                 f"{PRODUCT_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). primme_amd has no CPU implementation.")
-        lib = C.CDLL(PRODUCT_LIB, mode=C.RTLD_GLOBAL)
+        # torch wheels ship their own libamdhip64 / librccl: load torch first so that this
+        # process ends up with ONE HIP runtime (same SONAME -> the loader reuses torch's copy)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        lib = C.CDLL(PRODUCT_LIB)
         _declare_solver(lib, "hip_")
         _declare_kernels(lib)
         _cache["product"] = lib

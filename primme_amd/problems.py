@@ -122,9 +122,10 @@ def tile_block_diagonal(rowptr, colind, values, ntiles, scale_fn=None, row0_tile
 def csr_matvec_numpy(rowptr, colind, values, x):
     """y = A x for a CSR matrix with numpy (reference tests/COMMON/mat.c:64-90 amux)."""
     x = np.asarray(x)
-    prod = values[:, None] * x[colind].reshape(len(colind), -1)
-    y = np.add.reduceat(prod, rowptr[:-1].astype(np.int64), axis=0)
-    empty = rowptr[1:] == rowptr[:-1]
-    if empty.any():
-        y[empty] = 0
+    nrows = len(rowptr) - 1
+    xr = x.reshape(x.shape[0], -1)
+    rows = np.repeat(np.arange(nrows), np.diff(rowptr.astype(np.int64)))
+    y = np.zeros((nrows, xr.shape[1]), dtype=np.result_type(values, xr))
+    for c in range(xr.shape[1]):
+        y[:, c] = np.bincount(rows, weights=values * xr[colind, c], minlength=nrows)
     return y.reshape((len(rowptr) - 1,) + x.shape[1:])

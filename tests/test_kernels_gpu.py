@@ -1,0 +1,236 @@
+"""Kernel-level parity: every HIP entry point of include/primme_amd_kernels.h against the
+plain-C restatement oracle/hipk_cpu.c on the same seeded inputs (-m gpu).
+
+Tolerances: reductions differ from the oracle only by summation order, so they are
+compared at 1e-12 relative to sum|terms| (double) / 1e-5 (float); element-wise outputs
+of the update kernels at a few ulps."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from primme_amd import _ffi as F
+from primme_amd import problems
+from kernel_harness import Dev, Host, segs_array, NPDT
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1000, 5, 3), (70001, 15, 10), (300007, 41, 20)]
+
+
+def _panels(rng, m, k, L, dt, ld_pad=3):
+    npdt = NPDT[dt]
+    ld = m + ld_pad
+    V = rng.standard_normal((k + 8, ld)).astype(npdt)   # row j = column j (ld apart)
+    Q = rng.standard_normal((max(L, 1), ld + 5)).astype(npdt)
+    return V, ld, Q, ld + 5
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("m,k,L", SHAPES)
+@pytest.mark.parametrize("nx", [1, 2, 3, 8, 11])
+def test_panel_dots(built, dt, m, k, L, nx):
+    rng = np.random.default_rng(m + k + nx)
+    V, ld, Q, ldq = _panels(rng, m, k, L, dt)
+    X = rng.standard_normal((nx, ld)).astype(NPDT[dt])
+    outs = []
+    for side in (Dev(), Host()):
+        v, q, x = side.arr(V), side.arr(Q), side.arr(X)
+        out = side.arr(np.zeros((nx, k + L + 2)))
+        segs = segs_array(side, [(v, 0, ld, k), (q, 0, ldq, L), (x, 0, ld, 1)])
+        rc = side.lib.hipk_panel_dots(side.ctx, dt, m, segs, 3, side.ptr(x), ld, nx, side.ptr(out), k + L + 2)
+        assert rc == 0
+        outs.append(side.get(out)[:, :k + L + 1])
+        side.close()
+    scale = np.sqrt(m) * 4
+    tol = (1e-12 if dt == F.HIPK_F64 else 2e-5) * scale
+    assert np.max(np.abs(outs[0] - outs[1])) <= tol * max(1.0, np.abs(outs[1]).max() / scale)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("m,k,L", SHAPES)
+@pytest.mark.parametrize("nx", [1, 2, 5, 8, 9])
+def test_panel_project(built, dt, m, k, L, nx):
+    rng = np.random.default_rng(7 * m + k + nx)
+    V, ld, Q, ldq = _panels(rng, m, k, L, dt)
+    X = rng.standard_normal((nx, ld)).astype(NPDT[dt])
+    coef = rng.standard_normal((nx, k + L + 3)) / (k + L)
+    res = []
+    for side in (Dev(), Host()):
+        v, q, x, cf = side.arr(V), side.arr(Q), side.arr(X), side.arr(coef)
+        n2 = side.arr(np.zeros(nx))
+        segs = segs_array(side, [(v, 0, ld, k), (q, 0, ldq, L)])
+        rc = side.lib.hipk_panel_project(side.ctx, dt, m, segs, 2, side.ptr(cf), k + L + 3, side.ptr(x), ld, nx, side.ptr(n2))
+        assert rc == 0
+        res.append((side.get(x)[:, :m], side.get(n2)))
+        side.close()
+    tol = 1e-13 if dt == F.HIPK_F64 else 1e-5
+    assert np.max(np.abs(res[0][0] - res[1][0])) <= tol * 10
+    assert np.allclose(res[0][1], res[1][1], rtol=tol * 100)
+    # rows beyond m (padding of the leading dimension) must be untouched
+    # (checked implicitly: only [:m] is written by the oracle as well)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("m,k", [(999, 3), (50003, 15), (200001, 33), (40000, 41)])
+def test_ritz_update_inplace_restart(built, dt, m, k):
+    """The restart shape: V,W <- V h, W h in place + next block X,R + locked copies + norms."""
+    rng = np.random.default_rng(m + k)
+    npdt = NPDT[dt]
+    ld = m + 1
+    K = k + 6
+    V = rng.standard_normal((K, ld)).astype(npdt)
+    W = rng.standard_normal((K, ld)).astype(npdt)
+    E = np.zeros((4, ld), dtype=npdt)
+    h = np.linalg.qr(rng.standard_normal((k, k)))[0]
+    hfull = np.zeros((k, K + 2))
+    hfull[:, :k] = h.T            # row c = coefficient column c (leading dim K+2)
+    theta = rng.standard_normal(k)
+    rs = max(1, k // 2)
+    nb = min(2, k - rs) if k > rs else 0
+    nlock = min(3, k - rs)
+    jobs = []
+    for c in range(rs): jobs.append((F.HIPK_JOB_XV, c, ("V", c), -1))
+    for c in range(nb): jobs.append((F.HIPK_JOB_XV, c, ("V", rs + nlock + c), -1))
+    for c in range(nlock): jobs.append((F.HIPK_JOB_XV, rs + c, ("E", c), -1))
+    for c in range(rs): jobs.append((F.HIPK_JOB_XW, c, ("W", c), -1))
+    for c in range(nb): jobs.append((F.HIPK_JOB_RES, c, ("W", rs + nlock + c), c))
+    for c in range(nlock): jobs.append((F.HIPK_JOB_RES, rs + c, None, nb + c))
+    res = []
+    for side in (Dev(), Host()):
+        v, w, e, hh, th = side.arr(V), side.arr(W), side.arr(E), side.arr(hfull), side.arr(theta)
+        n2 = side.arr(np.zeros(nb + nlock + 1))
+        base = {"V": v, "W": w, "E": e}
+        arr = (F.HipkJob * len(jobs))()
+        for i, (kind, col, dst, slot) in enumerate(jobs):
+            arr[i].kind, arr[i].col, arr[i].slot = kind, col, slot
+            arr[i].dst = None if dst is None else side.ptr(base[dst[0]], dst[1] * ld).value
+        rc = side.lib.hipk_ritz_update(side.ctx, dt, m, side.ptr(v), side.ptr(w), ld, k, side.ptr(hh), K + 2,
+                                       side.ptr(th), arr, len(jobs), side.ptr(n2))
+        assert rc == 0
+        res.append((side.get(v), side.get(w), side.get(e), side.get(n2)))
+        side.close()
+    tol = 1e-12 if dt == F.HIPK_F64 else 1e-4
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert np.max(np.abs(a - b)) <= tol * 10
+    assert np.allclose(res[0][3][:nb + nlock], res[1][3][:nb + nlock], rtol=tol * 100)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+def test_ritz_update_many_residuals(built, dt):
+    """more than 4 residual columns exercises the 16-accumulator kernel variant"""
+    rng = np.random.default_rng(3)
+    npdt = NPDT[dt]
+    m, k, ld = 30011, 20, 30016
+    V = rng.standard_normal((k + 12, ld)).astype(npdt)
+    W = rng.standard_normal((k + 12, ld)).astype(npdt)
+    h = rng.standard_normal((k, k))
+    theta = rng.standard_normal(k)
+    jobs = [(F.HIPK_JOB_RES, c, ("W", k + c) if c < 8 else None, c) for c in range(12)]
+    res = []
+    for side in (Dev(), Host()):
+        v, w, hh, th = side.arr(V), side.arr(W), side.arr(h), side.arr(theta)
+        n2 = side.arr(np.zeros(12))
+        arr = (F.HipkJob * len(jobs))()
+        for i, (kind, col, dst, slot) in enumerate(jobs):
+            arr[i].kind, arr[i].col, arr[i].slot = kind, col, slot
+            arr[i].dst = None if dst is None else side.ptr(w, dst[1] * ld).value
+        rc = side.lib.hipk_ritz_update(side.ctx, dt, m, side.ptr(v), side.ptr(w), ld, k, side.ptr(hh), k,
+                                       side.ptr(th), arr, len(jobs), side.ptr(n2))
+        assert rc == 0
+        res.append((side.get(w), side.get(n2)))
+        side.close()
+    tol = 1e-12 if dt == F.HIPK_F64 else 1e-4
+    assert np.max(np.abs(res[0][0] - res[1][0])) <= tol * 20
+    assert np.allclose(res[0][1], res[1][1], rtol=tol * 100)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+def test_column_utilities(built, dt):
+    rng = np.random.default_rng(11)
+    npdt = NPDT[dt]
+    m, ld, nx = 123457, 123460, 5
+    X = rng.standard_normal((nx, ld)).astype(npdt)
+    Y = rng.standard_normal((nx, ld)).astype(npdt)
+    alpha = rng.standard_normal(nx)
+    perm = np.array([3, 0, 4, 1, 2], dtype=np.int32)
+    res = []
+    for side in (Dev(), Host()):
+        x, y = side.arr(X), side.arr(Y)
+        z = side.arr(np.zeros_like(X))
+        n2 = side.arr(np.zeros(nx)); r2 = side.arr(np.zeros(nx))
+        a = (C.c_double * nx)(*alpha)
+        L = side.lib
+        assert L.hipk_axpy_cols(side.ctx, dt, m, a, side.ptr(x), ld, side.ptr(y), ld, nx) == 0
+        assert L.hipk_scale_cols(side.ctx, dt, m, side.ptr(x), ld, nx, a) == 0
+        assert L.hipk_gather_cols(side.ctx, dt, m, side.ptr(y), ld, perm.ctypes.data_as(C.POINTER(C.c_int)), nx, side.ptr(z), ld) == 0
+        assert L.hipk_col_norms2(side.ctx, dt, m, side.ptr(z), ld, nx, side.ptr(n2)) == 0
+        assert L.hipk_residual_cols(side.ctx, dt, m, side.ptr(x), ld, side.ptr(z), ld, nx, a, side.ptr(r2)) == 0
+        assert L.hipk_copy_cols(side.ctx, dt, m, side.ptr(z), ld, side.ptr(y), ld, 2) == 0
+        res.append([side.get(t) for t in (x, y, z, n2, r2)])
+        side.close()
+    tol = 1e-13 if dt == F.HIPK_F64 else 1e-5
+    for a_, b_ in zip(res[0][:3], res[1][:3]):
+        assert np.max(np.abs(a_[:, :m] - b_[:, :m])) <= tol * 10
+    assert np.allclose(res[0][3], res[1][3], rtol=tol * 100)
+    assert np.allclose(res[0][4], res[1][4], rtol=tol * 100)
+
+
+def _csr_cases():
+    rp, ci, va, n = problems.laplacian_csr((37, 41, 29))
+    yield "lap3d", rp, ci, va, n
+    rp, ci, va, n = problems.laplacian_csr((300, 211))
+    yield "lap2d", rp, ci, va, n
+    # ragged: empty rows, one very long row (> LDS tile), random short rows
+    rng = np.random.default_rng(2)
+    n = 5000
+    counts = rng.integers(0, 9, size=n)
+    counts[17] = 0; counts[18] = 0; counts[100] = 4000; counts[n - 1] = 0
+    rp = np.zeros(n + 1, dtype=np.int64); np.cumsum(counts, out=rp[1:])
+    ci = np.concatenate([np.sort(rng.choice(n, size=c, replace=False)) for c in counts]).astype(np.int32)
+    va = rng.standard_normal(len(ci))
+    yield "ragged", rp.astype(np.int32), ci, va, n
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("ncols", [1, 3])
+def test_csr_matvec(built, dt, ncols):
+    npdt = NPDT[dt]
+    for name, rp, ci, va, n in _csr_cases():
+        rng = np.random.default_rng(n)
+        ld = n + 2
+        X = rng.standard_normal((ncols, ld)).astype(npdt)
+        res = []
+        for side in (Dev(), Host()):
+            A = C.c_void_p()
+            vv = np.ascontiguousarray(va, dtype=npdt)
+            assert side.lib.hipk_csr_create(side.ctx, dt, n, n, 0, rp.ctypes.data_as(C.c_void_p),
+                                            ci.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+            x = side.arr(X); y = side.arr(np.zeros_like(X))
+            assert side.lib.hipk_csr_matvec(A, None, side.ptr(x), ld, side.ptr(y), ld, ncols) == 0
+            res.append(side.get(y)[:, :n])
+            side.lib.hipk_csr_destroy(A)
+            side.close()
+        ref = problems.csr_matvec_numpy(rp, ci, va.astype(npdt).astype(np.float64), X[:, :n].T.astype(np.float64)).T
+        tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+        assert np.max(np.abs(res[0] - res[1])) <= tol * (1 + np.abs(res[1]).max()), name
+        assert np.max(np.abs(res[1] - ref)) <= tol * (1 + np.abs(ref).max()), name
+
+
+@pytest.mark.parametrize("dims", [(1000,), (123, 77), (31, 29, 37)])
+def test_stencil_matches_csr(built, dims):
+    dt = F.HIPK_F64
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((2, n))
+    side = Dev()
+    A = C.c_void_p(); S = C.c_void_p()
+    assert side.lib.hipk_csr_create(side.ctx, dt, n, n, 0, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                    va.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+    d = list(dims) + [1, 1]
+    assert side.lib.hipk_stencil_create(side.ctx, dt, d[0], d[1], d[2], 0, n, C.byref(S)) == 0
+    x = side.arr(X); y1 = side.arr(np.zeros_like(X)); y2 = side.arr(np.zeros_like(X))
+    assert side.lib.hipk_csr_matvec(A, None, side.ptr(x), n, side.ptr(y1), n, 2) == 0
+    assert side.lib.hipk_csr_matvec(S, None, side.ptr(x), n, side.ptr(y2), n, 2) == 0
+    a, b = side.get(y1), side.get(y2)
+    assert np.max(np.abs(a - b)) <= 1e-13 * 12
+    side.lib.hipk_csr_destroy(A); side.lib.hipk_csr_destroy(S); side.close()
