@@ -157,6 +157,12 @@ int64_t hipk_csr_nrows(const hipk_csr *A);
 /* ---- measurement helpers ------------------------------------------------------- */
 /* device copy bandwidth probe: copies `bytes` src->dst `reps` times, returns GB/s (read+write) */
 int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);
+/* live per-kernel-class timing with HIP events on the launching stream (process-wide,
+ * off by default).  cls: 0 = TN inner products, 1 = NN project, 2 = fused Ritz update,
+ * 3 = sparse matvec.  alg_bytes = algorithmic HBM bytes of the timed launches. */
+int hipk_prof_enable(int on);
+int hipk_prof_reset(void);
+int hipk_prof_get(int cls, double *ms, long *launches, double *alg_bytes);
 
 #ifdef __cplusplus
 }

@@ -282,3 +282,6 @@ int hipk_jacobi_apply(void *stream, hipk_dtype dt, int64_t m, const void *diag, 
    return 0;
 }
 int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps) { (void)ctx; (void)bytes; (void)reps; *gbps = 0; return 0; }
+int hipk_prof_enable(int on) { (void)on; return 0; }
+int hipk_prof_reset(void) { return 0; }
+int hipk_prof_get(int cls, double *ms, long *launches, double *alg_bytes) { (void)cls; *ms = 0; *launches = 0; *alg_bytes = 0; return 0; }

@@ -158,6 +158,7 @@ def _declare_kernels(lib):
         "hipk_csr_set_halo": [_vp, _vp, _vp],
         "hipk_jacobi_apply": [_vp, _i, _i64, _vp, _dp, _vp, _i64, _vp, _i64, _i],
         "hipk_bandwidth_probe": [_vp, C.c_size_t, _i, _dp],
+        "hipk_prof_enable": [_i], "hipk_prof_get": [_i, _dp, P(C.c_long), _dp],
         "primme_amd_operator_create": [P(_vp), _vp, _vp], "primme_amd_operator_destroy": [_vp],
         "primme_amd_operator_apply": [_vp, _vp, _vp, _i64, _vp, _i64, _i],
     }

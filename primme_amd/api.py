@@ -1,8 +1,9 @@
 """Thin Python driver over the C ABI (plumbing only: memory, handles, parameter block).
 
-`eigsh(...)` runs hip_dprimme / hip_sprimme of the product library on `cuda:0`
-(device memory through torch).  The same parameter plumbing can target the two
-CHECKER back ends used by tests and by bench.py's cpu_baseline leg:
+`Session` keeps a sparse operator resident (in HBM for backend="hip") and runs
+hip_dprimme / hip_sprimme solves on it; `eigsh(...)` is the one-shot form.
+The same parameter plumbing can target the two CHECKER back ends used by tests and
+by bench.py's cpu_baseline leg:
    backend="hostcheck"  product host solver over oracle/hipk_cpu.c (host memory)
    backend="reference"  the real reference library oracle/_ref/libprimme_ref.so
 The product path (backend="hip") never touches either of them.
@@ -14,7 +15,8 @@ from . import _ffi as F
 
 
 class Operator:
-    """A sparse operator: CSR arrays (global column indices) or a Laplacian stencil."""
+    """A sparse operator: CSR arrays (global column indices) or a Laplacian stencil,
+    rows [row0, row0+nrows) of an n x n matrix."""
 
     def __init__(self, n, csr=None, stencil=None, row0=0, nrows=None):
         self.n = int(n)
@@ -43,40 +45,6 @@ class Operator:
         return dg
 
 
-def _fill_params(lib, p, op, numEvals, target, method, eps, aNorm, maxBlockSize, maxBasisSize,
-                 minRestartSize, maxPrevRetain, locking, maxMatvecs, maxOuterIterations, targetShifts,
-                 initSize, initBasisMode, printLevel, numProcs, procID, nLocal, orth, iseed, keep):
-    lib.primme_initialize(C.byref(p))
-    p.n = op.n
-    p.numEvals = numEvals
-    p.target = F.TARGETS[target] if isinstance(target, str) else target
-    p.eps = eps
-    p.aNorm = aNorm
-    p.printLevel = printLevel
-    p.outputFile = None
-    if maxBlockSize: p.maxBlockSize = maxBlockSize
-    if maxBasisSize: p.maxBasisSize = maxBasisSize
-    if minRestartSize: p.minRestartSize = minRestartSize
-    if maxPrevRetain is not None: p.restartingParams.maxPrevRetain = maxPrevRetain
-    if locking is not None: p.locking = locking
-    if maxMatvecs: p.maxMatvecs = maxMatvecs
-    if maxOuterIterations: p.maxOuterIterations = maxOuterIterations
-    if orth is not None: p.orth = orth
-    if iseed is not None:
-        for i in range(4): p.iseed[i] = iseed[i]
-    if targetShifts is not None:
-        ts = (C.c_double * len(targetShifts))(*targetShifts)
-        keep.append(ts)
-        p.targetShifts = ts
-        p.numTargetShifts = len(targetShifts)
-    p.initSize = initSize
-    if initBasisMode is not None: p.initBasisMode = initBasisMode
-    p.numProcs = numProcs
-    p.procID = procID
-    p.nLocal = nLocal
-    return F.METHODS[method] if isinstance(method, str) else method
-
-
 class Result:
     def __init__(self, ret, evals, evecs, resNorms, params):
         self.ret, self.evals, self.evecs, self.resNorms = ret, evals, evecs, resNorms
@@ -88,155 +56,194 @@ class Result:
         self.params["maxPrevRetain"] = params.restartingParams.maxPrevRetain
 
 
-def eigsh(op, numEvals=1, target="smallest", method="GD_plusK", eps=1e-8, aNorm=0.0, v0=None,
-          maxBlockSize=0, maxBasisSize=0, minRestartSize=0, maxPrevRetain=None, locking=None,
-          maxMatvecs=0, maxOuterIterations=0, targetShifts=None, precond=None, dtype=np.float64,
-          backend="hip", printLevel=0, initBasisMode=None, comm=None, global_sum=None,
-          numProcs=1, procID=0, orth=None, iseed=None, profile=False, return_evecs=True,
-          monitor=None):
-    """Compute a few eigenpairs of the symmetric operator `op`.
-
-    v0: optional (nLocal x initSize) initial guesses -> initBasisMode defaults to
-    primme_init_user so that no random numbers enter (parity runs, SURVEY.md §7).
-    precond: None | "jacobi".
-    """
-    dtype = np.dtype(dtype)
-    dt = F.HIPK_F64 if dtype == np.float64 else F.HIPK_F32
-    keep = []
-    p = F.PrimmeParams()
-    nLocal = op.nrows
-    v0 = None if v0 is None else np.asarray(v0, dtype=dtype).reshape(nLocal, -1)
-    initSize = 0 if v0 is None else v0.shape[1]
-    if initBasisMode is None and v0 is not None:
-        initBasisMode = F.primme_init_user
-
-    if backend == "hip":
-        lib = F.load_product()
-    elif backend == "hostcheck":
-        lib = F.load_hostcheck()
-    elif backend == "reference":
-        lib = F.load_reference()
-    else:
-        raise ValueError(backend)
-
-    m = _fill_params(lib, p, op, numEvals, target, method, eps, aNorm, maxBlockSize, maxBasisSize,
-                     minRestartSize, maxPrevRetain, locking, maxMatvecs, maxOuterIterations,
-                     targetShifts, initSize, initBasisMode, printLevel, numProcs, procID, nLocal, orth,
-                     iseed, keep)
-    ncols = max(numEvals, initSize)
-    handles = []
-
-    if backend == "reference":
-        def mv(x, ldx, y, ldy, bs, pp, ierr):
-            nb, lx, ly = bs[0], ldx[0], ldy[0]
-            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double if dtype == np.float64 else C.c_float)), shape=(nb, lx))
-            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double if dtype == np.float64 else C.c_float)), shape=(nb, ly))
-            Y[:, :nLocal] = op.apply_numpy(X[:, :nLocal].T.astype(np.float64)).T
-            ierr[0] = 0
-        cb = F.BLOCK_OP(mv)
-        keep.append(cb)
-        p.matrixMatvec = C.cast(cb, C.c_void_p)
-        if precond == "jacobi":
-            dg = op.diagonal()
-            def pc(x, ldx, y, ldy, bs, pp, ierr):
-                nb, lx, ly = bs[0], ldx[0], ldy[0]
-                ct = C.c_double if dtype == np.float64 else C.c_float
-                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ct)), shape=(nb, lx))
-                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ct)), shape=(nb, ly))
-                sh = pp[0].ShiftsForPreconditioner
-                for c in range(nb):
-                    d = dg - (sh[c] if sh else 0.0)
-                    d[np.abs(d) < 1e-300] = 1e-300
-                    Y[c, :nLocal] = X[c, :nLocal] / d
-                ierr[0] = 0
-            pcb = F.BLOCK_OP(pc)
-            keep.append(pcb)
-            p.applyPreconditioner = C.cast(pcb, C.c_void_p)
-            p.correctionParams.precondition = 1
-        evecs = np.zeros((ncols, nLocal), dtype=dtype)   # row-major (ncols x n) == col-major n x ncols
-        if v0 is not None:
-            evecs[:initSize] = v0.T
-        evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
-        solver = lib.dprimme if dtype == np.float64 else lib.sprimme
-    else:
+class Session:
+    def __init__(self, op, comm=None, dtype=np.float64, backend="hip"):
+        self.op, self.comm, self.backend = op, comm, backend
+        self.dtype = np.dtype(dtype)
+        self.dt = F.HIPK_F64 if self.dtype == np.float64 else F.HIPK_F32
+        self.handles = []
+        self.keep = []
+        self._v0_cache = None
+        if backend == "hip":
+            self.lib = F.load_product()
+        elif backend == "hostcheck":
+            self.lib = F.load_hostcheck()
+        elif backend == "reference":
+            self.lib = F.load_reference()
+            return
+        else:
+            raise ValueError(backend)
+        lib = self.lib
         ctx = C.c_void_p()
         if lib.hipk_ctx_create(C.byref(ctx), None):
-            raise RuntimeError("hipk_ctx_create failed (no GPU?)")
-        handles.append(("ctx", ctx))
+            raise RuntimeError("hipk_ctx_create failed: no HIP device (primme_amd has no CPU path)")
+        self.handles.append(("ctx", ctx))
         A = C.c_void_p()
         if op.csr is not None:
             rp, ci, va = op.csr
             rp = np.ascontiguousarray(rp, dtype=np.int32)
             ci = np.ascontiguousarray(ci, dtype=np.int32)
-            va = np.ascontiguousarray(va, dtype=dtype)
-            rc = lib.hipk_csr_create(ctx, dt, nLocal, op.n, op.row0, rp.ctypes.data_as(C.c_void_p),
+            va = np.ascontiguousarray(va, dtype=self.dtype)
+            rc = lib.hipk_csr_create(ctx, self.dt, op.nrows, op.n, op.row0, rp.ctypes.data_as(C.c_void_p),
                                      ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), C.byref(A))
         else:
             nx, ny, nz = (list(op.stencil) + [1, 1])[:3]
-            rc = lib.hipk_stencil_create(ctx, dt, nx, ny or 1, nz or 1, op.row0, nLocal, C.byref(A))
+            rc = lib.hipk_stencil_create(ctx, self.dt, nx, ny or 1, nz or 1, op.row0, op.nrows, C.byref(A))
         if rc:
             raise RuntimeError(f"operator creation failed: {rc}")
-        handles.append(("csr", A))
+        self.handles.append(("csr", A))
         oph = C.c_void_p()
         if lib.primme_amd_operator_create(C.byref(oph), A, comm):
             raise RuntimeError("operator handle creation failed")
-        handles.append(("op", oph))
-        p.matrix = oph
-        p.matrixMatvec = C.cast(lib.primme_amd_matvec, C.c_void_p)
-        if precond == "jacobi":
-            p.preconditioner = oph
-            p.applyPreconditioner = C.cast(lib.primme_amd_jacobi_precond, C.c_void_p)
-            p.correctionParams.precondition = 1
-        if comm is not None:
-            p.commInfo = comm
-            p.globalSumReal = C.cast(lib.primme_amd_global_sum, C.c_void_p)
-        if profile:
-            p.profile = b"phases"
-        if backend == "hip":
-            import torch
-            tdt = torch.float64 if dtype == np.float64 else torch.float32
-            evecs_t = torch.zeros((ncols, nLocal), dtype=tdt, device="cuda")
-            if v0 is not None:
-                evecs_t[:initSize] = torch.from_numpy(np.ascontiguousarray(v0.T)).to("cuda")
-            torch.cuda.synchronize()
-            evecs_ptr = C.c_void_p(evecs_t.data_ptr())
-            keep.append(evecs_t)
-        else:
-            evecs = np.zeros((ncols, nLocal), dtype=dtype)
+        self.handles.append(("op", oph))
+        self.oph = oph
+
+    def close(self):
+        for kind, h in reversed(self.handles):
+            if kind == "op": self.lib.primme_amd_operator_destroy(h)
+            elif kind == "csr": self.lib.hipk_csr_destroy(h)
+            elif kind == "ctx": self.lib.hipk_ctx_destroy(h)
+        self.handles = []
+
+    def solve(self, numEvals=1, target="smallest", method="GD_plusK", eps=1e-8, aNorm=0.0, v0=None,
+              maxBlockSize=0, maxBasisSize=0, minRestartSize=0, maxPrevRetain=None, locking=None,
+              maxMatvecs=0, maxOuterIterations=0, targetShifts=None, precond=None, printLevel=0,
+              initBasisMode=None, global_sum=None, numProcs=1, procID=0, orth=None, iseed=None,
+              profile=False, return_evecs=True, monitor=None):
+        lib, op, dtype, backend = self.lib, self.op, self.dtype, self.backend
+        keep = []
+        p = F.PrimmeParams()
+        nLocal = op.nrows
+        v0 = None if v0 is None else np.asarray(v0, dtype=dtype).reshape(nLocal, -1)
+        initSize = 0 if v0 is None else v0.shape[1]
+        if initBasisMode is None and v0 is not None:
+            initBasisMode = F.primme_init_user
+
+        lib.primme_initialize(C.byref(p))
+        p.n = op.n
+        p.numEvals = numEvals
+        p.target = F.TARGETS[target] if isinstance(target, str) else target
+        p.eps, p.aNorm, p.printLevel, p.outputFile = eps, aNorm, printLevel, None
+        if maxBlockSize: p.maxBlockSize = maxBlockSize
+        if maxBasisSize: p.maxBasisSize = maxBasisSize
+        if minRestartSize: p.minRestartSize = minRestartSize
+        if maxPrevRetain is not None: p.restartingParams.maxPrevRetain = maxPrevRetain
+        if locking is not None: p.locking = locking
+        if maxMatvecs: p.maxMatvecs = maxMatvecs
+        if maxOuterIterations: p.maxOuterIterations = maxOuterIterations
+        if orth is not None: p.orth = orth
+        if iseed is not None:
+            for i in range(4): p.iseed[i] = iseed[i]
+        if targetShifts is not None:
+            ts = (C.c_double * len(targetShifts))(*targetShifts)
+            keep.append(ts)
+            p.targetShifts, p.numTargetShifts = ts, len(targetShifts)
+        p.initSize = initSize
+        if initBasisMode is not None: p.initBasisMode = initBasisMode
+        p.numProcs, p.procID, p.nLocal = numProcs, procID, nLocal
+        m = F.METHODS[method] if isinstance(method, str) else method
+        ncols = max(numEvals, initSize)
+        ctype = C.c_double if dtype == np.float64 else C.c_float
+        evecs_t = None
+
+        if backend == "reference":
+            def mv(x, ldx, y, ldy, bs, pp, ierr):
+                nb, lx, ly = bs[0], ldx[0], ldy[0]
+                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
+                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
+                Y[:, :nLocal] = op.apply_numpy(X[:, :nLocal].T.astype(np.float64)).T
+                ierr[0] = 0
+            cb = F.BLOCK_OP(mv)
+            keep.append(cb)
+            p.matrixMatvec = C.cast(cb, C.c_void_p)
+            if precond == "jacobi":
+                dg = op.diagonal()
+
+                def pc(x, ldx, y, ldy, bs, pp, ierr):
+                    nb, lx, ly = bs[0], ldx[0], ldy[0]
+                    X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
+                    Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
+                    sh = pp[0].ShiftsForPreconditioner
+                    for c in range(nb):
+                        d = dg - (sh[c] if sh else 0.0)
+                        d[np.abs(d) < 1e-300] = 1e-300
+                        Y[c, :nLocal] = X[c, :nLocal] / d
+                    ierr[0] = 0
+                pcb = F.BLOCK_OP(pc)
+                keep.append(pcb)
+                p.applyPreconditioner = C.cast(pcb, C.c_void_p)
+                p.correctionParams.precondition = 1
+            evecs = np.zeros((ncols, nLocal), dtype=dtype)  # row-major (ncols x n) == col-major n x ncols
             if v0 is not None:
                 evecs[:initSize] = v0.T
             evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
-        solver = lib.hip_dprimme if dtype == np.float64 else lib.hip_sprimme
+            solver = lib.dprimme if dtype == np.float64 else lib.sprimme
+        else:
+            p.matrix = self.oph
+            p.matrixMatvec = C.cast(lib.primme_amd_matvec, C.c_void_p)
+            if precond == "jacobi":
+                p.preconditioner = self.oph
+                p.applyPreconditioner = C.cast(lib.primme_amd_jacobi_precond, C.c_void_p)
+                p.correctionParams.precondition = 1
+            if self.comm is not None:
+                p.commInfo = self.comm
+                p.globalSumReal = C.cast(lib.primme_amd_global_sum, C.c_void_p)
+            if profile:
+                p.profile = b"phases"
+            if backend == "hip":
+                import torch
+                tdt = torch.float64 if dtype == np.float64 else torch.float32
+                evecs_t = torch.zeros((ncols, nLocal), dtype=tdt, device="cuda")
+                if v0 is not None:
+                    # the start vectors are uploaded once per Session and stay in HBM
+                    key = (v0.shape, float(v0.ravel()[0]), float(v0.ravel()[-1]))
+                    if self._v0_cache is None or self._v0_cache[0] != key:
+                        self._v0_cache = (key, torch.from_numpy(np.ascontiguousarray(v0.T)).to("cuda"))
+                    evecs_t[:initSize] = self._v0_cache[1]
+                torch.cuda.synchronize()
+                evecs_ptr = C.c_void_p(evecs_t.data_ptr())
+            else:
+                evecs = np.zeros((ncols, nLocal), dtype=dtype)
+                if v0 is not None:
+                    evecs[:initSize] = v0.T
+                evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
+            solver = lib.hip_dprimme if dtype == np.float64 else lib.hip_sprimme
 
-    if global_sum is not None:
-        def gs(send, recv, count, pp, ierr):
-            n_ = count[0]
-            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(n_,)).copy()
-            out = global_sum(a)
-            np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(n_,))[:] = out
-            ierr[0] = 0
-        gcb = F.GLOBAL_SUM(gs)
-        keep.append(gcb)
-        p.globalSumReal = C.cast(gcb, C.c_void_p)
+        if global_sum is not None:
+            def gs(send, recv, count, pp, ierr):
+                n_ = count[0]
+                a = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(n_,)).copy()
+                np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(n_,))[:] = global_sum(a)
+                ierr[0] = 0
+            gcb = F.GLOBAL_SUM(gs)
+            keep.append(gcb)
+            p.globalSumReal = C.cast(gcb, C.c_void_p)
+        if monitor is not None:
+            mcb = F.MONITOR(monitor)
+            keep.append(mcb)
+            p.monitorFun = C.cast(mcb, C.c_void_p)
 
-    if monitor is not None:
-        mcb = F.MONITOR(monitor)
-        keep.append(mcb)
-        p.monitorFun = C.cast(mcb, C.c_void_p)
+        if lib.primme_set_method(m, C.byref(p)):
+            raise ValueError("unknown method")
+        evals = np.zeros(numEvals, dtype=dtype)
+        resNorms = np.zeros(numEvals, dtype=dtype)
+        ret = solver(evals.ctypes.data_as(C.c_void_p), evecs_ptr, resNorms.ctypes.data_as(C.c_void_p), C.byref(p))
+        if backend == "hip":
+            import torch
+            torch.cuda.synchronize()
+            evecs = evecs_t.cpu().numpy() if return_evecs else None
+        return Result(ret, evals, None if evecs is None else evecs[:numEvals].T.copy(), resNorms, p)
 
-    if lib.primme_set_method(m, C.byref(p)):
-        raise ValueError("unknown method")
-    evals = np.zeros(numEvals, dtype=dtype)
-    resNorms = np.zeros(numEvals, dtype=dtype)
-    ret = solver(evals.ctypes.data_as(C.c_void_p), evecs_ptr, resNorms.ctypes.data_as(C.c_void_p), C.byref(p))
 
-    if backend == "hip":
-        import torch
-        torch.cuda.synchronize()
-        evecs = evecs_t.cpu().numpy() if return_evecs else None
-    res = Result(ret, evals, None if evecs is None else evecs[:numEvals].T.copy(), resNorms, p)
-    for kind, h in reversed(handles):
-        if kind == "op": lib.primme_amd_operator_destroy(h)
-        elif kind == "csr": lib.hipk_csr_destroy(h)
-        elif kind == "ctx": lib.hipk_ctx_destroy(h)
-    return res
+def eigsh(op, backend="hip", comm=None, dtype=np.float64, **kw):
+    """One-shot: compute a few eigenpairs of the symmetric operator `op` (see Session.solve).
+
+    v0: optional (nLocal x initSize) initial guesses -> initBasisMode defaults to
+    primme_init_user so that no random numbers enter (parity runs, SURVEY.md §7).
+    precond: None | "jacobi".
+    """
+    s = Session(op, comm=comm, dtype=dtype, backend=backend)
+    try:
+        return s.solve(**kw)
+    finally:
+        s.close()

@@ -173,3 +173,68 @@ extern "C" int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, doubl
    hipk_free(ctx, b);
    return 0;
 }
+
+/* ---- live kernel-class profiler ---------------------------------------------- */
+#define PROF_RING 4096
+static struct {
+   int enabled, inited;
+   hipEvent_t e0[PROF_RING], e1[PROF_RING];
+   int cls[PROF_RING];
+   int head, tail;                  /* slots [tail, head) are in flight */
+   double ms[HIPK_PROF_NCLASS], bytes[HIPK_PROF_NCLASS];
+   long launches[HIPK_PROF_NCLASS];
+} g_prof;
+
+static void prof_drain(int all) {
+   while (g_prof.tail != g_prof.head) {
+      const int s = g_prof.tail % PROF_RING;
+      if (!all && hipEventQuery(g_prof.e1[s]) != hipSuccess) break;
+      if (all) (void)hipEventSynchronize(g_prof.e1[s]);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, g_prof.e0[s], g_prof.e1[s]) == hipSuccess) {
+         g_prof.ms[g_prof.cls[s]] += ms;
+         g_prof.launches[g_prof.cls[s]]++;
+      }
+      g_prof.tail++;
+   }
+}
+
+int hipk_prof_begin(int cls, hipStream_t st, double alg_bytes) {
+   if (!g_prof.enabled) return -1;
+   if (g_prof.head - g_prof.tail >= PROF_RING - 1) prof_drain(0);
+   if (g_prof.head - g_prof.tail >= PROF_RING - 1) prof_drain(1);
+   const int s = g_prof.head % PROF_RING;
+   g_prof.cls[s] = cls;
+   g_prof.bytes[cls] += alg_bytes;
+   (void)hipEventRecord(g_prof.e0[s], st);
+   return s;
+}
+void hipk_prof_end(int slot, hipStream_t st) {
+   if (slot < 0) return;
+   (void)hipEventRecord(g_prof.e1[slot], st);
+   g_prof.head++;
+}
+
+extern "C" int hipk_prof_enable(int on) {
+   if (on && !g_prof.inited) {
+      for (int i = 0; i < PROF_RING; i++) {
+         if (hipEventCreate(&g_prof.e0[i]) != hipSuccess || hipEventCreate(&g_prof.e1[i]) != hipSuccess) return -1;
+      }
+      g_prof.inited = 1;
+   }
+   if (!on && g_prof.inited) prof_drain(1);
+   g_prof.enabled = on;
+   return 0;
+}
+extern "C" int hipk_prof_reset(void) {
+   if (g_prof.inited) prof_drain(1);
+   for (int c = 0; c < HIPK_PROF_NCLASS; c++) { g_prof.ms[c] = 0; g_prof.bytes[c] = 0; g_prof.launches[c] = 0; }
+   return 0;
+}
+/* cls: 0 dots (TN panel), 1 project (NN accumulate), 2 ritz (fused update), 3 spmv */
+extern "C" int hipk_prof_get(int cls, double *ms, long *launches, double *alg_bytes) {
+   if (cls < 0 || cls >= HIPK_PROF_NCLASS) return -1;
+   if (g_prof.inited) prof_drain(1);
+   *ms = g_prof.ms[cls]; *launches = g_prof.launches[cls]; *alg_bytes = g_prof.bytes[cls];
+   return 0;
+}

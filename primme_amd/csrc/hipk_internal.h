@@ -32,6 +32,13 @@ struct hipk_ctx {
       }                                                                           \
    } while (0)
 
+/* ---- live per-kernel-class timing (HIP events on the launching stream) ----------
+ * bench.py's roofline leg: average launch duration and algorithmic bytes of each
+ * hot kernel class, measured during the timed solves. Off by default. */
+enum { HIPK_PROF_DOTS = 0, HIPK_PROF_PROJECT = 1, HIPK_PROF_RITZ = 2, HIPK_PROF_SPMV = 3, HIPK_PROF_NCLASS = 4 };
+int hipk_prof_begin(int cls, hipStream_t st, double alg_bytes); /* returns slot or -1 */
+void hipk_prof_end(int slot, hipStream_t st);
+
 /* make sure ctx->partials can hold n doubles */
 int hipk_reserve_partials(hipk_ctx *ctx, size_t n);
 /* out[o] = sum_b partials[b*nout + o], deterministic order */

@@ -120,12 +120,14 @@ static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X,
    size_t nout = (size_t)sa.total * nx;
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    dim3 grid(gx, gy, gz), block(HIPK_BLOCK);
+   const int pslot = hipk_prof_begin(HIPK_PROF_DOTS, ctx->stream, (double)m * sizeof(T) * (sa.total + nx));
    switch (nxt) {
    case 1: hipLaunchKernelGGL((dots_kernel<T, 8, 1>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
    case 2: hipLaunchKernelGGL((dots_kernel<T, 8, 2>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
    case 4: hipLaunchKernelGGL((dots_kernel<T, 8, 4>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
    default: hipLaunchKernelGGL((dots_kernel<T, 8, 8>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
    }
+   hipk_prof_end(pslot, ctx->stream);
    HIPK_CHECK(hipGetLastError());
    hipLaunchKernelGGL(finalize_ld_kernel, dim3((unsigned)nout), dim3(HIPK_BLOCK), 0, ctx->stream,
          ctx->partials, gx, (int)nout, sa.total, ldout, out_dev);
@@ -219,6 +221,7 @@ static int panel_project_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
    if (nrm2_dev && hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
    double *part = nrm2_dev ? ctx->partials : NULL;
    dim3 block(HIPK_BLOCK);
+   const int pslot = hipk_prof_begin(HIPK_PROF_PROJECT, ctx->stream, (double)m * sizeof(T) * ((double)sa.total * ((nx + 7) / 8) + 2.0 * nx));
    for (int c0 = 0; c0 < nx;) {
       int rem = nx - c0;
       int step;
@@ -229,6 +232,7 @@ static int panel_project_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
       HIPK_CHECK(hipGetLastError());
       c0 += step;
    }
+   hipk_prof_end(pslot, ctx->stream);
    if (nrm2_dev) return hipk_finalize_partials(ctx, ctx->partials, gx, nx, nrm2_dev);
    return 0;
 }
@@ -382,6 +386,8 @@ static int ritz_update_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64
       /* every block writes every slot; slots must be 0..nslots-1, each used once */
       if (hipk_reserve_partials(ctx, (size_t)gx * nslots)) return -2;
    }
+   const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream,
+         (double)m * sizeof(T) * ((double)k * (1 + ((ja.nxw > 0 || ja.nres > 0) ? 1 : 0)) + ja.nxv + ja.nxw + ja.nres));
    int rc;
    if (k <= 8) rc = ritz_launch_nk<T, 8>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
    else if (k <= 16) rc = ritz_launch_nk<T, 16>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
@@ -389,7 +395,8 @@ static int ritz_update_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64
    else if (k <= 32) rc = ritz_launch_nk<T, 32>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
    else if (k <= 48) rc = ritz_launch_nk<T, 48>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
    else if (k <= 64) rc = ritz_launch_nk<T, 64>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
-   else return -1;
+   else rc = -1;
+   hipk_prof_end(pslot, ctx->stream);
    if (rc) return rc;
    if (nslots > 0) return hipk_finalize_partials(ctx, ctx->partials, gx, nslots, nrm2_dev);
    return 0;

@@ -282,6 +282,10 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
       fprintf(stderr, "primme_amd: matvec needs halo data (rows outside the local slab) but none was set\n");
       return -1;
    }
+   const double es = sizeof(T);
+   const double alg = (A->kind == 1) ? 2.0 * A->nrows * es * ncols
+                                     : (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 2.0 * A->nrows * es * ncols;
+   const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, stream, alg);
    if (A->kind == 1) {
       int gx = hipk_grid_for_rows(ctx, A->nrows, HIPK_BLOCK, 8);
       hipLaunchKernelGGL(stencil_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->sx,
@@ -294,6 +298,7 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
             ncols, A->row0, A->nrows, A->halo_lo, A->halo_hi, (const T *)A->xlo,
             (const T *)A->xhi);
    }
+   hipk_prof_end(pslot, stream);
    HIPK_CHECK(hipGetLastError());
    return 0;
 }
