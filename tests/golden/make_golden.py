@@ -1,0 +1,103 @@
+"""Generates tests/golden/*.json from the REAL reference (oracle/_ref/libprimme_ref.so, built
+from /root/reference by oracle/Makefile; BLAS/LAPACK = MKL of this image).  Run in the build
+container only:  python tests/golden/make_golden.py
+Fixtures are data: inputs are regenerated from closed forms (primme_amd.problems), outputs are
+the reference's evals / resNorms / stats, the struct layout and the dlarnv stream."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from primme_amd import eigsh, Operator, problems  # noqa: E402
+from primme_amd import _ffi as F  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    # name: (dims, kwargs)
+    "lap2d_gdk_lock": ((20, 21), dict(numEvals=10, method="GD_plusK", eps=1e-10, aNorm=8.0)),
+    "lap2d_gdk_soft": ((20, 21), dict(numEvals=4, method="GD_plusK", eps=1e-10, aNorm=8.0)),
+    "lap2d_gdk_soft_K20": ((20, 21), dict(numEvals=6, method="GD_plusK", eps=1e-10, aNorm=8.0, maxBasisSize=20, minRestartSize=8)),
+    "lap2d_largest": ((20, 21), dict(numEvals=5, target="largest", eps=1e-9, aNorm=8.0)),
+    "lap2d_gd": ((20, 21), dict(numEvals=3, method="GD", eps=1e-9, aNorm=8.0)),
+    "lap2d_gd_olsen": ((20, 21), dict(numEvals=10, method="GD_Olsen_plusK", eps=1e-9, aNorm=8.0)),
+    "lap2d_jacobi": ((20, 21), dict(numEvals=5, eps=1e-9, aNorm=8.0, precond="jacobi")),
+    "lap2d_closest_abs": ((20, 21), dict(numEvals=4, target="closest_abs", targetShifts=[1.0], eps=1e-8, aNorm=8.0)),
+    "lap2d_closest_geq": ((20, 21), dict(numEvals=3, target="closest_geq", targetShifts=[2.0], eps=1e-8, aNorm=8.0)),
+    "lap2d_closest_leq": ((20, 21), dict(numEvals=3, target="closest_leq", targetShifts=[2.0], eps=1e-8, aNorm=8.0)),
+    "lap2d_krylov_rng": ((20, 21), dict(numEvals=5, eps=1e-9, aNorm=8.0, v0=None)),
+    "lap1d_ex_dseq": ((100,), dict(numEvals=10, method="GD_plusK", eps=1e-9, aNorm=4.0, precond="jacobi")),
+    "lap3d_gdk": ((9, 10, 11), dict(numEvals=10, eps=1e-10, aNorm=12.0)),
+    "lap3d_noanorm": ((9, 10, 11), dict(numEvals=4, eps=1e-8)),
+    "lap3d_lobpcg": ((9, 10, 11), dict(numEvals=3, method="LOBPCG_OrthoBasis", eps=1e-6, aNorm=12.0, orth=F.primme_orth_implicit_I, v0=None)),
+    "lap3d_medium": ((30, 31, 32), dict(numEvals=10, eps=1e-8, aNorm=12.0)),
+}
+
+
+def main():
+    out = {}
+    for name, (dims, kw) in CASES.items():
+        rp, ci, va, n = problems.laplacian_csr(dims)
+        op = Operator(n, csr=(rp, ci, va))
+        kw = dict(kw)
+        if "v0" not in kw:
+            kw["v0"] = problems.start_vector(n)
+        r = eigsh(op, backend="reference", **kw)
+        kws = {k: v for k, v in kw.items() if k != "v0"}
+        kws["v0"] = "start_vector" if kw.get("v0") is not None else None
+        out[name] = dict(dims=list(dims), kwargs=kws, ret=r.ret, initSize=r.initSize, evals=r.evals.tolist(),
+                         resNorms=r.resNorms.tolist(), params=r.params,
+                         stats={k: r.stats[k] for k in ("numOuterIterations", "numMatvecs", "numRestarts", "numPreconds")})
+        print(name, r.ret, r.stats["numOuterIterations"])
+    json.dump(out, open(os.path.join(HERE, "reference_solves.json"), "w"), indent=1)
+
+    # ---- struct layout + defaults as the reference computes them ----
+    ref = F.load_reference()
+    abi = {"sizeof_primme_params": C.sizeof(F.PrimmeParams), "sizeof_primme_stats": C.sizeof(F.PrimmeStats),
+           "offsets": {f[0]: getattr(F.PrimmeParams, f[0]).offset for f in F.PrimmeParams._fields_}}
+    # the reference's own view: primme_get_member through labels is not needed; instead record the
+    # bytes primme_initialize / primme_set_method produce for a grid of inputs
+    presets = {}
+    for mname, m in F.METHODS.items():
+        for (nev, bs, tgt, prec) in [(1, 0, 0, 0), (10, 0, 0, 0), (10, 4, 0, 0), (20, 8, 4, 1), (3, 1, 1, 1), (7, 2, 2, 0)]:
+            p = F.PrimmeParams()
+            ref.primme_initialize(C.byref(p))
+            p.n = 10000
+            p.numEvals = nev
+            p.maxBlockSize = bs
+            p.target = tgt
+            if prec:
+                p.applyPreconditioner = 1  # any non-NULL pointer
+            rc = ref.primme_set_method(m, C.byref(p))
+            presets[f"{mname}|{nev}|{bs}|{tgt}|{prec}"] = dict(
+                rc=rc, maxBasisSize=p.maxBasisSize, minRestartSize=p.minRestartSize, maxBlockSize=p.maxBlockSize,
+                locking=p.locking, dynamicMethodSwitch=p.dynamicMethodSwitch, maxPrevRetain=p.restartingParams.maxPrevRetain,
+                precondition=p.correctionParams.precondition, robustShifts=p.correctionParams.robustShifts,
+                maxInnerIterations=p.correctionParams.maxInnerIterations,
+                projectors=[getattr(p.correctionParams.projectors, k) for k in ("LeftQ", "LeftX", "RightQ", "RightX", "SkewQ", "SkewX")],
+                convTest=p.correctionParams.convTest, relTolBase=p.correctionParams.relTolBase,
+                projection=p.projectionParams.projection, initBasisMode=p.initBasisMode)
+    p = F.PrimmeParams()
+    C.memset(C.byref(p), 0xAB, C.sizeof(p))
+    ref.primme_initialize(C.byref(p))
+    abi["initialize_bytes_hex"] = bytes(p).hex()
+    abi["presets"] = presets
+    json.dump(abi, open(os.path.join(HERE, "reference_abi.json"), "w"), indent=1)
+
+    # ---- LAPACK dlarnv(idist=2) stream of this image's MKL ----
+    mkl = C.CDLL("/opt/conda/lib/libmkl_rt.so")
+    rng = {}
+    for seed in ([0, 0, 0, 1], [5, 17, 2000, 4095], [1, 2, 3, 4095 - 2]):
+        iseed = (C.c_int * 4)(*seed)
+        x = np.zeros(300)
+        mkl.dlarnv_(C.byref(C.c_int(2)), iseed, C.byref(C.c_int(300)), x.ctypes.data_as(C.c_void_p))
+        rng[",".join(map(str, seed))] = dict(values=x.tolist(), seed_after=list(iseed))
+    json.dump(rng, open(os.path.join(HERE, "lapack_dlarnv.json"), "w"))
+
+
+if __name__ == "__main__":
+    main()
