@@ -55,6 +55,11 @@ int  hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* asy
 int  hipk_d2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async  */
 int  hipk_memset0(hipk_ctx *ctx, void *dst, size_t bytes);
 int  hipk_sync(hipk_ctx *ctx);
+/* zero-copy results: every reduction whose output lies in [dev_base, dev_base+count) is also
+ * written by the kernel into the pinned host array (same offsets); the host then needs only
+ * hipk_sync, no device->host copy (the reference GPU backend does a blocking hipMemcpy per
+ * Num_*_ddh call, cublas_wrapper.c:479-499).  Pass NULLs to switch off. */
+int  hipk_ctx_set_mirror(hipk_ctx *ctx, double *dev_base, double *pinned_host_base, size_t count);
 int  hipk_is_device_ptr(const void *p);  /* Num_check_pointer, cublas_wrapper.c:162 */
 /* events around a region on the ctx stream; ms returned by hipk_timer_stop (syncs) */
 int  hipk_timer_start(hipk_ctx *ctx);

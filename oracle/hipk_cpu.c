@@ -67,6 +67,12 @@ int hipk_d2h(hipk_ctx *c, void *d, const void *s, size_t b) { (void)c; memmove(d
 int hipk_d2d(hipk_ctx *c, void *d, const void *s, size_t b) { (void)c; memmove(d, s, b); return 0; }
 int hipk_memset0(hipk_ctx *c, void *d, size_t b) { (void)c; memset(d, 0, b); return 0; }
 int hipk_sync(hipk_ctx *c) { (void)c; return 0; }
+static double *g_mirror_dev, *g_mirror_host; static size_t g_mirror_n;
+int hipk_ctx_set_mirror(hipk_ctx *c, double *d, double *h, size_t n) { (void)c; g_mirror_dev = d; g_mirror_host = h; g_mirror_n = n; return 0; }
+static void mirror(const double *out, size_t cnt) {   /* keep the zero-copy contract on the host build */
+   if (g_mirror_dev && out >= g_mirror_dev && out < g_mirror_dev + g_mirror_n && g_mirror_host != g_mirror_dev)
+      memmove(g_mirror_host + (out - g_mirror_dev), out, cnt * sizeof(double));
+}
 int hipk_is_device_ptr(const void *p) { return p != NULL; }
 int hipk_timer_start(hipk_ctx *c) { c->t0 = now(); return 0; }
 int hipk_timer_stop(hipk_ctx *c, float *ms) { *ms = (float)((now() - c->t0) * 1e3); return 0; }
@@ -85,6 +91,7 @@ int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *seg
          out[j + (size_t)c * ldout] = s;
       }
    }
+   mirror(out, (size_t)ldout * (nx - 1) + tot);
    return 0;
 }
 
@@ -105,6 +112,7 @@ int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *
       }
       if (nrm2) nrm2[c] = n2;
    }
+   if (nrm2) mirror(nrm2, nx);
    return 0;
 }
 
@@ -134,6 +142,8 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
       }
    }
    free(vr); free(wr); free(outv);
+   { int ns = 0; for (int q = 0; q < njobs; q++) if (jobs[q].kind == HIPK_JOB_RES && jobs[q].slot + 1 > ns) ns = jobs[q].slot + 1;
+     if (ns > 0) mirror(nrm2, ns); }
    return 0;
 }
 
@@ -165,6 +175,7 @@ int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int
 int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, int nx, double *out) {
    (void)ctx;
    for (int c = 0; c < nx; c++) { const void *x = colp(dt, X, ldX, c); double s = 0; for (int64_t i = 0; i < m; i++) s += ld_(dt, x, i) * ld_(dt, x, i); out[c] = s; }
+   mirror(out, nx);
    return 0;
 }
 int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, void *Wr, int64_t ldW,
@@ -176,6 +187,7 @@ int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, i
       for (int64_t i = 0; i < m; i++) { st_(dt, w, i, ld_(dt, w, i) - theta[c] * ld_(dt, x, i)); double r = ld_(dt, w, i); s += r * r; }
       nrm2[c] = s;
    }
+   mirror(nrm2, nx);
    return 0;
 }
 

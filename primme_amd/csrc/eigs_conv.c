@@ -171,6 +171,11 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
    const int ldh = basisSize;
    int lasti = -1;
    *blockSize = 0;
+   /* fused GD mode: the residual IS the correction, so it is produced directly in the V
+    * slot of the new basis vector and the Ritz vector X is never materialised (the reference
+    * writes X and R and then copies R over X, correction.c:378 with no preconditioner) */
+   const int fused = s->fuse_gd && computeXR;
+   if (fused) { R = X; X = NULL; }
    int *flagsBlock = (int *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(int));
    double *hValsBlock = (double *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(double));
    hipk_job *jobs = (hipk_job *)malloc((size_t)(2 * maxBlockSize + 2) * sizeof(hipk_job));
@@ -190,7 +195,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
    *recentlyConverged = 0;
    for (;;) {
       for (int i = *blockSize; i < *blockSize + blockNormsSize; i++) flagsBlock[i - *blockSize] = flags[iev[i]];
-      rc = pa_check_convergence(s, X ? PCOL(s, X, s->ld, *blockSize) : NULL, s->ld, computeXR,
+      rc = pa_check_convergence(s, X ? PCOL(s, X, s->ld, *blockSize) : NULL, s->ld, computeXR && !fused,
             R ? PCOL(s, R, s->ld, *blockSize) : NULL, s->ld, computeXR, numLocked, 0, blockNormsSize,
             flagsBlock, blockNorms ? &blockNorms[*blockSize] : NULL, hValsBlock, reset, practConvChecking);
       if (rc) goto out;
@@ -223,7 +228,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
             blockNorms[*blockSize] = blockNorms[blki];
             iev[*blockSize] = iev[blki];
             if (computeXR && blki != *blockSize) {
-               if ((rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, X, s->ld, blki), s->ld, PCOL(s, X, s->ld, *blockSize), s->ld, 1))) goto out;
+               if (X && (rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, X, s->ld, blki), s->ld, PCOL(s, X, s->ld, *blockSize), s->ld, 1))) goto out;
                if ((rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, R, s->ld, blki), s->ld, PCOL(s, R, s->ld, *blockSize), s->ld, 1))) goto out;
             }
             (*blockSize)++;
@@ -245,7 +250,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
       for (int c = 0; c < blockNormsSize; c++) {
          const int col = iev[*blockSize + c];
          if (computeXR) {
-            jobs[nj++] = (hipk_job){HIPK_JOB_XV, col, PCOL(s, X, s->ld, *blockSize + c), -1};
+            if (X) jobs[nj++] = (hipk_job){HIPK_JOB_XV, col, PCOL(s, X, s->ld, *blockSize + c), -1};
             jobs[nj++] = (hipk_job){HIPK_JOB_RES, col, PCOL(s, R, s->ld, *blockSize + c), c};
          } else {
             jobs[nj++] = (hipk_job){HIPK_JOB_RES, col, NULL, c};

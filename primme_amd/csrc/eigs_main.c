@@ -225,7 +225,7 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
          for (int b = 0; b < blockSize; b++) olsen[b] = -olsen[b];
          rc = hipk_axpy_cols(s->ctx, s->dt, s->m, olsen, x, s->ld, r, s->ld, blockSize);
       }
-      if (!rc) rc = pa_precond(s, r, s->ld, x, s->ld, blockSize);
+      if (!rc && !s->fuse_gd) rc = pa_precond(s, r, s->ld, x, s->ld, blockSize);
    }
    p->ShiftsForPreconditioner = NULL;
    if (own) { free(sorted); free(ilev); }
@@ -655,6 +655,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->phase_timing = p->profile != NULL;
    s->dev_comm = (p->numProcs > 1 && p->globalSumReal == primme_amd_global_sum);
    s->coef_valid_k = -1;
+   s->fuse_gd = (p->correctionParams.maxInnerIterations == 0 && !p->correctionParams.precondition &&
+                 !p->correctionParams.projectors.RightX && p->convTestFun == pa_conv_test_absolute);
    s->maxRank = p->numOrthoConst + (p->locking ? p->numEvals : 0) + p->maxBasisSize;
    if (hipk_ctx_create(&s->ctx, p->queue)) { free(s); return PRIMME_UNEXPECTED_FAILURE; }
    /* callbacks find the solver's stream in primme->queue (reference: the queue/handle
@@ -680,6 +682,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->flags = (int *)calloc((size_t)K, sizeof(int)); s->map = (int *)calloc((size_t)K, sizeof(int));
    s->iev = (int *)calloc((size_t)K + b, sizeof(int)); s->perm = (int *)calloc((size_t)nev + 1, sizeof(int));
    s->lockedFlags = (int *)calloc((size_t)nev + 1, sizeof(int));
+   if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap);
    if (rc || !s->H || !s->hVecs || !s->prevhVecs || !s->hVals || !s->prevRitzVals || !s->blockNorms ||
          !s->basisNorms || !s->flags || !s->map || !s->iev || !s->perm || !s->lockedFlags) {
       free_solver(s);

@@ -43,7 +43,7 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
       CHK(hipk_d2h(s->ctx, s->h_red + (d_buf - s->d_red), d_buf, (size_t)count * sizeof(double)));
       if (!defer_sync) CHK(hipk_sync(s->ctx));
    } else {
-      CHK(hipk_d2h(s->ctx, s->h_red + (d_buf - s->d_red), d_buf, (size_t)count * sizeof(double)));
+      /* the reduction kernels already stored the local sums in h_red (zero-copy mirror) */
       if (parallel) {
          CHK(hipk_sync(s->ctx));
          int ierr = 0, cnt = count;
@@ -167,8 +167,6 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
             CHK(pa_reduce(s, d_ov, ndot, 1, 0));
          } else if (parallel) {
             CHK(pa_reduce(s, d_ov, ndot, 1, 1));
-         } else {
-            CHK(hipk_d2h(s->ctx, s->h_red, d_ov, (size_t)ndot * sizeof(double)));
          }
          CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, d_ov, nov > 0 ? nov : 1, v, ldV, 1, d_s1));
          p->stats.numOrthoInnerProds += nov + 1;

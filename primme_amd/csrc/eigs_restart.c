@@ -214,10 +214,12 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
    if (!jobs) return PRIMME_MALLOC_FAILURE;
    int nj = 0;
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, VCOL(s, c), -1};
-   for (int c = 0; c < nb; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, nc + c, VCOL(s, rs + c), -1};
+   if (!s->fuse_gd)
+      for (int c = 0; c < nb; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, nc + c, VCOL(s, rs + c), -1};
    for (int c = 0; c < nc; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, ECOL(s, p->numOrthoConst + c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
-   for (int c = 0; c < nb; c++) jobs[nj++] = (hipk_job){HIPK_JOB_RES, nc + c, WCOL(s, rs + c), c};
+   for (int c = 0; c < nb; c++)
+      jobs[nj++] = (hipk_job){HIPK_JOB_RES, nc + c, s->fuse_gd ? VCOL(s, rs + c) : WCOL(s, rs + c), c};
    int rc = pa_ritz_update(s, basisSize, jobs, nj, blockNorms, nb, (int64_t)2 * rs + 2 * nb + nc);
    free(jobs);
    if (rc) return rc;
@@ -271,10 +273,12 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
    if (!jobs || !norms) return PRIMME_MALLOC_FAILURE;
    int nj = 0;
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, VCOL(s, c), -1};
-   for (int c = 0; c < sizeBlockNorms; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, X, s->ld, c), -1};
+   if (!s->fuse_gd)
+      for (int c = 0; c < sizeBlockNorms; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, X, s->ld, c), -1};
    for (int c = 0; c < numPacked; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, left + c, ECOL(s, *numLocked + nOC + c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
-   for (int c = 0; c < sizeBlockNorms; c++) jobs[nj++] = (hipk_job){HIPK_JOB_RES, c, PCOL(s, R, s->ld, c), c};
+   for (int c = 0; c < sizeBlockNorms; c++)
+      jobs[nj++] = (hipk_job){HIPK_JOB_RES, c, s->fuse_gd ? PCOL(s, X, s->ld, c) : PCOL(s, R, s->ld, c), c};
    for (int c = 0; c < numPacked; c++) jobs[nj++] = (hipk_job){HIPK_JOB_RES, left + c, NULL, sizeBlockNorms + c};
    int rc = pa_ritz_update(s, basisSize, jobs, nj, norms, sizeBlockNorms + numPacked,
          (int64_t)2 * rs + 2 * sizeBlockNorms + 2 * numPacked);
@@ -332,12 +336,13 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
       int io = 0, ifl = 0;
       for (int id = 0; id < nd; id++) {
          if (io < sizeBlockNorms && hVecsPerm[id] == io) {
-            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, X, s->ld, io), s->ld, TCOL(s, id), s->ld, 1));
-            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, R, s->ld, io), s->ld, TCOL(s, nd + id), s->ld, 1));
+            /* fused GD mode: the candidate's residual sits in the X slot and there is no X */
+            if (!s->fuse_gd) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, X, s->ld, io), s->ld, TCOL(s, id), s->ld, 1));
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, s->fuse_gd ? PCOL(s, X, s->ld, io) : PCOL(s, R, s->ld, io), s->ld, TCOL(s, nd + id), s->ld, 1));
             io++;
          } else if (ifl < failed) {
             const int src = left + ifailed[ifl];
-            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, VCOL(s, src), s->ld, TCOL(s, id), s->ld, 1));
+            if (!s->fuse_gd) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, VCOL(s, src), s->ld, TCOL(s, id), s->ld, 1));
             CHK(hipk_copy_cols(s->ctx, s->dt, s->m, WCOL(s, src), s->ld, TCOL(s, nd + id), s->ld, 1));
             double th = s->hVals[src];
             CHK(hipk_residual_cols(s->ctx, s->dt, s->m, VCOL(s, src), s->ld, TCOL(s, nd + id), s->ld, 1, &th, s->d_red));
@@ -355,8 +360,12 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
          }
       }
       if (nbuilt > 0) {
-         CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, VCOL(s, left + failed), s->ld, nbuilt));
-         CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, nd), s->ld, WCOL(s, left + failed), s->ld, nbuilt));
+         if (s->fuse_gd) {
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, nd), s->ld, VCOL(s, left + failed), s->ld, nbuilt));
+         } else {
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, VCOL(s, left + failed), s->ld, nbuilt));
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, nd), s->ld, WCOL(s, left + failed), s->ld, nbuilt));
+         }
       }
    }
 

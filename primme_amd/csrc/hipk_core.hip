@@ -121,7 +121,7 @@ extern "C" int hipk_timer_stop(hipk_ctx *ctx, float *ms) {
 /* ---- stage 2 of every reduction: one block per output, fixed summation order -- */
 __global__ void __launch_bounds__(HIPK_BLOCK)
 hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
-      double *__restrict__ out) {
+      double *__restrict__ out, double *__restrict__ out_host) {
    __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
    const int o = blockIdx.x;
    double s = 0.0;
@@ -129,15 +129,31 @@ hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
    s = hipk_wave_sum(s);
    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
    __syncthreads();
-   if (threadIdx.x == 0) out[o] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+   if (threadIdx.x == 0) {
+      const double v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      out[o] = v;
+      if (out_host) out_host[o] = v;
+   }
 }
 
 int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, int nout,
       double *out_dev) {
    if (nout <= 0) return 0;
    hipLaunchKernelGGL(hipk_finalize_kernel, dim3(nout), dim3(HIPK_BLOCK), 0, ctx->stream,
-         partials, nblocks, nout, out_dev);
+         partials, nblocks, nout, out_dev, hipk_mirror_of(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
+extern "C" int hipk_ctx_set_mirror(hipk_ctx *ctx, double *dev_base, double *pinned_host_base, size_t count) {
+   ctx->mirror_dev = dev_base;
+   ctx->mirror_count = count;
+   ctx->mirror_host = NULL;
+   if (dev_base && pinned_host_base) {
+      void *dp = NULL;
+      HIPK_CHECK(hipHostGetDevicePointer(&dp, pinned_host_base, 0));
+      ctx->mirror_host = (double *)dp;
+   }
    return 0;
 }
 

@@ -20,7 +20,18 @@ struct hipk_ctx {
    double *partials;     /* per-block partial sums of the two-stage reductions */
    size_t partials_cap;  /* in doubles */
    hipEvent_t ev0, ev1;
+   /* reduction results written into [mirror_dev, mirror_dev+mirror_count) are also
+    * stored by the finalize kernels into pinned host memory (zero-copy), so the host
+    * needs only a stream synchronisation, no device->host copy */
+   double *mirror_dev, *mirror_host;
+   size_t mirror_count;
 };
+
+static inline double *hipk_mirror_of(const hipk_ctx *ctx, const double *out_dev) {
+   if (ctx->mirror_dev && out_dev >= ctx->mirror_dev && out_dev < ctx->mirror_dev + ctx->mirror_count)
+      return ctx->mirror_host + (out_dev - ctx->mirror_dev);
+   return NULL;
+}
 
 #define HIPK_CHECK(call)                                                          \
    do {                                                                           \

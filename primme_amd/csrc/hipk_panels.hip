@@ -43,7 +43,7 @@ __device__ __forceinline__ const T *seg_col(const SegArgs &s, int j) {
 /* finalize with an output leading dimension: out[(o % nrows) + (o / nrows)*ldout] */
 __global__ void __launch_bounds__(HIPK_BLOCK)
 finalize_ld_kernel(const double *__restrict__ partials, int nblocks, int nout, int nrows,
-      int ldout, double *__restrict__ out) {
+      int ldout, double *__restrict__ out, double *__restrict__ out_host) {
    __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
    const int o = blockIdx.x;
    double s = 0.0;
@@ -51,7 +51,12 @@ finalize_ld_kernel(const double *__restrict__ partials, int nblocks, int nout, i
    s = hipk_wave_sum(s);
    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
    __syncthreads();
-   if (threadIdx.x == 0) out[(o % nrows) + (size_t)(o / nrows) * ldout] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+   if (threadIdx.x == 0) {
+      const double v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      const size_t at = (o % nrows) + (size_t)(o / nrows) * ldout;
+      out[at] = v;
+      if (out_host) out_host[at] = v;
+   }
 }
 
 /* ============================ TN: inner products ============================== */
@@ -130,7 +135,7 @@ static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X,
    hipk_prof_end(pslot, ctx->stream);
    HIPK_CHECK(hipGetLastError());
    hipLaunchKernelGGL(finalize_ld_kernel, dim3((unsigned)nout), dim3(HIPK_BLOCK), 0, ctx->stream,
-         ctx->partials, gx, (int)nout, sa.total, ldout, out_dev);
+         ctx->partials, gx, (int)nout, sa.total, ldout, out_dev, hipk_mirror_of(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
    return 0;
 }
