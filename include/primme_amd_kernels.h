@@ -103,6 +103,16 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
       int64_t ldVW, int k, const double *h_dev, int ldh, const double *theta_dev,
       const hipk_job *jobs, int njobs, double *nrm2_dev);
 
+/* ---- fused Ritz residual + first Gram-Schmidt pass (block size 1) -------------------
+ * dst = W*h - theta*V*h  and  out_dev[0..k+L] = [ V' dst | Q' dst | dst' dst ]  in ONE pass
+ * over V, W and Q (hcol_dev: DEVICE k coefficients; theta by value).  Replaces
+ * Num_update_VWXR (auxiliary_eigs_normal.c:155-388) + the Num_gemv_ddh/Num_dot of the first
+ * CGS pass (ortho.c:229-249) when the residual itself is the new basis vector (GD without
+ * preconditioner).  k <= 32, L <= 32. */
+int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
+      const void *W, int64_t ldVW, int k, const double *hcol_dev, double theta, void *dst,
+      const void *Q, int64_t ldQ, int L, double *out_dev);
+
 /* ---- column utilities ---------------------------------------------------------
  * Num_scal (cublas_wrapper.c:678), Num_axpy (:616), Num_copy_matrix (:739),
  * permute_vecs / Num_compact_vecs on device columns (auxiliary.c:716, :897). */

@@ -147,6 +147,27 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
    return 0;
 }
 
+/* r = W h - theta V h; out = [V'r | Q'r | r'r]  (Num_update_VWXR + first CGS pass dots) */
+int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
+      int64_t ld, int k, const double *hcol, double theta, void *dst, const void *Q, int64_t ldQ, int L,
+      double *out) {
+   (void)ctx;
+   for (int j = 0; j < k + L + 1; j++) out[j] = 0.0;
+   for (int64_t i = 0; i < m; i++) {
+      double x = 0, y = 0;
+      for (int j = 0; j < k; j++) { x += ld_(dt, colp(dt, V, ld, j), i) * hcol[j]; y += ld_(dt, colp(dt, W, ld, j), i) * hcol[j]; }
+      st_(dt, dst, i, y - theta * x);
+   }
+   for (int64_t i = 0; i < m; i++) {
+      const double r = ld_(dt, dst, i);
+      for (int j = 0; j < k; j++) out[j] += ld_(dt, colp(dt, V, ld, j), i) * r;
+      for (int q = 0; q < L; q++) out[k + q] += ld_(dt, colp(dt, Q, ldQ, q), i) * r;
+      out[k + L] += r * r;
+   }
+   mirror(out, (size_t)k + L + 1);
+   return 0;
+}
+
 int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx, const double *a) {
    (void)ctx;
    for (int c = 0; c < nx; c++) { void *x = (void *)colp(dt, X, ldX, c); for (int64_t i = 0; i < m; i++) st_(dt, x, i, a[c] * ld_(dt, x, i)); }

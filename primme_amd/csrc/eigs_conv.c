@@ -176,6 +176,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
     * writes X and R and then copies R over X, correction.c:378 with no preconditioner) */
    const int fused = s->fuse_gd && computeXR;
    if (fused) { R = X; X = NULL; }
+   s->fov_valid = 0;   /* only overlaps computed in THIS call, for the candidate that stays, may be reused */
    int *flagsBlock = (int *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(int));
    double *hValsBlock = (double *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(double));
    hipk_job *jobs = (hipk_job *)malloc((size_t)(2 * maxBlockSize + 2) * sizeof(hipk_job));
@@ -246,18 +247,35 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
 
       /* X = V h, R = W h - X theta, norms — one fused pass over V and W */
       if ((rc = pa_push_coefficients(s, basisSize, ldh))) goto out;
-      int nj = 0;
-      for (int c = 0; c < blockNormsSize; c++) {
-         const int col = iev[*blockSize + c];
-         if (computeXR) {
-            if (X) jobs[nj++] = (hipk_job){HIPK_JOB_XV, col, PCOL(s, X, s->ld, *blockSize + c), -1};
-            jobs[nj++] = (hipk_job){HIPK_JOB_RES, col, PCOL(s, R, s->ld, *blockSize + c), c};
-         } else {
-            jobs[nj++] = (hipk_job){HIPK_JOB_RES, col, NULL, c};
+      const int nLk = p->numOrthoConst + numLocked;
+      if (fused && p->maxBlockSize == 1 && blockNormsSize == 1 && basisSize <= 32 && nLk <= 32) {
+         /* block size 1, GD without preconditioner: the residual is the next basis vector, so
+          * the same pass also delivers the first Gram-Schmidt pass' overlaps [V'r | Q'r | r'r] */
+         const int col = iev[*blockSize];
+         char *dstc = PCOL(s, R, s->ld, *blockSize);
+         double t0 = pa_wtime();
+         if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
+                    s->d_coef + (size_t)col * s->K, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, s->d_fov))) goto out;
+         if ((rc = pa_reduce(s, s->d_fov, basisSize + nLk + 1, 1, 0))) goto out;
+         blockNorms[*blockSize] = sqrt(s->h_fov[basisSize + nLk]);
+         s->fov_valid = 1; s->fov_k = basisSize; s->fov_L = nLk; s->fov_col = dstc;
+         p->stats.timeDense += pa_wtime() - t0;
+         p->stats.flopsDense += (double)s->m * 2.0 * basisSize;
+      } else {
+         s->fov_valid = 0;
+         int nj = 0;
+         for (int c = 0; c < blockNormsSize; c++) {
+            const int col = iev[*blockSize + c];
+            if (computeXR) {
+               if (X) jobs[nj++] = (hipk_job){HIPK_JOB_XV, col, PCOL(s, X, s->ld, *blockSize + c), -1};
+               jobs[nj++] = (hipk_job){HIPK_JOB_RES, col, PCOL(s, R, s->ld, *blockSize + c), c};
+            } else {
+               jobs[nj++] = (hipk_job){HIPK_JOB_RES, col, NULL, c};
+            }
          }
+         if ((rc = pa_ritz_update(s, basisSize, jobs, nj, &blockNorms[*blockSize], blockNormsSize,
+                    (int64_t)2 * blockNormsSize))) goto out;
       }
-      if ((rc = pa_ritz_update(s, basisSize, jobs, nj, &blockNorms[*blockSize], blockNormsSize,
-                 (int64_t)2 * blockNormsSize))) goto out;
       /* do not trust residual norms below the error already accumulated in V, W.
        * (the reference's loop bounds, main_iter.c:1686-1688, are kept literally) */
       for (int i = *blockSize; i < blockNormsSize; i++)

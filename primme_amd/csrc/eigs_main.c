@@ -671,9 +671,9 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    const size_t colBytes = (size_t)(s->ld > 0 ? s->ld : 1) * s->es;
    rc = hipk_malloc(s->ctx, colBytes * K, (void **)&s->V) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W) ||
         hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
-        hipk_malloc(s->ctx, (size_t)s->red_cap * 8, (void **)&s->d_red) ||
+        hipk_malloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->d_red) ||
         hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
-        hipk_host_alloc(s->ctx, (size_t)s->red_cap * 8, (void **)&s->h_red) ||
+        hipk_host_alloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->h_red) ||
         hipk_host_alloc(s->ctx, (size_t)K * K * 8, (void **)&s->h_coef) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta);
    s->H = (double *)calloc((size_t)K * K, 8); s->hVecs = (double *)calloc((size_t)K * K, 8);
    s->prevhVecs = (double *)calloc((size_t)K * K, 8); s->hVals = (double *)calloc((size_t)K, 8);
@@ -682,7 +682,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->flags = (int *)calloc((size_t)K, sizeof(int)); s->map = (int *)calloc((size_t)K, sizeof(int));
    s->iev = (int *)calloc((size_t)K + b, sizeof(int)); s->perm = (int *)calloc((size_t)nev + 1, sizeof(int));
    s->lockedFlags = (int *)calloc((size_t)nev + 1, sizeof(int));
-   if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap);
+   if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap * 2);
+   if (!rc) { s->d_fov = s->d_red + s->red_cap; s->h_fov = s->h_red + s->red_cap; }
    if (rc || !s->H || !s->hVecs || !s->prevhVecs || !s->hVals || !s->prevRitzVals || !s->blockNorms ||
          !s->basisNorms || !s->flags || !s->map || !s->iev || !s->perm || !s->lockedFlags) {
       free_solver(s);

@@ -99,6 +99,7 @@ int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc)
 
 /* random column (reference blaslapack.c:938-988 Num_larnv: host xLARNV then upload) */
 int pa_random_col(pa_solver *s, char *col) {
+   s->fov_valid = 0;
    double *tmp = (double *)malloc((size_t)(s->m > 0 ? s->m : 1) * sizeof(double));
    if (!tmp) return PRIMME_MALLOC_FAILURE;
    pa_larnv_uniform11(s->p->iseed, s->m, tmp);
@@ -160,22 +161,31 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
          const int nov = i + numLocked;           /* overlaps proper                  */
          const int ndot = nov + (first ? 1 : 0);  /* + |v|^2 on the first pass        */
          hipk_seg segs[3] = {{Vp, ldV, i}, {locked, ldLocked, numLocked}, {v, ldV, first ? 1 : 0}};
-         double *d_ov = s->d_red, *d_s1 = s->d_red + nov + 1;
-         CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segs, 3, v, ldV, 1, d_ov, ndot));
-         p->stats.numOrthoInnerProds += ndot;
-         if (parallel && !s->dev_comm) {
-            CHK(pa_reduce(s, d_ov, ndot, 1, 0));
-         } else if (parallel) {
-            CHK(pa_reduce(s, d_ov, ndot, 1, 1));
+         /* overlaps of the first pass may already be there: the fused residual kernel computed
+          * [Vp' v | locked' v | v'v] while it produced v (eigs_conv.c) */
+         const int use_fov = first && randomizations == 0 && s->fov_valid && Vp == s->V && v == s->fov_col &&
+                             i == s->fov_k && numLocked == s->fov_L && (numLocked == 0 || locked == s->evecs);
+         double *dbase = use_fov ? s->d_fov : s->d_red;
+         double *hbase = use_fov ? s->h_fov : s->h_red;
+         double *d_ov = dbase, *d_s1 = dbase + nov + 1;
+         if (first) s->fov_valid = 0;
+         if (!use_fov) {
+            CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segs, 3, v, ldV, 1, d_ov, ndot));
+            if (parallel && !s->dev_comm) {
+               CHK(pa_reduce(s, d_ov, ndot, 1, 0));
+            } else if (parallel) {
+               CHK(pa_reduce(s, d_ov, ndot, 1, 1));
+            }
          }
+         p->stats.numOrthoInnerProds += ndot;
          CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, d_ov, nov > 0 ? nov : 1, v, ldV, 1, d_s1));
          p->stats.numOrthoInnerProds += nov + 1;
-         CHK(pa_reduce(s, d_s1, 1, 0, 0)); /* synchronises: h_red now has overlaps, s02, s12 */
+         CHK(pa_reduce(s, d_s1, 1, 0, 0)); /* synchronises: hbase now has overlaps, s02, s12 */
 
          if (updateR)
-            for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += s->h_red[i + j];
-         if (first) { s02 = s->h_red[nov]; s0 = sqrt(s02); }
-         s12 = s->h_red[nov + 1];
+            for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += hbase[i + j];
+         if (first) { s02 = hbase[nov]; s0 = sqrt(s02); }
+         s12 = hbase[nov + 1];
          s1 = sqrt(s12);
 
          if (!isfinite(s0) || !isfinite(s1) || s1 <= eps_orth * s0) {

@@ -419,6 +419,7 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
    primme_params *p = s->p;
    const int ldh = basisSize;
    int i, restartSize;
+   s->fov_valid = 0;
 
    for (i = 0, *numConverged = *numLocked; i < basisSize; i++) {
       if (flags[i] == SKIP_RESTART) flags[i] = UNCONV;

@@ -43,6 +43,10 @@ typedef struct pa_solver {
 
    int dev_comm;           /* reductions run on the device through RCCL */
    int phase_timing;       /* primme->profile != NULL: sync after phases to time them */
+   /* first-pass CGS overlaps produced by the fused residual kernel (block size 1) */
+   double *d_fov, *h_fov;
+   int fov_valid, fov_k, fov_L;
+   char *fov_col;
    int fuse_gd;            /* GD without preconditioner/Olsen: residual written straight into V */
    int coef_valid_k;       /* d_coef/d_theta currently hold hVecs/hVals of this size, or -1 */
    double startTime;

@@ -33,6 +33,22 @@ static int pack_segs(const hipk_seg *segs, int nseg, SegArgs *a) {
    return 0;
 }
 
+/* 16-byte lane accesses: VW consecutive rows per lane (2 doubles / 4 floats) when every
+ * column involved is 16-byte aligned, VW = 1 otherwise */
+template <typename T, int VW> struct lanevec { T e[VW]; };
+template <> struct __attribute__((aligned(16))) lanevec<double, 2> { double e[2]; };
+template <> struct __attribute__((aligned(16))) lanevec<float, 4> { float e[4]; };
+template <typename T> struct vecwidth { enum { value = 16 / sizeof(T) }; };
+
+static inline bool aligned16(const void *p, int64_t ld, size_t es) {
+   return (((uintptr_t)p) & 15) == 0 && ((ld * (int64_t)es) & 15) == 0;
+}
+static bool segs_aligned16(const SegArgs &a, size_t es) {
+   for (int s = 0; s < HIPK_MAX_SEGS; s++)
+      if (a.n[s] > 0 && !aligned16(a.base[s], a.ld[s], es)) return false;
+   return true;
+}
+
 template <typename T>
 __device__ __forceinline__ const T *seg_col(const SegArgs &s, int j) {
    int q = 0;
@@ -60,10 +76,11 @@ finalize_ld_kernel(const double *__restrict__ partials, int nblocks, int nout, i
 }
 
 /* ============================ TN: inner products ============================== */
-template <typename T, int NC, int NX>
+template <typename T, int NC, int NX, int VW>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 dots_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int64_t m,
       double *__restrict__ partials) {
+   typedef lanevec<T, VW> LV;
    const int j0 = blockIdx.y * NC;             /* first basis column of this chunk */
    const int c0 = blockIdx.z * NX;             /* first right-hand column          */
    const int ncv = min(NC, segs.total - j0);
@@ -80,16 +97,35 @@ dots_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int64_t 
       for (int c = 0; c < NX; c++) acc[jj][c] = 0.0;
 
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
-   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
-      double xv[NX], a[NC];
+   const int64_t mg = m / VW;                   /* full lane groups */
+   for (int64_t g = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; g < mg; g += stride) {
+      LV xv[NX], a[NC];
 #pragma unroll
-      for (int c = 0; c < NX; c++) xv[c] = (c < nxv) ? (double)xp[i + (size_t)c * ldX] : 0.0;
-#pragma unroll
-      for (int jj = 0; jj < NC; jj++) a[jj] = (jj < ncv) ? (double)cp[jj][i] : 0.0;
+      for (int c = 0; c < NX; c++)
+         if (c < nxv) xv[c] = ((const LV *)(xp + (size_t)c * ldX))[g];
 #pragma unroll
       for (int jj = 0; jj < NC; jj++)
+         if (jj < ncv) a[jj] = ((const LV *)cp[jj])[g];
 #pragma unroll
-         for (int c = 0; c < NX; c++) acc[jj][c] = fma(a[jj], xv[c], acc[jj][c]);
+      for (int jj = 0; jj < NC; jj++)
+         if (jj < ncv) {
+#pragma unroll
+            for (int c = 0; c < NX; c++)
+               if (c < nxv) {
+#pragma unroll
+                  for (int r = 0; r < VW; r++) acc[jj][c] = fma((double)a[jj].e[r], (double)xv[c].e[r], acc[jj][c]);
+               }
+         }
+   }
+   if (VW > 1 && blockIdx.x == 0 && threadIdx.x < (unsigned)(m - mg * VW)) {   /* ragged tail rows */
+      const int64_t i = mg * VW + threadIdx.x;
+#pragma unroll
+      for (int jj = 0; jj < NC; jj++)
+         if (jj < ncv) {
+#pragma unroll
+            for (int c = 0; c < NX; c++)
+               if (c < nxv) acc[jj][c] = fma((double)cp[jj][i], (double)xp[i + (size_t)c * ldX], acc[jj][c]);
+         }
    }
 
    __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NC * NX];
@@ -112,26 +148,36 @@ dots_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int64_t 
    }
 }
 
+template <typename T, int VW>
+static void dots_launch(hipk_ctx *ctx, dim3 grid, int nxt, const SegArgs &sa, const T *X, int64_t ldX,
+      int nx, int64_t m) {
+   dim3 block(HIPK_BLOCK);
+   switch (nxt) {
+   case 1: hipLaunchKernelGGL((dots_kernel<T, 8, 1, VW>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
+   case 2: hipLaunchKernelGGL((dots_kernel<T, 8, 2, VW>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
+   case 4: hipLaunchKernelGGL((dots_kernel<T, 8, 4, VW>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
+   default: hipLaunchKernelGGL((dots_kernel<T, 8, 8, VW>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
+   }
+}
+
 template <typename T>
 static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X, int64_t ldX,
       int nx, double *out_dev, int ldout) {
    const int NC = 8;
    int nxt = nx <= 1 ? 1 : nx <= 2 ? 2 : nx <= 4 ? 4 : 8;
-   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   const bool vec = segs_aligned16(sa, sizeof(T)) && aligned16(X, ldX, sizeof(T));
+   const int VWm = vec ? (int)vecwidth<T>::value : 1;
+   int gx = hipk_grid_for_rows(ctx, m / VWm + 1, HIPK_BLOCK * 2, 4);
    int gy = (sa.total + NC - 1) / NC;
    int gz = (nx + nxt - 1) / nxt;
    /* keep the chip full when the chunk grid is already wide */
    while (gx > 1 && (int64_t)gx * gy * gz > (int64_t)ctx->num_cu * 8) gx = (gx + 1) / 2;
    size_t nout = (size_t)sa.total * nx;
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
-   dim3 grid(gx, gy, gz), block(HIPK_BLOCK);
+   dim3 grid(gx, gy, gz);
    const int pslot = hipk_prof_begin(HIPK_PROF_DOTS, ctx->stream, (double)m * sizeof(T) * (sa.total + nx));
-   switch (nxt) {
-   case 1: hipLaunchKernelGGL((dots_kernel<T, 8, 1>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
-   case 2: hipLaunchKernelGGL((dots_kernel<T, 8, 2>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
-   case 4: hipLaunchKernelGGL((dots_kernel<T, 8, 4>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
-   default: hipLaunchKernelGGL((dots_kernel<T, 8, 8>), grid, block, 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials); break;
-   }
+   if (vec) dots_launch<T, vecwidth<T>::value>(ctx, grid, nxt, sa, X, ldX, nx, m);
+   else dots_launch<T, 1>(ctx, grid, nxt, sa, X, ldX, nx, m);
    hipk_prof_end(pslot, ctx->stream);
    HIPK_CHECK(hipGetLastError());
    hipLaunchKernelGGL(finalize_ld_kernel, dim3((unsigned)nout), dim3(HIPK_BLOCK), 0, ctx->stream,
@@ -155,10 +201,11 @@ extern "C" int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hi
 
 /* ===================== NN-accumulate: project + norms ========================= */
 #define PROJ_MAXCOLS 192
-template <typename T, int NX>
+template <typename T, int NX, int VW>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__restrict__ X,
       int64_t ldX, int nx, int c0, int64_t m, double *__restrict__ partials) {
+   typedef lanevec<T, VW> LV;
    __shared__ double scoef[PROJ_MAXCOLS * NX];
    __shared__ const T *sptr[PROJ_MAXCOLS];
    const int total = segs.total;
@@ -176,32 +223,65 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__r
    for (int c = 0; c < NX; c++) n2[c] = 0.0;
 
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
-   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
-      double xv[NX];
+   const int64_t mg = m / VW;
+   for (int64_t g = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; g < mg; g += stride) {
+      double xv[NX][VW];
 #pragma unroll
-      for (int c = 0; c < NX; c++) xv[c] = (c < nxv) ? (double)xp[i + (size_t)c * ldX] : 0.0;
+      for (int c = 0; c < NX; c++) {
+         if (c < nxv) {
+            LV t = ((const LV *)(xp + (size_t)c * ldX))[g];
+#pragma unroll
+            for (int r = 0; r < VW; r++) xv[c][r] = (double)t.e[r];
+         } else {
+#pragma unroll
+            for (int r = 0; r < VW; r++) xv[c][r] = 0.0;
+         }
+      }
       int j = 0;
       for (; j + 8 <= total; j += 8) {
-         double a[8];
+         LV a[8];
 #pragma unroll
-         for (int u = 0; u < 8; u++) a[u] = (double)sptr[j + u][i];
+         for (int u = 0; u < 8; u++) a[u] = ((const LV *)sptr[j + u])[g];
 #pragma unroll
          for (int u = 0; u < 8; u++)
 #pragma unroll
-            for (int c = 0; c < NX; c++) xv[c] = fma(-a[u], scoef[(j + u) * NX + c], xv[c]);
+            for (int c = 0; c < NX; c++) {
+               const double cf = scoef[(j + u) * NX + c];
+#pragma unroll
+               for (int r = 0; r < VW; r++) xv[c][r] = fma(-(double)a[u].e[r], cf, xv[c][r]);
+            }
       }
       for (; j < total; j++) {
-         double a = (double)sptr[j][i];
+         LV a = ((const LV *)sptr[j])[g];
 #pragma unroll
-         for (int c = 0; c < NX; c++) xv[c] = fma(-a, scoef[j * NX + c], xv[c]);
+         for (int c = 0; c < NX; c++) {
+            const double cf = scoef[j * NX + c];
+#pragma unroll
+            for (int r = 0; r < VW; r++) xv[c][r] = fma(-(double)a.e[r], cf, xv[c][r]);
+         }
       }
 #pragma unroll
       for (int c = 0; c < NX; c++)
          if (c < nxv) {
-            T out = (T)xv[c];
-            xp[i + (size_t)c * ldX] = out;
-            n2[c] = fma((double)out, (double)out, n2[c]);
+            LV o;
+#pragma unroll
+            for (int r = 0; r < VW; r++) {
+               o.e[r] = (T)xv[c][r];
+               n2[c] = fma((double)o.e[r], (double)o.e[r], n2[c]);
+            }
+            ((LV *)(xp + (size_t)c * ldX))[g] = o;
          }
+   }
+   if (VW > 1 && blockIdx.x == 0 && threadIdx.x < (unsigned)(m - mg * VW)) {   /* ragged tail rows */
+      const int64_t i = mg * VW + threadIdx.x;
+      for (int c = 0; c < nxv; c++) {
+         double v = (double)xp[i + (size_t)c * ldX];
+         for (int j = 0; j < total; j++) v = fma(-(double)sptr[j][i], scoef[j * NX + c], v);
+         T o = (T)v;
+         xp[i + (size_t)c * ldX] = o;
+#pragma unroll
+         for (int cc = 0; cc < NX; cc++) if (cc == c) n2[cc] = fma((double)o, (double)o, n2[cc]);
+      }
    }
    if (partials) {
       __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NX];
@@ -218,11 +298,10 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__r
    }
 }
 
-template <typename T>
-static int panel_project_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const double *coef,
+template <typename T, int VW>
+static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const double *coef,
       int ldcoef, T *X, int64_t ldX, int nx, double *nrm2_dev) {
-   if (sa.total > PROJ_MAXCOLS) return -1;
-   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   int gx = hipk_grid_for_rows(ctx, m / VW + 1, HIPK_BLOCK * 2, 4);
    if (nrm2_dev && hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
    double *part = nrm2_dev ? ctx->partials : NULL;
    dim3 block(HIPK_BLOCK);
@@ -230,16 +309,25 @@ static int panel_project_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
    for (int c0 = 0; c0 < nx;) {
       int rem = nx - c0;
       int step;
-      if (rem >= 8) { step = 8; hipLaunchKernelGGL((project_kernel<T, 8>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
-      else if (rem >= 4) { step = 4; hipLaunchKernelGGL((project_kernel<T, 4>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
-      else if (rem >= 2) { step = 2; hipLaunchKernelGGL((project_kernel<T, 2>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
-      else { step = 1; hipLaunchKernelGGL((project_kernel<T, 1>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      if (rem >= 8) { step = 8; hipLaunchKernelGGL((project_kernel<T, 8, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      else if (rem >= 4) { step = 4; hipLaunchKernelGGL((project_kernel<T, 4, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      else if (rem >= 2) { step = 2; hipLaunchKernelGGL((project_kernel<T, 2, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      else { step = 1; hipLaunchKernelGGL((project_kernel<T, 1, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
       HIPK_CHECK(hipGetLastError());
       c0 += step;
    }
    hipk_prof_end(pslot, ctx->stream);
    if (nrm2_dev) return hipk_finalize_partials(ctx, ctx->partials, gx, nx, nrm2_dev);
    return 0;
+}
+
+template <typename T>
+static int panel_project_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const double *coef,
+      int ldcoef, T *X, int64_t ldX, int nx, double *nrm2_dev) {
+   if (sa.total > PROJ_MAXCOLS) return -1;
+   if (segs_aligned16(sa, sizeof(T)) && aligned16(X, ldX, sizeof(T)))
+      return panel_project_v<T, vecwidth<T>::value>(ctx, m, sa, coef, ldcoef, X, ldX, nx, nrm2_dev);
+   return panel_project_v<T, 1>(ctx, m, sa, coef, ldcoef, X, ldX, nx, nrm2_dev);
 }
 
 extern "C" int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs,
@@ -265,7 +353,10 @@ struct RitzArgs {
    void *xv_dst[RITZ_MAXOUT], *xw_dst[RITZ_MAXOUT], *res_dst[RITZ_MAXRES];
 };
 
-template <typename T, int NK, int NR>
+/* PRE: load the V row AND the W row before computing anything (2*NK registers): twice the
+ * loads in flight per lane, which is what makes this kernel bandwidth- instead of latency-bound
+ * (measured 3.0 -> see profiles/; used for NK <= 32).  !PRE: two phases sharing one row buffer. */
+template <typename T, int NK, int NR, bool PRE>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
       const double *__restrict__ h, int ldh, int nh, const double *__restrict__ theta,
@@ -282,14 +373,19 @@ ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
    double n2[NR];
 #pragma unroll
    for (int r = 0; r < NR; r++) n2[r] = 0.0;
+   const bool needW = (ja.nxw > 0 || ja.nres > 0);
 
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
    for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
       double row[NK];
+      double roww[PRE ? NK : 1];
       double xres[NR];
-      /* phase A: the V row */
 #pragma unroll
       for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)V[i + (size_t)j * ld] : 0.0;
+      if (PRE && needW) {
+#pragma unroll
+         for (int j = 0; j < NK; j++) roww[PRE ? j : 0] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+      }
 #pragma unroll
       for (int r = 0; r < NR; r++) {
          xres[r] = 0.0;
@@ -308,15 +404,16 @@ ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
          for (int j = 0; j < NK; j++) s = fma(row[j], hc[j], s);
          ((T *)ja.xv_dst[o])[i] = (T)s;
       }
-      /* phase B: the W row (only if something needs it) */
-      if (ja.nxw > 0 || ja.nres > 0) {
+      if (needW) {
+         if (!PRE) {
 #pragma unroll
-         for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+            for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+         }
          for (int o = 0; o < ja.nxw; o++) {
             const double *hc = hs + (int)ja.xw_col[o] * NK;
             double s = 0.0;
 #pragma unroll
-            for (int j = 0; j < NK; j++) s = fma(row[j], hc[j], s);
+            for (int j = 0; j < NK; j++) s = fma(PRE ? roww[PRE ? j : 0] : row[j], hc[j], s);
             ((T *)ja.xw_dst[o])[i] = (T)s;
          }
 #pragma unroll
@@ -325,7 +422,7 @@ ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
                const double *hc = hs + (int)ja.res_col[r] * NK;
                double s = 0.0;
 #pragma unroll
-               for (int j = 0; j < NK; j++) s = fma(row[j], hc[j], s);
+               for (int j = 0; j < NK; j++) s = fma(PRE ? roww[PRE ? j : 0] : row[j], hc[j], s);
                T res = (T)fma(-th[r], xres[r], s);
                if (ja.res_dst[r]) ((T *)ja.res_dst[r])[i] = res;
                n2[r] = fma((double)res, (double)res, n2[r]);
@@ -347,17 +444,29 @@ ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
    }
 }
 
-template <typename T, int NK>
+template <typename T, int NK, bool PRE>
 static int ritz_launch_nk(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
       const double *h, int ldh, int nh, const double *theta, const RitzArgs &ja, int gx,
       int nslots) {
    size_t shm = (size_t)NK * nh * sizeof(double);
    if (ja.nres <= 4)
-      hipLaunchKernelGGL((ritz_kernel<T, NK, 4>), dim3(gx), dim3(HIPK_BLOCK), shm, ctx->stream, V, W, ld, k, h, ldh, nh, theta, ja, m, ctx->partials, nslots);
+      hipLaunchKernelGGL((ritz_kernel<T, NK, 4, PRE>), dim3(gx), dim3(HIPK_BLOCK), shm, ctx->stream, V, W, ld, k, h, ldh, nh, theta, ja, m, ctx->partials, nslots);
    else
-      hipLaunchKernelGGL((ritz_kernel<T, NK, RITZ_MAXRES>), dim3(gx), dim3(HIPK_BLOCK), shm, ctx->stream, V, W, ld, k, h, ldh, nh, theta, ja, m, ctx->partials, nslots);
+      hipLaunchKernelGGL((ritz_kernel<T, NK, RITZ_MAXRES, PRE>), dim3(gx), dim3(HIPK_BLOCK), shm, ctx->stream, V, W, ld, k, h, ldh, nh, theta, ja, m, ctx->partials, nslots);
    HIPK_CHECK(hipGetLastError());
    return 0;
+}
+
+template <typename T>
+static int ritz_dispatch(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
+      const double *h, int ldh, int nh, const double *theta, const RitzArgs &ja, int gx, int nslots) {
+   if (k <= 8) return ritz_launch_nk<T, 8, true>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   if (k <= 16) return ritz_launch_nk<T, 16, true>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   if (k <= 24) return ritz_launch_nk<T, 24, true>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   if (k <= 32) return ritz_launch_nk<T, 32, true>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   if (k <= 48) return ritz_launch_nk<T, 48, false>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   if (k <= 64) return ritz_launch_nk<T, 64, false>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   return -1;
 }
 
 template <typename T>
@@ -393,14 +502,7 @@ static int ritz_update_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64
    }
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream,
          (double)m * sizeof(T) * ((double)k * (1 + ((ja.nxw > 0 || ja.nres > 0) ? 1 : 0)) + ja.nxv + ja.nxw + ja.nres));
-   int rc;
-   if (k <= 8) rc = ritz_launch_nk<T, 8>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
-   else if (k <= 16) rc = ritz_launch_nk<T, 16>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
-   else if (k <= 24) rc = ritz_launch_nk<T, 24>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
-   else if (k <= 32) rc = ritz_launch_nk<T, 32>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
-   else if (k <= 48) rc = ritz_launch_nk<T, 48>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
-   else if (k <= 64) rc = ritz_launch_nk<T, 64>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
-   else rc = -1;
+   int rc = ritz_dispatch<T>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
    hipk_prof_end(pslot, ctx->stream);
    if (rc) return rc;
    if (nslots > 0) return hipk_finalize_partials(ctx, ctx->partials, gx, nslots, nrm2_dev);
@@ -413,6 +515,104 @@ extern "C" int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
    switch (dt) {
    case HIPK_F64: return ritz_update_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev);
    case HIPK_F32: return ritz_update_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev);
+   default: return -44;
+   }
+}
+
+/* ============ fused Ritz residual + first-pass Gram-Schmidt overlaps (b = 1) ============
+ * r = W h - theta V h (written to dst), out = [ V' r | Q' r | r' r ].
+ * In Generalized Davidson without preconditioner the residual IS the new basis vector, and
+ * the V and W rows needed for r are exactly the rows the first classical Gram-Schmidt pass
+ * would stream again for V' r (reference: Num_update_VWXR, auxiliary_eigs_normal.c:155-388,
+ * followed by Num_gemv_ddh in ortho.c:236-246).  Fusing them removes one full pass over V
+ * per outer iteration; the locked vectors Q are streamed here instead of in the dots launch.
+ */
+template <typename T, int NK, int NL>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
+      const double *__restrict__ hcol, double theta, T *__restrict__ dst, const T *__restrict__ Q,
+      int64_t ldQ, int L, int64_t m, double *__restrict__ partials) {
+   __shared__ double hs[NK];
+   if (threadIdx.x < NK) hs[threadIdx.x] = (threadIdx.x < k) ? hcol[threadIdx.x] : 0.0;
+   __syncthreads();
+   double ov[NK], oq[NL > 0 ? NL : 1], n2 = 0.0;
+#pragma unroll
+   for (int j = 0; j < NK; j++) ov[j] = 0.0;
+#pragma unroll
+   for (int q = 0; q < NL; q++) oq[q] = 0.0;
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      double v[NK], w[NK], qv[NL > 0 ? NL : 1];
+#pragma unroll
+      for (int j = 0; j < NK; j++) v[j] = (j < k) ? (double)V[i + (size_t)j * ld] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NK; j++) w[j] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+#pragma unroll
+      for (int q = 0; q < NL; q++) qv[q] = (q < L) ? (double)Q[i + (size_t)q * ldQ] : 0.0;
+      double x = 0.0, y = 0.0;
+#pragma unroll
+      for (int j = 0; j < NK; j++) { x = fma(v[j], hs[j], x); y = fma(w[j], hs[j], y); }
+      const T rt = (T)fma(-theta, x, y);
+      dst[i] = rt;
+      const double r = (double)rt;
+      n2 = fma(r, r, n2);
+#pragma unroll
+      for (int j = 0; j < NK; j++) ov[j] = fma(v[j], r, ov[j]);
+#pragma unroll
+      for (int q = 0; q < NL; q++) oq[q] = fma(qv[q], r, oq[q]);
+   }
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NK + NL + 1];
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+   for (int j = 0; j < NK; j++) { double t = hipk_wave_sum(ov[j]); if (lane == 0) sm[wv][j] = t; }
+#pragma unroll
+   for (int q = 0; q < NL; q++) { double t = hipk_wave_sum(oq[q]); if (lane == 0) sm[wv][NK + q] = t; }
+   { double t = hipk_wave_sum(n2); if (lane == 0) sm[wv][NK + NL] = t; }
+   __syncthreads();
+   const int nout = k + L + 1;
+   if (threadIdx.x < nout) {
+      const int src = threadIdx.x < k ? threadIdx.x : (threadIdx.x < k + L ? NK + (threadIdx.x - k) : NK + NL);
+      partials[(size_t)blockIdx.x * nout + threadIdx.x] = (sm[0][src] + sm[1][src]) + (sm[2][src] + sm[3][src]);
+   }
+}
+
+template <typename T, int NK>
+static int ritz_cgs_nk(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const double *hcol,
+      double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m) {
+   dim3 g(gx), b(HIPK_BLOCK);
+   if (L == 0) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 0>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+   else if (L <= 8) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 8>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+   else if (L <= 16) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 16>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+   else if (L <= 32) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 32>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+   else return -1;
+   HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
+template <typename T>
+static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
+      const double *hcol, double theta, T *dst, const T *Q, int64_t ldQ, int L, double *out_dev) {
+   if (k <= 0 || k > 32 || L < 0 || L > 32) return -1;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4);
+   const int nout = k + L + 1;
+   if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
+   const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + 1));
+   int rc;
+   if (k <= 8) rc = ritz_cgs_nk<T, 8>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   else if (k <= 16) rc = ritz_cgs_nk<T, 16>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   else if (k <= 24) rc = ritz_cgs_nk<T, 24>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   else rc = ritz_cgs_nk<T, 32>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   hipk_prof_end(pslot, ctx->stream);
+   if (rc) return rc;
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nout, out_dev);
+}
+
+extern "C" int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
+      const void *W, int64_t ldVW, int k, const double *hcol_dev, double theta, void *dst,
+      const void *Q, int64_t ldQ, int L, double *out_dev) {
+   switch (dt) {
+   case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, hcol_dev, theta, (double *)dst, (const double *)Q, ldQ, L, out_dev);
+   case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, hcol_dev, theta, (float *)dst, (const float *)Q, ldQ, L, out_dev);
    default: return -44;
    }
 }

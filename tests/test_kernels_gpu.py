@@ -145,6 +145,33 @@ def test_ritz_update_many_residuals(built, dt):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("m,k,L", [(1001, 1, 0), (70001, 7, 3), (250000, 15, 10), (99999, 30, 20)])
+def test_ritz_residual_overlaps(built, dt, m, k, L):
+    """fused residual + first Gram-Schmidt pass: r = W h - theta V h, out = [V'r | Q'r | r'r]"""
+    rng = np.random.default_rng(m + k + L)
+    npdt = NPDT[dt]
+    ld, ldq = m + 2, m + 5
+    V = rng.standard_normal((k + 1, ld)).astype(npdt)
+    W = rng.standard_normal((k + 1, ld)).astype(npdt)
+    Q = rng.standard_normal((max(L, 1), ldq)).astype(npdt)
+    h = rng.standard_normal(k) / np.sqrt(k)
+    theta = 0.37
+    res = []
+    for side in (Dev(), Host()):
+        v, w, q, hh = side.arr(V), side.arr(W), side.arr(Q), side.arr(h)
+        out = side.arr(np.zeros(k + L + 1))
+        rc = side.lib.hipk_ritz_residual_overlaps(side.ctx, dt, m, side.ptr(v), side.ptr(w), ld, k, side.ptr(hh),
+                                                  C.c_double(theta), side.ptr(v, k * ld), side.ptr(q), ldq, L, side.ptr(out))
+        assert rc == 0
+        res.append((side.get(v)[k, :m], side.get(out)))
+        side.close()
+    tol = 1e-12 if dt == F.HIPK_F64 else 1e-4
+    assert np.max(np.abs(res[0][0] - res[1][0])) <= tol * 10
+    scale = np.sqrt(m) * 4
+    assert np.max(np.abs(res[0][1] - res[1][1])) <= tol * scale * max(1.0, np.abs(res[1][1]).max() / scale)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
 def test_column_utilities(built, dt):
     rng = np.random.default_rng(11)
     npdt = NPDT[dt]
