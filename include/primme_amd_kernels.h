@@ -105,12 +105,12 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
 
 /* ---- fused Ritz residual + first Gram-Schmidt pass (block size 1) -------------------
  * dst = W*h - theta*V*h  and  out_dev[0..k+L] = [ V' dst | Q' dst | dst' dst ]  in ONE pass
- * over V, W and Q (hcol_dev: DEVICE k coefficients; theta by value).  Replaces
+ * over V, W and Q (hcol_host: k coefficients on the HOST, passed in the kernel arguments; theta by value).  Replaces
  * Num_update_VWXR (auxiliary_eigs_normal.c:155-388) + the Num_gemv_ddh/Num_dot of the first
  * CGS pass (ortho.c:229-249) when the residual itself is the new basis vector (GD without
  * preconditioner).  k <= 32, L <= 32. */
 int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
-      const void *W, int64_t ldVW, int k, const double *hcol_dev, double theta, void *dst,
+      const void *W, int64_t ldVW, int k, const double *hcol_host, double theta, void *dst,
       const void *Q, int64_t ldQ, int L, double *out_dev);
 
 /* ---- column utilities ---------------------------------------------------------

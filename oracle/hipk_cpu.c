@@ -56,7 +56,10 @@ static int seg_total(const hipk_seg *segs, int nseg) {
 }
 
 int hipk_ctx_create(hipk_ctx **ctx, void *s) { (void)s; *ctx = calloc(1, sizeof(hipk_ctx)); return *ctx ? 0 : -2; }
-int hipk_ctx_destroy(hipk_ctx *ctx) { free(ctx); return 0; }
+static long g_cnt[8];
+/* launch counters of the plain-C layer (tests assert the solver's launch structure) */
+void hipk_cpu_counts(long *out, int reset) { for (int i = 0; i < 8; i++) { out[i] = g_cnt[i]; if (reset) g_cnt[i] = 0; } }
+int hipk_ctx_destroy(hipk_ctx *ctx) { if (getenv("HIPK_CPU_COUNTS")) fprintf(stderr, "hipk_cpu calls: dots %ld project %ld ritz %ld ritz_cgs %ld scale %ld\n", g_cnt[0], g_cnt[1], g_cnt[2], g_cnt[3], g_cnt[4]); free(ctx); return 0; }
 void *hipk_ctx_stream(hipk_ctx *ctx) { (void)ctx; return NULL; }
 int hipk_malloc(hipk_ctx *c, size_t b, void **p) { (void)c; *p = calloc(1, b ? b : 8); return *p ? 0 : -2; }
 int hipk_free(hipk_ctx *c, void *p) { (void)c; free(p); return 0; }
@@ -80,7 +83,7 @@ int hipk_timer_stop(hipk_ctx *c, float *ms) { *ms = (float)((now() - c->t0) * 1e
 /* out[j + c*ldout] = col_j' X(:,c)   (Num_gemm_ddh "C","N") */
 int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
       const void *X, int64_t ldX, int nx, double *out, int ldout) {
-   (void)ctx;
+   (void)ctx; g_cnt[0]++;
    const int tot = seg_total(segs, nseg);
    for (int c = 0; c < nx; c++) {
       const void *x = colp(dt, X, ldX, c);
@@ -98,7 +101,7 @@ int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *seg
 /* X(:,c) -= [segs]*coef(:,c); nrm2[c] = |X(:,c)|^2   (Num_gemv_dhd "N" + Num_dot) */
 int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
       const double *coef, int ldcoef, void *X, int64_t ldX, int nx, double *nrm2) {
-   (void)ctx;
+   (void)ctx; g_cnt[1]++;
    const int tot = seg_total(segs, nseg);
    for (int c = 0; c < nx; c++) {
       void *x = (void *)colp(dt, X, ldX, c);
@@ -151,7 +154,7 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
 int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
       int64_t ld, int k, const double *hcol, double theta, void *dst, const void *Q, int64_t ldQ, int L,
       double *out) {
-   (void)ctx;
+   (void)ctx; g_cnt[3]++;
    for (int j = 0; j < k + L + 1; j++) out[j] = 0.0;
    for (int64_t i = 0; i < m; i++) {
       double x = 0, y = 0;

@@ -246,7 +246,6 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
       for (int i = 0; i < blockNormsSize; i++) hValsBlock[i] = s->hVals[iev[*blockSize + i]];
 
       /* X = V h, R = W h - X theta, norms — one fused pass over V and W */
-      if ((rc = pa_push_coefficients(s, basisSize, ldh))) goto out;
       const int nLk = p->numOrthoConst + numLocked;
       if (fused && p->maxBlockSize == 1 && blockNormsSize == 1 && basisSize <= 32 && nLk <= 32) {
          /* block size 1, GD without preconditioner: the residual is the next basis vector, so
@@ -255,14 +254,33 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          char *dstc = PCOL(s, R, s->ld, *blockSize);
          double t0 = pa_wtime();
          if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
-                    s->d_coef + (size_t)col * s->K, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, s->d_fov))) goto out;
-         if ((rc = pa_reduce(s, s->d_fov, basisSize + nLk + 1, 1, 0))) goto out;
+                    s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, s->d_fov))) goto out;
+         /* Speculation: candidates are almost never converged (10 of 3287 iterations in
+          * config 2), so the first Gram-Schmidt update v -= [V Q]*overlaps and |v|^2 are
+          * enqueued right away and the host synchronises ONCE for |r|, the overlaps and |v|^2.
+          * If the pair turns out converged the slot is scratch anyway.  Not done when the
+          * convergence test may still project R (practical-convergence path). */
+         const int nov = basisSize + nLk;
+         const int parallel_host = (p->numProcs > 1 && p->globalSumReal && !s->dev_comm);
+         const int speculate = (practConvChecking < 0 || !p->locking || numLocked == 0);
+         s->fov_projected = 0;
+         if (speculate) {
+            if ((rc = pa_reduce(s, s->d_fov, nov + 1, 1, parallel_host ? 0 : 1))) goto out;
+            hipk_seg segs[2] = {{s->V, s->ld, basisSize}, {s->evecs, s->ldevecs, nLk}};
+            if ((rc = hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, dstc, s->ld, 1,
+                       s->d_fov + nov + 1))) goto out;
+            if ((rc = pa_reduce(s, s->d_fov + nov + 1, 1, 0, 0))) goto out;
+            s->fov_projected = 1;
+         } else {
+            if ((rc = pa_reduce(s, s->d_fov, nov + 1, 1, 0))) goto out;
+         }
          blockNorms[*blockSize] = sqrt(s->h_fov[basisSize + nLk]);
          s->fov_valid = 1; s->fov_k = basisSize; s->fov_L = nLk; s->fov_col = dstc;
          p->stats.timeDense += pa_wtime() - t0;
          p->stats.flopsDense += (double)s->m * 2.0 * basisSize;
       } else {
          s->fov_valid = 0;
+         if ((rc = pa_push_coefficients(s, basisSize, ldh))) goto out;
          int nj = 0;
          for (int c = 0; c < blockNormsSize; c++) {
             const int col = iev[*blockSize + c];

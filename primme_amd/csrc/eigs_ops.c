@@ -178,9 +178,12 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
             }
          }
          p->stats.numOrthoInnerProds += ndot;
-         CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, d_ov, nov > 0 ? nov : 1, v, ldV, 1, d_s1));
          p->stats.numOrthoInnerProds += nov + 1;
-         CHK(pa_reduce(s, d_s1, 1, 0, 0)); /* synchronises: hbase now has overlaps, s02, s12 */
+         if (!(use_fov && s->fov_projected)) {
+            CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, d_ov, nov > 0 ? nov : 1, v, ldV, 1, d_s1));
+            CHK(pa_reduce(s, d_s1, 1, 0, 0)); /* synchronises: hbase now has overlaps, s02, s12 */
+         }
+         s->fov_projected = 0;
 
          if (updateR)
             for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += hbase[i + j];

@@ -46,6 +46,7 @@ typedef struct pa_solver {
    /* first-pass CGS overlaps produced by the fused residual kernel (block size 1) */
    double *d_fov, *h_fov;
    int fov_valid, fov_k, fov_L;
+   int fov_projected;      /* the first pass' update + norm were already run speculatively */
    char *fov_col;
    int fuse_gd;            /* GD without preconditioner/Olsen: residual written straight into V */
    int coef_valid_k;       /* d_coef/d_theta currently hold hVecs/hVals of this size, or -1 */

@@ -527,13 +527,14 @@ extern "C" int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
  * followed by Num_gemv_ddh in ortho.c:236-246).  Fusing them removes one full pass over V
  * per outer iteration; the locked vectors Q are streamed here instead of in the dots launch.
  */
+struct HCol { double h[32]; };   /* the coefficient vector travels in the kernel arguments */
 template <typename T, int NK, int NL>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
-      const double *__restrict__ hcol, double theta, T *__restrict__ dst, const T *__restrict__ Q,
+      HCol hcol, double theta, T *__restrict__ dst, const T *__restrict__ Q,
       int64_t ldQ, int L, int64_t m, double *__restrict__ partials) {
    __shared__ double hs[NK];
-   if (threadIdx.x < NK) hs[threadIdx.x] = (threadIdx.x < k) ? hcol[threadIdx.x] : 0.0;
+   if (threadIdx.x < NK) hs[threadIdx.x] = (threadIdx.x < k) ? hcol.h[threadIdx.x] : 0.0;
    __syncthreads();
    double ov[NK], oq[NL > 0 ? NL : 1], n2 = 0.0;
 #pragma unroll
@@ -577,7 +578,7 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
 }
 
 template <typename T, int NK>
-static int ritz_cgs_nk(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const double *hcol,
+static int ritz_cgs_nk(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
       double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m) {
    dim3 g(gx), b(HIPK_BLOCK);
    if (L == 0) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 0>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
@@ -591,8 +592,10 @@ static int ritz_cgs_nk(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld
 
 template <typename T>
 static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
-      const double *hcol, double theta, T *dst, const T *Q, int64_t ldQ, int L, double *out_dev) {
+      const double *hcol_host, double theta, T *dst, const T *Q, int64_t ldQ, int L, double *out_dev) {
    if (k <= 0 || k > 32 || L < 0 || L > 32) return -1;
+   HCol hcol;
+   for (int j = 0; j < 32; j++) hcol.h[j] = (j < k) ? hcol_host[j] : 0.0;
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4);
    const int nout = k + L + 1;
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
@@ -608,11 +611,11 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
 }
 
 extern "C" int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
-      const void *W, int64_t ldVW, int k, const double *hcol_dev, double theta, void *dst,
+      const void *W, int64_t ldVW, int k, const double *hcol_host, double theta, void *dst,
       const void *Q, int64_t ldQ, int L, double *out_dev) {
    switch (dt) {
-   case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, hcol_dev, theta, (double *)dst, (const double *)Q, ldQ, L, out_dev);
-   case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, hcol_dev, theta, (float *)dst, (const float *)Q, ldQ, L, out_dev);
+   case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, hcol_host, theta, (double *)dst, (const double *)Q, ldQ, L, out_dev);
+   case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, hcol_host, theta, (float *)dst, (const float *)Q, ldQ, L, out_dev);
    default: return -44;
    }
 }

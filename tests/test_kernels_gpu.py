@@ -160,7 +160,8 @@ def test_ritz_residual_overlaps(built, dt, m, k, L):
     for side in (Dev(), Host()):
         v, w, q, hh = side.arr(V), side.arr(W), side.arr(Q), side.arr(h)
         out = side.arr(np.zeros(k + L + 1))
-        rc = side.lib.hipk_ritz_residual_overlaps(side.ctx, dt, m, side.ptr(v), side.ptr(w), ld, k, side.ptr(hh),
+        hhost = np.ascontiguousarray(h)
+        rc = side.lib.hipk_ritz_residual_overlaps(side.ctx, dt, m, side.ptr(v), side.ptr(w), ld, k, hhost.ctypes.data_as(C.c_void_p),
                                                   C.c_double(theta), side.ptr(v, k * ld), side.ptr(q), ldq, L, side.ptr(out))
         assert rc == 0
         res.append((side.get(v)[k, :m], side.get(out)))

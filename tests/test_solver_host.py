@@ -108,3 +108,23 @@ def test_edge_cases(built):
     # configurations that are not on the device path yet fail loudly with -44
     r = eigsh(op, backend="hostcheck", numEvals=2, method="JDQMR", aNorm=8.0, v0=problems.start_vector(n))
     assert r.ret == -44
+
+
+def test_launch_structure_block_size_one(built):
+    """GD+k, block size 1, no preconditioner: per outer iteration ONE fused residual+overlaps
+    pass, ONE Gram-Schmidt update (speculative, reused by the orthogonaliser), ONE projection
+    inner-product pass; a separate overlaps pass only after restarts / for second passes."""
+    import ctypes as C
+    lib = F.load_hostcheck()
+    cnt = (C.c_long * 8)()
+    lib.hipk_cpu_counts(cnt, 1)
+    rp, ci, va, n = problems.laplacian_csr((20, 21))
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", numEvals=10, eps=1e-10, aNorm=8.0,
+              v0=problems.start_vector(n))
+    lib.hipk_cpu_counts(cnt, 1)
+    its, rst = r.stats["numOuterIterations"], r.stats["numRestarts"]
+    dots, project, ritz_cgs = cnt[0], cnt[1], cnt[3]
+    assert r.ret == 0 and its == 490
+    assert ritz_cgs >= its - rst - 15 and ritz_cgs <= its
+    assert dots <= its + rst + 25            # projection pass each iteration + CGS dots after restarts
+    assert project <= its + 25               # one update per new vector (+ rare second passes)
