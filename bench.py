@@ -152,9 +152,20 @@ def main():
     dom = max(range(4), key=lambda c: prof[c][0])
     ms, launches, nbytes = prof[dom]
     achieved = (nbytes / max(ms, 1e-12)) / 1e6 if launches else 0.0   # bytes/ms -> GB/s
+    # HBM bytes per launch from the PMC counters cannot be collected from inside this process:
+    # they come from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over the
+    # same workload, calibrated and summarised in profiles/ (null when no such pass is on file)
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pj.get("workload") == args.workload and dom == 2 and world == 1:
+            traffic = round(pj["ritz_class_hbm_bytes_per_launch"])
+    except Exception:
+        pass
     roofline = {
         "kernel": KERNEL_CLASSES[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "traffic_source": "profiles/r01_pmc_traffic.md (separate --pmc passes, bytes per launch)" if traffic else None,
         "launches": launches, "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "alg_bytes_per_launch": round(nbytes / max(launches, 1)),
         "all_kernels": {KERNEL_CLASSES[c].split(" ")[0]: {
@@ -191,7 +202,8 @@ def main():
                 "sample": f"first {cb['sample_outer_iterations']} outer iterations of the same solve by the real "
                           f"reference dprimme (PRIMME 3.2 + MKL, OpenMP CSR matvec) = {cb['sample_seconds']:.1f} s; "
                           f"extrapolated to the {last.stats['numOuterIterations']} iterations the solve needs",
-                "seconds_per_outer_iteration": cb["seconds_per_outer_iteration"]}
+                "seconds_per_outer_iteration": cb["seconds_per_outer_iteration"],
+                "sample_phase_seconds": {k: cb[k] for k in ("timeMatvec", "timeOrtho", "timeDense")}}
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "eigenpairs/s", "cores": 0, "kind": "reference",
                                    "sample": f"failed: {e!r}"}
