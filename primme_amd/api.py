@@ -109,7 +109,7 @@ class Session:
               maxBlockSize=0, maxBasisSize=0, minRestartSize=0, maxPrevRetain=None, locking=None,
               maxMatvecs=0, maxOuterIterations=0, targetShifts=None, precond=None, printLevel=0,
               initBasisMode=None, global_sum=None, numProcs=1, procID=0, orth=None, iseed=None,
-              profile=False, return_evecs=True, monitor=None):
+              profile=False, return_evecs=True, monitor=None, user_matvec=None):
         lib, op, dtype, backend = self.lib, self.op, self.dtype, self.backend
         keep = []
         p = F.PrimmeParams()
@@ -181,6 +181,9 @@ class Session:
         else:
             p.matrix = self.oph
             p.matrixMatvec = C.cast(lib.primme_amd_matvec, C.c_void_p)
+            if user_matvec is not None:      # an application callback instead of the ready-made one
+                keep.append(user_matvec)
+                p.matrixMatvec = C.cast(user_matvec, C.c_void_p)
             if precond == "jacobi":
                 p.preconditioner = self.oph
                 p.applyPreconditioner = C.cast(lib.primme_amd_jacobi_precond, C.c_void_p)

@@ -1,0 +1,100 @@
+"""Worker of the world_size-2 gloo tests: each rank owns a slab of rows (reference
+examples/ex_eigs_mpi.c:100-123), reductions go through a user globalSumReal callback
+(dist.all_reduce on host buffers, the reference's contract), the matvec exchanges halos with
+dist.send/recv.  Runs the product's host solver over the plain-C kernel layer (no GPU)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(rank, world, port, case, out_path):
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from primme_amd import Operator, problems
+    from primme_amd.api import Session
+    from primme_amd import _ffi as F
+
+    def global_sum(a):
+        t = torch.from_numpy(a.copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    if case == "blockdiag":
+        # two independent, differently scaled Laplacians: no matvec communication at all
+        dims = (15, 16)
+        rp, ci, va, n0 = problems.laplacian_csr(dims)
+        rpt, cit, vat = problems.tile_block_diagonal(rp, ci, va, 1, scale_fn=lambda t: 1.0 + 0.37 * t, row0_tile=rank)
+        n = n0 * world
+        op = Operator(n, csr=(rpt, cit, vat), row0=rank * n0, nrows=n0)
+        v0 = problems.start_vector(n, row0=rank * n0, nrows=n0)
+        s = Session(op, backend="hostcheck")
+        r = s.solve(numEvals=6, eps=1e-10, aNorm=8.0 * 1.37, v0=v0, numProcs=world, procID=rank, global_sum=global_sum)
+        s.close()
+    elif case == "halo":
+        # one 2-D Laplacian split by rows; the callback matvec exchanges one grid line with the neighbour
+        dims = (20, 22)
+        n = dims[0] * dims[1]
+        base = n // world
+        row0, nloc = rank * base, base if rank < world - 1 else n - rank * base
+        rp, ci, va, _ = problems.laplacian_csr(dims, row0=row0, nrows=nloc)
+        lo = row0 - max(0, min(ci.min(), row0)) if row0 > 0 else 0
+        hi = max(0, int(ci.max()) - (row0 + nloc) + 1)
+        lib = F.load_hostcheck()
+        s = Session(Operator(n, csr=(rp, ci, va), row0=row0, nrows=nloc), backend="hostcheck")
+        A = [h for k, h in s.handles if k == "csr"][0]
+        assert lib.hipk_csr_halo_lo(A) == lo and lib.hipk_csr_halo_hi(A) == hi
+
+        def matvec(x, ldx, y, ldy, bs, pp, ierr):
+            nb, lx, ly = bs[0], ldx[0], ldy[0]
+            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(nb, lx))
+            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(nb, ly))
+            for c in range(nb):
+                xl = np.ascontiguousarray(X[c, :nloc])
+                lo_buf, hi_buf = np.zeros(max(lo, 1)), np.zeros(max(hi, 1))
+                reqs = []
+                if rank > 0:
+                    reqs.append(dist.isend(torch.from_numpy(xl[:hi_of[rank - 1]].copy()), rank - 1))
+                    tlo = torch.zeros(lo, dtype=torch.float64); reqs.append(dist.irecv(tlo, rank - 1))
+                if rank < world - 1:
+                    reqs.append(dist.isend(torch.from_numpy(xl[nloc - lo_of[rank + 1]:].copy()), rank + 1))
+                    thi = torch.zeros(hi, dtype=torch.float64); reqs.append(dist.irecv(thi, rank + 1))
+                for q in reqs: q.wait()
+                if rank > 0: lo_buf[:lo] = tlo.numpy()
+                if rank < world - 1: hi_buf[:hi] = thi.numpy()
+                lib.hipk_csr_set_halo(A, lo_buf.ctypes.data_as(C.c_void_p), hi_buf.ctypes.data_as(C.c_void_p))
+                yl = np.zeros(nloc)
+                lib.hipk_csr_matvec(A, None, xl.ctypes.data_as(C.c_void_p), nloc, yl.ctypes.data_as(C.c_void_p), nloc, 1)
+                Y[c, :nloc] = yl
+            ierr[0] = 0
+
+        # neighbours' halo sizes
+        mine = torch.tensor([lo, hi], dtype=torch.int64)
+        allh = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        lo_of = [int(t[0]) for t in allh]
+        hi_of = [int(t[1]) for t in allh]
+        cb = F.BLOCK_OP(matvec)
+        v0 = problems.start_vector(n, row0=row0, nrows=nloc)
+        r = s.solve(numEvals=5, eps=1e-10, aNorm=8.0, v0=v0, numProcs=world, procID=rank, global_sum=global_sum,
+                    user_matvec=cb)
+        s.close()
+    else:
+        raise ValueError(case)
+    res = dict(rank=rank, ret=r.ret, evals=r.evals.tolist(), resNorms=r.resNorms.tolist(), its=r.stats["numOuterIterations"],
+               numGlobalSum=r.stats["numGlobalSum"], evecs_norm2=float(np.sum(r.evecs ** 2)))
+    json.dump(res, open(f"{out_path}.{rank}", "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])

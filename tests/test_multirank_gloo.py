@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: world_size 2, gloo, row-partitioned solve through the reference's
+globalSumReal contract (host buffers), compared with the single-rank solve of the same matrix."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from primme_amd import eigsh, Operator, problems
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _launch(case, tmp_path, world=2):
+    port = _free_port()
+    out = str(tmp_path / f"res_{case}")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), str(r), str(world), str(port), case, out],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [json.load(open(f"{out}.{r}")) for r in range(world)]
+
+
+def test_block_diagonal_two_ranks(built, tmp_path):
+    res = _launch("blockdiag", tmp_path)
+    dims = (15, 16)
+    rp, ci, va, n0 = problems.laplacian_csr(dims)
+    rpt, cit, vat = problems.tile_block_diagonal(rp, ci, va, 2, scale_fn=lambda t: 1.0 + 0.37 * t)
+    n = 2 * n0
+    single = eigsh(Operator(n, csr=(rpt, cit, vat)), backend="hostcheck", numEvals=6, eps=1e-10, aNorm=8.0 * 1.37,
+                   v0=problems.start_vector(n))
+    ex = np.sort(np.concatenate([problems.laplacian_eigenvalues(dims, 6), 1.37 * problems.laplacian_eigenvalues(dims, 6)]))[:6]
+    for r in res:
+        assert r["ret"] == 0
+        assert np.max(np.abs(np.array(r["evals"]) - ex)) <= 1e-10 * 8 * 1.37
+        assert np.max(np.abs(np.array(r["evals"]) - single.evals)) <= 1e-10 * 8 * 1.37
+        assert r["numGlobalSum"] > 0
+    # every rank computed the identical small problem: bitwise equal eigenvalues, same iteration count
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"]
+    # the local slabs together are unit vectors
+    assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - 6.0) < 1e-8
+    assert abs(res[0]["its"] - single.stats["numOuterIterations"]) <= 0.05 * single.stats["numOuterIterations"]
+
+
+def test_halo_exchange_two_ranks(built, tmp_path):
+    res = _launch("halo", tmp_path)
+    dims = (20, 22)
+    ex = problems.laplacian_eigenvalues(dims, 5)
+    for r in res:
+        assert r["ret"] == 0
+        assert np.max(np.abs(np.array(r["evals"]) - ex)) <= 1e-10 * 8
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"]
+    assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - 5.0) < 1e-8
