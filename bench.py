@@ -70,6 +70,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # PRIMME_AMD_SAME_GPU=1: development aid, all ranks share device 0 (needs RCCL to accept it)
+    if os.environ.get("PRIMME_AMD_SAME_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     lib = F.load_product()
 

@@ -54,9 +54,14 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
 
 /* ---- block orthogonalisation dispatcher (reference ortho.c:429-439, :522-530):
  *      implicit_I -> vector-by-vector CGS. ----------------------------------------- */
+int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
+      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int maxRank, int *b2_out);
+
 static int ortho_block(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
       int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int *b2_out) {
    if (b2 < b1) { *b2_out = b2 + 1; return 0; }
+   if (s->VtBV)   /* explicit_I: iterative CholQR/SVQB with the tracked Gram matrix */
+      return pa_ortho_block_gram(s, Vp, ldV, b1, b2, locked, ldLocked, numLocked, RLocked, ldRLocked, s->maxRank, b2_out);
    return pa_ortho_cgs(s, Vp, ldV, b1, b2, locked, ldLocked, numLocked, RLocked, ldRLocked, b2_out);
 }
 
@@ -412,9 +417,18 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                 * (reference main_iter.c:721-797) */
                if (numLocked > 0) {
                   for (i = 0; i < blockSize0 && numConverged < p->numEvals; i++) {
-                     double nR = 0.0;
+                     double nR = 0.0, normXx = 0.0;
                      for (int j = 0; j < ldRlocked; j++) nR += Rlocked[j + (size_t)i * ldRlocked] * Rlocked[j + (size_t)i * ldRlocked];
-                     double newBlockNorm = sqrt(PA_MAX(s->blockNorms[i] * s->blockNorms[i] - nR, 0.0));
+                     if (s->VtBV) {
+                        /* |V_locked' x|^2 from the tracked Gram matrix (reference main_iter.c:747-758) */
+                        for (int j = 0; j < numLocked; j++) {
+                           double t = 0.0;
+                           for (int q = 0; q < basisSize; q++)
+                              t += s->VtBV[j + (size_t)(numLocked + q) * s->ldVtBV] * s->hVecs[q + (size_t)iev[i] * basisSize];
+                           normXx += t * t;
+                        }
+                     }
+                     double newBlockNorm = sqrt(PA_MAX(s->blockNorms[i] * s->blockNorms[i] - nR * (1. + normXx), 0.0));
                      int rc = pa_check_convergence(s, VCOL(s, basisSize + i), s->ld, 1, NULL, 0, 0, numLocked, 0, 1,
                            &flags[iev[i]], &newBlockNorm, &s->hVals[iev[i]], &reset, -1);
                      if (rc) { free(Rlocked); return rc; }
@@ -638,11 +652,10 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    /* what this build of the path covers; anything else must fail loudly */
    if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
    if (p->massMatrixMatvec || p->projectionParams.projection != primme_proj_RR ||
-         p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0 ||
-         p->orth != primme_orth_implicit_I) {
+         p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) {
       if (p->printLevel > 0 && p->outputFile)
          fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / non-RR projection / "
-               "JDQMR inner solver / dynamic method / explicit_I orthogonalisation) is not on the device path yet\n");
+               "JDQMR inner solver / dynamic method) is not on the device path yet\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
@@ -667,7 +680,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 
    const int K = s->K, nev = p->numEvals, b = p->maxBlockSize;
    s->nT = K + 2 * b + 2;
-   s->red_cap = (s->maxRank + 16) * (b + 8) + 64;
+   s->red_cap = PA_MAX((s->maxRank + 16) * (b + 8) + 64, K * K + 64);
    const size_t colBytes = (size_t)(s->ld > 0 ? s->ld : 1) * s->es;
    rc = hipk_malloc(s->ctx, colBytes * K, (void **)&s->V) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W) ||
         hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
@@ -682,6 +695,12 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->flags = (int *)calloc((size_t)K, sizeof(int)); s->map = (int *)calloc((size_t)K, sizeof(int));
    s->iev = (int *)calloc((size_t)K + b, sizeof(int)); s->perm = (int *)calloc((size_t)nev + 1, sizeof(int));
    s->lockedFlags = (int *)calloc((size_t)nev + 1, sizeof(int));
+   if (p->orth == primme_orth_explicit_I) {
+      s->ldVtBV = s->maxRank;
+      s->VtBV = (double *)calloc((size_t)s->maxRank * s->maxRank, 8);
+      s->fVtBV = (double *)calloc((size_t)s->maxRank * s->maxRank, 8);
+      if (!s->VtBV || !s->fVtBV) rc = 1;
+   }
    if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap * 2);
    if (!rc) { s->d_fov = s->d_red + s->red_cap; s->h_fov = s->h_red + s->red_cap; }
    if (rc || !s->H || !s->hVecs || !s->prevhVecs || !s->hVals || !s->prevRitzVals || !s->blockNorms ||

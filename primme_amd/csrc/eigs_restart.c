@@ -33,6 +33,39 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
       int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
       int *lockedFlags, double *lockedNorms, primme_event event);
 
+int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
+int pa_update_cholesky(const double *G, int ldG, double *fG, int ldfG, int n0, int n);
+
+/* explicit_I: after V <- V*h, W <- W*h recompute from the data the Gram block G = V'V and
+ * H = V'W of the restarted basis (reference auxiliary_eigs_normal.c:296-309 does it inside the
+ * fused update) and rotate the locked-vs-basis block of VtBV on the host
+ * (reference restart.c:1276-1290). */
+static int refresh_gram_after_restart(pa_solver *s, int evecsSize, int nVold, int rs, int ldh) {
+   if (!s->VtBV || rs <= 0) return 0;
+   const int ldG = s->ldVtBV;
+   double *work = (double *)malloc((size_t)(evecsSize > 0 ? evecsSize : 1) * rs * sizeof(double));
+   if (!work) return PRIMME_MALLOC_FAILURE;
+   for (int c = 0; c < rs; c++)
+      for (int i = 0; i < evecsSize; i++) {
+         double t = 0.0;
+         for (int q = 0; q < nVold; q++) t += s->VtBV[i + (size_t)(evecsSize + q) * ldG] * s->hVecs[q + (size_t)c * ldh];
+         work[i + (size_t)c * evecsSize] = t;
+      }
+   for (int c = 0; c < rs; c++)
+      for (int i = 0; i < evecsSize; i++) s->VtBV[i + (size_t)(evecsSize + c) * ldG] = work[i + (size_t)c * evecsSize];
+   free(work);
+   hipk_seg seg = {s->V, s->ld, rs};
+   CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, s->V, s->ld, rs, s->d_red, rs));
+   CHK(pa_reduce(s, s->d_red, rs * rs, 0, 0));
+   for (int c = 0; c < rs; c++)
+      for (int i = 0; i < rs; i++) s->VtBV[(evecsSize + i) + (size_t)(evecsSize + c) * ldG] = s->h_red[i + (size_t)c * rs];
+   CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, s->W, s->ld, rs, s->d_red, rs));
+   CHK(pa_reduce(s, s->d_red, rs * rs, 0, 0));
+   for (int c = 0; c < rs; c++)
+      for (int i = 0; i < rs; i++) s->H[i + (size_t)c * s->K] = s->h_red[i + (size_t)c * rs];
+   return 0;
+}
+
 /* Lock newVal by insertion into the sorted evals (smallest/largest) or in
  * convergence order within equal shifts (interior). perm remembers arrival order. */
 static int insertion_sort(double newVal, double *evals, double newNorm, double *resNorms,
@@ -223,6 +256,7 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
    int rc = pa_ritz_update(s, basisSize, jobs, nj, blockNorms, nb, (int64_t)2 * rs + 2 * nb + nc);
    free(jobs);
    if (rc) return rc;
+   CHK(refresh_gram_after_restart(s, p->numOrthoConst, basisSize, rs, ldh));
 
    for (i = 0; i < basisSize; i++) hVecsPerm[restartPerm[i]] = i;
    for (i = 0; i < *ievSize; i++)
@@ -288,6 +322,8 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
    for (int c = 0; c < numPacked; c++)
       lockedResNorms[c] = PA_MAX(norms[sizeBlockNorms + c], p->stats.estimateResidualError);
    free(norms);
+
+   CHK(refresh_gram_after_restart(s, *numLocked + nOC, basisSize, rs, ldh));
 
    /* re-test the pairs about to be locked with their true residual norms */
    pa_permute_ints(flags, basisSize, restartPerm);
@@ -385,7 +421,35 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
       free(tv);
       pa_permute_ints(&restartPerm[left], numPacked, ifailed);
    }
-   /* (explicit_I: VtBV and H rows/columns follow the same shuffle — see pa_restart) */
+   if (s->VtBV) {
+      /* accepted-to-lock columns move to the locked block, then the restarted ones, then the
+       * failed ones (reference restart.c:1092-1117) */
+      const int nLk = nOC + *numLocked, tot = left + numPacked, nG = nLk + tot, ldG = s->ldVtBV;
+      int *iV = (int *)malloc((size_t)(tot > 0 ? tot : 1) * sizeof(int));
+      double *rw = (double *)malloc((size_t)nG * (tot > 0 ? tot : 1) * sizeof(double));
+      for (i = 0; i < numPacked - failed; i++) iV[i] = ifailed[failed + i] + left;
+      for (i = 0; i < left; i++) iV[i + numPacked - failed] = i;
+      for (i = 0; i < failed; i++) iV[i + left + numPacked - failed] = ifailed[i] + left;
+      for (int c = 0; c < tot; c++)
+         for (int r2 = 0; r2 < nG; r2++) rw[r2 + (size_t)c * nG] = s->VtBV[r2 + (size_t)(nLk + iV[c]) * ldG];
+      for (int c = 0; c < tot; c++) {
+         for (int r2 = 0; r2 < nLk; r2++) s->VtBV[r2 + (size_t)(nLk + c) * ldG] = rw[r2 + (size_t)c * nG];
+         for (int r2 = 0; r2 < tot; r2++) s->VtBV[(nLk + r2) + (size_t)(nLk + c) * ldG] = rw[(nLk + iV[r2]) + (size_t)c * nG];
+      }
+      free(iV); free(rw);
+      /* H: failed rows/columns right after the restarted ones (reference :1119-1124) */
+      double *hc = (double *)malloc((size_t)(tot > 0 ? tot : 1) * (failed > 0 ? failed : 1) * sizeof(double));
+      for (int c = 0; c < failed; c++)
+         for (int r2 = 0; r2 < tot; r2++) hc[r2 + (size_t)c * tot] = s->H[r2 + (size_t)(left + ifailed[c]) * s->K];
+      for (int c = 0; c < failed; c++)
+         for (int r2 = 0; r2 < tot; r2++) s->H[r2 + (size_t)(left + c) * s->K] = hc[r2 + (size_t)c * tot];
+      for (int c = 0; c < left + failed; c++) {
+         double tmpc[64];
+         for (int r2 = 0; r2 < failed && r2 < 64; r2++) tmpc[r2] = s->H[(left + ifailed[r2]) + (size_t)c * s->K];
+         for (int r2 = 0; r2 < failed && r2 < 64; r2++) s->H[(left + r2) + (size_t)c * s->K] = tmpc[r2];
+      }
+      free(hc);
+   }
 
    /* lock: pack the accepted vectors in evecs and insertion-sort their values */
    for (i = left; i < left + numPacked; i++) {
@@ -463,6 +527,11 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
             &indexOfPreviousVecs, hVecsPerm);
    if (rc) { free(restartPerm); free(hVecsPerm); return rc; }
 
+   if (s->fVtBV) {
+      const int newnLocked = p->numOrthoConst + *numLocked;
+      CHK(pa_update_cholesky(s->VtBV, s->ldVtBV, s->fVtBV, s->ldVtBV, nLocked, newnLocked + restartSize));
+   }
+
    /* previous Ritz values follow the basis (only used by interior-target shifts) */
    if (p->target != primme_smallest && p->target != primme_largest) {
       if (s->numPrevRitzVals > 0) {
@@ -497,7 +566,26 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
 
    /* bound on the error accumulated in V and W (implicit_I branch of reference
     * restart.c:418-451; the explicit_I estimate from VtBV is added with that path) */
-   p->stats.estimateResidualError =
-         2 * sqrt((double)*restartsSinceReset) * s->mach_eps * pa_problem_norm(1, p);
+   double fn = 0.0;
+   if (s->VtBV) {
+      /* orthogonality level ||I - V'V||_F of [locked V] from the tracked Gram matrix
+       * (reference restart.c:398-446) */
+      const int nG = p->numOrthoConst + *numLocked + restartSize, ldG = s->ldVtBV;
+      double acc = 0.0;
+      for (int c = 0; c < nG; c++)
+         for (int r2 = 0; r2 < c; r2++) {
+            const double g = s->VtBV[r2 + (size_t)c * ldG];
+            acc += 2 * g * g / fabs(s->VtBV[c + (size_t)c * ldG]) / fabs(s->VtBV[r2 + (size_t)r2 * ldG]);
+         }
+      fn = sqrt(acc);
+   }
+   if (fn > 0.0) {
+      if (*restartsSinceReset <= 1)
+         p->stats.maxConvTol = PA_MAX(p->stats.maxConvTol, fn * p->stats.estimateLargestSVal);
+      p->stats.estimateResidualError = sqrt((double)*restartsSinceReset) * fn * pa_problem_norm(1, p);
+   } else {
+      p->stats.estimateResidualError =
+            2 * sqrt((double)*restartsSinceReset) * s->mach_eps * pa_problem_norm(1, p);
+   }
    return 0;
 }

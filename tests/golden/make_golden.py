@@ -35,7 +35,28 @@ CASES = {
     "lap3d_noanorm": ((9, 10, 11), dict(numEvals=4, eps=1e-8)),
     "lap3d_lobpcg": ((9, 10, 11), dict(numEvals=3, method="LOBPCG_OrthoBasis", eps=1e-6, aNorm=12.0, orth=F.primme_orth_implicit_I, v0=None)),
     "lap3d_medium": ((30, 31, 32), dict(numEvals=10, eps=1e-8, aNorm=12.0)),
+    # block sizes > 1 and single precision: orth = explicit_I (tracked Gram matrix, CholQR/SVQB);
+    # v0 = {"rng": seed, "cols": c} -> numpy default_rng(seed).standard_normal((n, 9))[:, :c]
+    "blk2_lock": ((20, 21), dict(numEvals=10, eps=1e-9, aNorm=8.0, maxBlockSize=2, v0={"rng": 5, "cols": 2})),
+    "blk2_soft": ((20, 21), dict(numEvals=3, eps=1e-9, aNorm=8.0, maxBlockSize=2, v0={"rng": 5, "cols": 2})),
+    "blk4_lock": ((20, 21), dict(numEvals=10, eps=1e-9, aNorm=8.0, maxBlockSize=4, v0={"rng": 5, "cols": 4})),
+    "blk4_largest": ((20, 21), dict(numEvals=6, eps=1e-9, aNorm=8.0, maxBlockSize=4, target="largest", v0={"rng": 5, "cols": 4})),
+    "blk8_K40": ((20, 21), dict(numEvals=12, eps=1e-8, aNorm=8.0, maxBlockSize=8, v0={"rng": 5, "cols": 8})),
+    "blk1_explicit": ((20, 21), dict(numEvals=5, eps=1e-9, aNorm=8.0, orth=F.primme_orth_explicit_I, v0={"rng": 5, "cols": 1})),
+    "blk2_jacobi": ((20, 21), dict(numEvals=6, eps=1e-9, aNorm=8.0, maxBlockSize=2, precond="jacobi", v0={"rng": 5, "cols": 2})),
+    "blk2_implicit": ((20, 21), dict(numEvals=5, eps=1e-9, aNorm=8.0, maxBlockSize=2, orth=F.primme_orth_implicit_I, v0={"rng": 5, "cols": 2})),
+    "lobpcg_default": ((20, 21), dict(numEvals=3, method="LOBPCG_OrthoBasis", eps=1e-6, aNorm=8.0, v0=None)),
+    "float_bs1": ((20, 21), dict(numEvals=4, eps=1e-4, aNorm=8.0, dtype="float32", v0={"rng": 5, "cols": 1})),
+    "float_bs2": ((20, 21), dict(numEvals=4, eps=1e-4, aNorm=8.0, dtype="float32", maxBlockSize=2, v0={"rng": 5, "cols": 2})),
 }
+
+
+def make_v0(spec, n):
+    if spec is None:
+        return None
+    if spec == "start_vector":
+        return problems.start_vector(n)
+    return np.random.default_rng(spec["rng"]).standard_normal((n, 9))[:, :spec["cols"]]
 
 
 def main():
@@ -45,10 +66,12 @@ def main():
         op = Operator(n, csr=(rp, ci, va))
         kw = dict(kw)
         if "v0" not in kw:
-            kw["v0"] = problems.start_vector(n)
+            kw["v0"] = "start_vector"
+        kws = dict(kw)
+        kw["v0"] = make_v0(kw["v0"], n)
+        if "dtype" in kw:
+            kw["dtype"] = np.dtype(kw["dtype"])
         r = eigsh(op, backend="reference", **kw)
-        kws = {k: v for k, v in kw.items() if k != "v0"}
-        kws["v0"] = "start_vector" if kw.get("v0") is not None else None
         out[name] = dict(dims=list(dims), kwargs=kws, ret=r.ret, initSize=r.initSize, evals=r.evals.tolist(),
                          resNorms=r.resNorms.tolist(), params=r.params,
                          stats={k: r.stats[k] for k in ("numOuterIterations", "numMatvecs", "numRestarts", "numPreconds")})

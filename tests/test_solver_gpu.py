@@ -19,6 +19,15 @@ from primme_amd import _ffi as F
 pytestmark = pytest.mark.gpu
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_solves.json")))
+
+
+def _make_v0(spec, n):
+    if spec is None:
+        return None
+    if spec == "start_vector":
+        return problems.start_vector(n)
+    return np.random.default_rng(spec["rng"]).standard_normal((n, 9))[:, :spec["cols"]]
+
 LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_leq": 0.05}
 
 
@@ -28,7 +37,9 @@ def _case(name):
     rp, ci, va, n = problems.laplacian_csr(dims)
     op = Operator(n, csr=(rp, ci, va))
     kw = dict(g["kwargs"])
-    kw["v0"] = problems.start_vector(n) if kw.get("v0") == "start_vector" else None
+    kw["v0"] = _make_v0(kw.get("v0"), n)
+    if "dtype" in kw:
+        kw["dtype"] = np.dtype(kw["dtype"])
     return op, kw, g
 
 
@@ -48,10 +59,11 @@ def test_hip_against_reference_fixture(built, name):
     ev, evg = np.array(r.evals), np.array(g["evals"])
     if name == "lap2d_closest_abs":
         ev, evg = np.sort(ev), np.sort(evg)
-    assert np.max(np.abs(ev - evg)) <= 1e-10 * aN
+    rel = 1e-4 if str(g["kwargs"].get("dtype", "")) == "float32" else 1e-10
+    assert np.max(np.abs(ev - evg)) <= rel * aN
     thr = (g["kwargs"].get("eps") or 0) * aN
     if thr > 0:
-        assert np.all(r.resNorms <= thr * (1 + 1e-9))
+        assert np.all(r.resNorms <= thr * (1 + 1e-6))
     its, itsg = r.stats["numOuterIterations"], g["stats"]["numOuterIterations"]
     # the device reductions add in a different order than the CPU BLAS: counts agree closely,
     # exactly for most cases; allow 2 % (5 % for the interior targets, where the reference
