@@ -133,6 +133,16 @@ int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int6
 int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
       void *Wr, int64_t ldW, int nx, const double *theta_host, double *nrm2_dev);
 
+/* ---- block QMR recurrences (JDQMR inner solver, reference src/eigs/inner_solve.c) ----------
+ * out_dev[c] = X(:,c)' Y(:,c)                      Num_dist_dots_real (auxiliary_eigs.c:695-706) */
+int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
+      const void *Y, int64_t ldY, int nx, double *out_dev);
+/* delta = gamma.*delta + eta.*d; sol += delta; dotsol_dev[c] = |sol(:,c)|^2 in one pass
+ * (the host path of the reference fuses the same three steps, inner_solve.c:384-397) */
+int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gamma_host,
+      const double *eta_host, const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol,
+      int64_t ldSol, double *dotsol_dev);
+
 /* ---- sparse operator: the user matvec ------------------------------------------
  * Replaces the hipsparseSpMM-based callback of examples/ex_eigs_dhipblas.c:239-264
  * and the SPARSKIT amux of tests/COMMON/mat.c:64-90.

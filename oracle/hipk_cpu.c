@@ -215,6 +215,34 @@ int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, i
    return 0;
 }
 
+int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *Y, int64_t ldY,
+      int nx, double *out) {
+   (void)ctx;
+   for (int c = 0; c < nx; c++) {
+      const void *x = colp(dt, X, ldX, c), *y = colp(dt, Y, ldY, c);
+      double s = 0; for (int64_t i = 0; i < m; i++) s += ld_(dt, x, i) * ld_(dt, y, i);
+      out[c] = s;
+   }
+   mirror(out, nx);
+   return 0;
+}
+int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gam, const double *eta,
+      const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, double *dotsol) {
+   (void)ctx;
+   for (int c = 0; c < nx; c++) {
+      const void *d = colp(dt, D, ldD, c); void *de = (void *)colp(dt, Delta, ldDelta, c); void *so = (void *)colp(dt, Sol, ldSol, c);
+      double s = 0;
+      for (int64_t i = 0; i < m; i++) {
+         st_(dt, de, i, ld_(dt, de, i) * gam[c] + ld_(dt, d, i) * eta[c]);
+         st_(dt, so, i, ld_(dt, de, i) + ld_(dt, so, i));
+         s += ld_(dt, so, i) * ld_(dt, so, i);
+      }
+      dotsol[c] = s;
+   }
+   mirror(dotsol, nx);
+   return 0;
+}
+
 /* ---- sparse operator (amux: y = A x, CSR) ----------------------------------- */
 struct hipk_csr {
    hipk_dtype dt; int kind; int64_t nrows, ncols, row0, nnz;

@@ -1,0 +1,336 @@
+/* eigs_jd.c — JDQMR: block symmetric QMR on the projected correction equation
+ *       (I - Q Q')(I - x x')(A - sigma I) t = -r,     t ⟂ [Q x]
+ * with adaptive stopping driven by recurrences for the updated Ritz value and
+ * eigen-residual.
+ *
+ *   pa_inner_solve            <- reference src/eigs/inner_solve.c:132-669
+ *   apply_projected_matrix    <- reference :838-891
+ *   apply_skew_projector      <- reference :769-808  (orthogonal projectors only here)
+ *   apply_projected_precond   <- reference :714-741
+ *   projector set-up          <- reference src/eigs/correction.c:862-997
+ *
+ * All n-length work is on the device: per QMR iteration one block SpMM, the projector
+ * panels (hipk_panel_dots / hipk_panel_project), pairwise dot products for the b scalar
+ * recurrences and one fused pass for delta/sol/|sol|^2.  The scalar recurrences and the
+ * stopping logic stay on the host, restated literally.
+ * Indexing note: the scalar recurrences are kept per ORIGINAL block column (index pm[i]) and
+ * every panel is permuted once when columns leave the block.  The reference writes some of
+ * them by position and reads them by original index (sigma_prev, Theta, rho: inner_solve.c:317,
+ * :373-377, :616-620) and permutes x twice when it is also a projector (:363-366); for block
+ * size 1 — where both versions coincide exactly — this does not matter, for b > 1 this file
+ * implements the consistent variant and parity is asserted on the converged results.
+ * Covered: the JDQMR / JDQMR_ETol presets (LeftQ iff preconditioning, LeftX, no right
+ * projectors) plus orthogonal right projectors; skew projectors (K^-1-weighted, presets
+ * JDQR / JD_Olsen) return PRIMME_FUNCTION_UNAVAILABLE.
+ */
+#include "eigs_solver.h"
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+double pa_problem_norm(int overrideUser, const primme_params *p);
+int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
+int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0, int nc);
+int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc);
+void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv, primme_params *p, int *ierr);
+void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags, int *iblock,
+      int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
+      int *lockedFlags, double *lockedNorms, primme_event event);
+
+static int conv_test(pa_solver *s, double eval, double rnorm, int *isconv) {
+   primme_params *p = s->p;
+   if (p->convTestFun == pa_conv_test_absolute) {
+      *isconv = rnorm < PA_MAX(p->eps, s->mach_eps * 2) * pa_problem_norm(0, p);
+      return 0;
+   }
+   int ierr = 0;
+   p->convTestFun(&eval, NULL, &rnorm, isconv, p, &ierr);
+   return ierr ? PRIMME_UNEXPECTED_FAILURE : 0;
+}
+
+/* v(:, 0:nb) <- (I - Qhat Q') v for a panel Q (numCols columns), orthogonal form */
+static int project_panel(pa_solver *s, char *Q, int64_t ldQ, char *Qhat, int64_t ldQhat, int numCols,
+      char *v, int64_t ldv, int nb) {
+   if (numCols <= 0 || nb <= 0) return 0;
+   double t0 = pa_wtime();
+   hipk_seg sq = {Q, ldQ, numCols}, sh = {Qhat, ldQhat, numCols};
+   CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, v, ldv, nb, s->d_red, numCols));
+   CHK(pa_reduce(s, s->d_red, numCols * nb, 1, 1));
+   CHK(hipk_panel_project(s->ctx, s->dt, s->m, &sh, 1, s->d_red, numCols, v, ldv, nb, NULL));
+   s->p->stats.numOrthoInnerProds += (double)numCols * nb;
+   s->p->stats.timeOrtho += pa_wtime() - t0;
+   return 0;
+}
+
+/* v_i <- (I - xhat_i x_i') v_i for every column i */
+static int project_each(pa_solver *s, char *X, int64_t ldX, char *Xhat, int64_t ldXhat, char *v, int64_t ldv, int nb) {
+   if (nb <= 0) return 0;
+   double t0 = pa_wtime();
+   CHK(hipk_pair_dots(s->ctx, s->dt, s->m, X, ldX, v, ldv, nb, s->d_red));
+   CHK(pa_reduce(s, s->d_red, nb, 0, 0));
+   double alpha[64];
+   for (int i = 0; i < nb; i++) alpha[i] = -s->h_red[i];
+   CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, alpha, Xhat, ldXhat, v, ldv, nb));
+   s->p->stats.numOrthoInnerProds += nb;
+   s->p->stats.timeOrtho += pa_wtime() - t0;
+   return 0;
+}
+
+static int pair_dots_host(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nb, double *out) {
+   CHK(hipk_pair_dots(s->ctx, s->dt, s->m, X, ldX, Y, ldY, nb, s->d_red));
+   CHK(pa_reduce(s, s->d_red, nb, 0, 0));
+   for (int i = 0; i < nb; i++) out[i] = s->h_red[i];
+   return 0;
+}
+
+/* in-place column permutation of a device panel through the scratch panel T */
+static int permute_panel(pa_solver *s, char *base, int64_t ldb, int n, const int *perm) {
+   int moved = 0;
+   for (int i = 0; i < n; i++) if (perm[i] != i) moved = 1;
+   if (!moved || !base) return 0;
+   for (int i = 0; i < n; i++)
+      CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, perm[i]), ldb, TCOL(s, i), s->ld, 1));
+   CHK(hipk_copy_cols(s->ctx, s->dt, s->m, s->T, s->ld, base, ldb, n));
+   return 0;
+}
+
+/* swap `val` into position `pos` of the permutation (reference inner_solve.c:913-925) */
+static void perm_set_value_on_pos(int *p, int val, int pos, int n) {
+   for (int i = 0; i < n; i++)
+      if (p[i] == val) { p[i] = p[pos]; p[pos] = val; return; }
+}
+
+typedef struct {
+   char *LQ, *LX; int64_t ldLQ, ldLX; int nLQ, nLX;   /* left projectors  (B = I: BQ = Q, BX = X) */
+   char *RQ, *RX; int64_t ldRQ, ldRX; int nRQ, nRX;   /* right projectors (orthogonal form)       */
+} jd_proj;
+
+static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const double *shift, const jd_proj *P,
+      int nb, char *result, int64_t ldres) {
+   /* result = (A - shift) v, then the left projectors */
+   CHK(pa_matvec(s, v, ldv, result, ldres, 0, nb));
+   double ms[64];
+   for (int i = 0; i < nb; i++) ms[i] = -shift[i];
+   CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
+   CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+   if (P->nLX > 0) CHK(project_each(s, P->LX, P->ldLX, P->LX, P->ldLX, result, ldres, nb));
+   return 0;
+}
+
+static int apply_projected_preconditioner(pa_solver *s, char *v, int64_t ldv, const jd_proj *P, int nb,
+      char *result, int64_t ldres) {
+   CHK(pa_precond(s, v, ldv, result, ldres, nb));
+   CHK(project_panel(s, s->evecs, s->ldevecs, P->RQ, P->ldRQ, P->nRQ, result, ldres, nb));
+   if (P->nRX > 0) CHK(project_each(s, P->RX, P->ldRX, P->RX, P->ldRX, result, ldres, nb));
+   return 0;
+}
+
+/* Block QMR.  x, r: the block's Ritz vectors and residuals (V / W slots at basisSize);
+ * sol receives the corrections.  eval[i], shift[i], rnorm[i] per block vector. */
+static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const double *rnorm, jd_proj *P,
+      char *sol, const double *eval, double *shift, int *touch) {
+   primme_params *p = s->p;
+   const int64_t ld = s->ld;
+   const int b0 = blockSize;
+   char *g = s->Jw, *d = PCOL(s, s->Jw, ld, b0), *delta = PCOL(s, s->Jw, ld, 2 * b0), *w = PCOL(s, s->Jw, ld, 3 * b0);
+   double sigma_prev[64], rho_prev[64], rho[64], alpha_prev[64], Theta_prev[64], Theta[64], tau_init[64],
+         tau_prev[64], tau[64], Beta_prev[64], Delta_prev[64], Psi_prev[64], eta[64], eval_prev[64],
+         eres_updated[64], Gamma_prev[64], Phi_prev[64], gamma[64], dot_sol[64], tmp[64];
+   int pm[64], p0[64];
+   const int adaptive = (p->correctionParams.convTest == primme_adaptive ||
+                         p->correctionParams.convTest == primme_adaptive_ETolerance);
+   int i, isConv;
+   if (blockSize > 64) return PRIMME_UNEXPECTED_FAILURE;
+
+   for (i = 0; i < blockSize; i++) tau_prev[i] = tau_init[i] = rnorm[i];
+   double LTolerance = s->mach_eps * pa_problem_norm(1, p), LTolerance_factor = 1.0, ETolerance = 0.0,
+          ETolerance_factor = 0.0;
+   switch (p->correctionParams.convTest) {
+   case primme_full_LTolerance: break;
+   case primme_decreasing_LTolerance:
+      LTolerance = PA_MAX(LTolerance, pow(p->correctionParams.relTolBase, -(double)*touch));
+      (*touch)++;
+      break;
+   case primme_adaptive:
+      LTolerance_factor = ETolerance_factor = pow(1.8, -(double)*touch);
+      break;
+   case primme_adaptive_ETolerance:
+      LTolerance_factor = ETolerance_factor = pow(1.8, -(double)*touch);
+      ETolerance = 0.1;
+      break;
+   }
+   int64_t maxIterations = (p->maxMatvecs > 0) ? p->maxMatvecs - p->stats.numMatvecs : INT_MAX;
+   if (p->correctionParams.maxInnerIterations > 0)
+      maxIterations = PA_MIN((int64_t)p->correctionParams.maxInnerIterations, maxIterations);
+
+   /* zero initial guess: g = r, d = K^-1 g (projected) */
+   CHK(hipk_copy_cols(s->ctx, s->dt, s->m, r, ld, g, ld, blockSize));
+   CHK(apply_projected_preconditioner(s, g, ld, P, blockSize, d, ld));
+   for (i = 0; i < blockSize; i++) { Theta_prev[i] = 0.0; eval_prev[i] = eval[i]; }
+   CHK(pair_dots_host(s, g, ld, d, ld, blockSize, rho_prev));
+   for (i = 0; i < blockSize; i++)
+      Beta_prev[i] = Delta_prev[i] = Psi_prev[i] = Gamma_prev[i] = Phi_prev[i] = eres_updated[i] = 0.0;
+   CHK(hipk_memset0(s->ctx, delta, (size_t)ld * s->es * blockSize));
+   CHK(hipk_memset0(s->ctx, sol, (size_t)ld * s->es * blockSize));
+   for (i = 0; i < blockSize; i++) pm[i] = i;
+
+   for (int64_t numIts = 0; numIts < maxIterations && blockSize > 0; numIts++) {
+      CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld));
+      CHK(pair_dots_host(s, d, ld, w, ld, blockSize, tmp));
+      for (i = 0; i < blockSize; i++) sigma_prev[pm[i]] = tmp[i];
+
+      int conv = 0;
+      double malpha[64];
+      for (i = 0; i < blockSize; i++) { p0[i] = i; malpha[i] = 0.0; }
+      for (i = 0; i < blockSize; i++) {
+         const int q = pm[i];
+         int bad = (!isfinite(sigma_prev[q]) || sigma_prev[q] == 0.0);
+         if (!bad) {
+            alpha_prev[q] = rho_prev[q] / sigma_prev[q];
+            bad = (!isfinite(alpha_prev[q]) || fabs(alpha_prev[q]) < s->mach_eps || fabs(alpha_prev[q]) > 1.0 / s->mach_eps);
+         }
+         if (bad) {
+            if (numIts == 0) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, r, ld, i), ld, PCOL(s, sol, ld, i), ld, 1));
+            perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize);
+            continue;
+         }
+         malpha[i] = -alpha_prev[q];
+      }
+      CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, malpha, w, ld, g, ld, blockSize));   /* g -= alpha w (0 for dropped) */
+
+#define SHRINK()                                                                                   \
+      do {                                                                                         \
+         pa_permute_ints(pm, blockSize, p0);                                                       \
+         pa_permute_cols(shift, 1, blockSize, 1, p0);                                              \
+         CHK(permute_panel(s, g, ld, blockSize, p0));                                              \
+         CHK(permute_panel(s, d, ld, blockSize, p0));                                              \
+         CHK(permute_panel(s, delta, ld, blockSize, p0));                                          \
+         CHK(permute_panel(s, r, ld, blockSize, p0));                                              \
+         CHK(permute_panel(s, x, ld, blockSize, p0));    /* LX / RX alias x */                     \
+         CHK(permute_panel(s, sol, ld, blockSize, p0));                                            \
+         blockSize -= conv;                                                                        \
+         if (P->nLX) P->nLX -= conv;                                                               \
+         if (P->nRX) P->nRX -= conv;                                                               \
+      } while (0)
+      SHRINK();
+      if (blockSize <= 0) break;
+
+      CHK(pair_dots_host(s, g, ld, g, ld, blockSize, tmp));
+      double gam_c[64], eta_c[64];
+      for (i = 0; i < blockSize; i++) {
+         const int q = pm[i];
+         Theta[q] = sqrt(tmp[i]) / tau_prev[q];
+         const double c = 1.0 / sqrt(1 + Theta[q] * Theta[q]);
+         tau[q] = tau_prev[q] * Theta[q] * c;
+         gamma[q] = c * c * Theta_prev[q] * Theta_prev[q];
+         eta[q] = alpha_prev[q] * c * c;
+         gam_c[i] = gamma[q]; eta_c[i] = eta[q];
+      }
+      /* delta = gamma delta + eta d; sol += delta; |sol|^2 */
+      CHK(hipk_qmr_update(s->ctx, s->dt, s->m, blockSize, gam_c, eta_c, d, ld, delta, ld, sol, ld, s->d_red));
+      if (adaptive) {
+         CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
+         for (i = 0; i < blockSize; i++) dot_sol[i] = s->h_red[i];
+      }
+
+      conv = 0;
+      for (i = 0; i < blockSize; i++) p0[i] = i;
+      for (i = 0; i < blockSize; i++) {
+         const int q = pm[i];
+         if (fabs(rho_prev[q]) == 0.0) { perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue; }
+         if (numIts > 0 && tau[q] < LTolerance) { perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue; }
+         if (ETolerance > 0.0 || ETolerance_factor > 0.0) {
+            /* recurrences for the Ritz value and eigen-residual of x + sol */
+            const double Delta = gamma[q] * Delta_prev[q] + eta[q] * rho_prev[q];
+            const double Beta = Beta_prev[q] - Delta;
+            const double Phi = gamma[q] * gamma[q] * Phi_prev[q] + eta[q] * eta[q] * sigma_prev[q];
+            const double Psi = gamma[q] * Psi_prev[q] + gamma[q] * Phi_prev[q];
+            const double Gamma = Gamma_prev[q] + 2.0 * Psi + Phi;
+            const double nrm = 1.0 + dot_sol[i];
+            const double eval_updated = shift[i] + (eval[q] - shift[i] + 2 * Beta + Gamma) / nrm;
+            const double eres2 = (tau[q] * tau[q]) / nrm + ((eval[q] - shift[i] + Beta) * (eval[q] - shift[i] + Beta)) / nrm -
+                                 (eval_updated - shift[i]) * (eval_updated - shift[i]);
+            const double eres_prev = eres_updated[q];
+            eres_updated[q] = (eres2 < 0) ? sqrt((tau[q] * tau[q]) / nrm) : sqrt(eres2);
+            Delta_prev[q] = Delta; Beta_prev[q] = Beta; Phi_prev[q] = Phi; Psi_prev[q] = Psi; Gamma_prev[q] = Gamma;
+
+            if (numIts > 0 && (tau_prev[q] <= eres_updated[q] || eres_prev <= tau[q])) {
+               perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue;
+            }
+            if ((p->target == primme_smallest && eval_updated > eval_prev[q]) ||
+                  (p->target == primme_largest && eval_updated < eval_prev[q]) ||
+                  (p->target == primme_closest_abs && fabs(eval[q] - eval_updated) > tau_init[q] + eres_updated[q])) {
+               perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue;
+            }
+            if (numIts > 0 && eres_updated[q] < ETolerance * tau_init[q]) {
+               perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue;
+            }
+            const double tol = PA_MIN(tau[q] / LTolerance_factor, eres_updated[q] / ETolerance_factor);
+            CHK(conv_test(s, eval_updated, tol, &isConv));
+            if (numIts > 0 && isConv) {
+               (*touch)++;
+               perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue;
+            }
+            eval_prev[q] = eval_updated;
+         } else {
+            CHK(conv_test(s, eval[q], tau[q] / LTolerance_factor * sqrt((double)numIts), &isConv));
+            if (numIts > 0 && isConv) { perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue; }
+         }
+      }
+      SHRINK();
+      if (blockSize <= 0) break;
+
+      if (numIts + 1 < maxIterations) {
+         CHK(apply_projected_preconditioner(s, g, ld, P, blockSize, w, ld));
+         CHK(pair_dots_host(s, g, ld, w, ld, blockSize, tmp));
+         double beta[64];
+         for (i = 0; i < blockSize; i++) {
+            const int q = pm[i];
+            rho[q] = tmp[i];
+            beta[i] = rho[q] / rho_prev[q];
+            rho_prev[q] = rho[q]; tau_prev[q] = tau[q]; Theta_prev[q] = Theta[q];
+         }
+         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, beta, d, ld, w, ld, blockSize));   /* w += beta d */
+         char *t = d; d = w; w = t;
+      }
+   }
+#undef SHRINK
+   return 0;
+}
+
+/* JDQMR correction for the block at V(:, basisSize..), W(:, basisSize..) (x and r), result in x's place.
+ * `shifts` are the correction-equation shifts computed by the caller (robust / Ritz / target). */
+int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double *blockNorms, const int *iev,
+      double *shifts, int numLocked, int numConvergedStored, int *touch) {
+   primme_params *p = s->p;
+   const JD_projectors *jp = &p->correctionParams.projectors;
+   if (p->correctionParams.precondition && ((jp->RightQ && jp->SkewQ) || (jp->RightX && jp->SkewX)))
+      return PRIMME_FUNCTION_UNAVAILABLE;   /* K^-1-weighted skew projectors are not on this path */
+   char *x = VCOL(s, basisSize), *r = WCOL(s, basisSize), *sol = PCOL(s, s->Jw, s->ld, 4 * blockSize);
+   const int sizeEvecs = p->numOrthoConst + (p->locking ? numLocked : numConvergedStored);
+   jd_proj P;
+   memset(&P, 0, sizeof(P));
+   if (jp->LeftQ) {
+      P.LQ = s->evecs; P.ldLQ = s->ldevecs; P.nLQ = sizeEvecs;
+      if (jp->LeftX) {
+         if (blockSize <= 1) {   /* keep x next to Q: one projector panel */
+            CHK(hipk_copy_cols(s->ctx, s->dt, s->m, x, s->ld, ECOL(s, sizeEvecs), s->ldevecs, blockSize));
+            P.nLQ += blockSize;
+         } else { P.LX = x; P.ldLX = s->ld; P.nLX = blockSize; }
+      }
+   } else if (jp->LeftX) { P.LX = x; P.ldLX = s->ld; P.nLX = blockSize; }
+   if (jp->RightQ) { P.RQ = s->evecs; P.ldRQ = s->ldevecs; P.nRQ = sizeEvecs; }
+   if (jp->RightX) { P.RX = x; P.ldRX = s->ld; P.nRX = blockSize; }
+
+   double evalb[64], rn[64];
+   if (blockSize > 64) return PRIMME_UNEXPECTED_FAILURE;
+   for (int i = 0; i < blockSize; i++) { evalb[i] = s->hVals[iev[i]]; rn[i] = blockNorms[i]; }
+   p->ShiftsForPreconditioner = shifts;
+   const int touch0 = *touch;
+   int touch1 = touch0;
+   CHK(inner_solve(s, blockSize, x, r, rn, &P, sol, evalb, shifts, &touch1));
+   *touch = PA_MAX(*touch, touch1);
+   CHK(hipk_copy_cols(s->ctx, s->dt, s->m, sol, s->ld, x, s->ld, blockSize));
+   return 0;
+}

@@ -149,8 +149,11 @@ static void merge_sort(const double *lockedEvals, int numLocked, const double *r
 
 /* GD correction: t = K^-1 (r - eps x) (approximate Olsen when RightX) or K^-1 r;
  * without a preconditioner a device copy.  Writes the correction over X. */
+int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double *blockNorms, const int *iev,
+      double *shifts, int numLocked, int numConvergedStored, int *touch);
+
 static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numLocked, int *flags,
-      int basisSize, double *blockNorms, int *iev, int blockSize) {
+      int basisSize, double *blockNorms, int *iev, int blockSize, int numConvergedStored, int *touch) {
    primme_params *p = s->p;
    if (blockSize <= 0) return 0;
    double *shifts = (double *)malloc((size_t)blockSize * sizeof(double));
@@ -221,7 +224,10 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
 
    char *r = WCOL(s, basisSize), *x = VCOL(s, basisSize);
    int rc = 0;
-   if (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX) {
+   if (p->correctionParams.maxInnerIterations != 0) {
+      /* JDQMR: inner-outer iteration (reference correction.c:385-467) */
+      rc = pa_correction_jdqmr(s, basisSize, blockSize, blockNorms, iev, shifts, numLocked, numConvergedStored, touch);
+   } else if (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX) {
       rc = PRIMME_FUNCTION_UNAVAILABLE; /* exact Olsen projector: not on this path */
    } else {
       if (p->correctionParams.projectors.RightX &&
@@ -306,7 +312,8 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
    primme_params *p = s->p;
    int i, blockSize = 0, availableBlockSize = 0, basisSize = 0, numLocked = 0, numGuesses = 0,
        nextGuess = 0, numConverged = 0, recentlyConverged = 0, maxRecentlyConverged = 0,
-       restartLimitReached, nprevhVecs = 0, reset = 0, restartsSinceReset = 0, wholeSpace = 0;
+       restartLimitReached, nprevhVecs = 0, reset = 0, restartsSinceReset = 0, wholeSpace = 0, touch = 0,
+       numConvergedStored = 0;
    const int maxNumRandoms = 10;
    double smallestResNorm = HUGE_VAL;
    int *flags = s->flags, *map = s->map, *iev = s->iev, *perm = s->perm;
@@ -334,7 +341,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
       (p->maxOuterIterations == 0 || p->stats.numOuterIterations < p->maxOuterIterations))
 
    while (OUTER_LIMITS_OK()) {
-      p->initSize = numConverged = numLocked;
+      p->initSize = numConverged = numConvergedStored = numLocked;
       reset = 0;
       for (i = 0; i < p->maxBasisSize; i++) flags[i] = UNCONV;
       s->targetShiftIndex = 0;
@@ -371,6 +378,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                blockSize = recentlyConverged = 0;
             }
             numConverged += recentlyConverged;
+            if (recentlyConverged > 0) touch = 0;   /* inner stopping criteria restart with every new pair */
             pa_monitor(s, s->hVals, basisSize, flags, iev, blockSize, s->basisNorms, numConverged, evals,
                   numLocked, s->lockedFlags, resNorms, primme_event_outer_iteration);
 
@@ -382,7 +390,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                break;
 
             if (blockSize > 0)
-               CHK(solve_correction_gd(s, evals, numLocked, flags, basisSize, s->blockNorms, iev, blockSize));
+               CHK(solve_correction_gd(s, evals, numLocked, flags, basisSize, s->blockNorms, iev, blockSize, numConvergedStored, &touch));
 
             /* orthogonalise the corrections; when GD runs with locking and no
              * preconditioner keep Q'r for the practical-convergence test below */
@@ -612,7 +620,7 @@ static void free_solver(pa_solver *s) {
    if (!s) return;
    if (s->ctx) {
       hipk_sync(s->ctx);
-      hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T);
+      hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T); hipk_free(s->ctx, s->Jw);
       hipk_free(s->ctx, s->d_red); hipk_free(s->ctx, s->d_coef); hipk_free(s->ctx, s->d_theta);
       hipk_host_free(s->ctx, s->h_red); hipk_host_free(s->ctx, s->h_coef); hipk_host_free(s->ctx, s->h_theta);
       hipk_ctx_destroy(s->ctx);
@@ -652,10 +660,10 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    /* what this build of the path covers; anything else must fail loudly */
    if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
    if (p->massMatrixMatvec || p->projectionParams.projection != primme_proj_RR ||
-         p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) {
+         p->dynamicMethodSwitch > 0) {
       if (p->printLevel > 0 && p->outputFile)
          fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / non-RR projection / "
-               "JDQMR inner solver / dynamic method) is not on the device path yet\n");
+               "dynamic method switching) is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
@@ -684,6 +692,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    const size_t colBytes = (size_t)(s->ld > 0 ? s->ld : 1) * s->es;
    rc = hipk_malloc(s->ctx, colBytes * K, (void **)&s->V) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W) ||
         hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
+        (p->correctionParams.maxInnerIterations != 0 && hipk_malloc(s->ctx, colBytes * 5 * b, (void **)&s->Jw)) ||
         hipk_malloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->d_red) ||
         hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
         hipk_host_alloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->h_red) ||

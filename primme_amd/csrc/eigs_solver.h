@@ -20,6 +20,7 @@ typedef struct pa_solver {
    /* HBM-resident panels */
    char *V, *W;            /* m x K */
    char *T;                /* scratch, m x nT */
+   char *Jw;               /* JDQMR work panels g, d, delta, w, sol: m x 5b (only with inner iterations) */
    int nT;
    char *evecs;            /* caller's device array: constraints | locked | guesses */
    int64_t ldevecs;

@@ -709,6 +709,55 @@ residual_kernel(const T *__restrict__ X, int64_t ldX, T *__restrict__ Wr, int64_
    }
 }
 
+/* out[c] = X(:,c)' Y(:,c): b independent dot products (block QMR recurrences) */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+pair_dots_kernel(const T *__restrict__ X, int64_t ldX, const T *__restrict__ Y, int64_t ldY, int nx,
+      int64_t m, double *__restrict__ partials) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *x = X + (size_t)c * ldX;
+      const T *y = Y + (size_t)c * ldY;
+      double s = 0.0;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride)
+         s = fma((double)x[i], (double)y[i], s);
+      s = hipk_wave_sum(s);
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * nx + c] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      __syncthreads();
+   }
+}
+
+/* delta = gamma*delta + eta*d; sol += delta; out[c] = |sol(:,c)|^2  (one pass, block QMR) */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+qmr_update_kernel(ColScal gam, ColScal eta, const T *__restrict__ D, int64_t ldD, T *__restrict__ Delta,
+      int64_t ldDelta, T *__restrict__ Sol, int64_t ldSol, int nx, int64_t m, double *__restrict__ partials) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *d = D + (size_t)c * ldD;
+      T *de = Delta + (size_t)c * ldDelta;
+      T *so = Sol + (size_t)c * ldSol;
+      const double g = gam.a[c], e = eta.a[c];
+      double s = 0.0;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+         T nd = (T)fma((double)de[i], g, (double)d[i] * e);
+         de[i] = nd;
+         T ns = (T)((double)nd + (double)so[i]);
+         so[i] = ns;
+         s = fma((double)ns, (double)ns, s);
+      }
+      s = hipk_wave_sum(s);
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * nx + c] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      __syncthreads();
+   }
+}
+
 #define DISPATCH_RT(dt, CALL_D, CALL_F)         \
    switch (dt) {                                \
    case HIPK_F64: { typedef double T; CALL_D; } break; \
@@ -795,4 +844,32 @@ extern "C" int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const
          hipLaunchKernelGGL(residual_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (T *)Wr, ldW, nx, th, m, ctx->partials));
    HIPK_CHECK(hipGetLastError());
    return hipk_finalize_partials(ctx, ctx->partials, gx, nx, nrm2_dev);
+}
+
+extern "C" int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
+      const void *Y, int64_t ldY, int nx, double *out_dev) {
+   if (nx <= 0) return 0;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(pair_dots_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (const T *)Y, ldY, nx, m, ctx->partials),
+         hipLaunchKernelGGL(pair_dots_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (const T *)Y, ldY, nx, m, ctx->partials));
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, out_dev);
+}
+
+extern "C" int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gamma_host,
+      const double *eta_host, const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol,
+      int64_t ldSol, double *dotsol_dev) {
+   if (nx <= 0) return 0;
+   if (nx > UTIL_MAXCOLS) return -1;
+   ColScal g, e;
+   for (int c = 0; c < nx; c++) { g.a[c] = gamma_host[c]; e.a[c] = eta_host[c]; }
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(qmr_update_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, nx, m, ctx->partials),
+         hipLaunchKernelGGL(qmr_update_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, nx, m, ctx->partials));
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, dotsol_dev);
 }

@@ -48,6 +48,18 @@ CASES = {
     "lobpcg_default": ((20, 21), dict(numEvals=3, method="LOBPCG_OrthoBasis", eps=1e-6, aNorm=8.0, v0=None)),
     "float_bs1": ((20, 21), dict(numEvals=4, eps=1e-4, aNorm=8.0, dtype="float32", v0={"rng": 5, "cols": 1})),
     "float_bs2": ((20, 21), dict(numEvals=4, eps=1e-4, aNorm=8.0, dtype="float32", maxBlockSize=2, v0={"rng": 5, "cols": 2})),
+    # JDQMR inner-outer iteration (row a11 / f1)
+    "jdqmr_bs1": ((30, 31), dict(numEvals=4, method="JDQMR", eps=1e-10, aNorm=8.0)),
+    "jdqmr_etol_bs1": ((30, 31), dict(numEvals=4, method="JDQMR_ETol", eps=1e-10, aNorm=8.0)),
+    "jdqmr_largest_3d": ((20, 21, 22), dict(numEvals=6, method="JDQMR", eps=1e-9, aNorm=12.0, target="largest")),
+    "jdqmr_etol_largest_3d": ((20, 21, 22), dict(numEvals=6, method="JDQMR_ETol", eps=1e-9, aNorm=12.0, target="largest")),
+    "jdqmr_jacobi": ((30, 31), dict(numEvals=4, method="JDQMR", eps=1e-10, aNorm=8.0, precond="jacobi")),
+    "jdqmr_etol_jacobi": ((30, 31), dict(numEvals=4, method="JDQMR_ETol", eps=1e-10, aNorm=8.0, precond="jacobi")),
+    "jdqmr_soft": ((30, 31), dict(numEvals=4, method="JDQMR", eps=1e-10, aNorm=8.0, locking=0)),
+    "jdqmr_float": ((30, 31), dict(numEvals=3, method="JDQMR", eps=1e-4, aNorm=8.0, dtype="float32")),
+    "jdqmr_blk4": ((30, 31), dict(numEvals=6, method="JDQMR", eps=1e-10, aNorm=8.0, maxBlockSize=4)),
+    "jdqmr_etol_blk8_jacobi": ((20, 21, 22), dict(numEvals=10, method="JDQMR_ETol", eps=1e-9, aNorm=12.0, maxBlockSize=8, precond="jacobi")),
+    "jdqmr_closest_abs": ((30, 31), dict(numEvals=3, method="JDQMR", eps=1e-9, aNorm=8.0, target="closest_abs", targetShifts=[2.1])),
 }
 
 

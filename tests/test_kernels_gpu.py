@@ -203,6 +203,35 @@ def test_column_utilities(built, dt):
     assert np.allclose(res[0][4], res[1][4], rtol=tol * 100)
 
 
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("m,nx", [(777, 1), (123457, 3), (300001, 8)])
+def test_qmr_recurrence_kernels(built, dt, m, nx):
+    """hipk_pair_dots / hipk_qmr_update (block QMR of the JDQMR inner solver)."""
+    rng = np.random.default_rng(13 * m + nx)
+    npdt = NPDT[dt]
+    ld = m + 3
+    X, Y, D, Dl, S = (rng.standard_normal((nx, ld)).astype(npdt) for _ in range(5))
+    gam, eta = rng.standard_normal(nx), rng.standard_normal(nx)
+    res = []
+    for side in (Dev(), Host()):
+        x, y, d, dl, so = (side.arr(t) for t in (X, Y, D, Dl, S))
+        o1 = side.arr(np.zeros(nx)); o2 = side.arr(np.zeros(nx))
+        L = side.lib
+        assert L.hipk_pair_dots(side.ctx, dt, m, side.ptr(x), ld, side.ptr(y), ld, nx, side.ptr(o1)) == 0
+        assert L.hipk_qmr_update(side.ctx, dt, m, nx, (C.c_double * nx)(*gam), (C.c_double * nx)(*eta), side.ptr(d), ld,
+                                 side.ptr(dl), ld, side.ptr(so), ld, side.ptr(o2)) == 0
+        res.append([side.get(t) for t in (o1, o2, dl, so)])
+        side.close()
+    tol = 1e-12 if dt == F.HIPK_F64 else 2e-5
+    ref_dots = np.einsum("ij,ij->i", X[:, :m].astype(np.float64), Y[:, :m].astype(np.float64))
+    assert np.max(np.abs(res[0][0] - res[1][0])) <= tol * np.sqrt(m) * 4
+    assert np.max(np.abs(res[1][0] - ref_dots)) <= tol * np.sqrt(m) * 4
+    assert np.allclose(res[0][1], res[1][1], rtol=tol * 100)
+    for a_, b_ in zip(res[0][2:], res[1][2:]):
+        assert np.max(np.abs(a_[:, :m] - b_[:, :m])) <= (1e-13 if dt == F.HIPK_F64 else 1e-5) * 10
+        assert np.array_equal(a_[:, m:], b_[:, m:])      # padding rows untouched
+
+
 def _csr_cases():
     rp, ci, va, n = problems.laplacian_csr((37, 41, 29))
     yield "lap3d", rp, ci, va, n

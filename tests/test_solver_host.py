@@ -25,7 +25,10 @@ def _make_v0(spec, n):
     return np.random.default_rng(spec["rng"]).standard_normal((n, 9))[:, :spec["cols"]]
 
 # cases whose iteration path is chaotic (interior targets: the reference itself differs run to run)
-LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_leq": 0.05}
+LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_leq": 0.05,
+         # block JDQMR: the reference's inner solver mixes position- and column-indexed scalars once a
+         # block column has converged (see eigs_jd.c header); results agree, the paths do not
+         "jdqmr_blk4": 0.5, "jdqmr_etol_blk8_jacobi": 0.5, "jdqmr_closest_abs": 0.5}
 
 
 def _run(name, backend):
@@ -49,7 +52,7 @@ def test_against_reference_fixture(built, name):
     for k in ("maxBasisSize", "minRestartSize", "maxBlockSize", "locking", "orth", "maxPrevRetain"):
         assert r.params[k] == g["params"][k], k
     ev, evg = np.array(r.evals), np.array(g["evals"])
-    if name in ("lap2d_closest_abs",):
+    if name in ("lap2d_closest_abs", "jdqmr_closest_abs"):
         ev, evg = np.sort(ev), np.sort(evg)
     rel = 1e-4 if str(g["kwargs"].get("dtype", "")) == "float32" else 1e-10
     assert np.max(np.abs(ev - evg)) <= rel * aN
@@ -117,8 +120,10 @@ def test_edge_cases(built):
     op = Operator(n, csr=(rp, ci, va))
     r = eigsh(op, backend="hostcheck", numEvals=5, eps=1e-12, aNorm=8.0, v0=problems.start_vector(n), maxMatvecs=40)
     assert r.ret == -3 and r.stats["numMatvecs"] <= 41
-    # configurations that are not on the device path yet fail loudly with -44
-    r = eigsh(op, backend="hostcheck", numEvals=2, method="JDQMR", aNorm=8.0, v0=problems.start_vector(n))
+    # configurations that are not on the device path fail loudly with -44
+    r = eigsh(op, backend="hostcheck", numEvals=2, method="DYNAMIC", aNorm=8.0, v0=problems.start_vector(n))
+    assert r.ret == -44
+    r = eigsh(op, backend="hostcheck", numEvals=2, method="JD_Olsen_plusK", aNorm=8.0, precond="jacobi", v0=problems.start_vector(n))
     assert r.ret == -44
 
 
