@@ -52,7 +52,7 @@ class Result:
         s = params.stats
         self.stats = {k: getattr(s, k) for k, _ in F.PrimmeStats._fields_}
         self.params = {k: getattr(params, k) for k in ("maxBasisSize", "minRestartSize", "maxBlockSize",
-                                                       "locking", "orth", "aNorm", "eps", "initSize")}
+                                                       "locking", "orth", "aNorm", "eps", "initSize", "dynamicMethodSwitch")}
         self.params["maxPrevRetain"] = params.restartingParams.maxPrevRetain
 
 

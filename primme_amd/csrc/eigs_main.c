@@ -149,6 +149,12 @@ static void merge_sort(const double *lockedEvals, int numLocked, const double *r
 
 /* GD correction: t = K^-1 (r - eps x) (approximate Olsen when RightX) or K^-1 r;
  * without a preconditioner a device copy.  Writes the correction over X. */
+void pa_dyn_init(pa_cost_model *c, const primme_params *p);
+int pa_dyn_observe(pa_cost_model *c, primme_params *p, double now, int recentConv, int atRestart,
+      int numConverged, double currentResNorm);
+int pa_dyn_leave_gd(pa_solver *s, pa_cost_model *c);
+int pa_dyn_leave_jdqmr(pa_solver *s, pa_cost_model *c);
+void pa_dyn_recommend(const pa_cost_model *c, primme_params *p);
 int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double *blockNorms, const int *iev,
       double *shifts, int numLocked, int numConvergedStored, int *touch);
 
@@ -317,8 +323,11 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
    const int maxNumRandoms = 10;
    double smallestResNorm = HUGE_VAL;
    int *flags = s->flags, *map = s->map, *iev = s->iev, *perm = s->perm;
-   const int gdNoPrecondLocking = p->locking && !p->correctionParams.precondition &&
-                                  p->correctionParams.maxInnerIterations == 0;
+   /* re-evaluated at every use: the dynamic method changes maxInnerIterations on the way */
+#define gdNoPrecondLocking (p->locking && !p->correctionParams.precondition && \
+                            p->correctionParams.maxInnerIterations == 0)
+   pa_cost_model cost;
+   double tstart = 0.0;
 
    *ret = PRIMME_MAIN_ITER_FAILURE;
    *numRet = 0;
@@ -336,6 +345,15 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
    CHK(init_basis(s, &basisSize, &nextGuess, &numGuesses));
    p->initSize = 0;
+
+   if (p->dynamicMethodSwitch > 0) {
+      /* start with GD+k; JDQMR_ETol gets its turn once there are timings (eigs_dynamic.c) */
+      pa_dyn_init(&cost, p);
+      cost.t_mv = p->stats.timeMatvec / (double)p->stats.numMatvecs;
+      p->dynamicMethodSwitch = (p->numEvals < 5 ||
+            p->maxBasisSize + (p->locking ? p->numEvals : 0) >= p->n) ? 1 : 3;
+      p->correctionParams.maxInnerIterations = 0;
+   }
 
 #define OUTER_LIMITS_OK() (p->stats.numMatvecs < p->maxMatvecs && \
       (p->maxOuterIterations == 0 || p->stats.numOuterIterations < p->maxOuterIterations))
@@ -382,6 +400,17 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
             pa_monitor(s, s->hVals, basisSize, flags, iev, blockSize, s->basisNorms, numConverged, evals,
                   numLocked, s->lockedFlags, resNorms, primme_event_outer_iteration);
 
+            if (p->dynamicMethodSwitch > 0) {
+               if (cost.res0 == -1.0) cost.res0 = s->blockNorms[0];
+               if (recentlyConverged > 0 || p->dynamicMethodSwitch == 2) {
+                  cost.t_mv = p->stats.timeMatvec / (double)p->stats.numMatvecs;
+                  if (pa_dyn_observe(&cost, p, tstart, recentlyConverged, 0, numConverged, s->blockNorms[0])) {
+                     if (p->dynamicMethodSwitch == 3) CHK(pa_dyn_leave_gd(s, &cost));
+                     else if (p->dynamicMethodSwitch == 2 || p->dynamicMethodSwitch == 4) CHK(pa_dyn_leave_jdqmr(s, &cost));
+                  }
+               }
+            }
+
             if (numConverged >= p->numEvals ||
                   (p->locking && numConverged > numLocked && p->target != primme_smallest &&
                         p->target != primme_largest) ||
@@ -389,8 +418,11 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                   (numConverged >= nextGuess - p->numOrthoConst && numGuesses > 0))
                break;
 
-            if (blockSize > 0)
+            if (blockSize > 0) {
+               if (p->dynamicMethodSwitch > 0) { CHK(hipk_sync(s->ctx)); tstart = pa_wtime(); }
                CHK(solve_correction_gd(s, evals, numLocked, flags, basisSize, s->blockNorms, iev, blockSize, numConvergedStored, &touch));
+               if (p->dynamicMethodSwitch > 0) { CHK(hipk_sync(s->ctx)); cost.t_inner += pa_wtime() - tstart; }
+            }
 
             /* orthogonalise the corrections; when GD runs with locking and no
              * preconditioner keep Q'r for the practical-convergence test below */
@@ -566,6 +598,14 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
          p->stats.numRestarts++;
          p->initSize = numConverged;
+         if (p->dynamicMethodSwitch == 1) {
+            /* few eigenpairs: GD+k is judged after each restart, restart cost included */
+            CHK(hipk_sync(s->ctx));
+            tstart = pa_wtime();
+            cost.t_mv = p->stats.timeMatvec / (double)p->stats.numMatvecs;
+            pa_dyn_observe(&cost, p, tstart, 0, 1, numConverged, s->blockNorms[0]);
+            CHK(pa_dyn_leave_gd(s, &cost));
+         }
          for (i = 0; i < p->maxBasisSize; i++) map[i] = i;
       } /* restarting loop */
 
@@ -578,6 +618,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
       if (p->locking) {
          CHK(copy_back_candidates(s, basisSize, evals, resNorms, numConverged, numRet));
          if (*numRet < numConverged) *numRet = numConverged;
+         pa_dyn_recommend(&cost, p);
          p->stats.lockingIssue = 0;
          *ret = (numConverged == p->numEvals || wholeSpace) ? 0 : PRIMME_MAIN_ITER_FAILURE;
          goto clean;
@@ -585,6 +626,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
          restartLimitReached = OUTER_LIMITS_OK() ? 0 : 1;
          CHK(verify_norms(s, restartLimitReached ? PA_MIN(p->numEvals, basisSize) : numConverged, resNorms, flags, &numConverged));
          if (restartLimitReached || numConverged >= p->numEvals || wholeSpace) {
+            pa_dyn_recommend(&cost, p);
             for (i = 0; i < p->numEvals; i++) { evals[i] = s->hVals[i]; perm[i] = i; }
             CHK(hipk_copy_cols(s->ctx, s->dt, s->m, s->V, s->ld, ECOL(s, p->numOrthoConst), s->ldevecs, p->numEvals));
             *numRet = p->numEvals;
@@ -659,11 +701,10 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 
    /* what this build of the path covers; anything else must fail loudly */
    if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
-   if (p->massMatrixMatvec || p->projectionParams.projection != primme_proj_RR ||
-         p->dynamicMethodSwitch > 0) {
+   if (p->massMatrixMatvec || p->projectionParams.projection != primme_proj_RR) {
       if (p->printLevel > 0 && p->outputFile)
-         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / non-RR projection / "
-               "dynamic method switching) is not on the device path\n");
+         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / non-RR projection) "
+               "is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
@@ -673,10 +714,11 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->m = p->nLocal; s->ld = p->ldOPs; s->K = p->maxBasisSize;
    s->evecs = (char *)evecs; s->ldevecs = p->ldevecs;
    s->startTime = t0;
-   s->phase_timing = p->profile != NULL;
+   /* the dynamic method's cost model needs device time, not launch time */
+   s->phase_timing = p->profile != NULL || p->dynamicMethodSwitch > 0;
    s->dev_comm = (p->numProcs > 1 && p->globalSumReal == primme_amd_global_sum);
    s->coef_valid_k = -1;
-   s->fuse_gd = (p->correctionParams.maxInnerIterations == 0 && !p->correctionParams.precondition &&
+   s->fuse_gd = (p->correctionParams.maxInnerIterations == 0 && p->dynamicMethodSwitch <= 0 && !p->correctionParams.precondition &&
                  !p->correctionParams.projectors.RightX && p->convTestFun == pa_conv_test_absolute);
    s->maxRank = p->numOrthoConst + (p->locking ? p->numEvals : 0) + p->maxBasisSize;
    if (hipk_ctx_create(&s->ctx, p->queue)) { free(s); return PRIMME_UNEXPECTED_FAILURE; }
@@ -692,7 +734,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    const size_t colBytes = (size_t)(s->ld > 0 ? s->ld : 1) * s->es;
    rc = hipk_malloc(s->ctx, colBytes * K, (void **)&s->V) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W) ||
         hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
-        (p->correctionParams.maxInnerIterations != 0 && hipk_malloc(s->ctx, colBytes * 5 * b, (void **)&s->Jw)) ||
+        ((p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) && hipk_malloc(s->ctx, colBytes * 5 * b, (void **)&s->Jw)) ||
         hipk_malloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->d_red) ||
         hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
         hipk_host_alloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->h_red) ||

@@ -63,6 +63,19 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
    return 0;
 }
 
+/* global sum of a few host scalars (cost-model ratios): through the same path as the
+ * device partials so that every communicator flavour is covered */
+int pa_reduce_host(pa_solver *s, double *buf, int count) {
+   primme_params *p = s->p;
+   if (count <= 0 || p->numProcs <= 1 || !p->globalSumReal) return 0;
+   CHK(hipk_sync(s->ctx));
+   memcpy(s->h_red, buf, (size_t)count * sizeof(double));
+   if (s->dev_comm) CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, (size_t)count * sizeof(double)));
+   CHK(pa_reduce(s, s->d_red, count, 0, 0));
+   memcpy(buf, s->h_red, (size_t)count * sizeof(double));
+   return 0;
+}
+
 /* ---- W(:,c0:c0+nc) = A * V(:,c0:c0+nc)  (reference auxiliary_eigs.c:183-230) ---- */
 int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0, int nc) {
    primme_params *p = s->p;

@@ -7,6 +7,21 @@
 enum { UNCONV = PRIMME_AMD_UNCONVERGED, SKIP_RESTART = PRIMME_AMD_SKIP_UNTIL_RESTART,
        CONV = PRIMME_AMD_CONVERGED, PRACT_CONV = PRIMME_AMD_PRACTICALLY_CONVERGED };
 
+/* run-time cost model of the dynamic method (eigs_dynamic.c) */
+typedef struct {
+   double t_mv_pr, t_mv, t_pr;        /* operator, preconditioner time per application      */
+   double t_qmr, t_qmr_mv_pr;         /* one QMR step without / with the operators          */
+   double t_gd_mv_pr, t_gd_mv;        /* one GD+k outer step with / without the correction  */
+   double rate_gd, rate_jd;           /* residual reduction per matvec seen so far          */
+   double slowdown, mv_per_outer;
+   int next_reset;
+   double logred_gd, logred_jd, mv_gd, mv_jd;
+   int found_gd, found_jd;
+   int it0, mv0;                      /* counters at the last observation                   */
+   double t0, t_inner, res0;
+   double acc_jd, acc_gd, acc_ratio;  /* expected accumulated times, for the recommendation */
+} pa_cost_model;
+
 typedef struct pa_solver {
    primme_params *p;
    hipk_ctx *ctx;

@@ -48,6 +48,11 @@ CASES = {
     "lobpcg_default": ((20, 21), dict(numEvals=3, method="LOBPCG_OrthoBasis", eps=1e-6, aNorm=8.0, v0=None)),
     "float_bs1": ((20, 21), dict(numEvals=4, eps=1e-4, aNorm=8.0, dtype="float32", v0={"rng": 5, "cols": 1})),
     "float_bs2": ((20, 21), dict(numEvals=4, eps=1e-4, aNorm=8.0, dtype="float32", maxBlockSize=2, v0={"rng": 5, "cols": 2})),
+    # BASELINE configs[0] as the file has it (examples/ex_eigs_dseq.c: n=100, 10 smallest, Jacobi,
+    # eps 1e-9, PRIMME_DYNAMIC).  The path taken depends on wall-clock timings; the results do not.
+    "lap1d_ex_dseq_dynamic": ((100,), dict(numEvals=10, method="DYNAMIC", eps=1e-9, aNorm=4.0, precond="jacobi")),
+    "lap3d_dynamic": ((30, 31, 32), dict(numEvals=12, method="DYNAMIC", eps=1e-9, aNorm=12.0)),
+    "lap2d_dynamic_few_soft": ((40, 41), dict(numEvals=3, method="DYNAMIC", eps=1e-10, aNorm=8.0, locking=0)),
     # JDQMR inner-outer iteration (row a11 / f1)
     "jdqmr_bs1": ((30, 31), dict(numEvals=4, method="JDQMR", eps=1e-10, aNorm=8.0)),
     "jdqmr_etol_bs1": ((30, 31), dict(numEvals=4, method="JDQMR_ETol", eps=1e-10, aNorm=8.0)),

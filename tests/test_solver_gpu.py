@@ -29,6 +29,7 @@ def _make_v0(spec, n):
     return np.random.default_rng(spec["rng"]).standard_normal((n, 9))[:, :spec["cols"]]
 
 LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_leq": 0.05,
+         "lap1d_ex_dseq_dynamic": 1e9, "lap3d_dynamic": 1e9, "lap2d_dynamic_few_soft": 1e9,   # timing-driven paths
          "jdqmr_blk4": 0.5, "jdqmr_etol_blk8_jacobi": 0.5, "jdqmr_closest_abs": 0.5}
 
 

@@ -28,6 +28,7 @@ def _make_v0(spec, n):
 LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_leq": 0.05,
          # block JDQMR: the reference's inner solver mixes position- and column-indexed scalars once a
          # block column has converged (see eigs_jd.c header); results agree, the paths do not
+         "lap1d_ex_dseq_dynamic": 1e9, "lap3d_dynamic": 1e9, "lap2d_dynamic_few_soft": 1e9,   # timing-driven paths
          "jdqmr_blk4": 0.5, "jdqmr_etol_blk8_jacobi": 0.5, "jdqmr_closest_abs": 0.5}
 
 
@@ -121,10 +122,21 @@ def test_edge_cases(built):
     r = eigsh(op, backend="hostcheck", numEvals=5, eps=1e-12, aNorm=8.0, v0=problems.start_vector(n), maxMatvecs=40)
     assert r.ret == -3 and r.stats["numMatvecs"] <= 41
     # configurations that are not on the device path fail loudly with -44
-    r = eigsh(op, backend="hostcheck", numEvals=2, method="DYNAMIC", aNorm=8.0, v0=problems.start_vector(n))
-    assert r.ret == -44
     r = eigsh(op, backend="hostcheck", numEvals=2, method="JD_Olsen_plusK", aNorm=8.0, precond="jacobi", v0=problems.start_vector(n))
     assert r.ret == -44
+
+
+def test_dynamic_method_leaves_a_recommendation(built):
+    """PRIMME_DYNAMIC (reference main_iter.c:427-436, :1221-1228): converges like the fixed methods
+    and reports -1 (GD+k), -2 (JDQMR_ETol) or -3 (close call) in dynamicMethodSwitch."""
+    dims = (100,)
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    op = Operator(n, csr=(rp, ci, va))
+    r = eigsh(op, backend="hostcheck", numEvals=10, eps=1e-9, aNorm=4.0, precond="jacobi", method="DYNAMIC",
+              v0=problems.start_vector(n))
+    assert r.ret == 0 and r.params["dynamicMethodSwitch"] in (-1, -2, -3)
+    assert np.max(np.abs(r.evals - problems.laplacian_eigenvalues(dims, 10))) <= 1e-10 * 4.0
+    assert np.all(r.resNorms <= 1e-9 * 4.0 * (1 + 1e-6))
 
 
 def test_launch_structure_block_size_one(built):
