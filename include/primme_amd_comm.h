@@ -37,6 +37,10 @@ int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n
 typedef struct primme_amd_operator primme_amd_operator;
 int primme_amd_operator_create(primme_amd_operator **op, hipk_csr *A, primme_amd_comm *comm_or_null);
 int primme_amd_operator_destroy(primme_amd_operator *op);
+/* flavour of primme_amd_jacobi_precond for this operator: fixed = 0 (default) divides by
+ * diag(A) - ShiftsForPreconditioner[c] (reference tests/COMMON/mat.c:187-193, examples/
+ * ex_eigs_dseq.c:187-202); fixed = 1 by diag(A) - shift (mat.c:137-147, :166-170) */
+int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double shift);
 hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op);
 /* y = A x on `hip_stream` including the halo exchange */
 int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stream, const void *x, int64_t ldx,

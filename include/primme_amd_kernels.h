@@ -173,9 +173,11 @@ int64_t hipk_csr_halo_hi(const hipk_csr *A);
  * halo length) the communicator fills before each matvec */
 int hipk_csr_set_halo(hipk_csr *A, const void *lo, const void *hi);
 
-/* y(:,c) = x(:,c) / (d - shift[c])  (Jacobi), shifts on host */
+/* y(:,c) = x(:,c) / (d - shift[c])  (Jacobi), shifts on host; |d - shift| is kept above
+ * min_denominator with its sign (reference tests/COMMON/mat.c:149-165) */
 int hipk_jacobi_apply(void *hip_stream, hipk_dtype dt, int64_t m, const void *diag,
-      const double *shift_host, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols);
+      const double *shift_host, double min_denominator, const void *x, int64_t ldx, void *y,
+      int64_t ldy, int ncols);
 hipk_dtype hipk_csr_dtype(const hipk_csr *A);
 int64_t hipk_csr_nrows(const hipk_csr *A);
 

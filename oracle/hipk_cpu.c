@@ -333,13 +333,14 @@ int hipk_csr_matvec(hipk_csr *A, void *stream, const void *x, int64_t ldx, void 
 }
 
 int hipk_jacobi_apply(void *stream, hipk_dtype dt, int64_t m, const void *diag, const double *shift,
-      const void *x, int64_t ldx, void *y, int64_t ldy, int ncols) {
+      double min_den, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols) {
    (void)stream;
+   if (!(min_den > 0.0)) min_den = 1e-300;
    for (int c = 0; c < ncols; c++) {
       const void *xc = colp(dt, x, ldx, c); void *yc = (void *)colp(dt, y, ldy, c);
       for (int64_t i = 0; i < m; i++) {
          double d = ld_(dt, diag, i) - (shift ? shift[c] : 0.0);
-         if (fabs(d) < 1e-300) d = d < 0 ? -1e-300 : 1e-300;
+         if (!(fabs(d) > min_den)) d = copysign(min_den, d);
          st_(dt, yc, i, ld_(dt, xc, i) / d);
       }
    }

@@ -7,7 +7,8 @@
 #include "primme_amd.h"
 #include "primme_amd_comm.h"
 
-struct primme_amd_operator { hipk_csr *A; };
+struct primme_amd_operator { hipk_csr *A; int jacobi_fixed; double jacobi_shift; };
+int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double shift) { op->jacobi_fixed = fixed; op->jacobi_shift = shift; return 0; }
 int primme_amd_operator_create(primme_amd_operator **op, hipk_csr *A, primme_amd_comm *c) {
    (void)c; *op = calloc(1, sizeof(**op)); (*op)->A = A; return 0;
 }
@@ -21,8 +22,11 @@ void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *
 }
 void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)p->preconditioner;
+   double fixed[64];
+   for (int c = 0; c < *bs && c < 64; c++) fixed[c] = op->jacobi_shift;
    *ierr = hipk_jacobi_apply(NULL, hipk_csr_dtype(op->A), hipk_csr_nrows(op->A), hipk_csr_diag(op->A),
-         p->ShiftsForPreconditioner, x, *ldx, y, *ldy, *bs);
+         op->jacobi_fixed ? fixed : p->ShiftsForPreconditioner, 1e-14 * (p->aNorm >= 0.0 ? p->aNorm : 1.0),
+         x, *ldx, y, *ldy, *bs);
 }
 void primme_amd_global_sum(void *s, void *r, int *c, struct primme_params *p, int *ierr) {
    (void)s; (void)r; (void)c; (void)p; *ierr = 1; /* RCCL only exists in the product library */

@@ -159,7 +159,8 @@ def _declare_kernels(lib):
         "hipk_stencil_create": [_vp, _i, _i, _i, _i, _i64, _i64, P(_vp)],
         "hipk_csr_destroy": [_vp], "hipk_csr_matvec": [_vp, _vp, _vp, _i64, _vp, _i64, _i],
         "hipk_csr_set_halo": [_vp, _vp, _vp],
-        "hipk_jacobi_apply": [_vp, _i, _i64, _vp, _dp, _vp, _i64, _vp, _i64, _i],
+        "hipk_jacobi_apply": [_vp, _i, _i64, _vp, _dp, C.c_double, _vp, _i64, _vp, _i64, _i],
+        "primme_amd_operator_set_jacobi": [_vp, _i, C.c_double],
         "hipk_bandwidth_probe": [_vp, C.c_size_t, _i, _dp],
         "hipk_prof_enable": [_i], "hipk_prof_get": [_i, _dp, P(C.c_long), _dp],
         "primme_amd_operator_create": [P(_vp), _vp, _vp], "primme_amd_operator_destroy": [_vp],

@@ -156,17 +156,21 @@ class Session:
             cb = F.BLOCK_OP(mv)
             keep.append(cb)
             p.matrixMatvec = C.cast(cb, C.c_void_p)
-            if precond == "jacobi":
+            if precond is not None:
                 dg = op.diagonal()
+                jfixed = None if precond == "jacobi" else float(precond[1])
 
                 def pc(x, ldx, y, ldy, bs, pp, ierr):
                     nb, lx, ly = bs[0], ldx[0], ldy[0]
                     X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
                     Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
                     sh = pp[0].ShiftsForPreconditioner
+                    an = pp[0].aNorm
+                    mind = 1e-14 * (an if an >= 0 else 1.0)
                     for c in range(nb):
-                        d = dg - (sh[c] if sh else 0.0)
-                        d[np.abs(d) < 1e-300] = 1e-300
+                        d = dg - (jfixed if jfixed is not None else (sh[c] if sh else 0.0))
+                        small = ~(np.abs(d) > mind)
+                        d[small] = np.copysign(mind, d[small])
                         Y[c, :nLocal] = X[c, :nLocal] / d
                     ierr[0] = 0
                 pcb = F.BLOCK_OP(pc)
@@ -184,7 +188,10 @@ class Session:
             if user_matvec is not None:      # an application callback instead of the ready-made one
                 keep.append(user_matvec)
                 p.matrixMatvec = C.cast(user_matvec, C.c_void_p)
-            if precond == "jacobi":
+            if precond is not None:
+                # "jacobi": per-vector shifts of the solver; ("jacobi", s): fixed K = diag(A) - s
+                if precond == "jacobi": lib.primme_amd_operator_set_jacobi(self.oph, 0, 0.0)
+                else: lib.primme_amd_operator_set_jacobi(self.oph, 1, float(precond[1]))
                 p.preconditioner = self.oph
                 p.applyPreconditioner = C.cast(lib.primme_amd_jacobi_precond, C.c_void_p)
                 p.correctionParams.precondition = 1
@@ -243,7 +250,7 @@ def eigsh(op, backend="hip", comm=None, dtype=np.float64, **kw):
 
     v0: optional (nLocal x initSize) initial guesses -> initBasisMode defaults to
     primme_init_user so that no random numbers enter (parity runs).
-    precond: None | "jacobi".
+    precond: None | "jacobi" (Davidson: per-vector shifts) | ("jacobi", shift) (fixed shift).
     """
     s = Session(op, comm=comm, dtype=dtype, backend=backend)
     try:

@@ -18,6 +18,8 @@ struct primme_amd_operator {
    void *xfull;              /* all-gather buffer */
    size_t cap_full;
    int64_t row0, nrows, n;
+   int jacobi_fixed;         /* 1: K = diag(A) - jacobi_shift, 0: per-vector shifts of the solver */
+   double jacobi_shift;
 };
 
 static size_t op_elem(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : dt == HIPK_F32 ? 4 : 16; }
@@ -129,7 +131,16 @@ extern "C" void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRI
       int *blockSize, struct primme_params *primme, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)primme->preconditioner;
    void *stream = primme->queue ? (void *)*(hipStream_t *)primme->queue : NULL;
-   if (!op) { *ierr = 1; return; }
+   if (!op || *blockSize > 64) { *ierr = 1; return; }
+   double fixed[64];
+   for (int c = 0; c < *blockSize; c++) fixed[c] = op->jacobi_shift;
    *ierr = hipk_jacobi_apply(stream, hipk_csr_dtype(op->A), hipk_csr_nrows(op->A), hipk_csr_diag(op->A),
-         primme->ShiftsForPreconditioner, x, *ldx, y, *ldy, *blockSize);
+         op->jacobi_fixed ? fixed : primme->ShiftsForPreconditioner,
+         1e-14 * (primme->aNorm >= 0.0 ? primme->aNorm : 1.0), x, *ldx, y, *ldy, *blockSize);
+}
+
+extern "C" int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double shift) {
+   if (!op) return -1;
+   op->jacobi_fixed = fixed; op->jacobi_shift = shift;
+   return 0;
 }

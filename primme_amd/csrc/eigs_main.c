@@ -708,6 +708,12 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
+   if (p->maxBasisSize > 255) {
+      if (p->printLevel > 0 && p->outputFile)
+         fprintf(p->outputFile, "primme_amd: maxBasisSize > 255 is not on the device path\n");
+      return PRIMME_FUNCTION_UNAVAILABLE;
+   }
+
    pa_solver *s = (pa_solver *)calloc(1, sizeof(pa_solver));
    if (!s) return PRIMME_MALLOC_FAILURE;
    s->p = p; s->dt = dt; s->es = (dt == HIPK_F64) ? 8 : 4; s->mach_eps = mach_eps;

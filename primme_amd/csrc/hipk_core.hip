@@ -35,6 +35,7 @@ extern "C" int hipk_ctx_destroy(hipk_ctx *ctx) {
    if (!ctx) return 0;
    hipStreamSynchronize(ctx->stream);
    if (ctx->partials) hipFree(ctx->partials);
+   if (ctx->jobtab) hipFree(ctx->jobtab);
    hipEventDestroy(ctx->ev0);
    hipEventDestroy(ctx->ev1);
    if (ctx->own_stream) hipStreamDestroy(ctx->stream);

@@ -25,6 +25,7 @@ struct hipk_ctx {
     * needs only a stream synchronisation, no device->host copy */
    double *mirror_dev, *mirror_host;
    size_t mirror_count;
+   void *jobtab;         /* device copy of a large Ritz-update job table (basis sizes > 64) */
 };
 
 static inline double *hipk_mirror_of(const hipk_ctx *ctx, const double *out_dev) {

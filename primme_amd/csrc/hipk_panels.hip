@@ -336,6 +336,28 @@ extern "C" int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const
    SegArgs sa;
    if (pack_segs(segs, nseg, &sa)) return -1;
    if (nx <= 0) return 0;
+   if (sa.total > PROJ_MAXCOLS) {
+      /* more columns than one launch stages in LDS: project window by window (the operation
+       * is a sum over columns); the norms come from the last window */
+      const size_t es = (dt == HIPK_F64) ? 8 : 4;
+      for (int w0 = 0; w0 < sa.total; w0 += PROJ_MAXCOLS) {
+         const int wn = sa.total - w0 < PROJ_MAXCOLS ? sa.total - w0 : PROJ_MAXCOLS;
+         hipk_seg sub[HIPK_MAX_SEGS];
+         int ns = 0, c = 0;
+         for (int q = 0; q < HIPK_MAX_SEGS; q++) {
+            const int lo = w0 > c ? w0 : c, hi = (w0 + wn < c + sa.n[q]) ? w0 + wn : c + sa.n[q];
+            if (hi > lo) {
+               sub[ns].base = (char *)sa.base[q] + (size_t)(lo - c) * (size_t)sa.ld[q] * es;
+               sub[ns].ld = sa.ld[q]; sub[ns].ncols = hi - lo; ns++;
+            }
+            c += sa.n[q];
+         }
+         int rc = hipk_panel_project(ctx, dt, m, sub, ns, coef_dev + w0, ldcoef, X, ldX, nx,
+               (w0 + wn >= sa.total) ? nrm2_dev : NULL);
+         if (rc) return rc;
+      }
+      return 0;
+   }
    switch (dt) {
    case HIPK_F64: return panel_project_t<double>(ctx, m, sa, coef_dev, ldcoef, (double *)X, ldX, nx, nrm2_dev);
    case HIPK_F32: return panel_project_t<float>(ctx, m, sa, coef_dev, ldcoef, (float *)X, ldX, nx, nrm2_dev);
@@ -444,6 +466,86 @@ ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
    }
 }
 
+
+/* General basis size (64 < k <= 255; unrestarted or user-chosen large maxBasisSize, e.g. the
+ * reference's tests/tests/test_001 with maxBasisSize 140).  Workgroup = one wave, 32 rows per
+ * tile; the tile's V (then W) rows are staged in LDS ([k][32] doubles = k/4 KB), so the update
+ * is still in place and every column is read exactly once.  The two half-waves split the
+ * outputs.  Not a roofline kernel: with k this large the small dense eigenproblem on the host
+ * dominates anyway. */
+#define RITZ_BIG_ROWS 32
+#define RITZ_BIG_MAXOUT 256
+struct RitzBigArgs {       /* output lists live in device memory (ctx->jobtab) */
+   int nxv, nxw, nres;
+   const unsigned char *xv_col, *xw_col;
+   void *const *xv_dst, *const *xw_dst;
+   unsigned char res_col[RITZ_MAXRES];
+   short res_slot[RITZ_MAXRES];
+   void *res_dst[RITZ_MAXRES];
+};
+template <typename T>
+__global__ void __launch_bounds__(64)
+ritz_big_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
+      const double *__restrict__ h, int ldh, const double *__restrict__ theta, RitzBigArgs ja,
+      int64_t m, double *__restrict__ partials, int nslots) {
+   extern __shared__ double tile[];                /* tile[j*32 + r] */
+   __shared__ double xres[RITZ_MAXRES][RITZ_BIG_ROWS];
+   __shared__ double n2s[RITZ_MAXRES][2];
+   const int lane = threadIdx.x, r = lane & 31, half = lane >> 5;
+   const bool needW = (ja.nxw > 0 || ja.nres > 0);
+   double n2[RITZ_MAXRES];
+#pragma unroll
+   for (int q = 0; q < RITZ_MAXRES; q++) n2[q] = 0.0;
+   const int64_t ntiles = (m + RITZ_BIG_ROWS - 1) / RITZ_BIG_ROWS;
+   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const int64_t i = t * RITZ_BIG_ROWS + r;
+      const bool live = i < m;
+      __syncthreads();
+      for (int j = half; j < k; j += 2) tile[j * RITZ_BIG_ROWS + r] = live ? (double)V[i + (size_t)j * ld] : 0.0;
+      __syncthreads();
+      for (int o = half; o < ja.nxv + ja.nres; o += 2) {
+         const bool isres = o >= ja.nxv;
+         const int col = isres ? ja.res_col[o - ja.nxv] : ja.xv_col[o];
+         const double *hc = h + (size_t)col * ldh;
+         double s = 0.0;
+         for (int j = 0; j < k; j++) s = fma(tile[j * RITZ_BIG_ROWS + r], hc[j], s);
+         if (isres) xres[o - ja.nxv][r] = s;
+         else if (live) ((T *)ja.xv_dst[o])[i] = (T)s;
+      }
+      if (!needW) continue;
+      __syncthreads();
+      for (int j = half; j < k; j += 2) tile[j * RITZ_BIG_ROWS + r] = live ? (double)W[i + (size_t)j * ld] : 0.0;
+      __syncthreads();
+      for (int o = half; o < ja.nxw + ja.nres; o += 2) {
+         const bool isres = o >= ja.nxw;
+         const int q = o - ja.nxw;
+         const int col = isres ? ja.res_col[q] : ja.xw_col[o];
+         const double *hc = h + (size_t)col * ldh;
+         double s = 0.0;
+         for (int j = 0; j < k; j++) s = fma(tile[j * RITZ_BIG_ROWS + r], hc[j], s);
+         if (!isres) { if (live) ((T *)ja.xw_dst[o])[i] = (T)s; continue; }
+         T res = (T)fma(-theta[col], xres[q][r], s);
+         if (live) {
+            if (ja.res_dst[q]) ((T *)ja.res_dst[q])[i] = res;
+#pragma unroll
+            for (int qq = 0; qq < RITZ_MAXRES; qq++) if (qq == q) n2[qq] = fma((double)res, (double)res, n2[qq]);
+         }
+      }
+   }
+   if (nslots > 0) {
+      /* residual q was accumulated by half-wave (nxw + q) & 1 only */
+#pragma unroll
+      for (int q = 0; q < RITZ_MAXRES; q++) {
+         double v = n2[q];
+         for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
+         if (r == 0) n2s[q][half] = v;
+      }
+      __syncthreads();
+      if (lane < ja.nres && ja.res_slot[lane] >= 0)
+         partials[(size_t)blockIdx.x * nslots + ja.res_slot[lane]] = n2s[lane][0] + n2s[lane][1];
+   }
+}
+
 template <typename T, int NK, bool PRE>
 static int ritz_launch_nk(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
       const double *h, int ldh, int nh, const double *theta, const RitzArgs &ja, int gx,
@@ -473,36 +575,64 @@ template <typename T>
 static int ritz_update_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
       const double *h, int ldh, const double *theta, const hipk_job *jobs, int njobs,
       double *nrm2_dev) {
-   RitzArgs ja;
-   memset(&ja, 0, sizeof(ja));
+   /* host-side job table; the small kernels take it by value, the general one from HBM */
+   struct { unsigned char xv_col[RITZ_BIG_MAXOUT], xw_col[RITZ_BIG_MAXOUT]; void *xv_dst[RITZ_BIG_MAXOUT], *xw_dst[RITZ_BIG_MAXOUT]; } tab;
+   RitzBigArgs jb_;
+   memset(&jb_, 0, sizeof(jb_));
    int nh = 0, nslots = 0;
    for (int q = 0; q < njobs; q++) {
       const hipk_job &jb = jobs[q];
       if (jb.col < 0 || jb.col > 255) return -1;
       if (jb.col + 1 > nh) nh = jb.col + 1;
       if (jb.kind == HIPK_JOB_XV) {
-         if (ja.nxv >= RITZ_MAXOUT) return -1;
-         ja.xv_col[ja.nxv] = (unsigned char)jb.col; ja.xv_dst[ja.nxv++] = jb.dst;
+         if (jb_.nxv >= RITZ_BIG_MAXOUT) return -1;
+         tab.xv_col[jb_.nxv] = (unsigned char)jb.col; tab.xv_dst[jb_.nxv++] = jb.dst;
       } else if (jb.kind == HIPK_JOB_XW) {
-         if (ja.nxw >= RITZ_MAXOUT) return -1;
-         ja.xw_col[ja.nxw] = (unsigned char)jb.col; ja.xw_dst[ja.nxw++] = jb.dst;
+         if (jb_.nxw >= RITZ_BIG_MAXOUT) return -1;
+         tab.xw_col[jb_.nxw] = (unsigned char)jb.col; tab.xw_dst[jb_.nxw++] = jb.dst;
       } else if (jb.kind == HIPK_JOB_RES) {
-         if (ja.nres >= RITZ_MAXRES) return -1;
-         ja.res_col[ja.nres] = (unsigned char)jb.col; ja.res_dst[ja.nres] = jb.dst;
-         ja.res_slot[ja.nres++] = (short)jb.slot;
+         if (jb_.nres >= RITZ_MAXRES) return -1;
+         jb_.res_col[jb_.nres] = (unsigned char)jb.col; jb_.res_dst[jb_.nres] = jb.dst;
+         jb_.res_slot[jb_.nres++] = (short)jb.slot;
          if (jb.slot + 1 > nslots) nslots = jb.slot + 1;
       } else return -1;
    }
    if (k <= 0 || njobs <= 0) return 0;
    if (nslots > 0 && !nrm2_dev) return -1;
-   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4);
+   const bool small = (k <= 64 && jb_.nxv <= RITZ_MAXOUT && jb_.nxw <= RITZ_MAXOUT);
+   int gx = small ? hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4) : hipk_grid_for_rows(ctx, m, RITZ_BIG_ROWS, 8);
    if (nslots > 0) {
       /* every block writes every slot; slots must be 0..nslots-1, each used once */
       if (hipk_reserve_partials(ctx, (size_t)gx * nslots)) return -2;
    }
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream,
-         (double)m * sizeof(T) * ((double)k * (1 + ((ja.nxw > 0 || ja.nres > 0) ? 1 : 0)) + ja.nxv + ja.nxw + ja.nres));
-   int rc = ritz_dispatch<T>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+         (double)m * sizeof(T) * ((double)k * (1 + ((jb_.nxw > 0 || jb_.nres > 0) ? 1 : 0)) + jb_.nxv + jb_.nxw + jb_.nres));
+   int rc;
+   if (small) {
+      RitzArgs ja;
+      memset(&ja, 0, sizeof(ja));
+      ja.nxv = jb_.nxv; ja.nxw = jb_.nxw; ja.nres = jb_.nres;
+      memcpy(ja.xv_col, tab.xv_col, (size_t)jb_.nxv); memcpy(ja.xv_dst, tab.xv_dst, (size_t)jb_.nxv * sizeof(void *));
+      memcpy(ja.xw_col, tab.xw_col, (size_t)jb_.nxw); memcpy(ja.xw_dst, tab.xw_dst, (size_t)jb_.nxw * sizeof(void *));
+      memcpy(ja.res_col, jb_.res_col, sizeof(ja.res_col)); memcpy(ja.res_slot, jb_.res_slot, sizeof(ja.res_slot));
+      memcpy(ja.res_dst, jb_.res_dst, sizeof(ja.res_dst));
+      rc = ritz_dispatch<T>(ctx, m, V, W, ld, k, h, ldh, nh, theta, ja, gx, nslots);
+   } else {
+      const size_t shm = (size_t)k * RITZ_BIG_ROWS * sizeof(double);
+      if (k > 255 || shm > 64 * 1024) return -1;
+      if (!ctx->jobtab) HIPK_CHECK(hipMalloc(&ctx->jobtab, sizeof(tab)));
+      /* the table is tiny and this is the rare path: a blocking copy keeps `tab` safe to reuse */
+      HIPK_CHECK(hipMemcpyAsync(ctx->jobtab, &tab, sizeof(tab), hipMemcpyHostToDevice, ctx->stream));
+      HIPK_CHECK(hipStreamSynchronize(ctx->stream));
+      char *dt_ = (char *)ctx->jobtab;
+      jb_.xv_col = (const unsigned char *)dt_;
+      jb_.xw_col = (const unsigned char *)(dt_ + RITZ_BIG_MAXOUT);
+      jb_.xv_dst = (void *const *)(dt_ + 2 * RITZ_BIG_MAXOUT);
+      jb_.xw_dst = (void *const *)(dt_ + 2 * RITZ_BIG_MAXOUT + RITZ_BIG_MAXOUT * sizeof(void *));
+      hipLaunchKernelGGL((ritz_big_kernel<T>), dim3(gx), dim3(64), shm, ctx->stream, V, W, ld, k, h, ldh, theta, jb_, m, ctx->partials, nslots);
+      HIPK_CHECK(hipGetLastError());
+      rc = 0;
+   }
    hipk_prof_end(pslot, ctx->stream);
    if (rc) return rc;
    if (nslots > 0) return hipk_finalize_partials(ctx, ctx->partials, gx, nslots, nrm2_dev);

@@ -152,7 +152,7 @@ fill_kernel(T *__restrict__ d, int64_t n, double v) {
 struct JacShift { double s[64]; };
 template <typename T>
 __global__ void __launch_bounds__(HIPK_BLOCK)
-jacobi_kernel(const T *__restrict__ diag, JacShift sh, const T *__restrict__ x, int64_t ldx,
+jacobi_kernel(const T *__restrict__ diag, JacShift sh, double min_den, const T *__restrict__ x, int64_t ldx,
       T *__restrict__ y, int64_t ldy, int ncols, int64_t m) {
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
    for (int c = 0; c < ncols; c++) {
@@ -160,7 +160,7 @@ jacobi_kernel(const T *__restrict__ diag, JacShift sh, const T *__restrict__ x, 
       for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
          double d = (double)diag[i] - shift;
          /* same guard as the reference's test preconditioner: avoid dividing by ~0 */
-         if (fabs(d) < 1e-300) d = (d < 0 ? -1e-300 : 1e-300);
+         if (!(fabs(d) > min_den)) d = copysign(min_den, d);
          y[i + (size_t)c * ldy] = (T)((double)x[i + (size_t)c * ldx] / d);
       }
    }
@@ -314,8 +314,9 @@ extern "C" hipk_dtype hipk_csr_dtype(const hipk_csr *A) { return A->dt; }
 extern "C" int64_t hipk_csr_nrows(const hipk_csr *A) { return A->nrows; }
 
 extern "C" int hipk_jacobi_apply(void *hip_stream, hipk_dtype dt, int64_t m, const void *diag,
-      const double *shift_host, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols) {
+      const double *shift_host, double min_den, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols) {
    if (ncols <= 0) return 0;
+   if (!(min_den > 0.0)) min_den = 1e-300;
    if (ncols > 64) return -1;
    JacShift sh;
    for (int c = 0; c < ncols; c++) sh.s[c] = shift_host ? shift_host[c] : 0.0;
@@ -323,9 +324,9 @@ extern "C" int hipk_jacobi_apply(void *hip_stream, hipk_dtype dt, int64_t m, con
    hipk_ctx *ctx = &fake;
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
    if (dt == HIPK_F64)
-      hipLaunchKernelGGL(jacobi_kernel<double>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const double *)diag, sh, (const double *)x, ldx, (double *)y, ldy, ncols, m);
+      hipLaunchKernelGGL(jacobi_kernel<double>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const double *)diag, sh, min_den, (const double *)x, ldx, (double *)y, ldy, ncols, m);
    else if (dt == HIPK_F32)
-      hipLaunchKernelGGL(jacobi_kernel<float>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const float *)diag, sh, (const float *)x, ldx, (float *)y, ldy, ncols, m);
+      hipLaunchKernelGGL(jacobi_kernel<float>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const float *)diag, sh, min_den, (const float *)x, ldx, (float *)y, ldy, ncols, m);
    else return -44;
    HIPK_CHECK(hipGetLastError());
    return 0;

@@ -1,0 +1,88 @@
+"""The reference's own regression cases on LUNDA.mtx (tests/tests/test_001..006) and the
+acceptance test its driver applies to every solve (check_solution, tests/COMMON/ioandtest.c:71-157),
+restated for use by the CPU (hostcheck / reference) and GPU (hip) test modules.
+
+Data under tests/golden/reference_driver/ are the reference's test DATA files: the Matrix-Market
+matrix and the stored eigenvector files sol_00N_double (binary: [sizeof(scalar), n, cols], then
+cols columns of n doubles, then a parameter-block dump that is ignored here, cf.
+ioandtest.c:159-206)."""
+import os
+import numpy as np
+
+from primme_amd import problems
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "reference_driver")
+
+# primme.* settings of tests/tests/test_00N (driver.* lines become precond / sol); aNorm is left at
+# 0 (the driver only overrides a negative aNorm, tests/driver.c:575), initial guesses are PRIMME's own
+CASES = {
+    # test_001: "unrestarted configuration"
+    "test_001": dict(sol="sol_001_double", kw=dict(numEvals=5, eps=1e-12, maxBasisSize=140, minRestartSize=1,
+                     maxBlockSize=1, maxMatvecs=140, target="largest", locking=1, method="GD_Olsen_plusK")),
+    # test_002: tiny basis
+    "test_002": dict(sol="sol_002_double", kw=dict(numEvals=30, eps=1e-12, maxBasisSize=3, minRestartSize=1,
+                     maxBlockSize=1, maxOuterIterations=7800, target="largest", locking=1, maxPrevRetain=1,
+                     method="GD_Olsen_plusK")),
+    # test_003: default values
+    "test_003": dict(sol="sol_003_double", kw=dict(numEvals=50, eps=1e-12, maxOuterIterations=7500, target="largest",
+                     method="GD_Olsen_plusK")),
+    # test_004: interior, closest to 0
+    "test_004": dict(sol="sol_004_double", kw=dict(numEvals=50, eps=1e-12, maxOuterIterations=7500,
+                     target="closest_abs", targetShifts=[0.0], method="GD_Olsen_plusK")),
+    # test_005: same with the driver's Jacobi preconditioner, shift 0
+    "test_005": dict(sol="sol_005_double", kw=dict(numEvals=50, eps=1e-12, maxOuterIterations=7500,
+                     target="closest_abs", targetShifts=[0.0], method="GD_Olsen_plusK", precond=("jacobi", 0.0))),
+    # test_006: JDQMR with preconditioner on an extreme problem
+    "test_006": dict(sol="sol_006_double", kw=dict(numEvals=5, eps=1e-12, maxBasisSize=50, minRestartSize=30,
+                     maxOuterIterations=9000, target="largest", method="DEFAULT_MIN_TIME", precond=("jacobi", 3e8))),
+}
+
+
+def lunda():
+    rp, ci, va, n, _ = problems.read_matrix_market(os.path.join(DATA, "LUNDA.mtx"))
+    return rp, ci, va, n
+
+
+def read_sol(name, n):
+    d = np.fromfile(os.path.join(DATA, name), dtype=np.float64)
+    assert int(d[0]) == 8 and int(d[1]) == n
+    cols = int(d[2])
+    return d[3:3 + n * cols].reshape(cols, n).T.copy()
+
+
+def check_solution(A_apply, evals, evecs, rnorms, aNorm, eps, X):
+    """ioandtest.c:71-157.  evecs n x k (columns), X the stored vectors.  Returns the list of
+    violated checks (empty = pass)."""
+    bad = []
+    k = len(evals)
+    delta = aNorm if aNorm > 0 else np.inf
+    for i in range(1, k):
+        delta = min(delta, abs(evals[i] - evals[i - 1]))
+    meps = np.finfo(np.float64).eps
+    for i in range(k):
+        v = evecs[:, i]
+        h = evecs[:, :i + 1].T @ v
+        if np.linalg.norm(h[:i]) > 1e-7:
+            bad.append(f"ortho[{i}]={np.linalg.norm(h[:i]):.2e}")
+        if abs(np.sqrt(h[i]) - 1) > 1e-7:
+            bad.append(f"norm[{i}]")
+        Ax = A_apply(v)
+        eval0 = v @ Ax
+        if abs(evals[i] - eval0) > max(rnorms[i], aNorm * eps):
+            bad.append(f"rayleigh[{i}]={abs(evals[i] - eval0):.2e}")
+        r = Ax - evals[i] * v
+        rnorm0 = np.linalg.norm(r)
+        if abs(rnorms[i] - rnorm0) > max(2 * rnorm0, 10 * max(aNorm, abs(evals[i])) * meps):
+            bad.append(f"resnorm[{i}] {rnorms[i]:.2e} vs {rnorm0:.2e}")
+        # residual after projecting out the returned vectors (one Gram-Schmidt pass)
+        rp = r - evecs @ (evecs.T @ r)
+        if aNorm > 0 and np.linalg.norm(rp) > eps * aNorm * 2:
+            bad.append(f"rr_residual[{i}]={np.linalg.norm(rp):.2e}")
+        # angle against the stored invariant subspace
+        prod = float(np.sum((X.T @ v) ** 2))
+        bound = aNorm * eps / delta
+        s2 = np.sqrt(2.0)
+        if (s2 * prod + 1.0) / (s2 * bound + 1.0) < (s2 * prod - 1.0) / (1.0 - s2 * bound):
+            bad.append(f"angle[{i}] cos={prod:.3e}")
+    return bad

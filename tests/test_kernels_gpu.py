@@ -14,7 +14,7 @@ from kernel_harness import Dev, Host, segs_array, NPDT
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(1000, 5, 3), (70001, 15, 10), (300007, 41, 20)]
+SHAPES = [(1000, 5, 3), (70001, 15, 10), (300007, 41, 20), (20011, 170, 60)]
 
 
 def _panels(rng, m, k, L, dt, ld_pad=3):
@@ -71,7 +71,7 @@ def test_panel_project(built, dt, m, k, L, nx):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
-@pytest.mark.parametrize("m,k", [(999, 3), (50003, 15), (200001, 33), (40000, 41)])
+@pytest.mark.parametrize("m,k", [(999, 3), (50003, 15), (200001, 33), (40000, 41), (30011, 140), (5000, 255)])
 def test_ritz_update_inplace_restart(built, dt, m, k):
     """The restart shape: V,W <- V h, W h in place + next block X,R + locked copies + norms."""
     rng = np.random.default_rng(m + k)

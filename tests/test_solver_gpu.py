@@ -157,3 +157,50 @@ def test_full_size_config2_properties(built):
         true_rn = np.linalg.norm(AV[:, i] - r.evals[i] * V[:, i])
         assert abs(V[:, i] @ AV[:, i] - r.evals[i]) <= max(r.resNorms[i], aN * 1e-14)   # (ii)
         assert true_rn <= eps * aN * 1.05 and abs(true_rn - r.resNorms[i]) <= 2 * true_rn + 1e-13   # (iii)
+
+
+# ---- the reference's own driver regression cases on LUNDA.mtx (tests/tests/test_00N) --------
+import reference_driver_cases as RD
+
+
+@pytest.mark.parametrize("name", sorted(RD.CASES))
+def test_hip_reference_driver_case(built, name):
+    """HIP path on the reference's regression inputs, accepted by the reference driver's
+    check_solution against the reference's stored eigenvectors (sol_00N_double), and equal to the
+    oracle's eigenvalues."""
+    rp, ci, va, n = RD.lunda()
+    op = Operator(n, csr=(rp, ci, va))
+    case = RD.CASES[name]
+    r = eigsh(op, backend="hip", **case["kw"])
+    assert r.ret == 0 and r.initSize == case["kw"]["numEvals"]
+    X = RD.read_sol(case["sol"], n)
+    bad = RD.check_solution(lambda v: problems.csr_matvec_numpy(rp, ci, va, v.reshape(-1, 1)).ravel(),
+                            r.evals, np.asarray(r.evecs, dtype=np.float64), r.resNorms, r.params["aNorm"],
+                            case["kw"]["eps"], X)
+    assert not bad, bad
+    h = eigsh(op, backend="hostcheck", **case["kw"])
+    assert h.ret == 0
+    assert np.max(np.abs(np.sort(h.evals) - np.sort(r.evals))) <= 1e-10 * r.params["aNorm"]
+
+
+def test_hip_tiled_lunda_block_jdqmr(built):
+    """BASELINE configs[2] in small: block-diagonal tiles of LUNDA.mtx (tile t scaled by
+    1 + t/1000, so the spectrum stays simple), JDQMR, block size 8, 20 eigenvalues closest to a
+    shift; truth = union of the scaled dense spectra."""
+    rp, ci, va, n0 = RD.lunda()
+    T = 64
+    scale = lambda t: 1.0 + t / 1000.0
+    trp, tci, tva = problems.tile_block_diagonal(rp, ci, va, T, scale)
+    n = n0 * T
+    A = np.zeros((n0, n0))
+    A[np.repeat(np.arange(n0), np.diff(rp)), ci] = va
+    w0 = np.linalg.eigvalsh(A)
+    w = np.concatenate([w0 * scale(t) for t in range(T)])
+    shift = 1.0e7
+    want = w[np.argsort(np.abs(w - shift))][:20]
+    op = Operator(n, csr=(trp, tci, tva))
+    r = eigsh(op, backend="hip", numEvals=20, target="closest_abs", targetShifts=[shift], method="JDQMR",
+              maxBlockSize=8, eps=1e-10, aNorm=float(np.abs(w).max()), precond="jacobi")
+    assert r.ret == 0
+    assert np.max(np.abs(np.sort(r.evals) - np.sort(want))) <= 1e-10 * np.abs(w).max()
+    assert np.all(r.resNorms <= 1e-10 * np.abs(w).max() * (1 + 1e-6))

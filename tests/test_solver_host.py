@@ -157,3 +157,55 @@ def test_launch_structure_block_size_one(built):
     assert ritz_cgs >= its - rst - 15 and ritz_cgs <= its
     assert dots <= its + rst + 25            # projection pass each iteration + CGS dots after restarts
     assert project <= its + 25               # one update per new vector (+ rare second passes)
+
+
+# ---- the reference's own driver regression cases on LUNDA.mtx -----------------------------
+import reference_driver_cases as RD
+
+
+def _run_driver_case(name, backend):
+    rp, ci, va, n = RD.lunda()
+    op = Operator(n, csr=(rp, ci, va))
+    case = RD.CASES[name]
+    r = eigsh(op, backend=backend, **case["kw"])
+    X = RD.read_sol(case["sol"], n)
+    bad = RD.check_solution(lambda v: problems.csr_matvec_numpy(rp, ci, va, v.reshape(-1, 1)).ravel(),
+                            r.evals, np.asarray(r.evecs, dtype=np.float64), r.resNorms, r.params["aNorm"],
+                            case["kw"]["eps"], X)
+    return r, bad
+
+
+@pytest.mark.parametrize("name", sorted(RD.CASES))
+def test_reference_driver_case(built, name):
+    """tests/tests/test_00N through the product host solver; accepted by the reference driver's
+    check_solution against the reference's stored eigenvectors sol_00N_double."""
+    r, bad = _run_driver_case(name, "hostcheck")
+    assert r.ret == 0 and r.initSize == RD.CASES[name]["kw"]["numEvals"]
+    assert not bad, bad
+    # the spectrum itself: dense truth
+    rp, ci, va, n = RD.lunda()
+    A = np.zeros((n, n))
+    A[np.repeat(np.arange(n), np.diff(rp)), ci] = va
+    w = np.linalg.eigvalsh(A)
+    k = len(r.evals)
+    want = np.sort(w)[::-1][:k] if RD.CASES[name]["kw"]["target"] == "largest" else w[np.argsort(np.abs(w))][:k]
+    assert np.max(np.abs(np.sort(r.evals) - np.sort(want))) <= 1e-10 * r.params["aNorm"]
+
+
+@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", sorted(RD.CASES))
+def test_reference_driver_case_pins_the_checker(built, name):
+    """The same acceptance test applied to the live reference build: pins check_solution's
+    restatement and the data files (if this failed, the test above would prove nothing)."""
+    r, bad = _run_driver_case(name, "reference")
+    assert r.ret == 0 and not bad, bad
+    h, _ = _run_driver_case(name, "hostcheck")
+    assert np.max(np.abs(np.sort(h.evals) - np.sort(r.evals))) <= 1e-10 * r.params["aNorm"]
+    if name == "test_001":
+        # unrestarted: the product host logic follows the reference step for step
+        for k in ("numOuterIterations", "numMatvecs", "numRestarts"):
+            assert h.stats[k] == r.stats[k], k
+    else:
+        # eps = 1e-12 on a matrix with cond 3e6 converges at the rounding-noise floor (residuals
+        # 1e-12 |A|), where the summation order of the inner products decides the last steps
+        assert abs(h.stats["numOuterIterations"] - r.stats["numOuterIterations"]) <= 0.15 * r.stats["numOuterIterations"]
