@@ -105,6 +105,95 @@ csr_stream_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32_t *
    }
 }
 
+/* Block of vectors (the JDQMR / block Davidson SpMM).  The tile's (value, column) pairs are
+ * staged ONCE in LDS with coalesced loads (one barrier per tile, not two per column); then one
+ * lane per (row, group of NC columns) walks its row in LDS and gathers x for its NC columns with
+ * independent accumulators, so a lane keeps ~NC x row-length gathers in flight and nothing is
+ * re-read from HBM for the second and later columns. */
+template <typename T, int NC>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ rowptr,
+      const int32_t *__restrict__ colind, const T *__restrict__ val, const T *__restrict__ x,
+      int64_t ldx, T *__restrict__ y, int64_t ldy, int ncols, int64_t row0, int64_t nrows,
+      int64_t halo_lo, int64_t halo_hi, const T *__restrict__ xlo, const T *__restrict__ xhi) {
+   __shared__ T sval[TILE_NNZ];
+   __shared__ int32_t scol[TILE_NNZ];
+   __shared__ int rp[TILE_ROWS + 1];
+   const int tile = xcd_tile(blockIdx.x, ntiles);
+   if (tile >= ntiles) return;
+   const int r0 = tiles[tile], r1 = tiles[tile + 1];
+   const int p0 = rowptr[r0], p1 = rowptr[r1];
+   const int nz = p1 - p0, nr = r1 - r0;
+   const bool local = (halo_lo == 0 && halo_hi == 0);
+
+   if (nz <= TILE_NNZ) {
+      for (int q = threadIdx.x; q < nz; q += HIPK_BLOCK) { sval[q] = val[p0 + q]; scol[q] = colind[p0 + q]; }
+      for (int r = threadIdx.x; r <= nr; r += HIPK_BLOCK) rp[r] = rowptr[r0 + r] - p0;
+      __syncthreads();
+      const int ngroups = (ncols + NC - 1) / NC;
+      for (int idx = threadIdx.x; idx < nr * ngroups; idx += HIPK_BLOCK) {
+         const int g = idx / nr, r = idx - g * nr, c0 = g * NC;
+         double acc[NC];
+#pragma unroll
+         for (int c = 0; c < NC; c++) acc[c] = 0.0;
+         const int qa = rp[r], qb = rp[r + 1];
+         if (local) {
+            /* columns past ncols alias the last valid one (computed, never stored): no branches
+             * in the gather loop; 4 row entries per trip = 4*NC independent gathers in flight */
+            const T *xg[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) xg[c] = x + (size_t)((c0 + c < ncols) ? c0 + c : ncols - 1) * ldx - row0;
+            const int64_t self = row0 + r0 + r;
+            for (int q = qa; q < qb; q += 4) {
+               double v[4];
+               int64_t gc[4];
+#pragma unroll
+               for (int u = 0; u < 4; u++) {
+                  const bool ok = q + u < qb;
+                  v[u] = ok ? (double)sval[ok ? q + u : qa] : 0.0;
+                  gc[u] = ok ? (int64_t)scol[ok ? q + u : qa] : self;
+               }
+#pragma unroll
+               for (int u = 0; u < 4; u++)
+#pragma unroll
+                  for (int c = 0; c < NC; c++) acc[c] = fma(v[u], (double)xg[c][gc[u]], acc[c]);
+            }
+         } else {
+            for (int q = qa; q < qb; q++) {
+               const double v = (double)sval[q];
+               const int64_t gcol = scol[q];
+#pragma unroll
+               for (int c = 0; c < NC; c++)
+                  if (c0 + c < ncols)
+                     acc[c] = fma(v, fetch_x<T>(x + (size_t)(c0 + c) * ldx, xlo ? xlo + (size_t)(c0 + c) * halo_lo : NULL,
+                                                 xhi ? xhi + (size_t)(c0 + c) * halo_hi : NULL, row0, nrows, halo_lo, gcol), acc[c]);
+            }
+         }
+#pragma unroll
+         for (int c = 0; c < NC; c++)
+            if (c0 + c < ncols) y[r0 + r + (size_t)(c0 + c) * ldy] = (T)acc[c];
+      }
+   } else {
+      __shared__ double red[HIPK_BLOCK / HIPK_WAVE];
+      for (int c = 0; c < ncols; c++) {
+         const T *xc = x + (size_t)c * ldx;
+         const T *xloc = xlo ? xlo + (size_t)c * halo_lo : NULL;
+         const T *xhic = xhi ? xhi + (size_t)c * halo_hi : NULL;
+         for (int r = r0; r < r1; r++) {
+            const int a = rowptr[r], b = rowptr[r + 1];
+            double sum = 0.0;
+            for (int q = a + threadIdx.x; q < b; q += HIPK_BLOCK)
+               sum = fma((double)val[q], fetch_x<T>(xc, xloc, xhic, row0, nrows, halo_lo, (int64_t)colind[q]), sum);
+            sum = hipk_wave_sum(sum);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) y[r + (size_t)c * ldy] = (T)((red[0] + red[1]) + (red[2] + red[3]));
+            __syncthreads();
+         }
+      }
+   }
+}
+
 /* Laplacian stencil: diag 2*dims, -1 to each grid neighbour, Dirichlet boundary. */
 template <typename T>
 __global__ void __launch_bounds__(HIPK_BLOCK)
@@ -293,10 +382,20 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
             (const T *)A->xlo, (const T *)A->xhi);
    } else {
       int gx = ((A->ntiles + 7) / 8) * 8;
-      hipLaunchKernelGGL(csr_stream_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, stream,
-            A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
-            ncols, A->row0, A->nrows, A->halo_lo, A->halo_hi, (const T *)A->xlo,
-            (const T *)A->xhi);
+#define LAUNCH_ROWS(NCV) hipLaunchKernelGGL((csr_rows_block_kernel<T, NCV>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, \
+               A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, \
+               ncols, A->row0, A->nrows, A->halo_lo, A->halo_hi, (const T *)A->xlo, (const T *)A->xhi)
+      const char *env = getenv("HIPK_SPMM_NC");   /* development knob */
+      const int force = env ? atoi(env) : 0;
+      if (ncols == 1 && force == 0)
+         hipLaunchKernelGGL(csr_stream_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, stream,
+               A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
+               ncols, A->row0, A->nrows, A->halo_lo, A->halo_hi, (const T *)A->xlo,
+               (const T *)A->xhi);
+      else if (force == 1) LAUNCH_ROWS(1);
+      else if (force == 2 || (force == 0 && ncols <= 2)) LAUNCH_ROWS(2);
+      else LAUNCH_ROWS(4);
+#undef LAUNCH_ROWS
    }
    hipk_prof_end(pslot, stream);
    HIPK_CHECK(hipGetLastError());

@@ -249,7 +249,7 @@ def _csr_cases():
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
-@pytest.mark.parametrize("ncols", [1, 3])
+@pytest.mark.parametrize("ncols", [1, 3, 8])
 def test_csr_matvec(built, dt, ncols):
     npdt = NPDT[dt]
     for name, rp, ci, va, n in _csr_cases():
