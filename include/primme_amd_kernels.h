@@ -167,6 +167,10 @@ int64_t hipk_csr_nnz(const hipk_csr *A);
 int hipk_stencil_create(hipk_ctx *ctx, hipk_dtype dt, int nx, int ny, int nz, int64_t row0,
       int64_t nrows_local, hipk_csr **A);
 /* rows below/above the owned slab that the operator reads (0 for block-diagonal) */
+/* single-rank rectangular matrix (nrows x ncols), the whole input vector is local: the two
+ * factors of the singular value operator A'A */
+int hipk_csr_create_rect(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows, int64_t ncols,
+      const int32_t *rowptr_host, const int32_t *colind_host, const void *values_host, hipk_csr **A);
 int64_t hipk_csr_halo_lo(const hipk_csr *A);
 int64_t hipk_csr_halo_hi(const hipk_csr *A);
 /* halo buffers (device, halo_lo / halo_hi elements per column, column stride =

@@ -245,21 +245,20 @@ int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const doubl
 
 /* ---- sparse operator (amux: y = A x, CSR) ----------------------------------- */
 struct hipk_csr {
-   hipk_dtype dt; int kind; int64_t nrows, ncols, row0, nnz;
+   hipk_dtype dt; int kind; int64_t nrows, ncols, row0, nnz, x0, xlen;
    int32_t *rowptr, *colind; void *values; void *diag;
    int64_t halo_lo, halo_hi; const void *xlo, *xhi; int sx, sy, sz;
 };
 static double fetch(const hipk_csr *A, const void *x, const void *xlo, const void *xhi, int64_t g) {
-   int64_t l = g - A->row0;
-   if (l >= 0 && l < A->nrows) return ld_(A->dt, x, l);
+   int64_t l = g - A->x0;
+   if (l >= 0 && l < A->xlen) return ld_(A->dt, x, l);
    if (l < 0) return ld_(A->dt, xlo, l + A->halo_lo);
-   return ld_(A->dt, xhi, l - A->nrows);
+   return ld_(A->dt, xhi, l - A->xlen);
 }
-int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nr, int64_t nc, int64_t row0, const int32_t *rp,
-      const int32_t *ci, const void *val, hipk_csr **out) {
-   (void)ctx;
+static int csr_create_impl(hipk_dtype dt, int64_t nr, int64_t nc, int64_t row0, int64_t x0, int64_t xlen,
+      const int32_t *rp, const int32_t *ci, const void *val, hipk_csr **out) {
    hipk_csr *A = calloc(1, sizeof(*A));
-   A->dt = dt; A->nrows = nr; A->ncols = nc; A->row0 = row0; A->nnz = rp[nr];
+   A->dt = dt; A->nrows = nr; A->ncols = nc; A->row0 = row0; A->nnz = rp[nr]; A->x0 = x0; A->xlen = xlen;
    A->rowptr = malloc((size_t)(nr + 1) * 4); memcpy(A->rowptr, rp, (size_t)(nr + 1) * 4);
    A->colind = malloc((size_t)A->nnz * 4 + 4); memcpy(A->colind, ci, (size_t)A->nnz * 4);
    A->values = malloc((size_t)A->nnz * esz(dt) + 8); memcpy(A->values, val, (size_t)A->nnz * esz(dt));
@@ -267,19 +266,29 @@ int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nr, int64_t nc, int64_
    for (int64_t i = 0; i < nr; i++)
       for (int32_t p = rp[i]; p < rp[i + 1]; p++) {
          int64_t g = ci[p];
-         if (g < row0 && row0 - g > A->halo_lo) A->halo_lo = row0 - g;
-         if (g >= row0 + nr && g - (row0 + nr) + 1 > A->halo_hi) A->halo_hi = g - (row0 + nr) + 1;
+         if (g < x0 && x0 - g > A->halo_lo) A->halo_lo = x0 - g;
+         if (g >= x0 + xlen && g - (x0 + xlen) + 1 > A->halo_hi) A->halo_hi = g - (x0 + xlen) + 1;
          if (g == row0 + i) st_(dt, A->diag, i, ld_(dt, val, p));
       }
    *out = A;
    return 0;
+}
+int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nr, int64_t nc, int64_t row0, const int32_t *rp,
+      const int32_t *ci, const void *val, hipk_csr **out) {
+   (void)ctx;
+   return csr_create_impl(dt, nr, nc, row0, row0, nr, rp, ci, val, out);
+}
+int hipk_csr_create_rect(hipk_ctx *ctx, hipk_dtype dt, int64_t nr, int64_t nc, const int32_t *rp,
+      const int32_t *ci, const void *val, hipk_csr **out) {
+   (void)ctx;
+   return csr_create_impl(dt, nr, nc, 0, 0, nc, rp, ci, val, out);
 }
 int hipk_stencil_create(hipk_ctx *ctx, hipk_dtype dt, int nx, int ny, int nz, int64_t row0, int64_t nr, hipk_csr **out) {
    (void)ctx;
    hipk_csr *A = calloc(1, sizeof(*A));
    A->dt = dt; A->kind = 1; A->sx = nx; A->sy = ny > 0 ? ny : 1; A->sz = nz > 0 ? nz : 1;
    int64_t n = (int64_t)A->sx * A->sy * A->sz;
-   A->nrows = nr; A->ncols = n; A->row0 = row0;
+   A->nrows = nr; A->ncols = n; A->row0 = row0; A->x0 = row0; A->xlen = nr;
    int dims = A->sz > 1 ? 3 : (A->sy > 1 ? 2 : 1);
    A->nnz = n * (2 * dims + 1);
    int64_t reach = A->sz > 1 ? (int64_t)A->sx * A->sy : (A->sy > 1 ? A->sx : 1);

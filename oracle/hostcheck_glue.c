@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include "primme_amd.h"
 #include "primme_amd_comm.h"
+#include "primme_amd_svds.h"
+#include "primme_amd_io.h"
 
 struct primme_amd_operator { hipk_csr *A; int jacobi_fixed; double jacobi_shift; };
 int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double shift) { op->jacobi_fixed = fixed; op->jacobi_shift = shift; return 0; }
@@ -32,3 +34,26 @@ void primme_amd_global_sum(void *s, void *r, int *c, struct primme_params *p, in
    (void)s; (void)r; (void)c; (void)p; *ierr = 1; /* RCCL only exists in the product library */
 }
 int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) { (void)ci; (void)d; (void)n; (void)st; return -43; }
+
+/* singular value operator on host memory */
+struct primme_amd_svds_operator { hipk_csr *A, *At; };
+int primme_amd_svds_operator_create(primme_amd_svds_operator **out, struct hipk_ctx *ctx, int dt, int64_t m, int64_t n,
+      const int32_t *rp, const int32_t *ci, const void *val) {
+   primme_amd_svds_operator *op = calloc(1, sizeof(*op));
+   int32_t *rpT = NULL, *ciT = NULL; void *vT = NULL;
+   int rc = hipk_csr_create_rect((hipk_ctx *)ctx, (hipk_dtype)dt, m, n, rp, ci, val, &op->A);
+   if (!rc) rc = primme_amd_csr_transpose(m, n, rp, ci, val, dt == HIPK_F64 ? 8 : 4, &rpT, &ciT, &vT);
+   if (!rc) rc = hipk_csr_create_rect((hipk_ctx *)ctx, (hipk_dtype)dt, n, m, rpT, ciT, vT, &op->At);
+   primme_amd_host_free(rpT); primme_amd_host_free(ciT); primme_amd_host_free(vT);
+   *out = op;
+   return rc;
+}
+int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op) {
+   if (op) { hipk_csr_destroy(op->A); hipk_csr_destroy(op->At); free(op); }
+   return 0;
+}
+void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, int *transpose,
+      struct primme_svds_params *ps, int *ierr) {
+   primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->matrix;
+   *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, NULL, x, *ldx, y, *ldy, *bs);
+}

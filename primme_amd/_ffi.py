@@ -109,6 +109,42 @@ PrimmeParams._fields_ = [
 ]
 
 
+class PrimmeSvdsStats(C.Structure):
+    _fields_ = [(n, PRIMME_INT) for n in (
+        "numOuterIterations", "numRestarts", "numMatvecs", "numPreconds", "numGlobalSum", "numBroadcast",
+        "volumeGlobalSum", "volumeBroadcast")] + [(n, C.c_double) for n in (
+        "numOrthoInnerProds", "elapsedTime", "timeMatvec", "timePrecond", "timeOrtho", "timeGlobalSum",
+        "timeBroadcast")] + [("lockingIssue", PRIMME_INT)]
+
+
+class PrimmeSvdsParams(C.Structure):
+    """primme_svds_params (reference include/primme_svds.h:84-168; include/primme_amd_svds.h)."""
+    _fields_ = [
+        ("primme", PrimmeParams), ("primmeStage2", PrimmeParams), ("m", PRIMME_INT), ("n", PRIMME_INT),
+        ("matrixMatvec", C.c_void_p), ("matrixMatvec_type", C.c_int),
+        ("applyPreconditioner", C.c_void_p), ("applyPreconditioner_type", C.c_int),
+        ("numProcs", C.c_int), ("procID", C.c_int), ("mLocal", PRIMME_INT), ("nLocal", PRIMME_INT),
+        ("commInfo", C.c_void_p), ("globalSumReal", C.c_void_p), ("globalSumReal_type", C.c_int),
+        ("broadcastReal", C.c_void_p), ("broadcastReal_type", C.c_int),
+        ("numSvals", C.c_int), ("target", C.c_int), ("numTargetShifts", C.c_int),
+        ("targetShifts", C.POINTER(C.c_double)), ("method", C.c_int), ("methodStage2", C.c_int),
+        ("matrix", C.c_void_p), ("preconditioner", C.c_void_p), ("locking", C.c_int), ("numOrthoConst", C.c_int),
+        ("aNorm", C.c_double), ("eps", C.c_double), ("precondition", C.c_int), ("initSize", C.c_int),
+        ("maxBasisSize", C.c_int), ("maxBlockSize", C.c_int), ("maxMatvecs", PRIMME_INT),
+        ("iseed", PRIMME_INT * 4), ("printLevel", C.c_int), ("internalPrecision", C.c_int),
+        ("outputFile", C.c_void_p), ("stats", PrimmeSvdsStats),
+        ("convTestFun", C.c_void_p), ("convTestFun_type", C.c_int), ("convtest", C.c_void_p),
+        ("monitorFun", C.c_void_p), ("monitorFun_type", C.c_int), ("monitor", C.c_void_p),
+        ("queue", C.c_void_p), ("profile", C.c_char_p),
+    ]
+
+
+SVDS_BLOCK_OP = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(PRIMME_INT), C.c_void_p, C.POINTER(PRIMME_INT),
+                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(PrimmeSvdsParams), C.POINTER(C.c_int))
+SVDS_TARGETS = {"largest": 0, "smallest": 1, "closest_abs": 2}
+SVDS_METHODS = {"default": 0, "hybrid": 1, "normalequations": 2, "augmented": 3}
+
+
 class HipkSeg(C.Structure):
     _fields_ = [("base", C.c_void_p), ("ld", C.c_int64), ("ncols", C.c_int)]
 
@@ -129,10 +165,18 @@ def _declare_solver(lib, prefix):
     lib.primme_initialize.restype = None
     lib.primme_set_method.argtypes = [C.c_int, C.POINTER(PrimmeParams)]
     lib.primme_set_method.restype = C.c_int
+    lib.primme_svds_initialize.argtypes = [C.POINTER(PrimmeSvdsParams)]
+    lib.primme_svds_initialize.restype = None
+    lib.primme_svds_set_method.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(PrimmeSvdsParams)]
+    lib.primme_svds_set_method.restype = C.c_int
     for t in "ds":
         f = getattr(lib, f"{prefix}{t}primme", None)
         if f is not None:
             f.argtypes = [_vp, _vp, _vp, C.POINTER(PrimmeParams)]
+        f = getattr(lib, f"{prefix}{t}primme_svds", None)
+        if f is not None:
+            f.argtypes = [_vp, _vp, _vp, C.POINTER(PrimmeSvdsParams)]
+            f.restype = C.c_int
             f.restype = C.c_int
 
 
@@ -164,12 +208,20 @@ def _declare_kernels(lib):
         "hipk_bandwidth_probe": [_vp, C.c_size_t, _i, _dp],
         "hipk_prof_enable": [_i], "hipk_prof_get": [_i, _dp, P(C.c_long), _dp],
         "primme_amd_operator_create": [P(_vp), _vp, _vp], "primme_amd_operator_destroy": [_vp],
+        "primme_amd_svds_operator_create": [P(_vp), _vp, _i, _i64, _i64, _vp, _vp, _vp],
+        "primme_amd_svds_operator_destroy": [_vp],
+        "hipk_csr_create_rect": [_vp, _i, _i64, _i64, _vp, _vp, _vp, P(_vp)],
+        "primme_amd_mm_read": [C.c_char_p, P(_i64), P(_i64), P(_i64), P(_vp), P(_vp), P(_vp), P(_i)],
+        "primme_amd_csr_transpose": [_i64, _i64, _vp, _vp, _vp, C.c_size_t, P(_vp), P(_vp), P(_vp)],
+        "primme_amd_csr_tile_block_diagonal": [_i64, _vp, _vp, _vp, _i64, _i64, C.c_double, C.c_double, P(_vp), P(_vp), P(_vp)],
         "primme_amd_operator_apply": [_vp, _vp, _vp, _i64, _vp, _i64, _i],
     }
     for name, args in sig.items():
         f = getattr(lib, name)
         f.argtypes = args
         f.restype = C.c_int
+    lib.primme_amd_host_free.argtypes = [_vp]
+    lib.primme_amd_host_free.restype = None
     for name in ("hipk_csr_diag", "hipk_ctx_stream"):
         getattr(lib, name).restype = _vp
         getattr(lib, name).argtypes = [_vp]

@@ -144,3 +144,37 @@ extern "C" int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed
    op->jacobi_fixed = fixed; op->jacobi_shift = shift;
    return 0;
 }
+
+
+/* ---- singular value operator: A and A' both resident in CSR ------------------------------ */
+#include "primme_amd_svds.h"
+#include "primme_amd_io.h"
+struct primme_amd_svds_operator { hipk_csr *A, *At; };
+
+extern "C" int primme_amd_svds_operator_create(primme_amd_svds_operator **out, hipk_ctx *ctx, int dt,
+      int64_t m, int64_t n, const int32_t *rp, const int32_t *ci, const void *val) {
+   primme_amd_svds_operator *op = (primme_amd_svds_operator *)calloc(1, sizeof(*op));
+   if (!op) return -2;
+   const size_t es = (dt == HIPK_F64) ? 8 : 4;
+   int32_t *rpT = NULL, *ciT = NULL;
+   void *vT = NULL;
+   int rc = hipk_csr_create_rect(ctx, (hipk_dtype)dt, m, n, rp, ci, val, &op->A);
+   if (!rc) rc = primme_amd_csr_transpose(m, n, rp, ci, val, es, &rpT, &ciT, &vT);
+   if (!rc) rc = hipk_csr_create_rect(ctx, (hipk_dtype)dt, n, m, rpT, ciT, vT, &op->At);
+   primme_amd_host_free(rpT); primme_amd_host_free(ciT); primme_amd_host_free(vT);
+   if (rc) { if (op->A) hipk_csr_destroy(op->A); free(op); return rc; }
+   *out = op;
+   return 0;
+}
+extern "C" int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op) {
+   if (!op) return 0;
+   hipk_csr_destroy(op->A); hipk_csr_destroy(op->At);
+   free(op);
+   return 0;
+}
+extern "C" void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
+      int *transpose, struct primme_svds_params *ps, int *ierr) {
+   primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->matrix;
+   void *stream = ps->queue ? (void *)*(hipStream_t *)ps->queue : NULL;
+   *ierr = op ? hipk_csr_matvec(*transpose ? op->At : op->A, stream, x, *ldx, y, *ldy, *blockSize) : 1;
+}

@@ -675,16 +675,19 @@ static void free_solver(pa_solver *s) {
 
 extern void primme_amd_global_sum(void *, void *, int *, struct primme_params *, int *);
 
-static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt) {
+int pa_svds_conv_test_is_vector_free(const primme_params *p);
+
+static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double) {
    const double t0 = pa_wtime();
    if (!p) return -4;
-   const int real_out_is_float = (dt == HIPK_F32 || dt == HIPK_C32);
-   const double mach_eps = real_out_is_float ? 1.1920928955078125e-07 : PA_EPS;
+   const int work_is_float = (dt == HIPK_F32 || dt == HIPK_C32);
+   const int real_out_is_float = work_is_float && !out_double;
+   const double mach_eps = work_is_float ? 1.1920928955078125e-07 : PA_EPS;
 
    if (p->numProcs <= 1 && evals_out && evecs && resNorms_out) { p->nLocal = p->n; p->procID = 0; }
    primme_set_defaults(p);
    if (p->orth == primme_orth_default)
-      p->orth = (real_out_is_float || p->maxBlockSize > 1) ? primme_orth_explicit_I : primme_orth_implicit_I;
+      p->orth = (work_is_float || p->maxBlockSize > 1) ? primme_orth_explicit_I : primme_orth_implicit_I;
    if (p->ldOPs == -1) p->ldOPs = p->nLocal;
    if (!evals_out && !evecs && !resNorms_out) return 0;
    if (p->iseed[0] < 0 || p->iseed[0] > 4095) p->iseed[0] = p->procID % 4096;
@@ -725,7 +728,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->dev_comm = (p->numProcs > 1 && p->globalSumReal == primme_amd_global_sum);
    s->coef_valid_k = -1;
    s->fuse_gd = (p->correctionParams.maxInnerIterations == 0 && p->dynamicMethodSwitch <= 0 && !p->correctionParams.precondition &&
-                 !p->correctionParams.projectors.RightX && p->convTestFun == pa_conv_test_absolute);
+                 !p->correctionParams.projectors.RightX &&
+                 (p->convTestFun == pa_conv_test_absolute || pa_svds_conv_test_is_vector_free(p)));
    s->maxRank = p->numOrthoConst + (p->locking ? p->numEvals : 0) + p->maxBasisSize;
    if (hipk_ctx_create(&s->ctx, p->queue)) { free(s); return PRIMME_UNEXPECTED_FAILURE; }
    /* callbacks find the solver's stream in primme->queue (reference: the queue/handle
@@ -788,14 +792,19 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 }
 
 int hip_dprimme(double *evals, double *evecs, double *resNorms, primme_params *primme) {
-   return solve(evals, evecs, resNorms, primme, HIPK_F64);
+   return solve(evals, evecs, resNorms, primme, HIPK_F64, 0);
 }
 int hip_sprimme(float *evals, float *evecs, float *resNorms, primme_params *primme) {
-   return solve(evals, evecs, resNorms, primme, HIPK_F32);
+   return solve(evals, evecs, resNorms, primme, HIPK_F32, 0);
 }
 int hip_zprimme(double *evals, void *evecs, double *resNorms, primme_params *primme) {
-   return solve(evals, evecs, resNorms, primme, HIPK_C64);
+   return solve(evals, evecs, resNorms, primme, HIPK_C64, 0);
 }
 int hip_cprimme(float *evals, void *evecs, float *resNorms, primme_params *primme) {
-   return solve(evals, evecs, resNorms, primme, HIPK_C32);
+   return solve(evals, evecs, resNorms, primme, HIPK_C32, 0);
+}
+
+/* internal entry for the svds front end: eigenvalues and residual norms always in double */
+int pa_eigs_solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double) {
+   return solve(evals_out, evecs, resNorms_out, p, dt, out_double);
 }

@@ -25,6 +25,8 @@ struct hipk_csr {
    hipk_dtype dt;
    int kind;               /* 0 = CSR, 1 = stencil */
    int64_t nrows, ncols_global, row0, nnz;
+   int64_t x0, xlen;       /* entries [x0, x0+xlen) of the input vector are owned (= the row slab for
+                              square row-partitioned operators, everything for rectangular ones) */
    int32_t *rowptr, *colind;   /* device */
    void *values;               /* device */
    int32_t *tiles;             /* device: ntiles+1 row offsets */
@@ -143,7 +145,7 @@ csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32
             const T *xg[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) xg[c] = x + (size_t)((c0 + c < ncols) ? c0 + c : ncols - 1) * ldx - row0;
-            const int64_t self = row0 + r0 + r;
+            const int64_t self = row0;   /* any owned entry: multiplied by zero */
             for (int q = qa; q < qb; q += 4) {
                double v[4];
                int64_t gc[4];
@@ -259,8 +261,8 @@ static size_t elem_size(hipk_dtype dt) {
    return dt == HIPK_F64 ? 8 : dt == HIPK_F32 ? 4 : dt == HIPK_C64 ? 16 : 8;
 }
 
-extern "C" int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
-      int64_t ncols_global, int64_t row0, const int32_t *rowptr_host,
+static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
+      int64_t ncols_global, int64_t row0, int64_t x0, int64_t xlen, const int32_t *rowptr_host,
       const int32_t *colind_host, const void *values_host, hipk_csr **out) {
    if (dt != HIPK_F64 && dt != HIPK_F32) return -44;
    if (nrows_local >= ((int64_t)1 << 31)) return -1;
@@ -268,6 +270,7 @@ extern "C" int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local
    if (!A) return -2;
    A->ctx = ctx; A->dt = dt; A->kind = 0;
    A->nrows = nrows_local; A->ncols_global = ncols_global; A->row0 = row0;
+   A->x0 = x0; A->xlen = xlen;
    const int64_t nnz = rowptr_host[nrows_local];
    A->nnz = nnz;
    const size_t es = elem_size(dt);
@@ -293,8 +296,8 @@ extern "C" int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local
    for (int64_t i = 0; i < nrows_local; i++)
       for (int32_t p = rowptr_host[i]; p < rowptr_host[i + 1]; p++) {
          int64_t g = colind_host[p];
-         if (g < row0 && row0 - g > lo) lo = row0 - g;
-         if (g >= row0 + nrows_local && g - (row0 + nrows_local) + 1 > hi) hi = g - (row0 + nrows_local) + 1;
+         if (g < x0 && x0 - g > lo) lo = x0 - g;
+         if (g >= x0 + xlen && g - (x0 + xlen) + 1 > hi) hi = g - (x0 + xlen) + 1;
          if (g == row0 + i) memcpy(&dg[(size_t)i * es], (const char *)values_host + (size_t)p * es, es);
       }
    A->halo_lo = lo; A->halo_hi = hi;
@@ -315,6 +318,17 @@ extern "C" int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local
    return 0;
 }
 
+extern "C" int hipk_csr_create(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
+      int64_t ncols_global, int64_t row0, const int32_t *rowptr_host,
+      const int32_t *colind_host, const void *values_host, hipk_csr **out) {
+   return csr_create_impl(ctx, dt, nrows_local, ncols_global, row0, row0, nrows_local, rowptr_host,
+         colind_host, values_host, out);
+}
+extern "C" int hipk_csr_create_rect(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows, int64_t ncols,
+      const int32_t *rowptr_host, const int32_t *colind_host, const void *values_host, hipk_csr **out) {
+   return csr_create_impl(ctx, dt, nrows, ncols, 0, 0, ncols, rowptr_host, colind_host, values_host, out);
+}
+
 extern "C" int hipk_stencil_create(hipk_ctx *ctx, hipk_dtype dt, int nx, int ny, int nz,
       int64_t row0, int64_t nrows_local, hipk_csr **out) {
    if (dt != HIPK_F64 && dt != HIPK_F32) return -44;
@@ -324,6 +338,7 @@ extern "C" int hipk_stencil_create(hipk_ctx *ctx, hipk_dtype dt, int nx, int ny,
    A->sx = nx; A->sy = ny > 0 ? ny : 1; A->sz = nz > 0 ? nz : 1;
    const int64_t n = (int64_t)A->sx * A->sy * A->sz;
    A->nrows = nrows_local; A->ncols_global = n; A->row0 = row0;
+   A->x0 = row0; A->xlen = nrows_local;
    const int dims = (A->sz > 1) ? 3 : (A->sy > 1 ? 2 : 1);
    A->nnz = n * (2 * dims + 1); /* nominal */
    /* reach of the stencil outside the slab: one x-y plane (3-D), one x line (2-D) */
@@ -384,13 +399,13 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
       int gx = ((A->ntiles + 7) / 8) * 8;
 #define LAUNCH_ROWS(NCV) hipLaunchKernelGGL((csr_rows_block_kernel<T, NCV>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, \
                A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, \
-               ncols, A->row0, A->nrows, A->halo_lo, A->halo_hi, (const T *)A->xlo, (const T *)A->xhi)
+               ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo, (const T *)A->xhi)
       const char *env = getenv("HIPK_SPMM_NC");   /* development knob */
       const int force = env ? atoi(env) : 0;
       if (ncols == 1 && force == 0)
          hipLaunchKernelGGL(csr_stream_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, stream,
                A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
-               ncols, A->row0, A->nrows, A->halo_lo, A->halo_hi, (const T *)A->xlo,
+               ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo,
                (const T *)A->xhi);
       else if (force == 1) LAUNCH_ROWS(1);
       else if (force == 2 || (force == 0 && ncols <= 2)) LAUNCH_ROWS(2);

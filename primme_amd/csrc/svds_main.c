@@ -1,0 +1,379 @@
+/* svds_main.c — singular triplets through the normal equations, on the device.
+ *
+ *   hip_dprimme_svds / hip_sprimme_svds  <- reference src/svds/primme_svds_c.c:219-224, :271-366,
+ *                                           wrapper_svds :388-540
+ *   stage_begin   <- copy_last_params_from_svds :547-854 (normal-equation branches)
+ *   stage_end     <- copy_last_params_to_svds   :856-1025
+ *   pa_svds_matvec_eigs     <- matrixMatvec_eigs :1323-1385   (y = A'(A x) or A(A' x))
+ *   pa_svds_conv_test_ata   <- convTestFunATA    :1640-1690
+ *   pa_svds_default_conv_test <- default_convTestFun :1594-1622
+ *
+ * The eigenproblem itself is the same device path as hip_dprimme (eigs_main.c).  What this file
+ * adds runs on the solver's stream too: the intermediate vector of the two-step operator stays in
+ * HBM (allocated once per solve, not per call as the reference does), U = A V / sigma is one SpMM
+ * plus a column scaling, and the [U | V] layout shuffles are device-to-device copies.
+ *
+ * Augmented / hybrid methods and closest_abs targets (refined extraction) are not on the device
+ * path: they return PRIMME_FUNCTION_UNAVAILABLE (-44) offset by -100 like any first-stage error.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "eigs_solver.h"
+#include "primme_amd_svds.h"
+
+int pa_eigs_solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double);
+
+/* per-solve device state, found again from the callbacks through the params address */
+typedef struct {
+   primme_svds_params *key;
+   hipk_ctx *ctx;
+   hipk_dtype dt;
+   char *aux;          /* intermediate of the two-step operator */
+   size_t aux_cols;
+} svds_side;
+#define MAX_SIDES 8
+static svds_side g_sides[MAX_SIDES];
+
+static svds_side *side_of(primme_svds_params *ps) {
+   for (int i = 0; i < MAX_SIDES; i++) if (g_sides[i].key == ps) return &g_sides[i];
+   return NULL;
+}
+static svds_side *side_new(primme_svds_params *ps) {
+   for (int i = 0; i < MAX_SIDES; i++) if (!g_sides[i].key) { memset(&g_sides[i], 0, sizeof(svds_side)); g_sides[i].key = ps; return &g_sides[i]; }
+   return NULL;
+}
+
+static size_t es_of(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : 4; }
+
+/* W(:, 0:nb) = A V or A' V through the user's operator (reference :1116-1172) */
+static int svds_matvec(primme_svds_params *ps, void *V, PRIMME_INT ldV, void *W, PRIMME_INT ldW, int nb, int transpose) {
+   if (nb <= 0) return 0;
+   double t0 = pa_wtime();
+   int ierr = 0;
+   ps->matrixMatvec(V, &ldV, W, &ldW, &nb, &transpose, ps, &ierr);
+   if (ierr) return PRIMME_USER_FAILURE;
+   ps->stats.timeMatvec += pa_wtime() - t0;
+   ps->stats.numMatvecs += nb;
+   return 0;
+}
+
+/* the eigensolver's operator: A'A x (method AtA) or A A' x (method AAt) */
+void pa_svds_matvec_eigs(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
+      primme_params *primme, int *ierr) {
+   primme_svds_params *ps = (primme_svds_params *)primme->matrix;
+   svds_side *sd = side_of(ps);
+   const primme_svds_operator op = (&ps->primme == primme) ? ps->method : ps->methodStage2;
+   *ierr = 1;
+   if (!sd || (op != primme_svds_op_AtA && op != primme_svds_op_AAt)) return;
+   const size_t es = es_of(sd->dt);
+   PRIMME_INT mid = (op == primme_svds_op_AtA) ? ps->mLocal : ps->nLocal;
+   int first = (op == primme_svds_op_AtA) ? 0 : 1, second = 1 - first;
+   const int nb = *blockSize;
+   if ((size_t)nb > sd->aux_cols) {
+      if (sd->aux) hipk_free(sd->ctx, sd->aux);
+      sd->aux = NULL; sd->aux_cols = 0;
+      if (hipk_malloc(sd->ctx, (size_t)mid * es * nb, (void **)&sd->aux)) return;
+      sd->aux_cols = nb;
+   }
+   int bs = nb, e = 0;
+   ps->matrixMatvec(x, ldx, sd->aux, &mid, &bs, &first, ps, &e);
+   if (e) return;
+   ps->matrixMatvec(sd->aux, &mid, y, ldy, &bs, &second, ps, &e);
+   if (e) return;
+   *ierr = 0;
+}
+
+/* the eigensolver's preconditioner: the user's, told which operator it is for (reference :1405-1416) */
+static void pa_svds_precond_eigs(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
+      primme_params *primme, int *ierr) {
+   primme_svds_params *ps = (primme_svds_params *)primme->preconditioner;
+   int method = (int)((&ps->primme == primme) ? ps->method : ps->methodStage2);
+   ps->applyPreconditioner(x, ldx, y, ldy, blockSize, &method, ps, ierr);
+}
+
+/* |r| < max(eps, 3.16 machEps) |A|: the default test on a triplet */
+void pa_svds_default_conv_test(double *sval, void *leftsvec, void *rightsvec, double *rNorm, int *method,
+      int *isConv, primme_svds_params *ps, int *ierr) {
+   (void)sval; (void)leftsvec; (void)rightsvec; (void)method;
+   svds_side *sd = side_of(ps);
+   const double meps = (sd && sd->dt == HIPK_F32) ? 1.1920928955078125e-07 : PA_EPS;
+   *isConv = *rNorm < PA_MAX(ps->eps, meps * 3.16) * ps->aNorm;
+   *ierr = 0;
+}
+
+/* the eigensolver's convergence test: translate (eval, |r_eig|) to (sigma, |r_eig| / sigma) */
+void pa_svds_conv_test_ata(double *eval, void *evec, double *rNorm, int *isConv, primme_params *primme, int *ierr) {
+   primme_svds_params *ps = (primme_svds_params *)primme->matrix;
+   svds_side *sd = side_of(ps);
+   const primme_svds_operator op = (&ps->primme == primme) ? ps->method : ps->methodStage2;
+   const double aNorm = primme->aNorm > 0.0 ? primme->aNorm : primme->stats.estimateLargestSVal;
+   const double maxaNorm = PA_MAX(primme->aNorm, primme->stats.estimateLargestSVal);
+   const double meps = (sd && sd->dt == HIPK_F32) ? 1.1920928955078125e-07 : PA_EPS;
+   *ierr = 0;
+   if (rNorm && *rNorm < meps * maxaNorm * 3.16) { *isConv = 1; return; }
+   const double old = ps->aNorm;
+   if (ps->aNorm <= 0.0) ps->aNorm = sqrt(aNorm);
+   double sval = eval ? sqrt(fabs(*eval)) : 0.0;
+   double srNorm = (rNorm && eval) ? *rNorm / sval : 0.0;
+   int method = (int)op;
+   ps->convTestFun(&sval, (op == primme_svds_op_AAt) ? evec : NULL, (op == primme_svds_op_AtA) ? evec : NULL,
+         &srNorm, &method, isConv, ps, ierr);
+   ps->aNorm = old;
+}
+
+/* does the installed convergence test look at the vectors? (lets the eigensolver keep its
+ * fused residual path, which never forms the Ritz vector) */
+int pa_svds_conv_test_is_vector_free(const primme_params *p) {
+   if (p->convTestFun != pa_svds_conv_test_ata) return 0;
+   const primme_svds_params *ps = (const primme_svds_params *)p->matrix;
+   return ps && ps->convTestFun == pa_svds_default_conv_test;
+}
+
+/* eigensolver events forwarded to the user's svds monitor with singular values
+ * (reference monitor_single_stage :1897-2020, normal-equation branch) */
+static void monitor_single_stage(void *basisEvals_, int *basisSize, int *basisFlags, int *iblock, int *blockSize,
+      void *basisNorms_, int *numConverged, void *lockedEvals_, int *numLocked, int *lockedFlags,
+      void *lockedNorms_, int *inner_its, void *LSRes, const char *msg, double *time, primme_event *event,
+      primme_params *primme, int *err) {
+   primme_svds_params *ps = (primme_svds_params *)primme->matrix;
+   *err = 0;
+   if (!ps->monitorFun) return;
+   const int nb = (basisEvals_ && basisSize) ? *basisSize : 0, nl = (lockedEvals_ && numLocked) ? *numLocked : 0;
+   double *bs = (double *)malloc(sizeof(double) * (size_t)(2 * nb + 2 * nl + 1));
+   if (!bs) { *err = 1; return; }
+   double *bn = bs + nb, *ls = bn + nb, *ln = ls + nl;
+   for (int i = 0; i < nb; i++) {
+      bs[i] = sqrt(PA_MAX(0.0, ((double *)basisEvals_)[i]));
+      bn[i] = basisNorms_ ? ((double *)basisNorms_)[i] / PA_MAX(bs[i], 1e-300) : 0.0;
+   }
+   for (int i = 0; i < nl; i++) {
+      ls[i] = sqrt(PA_MAX(0.0, ((double *)lockedEvals_)[i]));
+      ln[i] = lockedNorms_ ? ((double *)lockedNorms_)[i] / PA_MAX(ls[i], 1e-300) : 0.0;
+   }
+   int stage = 0;
+   ps->monitorFun(nb ? bs : NULL, basisSize, basisFlags, iblock, blockSize, nb ? bn : NULL, numConverged,
+         nl ? ls : NULL, numLocked, lockedFlags, nl ? ln : NULL, inner_its, LSRes, msg, time, event, &stage, ps, err);
+   free(bs);
+}
+
+static int check_input(void *svals, void *svecs, void *resNorms, primme_svds_params *ps) {
+   if (!ps) return -4;
+   if (ps->n < 0 || ps->m < 0 || ps->nLocal < 0 || ps->mLocal < 0 || ps->nLocal > ps->n || ps->mLocal > ps->m) return -5;
+   if (ps->numProcs < 1) return -6;
+   if (!ps->matrixMatvec) return -7;
+   if (!ps->applyPreconditioner && ps->precondition == 1) return -8;
+   if (ps->numProcs > 1 && !ps->globalSumReal) return -9;
+   if (ps->numSvals > PA_MIN(ps->n, ps->m)) return -10;
+   if (ps->numSvals < 1) return -11;
+   if (ps->target != primme_svds_smallest && ps->target != primme_svds_largest && ps->target != primme_svds_closest_abs) return -13;
+   if (ps->method != primme_svds_op_AtA && ps->method != primme_svds_op_AAt && ps->method != primme_svds_op_augmented) return -14;
+   if ((ps->method == primme_svds_op_augmented && ps->methodStage2 != primme_svds_op_none) ||
+         (ps->method != primme_svds_op_augmented && ps->methodStage2 != primme_svds_op_augmented &&
+               ps->methodStage2 != primme_svds_op_none)) return -15;
+   if (ps->printLevel < 0 || ps->printLevel > 5) return -16;
+   if (!svals) return -17;
+   if (!svecs) return -18;
+   if (!resNorms) return -19;
+   return 0;
+}
+
+/* device column-block move that tolerates overlap (through a temporary) */
+static int move_cols(svds_side *sd, PRIMME_INT rows, int ncols, char *src, char *dst) {
+   if (ncols <= 0 || rows <= 0 || src == dst) return 0;
+   const size_t bytes = (size_t)rows * ncols * es_of(sd->dt);
+   char *tmp = NULL;
+   CHK(hipk_malloc(sd->ctx, bytes, (void **)&tmp));
+   CHK(hipk_copy_cols(sd->ctx, sd->dt, rows, src, rows, tmp, rows, ncols));
+   CHK(hipk_copy_cols(sd->ctx, sd->dt, rows, tmp, rows, dst, rows, ncols));
+   CHK(hipk_sync(sd->ctx));
+   hipk_free(sd->ctx, tmp);
+   return 0;
+}
+
+/* x(:,i) /= factors[i], or normalise when the factor is unusable (reference :1418-1438) */
+static int scale_inverse(primme_svds_params *ps, svds_side *sd, char *x, PRIMME_INT rows, int ncols, const double *factors) {
+   if (ncols <= 0) return 0;
+   double *f = (double *)malloc(sizeof(double) * (size_t)ncols);
+   double *d_n = NULL;
+   if (!f) return PRIMME_MALLOC_FAILURE;
+   int need_norms = 0;
+   for (int i = 0; i < ncols; i++) if (!(factors[i] > 0.0 && 1.0 / factors[i] < 1.79e308)) need_norms = 1;
+   double *norms = NULL;
+   if (need_norms) {
+      norms = (double *)malloc(sizeof(double) * (size_t)ncols);
+      if (!norms || hipk_malloc(sd->ctx, sizeof(double) * (size_t)ncols, (void **)&d_n)) { free(f); free(norms); return PRIMME_MALLOC_FAILURE; }
+      int rc = hipk_col_norms2(sd->ctx, sd->dt, rows, x, rows, ncols, d_n);
+      if (!rc) rc = hipk_d2h(sd->ctx, norms, d_n, sizeof(double) * (size_t)ncols);
+      if (!rc) rc = hipk_sync(sd->ctx);
+      hipk_free(sd->ctx, d_n);
+      if (rc) { free(f); free(norms); return rc; }
+      if (ps->globalSumReal) {
+         int cnt = ncols, ierr = 0;
+         ps->globalSumReal(norms, norms, &cnt, ps, &ierr);
+         if (ierr) { free(f); free(norms); return PRIMME_USER_FAILURE; }
+      }
+   }
+   for (int i = 0; i < ncols; i++)
+      f[i] = 1.0 / ((factors[i] > 0.0 && 1.0 / factors[i] < 1.79e308) ? factors[i] : sqrt(norms[i]));
+   int rc = hipk_scale_cols(sd->ctx, sd->dt, rows, x, rows, ncols, f);
+   free(f); free(norms);
+   return rc;
+}
+
+static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_svds_params *ps, hipk_dtype dt) {
+   if (!ps) return -4;
+   const int out_float = (dt == HIPK_F32);
+   const double meps = out_float ? 1.1920928955078125e-07 : PA_EPS;
+   const primme_op_datatype scalar_t = out_float ? primme_op_float : primme_op_double;
+   if (ps->matrixMatvec && ps->matrixMatvec_type == primme_op_default) ps->matrixMatvec_type = scalar_t;
+   if (ps->applyPreconditioner && ps->applyPreconditioner_type == primme_op_default) ps->applyPreconditioner_type = scalar_t;
+   if (ps->globalSumReal && ps->globalSumReal_type == primme_op_default) ps->globalSumReal_type = scalar_t;
+   if (ps->broadcastReal && ps->broadcastReal_type == primme_op_default) ps->broadcastReal_type = scalar_t;
+   if (ps->convTestFun && ps->convTestFun_type == primme_op_default) ps->convTestFun_type = scalar_t;
+   if (ps->monitorFun && ps->monitorFun_type == primme_op_default) ps->monitorFun_type = scalar_t;
+
+   if (ps->numProcs <= 1 && svals_out && svecs_ && resNorms_out) {
+      ps->mLocal = ps->m; ps->nLocal = ps->n; ps->procID = 0; ps->numProcs = 1;
+   }
+   primme_svds_set_defaults(ps);
+   if (!svals_out && !svecs_ && !resNorms_out) return 0;
+   int rc = check_input(svals_out, svecs_, resNorms_out, ps);
+   if (rc) { ps->initSize = 0; return rc; }
+
+   /* what is not on the device path fails loudly, as a first-stage error */
+   primme_params *p = &ps->primme;
+   if (ps->method == primme_svds_op_augmented || ps->methodStage2 != primme_svds_op_none ||
+         ps->target == primme_svds_closest_abs) {
+      if (ps->printLevel > 0 && ps->outputFile)
+         fprintf(ps->outputFile, "primme_amd: svds augmented / hybrid methods and closest_abs targets are not on the "
+               "device path; use primme_svds_normalequations\n");
+      ps->initSize = 0;
+      return PRIMME_FUNCTION_UNAVAILABLE - 100;
+   }
+
+   if (!ps->convTestFun) {
+      ps->convTestFun = pa_svds_default_conv_test;
+      ps->convTestFun_type = scalar_t;
+      if (ps->eps == 0.0) ps->eps = meps * 1e4;
+   }
+   memset(&ps->stats, 0, sizeof(ps->stats));
+
+   svds_side *sd = side_new(ps);
+   if (!sd) { ps->initSize = 0; return PRIMME_MALLOC_FAILURE; }
+   sd->dt = dt;
+   if (hipk_ctx_create(&sd->ctx, ps->queue)) { sd->key = NULL; ps->initSize = 0; return PRIMME_UNEXPECTED_FAILURE; }
+   void *stream = hipk_ctx_stream(sd->ctx);
+   void *user_queue = ps->queue;
+   if (!ps->queue) ps->queue = &stream;
+
+   const size_t es = es_of(dt);
+   char *svecs = (char *)svecs_;
+   const PRIMME_INT mL = ps->mLocal, nL = ps->nLocal;
+   const primme_svds_operator op = ps->method;
+   int ret = 0, allocatedShifts = 0;
+   double *svals = (double *)calloc((size_t)ps->numSvals + 1, 8), *rnorms = (double *)calloc((size_t)ps->numSvals + 1, 8);
+   if (!svals || !rnorms) { rc = PRIMME_MALLOC_FAILURE; goto done; }
+
+   /* ---- stage set-up ---- */
+   if (!p->matrixMatvec) { p->matrixMatvec = pa_svds_matvec_eigs; p->matrixMatvec_type = ps->matrixMatvec_type; p->matrix = ps; }
+   if (ps->applyPreconditioner && !p->applyPreconditioner) {
+      p->applyPreconditioner = pa_svds_precond_eigs; p->applyPreconditioner_type = ps->applyPreconditioner_type; p->preconditioner = ps;
+   }
+   if (ps->aNorm > 0.0) p->aNorm = ps->aNorm * ps->aNorm;
+   p->convTestFun = pa_svds_conv_test_ata;
+   p->convTestFun_type = scalar_t;
+   p->initSize = ps->initSize;
+   p->numOrthoConst = ps->numOrthoConst;
+   const int n0 = ps->initSize + ps->numOrthoConst;
+   const int nMax = PA_MAX(ps->initSize, ps->numSvals) + ps->numOrthoConst;
+   /* [Uc U0 Vc V0]: park Vc (and V0 for A'A) at the far right; A'A iterates there */
+   char *right = svecs + (size_t)nMax * mL * es;
+   rc = move_cols(sd, nL, op == primme_svds_op_AtA ? n0 : ps->numOrthoConst, svecs + (size_t)mL * n0 * es, right);
+   if (rc) goto done;
+   char *eig_vecs = (op == primme_svds_op_AtA) ? right : svecs;
+   for (int i = 0; i < 4; i++) p->iseed[i] = ps->iseed[i];
+   p->maxMatvecs = ps->maxMatvecs / 2;
+   if (ps->numTargetShifts > 0) {
+      p->numTargetShifts = ps->numTargetShifts;
+      p->targetShifts = (double *)malloc(sizeof(double) * (size_t)ps->numSvals);
+      if (!p->targetShifts) { rc = PRIMME_MALLOC_FAILURE; goto done; }
+      allocatedShifts = 1;
+      for (int i = 0; i < p->numTargetShifts; i++) p->targetShifts[i] = ps->targetShifts[i] * ps->targetShifts[i];
+   }
+   if (ps->locking >= 0) p->locking = ps->locking;
+   int own_monitor = 0;
+   if (!p->monitorFun && ps->monitorFun) { p->monitorFun = monitor_single_stage; p->monitorFun_type = scalar_t; own_monitor = 1; }
+   p->queue = &stream;
+   p->profile = ps->profile;
+
+   /* ---- the eigenproblem ---- */
+   ret = pa_eigs_solve(svals, eig_vecs, rnorms, p, dt, 1);
+
+   /* ---- back to triplets ---- */
+   ps->stats.numOuterIterations += p->stats.numOuterIterations;
+   ps->stats.numRestarts += p->stats.numRestarts;
+   ps->stats.numMatvecs += p->stats.numMatvecs * 2;
+   ps->stats.numPreconds += p->stats.numPreconds;
+   ps->stats.numGlobalSum += p->stats.numGlobalSum;
+   ps->stats.numBroadcast += p->stats.numBroadcast;
+   ps->stats.volumeGlobalSum += p->stats.volumeGlobalSum;
+   ps->stats.volumeBroadcast += p->stats.volumeBroadcast;
+   ps->stats.numOrthoInnerProds += p->stats.numOrthoInnerProds;
+   ps->stats.elapsedTime += p->stats.elapsedTime;
+   ps->stats.timeMatvec += p->stats.timeMatvec;
+   ps->stats.timePrecond += p->stats.timePrecond;
+   ps->stats.timeOrtho += p->stats.timeOrtho;
+   ps->stats.timeGlobalSum += p->stats.timeGlobalSum;
+   ps->stats.timeBroadcast += p->stats.timeBroadcast;
+   ps->stats.lockingIssue += p->stats.lockingIssue;
+   if (p->aNorm > 0.0) ps->aNorm = sqrt(p->aNorm);
+   for (int i = 0; i < p->initSize; i++) svals[i] = sqrt(PA_MAX(0.0, svals[i]));
+   ps->initSize = p->initSize;
+   {
+      const int n1 = ps->initSize + ps->numOrthoConst;
+      if (op == primme_svds_op_AtA) {
+         /* U = A V / Sigma, then [Vc V] moves next to it */
+         char *Vfound = right + (size_t)nL * ps->numOrthoConst * es, *U = svecs + (size_t)mL * ps->numOrthoConst * es;
+         rc = svds_matvec(ps, Vfound, nL, U, mL, ps->initSize, 0);
+         if (!rc) rc = scale_inverse(ps, sd, U, mL, ps->initSize, svals);
+         if (!rc) rc = move_cols(sd, nL, n1, right, svecs + (size_t)mL * n1 * es);
+      } else {
+         /* V = A' U / Sigma behind [Uc U Vc] */
+         rc = move_cols(sd, nL, ps->numOrthoConst, right, svecs + (size_t)mL * n1 * es);
+         char *U = svecs + (size_t)mL * ps->numOrthoConst * es;
+         char *V = svecs + (size_t)mL * n1 * es + (size_t)nL * ps->numOrthoConst * es;
+         if (!rc) rc = svds_matvec(ps, U, mL, V, nL, ps->initSize, 1);
+         if (!rc) rc = scale_inverse(ps, sd, V, nL, ps->initSize, svals);
+      }
+      if (rc) goto done;
+   }
+   for (int i = 0; i < 4; i++) ps->iseed[i] = p->iseed[i];
+   for (int i = 0; i < ps->initSize; i++) rnorms[i] = PA_MIN(rnorms[i] / svals[i], ps->aNorm);
+   if (own_monitor) p->monitorFun = NULL;
+   rc = hipk_sync(sd->ctx);
+
+   for (int i = 0; i < ps->initSize; i++) {
+      if (out_float) { ((float *)svals_out)[i] = (float)svals[i]; ((float *)resNorms_out)[i] = (float)rnorms[i]; }
+      else { ((double *)svals_out)[i] = svals[i]; ((double *)resNorms_out)[i] = rnorms[i]; }
+   }
+   if (ret != 0) ret -= 100;
+
+done:
+   if (allocatedShifts) { free(p->targetShifts); p->targetShifts = NULL; }
+   free(svals); free(rnorms);
+   p->queue = NULL;
+   ps->queue = user_queue;
+   if (sd->aux) hipk_free(sd->ctx, sd->aux);
+   hipk_ctx_destroy(sd->ctx);
+   sd->key = NULL;
+   if (rc) { ps->initSize = 0; return rc; }
+   return ret;
+}
+
+int hip_dprimme_svds(double *svals, double *svecs, double *resNorms, primme_svds_params *ps) {
+   return solve_svds(svals, svecs, resNorms, ps, HIPK_F64);
+}
+int hip_sprimme_svds(float *svals, float *svecs, float *resNorms, primme_svds_params *ps) {
+   return solve_svds(svals, svecs, resNorms, ps, HIPK_F32);
+}

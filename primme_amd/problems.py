@@ -129,3 +129,30 @@ def csr_matvec_numpy(rowptr, colind, values, x):
     for c in range(xr.shape[1]):
         y[:, c] = np.bincount(rows, weights=values * xr[colind, c], minlength=nrows)
     return y.reshape((len(rowptr) - 1,) + x.shape[1:])
+
+
+SVDS_PRIMES = (1, 7919, 104729, 1299709, 15485863)
+
+
+def svds_synthetic_csr(m, n, row0=0, nrows=None):
+    """BASELINE configs[4] matrix: row i has 5 nonzeros at columns
+    (i*p_q + q) mod n, p = SVDS_PRIMES, values 1 + ((i+q) mod 13)/13; duplicates in a row are summed.
+    Returns CSR (rowptr int32, colind int32, values) for rows [row0, row0+nrows)."""
+    nrows = m - row0 if nrows is None else nrows
+    i = np.arange(row0, row0 + nrows, dtype=np.int64)
+    cols = np.stack([(i * p + q) % n for q, p in enumerate(SVDS_PRIMES)], axis=1)
+    vals = np.stack([1.0 + ((i + q) % 13) / 13.0 for q in range(5)], axis=1)
+    order = np.argsort(cols, axis=1, kind="stable")
+    cols = np.take_along_axis(cols, order, axis=1)
+    vals = np.take_along_axis(vals, order, axis=1)
+    # merge duplicate columns inside a row
+    dup = np.zeros_like(cols, dtype=bool)
+    dup[:, 1:] = cols[:, 1:] == cols[:, :-1]
+    if dup.any():
+        for q in range(4, 0, -1):
+            d = dup[:, q]
+            vals[d, q - 1] += vals[d, q]
+    keep = ~dup
+    rowptr = np.zeros(nrows + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(keep.sum(axis=1))
+    return rowptr.astype(np.int32), cols[keep].astype(np.int32), vals[keep]

@@ -1,0 +1,129 @@
+"""Python driver over the singular value C ABI (include/primme_amd_svds.h): plumbing only.
+
+    svds(m, n, (rowptr, colind, values), numSvals=..., backend="hip" | "hostcheck" | "reference")
+
+backend="hip" runs hip_dprimme_svds / hip_sprimme_svds of primme_amd/libprimme_amd.so with the
+matrix and its transpose resident in HBM; the two checker back ends are the same as in api.py
+(tests and bench baselines only)."""
+import ctypes as C
+import numpy as np
+
+from . import _ffi as F
+from .problems import csr_matvec_numpy
+
+
+class SvdsResult:
+    def __init__(self, ret, svals, U, V, resNorms, ps):
+        self.ret, self.svals, self.U, self.V, self.resNorms = ret, svals, U, V, resNorms
+        self.initSize = ps.initSize
+        self.stats = {k: getattr(ps.stats, k) for k, _ in F.PrimmeSvdsStats._fields_}
+        self.eig_stats = {k: getattr(ps.primme.stats, k) for k, _ in F.PrimmeStats._fields_}
+        self.params = dict(aNorm=ps.aNorm, eps=ps.eps, method=ps.method, methodStage2=ps.methodStage2,
+                           maxBasisSize=ps.primme.maxBasisSize, maxBlockSize=ps.primme.maxBlockSize,
+                           minRestartSize=ps.primme.minRestartSize, locking=ps.primme.locking,
+                           eig_n=ps.primme.n, eig_target=ps.primme.target)
+
+
+def transpose_csr(m, n, rp, ci, va):
+    order = np.argsort(ci, kind="stable")
+    rows = np.repeat(np.arange(m, dtype=np.int64), np.diff(rp))
+    rpT = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rpT, ci.astype(np.int64) + 1, 1)
+    return np.cumsum(rpT).astype(np.int32), rows[order].astype(np.int32), va[order]
+
+
+def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", methodStage1="DEFAULT_METHOD",
+         eps=1e-8, aNorm=0.0, backend="hip", dtype=np.float64, maxBlockSize=0, maxBasisSize=0, locking=None,
+         maxMatvecs=0, v0=None, iseed=None, printLevel=0, return_vectors=True):
+    dtype = np.dtype(dtype)
+    dt = F.HIPK_F64 if dtype == np.float64 else F.HIPK_F32
+    ctype = C.c_double if dtype == np.float64 else C.c_float
+    rp, ci, va = csr
+    rp = np.ascontiguousarray(rp, dtype=np.int32)
+    ci = np.ascontiguousarray(ci, dtype=np.int32)
+    va = np.ascontiguousarray(va, dtype=dtype)
+    lib = {"hip": F.load_product, "hostcheck": F.load_hostcheck, "reference": F.load_reference}[backend]()
+    keep = []
+    ps = F.PrimmeSvdsParams()
+    lib.primme_svds_initialize(C.byref(ps))
+    ps.m, ps.n, ps.numSvals = m, n, numSvals
+    ps.target = F.SVDS_TARGETS[target]
+    ps.eps, ps.aNorm, ps.printLevel, ps.outputFile = eps, aNorm, printLevel, None
+    if maxBlockSize: ps.maxBlockSize = maxBlockSize
+    if maxBasisSize: ps.maxBasisSize = maxBasisSize
+    if locking is not None: ps.locking = locking
+    if maxMatvecs: ps.maxMatvecs = maxMatvecs
+    if iseed is not None:
+        for i in range(4): ps.iseed[i] = iseed[i]
+    v0 = None if v0 is None else np.asarray(v0, dtype=dtype).reshape(n, -1)
+    ps.initSize = 0 if v0 is None else v0.shape[1]
+    ncols = max(numSvals, ps.initSize)
+    handles = []
+
+    if backend == "reference":
+        rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
+
+        def mv(x, ldx, y, ldy, bs, tr, pp, ierr):
+            nb, lx, ly = bs[0], ldx[0], ldy[0]
+            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
+            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
+            if tr[0]:
+                Y[:, :n] = csr_matvec_numpy(rpT, ciT, vaT, X[:, :m].T.astype(np.float64)).T
+            else:
+                Y[:, :m] = csr_matvec_numpy(rp, ci, va, X[:, :n].T.astype(np.float64)).T
+            ierr[0] = 0
+        cb = F.SVDS_BLOCK_OP(mv)
+        keep.append(cb)
+        ps.matrixMatvec = C.cast(cb, C.c_void_p)
+        solver = lib.dprimme_svds if dtype == np.float64 else lib.sprimme_svds
+    else:
+        ctx = C.c_void_p()
+        if lib.hipk_ctx_create(C.byref(ctx), None):
+            raise RuntimeError("hipk_ctx_create failed: no HIP device (primme_amd has no CPU path)")
+        handles.append(("ctx", ctx))
+        oph = C.c_void_p()
+        rc = lib.primme_amd_svds_operator_create(C.byref(oph), ctx, dt, m, n, rp.ctypes.data_as(C.c_void_p),
+                                                 ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise RuntimeError(f"svds operator creation failed: {rc}")
+        handles.append(("op", oph))
+        ps.matrix = oph
+        ps.matrixMatvec = C.cast(lib.primme_amd_svds_matvec, C.c_void_p)
+        solver = lib.hip_dprimme_svds if dtype == np.float64 else lib.hip_sprimme_svds
+
+    mset = getattr(F, "PRIMME_" + methodStage1) if isinstance(methodStage1, str) and hasattr(F, "PRIMME_" + methodStage1) \
+        else F.METHODS.get(methodStage1, 0) if isinstance(methodStage1, str) else methodStage1
+    lib.primme_svds_set_method(F.SVDS_METHODS[method], mset, 0, C.byref(ps))
+
+    svals = np.zeros(numSvals, dtype=dtype)
+    rnorms = np.zeros(numSvals, dtype=dtype)
+    total = (m + n) * ncols
+    sv_t = None
+    if backend == "hip":
+        import torch
+        sv_t = torch.zeros(total, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
+        if v0 is not None:
+            # [U0 (m x initSize) | V0 (n x initSize)]: only V0 is used by A'A, U0 by AA'
+            sv_t[m * ps.initSize: m * ps.initSize + n * ps.initSize] = torch.from_numpy(np.ascontiguousarray(v0.T).ravel()).cuda()
+        torch.cuda.synchronize()
+        svp = C.c_void_p(sv_t.data_ptr())
+    else:
+        sv = np.zeros(total, dtype=dtype)
+        if v0 is not None:
+            sv[m * ps.initSize: m * ps.initSize + n * ps.initSize] = np.ascontiguousarray(v0.T).ravel()
+        svp = sv.ctypes.data_as(C.c_void_p)
+    ret = solver(svals.ctypes.data_as(C.c_void_p), svp, rnorms.ctypes.data_as(C.c_void_p), C.byref(ps))
+    k = ps.initSize
+    U = V = None
+    if return_vectors and k > 0:
+        if backend == "hip":
+            import torch
+            torch.cuda.synchronize()
+            sv = sv_t.cpu().numpy()
+        U = sv[:m * k].reshape(k, m).T.copy()
+        V = sv[m * k:m * k + n * k].reshape(k, n).T.copy()
+    res = SvdsResult(ret, svals[:max(k, 0)].copy(), U, V, rnorms[:max(k, 0)].copy(), ps)
+    for kind, h in reversed(handles):
+        if kind == "op": lib.primme_amd_svds_operator_destroy(h)
+        elif kind == "ctx": lib.hipk_ctx_destroy(h)
+    return res

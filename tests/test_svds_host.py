@@ -1,0 +1,100 @@
+"""Singular value front end on the CPU: parameter block ABI against the live
+reference, the product host logic (hostcheck backend) against the reference's dprimme_svds on the
+same inputs, and the reference driver's own svds regression cases with its acceptance test."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from primme_amd import _ffi as F
+from primme_amd import problems
+from primme_amd.svds_api import svds, transpose_csr
+import reference_driver_cases as RD
+
+HAVE_REF = os.path.exists(F.REFERENCE_LIB)
+
+
+def _rect(m, n, seed=0):
+    rng = np.random.default_rng(seed)
+    d = min(m, n)
+    rows = np.concatenate([np.repeat(np.arange(m), 3), np.arange(d)])
+    cols = np.concatenate([rng.integers(0, n, size=3 * m), np.arange(d)])
+    vals = np.concatenate([rng.standard_normal(3 * m), 5 + np.arange(d) * 10.0 / d])
+    A = np.zeros((m, n))
+    np.add.at(A, (rows, cols), vals)
+    r, c = np.nonzero(A)
+    rp = np.zeros(m + 1, dtype=np.int64)
+    np.add.at(rp, r + 1, 1)
+    return A, (np.cumsum(rp).astype(np.int32), c.astype(np.int32), A[r, c])
+
+
+def test_svds_params_abi():
+    assert C.sizeof(F.PrimmeSvdsParams) == 1720 and C.sizeof(F.PrimmeSvdsStats) == 128
+    assert F.PrimmeSvdsParams.primmeStage2.offset == 640 and F.PrimmeSvdsParams.stats.offset == 1528
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built")
+def test_svds_defaults_byte_identical_to_reference(built):
+    lib, ref = F.load_hostcheck(), F.load_reference()
+    a, b = F.PrimmeSvdsParams(), F.PrimmeSvdsParams()
+    for (m, n, k, meth, tgt, stage1) in [(1000, 500, 5, 2, 0, 0), (500, 1000, 3, 2, 1, F.METHODS["GD_plusK"]),
+                                         (800, 800, 10, 2, 0, F.METHODS["JDQMR"]), (900, 700, 4, 1, 0, 0),
+                                         (900, 700, 4, 3, 1, 0), (300, 700, 2, 0, 2, 0)]:
+        for x, l in ((a, lib), (b, ref)):
+            l.primme_svds_initialize(C.byref(x))
+            x.outputFile = None
+            x.m, x.n, x.numSvals, x.target = m, n, k, tgt
+            l.primme_svds_set_method(meth, stage1, 0, C.byref(x))
+        assert bytes(a) == bytes(b), (m, n, k, meth, tgt)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built")
+@pytest.mark.parametrize("m,n,k,target", [(300, 200, 5, "largest"), (200, 300, 4, "largest"), (300, 200, 3, "smallest")])
+def test_svds_hostcheck_follows_reference(built, m, n, k, target):
+    A, csr = _rect(m, n)
+    s = np.linalg.svd(A, compute_uv=False)
+    want = s[:k] if target == "largest" else s[::-1][:k]
+    out = {}
+    for be in ("hostcheck", "reference"):
+        r = svds(m, n, csr, numSvals=k, target=target, eps=1e-10, methodStage1="GD_plusK", backend=be)
+        assert r.ret == 0 and r.initSize == k
+        assert np.max(np.abs(r.svals - want)) <= 1e-10 * s[0]
+        assert np.all(r.resNorms <= 1e-10 * r.params["aNorm"] * (1 + 1e-6))
+        assert np.linalg.norm(A @ r.V - r.U * r.svals) <= 1e-8 * s[0]
+        assert np.linalg.norm(r.U.T @ r.U - np.eye(k)) <= 1e-8 and np.linalg.norm(r.V.T @ r.V - np.eye(k)) <= 1e-8
+        out[be] = r
+    h, r = out["hostcheck"], out["reference"]
+    for key in ("numOuterIterations", "numMatvecs", "numRestarts"):
+        assert h.stats[key] == r.stats[key], key
+    assert h.params["aNorm"] == pytest.approx(r.params["aNorm"], rel=1e-12)
+
+
+@pytest.mark.parametrize("name", sorted(RD.SVDS_CASES))
+@pytest.mark.parametrize("backend", ["hostcheck"] + (["reference"] if HAVE_REF else []))
+def test_svds_reference_driver_case(built, name, backend):
+    """tests/tests/test_20N on rect.mtx, accepted by the driver's check_solution_svds against the
+    reference's stored singular vectors (the `reference` leg pins the checker itself)."""
+    rp, ci, va, m, n = RD.rect()
+    rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
+    case = RD.SVDS_CASES[name]
+    r = svds(m, n, (rp, ci, va), backend=backend, methodStage1="GD_plusK", **case["kw"])
+    assert r.ret == 0 and r.initSize == case["kw"]["numSvals"]
+    XU, _ = RD.read_sol_svds(case["sol"], m, n)
+    bad = RD.check_solution_svds(lambda v: problems.csr_matvec_numpy(rp, ci, va, v.reshape(-1, 1)).ravel(),
+                                 lambda u: problems.csr_matvec_numpy(rpT, ciT, vaT, u.reshape(-1, 1)).ravel(),
+                                 r.svals, r.U, r.V, r.resNorms, r.params["aNorm"], case["kw"]["eps"], XU)
+    assert not bad, bad
+    A = np.zeros((m, n))
+    A[np.repeat(np.arange(m), np.diff(rp)), ci] = va
+    s = np.linalg.svd(A, compute_uv=False)
+    k = len(r.svals)
+    want = s[:k] if case["kw"]["target"] == "largest" else s[::-1][:k]
+    assert np.max(np.abs(r.svals - want)) <= max(case["kw"]["eps"], 1e-10) * s[0]
+
+
+def test_svds_unsupported_methods_fail_loudly(built):
+    A, csr = _rect(60, 40)
+    assert svds(60, 40, csr, numSvals=2, method="hybrid", backend="hostcheck").ret == -144
+    assert svds(60, 40, csr, numSvals=2, method="augmented", backend="hostcheck").ret == -144
+    assert svds(60, 40, csr, numSvals=70, backend="hostcheck").ret == -10
