@@ -118,6 +118,10 @@ int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
  * permute_vecs / Num_compact_vecs on device columns (auxiliary.c:716, :897). */
 int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx,
       const double *alpha_host /* nx real scale factors */);
+/* X(:,c) *= 1/sqrt(norm2_dev[c]) with the squared norms still in HBM: normalisation without
+ * a host round trip (the speculative tail of the block-size-1 GD iteration) */
+int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx,
+      const double *norm2_dev);
 int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
       const void *X, int64_t ldX, void *Y, int64_t ldY, int nx);
 int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,

@@ -176,6 +176,12 @@ int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ld
    for (int c = 0; c < nx; c++) { void *x = (void *)colp(dt, X, ldX, c); for (int64_t i = 0; i < m; i++) st_(dt, x, i, a[c] * ld_(dt, x, i)); }
    return 0;
 }
+int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx, const double *n2) {
+   double a[64];
+   if (nx > 64) return -1;
+   for (int c = 0; c < nx; c++) a[c] = 1.0 / sqrt(n2[c]);
+   return hipk_scale_cols(ctx, dt, m, X, ldX, nx, a);
+}
 int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *a, const void *X, int64_t ldX,
       void *Y, int64_t ldY, int nx) {
    (void)ctx;

@@ -194,6 +194,7 @@ def _declare_kernels(lib):
         "hipk_pair_dots": [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i, _vp],
         "hipk_qmr_update": [_vp, _i, _i64, _i, _dp, _dp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
         "hipk_scale_cols": [_vp, _i, _i64, _vp, _i64, _i, _dp],
+        "hipk_scale_cols_rsqrt_dev": [_vp, _i, _i64, _vp, _i64, _i, _vp],
         "hipk_axpy_cols": [_vp, _i, _i64, _dp, _vp, _i64, _vp, _i64, _i],
         "hipk_copy_cols": [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i],
         "hipk_gather_cols": [_vp, _i, _i64, _vp, _i64, P(_i), _i, _vp, _i64],

@@ -47,7 +47,7 @@ int pa_project_once(pa_solver *s, char *Q, int64_t ldQ, int nQ, char *X, int64_t
       char *x = PCOL(s, X, ldX, inX ? inX[c] : c);
       hipk_seg seg = {Q, ldQ, nQ};
       CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, x, ldX, 1, s->d_red, nQ));
-      CHK(pa_reduce(s, s->d_red, nQ, 1, (p->numProcs > 1 && !s->dev_comm) ? 0 : 1));
+      CHK(pa_reduce(s, s->d_red, nQ, 1, (s->parallel && !s->dev_comm) ? 0 : 1));
       CHK(hipk_panel_project(s->ctx, s->dt, s->m, &seg, 1, s->d_red, nQ, x, ldX, 1, s->d_red + nQ));
       CHK(pa_reduce(s, s->d_red + nQ, 1, 0, 0));
       if (norms) norms[c] = sqrt(s->h_red[nQ]);
@@ -177,6 +177,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
    const int fused = s->fuse_gd && computeXR;
    if (fused) { R = X; X = NULL; }
    s->fov_valid = 0;   /* only overlaps computed in THIS call, for the candidate that stays, may be reused */
+   s->spec2_valid = 0;
    int *flagsBlock = (int *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(int));
    double *hValsBlock = (double *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(double));
    hipk_job *jobs = (hipk_job *)malloc((size_t)(2 * maxBlockSize + 2) * sizeof(hipk_job));
@@ -261,15 +262,35 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
           * If the pair turns out converged the slot is scratch anyway.  Not done when the
           * convergence test may still project R (practical-convergence path). */
          const int nov = basisSize + nLk;
-         const int parallel_host = (p->numProcs > 1 && p->globalSumReal && !s->dev_comm);
+         const int parallel_host = (s->parallel && !s->dev_comm);
          const int speculate = (practConvChecking < 0 || !p->locking || numLocked == 0);
          s->fov_projected = 0;
+         s->spec2_valid = 0;
+         /* second stage of the speculation: normalise with the norm still on the device, apply
+          * the operator and project, so that the whole outer iteration costs ONE host
+          * synchronisation.  Needs in-stream reductions (single rank or the RCCL communicator). */
+         const int speculate2 = speculate && !parallel_host && !s->phase_timing && dstc == VCOL(s, basisSize) &&
+                                basisSize + 1 <= p->maxBasisSize && !getenv("PRIMME_AMD_NO_SPEC2");
          if (speculate) {
             if ((rc = pa_reduce(s, s->d_fov, nov + 1, 1, parallel_host ? 0 : 1))) goto out;
             hipk_seg segs[2] = {{s->V, s->ld, basisSize}, {s->evecs, s->ldevecs, nLk}};
             if ((rc = hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, dstc, s->ld, 1,
                        s->d_fov + nov + 1))) goto out;
-            if ((rc = pa_reduce(s, s->d_fov + nov + 1, 1, 0, 0))) goto out;
+            if (speculate2) {
+               if ((rc = pa_reduce(s, s->d_fov + nov + 1, 1, 1, 1))) goto out;
+               if ((rc = hipk_scale_cols_rsqrt_dev(s->ctx, s->dt, s->m, dstc, s->ld, 1, s->d_fov + nov + 1))) goto out;
+               int one = 1, ierr = 0;
+               PRIMME_INT ldx = s->ld;
+               p->matrixMatvec(dstc, &ldx, WCOL(s, basisSize), &ldx, &one, p, &ierr);
+               if (ierr) { rc = PRIMME_USER_FAILURE; goto out; }
+               hipk_seg vseg = {s->V, s->ld, basisSize + 1};
+               if ((rc = hipk_panel_dots(s->ctx, s->dt, s->m, &vseg, 1, WCOL(s, basisSize), s->ld, 1, s->d_red, basisSize + 1))) goto out;
+               if ((rc = pa_reduce(s, s->d_red, basisSize + 1, 0, 0))) goto out;      /* the one synchronisation */
+               memcpy(s->spec_hcol, s->h_red, (size_t)(basisSize + 1) * sizeof(double));
+               s->spec2_valid = 1; s->spec2_k = basisSize;
+            } else {
+               if ((rc = pa_reduce(s, s->d_fov + nov + 1, 1, 0, 0))) goto out;
+            }
             s->fov_projected = 1;
          } else {
             if ((rc = pa_reduce(s, s->d_fov, nov + 1, 1, 0))) goto out;

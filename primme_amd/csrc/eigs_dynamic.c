@@ -119,7 +119,7 @@ int pa_dyn_observe(pa_cost_model *c, primme_params *p, double now, int recentCon
 }
 
 static int averaged_ratio(pa_solver *s, double *ratio) {
-   if (s->p->numProcs > 1) {
+   if (s->parallel) {
       int rc = pa_reduce_host(s, ratio, 1);
       if (rc) return rc;
       *ratio /= (double)s->p->numProcs;

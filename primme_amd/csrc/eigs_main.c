@@ -487,8 +487,15 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                   break;
             }
 
-            CHK(pa_matvec(s, s->V, s->ld, s->W, s->ld, basisSize, blockSize));
-            CHK(pa_update_projection(s, basisSize, blockSize));
+            if (s->spec2_valid && s->spec2_k == basisSize && blockSize == 1) {
+               /* W(:,k) = A v and V'W(:,k) were produced by the speculative tail (eigs_conv.c) */
+               p->stats.numMatvecs += 1;
+               for (i = 0; i <= basisSize; i++) s->H[i + (size_t)basisSize * s->K] = s->spec_hcol[i];
+            } else {
+               CHK(pa_matvec(s, s->V, s->ld, s->W, s->ld, basisSize, blockSize));
+               CHK(pa_update_projection(s, basisSize, blockSize));
+            }
+            s->spec2_valid = 0;
 
             /* remember the coefficient vectors of this step (the +k directions) */
             for (int j = 0; j < basisSize; j++) {
@@ -668,7 +675,7 @@ static void free_solver(pa_solver *s) {
       hipk_ctx_destroy(s->ctx);
    }
    free(s->H); free(s->hVecs); free(s->prevhVecs); free(s->hVals); free(s->prevRitzVals);
-   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms);
+   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol);
    free(s->flags); free(s->map); free(s->iev); free(s->perm); free(s->lockedFlags);
    free(s);
 }
@@ -725,7 +732,10 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->startTime = t0;
    /* the dynamic method's cost model needs device time, not launch time */
    s->phase_timing = p->profile != NULL || p->dynamicMethodSwitch > 0;
-   s->dev_comm = (p->numProcs > 1 && p->globalSumReal == primme_amd_global_sum);
+   /* PRIMME_AMD_FORCE_COMM: run the cross-rank reduction path with a one-rank communicator, which is
+    * how the RCCL calls are exercised on a single-GPU box (tests/test_comm_gpu.py) */
+   s->parallel = ((p->numProcs > 1 || getenv("PRIMME_AMD_FORCE_COMM")) && p->globalSumReal != NULL);
+   s->dev_comm = (s->parallel && p->globalSumReal == primme_amd_global_sum);
    s->coef_valid_k = -1;
    s->fuse_gd = (p->correctionParams.maxInnerIterations == 0 && p->dynamicMethodSwitch <= 0 && !p->correctionParams.precondition &&
                  !p->correctionParams.projectors.RightX &&
@@ -753,6 +763,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->prevhVecs = (double *)calloc((size_t)K * K, 8); s->hVals = (double *)calloc((size_t)K, 8);
    s->prevRitzVals = (double *)calloc((size_t)K + nev, 8);
    s->blockNorms = (double *)calloc((size_t)K + b, 8); s->basisNorms = (double *)calloc((size_t)K, 8);
+   s->spec_hcol = (double *)calloc((size_t)K + 2, 8);
    s->flags = (int *)calloc((size_t)K, sizeof(int)); s->map = (int *)calloc((size_t)K, sizeof(int));
    s->iev = (int *)calloc((size_t)K + b, sizeof(int)); s->perm = (int *)calloc((size_t)nev + 1, sizeof(int));
    s->lockedFlags = (int *)calloc((size_t)nev + 1, sizeof(int));

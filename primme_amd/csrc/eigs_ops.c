@@ -36,7 +36,7 @@ double pa_problem_norm(int overrideUser, const primme_params *p) {
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync) {
    primme_params *p = s->p;
    if (count <= 0) return 0;
-   const int parallel = (p->numProcs > 1 && p->globalSumReal);
+   const int parallel = s->parallel;
    double t0 = parallel ? pa_wtime() : 0.0;
    if (parallel && s->dev_comm) {
       CHK(pa_comm_allreduce_device(p->commInfo, d_buf, count, hipk_ctx_stream(s->ctx)));
@@ -67,7 +67,7 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
  * device partials so that every communicator flavour is covered */
 int pa_reduce_host(pa_solver *s, double *buf, int count) {
    primme_params *p = s->p;
-   if (count <= 0 || p->numProcs <= 1 || !p->globalSumReal) return 0;
+   if (count <= 0 || !s->parallel) return 0;
    CHK(hipk_sync(s->ctx));
    memcpy(s->h_red, buf, (size_t)count * sizeof(double));
    if (s->dev_comm) CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, (size_t)count * sizeof(double)));
@@ -149,7 +149,7 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
    const int maxNumOrthos = 3, maxNumRandoms = 10;
    const double tol = sqrt(2.0) / 2.0;
    const double eps_orth = s->mach_eps;
-   const int parallel = (p->numProcs > 1 && p->globalSumReal);
+   const int parallel = s->parallel;
    double t0 = pa_wtime();
 
    if (RLocked)
@@ -192,11 +192,16 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
          }
          p->stats.numOrthoInnerProds += ndot;
          p->stats.numOrthoInnerProds += nov + 1;
-         if (!(use_fov && s->fov_projected)) {
+         const int speculated = use_fov && s->fov_projected;
+         if (!speculated) {
             CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, d_ov, nov > 0 ? nov : 1, v, ldV, 1, d_s1));
             CHK(pa_reduce(s, d_s1, 1, 0, 0)); /* synchronises: hbase now has overlaps, s02, s12 */
          }
          s->fov_projected = 0;
+         /* the speculative tail (normalise on device, operator, projection) stands only if THIS
+          * first pass is the last one */
+         const int tail_done = speculated && s->spec2_valid && s->spec2_k == i && b1 == b2;
+         if (!tail_done) s->spec2_valid = 0;
 
          if (updateR)
             for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += hbase[i + j];
@@ -211,11 +216,12 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
          } else {
             double inv = 1.0 / s1;
             if (isfinite(inv)) {
-               CHK(hipk_scale_cols(s->ctx, s->dt, s->m, v, ldV, 1, &inv));
+               if (!tail_done) CHK(hipk_scale_cols(s->ctx, s->dt, s->m, v, ldV, 1, &inv));
                break;
             }
             nOrth = maxNumOrthos;
          }
+         s->spec2_valid = 0;   /* another pass or a random restart: the tail used a stale vector */
       }
       if (b2_out) *b2_out = i + 1;
    }

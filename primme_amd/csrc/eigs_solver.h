@@ -64,6 +64,12 @@ typedef struct pa_solver {
    int fov_valid, fov_k, fov_L;
    int fov_projected;      /* the first pass' update + norm were already run speculatively */
    char *fov_col;
+   /* speculative tail of the block-size-1 GD iteration: the new basis vector was normalised with
+    * the device-resident norm, multiplied by the operator and projected before the host looked
+    * at anything; accepted by the orthogonaliser if Daniel's test passes on the first pass */
+   int spec2_valid, spec2_k;
+   double *spec_hcol;      /* K+1 entries: V(:,0:k+1)' W(:,k) */
+   int parallel;           /* reductions cross ranks (numProcs > 1 and a globalSumReal installed) */
    int fuse_gd;            /* GD without preconditioner/Olsen: residual written straight into V */
    int coef_valid_k;       /* d_coef/d_theta currently hold hVecs/hVals of this size, or -1 */
    double startTime;

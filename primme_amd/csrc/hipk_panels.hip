@@ -769,6 +769,18 @@ scale_kernel(T *__restrict__ X, int64_t ldX, int nx, ColScal sc, int64_t m) {
 
 template <typename T>
 __global__ void __launch_bounds__(HIPK_BLOCK)
+scale_rsqrt_kernel(T *__restrict__ X, int64_t ldX, int nx, const double *__restrict__ norm2, int64_t m) {
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      T *x = X + (size_t)c * ldX;
+      const double a = 1.0 / sqrt(norm2[c]);     /* same two IEEE operations as the host path */
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride)
+         x[i] = (T)(a * (double)x[i]);
+   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
 axpy_kernel(ColScal sc, const T *__restrict__ X, int64_t ldX, T *__restrict__ Y, int64_t ldY,
       int nx, int64_t m) {
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
@@ -907,6 +919,17 @@ extern "C" int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X,
             hipLaunchKernelGGL(scale_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (T *)X + (size_t)c0 * ldX, ldX, n, sc, m));
       HIPK_CHECK(hipGetLastError());
    }
+   return 0;
+}
+
+extern "C" int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX,
+      int nx, const double *norm2_dev) {
+   if (nx <= 0) return 0;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(scale_rsqrt_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (T *)X, ldX, nx, norm2_dev, m),
+         hipLaunchKernelGGL(scale_rsqrt_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (T *)X, ldX, nx, norm2_dev, m));
+   HIPK_CHECK(hipGetLastError());
    return 0;
 }
 

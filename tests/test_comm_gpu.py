@@ -1,0 +1,64 @@
+"""The RCCL communicator on the one GPU a test box has: a ONE-rank communicator exercises every call
+the multi-rank path makes (ncclCommInitRank, in-stream ncclAllReduce of the device partials,
+all-gather, grouped send/recv halo with no neighbours) and must not change any result.
+Cross-rank arithmetic itself is covered by the world-size-2 gloo tests (tests/test_multirank_gloo.py);
+two ranks on one device are rejected by RCCL ("Duplicate GPU detected")."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from primme_amd import _ffi as F
+from primme_amd import eigsh, Operator, problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _comm(lib):
+    buf = (C.c_char * 128)()
+    assert lib.primme_amd_comm_unique_id(buf) == 0
+    comm = C.c_void_p()
+    assert lib.primme_amd_comm_create(C.byref(comm), bytes(buf.raw), 0, 1) == 0
+    return comm
+
+
+def test_one_rank_communicator_calls(built):
+    import torch
+    lib = F.load_product()
+    comm = _comm(lib)
+    lib.primme_amd_comm_rank.argtypes = [C.c_void_p]; lib.primme_amd_comm_size.argtypes = [C.c_void_p]
+    assert lib.primme_amd_comm_rank(comm) == 0 and lib.primme_amd_comm_size(comm) == 1
+    x = torch.arange(1000, dtype=torch.float64, device="cuda")
+    y = torch.zeros_like(x)
+    lib.primme_amd_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    assert lib.primme_amd_comm_allgather(comm, None, x.data_ptr(), y.data_ptr(), 8000) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    mine = (C.c_int64 * 2)(7, 9); allv = (C.c_int64 * 2)()
+    lib.primme_amd_comm_allgather_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    assert lib.primme_amd_comm_allgather_i64(comm, mine, 2, allv) == 0 and list(allv) == [7, 9]
+    lib.primme_amd_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("kw", [dict(numEvals=4, eps=1e-9, aNorm=8.0), dict(numEvals=3, eps=1e-9, aNorm=8.0, method="JDQMR"),
+                                dict(numEvals=4, eps=1e-9, aNorm=8.0, maxBlockSize=2)])
+def test_solver_through_rccl_reductions(built, kw):
+    """Same solve with and without the device-communicator reduction path (forced on one rank)."""
+    lib = F.load_product()
+    rp, ci, va, n = problems.laplacian_csr((40, 41))
+    op = Operator(n, csr=(rp, ci, va))
+    v0 = problems.start_vector(n)
+    a = eigsh(op, backend="hip", v0=v0, **kw)
+    comm = _comm(lib)
+    os.environ["PRIMME_AMD_FORCE_COMM"] = "1"
+    try:
+        b = eigsh(op, backend="hip", v0=v0, comm=comm, **kw)
+    finally:
+        del os.environ["PRIMME_AMD_FORCE_COMM"]
+    assert a.ret == 0 and b.ret == 0
+    assert b.stats["numGlobalSum"] > 0 and a.stats["numGlobalSum"] == 0
+    assert np.array_equal(a.evals, b.evals) and np.array_equal(a.resNorms, b.resNorms)
+    for k in ("numOuterIterations", "numMatvecs", "numRestarts"):
+        assert a.stats[k] == b.stats[k]
+    lib.primme_amd_comm_destroy(comm)
