@@ -124,6 +124,9 @@ int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, 
       const double *norm2_dev);
 int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
       const void *X, int64_t ldX, void *Y, int64_t ldY, int nx);
+/* Y(:,c) = alpha[c] Y(:,c) + X(:,c) */
+int hipk_xpay_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
+      const void *X, int64_t ldX, void *Y, int64_t ldY, int nx);
 int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
       void *Y, int64_t ldY, int nx);
 /* Y(:,i) = X(:,perm[i]) for i < n, X and Y distinct panels */
@@ -141,6 +144,12 @@ int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, i
  * out_dev[c] = X(:,c)' Y(:,c)                      Num_dist_dots_real (auxiliary_eigs.c:695-706) */
 int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
       const void *Y, int64_t ldY, int nx, double *out_dev);
+/* Y(:,c) += alpha[c] X(:,c) (stored), then out_dev[c] = Z(:,c)' Y(:,c)  (Z == NULL: |Y(:,c)|^2), in
+ * one pass: the axpy + dot pairs of the QMR step (w -= sigma d, x'w; w -= (x'w) x, d'w;
+ * g -= alpha w, g'g  — inner_solve.c:853-880, :317-333, :371-377) with the arithmetic of the
+ * separate calls (element-wise fma, same reduction tree as hipk_pair_dots) */
+int hipk_axpy_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha_host,
+      const void *X, int64_t ldX, void *Y, int64_t ldY, const void *Z, int64_t ldZ, double *out_dev);
 /* delta = gamma.*delta + eta.*d; sol += delta; dotsol_dev[c] = |sol(:,c)|^2 in one pass
  * (the host path of the reference fuses the same three steps, inner_solve.c:384-397) */
 int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gamma_host,

@@ -232,6 +232,21 @@ int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64
    mirror(out, nx);
    return 0;
 }
+int hipk_xpay_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *a, const void *X, int64_t ldX,
+      void *Y, int64_t ldY, int nx) {
+   (void)ctx;
+   for (int c = 0; c < nx; c++) {
+      const void *x = colp(dt, X, ldX, c); void *y = (void *)colp(dt, Y, ldY, c);
+      for (int64_t i = 0; i < m; i++) st_(dt, y, i, a[c] * ld_(dt, y, i) + ld_(dt, x, i));
+   }
+   return 0;
+}
+int hipk_axpy_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *a, const void *X, int64_t ldX,
+      void *Y, int64_t ldY, const void *Z, int64_t ldZ, double *out) {
+   int rc = hipk_axpy_cols(ctx, dt, m, a, X, ldX, Y, ldY, nx);
+   if (rc) return rc;
+   return hipk_pair_dots(ctx, dt, m, Z ? Z : Y, Z ? ldZ : ldY, Y, ldY, nx, out);
+}
 int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gam, const double *eta,
       const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, double *dotsol) {
    (void)ctx;

@@ -106,15 +106,38 @@ typedef struct {
    char *RQ, *RX; int64_t ldRQ, ldRX; int nRQ, nRX;   /* right projectors (orthogonal form)       */
 } jd_proj;
 
+/* result = (I - Q Q')(I - x x')... (A - shift) v, and vdot[c] = v_c' result_c.  The axpy of every
+ * step is fused with the dot product that follows it (hipk_axpy_dot): same arithmetic as the
+ * reference's separate Num_axpy / Num_dist_dots calls, two passes over the panels fewer. */
 static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const double *shift, const jd_proj *P,
-      int nb, char *result, int64_t ldres) {
-   /* result = (A - shift) v, then the left projectors */
+      int nb, char *result, int64_t ldres, double *vdot) {
    CHK(pa_matvec(s, v, ldv, result, ldres, 0, nb));
    double ms[64];
    for (int i = 0; i < nb; i++) ms[i] = -shift[i];
-   CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
-   CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
-   if (P->nLX > 0) CHK(project_each(s, P->LX, P->ldLX, P->LX, P->ldLX, result, ldres, nb));
+   if (P->nLX > 0) {
+      double t0 = pa_wtime();
+      if (P->nLQ > 0) {
+         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
+         CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+         CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, result, ldres, nb, s->d_red));
+      } else {
+         /* result -= shift v  and  x' result */
+         CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, nb, ms, v, ldv, result, ldres, P->LX, P->ldLX, s->d_red));
+      }
+      CHK(pa_reduce(s, s->d_red, nb, 0, 0));
+      double ma[64];
+      for (int i = 0; i < nb; i++) ma[i] = -s->h_red[i];
+      /* result -= (x' result) x  and  v' result */
+      CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, nb, ma, P->LX, P->ldLX, result, ldres, v, ldv, s->d_red));
+      CHK(pa_reduce(s, s->d_red, nb, 0, 0));
+      for (int i = 0; i < nb; i++) vdot[i] = s->h_red[i];
+      s->p->stats.numOrthoInnerProds += nb;
+      s->p->stats.timeOrtho += pa_wtime() - t0;
+   } else {
+      CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
+      CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+      CHK(pair_dots_host(s, v, ldv, result, ldres, nb, vdot));
+   }
    return 0;
 }
 
@@ -136,7 +159,10 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    char *g = s->Jw, *d = PCOL(s, s->Jw, ld, b0), *delta = PCOL(s, s->Jw, ld, 2 * b0), *w = PCOL(s, s->Jw, ld, 3 * b0);
    double sigma_prev[64], rho_prev[64], rho[64], alpha_prev[64], Theta_prev[64], Theta[64], tau_init[64],
          tau_prev[64], tau[64], Beta_prev[64], Delta_prev[64], Psi_prev[64], eta[64], eval_prev[64],
-         eres_updated[64], Gamma_prev[64], Phi_prev[64], gamma[64], dot_sol[64], tmp[64];
+         eres_updated[64], Gamma_prev[64], Phi_prev[64], gamma[64], dot_sol[64], tmp[64], gg[64];
+   /* without preconditioner and right projectors the "preconditioned" vector is g itself: no
+    * copy, and rho = g'g is the dot product already taken for Theta */
+   const int plain_K = (!p->correctionParams.precondition && P->nRQ == 0 && P->nRX == 0);
    int pm[64], p0[64];
    const int adaptive = (p->correctionParams.convTest == primme_adaptive ||
                          p->correctionParams.convTest == primme_adaptive_ETolerance);
@@ -176,8 +202,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    for (i = 0; i < blockSize; i++) pm[i] = i;
 
    for (int64_t numIts = 0; numIts < maxIterations && blockSize > 0; numIts++) {
-      CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld));
-      CHK(pair_dots_host(s, d, ld, w, ld, blockSize, tmp));
+      CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld, tmp));
       for (i = 0; i < blockSize; i++) sigma_prev[pm[i]] = tmp[i];
 
       int conv = 0;
@@ -197,12 +222,16 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          }
          malpha[i] = -alpha_prev[q];
       }
-      CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, malpha, w, ld, g, ld, blockSize));   /* g -= alpha w (0 for dropped) */
+      /* g -= alpha w (0 for dropped columns) and g'g in the same pass */
+      CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, blockSize, malpha, w, ld, g, ld, NULL, 0, s->d_red));
+      CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
+      for (i = 0; i < blockSize; i++) gg[i] = s->h_red[i];
 
 #define SHRINK()                                                                                   \
       do {                                                                                         \
          pa_permute_ints(pm, blockSize, p0);                                                       \
          pa_permute_cols(shift, 1, blockSize, 1, p0);                                              \
+         pa_permute_cols(gg, 1, blockSize, 1, p0);                                                 \
          CHK(permute_panel(s, g, ld, blockSize, p0));                                              \
          CHK(permute_panel(s, d, ld, blockSize, p0));                                              \
          CHK(permute_panel(s, delta, ld, blockSize, p0));                                          \
@@ -216,11 +245,10 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
       SHRINK();
       if (blockSize <= 0) break;
 
-      CHK(pair_dots_host(s, g, ld, g, ld, blockSize, tmp));
       double gam_c[64], eta_c[64];
       for (i = 0; i < blockSize; i++) {
          const int q = pm[i];
-         Theta[q] = sqrt(tmp[i]) / tau_prev[q];
+         Theta[q] = sqrt(gg[i]) / tau_prev[q];
          const double c = 1.0 / sqrt(1 + Theta[q] * Theta[q]);
          tau[q] = tau_prev[q] * Theta[q] * c;
          gamma[q] = c * c * Theta_prev[q] * Theta_prev[q];
@@ -282,17 +310,23 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
       if (blockSize <= 0) break;
 
       if (numIts + 1 < maxIterations) {
-         CHK(apply_projected_preconditioner(s, g, ld, P, blockSize, w, ld));
-         CHK(pair_dots_host(s, g, ld, w, ld, blockSize, tmp));
+         if (!plain_K) {
+            CHK(apply_projected_preconditioner(s, g, ld, P, blockSize, w, ld));
+            CHK(pair_dots_host(s, g, ld, w, ld, blockSize, tmp));
+         }
          double beta[64];
          for (i = 0; i < blockSize; i++) {
             const int q = pm[i];
-            rho[q] = tmp[i];
+            rho[q] = plain_K ? gg[i] : tmp[i];
             beta[i] = rho[q] / rho_prev[q];
             rho_prev[q] = rho[q]; tau_prev[q] = tau[q]; Theta_prev[q] = Theta[q];
          }
-         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, beta, d, ld, w, ld, blockSize));   /* w += beta d */
-         char *t = d; d = w; w = t;
+         if (plain_K) {
+            CHK(hipk_xpay_cols(s->ctx, s->dt, s->m, beta, g, ld, d, ld, blockSize));      /* d = g + beta d */
+         } else {
+            CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, beta, d, ld, w, ld, blockSize));      /* w += beta d */
+            char *t = d; d = w; w = t;
+         }
       }
    }
 #undef SHRINK

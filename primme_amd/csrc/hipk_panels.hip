@@ -795,6 +795,20 @@ axpy_kernel(ColScal sc, const T *__restrict__ X, int64_t ldX, T *__restrict__ Y,
 
 template <typename T>
 __global__ void __launch_bounds__(HIPK_BLOCK)
+xpay_kernel(ColScal sc, const T *__restrict__ X, int64_t ldX, T *__restrict__ Y, int64_t ldY,
+      int nx, int64_t m) {
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *x = X + (size_t)c * ldX;
+      T *y = Y + (size_t)c * ldY;
+      const double a = sc.a[c];
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride)
+         y[i] = (T)fma(a, (double)y[i], (double)x[i]);
+   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
 gather_kernel(const T *__restrict__ X, int64_t ldX, ColPerm pm, int n, T *__restrict__ Y,
       int64_t ldY, int64_t m) {
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
@@ -864,6 +878,32 @@ pair_dots_kernel(const T *__restrict__ X, int64_t ldX, const T *__restrict__ Y, 
       double s = 0.0;
       for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride)
          s = fma((double)x[i], (double)y[i], s);
+      s = hipk_wave_sum(s);
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * nx + c] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      __syncthreads();
+   }
+}
+
+/* y += a x (stored); out[c] = z'y or y'y: the axpy and the dot that follows it in one pass */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+axpy_dot_kernel(ColScal sc, const T *__restrict__ X, int64_t ldX, T *__restrict__ Y, int64_t ldY,
+      const T *__restrict__ Z, int64_t ldZ, int nx, int64_t m, double *__restrict__ partials) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *x = X + (size_t)c * ldX;
+      T *y = Y + (size_t)c * ldY;
+      const T *z = Z ? Z + (size_t)c * ldZ : NULL;
+      const double a = sc.a[c];
+      double s = 0.0;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+         const T ny = (T)fma(a, (double)x[i], (double)y[i]);
+         y[i] = ny;
+         s = fma(z ? (double)z[i] : (double)ny, (double)ny, s);
+      }
       s = hipk_wave_sum(s);
       if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
       __syncthreads();
@@ -1007,6 +1047,36 @@ extern "C" int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const voi
    DISPATCH_RT(dt,
          hipLaunchKernelGGL(pair_dots_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (const T *)Y, ldY, nx, m, ctx->partials),
          hipLaunchKernelGGL(pair_dots_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (const T *)Y, ldY, nx, m, ctx->partials));
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, out_dev);
+}
+
+extern "C" int hipk_xpay_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
+      const void *X, int64_t ldX, void *Y, int64_t ldY, int nx) {
+   for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
+      int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
+      ColScal sc;
+      for (int c = 0; c < n; c++) sc.a[c] = alpha_host[c0 + c];
+      int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
+      DISPATCH_RT(dt,
+            hipLaunchKernelGGL(xpay_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sc, (const T *)X + (size_t)c0 * ldX, ldX, (T *)Y + (size_t)c0 * ldY, ldY, n, m),
+            hipLaunchKernelGGL(xpay_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sc, (const T *)X + (size_t)c0 * ldX, ldX, (T *)Y + (size_t)c0 * ldY, ldY, n, m));
+      HIPK_CHECK(hipGetLastError());
+   }
+   return 0;
+}
+
+extern "C" int hipk_axpy_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha_host,
+      const void *X, int64_t ldX, void *Y, int64_t ldY, const void *Z, int64_t ldZ, double *out_dev) {
+   if (nx <= 0) return 0;
+   if (nx > UTIL_MAXCOLS) return -1;
+   ColScal sc;
+   for (int c = 0; c < nx; c++) sc.a[c] = alpha_host[c];
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);   /* same grid as hipk_pair_dots: same sums */
+   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(axpy_dot_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sc, (const T *)X, ldX, (T *)Y, ldY, (const T *)Z, ldZ, nx, m, ctx->partials),
+         hipLaunchKernelGGL(axpy_dot_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sc, (const T *)X, ldX, (T *)Y, ldY, (const T *)Z, ldZ, nx, m, ctx->partials));
    HIPK_CHECK(hipGetLastError());
    return hipk_finalize_partials(ctx, ctx->partials, gx, nx, out_dev);
 }

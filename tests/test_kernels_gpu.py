@@ -220,14 +220,29 @@ def test_qmr_recurrence_kernels(built, dt, m, nx):
         assert L.hipk_pair_dots(side.ctx, dt, m, side.ptr(x), ld, side.ptr(y), ld, nx, side.ptr(o1)) == 0
         assert L.hipk_qmr_update(side.ctx, dt, m, nx, (C.c_double * nx)(*gam), (C.c_double * nx)(*eta), side.ptr(d), ld,
                                  side.ptr(dl), ld, side.ptr(so), ld, side.ptr(o2)) == 0
-        res.append([side.get(t) for t in (o1, o2, dl, so)])
+        # fused axpy + dot (z'y and y'y flavours) and y = a y + x
+        o3 = side.arr(np.zeros(nx)); o4 = side.arr(np.zeros(nx))
+        assert L.hipk_axpy_dot(side.ctx, dt, m, nx, (C.c_double * nx)(*gam), side.ptr(x), ld, side.ptr(y), ld,
+                               side.ptr(d), ld, side.ptr(o3)) == 0
+        assert L.hipk_axpy_dot(side.ctx, dt, m, nx, (C.c_double * nx)(*eta), side.ptr(d), ld, side.ptr(y), ld,
+                               None, 0, side.ptr(o4)) == 0
+        assert L.hipk_xpay_cols(side.ctx, dt, m, (C.c_double * nx)(*gam), side.ptr(y), ld, side.ptr(x), ld, nx) == 0
+        res.append([side.get(t) for t in (o1, o2, dl, so, o3, o4, y, x)])
         side.close()
     tol = 1e-12 if dt == F.HIPK_F64 else 2e-5
+    Xd, Yd, Dd = (t[:, :m].astype(np.float64) for t in (X, Y, D))
+    y1 = (Yd + gam[:, None] * Xd).astype(npdt).astype(np.float64)
+    assert np.max(np.abs(res[1][4] - np.einsum("ij,ij->i", Dd, y1))) <= tol * np.sqrt(m) * 16
+    for q in (4, 5):
+        assert np.max(np.abs(res[0][q] - res[1][q])) <= tol * np.sqrt(m) * 16 * max(1.0, np.abs(res[1][q]).max() / m)
+    for q in (6, 7):
+        assert np.max(np.abs(res[0][q][:, :m] - res[1][q][:, :m])) <= (1e-13 if dt == F.HIPK_F64 else 1e-5) * 50
+        assert np.array_equal(res[0][q][:, m:], res[1][q][:, m:])
     ref_dots = np.einsum("ij,ij->i", X[:, :m].astype(np.float64), Y[:, :m].astype(np.float64))
     assert np.max(np.abs(res[0][0] - res[1][0])) <= tol * np.sqrt(m) * 4
     assert np.max(np.abs(res[1][0] - ref_dots)) <= tol * np.sqrt(m) * 4
     assert np.allclose(res[0][1], res[1][1], rtol=tol * 100)
-    for a_, b_ in zip(res[0][2:], res[1][2:]):
+    for a_, b_ in zip(res[0][2:4], res[1][2:4]):
         assert np.max(np.abs(a_[:, :m] - b_[:, :m])) <= (1e-13 if dt == F.HIPK_F64 else 1e-5) * 10
         assert np.array_equal(a_[:, m:], b_[:, m:])      # padding rows untouched
 
