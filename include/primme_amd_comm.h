@@ -30,6 +30,9 @@ int primme_amd_comm_halo(primme_amd_comm *c, void *hip_stream, const void *x, in
       int64_t recv_lo_cnt, void *hi, int64_t recv_hi_cnt);
 int primme_amd_comm_allgather(primme_amd_comm *c, void *hip_stream, const void *send, void *recv,
       size_t bytes_per_rank);
+/* recv[0:count) = sum over ranks of send[rank*count : (rank+1)*count), count elements per rank */
+int primme_amd_comm_reduce_scatter(primme_amd_comm *c, void *hip_stream, const void *send, void *recv,
+      size_t count_per_rank, int is_double);
 int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n, int64_t *all);
 
 /* Operator handle for primme->matrix / primme->preconditioner: a local sparse

@@ -111,7 +111,20 @@ struct hipk_ctx;
 int primme_amd_svds_operator_create(primme_amd_svds_operator **op, struct hipk_ctx *ctx, int dt,
       int64_t m, int64_t n, const int32_t *rowptr_host, const int32_t *colind_host,
       const void *values_host);
+/* Row-partitioned A across the ranks of a communicator (BASELINE configs[4]: 8 M x 2 M over 8
+ * GPUs): this rank owns rows [row0, row0+mLocal) of A and entries [col0, col0+nLocal) of every
+ * n-vector, nLocal equal on all ranks.  rowptr/colind (GLOBAL column numbers)/values describe the
+ * local rows.  y = A x: all-gather of x, local product.  y = A' x: local product with the local
+ * rows' transpose into a full n-vector, reduce-scatter.  comm = primme_amd_comm* (primme_amd_comm.h). */
+int primme_amd_svds_operator_create_dist(primme_amd_svds_operator **op, struct hipk_ctx *ctx, int dt,
+      int64_t mLocal, int64_t n, int64_t nLocal, const int32_t *rowptr_host, const int32_t *colind_host,
+      const void *values_host, void *comm);
 int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op);
+/* globalSumReal with the primme_svds signature over the same communicator
+ * (primme_svds->commInfo = primme_amd_comm*).  When hip_dprimme_svds sees this function installed
+ * it gives the eigensolver the in-stream RCCL reduction of primme_amd_global_sum. */
+void primme_amd_svds_global_sum(void *sendBuf, void *recvBuf, int *count,
+      struct primme_svds_params *primme_svds, int *ierr);
 void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       int *transpose, struct primme_svds_params *primme_svds, int *ierr);
 

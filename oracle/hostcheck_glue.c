@@ -57,3 +57,15 @@ void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, 
    primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->matrix;
    *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, NULL, x, *ldx, y, *ldy, *bs);
 }
+
+int primme_amd_svds_operator_create_dist(primme_amd_svds_operator **op, struct hipk_ctx *ctx, int dt, int64_t mLocal,
+      int64_t n, int64_t nLocal, const int32_t *rp, const int32_t *ci, const void *val, void *comm) {
+   (void)op; (void)ctx; (void)dt; (void)mLocal; (void)n; (void)nLocal; (void)rp; (void)ci; (void)val; (void)comm;
+   return -43;   /* RCCL only exists in the product library */
+}
+void primme_amd_svds_global_sum(void *s, void *r, int *c, struct primme_svds_params *ps, int *ierr) {
+   (void)s; (void)r; (void)c; (void)ps; *ierr = 1;
+}
+int primme_amd_comm_reduce_scatter(primme_amd_comm *c, void *st, const void *s, void *r, size_t n, int d) {
+   (void)c; (void)st; (void)s; (void)r; (void)n; (void)d; return -43;
+}

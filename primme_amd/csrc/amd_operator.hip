@@ -149,7 +149,14 @@ extern "C" int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed
 /* ---- singular value operator: A and A' both resident in CSR ------------------------------ */
 #include "primme_amd_svds.h"
 #include "primme_amd_io.h"
-struct primme_amd_svds_operator { hipk_csr *A, *At; };
+struct primme_amd_svds_operator {
+   hipk_csr *A, *At;
+   primme_amd_comm *comm;        /* NULL: single rank */
+   int64_t mLocal, n, nLocal;
+   void *full;                   /* n-vector staging (all-gather target / reduce-scatter source) */
+   size_t full_cap;
+   hipk_dtype dt;
+};
 
 extern "C" int primme_amd_svds_operator_create(primme_amd_svds_operator **out, hipk_ctx *ctx, int dt,
       int64_t m, int64_t n, const int32_t *rp, const int32_t *ci, const void *val) {
@@ -166,8 +173,19 @@ extern "C" int primme_amd_svds_operator_create(primme_amd_svds_operator **out, h
    *out = op;
    return 0;
 }
+extern "C" int primme_amd_svds_operator_create_dist(primme_amd_svds_operator **out, hipk_ctx *ctx, int dt,
+      int64_t mLocal, int64_t n, int64_t nLocal, const int32_t *rp, const int32_t *ci, const void *val, void *comm) {
+   primme_amd_comm *c = (primme_amd_comm *)comm;
+   if (!c || nLocal * primme_amd_comm_size(c) != n) return -1;     /* equal column slabs */
+   int rc = primme_amd_svds_operator_create(out, ctx, dt, mLocal, n, rp, ci, val);
+   if (rc) return rc;
+   (*out)->comm = c; (*out)->mLocal = mLocal; (*out)->n = n; (*out)->nLocal = nLocal; (*out)->dt = (hipk_dtype)dt;
+   return 0;
+}
+
 extern "C" int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op) {
    if (!op) return 0;
+   if (op->full) hipFree(op->full);
    hipk_csr_destroy(op->A); hipk_csr_destroy(op->At);
    free(op);
    return 0;
@@ -176,5 +194,25 @@ extern "C" void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME
       int *transpose, struct primme_svds_params *ps, int *ierr) {
    primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->matrix;
    void *stream = ps->queue ? (void *)*(hipStream_t *)ps->queue : NULL;
-   *ierr = op ? hipk_csr_matvec(*transpose ? op->At : op->A, stream, x, *ldx, y, *ldy, *blockSize) : 1;
+   *ierr = 1;
+   if (!op) return;
+   if (!op->comm) {
+      *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, stream, x, *ldx, y, *ldy, *blockSize);
+      return;
+   }
+   /* row-partitioned A: one column at a time through the n-vector staging buffer */
+   const size_t es = (op->dt == HIPK_F64) ? 8 : 4;
+   if (grow(&op->full, &op->full_cap, (size_t)op->n * es)) return;
+   for (int c = 0; c < *blockSize; c++) {
+      const char *xc = (const char *)x + (size_t)c * (size_t)*ldx * es;
+      char *yc = (char *)y + (size_t)c * (size_t)*ldy * es;
+      if (!*transpose) {
+         if (primme_amd_comm_allgather(op->comm, stream, xc, op->full, (size_t)op->nLocal * es)) return;
+         if (hipk_csr_matvec(op->A, stream, op->full, op->n, yc, op->mLocal, 1)) return;
+      } else {
+         if (hipk_csr_matvec(op->At, stream, xc, op->mLocal, op->full, op->n, 1)) return;
+         if (primme_amd_comm_reduce_scatter(op->comm, stream, op->full, yc, (size_t)op->nLocal, op->dt == HIPK_F64)) return;
+      }
+   }
+   *ierr = 0;
 }

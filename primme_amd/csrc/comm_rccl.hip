@@ -131,6 +131,23 @@ extern "C" int primme_amd_comm_allgather(primme_amd_comm *c, void *hip_stream, c
    return 0;
 }
 
+extern "C" int primme_amd_comm_reduce_scatter(primme_amd_comm *c, void *hip_stream, const void *send,
+      void *recv, size_t count_per_rank, int is_double) {
+   NCCL_CHECK(ncclReduceScatter(send, recv, count_per_rank, is_double ? ncclDouble : ncclFloat, ncclSum, c->comm,
+         (hipStream_t)hip_stream));
+   return 0;
+}
+
+/* globalSumReal with the primme_svds signature (host buffers), same communicator */
+#include "primme_amd_svds.h"
+extern "C" void primme_amd_svds_global_sum(void *sendBuf, void *recvBuf, int *count,
+      struct primme_svds_params *ps, int *ierr) {
+   struct primme_params tmp;
+   memset(&tmp, 0, sizeof(tmp));
+   tmp.commInfo = ps->commInfo;
+   primme_amd_global_sum(sendBuf, recvBuf, count, &tmp, ierr);
+}
+
 /* small integer exchange at set-up time (neighbour halo sizes) */
 extern "C" int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n, int64_t *all) {
    int64_t *d = NULL;

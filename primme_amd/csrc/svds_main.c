@@ -306,6 +306,8 @@ static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_
    if (!p->monitorFun && ps->monitorFun) { p->monitorFun = monitor_single_stage; p->monitorFun_type = scalar_t; own_monitor = 1; }
    p->queue = &stream;
    p->profile = ps->profile;
+   /* the library's own communicator: let the eigensolver reduce its device partials in stream */
+   if (ps->globalSumReal == primme_amd_svds_global_sum) { p->globalSumReal = primme_amd_global_sum; p->commInfo = ps->commInfo; }
 
    /* ---- the eigenproblem ---- */
    ret = pa_eigs_solve(svals, eig_vecs, rnorms, p, dt, 1);

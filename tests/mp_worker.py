@@ -87,6 +87,63 @@ def run(rank, world, port, case, out_path):
         r = s.solve(numEvals=5, eps=1e-10, aNorm=8.0, v0=v0, numProcs=world, procID=rank, global_sum=global_sum,
                     user_matvec=cb)
         s.close()
+    elif case == "svds":
+        # A (m x n) split by rows, n-vectors split in equal slabs: y = A x needs an all-gather of x,
+        # y = A' x a reduce-scatter of the local products (BASELINE configs[4] in small)
+        from primme_amd.svds_api import transpose_csr
+        m, n, k = 600, 200, 4
+        rp, ci, va = problems.svds_synthetic_csr(m, n)
+        mloc, nloc = m // world, n // world
+        r0 = rank * mloc
+        lrp = (rp[r0:r0 + mloc + 1] - rp[r0]).astype(np.int32)
+        lci, lva = ci[rp[r0]:rp[r0 + mloc]], va[rp[r0]:rp[r0 + mloc]]
+        trp, tci, tva = transpose_csr(mloc, n, lrp, lci, lva)
+        lib = F.load_hostcheck()
+
+        def mv(x, ldx, y, ldy, bs, tr, pp, ierr):
+            nb, lx, ly = bs[0], ldx[0], ldy[0]
+            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(nb, lx))
+            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(nb, ly))
+            for c in range(nb):
+                if not tr[0]:
+                    parts = [torch.zeros(nloc, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts, torch.from_numpy(X[c, :nloc].copy()))
+                    xf = torch.cat(parts).numpy()
+                    Y[c, :mloc] = problems.csr_matvec_numpy(lrp, lci, lva, xf.reshape(-1, 1)).ravel()
+                else:
+                    z = torch.from_numpy(problems.csr_matvec_numpy(trp, tci, tva, X[c, :mloc].reshape(-1, 1)).ravel().copy())
+                    dist.all_reduce(z)
+                    Y[c, :nloc] = z.numpy()[rank * nloc:(rank + 1) * nloc]
+            ierr[0] = 0
+
+        GS = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(F.PrimmeSvdsParams), C.POINTER(C.c_int))
+
+        def gs(send, recv, count, pp, ierr):
+            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(count[0],))
+            out = global_sum(a)
+            np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(count[0],))[:] = out
+            ierr[0] = 0
+        cb, gcb = F.SVDS_BLOCK_OP(mv), GS(gs)
+        ps = F.PrimmeSvdsParams()
+        lib.primme_svds_initialize(C.byref(ps))
+        ps.m, ps.n, ps.numSvals, ps.eps, ps.printLevel, ps.outputFile = m, n, k, 1e-10, 0, None
+        ps.numProcs, ps.procID, ps.mLocal, ps.nLocal = world, rank, mloc, nloc
+        ps.matrixMatvec = C.cast(cb, C.c_void_p)
+        ps.globalSumReal = C.cast(gcb, C.c_void_p)
+        lib.primme_svds_set_method(F.SVDS_METHODS["normalequations"], F.METHODS["GD_plusK"], 0, C.byref(ps))
+        svals, rn = np.zeros(k), np.zeros(k)
+        sv = np.zeros((mloc + nloc) * k)
+        ret = lib.hip_dprimme_svds(svals.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p),
+                                   rn.ctypes.data_as(C.c_void_p), C.byref(ps))
+        U = sv[:mloc * k].reshape(k, mloc)
+        V = sv[mloc * k:].reshape(k, nloc)
+        res = dict(rank=rank, ret=ret, evals=svals.tolist(), resNorms=rn.tolist(), its=int(ps.stats.numOuterIterations),
+                   numGlobalSum=int(ps.stats.numGlobalSum), evecs_norm2=float(np.sum(V ** 2)), u_norm2=float(np.sum(U ** 2)),
+                   aNorm=float(ps.aNorm))
+        json.dump(res, open(f"{out_path}.{rank}", "w"))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     else:
         raise ValueError(case)
     res = dict(rank=rank, ret=r.ret, evals=r.evals.tolist(), resNorms=r.resNorms.tolist(), its=r.stats["numOuterIterations"],
