@@ -209,3 +209,49 @@ def test_reference_driver_case_pins_the_checker(built, name):
         # eps = 1e-12 on a matrix with cond 3e6 converges at the rounding-noise floor (residuals
         # 1e-12 |A|), where the summation order of the inner products decides the last steps
         assert abs(h.stats["numOuterIterations"] - r.stats["numOuterIterations"]) <= 0.15 * r.stats["numOuterIterations"]
+
+
+@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+def test_orthogonality_constraints_against_live_reference(built):
+    """numOrthoConst > 0 (reference primme_eigs.h: the first numOrthoConst columns of evecs are
+    constraints): same path, same counts, results orthogonal to the constraints."""
+    import ctypes as C
+    dims = (20, 21)
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    rng = np.random.default_rng(3)
+    Q = np.linalg.qr(rng.standard_normal((n, 2)))[0]
+    out = {}
+    for be in ("hostcheck", "reference"):
+        lib = F.load_hostcheck() if be == "hostcheck" else F.load_reference()
+        p = F.PrimmeParams()
+        lib.primme_initialize(C.byref(p))
+        p.n, p.numEvals, p.eps, p.aNorm, p.numOrthoConst, p.printLevel, p.outputFile = n, 4, 1e-10, 8.0, 2, 0, None
+        keep = []
+        if be == "reference":
+            def mv(x, ldx, y, ldy, bs, pp, ierr):
+                nb = bs[0]
+                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(nb, ldx[0]))
+                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(nb, ldy[0]))
+                Y[:, :n] = problems.csr_matvec_numpy(rp, ci, va, X[:, :n].T).T
+                ierr[0] = 0
+            cb = F.BLOCK_OP(mv); keep.append(cb)
+            p.matrixMatvec = C.cast(cb, C.c_void_p)
+            solver = lib.dprimme
+        else:
+            ctx = C.c_void_p(); lib.hipk_ctx_create(C.byref(ctx), None)
+            A = C.c_void_p()
+            lib.hipk_csr_create(ctx, F.HIPK_F64, n, n, 0, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                va.ctypes.data_as(C.c_void_p), C.byref(A))
+            oph = C.c_void_p(); lib.primme_amd_operator_create(C.byref(oph), A, None)
+            p.matrix = oph
+            p.matrixMatvec = C.cast(lib.primme_amd_matvec, C.c_void_p)
+            solver = lib.hip_dprimme
+        lib.primme_set_method(F.METHODS["GD_plusK"], C.byref(p))
+        ev, rn, vecs = np.zeros(4), np.zeros(4), np.zeros((6, n))
+        vecs[:2] = Q.T
+        ret = solver(ev.ctypes.data_as(C.c_void_p), vecs.ctypes.data_as(C.c_void_p), rn.ctypes.data_as(C.c_void_p), C.byref(p))
+        assert ret == 0 and p.initSize == 4
+        assert np.linalg.norm(vecs[2:6] @ Q) <= 1e-9 and np.allclose(vecs[:2], Q.T, atol=1e-13)
+        out[be] = (ev.copy(), p.stats.numOuterIterations, p.stats.numMatvecs, p.stats.numRestarts)
+    assert np.max(np.abs(out["hostcheck"][0] - out["reference"][0])) <= 1e-10 * 8.0
+    assert out["hostcheck"][1:] == out["reference"][1:]
