@@ -218,8 +218,14 @@ def test_orthogonality_constraints_against_live_reference(built):
     import ctypes as C
     dims = (20, 21)
     rp, ci, va, n = problems.laplacian_csr(dims)
-    rng = np.random.default_rng(3)
-    Q = np.linalg.qr(rng.standard_normal((n, 2)))[0]
+    # constraints = the two lowest eigenvectors (analytic): the solver must return pairs 3..6
+    def evec(i, j):
+        x = np.sin(np.pi * i * np.arange(1, dims[0] + 1) / (dims[0] + 1))
+        y = np.sin(np.pi * j * np.arange(1, dims[1] + 1) / (dims[1] + 1))
+        v = np.outer(y, x).ravel()
+        return v / np.linalg.norm(v)
+    Q = np.stack([evec(1, 1), evec(1, 2)], axis=1)
+    exact = problems.laplacian_eigenvalues(dims, 6)
     out = {}
     for be in ("hostcheck", "reference"):
         lib = F.load_hostcheck() if be == "hostcheck" else F.load_reference()
@@ -251,6 +257,7 @@ def test_orthogonality_constraints_against_live_reference(built):
         vecs[:2] = Q.T
         ret = solver(ev.ctypes.data_as(C.c_void_p), vecs.ctypes.data_as(C.c_void_p), rn.ctypes.data_as(C.c_void_p), C.byref(p))
         assert ret == 0 and p.initSize == 4
+        assert np.max(np.abs(ev - exact[2:6])) <= 1e-10 * 8.0
         assert np.linalg.norm(vecs[2:6] @ Q) <= 1e-9 and np.allclose(vecs[:2], Q.T, atol=1e-13)
         out[be] = (ev.copy(), p.stats.numOuterIterations, p.stats.numMatvecs, p.stats.numRestarts)
     assert np.max(np.abs(out["hostcheck"][0] - out["reference"][0])) <= 1e-10 * 8.0
