@@ -234,7 +234,21 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
       /* JDQMR: inner-outer iteration (reference correction.c:385-467) */
       rc = pa_correction_jdqmr(s, basisSize, blockSize, blockNorms, iev, shifts, numLocked, numConvergedStored, touch);
    } else if (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX) {
-      rc = PRIMME_FUNCTION_UNAVAILABLE; /* exact Olsen projector: not on this path */
+      /* exact Olsen: x <- K^-1 r - (x'K^-1 r / x'K^-1 x) K^-1 x  (reference correction.c:718-777);
+       * K^-1 [x r] live in the scratch panel */
+      if (2 * blockSize > s->nT) rc = PRIMME_UNEXPECTED_FAILURE;
+      char *Kx = s->T, *Kr = TCOL(s, blockSize);
+      if (!rc) rc = pa_precond(s, x, s->ld, Kx, s->ld, blockSize);
+      if (!rc) rc = pa_precond(s, r, s->ld, Kr, s->ld, blockSize);
+      if (!rc) rc = hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kx, s->ld, blockSize, s->d_red);
+      if (!rc) rc = hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kr, s->ld, blockSize, s->d_red + blockSize);
+      if (!rc) rc = pa_reduce(s, s->d_red, 2 * blockSize, 0, 0);
+      if (!rc) {
+         for (int b = 0; b < blockSize; b++)
+            olsen[b] = (fabs(s->h_red[b]) > 0.0) ? -s->h_red[blockSize + b] / s->h_red[b] : 0.0;
+         rc = hipk_copy_cols(s->ctx, s->dt, s->m, Kr, s->ld, x, s->ld, blockSize);
+         if (!rc) rc = hipk_axpy_cols(s->ctx, s->dt, s->m, olsen, Kx, s->ld, x, s->ld, blockSize);
+      }
    } else {
       if (p->correctionParams.projectors.RightX &&
             ((p->correctionParams.precondition && p->applyPreconditioner) ||

@@ -125,7 +125,7 @@ def test_float_path(built):
 def test_unsupported_configurations_fail_loudly(built):
     rp, ci, va, n = problems.laplacian_csr((20, 21))
     op = Operator(n, csr=(rp, ci, va))
-    r = eigsh(op, backend="hip", numEvals=2, method="JD_Olsen_plusK", aNorm=8.0, precond="jacobi", v0=problems.start_vector(n))
+    r = eigsh(op, backend="hip", numEvals=2, method="JDQR", aNorm=8.0, precond="jacobi", v0=problems.start_vector(n))
     assert r.ret == -44      # PRIMME_FUNCTION_UNAVAILABLE, no silent CPU fallback
     # host (non-device) evecs pointer is rejected like the reference's GPU flavour does (-31)
     import ctypes as C

@@ -122,7 +122,7 @@ def test_edge_cases(built):
     r = eigsh(op, backend="hostcheck", numEvals=5, eps=1e-12, aNorm=8.0, v0=problems.start_vector(n), maxMatvecs=40)
     assert r.ret == -3 and r.stats["numMatvecs"] <= 41
     # configurations that are not on the device path fail loudly with -44
-    r = eigsh(op, backend="hostcheck", numEvals=2, method="JD_Olsen_plusK", aNorm=8.0, precond="jacobi", v0=problems.start_vector(n))
+    r = eigsh(op, backend="hostcheck", numEvals=2, method="JDQR", aNorm=8.0, precond="jacobi", v0=problems.start_vector(n))
     assert r.ret == -44
 
 
@@ -262,3 +262,20 @@ def test_orthogonality_constraints_against_live_reference(built):
         out[be] = (ev.copy(), p.stats.numOuterIterations, p.stats.numMatvecs, p.stats.numRestarts)
     assert np.max(np.abs(out["hostcheck"][0] - out["reference"][0])) <= 1e-10 * 8.0
     assert out["hostcheck"][1:] == out["reference"][1:]
+
+
+@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+def test_exact_olsen_against_live_reference(built):
+    """JD_Olsen_plusK (RightX + SkewX with maxInnerIterations = 0): the exact Olsen correction
+    K^-1 r - (x'K^-1 r / x'K^-1 x) K^-1 x (reference correction.c:718-777) with a non-trivial
+    diagonal preconditioner (LUNDA.mtx, K = diag(A) - 3e8)."""
+    rp, ci, va, n = RD.lunda()
+    op = Operator(n, csr=(rp, ci, va))
+    kw = dict(numEvals=4, eps=1e-10, target="largest", method="JD_Olsen_plusK", precond=("jacobi", 3e8))
+    a = eigsh(op, backend="reference", **kw)
+    b = eigsh(op, backend="hostcheck", **kw)
+    assert a.ret == 0 and b.ret == 0
+    assert np.max(np.abs(a.evals - b.evals)) <= 1e-10 * a.params["aNorm"]
+    assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= 0.05 * a.stats["numOuterIterations"] + 2
+    assert a.stats["numPreconds"] > a.stats["numMatvecs"]      # two preconditioner applications per step
+    assert abs(a.stats["numPreconds"] - b.stats["numPreconds"]) <= 0.05 * a.stats["numPreconds"] + 4
