@@ -270,7 +270,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
           * the operator and project, so that the whole outer iteration costs ONE host
           * synchronisation.  Needs in-stream reductions (single rank or the RCCL communicator). */
          const int speculate2 = speculate && !parallel_host && !s->phase_timing && dstc == VCOL(s, basisSize) &&
-                                basisSize + 1 <= p->maxBasisSize && !getenv("PRIMME_AMD_NO_SPEC2");
+                                basisSize + 1 <= p->maxBasisSize && s->spec2_enabled;
          if (speculate) {
             if ((rc = pa_reduce(s, s->d_fov, nov + 1, 1, parallel_host ? 0 : 1))) goto out;
             hipk_seg segs[2] = {{s->V, s->ld, basisSize}, {s->evecs, s->ldevecs, nLk}};

@@ -400,8 +400,8 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
 #define LAUNCH_ROWS(NCV) hipLaunchKernelGGL((csr_rows_block_kernel<T, NCV>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, \
                A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, \
                ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo, (const T *)A->xhi)
-      const char *env = getenv("HIPK_SPMM_NC");   /* development knob */
-      const int force = env ? atoi(env) : 0;
+      static int force = -1;                     /* HIPK_SPMM_NC: measurement knob, read once */
+      if (force < 0) { const char *env = getenv("HIPK_SPMM_NC"); force = env ? atoi(env) : 0; }
       if (ncols == 1 && force == 0)
          hipLaunchKernelGGL(csr_stream_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, stream,
                A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
