@@ -162,6 +162,9 @@ class Session:
 
                 def pc(x, ldx, y, ldy, bs, pp, ierr):
                     nb, lx, ly = bs[0], ldx[0], ldy[0]
+                    if nb <= 0 or not x or not y:
+                        ierr[0] = 0
+                        return
                     X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
                     Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
                     sh = pp[0].ShiftsForPreconditioner

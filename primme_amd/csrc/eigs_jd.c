@@ -103,8 +103,103 @@ static void perm_set_value_on_pos(int *p, int val, int pos, int n) {
 
 typedef struct {
    char *LQ, *LX; int64_t ldLQ, ldLX; int nLQ, nLX;   /* left projectors  (B = I: BQ = Q, BX = X) */
-   char *RQ, *RX; int64_t ldRQ, ldRX; int nRQ, nRX;   /* right projectors (orthogonal form)       */
+   char *RQ, *RX; int64_t ldRQ, ldRX; int nRQ, nRX;   /* right projectors: I - RQ M^-1 Q', I - RX_i x_i'/xKx_i */
+   int skewQ, skewX;       /* RQ = K^-1 Q with M = Q'K^-1 Q factorised; RX = K^-1 x with xKx = x'K^-1 x */
+   char *x;                /* the Ritz vectors (dotted against in the X projector) */
+   double xKx[64];
 } jd_proj;
+
+/* ---- M = evecs' evecsHat: dense LU with partial pivoting on the host (the reference keeps a
+ * Bunch-Kaufman factorisation, factorize.c:183-262; same solution up to rounding) ---- */
+static int lu_factor(const double *A, int ldA, int n, double *LU, int *piv) {
+   for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) LU[i + (size_t)j * n] = A[i + (size_t)j * ldA];
+   for (int k = 0; k < n; k++) {
+      int pi = k;
+      for (int i = k + 1; i < n; i++) if (fabs(LU[i + (size_t)k * n]) > fabs(LU[pi + (size_t)k * n])) pi = i;
+      piv[k] = pi;
+      if (LU[pi + (size_t)k * n] == 0.0) return PRIMME_LAPACK_FAILURE;
+      if (pi != k) for (int j = 0; j < n; j++) { double t = LU[k + (size_t)j * n]; LU[k + (size_t)j * n] = LU[pi + (size_t)j * n]; LU[pi + (size_t)j * n] = t; }
+      for (int i = k + 1; i < n; i++) {
+         const double l = LU[i + (size_t)k * n] /= LU[k + (size_t)k * n];
+         for (int j = k + 1; j < n; j++) LU[i + (size_t)j * n] -= l * LU[k + (size_t)j * n];
+      }
+   }
+   return 0;
+}
+static void lu_solve(const double *LU, const int *piv, int n, double *b) {
+   for (int k = 0; k < n; k++) { const int pi = piv[k]; if (pi != k) { double t = b[k]; b[k] = b[pi]; b[pi] = t; } }
+   for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) b[i] -= LU[i + (size_t)j * n] * b[j];
+   for (int i = n - 1; i >= 0; i--) { for (int j = i + 1; j < n; j++) b[i] -= LU[i + (size_t)j * n] * b[j]; b[i] /= LU[i + (size_t)i * n]; }
+}
+
+/* evecsHat(:, c0:c0+count) = K^-1 evecs(:, c0:c0+count); M and its factors extended accordingly
+ * (reference restart.c:1471-1531, init.c:152-169, factorize.c:183-262).  Column indices include
+ * the orthogonality constraints. */
+static int extend_evecs_hat(pa_solver *s, int c0, int count) {
+   if (count <= 0) return 0;
+   char *hat = s->evecsHat + (size_t)c0 * s->ldevecs * s->es;
+   CHK(pa_precond(s, ECOL(s, c0), s->ldevecs, hat, s->ldevecs, count));
+   const int nM = c0 + count;
+   for (int j0 = 0; j0 < count; j0 += 8) {
+      const int nj = PA_MIN(8, count - j0);
+      hipk_seg sq = {s->evecs, s->ldevecs, nM};
+      CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, hat + (size_t)j0 * s->ldevecs * s->es, s->ldevecs, nj, s->d_red, nM));
+      CHK(pa_reduce(s, s->d_red, nM * nj, 0, 0));
+      for (int j = 0; j < nj; j++)
+         for (int i = 0; i < nM; i++) {
+            s->Mq[i + (size_t)(c0 + j0 + j) * s->ldM] = s->h_red[i + (size_t)j * nM];
+            if (i < c0) s->Mq[(c0 + j0 + j) + (size_t)i * s->ldM] = s->h_red[i + (size_t)j * nM];   /* K symmetric */
+         }
+   }
+   return lu_factor(s->Mq, s->ldM, nM, s->Mlu, s->Mpiv);
+}
+
+int pa_evecs_hat_init(pa_solver *s) {
+   if (!s->evecsHat) return 0;
+   s->p->ShiftsForPreconditioner = NULL;
+   return extend_evecs_hat(s, 0, s->p->numOrthoConst);
+}
+
+/* after a restart: K^-1 of the vectors that converged since the last call */
+int pa_evecs_hat_update(pa_solver *s, int *numConvergedStored, int numConverged) {
+   primme_params *p = s->p;
+   if (!s->evecsHat) return 0;
+   if (!p->locking) *numConvergedStored = 0;
+   const int stored = *numConvergedStored, recent = numConverged - stored;
+   double *shifts = NULL;
+   int own = 0;
+   if (numConverged <= p->numTargetShifts) shifts = &p->targetShifts[stored];
+   else if (p->numTargetShifts > 0) {
+      shifts = (double *)malloc(sizeof(double) * (size_t)(numConverged > 0 ? numConverged : 1));
+      if (!shifts) return PRIMME_MALLOC_FAILURE;
+      own = 1;
+      for (int i = 0; i < recent; i++) shifts[i] = p->targetShifts[PA_MIN(i + stored, p->numTargetShifts - 1)];
+   }
+   p->ShiftsForPreconditioner = shifts;
+   int rc = extend_evecs_hat(s, p->numOrthoConst + stored, recent);
+   p->ShiftsForPreconditioner = NULL;
+   if (own) free(shifts);
+   if (rc) return rc;
+   *numConvergedStored = numConverged;
+   return 0;
+}
+
+/* v <- (I - Qhat M^-1 Q') v: overlaps on the device, the small solve on the host */
+static int skew_project_Q(pa_solver *s, const jd_proj *P, char *v, int64_t ldv, int nb) {
+   const int nQ = P->nRQ;
+   if (nQ <= 0 || nb <= 0) return 0;
+   double t0 = pa_wtime();
+   hipk_seg sq = {s->evecs, s->ldevecs, nQ}, sh = {P->RQ, P->ldRQ, nQ};
+   CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, v, ldv, nb, s->d_red, nQ));
+   CHK(pa_reduce(s, s->d_red, nQ * nb, 0, 0));
+   if (nQ > 1) for (int c = 0; c < nb; c++) lu_solve(s->Mlu, s->Mpiv, nQ, s->h_red + (size_t)c * nQ);
+   else for (int c = 0; c < nb; c++) s->h_red[c] /= s->Mq[0];
+   CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, sizeof(double) * (size_t)nQ * nb));
+   CHK(hipk_panel_project(s->ctx, s->dt, s->m, &sh, 1, s->d_red, nQ, v, ldv, nb, NULL));
+   s->p->stats.numOrthoInnerProds += (double)nQ * nb;
+   s->p->stats.timeOrtho += pa_wtime() - t0;
+   return 0;
+}
 
 /* result = (I - Q Q')(I - x x')... (A - shift) v, and vdot[c] = v_c' result_c.  The axpy of every
  * step is fused with the dot product that follows it (hipk_axpy_dot): same arithmetic as the
@@ -144,8 +239,23 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
 static int apply_projected_preconditioner(pa_solver *s, char *v, int64_t ldv, const jd_proj *P, int nb,
       char *result, int64_t ldres) {
    CHK(pa_precond(s, v, ldv, result, ldres, nb));
-   CHK(project_panel(s, s->evecs, s->ldevecs, P->RQ, P->ldRQ, P->nRQ, result, ldres, nb));
-   if (P->nRX > 0) CHK(project_each(s, P->RX, P->ldRX, P->RX, P->ldRX, result, ldres, nb));
+   if (P->skewQ) CHK(skew_project_Q(s, P, result, ldres, nb));
+   else CHK(project_panel(s, s->evecs, s->ldevecs, P->RQ, P->ldRQ, P->nRQ, result, ldres, nb));
+   if (P->nRX > 0) {
+      if (P->skewX) {
+         /* result_i -= K^-1 x_i (x_i' result_i) / (x_i' K^-1 x_i)  (reference inner_solve.c:737-741) */
+         double t0 = pa_wtime();
+         CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->x, s->ld, result, ldres, nb, s->d_red));
+         CHK(pa_reduce(s, s->d_red, nb, 0, 0));
+         double alpha[64];
+         for (int i = 0; i < nb; i++) alpha[i] = -s->h_red[i] / P->xKx[i];
+         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, alpha, P->RX, P->ldRX, result, ldres, nb));
+         s->p->stats.numOrthoInnerProds += nb;
+         s->p->stats.timeOrtho += pa_wtime() - t0;
+      } else {
+         CHK(project_each(s, P->RX, P->ldRX, P->RX, P->ldRX, result, ldres, nb));
+      }
+   }
    return 0;
 }
 
@@ -237,6 +347,10 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          CHK(permute_panel(s, delta, ld, blockSize, p0));                                          \
          CHK(permute_panel(s, r, ld, blockSize, p0));                                              \
          CHK(permute_panel(s, x, ld, blockSize, p0));    /* LX / RX alias x */                     \
+         if (P->skewX && P->nRX) {                                                                 \
+            CHK(permute_panel(s, P->RX, P->ldRX, blockSize, p0));                                  \
+            pa_permute_cols(P->xKx, 1, blockSize, 1, p0);                                          \
+         }                                                                                         \
          CHK(permute_panel(s, sol, ld, blockSize, p0));                                            \
          blockSize -= conv;                                                                        \
          if (P->nLX) P->nLX -= conv;                                                               \
@@ -339,8 +453,6 @@ int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double
       double *shifts, int numLocked, int numConvergedStored, int *touch) {
    primme_params *p = s->p;
    const JD_projectors *jp = &p->correctionParams.projectors;
-   if (p->correctionParams.precondition && ((jp->RightQ && jp->SkewQ) || (jp->RightX && jp->SkewX)))
-      return PRIMME_FUNCTION_UNAVAILABLE;   /* K^-1-weighted skew projectors are not on this path */
    char *x = VCOL(s, basisSize), *r = WCOL(s, basisSize), *sol = PCOL(s, s->Jw, s->ld, 4 * blockSize);
    const int sizeEvecs = p->numOrthoConst + (p->locking ? numLocked : numConvergedStored);
    jd_proj P;
@@ -354,8 +466,28 @@ int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double
          } else { P.LX = x; P.ldLX = s->ld; P.nLX = blockSize; }
       }
    } else if (jp->LeftX) { P.LX = x; P.ldLX = s->ld; P.nLX = blockSize; }
-   if (jp->RightQ) { P.RQ = s->evecs; P.ldRQ = s->ldevecs; P.nRQ = sizeEvecs; }
-   if (jp->RightX) { P.RX = x; P.ldRX = s->ld; P.nRX = blockSize; }
+   P.x = x;
+   p->ShiftsForPreconditioner = shifts;
+   if (jp->RightQ) {
+      P.nRQ = sizeEvecs;
+      if (p->correctionParams.precondition && jp->SkewQ) {
+         if (!s->evecsHat) return PRIMME_UNEXPECTED_FAILURE;
+         P.RQ = s->evecsHat; P.ldRQ = s->ldevecs; P.skewQ = 1;
+      } else { P.RQ = s->evecs; P.ldRQ = s->ldevecs; }
+   }
+   if (jp->RightX) {
+      P.nRX = blockSize;
+      if (p->correctionParams.precondition && jp->SkewX) {
+         /* K^-1 x and x'K^-1 x (reference correction.c:969-977) */
+         char *Kx = PCOL(s, s->Jw, s->ld, 5 * p->maxBlockSize);
+         CHK(pa_precond(s, x, s->ld, Kx, s->ld, blockSize));
+         CHK(pair_dots_host(s, x, s->ld, Kx, s->ld, blockSize, P.xKx));
+         P.RX = Kx; P.ldRX = s->ld; P.skewX = 1;
+      } else {
+         P.RX = x; P.ldRX = s->ld;
+         for (int i = 0; i < blockSize; i++) P.xKx[i] = 1.0;
+      }
+   }
 
    double evalb[64], rn[64];
    if (blockSize > 64) return PRIMME_UNEXPECTED_FAILURE;

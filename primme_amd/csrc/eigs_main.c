@@ -155,6 +155,8 @@ int pa_dyn_observe(pa_cost_model *c, primme_params *p, double now, int recentCon
 int pa_dyn_leave_gd(pa_solver *s, pa_cost_model *c);
 int pa_dyn_leave_jdqmr(pa_solver *s, pa_cost_model *c);
 void pa_dyn_recommend(const pa_cost_model *c, primme_params *p);
+int pa_evecs_hat_init(pa_solver *s);
+int pa_evecs_hat_update(pa_solver *s, int *numConvergedStored, int numConverged);
 int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double *blockNorms, const int *iev,
       double *shifts, int numLocked, int numConvergedStored, int *touch);
 
@@ -358,6 +360,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
    if (p->numEvals == 0) { p->initSize = 0; *ret = 0; goto clean; }
 
    CHK(init_basis(s, &basisSize, &nextGuess, &numGuesses));
+   CHK(pa_evecs_hat_init(s));
    p->initSize = 0;
 
    if (p->dynamicMethodSwitch > 0) {
@@ -591,6 +594,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                &numConverged, &numLocked, s->lockedFlags, nprevhVecs, numGuesses, &basisSize,
                &restartsSinceReset));
          restartsSinceReset++;
+         CHK(pa_evecs_hat_update(s, &numConvergedStored, numConverged));
 
          if (numGuesses > 0) {
             /* feed remaining initial guesses into the restarted basis */
@@ -684,11 +688,13 @@ static void free_solver(pa_solver *s) {
    if (s->ctx) {
       hipk_sync(s->ctx);
       hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T); hipk_free(s->ctx, s->Jw);
+      hipk_free(s->ctx, s->evecsHat);
       hipk_free(s->ctx, s->d_red); hipk_free(s->ctx, s->d_coef); hipk_free(s->ctx, s->d_theta);
       hipk_host_free(s->ctx, s->h_red); hipk_host_free(s->ctx, s->h_coef); hipk_host_free(s->ctx, s->h_theta);
       hipk_ctx_destroy(s->ctx);
    }
    free(s->H); free(s->hVecs); free(s->prevhVecs); free(s->hVals); free(s->prevRitzVals);
+   free(s->Mq); free(s->Mlu); free(s->Mpiv);
    free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol);
    free(s->flags); free(s->map); free(s->iev); free(s->perm); free(s->lockedFlags);
    free(s);
@@ -767,10 +773,22 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->nT = K + 2 * b + 2;
    s->red_cap = PA_MAX((s->maxRank + 16) * (b + 8) + 64, K * K + 64);
    const size_t colBytes = (size_t)(s->ld > 0 ? s->ld : 1) * s->es;
+   /* K^-1-weighted right projector (reference main_iter.c:324-333) */
+   const int maxEvecs = p->numOrthoConst + nev;
+   const int need_hat = p->correctionParams.precondition && p->correctionParams.maxInnerIterations != 0 &&
+                        p->correctionParams.projectors.RightQ && p->correctionParams.projectors.SkewQ;
+   if (need_hat) {
+      s->ldM = maxEvecs;
+      s->Mq = (double *)calloc((size_t)maxEvecs * maxEvecs + 1, 8);
+      s->Mlu = (double *)calloc((size_t)maxEvecs * maxEvecs + 1, 8);
+      s->Mpiv = (int *)calloc((size_t)maxEvecs + 1, sizeof(int));
+      if (!s->Mq || !s->Mlu || !s->Mpiv) { free_solver(s); p->queue = user_queue; return PRIMME_MALLOC_FAILURE; }
+   }
    rc = hipk_malloc(s->ctx, colBytes * K, (void **)&s->V) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W) ||
         hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
-        ((p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) && hipk_malloc(s->ctx, colBytes * 5 * b, (void **)&s->Jw)) ||
+        ((p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) && hipk_malloc(s->ctx, colBytes * 6 * b, (void **)&s->Jw)) ||
         hipk_malloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->d_red) ||
+        (need_hat && hipk_malloc(s->ctx, (size_t)(s->ldevecs > 0 ? s->ldevecs : 1) * s->es * maxEvecs, (void **)&s->evecsHat)) ||
         hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
         hipk_host_alloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->h_red) ||
         hipk_host_alloc(s->ctx, (size_t)K * K * 8, (void **)&s->h_coef) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta);

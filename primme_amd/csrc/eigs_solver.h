@@ -35,6 +35,11 @@ typedef struct pa_solver {
    /* HBM-resident panels */
    char *V, *W;            /* m x K */
    char *T;                /* scratch, m x nT */
+   /* K^-1-weighted (skew) right projector of the correction equation: evecsHat = K^-1 evecs for
+    * the stored converged / constraint vectors, M = evecs' evecsHat and its LU factors (host) */
+   char *evecsHat;
+   double *Mq, *Mlu;
+   int *Mpiv, ldM;
    char *Jw;               /* JDQMR work panels g, d, delta, w, sol: m x 5b (only with inner iterations) */
    int nT;
    char *evecs;            /* caller's device array: constraints | locked | guesses */

@@ -125,7 +125,7 @@ def test_float_path(built):
 def test_unsupported_configurations_fail_loudly(built):
     rp, ci, va, n = problems.laplacian_csr((20, 21))
     op = Operator(n, csr=(rp, ci, va))
-    r = eigsh(op, backend="hip", numEvals=2, method="JDQR", aNorm=8.0, precond="jacobi", v0=problems.start_vector(n))
+    r = eigsh(op, backend="hip", numEvals=2, maxBasisSize=300, aNorm=8.0, v0=problems.start_vector(n))
     assert r.ret == -44      # PRIMME_FUNCTION_UNAVAILABLE, no silent CPU fallback
     # host (non-device) evecs pointer is rejected like the reference's GPU flavour does (-31)
     import ctypes as C
@@ -204,3 +204,18 @@ def test_hip_tiled_lunda_block_jdqmr(built):
     assert r.ret == 0
     assert np.max(np.abs(np.sort(r.evals) - np.sort(want))) <= 1e-10 * np.abs(w).max()
     assert np.all(r.resNorms <= 1e-10 * np.abs(w).max() * (1 + 1e-6))
+
+
+@pytest.mark.parametrize("kw", [dict(numEvals=6, method="JDQR"), dict(numEvals=6, method="JDQR", locking=0),
+                                dict(numEvals=4, method="JD_Olsen_plusK")])
+def test_hip_skew_projectors_and_exact_olsen(built, kw):
+    """K^-1-weighted projectors (JDQR) and the exact Olsen correction on the device against the oracle."""
+    rp, ci, va, n = RD.lunda()
+    op = Operator(n, csr=(rp, ci, va))
+    args = dict(eps=1e-10, target="largest", precond=("jacobi", 3e8), **kw)
+    r = eigsh(op, backend="hip", **args)
+    h = eigsh(op, backend="hostcheck", **args)
+    assert r.ret == 0 and h.ret == 0
+    assert np.max(np.abs(np.sort(r.evals) - np.sort(h.evals))) <= 1e-10 * r.params["aNorm"]
+    assert np.all(r.resNorms <= 1e-10 * r.params["aNorm"] * (1 + 1e-6))
+    assert abs(r.stats["numOuterIterations"] - h.stats["numOuterIterations"]) <= max(3, 0.1 * h.stats["numOuterIterations"])

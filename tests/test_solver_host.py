@@ -122,7 +122,7 @@ def test_edge_cases(built):
     r = eigsh(op, backend="hostcheck", numEvals=5, eps=1e-12, aNorm=8.0, v0=problems.start_vector(n), maxMatvecs=40)
     assert r.ret == -3 and r.stats["numMatvecs"] <= 41
     # configurations that are not on the device path fail loudly with -44
-    r = eigsh(op, backend="hostcheck", numEvals=2, method="JDQR", aNorm=8.0, precond="jacobi", v0=problems.start_vector(n))
+    r = eigsh(op, backend="hostcheck", numEvals=2, maxBasisSize=300, aNorm=8.0, v0=problems.start_vector(n))
     assert r.ret == -44
 
 
@@ -279,3 +279,39 @@ def test_exact_olsen_against_live_reference(built):
     assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= 0.05 * a.stats["numOuterIterations"] + 2
     assert a.stats["numPreconds"] > a.stats["numMatvecs"]      # two preconditioner applications per step
     assert abs(a.stats["numPreconds"] - b.stats["numPreconds"]) <= 0.05 * a.stats["numPreconds"] + 4
+
+
+def _lunda_dense():
+    rp, ci, va, n = RD.lunda()
+    A = np.zeros((n, n))
+    A[np.repeat(np.arange(n), np.diff(rp)), ci] = va
+    return rp, ci, va, n, np.linalg.eigvalsh(A)
+
+
+@pytest.mark.parametrize("kw", [dict(numEvals=6, method="JDQR"), dict(numEvals=6, method="JDQR", locking=0),
+                                dict(numEvals=6, method="JDQR", maxBlockSize=2)])
+def test_skew_projectors(built, kw):
+    """K^-1-weighted right projectors of the correction equation (reference inner_solve.c:714-808,
+    correction.c:942-983, restart.c:1471-1531): JDQR with a diagonal preconditioner on LUNDA.mtx."""
+    rp, ci, va, n, w = _lunda_dense()
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", eps=1e-10, target="largest", precond=("jacobi", 3e8), **kw)
+    k = kw["numEvals"]
+    assert r.ret == 0 and r.initSize == k
+    assert np.max(np.abs(np.sort(r.evals) - np.sort(w)[-k:])) <= 1e-10 * r.params["aNorm"]
+    assert np.all(r.resNorms <= 1e-10 * r.params["aNorm"] * (1 + 1e-6))
+    assert r.stats["numPreconds"] > 0
+
+
+@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+def test_skew_projector_single_pair_against_live_reference(built):
+    """One wanted pair keeps M = q'K^-1 q scalar; for more stored vectors the reference as built here
+    crashes (it hands its factorisation a leading dimension of 0: main_iter.c:417, :1089 ->
+    factorize.c:228-236), so only this case can be compared count for count."""
+    rp, ci, va, n = RD.lunda()
+    op = Operator(n, csr=(rp, ci, va))
+    kw = dict(numEvals=1, eps=1e-10, target="largest", method="JDQR", precond=("jacobi", 3e8))
+    a = eigsh(op, backend="reference", **kw)
+    b = eigsh(op, backend="hostcheck", **kw)
+    assert a.ret == 0 and b.ret == 0 and abs(a.evals[0] - b.evals[0]) <= 1e-10 * a.params["aNorm"]
+    for key in ("numOuterIterations", "numMatvecs", "numPreconds", "numRestarts"):
+        assert a.stats[key] == b.stats[key], key
