@@ -109,7 +109,7 @@ class Session:
               maxBlockSize=0, maxBasisSize=0, minRestartSize=0, maxPrevRetain=None, locking=None,
               maxMatvecs=0, maxOuterIterations=0, targetShifts=None, precond=None, printLevel=0,
               initBasisMode=None, global_sum=None, numProcs=1, procID=0, orth=None, iseed=None,
-              profile=False, return_evecs=True, monitor=None, user_matvec=None):
+              profile=False, return_evecs=True, monitor=None, user_matvec=None, projection=None):
         lib, op, dtype, backend = self.lib, self.op, self.dtype, self.backend
         keep = []
         p = F.PrimmeParams()
@@ -132,6 +132,8 @@ class Session:
         if maxMatvecs: p.maxMatvecs = maxMatvecs
         if maxOuterIterations: p.maxOuterIterations = maxOuterIterations
         if orth is not None: p.orth = orth
+        if projection is not None:
+            p.projectionParams.projection = {"RR": 1, "harmonic": 2, "refined": 3}[projection]
         if iseed is not None:
             for i in range(4): p.iseed[i] = iseed[i]
         if targetShifts is not None:

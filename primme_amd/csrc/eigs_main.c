@@ -155,6 +155,8 @@ int pa_dyn_observe(pa_cost_model *c, primme_params *p, double now, int recentCon
 int pa_dyn_leave_gd(pa_solver *s, pa_cost_model *c);
 int pa_dyn_leave_jdqmr(pa_solver *s, pa_cost_model *c);
 void pa_dyn_recommend(const pa_cost_model *c, primme_params *p);
+int pa_update_Q(pa_solver *s, double tau, int col0, int bs, int *nQ);
+int pa_update_QtV(pa_solver *s, int col0, int bs);
 int pa_evecs_hat_init(pa_solver *s);
 int pa_evecs_hat_update(pa_solver *s, int *numConvergedStored, int numConverged);
 int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double *blockNorms, const int *iev,
@@ -380,7 +382,13 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
       reset = 0;
       for (i = 0; i < p->maxBasisSize; i++) flags[i] = UNCONV;
       s->targetShiftIndex = 0;
+      if (s->Q) {
+         int nQ = 0;
+         CHK(pa_update_Q(s, p->targetShifts[s->targetShiftIndex], 0, basisSize, &nQ));
+         if (nQ != basisSize) return PRIMME_UNEXPECTED_FAILURE;       /* "Not supported deficient QR" */
+      }
       CHK(pa_update_projection(s, 0, basisSize));
+      CHK(pa_update_QtV(s, 0, basisSize));
       CHK(pa_solve_H(s, basisSize, numLocked, numConverged));
       maxRecentlyConverged = availableBlockSize = blockSize = 0;
       smallestResNorm = HUGE_VAL;
@@ -395,8 +403,14 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
          /* ------------------ main block Davidson loop ------------------ */
          while (basisSize < p->maxBasisSize && OUTER_LIMITS_OK()) {
             p->stats.numOuterIterations++;
-            availableBlockSize = p->maxBlockSize;
-            maxRecentlyConverged = PA_MAX(0, p->numEvals - numConverged);
+            if (p->numTargetShifts > numConverged + 1 && s->Q) {
+               /* a QR per target shift: one pair at a time (reference main_iter.c:527-530) */
+               availableBlockSize = 1;
+               maxRecentlyConverged = numConverged - numLocked + 1;
+            } else {
+               availableBlockSize = p->maxBlockSize;
+               maxRecentlyConverged = PA_MAX(0, p->numEvals - numConverged);
+            }
             availableBlockSize = PA_MIN(availableBlockSize, p->maxBasisSize - basisSize);
             availableBlockSize = PA_MIN(availableBlockSize, maxRecentlyConverged + 1);
 
@@ -430,8 +444,12 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
             if (numConverged >= p->numEvals ||
                   (p->locking && numConverged > numLocked && p->target != primme_smallest &&
-                        p->target != primme_largest) ||
+                        p->target != primme_largest &&
+                        (!s->Q || p->target == primme_closest_geq || p->target == primme_closest_leq)) ||
                   s->targetShiftIndex < 0 || (blockSize == 0 && recentlyConverged > 0) ||
+                  (s->Q && fabs(p->targetShifts[s->targetShiftIndex] -
+                                p->targetShifts[PA_MIN(p->numTargetShifts - 1, numConverged)]) >=
+                                PA_MAX(p->aNorm, p->stats.estimateLargestSVal)) ||
                   (numConverged >= nextGuess - p->numOrthoConst && numGuesses > 0))
                break;
 
@@ -513,6 +531,12 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                CHK(pa_update_projection(s, basisSize, blockSize));
             }
             s->spec2_valid = 0;
+            if (s->Q) {
+               int nQ = basisSize;
+               CHK(pa_update_Q(s, p->targetShifts[s->targetShiftIndex], basisSize, blockSize, &nQ));
+               if (nQ != basisSize + blockSize) { blockSize = 0; reset = 1; break; }
+               CHK(pa_update_QtV(s, basisSize, blockSize));
+            }
 
             /* remember the coefficient vectors of this step (the +k directions) */
             for (int j = 0; j < basisSize; j++) {
@@ -550,7 +574,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
             if (availableBlockSize <= 0 ||
                   p->minRestartSize + p->restartingParams.maxPrevRetain + availableBlockSize < p->maxBasisSize ||
-                  p->numOrthoConst + numLocked + basisSize >= p->n) {
+                  p->numOrthoConst + numLocked + basisSize >= p->n || s->Q) {
                double dummyZero = 0.0;
                double *srn = (p->target == primme_closest_abs || p->target == primme_largest_abs)
                                    ? &dummyZero : &smallestResNorm;
@@ -558,6 +582,8 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                      blockSize, availableBlockSize, numLocked, evals, resNorms, iev, &blockSize,
                      &recentlyConverged, srn, numConverged, s->basisNorms, &reset, nprevhVecs, 0, map));
 
+               if (s->Q && numConverged + recentlyConverged > numLocked && p->numTargetShifts > numLocked + 1)
+                  blockSize = 0;   /* the next pair may belong to a different target shift */
                for (i = 0, numConverged = numLocked; i < basisSize; i++)
                   if (flags[i] != UNCONV && numConverged < p->numEvals &&
                         (i < p->numEvals - numLocked || p->target == primme_closest_geq ||
@@ -616,7 +642,13 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
             {
                /* hVecs currently has leading dimension basisSize; H is K x K already */
             }
+            if (s->Q) {
+               int nQ = basisSize;
+               CHK(pa_update_Q(s, p->targetShifts[s->targetShiftIndex], basisSize, numNew, &nQ));
+               if (nQ != basisSize + numNew) return PRIMME_UNEXPECTED_FAILURE;
+            }
             CHK(pa_update_projection(s, basisSize, numNew));
+            CHK(pa_update_QtV(s, basisSize, numNew));
             basisSize += numNew;
             CHK(pa_solve_H(s, basisSize, numLocked, numConverged));
          }
@@ -688,13 +720,13 @@ static void free_solver(pa_solver *s) {
    if (s->ctx) {
       hipk_sync(s->ctx);
       hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T); hipk_free(s->ctx, s->Jw);
-      hipk_free(s->ctx, s->evecsHat);
+      hipk_free(s->ctx, s->evecsHat); hipk_free(s->ctx, s->Q);
       hipk_free(s->ctx, s->d_red); hipk_free(s->ctx, s->d_coef); hipk_free(s->ctx, s->d_theta);
       hipk_host_free(s->ctx, s->h_red); hipk_host_free(s->ctx, s->h_coef); hipk_host_free(s->ctx, s->h_theta);
       hipk_ctx_destroy(s->ctx);
    }
    free(s->H); free(s->hVecs); free(s->prevhVecs); free(s->hVals); free(s->prevRitzVals);
-   free(s->Mq); free(s->Mlu); free(s->Mpiv);
+   free(s->Mq); free(s->Mlu); free(s->Mpiv); free(s->R); free(s->QtV); free(s->hU);
    free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol);
    free(s->flags); free(s->map); free(s->iev); free(s->perm); free(s->lockedFlags);
    free(s);
@@ -731,10 +763,13 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 
    /* what this build of the path covers; anything else must fail loudly */
    if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
-   if (p->massMatrixMatvec || p->projectionParams.projection != primme_proj_RR) {
+   const int harmonic = (p->projectionParams.projection == primme_proj_harmonic);
+   if (p->massMatrixMatvec || (p->projectionParams.projection != primme_proj_RR && !harmonic) ||
+         (harmonic && (p->orth != primme_orth_implicit_I || p->target == primme_smallest ||
+                       p->target == primme_largest || p->target == primme_largest_abs))) {
       if (p->printLevel > 0 && p->outputFile)
-         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / non-RR projection) "
-               "is not on the device path\n");
+         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / refined projection / harmonic "
+               "projection with explicit_I or an extremal target) is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
@@ -788,6 +823,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
         hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
         ((p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) && hipk_malloc(s->ctx, colBytes * 6 * b, (void **)&s->Jw)) ||
         hipk_malloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->d_red) ||
+        (harmonic && hipk_malloc(s->ctx, colBytes * K, (void **)&s->Q)) ||
         (need_hat && hipk_malloc(s->ctx, (size_t)(s->ldevecs > 0 ? s->ldevecs : 1) * s->es * maxEvecs, (void **)&s->evecsHat)) ||
         hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
         hipk_host_alloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->h_red) ||
@@ -797,6 +833,11 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->prevRitzVals = (double *)calloc((size_t)K + nev, 8);
    s->blockNorms = (double *)calloc((size_t)K + b, 8); s->basisNorms = (double *)calloc((size_t)K, 8);
    s->spec_hcol = (double *)calloc((size_t)K + 2, 8);
+   if (harmonic) {
+      s->R = (double *)calloc((size_t)K * K + 1, 8); s->QtV = (double *)calloc((size_t)K * K + 1, 8);
+      s->hU = (double *)calloc((size_t)K * K + 1, 8);
+      if (!s->R || !s->QtV || !s->hU) { free_solver(s); p->queue = user_queue; return PRIMME_MALLOC_FAILURE; }
+   }
    s->flags = (int *)calloc((size_t)K, sizeof(int)); s->map = (int *)calloc((size_t)K, sizeof(int));
    s->iev = (int *)calloc((size_t)K + b, sizeof(int)); s->perm = (int *)calloc((size_t)nev + 1, sizeof(int));
    s->lockedFlags = (int *)calloc((size_t)nev + 1, sizeof(int));

@@ -34,6 +34,8 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
       int *lockedFlags, double *lockedNorms, primme_event event);
 
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
+int pa_restart_harmonic(pa_solver *s, int ldh, int restartSize, int basisSize, int numConverged);
+int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged);
 int pa_update_cholesky(const double *G, int ldG, double *fG, int ldfG, int n0, int n);
 
 /* explicit_I: after V <- V*h, W <- W*h recompute from the data the Gram block G = V'V and
@@ -544,6 +546,12 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       s->numPrevRitzVals = restartSize;
    }
 
+   if (s->Q) {
+      /* harmonic extraction: fresh QR of (A - tau I) V for the restarted basis, then the projected
+       * problem from scratch (reference restart.c:2255-2326) */
+      rc = pa_restart_harmonic(s, ldh, restartSize, basisSize, *numConverged);
+      if (!rc) rc = pa_solve_H(s, restartSize, p->locking ? *numConverged : 0, *numConverged);
+   } else
    rc = restart_RR(s, ldh, restartSize, restartSize, basisSize, *numConverged, numPrevRetained,
          indexOfPreviousVecs, hVecsPerm);
    free(restartPerm);

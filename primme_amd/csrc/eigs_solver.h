@@ -35,6 +35,9 @@ typedef struct pa_solver {
    /* HBM-resident panels */
    char *V, *W;            /* m x K */
    char *T;                /* scratch, m x nT */
+   /* harmonic extraction: (A - tau I) V = Q R, with Q in HBM, R / Q'V / left vectors on the host */
+   char *Q;
+   double *R, *QtV, *hU;
    /* K^-1-weighted (skew) right projector of the correction equation: evecsHat = K^-1 evecs for
     * the stored converged / constraint vectors, M = evecs' evecsHat and its LU factors (host) */
    char *evecsHat;

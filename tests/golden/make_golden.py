@@ -53,6 +53,11 @@ CASES = {
     "lap1d_ex_dseq_dynamic": ((100,), dict(numEvals=10, method="DYNAMIC", eps=1e-9, aNorm=4.0, precond="jacobi")),
     "lap3d_dynamic": ((30, 31, 32), dict(numEvals=12, method="DYNAMIC", eps=1e-9, aNorm=12.0)),
     "lap2d_dynamic_few_soft": ((40, 41), dict(numEvals=3, method="DYNAMIC", eps=1e-10, aNorm=8.0, locking=0)),
+    # harmonic extraction (row f4)
+    "harm_closest_abs": ((20, 21), dict(numEvals=4, target="closest_abs", targetShifts=[1.0], eps=1e-9, aNorm=8.0, projection="harmonic")),
+    "harm_closest_geq": ((20, 21), dict(numEvals=3, target="closest_geq", targetShifts=[2.0], eps=1e-9, aNorm=8.0, projection="harmonic")),
+    "harm_closest_leq_jdqmr": ((20, 21), dict(numEvals=3, target="closest_leq", targetShifts=[2.0], eps=1e-9, aNorm=8.0, projection="harmonic", method="JDQMR")),
+    "harm_two_shifts": ((20, 21), dict(numEvals=4, target="closest_abs", targetShifts=[1.0, 3.0], eps=1e-9, aNorm=8.0, projection="harmonic")),
     # JDQMR inner-outer iteration (row a11 / f1)
     "jdqmr_bs1": ((30, 31), dict(numEvals=4, method="JDQMR", eps=1e-10, aNorm=8.0)),
     "jdqmr_etol_bs1": ((30, 31), dict(numEvals=4, method="JDQMR_ETol", eps=1e-10, aNorm=8.0)),

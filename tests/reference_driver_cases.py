@@ -1,4 +1,4 @@
-"""The reference's own regression cases on LUNDA.mtx (tests/tests/test_001..006) and the
+"""The reference's own regression cases on LUNDA.mtx (tests/tests/test_001..007) and the
 acceptance test its driver applies to every solve (check_solution, tests/COMMON/ioandtest.c:71-157),
 restated for use by the CPU (hostcheck / reference) and GPU (hip) test modules.
 
@@ -36,6 +36,9 @@ CASES = {
     # test_006: JDQMR with preconditioner on an extreme problem
     "test_006": dict(sol="sol_006_double", kw=dict(numEvals=5, eps=1e-12, maxBasisSize=50, minRestartSize=30,
                      maxOuterIterations=9000, target="largest", method="DEFAULT_MIN_TIME", precond=("jacobi", 3e8))),
+    # test_007: interior pairs through the harmonic extraction
+    "test_007": dict(sol="sol_007_double", kw=dict(numEvals=50, eps=1e-12, maxOuterIterations=7500,
+                     target="closest_abs", targetShifts=[0.0], method="GD_Olsen_plusK", projection="harmonic")),
 }
 
 
