@@ -70,14 +70,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # PRIMME_AMD_SAME_GPU=1: development aid, all ranks share device 0 (needs RCCL to accept it)
-    if os.environ.get("PRIMME_AMD_SAME_GPU"):
-        local_rank = 0
+    # PRIMME_AMD_BENCH_DIST=1: run the multi-rank plumbing (process group, RCCL communicator,
+    # in-stream reductions) even with one rank — the only way to exercise it on a one-GPU box
+    dist_path = world > 1 or bool(os.environ.get("PRIMME_AMD_BENCH_DIST"))
+    if dist_path and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ["PRIMME_AMD_FORCE_COMM"] = "1"
     torch.cuda.set_device(local_rank)
     lib = F.load_product()
 
     comm = None
-    if world > 1:
+    if dist_path:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -110,7 +113,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_path:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
@@ -135,7 +138,7 @@ def main():
     sess.solve(**{k: v for k, v in kw.items() if k not in ("backend", "comm")})
     barrier()
     lib.hipk_prof_enable(0)
-    if world > 1:
+    if dist_path:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -215,7 +218,7 @@ def main():
         lib.primme_amd_comm_destroy(comm)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_path:
         import torch.distributed as dist
         dist.destroy_process_group()
 
