@@ -58,15 +58,27 @@ static int svds_matvec(primme_svds_params *ps, void *V, PRIMME_INT ldV, void *W,
    return 0;
 }
 
-/* the eigensolver's operator: A'A x (method AtA) or A A' x (method AAt) */
+static int true_res_norm(primme_svds_params *ps, svds_side *sd, char *u, char *v, double *rNorm);
+
+/* the eigensolver's operator: A'A x (method AtA), A A' x (method AAt) or [0 A'; A 0] x */
 void pa_svds_matvec_eigs(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       primme_params *primme, int *ierr) {
    primme_svds_params *ps = (primme_svds_params *)primme->matrix;
    svds_side *sd = side_of(ps);
    const primme_svds_operator op = (&ps->primme == primme) ? ps->method : ps->methodStage2;
    *ierr = 1;
-   if (!sd || (op != primme_svds_op_AtA && op != primme_svds_op_AAt)) return;
+   if (!sd || op == primme_svds_op_none) return;
    const size_t es = es_of(sd->dt);
+   if (op == primme_svds_op_augmented) {
+      /* x = [v; u] (nLocal + mLocal rows): y = [A'u; A v] */
+      int tr = 1, no = 0, e = 0;
+      ps->matrixMatvec((char *)x + (size_t)ps->nLocal * es, ldx, y, ldy, blockSize, &tr, ps, &e);
+      if (e) return;
+      ps->matrixMatvec(x, ldx, (char *)y + (size_t)ps->nLocal * es, ldy, blockSize, &no, ps, &e);
+      if (e) return;
+      *ierr = 0;
+      return;
+   }
    PRIMME_INT mid = (op == primme_svds_op_AtA) ? ps->mLocal : ps->nLocal;
    int first = (op == primme_svds_op_AtA) ? 0 : 1, second = 1 - first;
    const int nb = *blockSize;
@@ -95,14 +107,22 @@ static void pa_svds_precond_eigs(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *
 /* |r| < max(eps, 3.16 machEps) |A|: the default test on a triplet */
 void pa_svds_default_conv_test(double *sval, void *leftsvec, void *rightsvec, double *rNorm, int *method,
       int *isConv, primme_svds_params *ps, int *ierr) {
-   (void)sval; (void)leftsvec; (void)rightsvec; (void)method;
+   (void)sval;
    svds_side *sd = side_of(ps);
    const double meps = (sd && sd->dt == HIPK_F32) ? 1.1920928955078125e-07 : PA_EPS;
    *isConv = *rNorm < PA_MAX(ps->eps, meps * 3.16) * ps->aNorm;
    *ierr = 0;
+   /* the augmented operator's residual norm is an estimate: confirm with the true one */
+   if (*isConv && *method == (int)primme_svds_op_augmented && leftsvec && rightsvec && sd) {
+      double rn = 0.0;
+      if (true_res_norm(ps, sd, (char *)leftsvec, (char *)rightsvec, &rn)) { *ierr = 1; return; }
+      *isConv = rn < PA_MAX(ps->eps, meps * 3.16) * ps->aNorm;
+   }
 }
 
 /* the eigensolver's convergence test: translate (eval, |r_eig|) to (sigma, |r_eig| / sigma) */
+void pa_larnv_uniform11(int64_t iseed[4], int64_t n, double *x);
+
 void pa_svds_conv_test_ata(double *eval, void *evec, double *rNorm, int *isConv, primme_params *primme, int *ierr) {
    primme_svds_params *ps = (primme_svds_params *)primme->matrix;
    svds_side *sd = side_of(ps);
@@ -221,6 +241,261 @@ static int scale_inverse(primme_svds_params *ps, svds_side *sd, char *x, PRIMME_
    return rc;
 }
 
+/* true residual norm of a triplet, sqrt(|A v/|v| - s u/|u||^2 + |A'u/|u| - s v/|v||^2) with
+ * s = u'Av/(|u||v|)  (reference primme_svds_c.c:1512-1570): two operator applications and a few
+ * reductions on the device */
+static int true_res_norm(primme_svds_params *ps, svds_side *sd, char *u, char *v, double *rNorm) {
+   const PRIMME_INT mL = ps->mLocal, nL = ps->nLocal;
+   const size_t es = es_of(sd->dt);
+   char *Atu = NULL;
+   double *d_ip = NULL, ip[3];
+   CHK(hipk_malloc(sd->ctx, (size_t)(mL + nL) * es, (void **)&Atu));
+   if (hipk_malloc(sd->ctx, 4 * sizeof(double), (void **)&d_ip)) { hipk_free(sd->ctx, Atu); return PRIMME_MALLOC_FAILURE; }
+   char *Av = Atu + (size_t)nL * es;
+   int rc = svds_matvec(ps, u, mL, Atu, nL, 1, 1);
+   if (!rc) rc = svds_matvec(ps, v, nL, Av, mL, 1, 0);
+   if (!rc) rc = hipk_pair_dots(sd->ctx, sd->dt, nL, v, nL, v, nL, 1, d_ip);
+   if (!rc) rc = hipk_pair_dots(sd->ctx, sd->dt, mL, u, mL, u, mL, 1, d_ip + 1);
+   if (!rc) rc = hipk_pair_dots(sd->ctx, sd->dt, mL, u, mL, Av, mL, 1, d_ip + 2);
+   if (!rc) rc = hipk_d2h(sd->ctx, ip, d_ip, 3 * sizeof(double));
+   if (!rc) rc = hipk_sync(sd->ctx);
+   if (!rc && ps->globalSumReal) { int c = 3, e = 0; ps->globalSumReal(ip, ip, &c, ps, &e); if (e) rc = PRIMME_USER_FAILURE; }
+   if (!rc) {
+      ip[0] = sqrt(ip[0]); ip[1] = sqrt(ip[1]);
+      const double sval = ip[2] / ip[0] / ip[1];
+      if (sval < -0.0) *rNorm = 1.79e308;
+      else {
+         double a;
+         a = 1.0 / ip[1]; rc = hipk_scale_cols(sd->ctx, sd->dt, nL, Atu, nL, 1, &a);
+         a = -sval / ip[0]; if (!rc) rc = hipk_axpy_cols(sd->ctx, sd->dt, nL, &a, v, nL, Atu, nL, 1);
+         a = 1.0 / ip[0]; if (!rc) rc = hipk_scale_cols(sd->ctx, sd->dt, mL, Av, mL, 1, &a);
+         a = -sval / ip[1]; if (!rc) rc = hipk_axpy_cols(sd->ctx, sd->dt, mL, &a, u, mL, Av, mL, 1);
+         if (!rc) rc = hipk_col_norms2(sd->ctx, sd->dt, mL + nL, Atu, mL + nL, 1, d_ip);
+         if (!rc) rc = hipk_d2h(sd->ctx, ip, d_ip, sizeof(double));
+         if (!rc) rc = hipk_sync(sd->ctx);
+         if (!rc && ps->globalSumReal) { int c = 1, e = 0; ps->globalSumReal(ip, ip, &c, ps, &e); if (e) rc = PRIMME_USER_FAILURE; }
+         if (!rc) *rNorm = sqrt(ip[0]);
+      }
+   }
+   hipk_free(sd->ctx, Atu); hipk_free(sd->ctx, d_ip);
+   return rc;
+}
+
+/* the eigensolver's convergence test for the augmented operator (reference :1705-1745) */
+void pa_svds_conv_test_aug(double *eval, void *evec, double *rNorm, int *isConv, primme_params *primme, int *ierr) {
+   primme_svds_params *ps = (primme_svds_params *)primme->matrix;
+   const double aNorm = primme->aNorm > 0.0 ? primme->aNorm : primme->stats.estimateLargestSVal;
+   *ierr = 0;
+   const double old = ps->aNorm;
+   if (ps->aNorm <= 0.0) ps->aNorm = aNorm;
+   double sval = eval ? fabs(*eval) : 0.0, srNorm = rNorm ? *rNorm * sqrt(2.0) : 0.0;
+   int method = (int)primme_svds_op_augmented;
+   svds_side *sd = side_of(ps);
+   const size_t es = sd ? es_of(sd->dt) : 8;
+   ps->convTestFun(&sval, evec ? (char *)evec + (size_t)ps->nLocal * es : NULL, evec, &srNorm, &method, isConv, ps, ierr);
+   ps->aNorm = old;
+}
+
+typedef struct { primme_params *p; primme_svds_operator op; char *eig_vecs; int allocatedShifts, own_monitor; } svds_stage;
+
+/* parameters and vectors of one stage from the svds block (reference copy_last_params_from_svds) */
+static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double *svals, char *svecs, double *rnorms,
+      void **stream_slot, svds_stage *st) {
+   primme_params *p = stage == 0 ? &ps->primme : &ps->primmeStage2;
+   const primme_svds_operator op = stage == 0 ? ps->method : ps->methodStage2;
+   const primme_op_datatype scalar_t = sd->dt == HIPK_F32 ? primme_op_float : primme_op_double;
+   const size_t es = es_of(sd->dt);
+   const PRIMME_INT mL = ps->mLocal, nL = ps->nLocal, tot = mL + nL;
+   st->p = p; st->op = op; st->eig_vecs = svecs; st->allocatedShifts = 0; st->own_monitor = 0;
+   if (op == primme_svds_op_none) { p->maxMatvecs = 0; return 0; }
+   const int normal = (op == primme_svds_op_AtA || op == primme_svds_op_AAt);
+
+   if (!p->matrixMatvec) { p->matrixMatvec = pa_svds_matvec_eigs; p->matrixMatvec_type = ps->matrixMatvec_type; p->matrix = ps; }
+   if (ps->applyPreconditioner && !p->applyPreconditioner) {
+      p->applyPreconditioner = pa_svds_precond_eigs; p->applyPreconditioner_type = ps->applyPreconditioner_type; p->preconditioner = ps;
+   }
+   if (ps->aNorm > 0.0) p->aNorm = normal ? ps->aNorm * ps->aNorm : ps->aNorm;
+   p->convTestFun = normal ? pa_svds_conv_test_ata : pa_svds_conv_test_aug;
+   p->convTestFun_type = scalar_t;
+   p->initSize = ps->initSize;
+   p->numOrthoConst = ps->numOrthoConst;
+   const int n0 = ps->initSize + ps->numOrthoConst;
+   const int nMax = PA_MAX(ps->initSize, ps->numSvals) + ps->numOrthoConst;
+   if (normal) {
+      /* [Uc U0 Vc V0]: park Vc (and V0 for A'A) at the far right; A'A iterates there */
+      char *right = svecs + (size_t)nMax * mL * es;
+      CHK(move_cols(sd, nL, op == primme_svds_op_AtA ? n0 : ps->numOrthoConst, svecs + (size_t)mL * n0 * es, right));
+      if (op == primme_svds_op_AtA) st->eig_vecs = right;
+   } else if (n0 > 0) {
+      /* [Uc U Vc V] -> n0 columns [v; u] of length nLocal + mLocal; unit constraints */
+      char *aux = NULL;
+      CHK(hipk_malloc(sd->ctx, (size_t)tot * n0 * es, (void **)&aux));
+      int rc = hipk_copy_cols(sd->ctx, sd->dt, tot * n0, svecs, tot * n0, aux, tot * n0, 1);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, nL, aux + (size_t)mL * n0 * es, nL, svecs, tot, n0);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, mL, aux, mL, svecs + (size_t)nL * es, tot, n0);
+      if (!rc && ps->numOrthoConst > 0) {
+         double f[64];
+         for (int c0 = 0; c0 < ps->numOrthoConst && !rc; c0 += 64) {
+            const int nc = PA_MIN(64, ps->numOrthoConst - c0);
+            for (int c = 0; c < nc; c++) f[c] = 1.0 / sqrt(2.0);
+            rc = hipk_scale_cols(sd->ctx, sd->dt, tot, svecs + (size_t)c0 * tot * es, tot, nc, f);
+         }
+      }
+      if (!rc) rc = hipk_sync(sd->ctx);
+      hipk_free(sd->ctx, aux);
+      if (rc) return rc;
+   }
+   for (int i = 0; i < 4; i++) p->iseed[i] = ps->iseed[i];
+   p->maxMatvecs = (stage == 0) ? ps->maxMatvecs / 2 : ps->maxMatvecs / 2 - ps->primme.stats.numMatvecs;
+   if (stage == 0 && ps->numTargetShifts > 0) {
+      p->numTargetShifts = ps->numTargetShifts;
+      if (normal) {
+         p->targetShifts = (double *)malloc(sizeof(double) * (size_t)ps->numSvals);
+         if (!p->targetShifts) return PRIMME_MALLOC_FAILURE;
+         st->allocatedShifts = 1;
+         for (int i = 0; i < p->numTargetShifts; i++) p->targetShifts[i] = ps->targetShifts[i] * ps->targetShifts[i];
+      } else p->targetShifts = ps->targetShifts;
+   }
+
+   /* augmented operator without guesses: start from [A'x; x] or [x; A x]  (reference :760-790) */
+   if (!normal && p->initSize <= 0) {
+      char *v0 = svecs + (size_t)p->numOrthoConst * tot * es, *u0 = v0 + (size_t)nL * es;
+      const PRIMME_INT len = (ps->m >= ps->n) ? mL : nL;
+      double *h = (double *)malloc(sizeof(double) * (size_t)(len > 0 ? len : 1));
+      if (!h) return PRIMME_MALLOC_FAILURE;
+      pa_larnv_uniform11(p->iseed, len, h);
+      int rc = 0;
+      if (sd->dt == HIPK_F32) {
+         float *hf = (float *)h;
+         for (PRIMME_INT i = 0; i < len; i++) hf[i] = (float)h[i];
+      }
+      rc = hipk_h2d(sd->ctx, (ps->m >= ps->n) ? u0 : v0, h, (size_t)len * es);
+      if (!rc) rc = hipk_sync(sd->ctx);
+      free(h);
+      if (!rc) rc = (ps->m >= ps->n) ? svds_matvec(ps, u0, mL, v0, nL, 1, 1) : svds_matvec(ps, v0, nL, u0, mL, 1, 0);
+      double n2[2], *d_n = NULL;
+      if (!rc) rc = hipk_malloc(sd->ctx, 2 * sizeof(double), (void **)&d_n) ? PRIMME_MALLOC_FAILURE : 0;
+      if (!rc) rc = hipk_col_norms2(sd->ctx, sd->dt, nL, v0, nL, 1, d_n);
+      if (!rc) rc = hipk_col_norms2(sd->ctx, sd->dt, mL, u0, mL, 1, d_n + 1);
+      if (!rc) rc = hipk_d2h(sd->ctx, n2, d_n, 2 * sizeof(double));
+      if (!rc) rc = hipk_sync(sd->ctx);
+      hipk_free(sd->ctx, d_n);
+      if (!rc && ps->globalSumReal) { int c = 2, e = 0; ps->globalSumReal(n2, n2, &c, ps, &e); if (e) rc = PRIMME_USER_FAILURE; }
+      if (rc) return rc;
+      double f = 1.0 / sqrt(n2[0]);
+      CHK(hipk_scale_cols(sd->ctx, sd->dt, nL, v0, nL, 1, &f));
+      f = 1.0 / sqrt(n2[1]);
+      CHK(hipk_scale_cols(sd->ctx, sd->dt, mL, u0, mL, 1, &f));
+      p->initSize = 1;
+      if (rnorms) rnorms[0] = 1.79e308;
+      p->initBasisMode = primme_init_user;
+   }
+
+   /* second stage: triplets that already pass the criterion become constraints (reference :795-826) */
+   if (stage == 1) {
+      for (int i = 0; p->initSize > 0; i++) {
+         int isConv = 0, ierr = 0, method = (int)op;
+         double sv = svals[i], rn = rnorms[i];
+         char *vi = svecs + (size_t)p->numOrthoConst * tot * es;
+         ps->convTestFun(&sv, vi + (size_t)nL * es, vi, &rn, &method, &isConv, ps, &ierr);
+         if (ierr) return PRIMME_USER_FAILURE;
+         if (!isConv) break;
+         p->numOrthoConst++; p->initSize--; p->numEvals--;
+      }
+   }
+   if (ps->locking >= 0) p->locking = ps->locking;
+   if (!p->monitorFun && ps->monitorFun) { p->monitorFun = monitor_single_stage; p->monitorFun_type = scalar_t; st->own_monitor = 1; }
+   p->queue = stream_slot;
+   p->profile = ps->profile;
+   /* the library's own communicator: let the eigensolver reduce its device partials in stream */
+   if (ps->globalSumReal == primme_amd_svds_global_sum) { p->globalSumReal = primme_amd_global_sum; p->commInfo = ps->commInfo; }
+   return 0;
+}
+
+/* results of one stage back into the svds block (reference copy_last_params_to_svds) */
+static int stage_end(primme_svds_params *ps, svds_side *sd, int stage, double *svals, char *svecs, double *rnorms,
+      svds_stage *st) {
+   primme_params *p = st->p;
+   const primme_svds_operator op = st->op;
+   const size_t es = es_of(sd->dt);
+   const PRIMME_INT mL = ps->mLocal, nL = ps->nLocal, tot = mL + nL;
+   if (op == primme_svds_op_none) { p->maxMatvecs = 0; return 0; }
+   const int normal = (op == primme_svds_op_AtA || op == primme_svds_op_AAt);
+   if (stage == 1) {
+      const int nconv = ps->numSvals - p->numEvals;
+      p->initSize += nconv; p->numOrthoConst -= nconv; p->numEvals += nconv;
+   }
+   ps->stats.numOuterIterations += p->stats.numOuterIterations;
+   ps->stats.numRestarts += p->stats.numRestarts;
+   ps->stats.numMatvecs += p->stats.numMatvecs * 2;
+   ps->stats.numPreconds += p->stats.numPreconds;
+   ps->stats.numGlobalSum += p->stats.numGlobalSum;
+   ps->stats.numBroadcast += p->stats.numBroadcast;
+   ps->stats.volumeGlobalSum += p->stats.volumeGlobalSum;
+   ps->stats.volumeBroadcast += p->stats.volumeBroadcast;
+   ps->stats.numOrthoInnerProds += p->stats.numOrthoInnerProds;
+   ps->stats.elapsedTime += p->stats.elapsedTime;
+   ps->stats.timeMatvec += p->stats.timeMatvec;
+   ps->stats.timePrecond += p->stats.timePrecond;
+   ps->stats.timeOrtho += p->stats.timeOrtho;
+   ps->stats.timeGlobalSum += p->stats.timeGlobalSum;
+   ps->stats.timeBroadcast += p->stats.timeBroadcast;
+   ps->stats.lockingIssue += p->stats.lockingIssue;
+   if (p->aNorm > 0.0) ps->aNorm = normal ? sqrt(p->aNorm) : p->aNorm;
+   if (normal) for (int i = 0; i < p->initSize; i++) svals[i] = sqrt(PA_MAX(0.0, svals[i]));
+
+   const int nMax = PA_MAX(ps->initSize, ps->numSvals) + ps->numOrthoConst;
+   ps->initSize = p->initSize;
+   const int n1 = ps->initSize + ps->numOrthoConst;
+   int rc = 0;
+   if (op == primme_svds_op_AtA) {
+      /* U = A V / Sigma, then [Vc V] moves next to it */
+      char *right = svecs + (size_t)nMax * mL * es;
+      char *Vfound = right + (size_t)nL * ps->numOrthoConst * es, *U = svecs + (size_t)mL * ps->numOrthoConst * es;
+      rc = svds_matvec(ps, Vfound, nL, U, mL, ps->initSize, 0);
+      if (!rc) rc = scale_inverse(ps, sd, U, mL, ps->initSize, svals);
+      if (!rc) rc = move_cols(sd, nL, n1, right, svecs + (size_t)mL * n1 * es);
+   } else if (op == primme_svds_op_AAt) {
+      /* V = A' U / Sigma behind [Uc U Vc] */
+      char *right = svecs + (size_t)nMax * mL * es;
+      rc = move_cols(sd, nL, ps->numOrthoConst, right, svecs + (size_t)mL * n1 * es);
+      char *U = svecs + (size_t)mL * ps->numOrthoConst * es;
+      char *V = svecs + (size_t)mL * n1 * es + (size_t)nL * ps->numOrthoConst * es;
+      if (!rc) rc = svds_matvec(ps, U, mL, V, nL, ps->initSize, 1);
+      if (!rc) rc = scale_inverse(ps, sd, V, nL, ps->initSize, svals);
+   } else if (n1 > 0) {
+      /* constraints back to their scale, [v; u] columns -> [Uc U Vc V], unit u and v */
+      if (ps->numOrthoConst > 0) {
+         double f[64];
+         for (int c0 = 0; c0 < ps->numOrthoConst && !rc; c0 += 64) {
+            const int nc = PA_MIN(64, ps->numOrthoConst - c0);
+            for (int c = 0; c < nc; c++) f[c] = sqrt(2.0);
+            rc = hipk_scale_cols(sd->ctx, sd->dt, tot, svecs + (size_t)c0 * tot * es, tot, nc, f);
+         }
+      }
+      char *aux = NULL;
+      if (!rc) rc = hipk_malloc(sd->ctx, (size_t)tot * n1 * es, (void **)&aux) ? PRIMME_MALLOC_FAILURE : 0;
+      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, tot * n1, svecs, tot * n1, aux, tot * n1, 1);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, nL, aux, tot, svecs + (size_t)mL * n1 * es, nL, n1);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, mL, aux + (size_t)nL * es, tot, svecs, mL, n1);
+      if (!rc) rc = hipk_sync(sd->ctx);
+      hipk_free(sd->ctx, aux);
+      double *zero = (double *)calloc((size_t)n1, sizeof(double));     /* "factor unusable" -> normalise */
+      if (!zero) rc = PRIMME_MALLOC_FAILURE;
+      if (!rc) rc = scale_inverse(ps, sd, svecs, mL, n1, zero);
+      if (!rc) rc = scale_inverse(ps, sd, svecs + (size_t)mL * n1 * es, nL, n1, zero);
+      free(zero);
+   }
+   if (rc) return rc;
+   for (int i = 0; i < 4; i++) ps->iseed[i] = p->iseed[i];
+   if (st->allocatedShifts) { free(p->targetShifts); p->targetShifts = NULL; }
+   if (normal) for (int i = 0; i < ps->initSize; i++) rnorms[i] = PA_MIN(rnorms[i] / svals[i], ps->aNorm);
+   else for (int i = 0; i < ps->initSize; i++) rnorms[i] *= sqrt(2.0);
+   if (st->own_monitor) p->monitorFun = NULL;
+   p->queue = NULL;
+   return hipk_sync(sd->ctx);
+}
+
 static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_svds_params *ps, hipk_dtype dt) {
    if (!ps) return -4;
    const int out_float = (dt == HIPK_F32);
@@ -241,13 +516,13 @@ static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_
    int rc = check_input(svals_out, svecs_, resNorms_out, ps);
    if (rc) { ps->initSize = 0; return rc; }
 
-   /* what is not on the device path fails loudly, as a first-stage error */
-   primme_params *p = &ps->primme;
-   if (ps->method == primme_svds_op_augmented || ps->methodStage2 != primme_svds_op_none ||
-         ps->target == primme_svds_closest_abs) {
+   /* The augmented operator is on the device path with Rayleigh-Ritz, i.e. for the largest
+    * triplets.  Smallest / closest_abs with it need the refined extraction: fail loudly. */
+   const int uses_aug = (ps->method == primme_svds_op_augmented || ps->methodStage2 == primme_svds_op_augmented);
+   if (ps->target == primme_svds_closest_abs || (uses_aug && ps->target != primme_svds_largest)) {
       if (ps->printLevel > 0 && ps->outputFile)
-         fprintf(ps->outputFile, "primme_amd: svds augmented / hybrid methods and closest_abs targets are not on the "
-               "device path; use primme_svds_normalequations\n");
+         fprintf(ps->outputFile, "primme_amd: svds closest_abs targets and the augmented stage for the smallest triplets "
+               "(refined extraction) are not on the device path; use primme_svds_normalequations\n");
       ps->initSize = 0;
       return PRIMME_FUNCTION_UNAVAILABLE - 100;
    }
@@ -267,104 +542,41 @@ static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_
    void *user_queue = ps->queue;
    if (!ps->queue) ps->queue = &stream;
 
-   const size_t es = es_of(dt);
    char *svecs = (char *)svecs_;
-   const PRIMME_INT mL = ps->mLocal, nL = ps->nLocal;
-   const primme_svds_operator op = ps->method;
-   int ret = 0, allocatedShifts = 0;
+   int ret = 0;
    double *svals = (double *)calloc((size_t)ps->numSvals + 1, 8), *rnorms = (double *)calloc((size_t)ps->numSvals + 1, 8);
+   svds_stage st;
+   memset(&st, 0, sizeof(st));
    if (!svals || !rnorms) { rc = PRIMME_MALLOC_FAILURE; goto done; }
 
-   /* ---- stage set-up ---- */
-   if (!p->matrixMatvec) { p->matrixMatvec = pa_svds_matvec_eigs; p->matrixMatvec_type = ps->matrixMatvec_type; p->matrix = ps; }
-   if (ps->applyPreconditioner && !p->applyPreconditioner) {
-      p->applyPreconditioner = pa_svds_precond_eigs; p->applyPreconditioner_type = ps->applyPreconditioner_type; p->preconditioner = ps;
-   }
-   if (ps->aNorm > 0.0) p->aNorm = ps->aNorm * ps->aNorm;
-   p->convTestFun = pa_svds_conv_test_ata;
-   p->convTestFun_type = scalar_t;
-   p->initSize = ps->initSize;
-   p->numOrthoConst = ps->numOrthoConst;
-   const int n0 = ps->initSize + ps->numOrthoConst;
-   const int nMax = PA_MAX(ps->initSize, ps->numSvals) + ps->numOrthoConst;
-   /* [Uc U0 Vc V0]: park Vc (and V0 for A'A) at the far right; A'A iterates there */
-   char *right = svecs + (size_t)nMax * mL * es;
-   rc = move_cols(sd, nL, op == primme_svds_op_AtA ? n0 : ps->numOrthoConst, svecs + (size_t)mL * n0 * es, right);
+   /* ---- first stage ---- */
+   rc = stage_begin(ps, sd, 0, NULL, svecs, rnorms, &stream, &st);
    if (rc) goto done;
-   char *eig_vecs = (op == primme_svds_op_AtA) ? right : svecs;
-   for (int i = 0; i < 4; i++) p->iseed[i] = ps->iseed[i];
-   p->maxMatvecs = ps->maxMatvecs / 2;
-   if (ps->numTargetShifts > 0) {
-      p->numTargetShifts = ps->numTargetShifts;
-      p->targetShifts = (double *)malloc(sizeof(double) * (size_t)ps->numSvals);
-      if (!p->targetShifts) { rc = PRIMME_MALLOC_FAILURE; goto done; }
-      allocatedShifts = 1;
-      for (int i = 0; i < p->numTargetShifts; i++) p->targetShifts[i] = ps->targetShifts[i] * ps->targetShifts[i];
-   }
-   if (ps->locking >= 0) p->locking = ps->locking;
-   int own_monitor = 0;
-   if (!p->monitorFun && ps->monitorFun) { p->monitorFun = monitor_single_stage; p->monitorFun_type = scalar_t; own_monitor = 1; }
-   p->queue = &stream;
-   p->profile = ps->profile;
-   /* the library's own communicator: let the eigensolver reduce its device partials in stream */
-   if (ps->globalSumReal == primme_amd_svds_global_sum) { p->globalSumReal = primme_amd_global_sum; p->commInfo = ps->commInfo; }
+   ret = pa_eigs_solve(svals, st.eig_vecs, rnorms, st.p, dt, 1);
+   rc = stage_end(ps, sd, 0, svals, svecs, rnorms, &st);
+   if (rc) goto done;
+   if (ret != 0) ret -= 100;
 
-   /* ---- the eigenproblem ---- */
-   ret = pa_eigs_solve(svals, eig_vecs, rnorms, p, dt, 1);
-
-   /* ---- back to triplets ---- */
-   ps->stats.numOuterIterations += p->stats.numOuterIterations;
-   ps->stats.numRestarts += p->stats.numRestarts;
-   ps->stats.numMatvecs += p->stats.numMatvecs * 2;
-   ps->stats.numPreconds += p->stats.numPreconds;
-   ps->stats.numGlobalSum += p->stats.numGlobalSum;
-   ps->stats.numBroadcast += p->stats.numBroadcast;
-   ps->stats.volumeGlobalSum += p->stats.volumeGlobalSum;
-   ps->stats.volumeBroadcast += p->stats.volumeBroadcast;
-   ps->stats.numOrthoInnerProds += p->stats.numOrthoInnerProds;
-   ps->stats.elapsedTime += p->stats.elapsedTime;
-   ps->stats.timeMatvec += p->stats.timeMatvec;
-   ps->stats.timePrecond += p->stats.timePrecond;
-   ps->stats.timeOrtho += p->stats.timeOrtho;
-   ps->stats.timeGlobalSum += p->stats.timeGlobalSum;
-   ps->stats.timeBroadcast += p->stats.timeBroadcast;
-   ps->stats.lockingIssue += p->stats.lockingIssue;
-   if (p->aNorm > 0.0) ps->aNorm = sqrt(p->aNorm);
-   for (int i = 0; i < p->initSize; i++) svals[i] = sqrt(PA_MAX(0.0, svals[i]));
-   ps->initSize = p->initSize;
-   {
-      const int n1 = ps->initSize + ps->numOrthoConst;
-      if (op == primme_svds_op_AtA) {
-         /* U = A V / Sigma, then [Vc V] moves next to it */
-         char *Vfound = right + (size_t)nL * ps->numOrthoConst * es, *U = svecs + (size_t)mL * ps->numOrthoConst * es;
-         rc = svds_matvec(ps, Vfound, nL, U, mL, ps->initSize, 0);
-         if (!rc) rc = scale_inverse(ps, sd, U, mL, ps->initSize, svals);
-         if (!rc) rc = move_cols(sd, nL, n1, right, svecs + (size_t)mL * n1 * es);
-      } else {
-         /* V = A' U / Sigma behind [Uc U Vc] */
-         rc = move_cols(sd, nL, ps->numOrthoConst, right, svecs + (size_t)mL * n1 * es);
-         char *U = svecs + (size_t)mL * ps->numOrthoConst * es;
-         char *V = svecs + (size_t)mL * n1 * es + (size_t)nL * ps->numOrthoConst * es;
-         if (!rc) rc = svds_matvec(ps, U, mL, V, nL, ps->initSize, 1);
-         if (!rc) rc = scale_inverse(ps, sd, V, nL, ps->initSize, svals);
-      }
+   /* ---- second stage (hybrid): the augmented operator refines what the normal equations left ---- */
+   if (ps->methodStage2 != primme_svds_op_none && ret == 0) {
+      rc = stage_begin(ps, sd, 1, svals, svecs, rnorms, &stream, &st);
       if (rc) goto done;
+      const int nconv = ps->numSvals - ps->primmeStage2.numEvals;
+      ret = pa_eigs_solve(svals + nconv, st.eig_vecs, rnorms + nconv, st.p, dt, 1);
+      rc = stage_end(ps, sd, 1, svals, svecs, rnorms, &st);
+      if (rc) goto done;
+      if (ret != 0) ret -= 200;
    }
-   for (int i = 0; i < 4; i++) ps->iseed[i] = p->iseed[i];
-   for (int i = 0; i < ps->initSize; i++) rnorms[i] = PA_MIN(rnorms[i] / svals[i], ps->aNorm);
-   if (own_monitor) p->monitorFun = NULL;
-   rc = hipk_sync(sd->ctx);
 
    for (int i = 0; i < ps->initSize; i++) {
       if (out_float) { ((float *)svals_out)[i] = (float)svals[i]; ((float *)resNorms_out)[i] = (float)rnorms[i]; }
       else { ((double *)svals_out)[i] = svals[i]; ((double *)resNorms_out)[i] = rnorms[i]; }
    }
-   if (ret != 0) ret -= 100;
 
 done:
-   if (allocatedShifts) { free(p->targetShifts); p->targetShifts = NULL; }
+   if (st.allocatedShifts && st.p && st.p->targetShifts) { free(st.p->targetShifts); st.p->targetShifts = NULL; }
    free(svals); free(rnorms);
-   p->queue = NULL;
+   ps->primme.queue = NULL; ps->primmeStage2.queue = NULL;
    ps->queue = user_queue;
    if (sd->aux) hipk_free(sd->ctx, sd->aux);
    hipk_ctx_destroy(sd->ctx);

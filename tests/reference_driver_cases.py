@@ -92,11 +92,15 @@ def check_solution(A_apply, evals, evecs, rnorms, aNorm, eps, X):
 
 
 # ---- singular value cases (tests/tests/test_20N, driver tests/driversvds.c) -----------------
-# The driver's default method is the hybrid one; the device path covers the normal equations, which
-# is what these run (the acceptance test does not depend on the method).
+# The driver's default method is the hybrid one (normal equations, then the augmented operator).
 SVDS_CASES = {
     "test_201": dict(sol="sol_201svds_double", kw=dict(numSvals=5, eps=1e-6, target="largest")),
     "test_202": dict(sol="sol_202svds_double", kw=dict(numSvals=5, eps=1e-12, target="largest")),
+    # test_201 / test_202 as the driver runs them: the default (hybrid) method
+    "test_201_hybrid": dict(sol="sol_201svds_double", kw=dict(numSvals=5, eps=1e-6, target="largest", method="default")),
+    "test_202_hybrid": dict(sol="sol_202svds_double", kw=dict(numSvals=5, eps=1e-12, target="largest", method="default")),
+    # test_207: the augmented operator alone
+    "test_207": dict(sol="sol_207svds_double", kw=dict(numSvals=5, eps=1e-6, target="largest", method="augmented")),
 }
 # test_203..206 ask for the smallest triplets of matrices whose smallest singular values are
 # ~1e-9 |A| (rect.mtx: 1.5e-9 .. 4.7e-9 against |A| = 31.6): sigma^2 is below the resolution of

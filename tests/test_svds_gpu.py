@@ -29,6 +29,18 @@ def test_hip_svds_against_oracle(built, m, n, k, target):
     assert abs(r.stats["numOuterIterations"] - h.stats["numOuterIterations"]) <= max(2, 0.03 * h.stats["numOuterIterations"])
 
 
+@pytest.mark.parametrize("method", ["hybrid", "augmented"])
+def test_hip_svds_hybrid_and_augmented(built, method):
+    A, csr = _rect(300, 200)
+    s = np.linalg.svd(A, compute_uv=False)
+    r = svds(300, 200, csr, numSvals=4, target="largest", eps=1e-9, method=method, methodStage1="GD_plusK", backend="hip")
+    h = svds(300, 200, csr, numSvals=4, target="largest", eps=1e-9, method=method, methodStage1="GD_plusK", backend="hostcheck")
+    assert r.ret == 0 and h.ret == 0 and r.initSize == 4
+    assert np.max(np.abs(r.svals - s[:4])) <= 1e-9 * s[0] and np.max(np.abs(r.svals - h.svals)) <= 1e-9 * s[0]
+    assert np.linalg.norm(A @ r.V - r.U * r.svals) <= 1e-7 * s[0]
+    assert abs(r.stats["numOuterIterations"] - h.stats["numOuterIterations"]) <= max(3, 0.1 * h.stats["numOuterIterations"])
+
+
 def test_hip_svds_float(built):
     A, csr = _rect(400, 250)
     s = np.linalg.svd(A, compute_uv=False)
@@ -41,7 +53,7 @@ def test_hip_svds_reference_driver_case(built, name):
     rp, ci, va, m, n = RD.rect()
     rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
     case = RD.SVDS_CASES[name]
-    r = svds(m, n, (rp, ci, va), backend="hip", methodStage1="GD_plusK", **case["kw"])
+    r = svds(m, n, (rp, ci, va), backend="hip", **{"methodStage1": "GD_plusK", **case["kw"]})
     assert r.ret == 0 and r.initSize == case["kw"]["numSvals"]
     XU, _ = RD.read_sol_svds(case["sol"], m, n)
     bad = RD.check_solution_svds(lambda v: problems.csr_matvec_numpy(rp, ci, va, v.reshape(-1, 1)).ravel(),
@@ -52,7 +64,7 @@ def test_hip_svds_reference_driver_case(built, name):
 
 def test_hip_svds_unsupported_fails_loudly(built):
     A, csr = _rect(60, 40)
-    assert svds(60, 40, csr, numSvals=2, method="hybrid", backend="hip").ret == -144
+    assert svds(60, 40, csr, numSvals=2, method="hybrid", target="smallest", backend="hip").ret == -144
 
 
 def test_hip_svds_config5_shape(built):

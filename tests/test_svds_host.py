@@ -78,7 +78,7 @@ def test_svds_reference_driver_case(built, name, backend):
     rp, ci, va, m, n = RD.rect()
     rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
     case = RD.SVDS_CASES[name]
-    r = svds(m, n, (rp, ci, va), backend=backend, methodStage1="GD_plusK", **case["kw"])
+    r = svds(m, n, (rp, ci, va), backend=backend, **{"methodStage1": "GD_plusK", **case["kw"]})
     assert r.ret == 0 and r.initSize == case["kw"]["numSvals"]
     XU, _ = RD.read_sol_svds(case["sol"], m, n)
     bad = RD.check_solution_svds(lambda v: problems.csr_matvec_numpy(rp, ci, va, v.reshape(-1, 1)).ravel(),
@@ -93,8 +93,34 @@ def test_svds_reference_driver_case(built, name, backend):
     assert np.max(np.abs(r.svals - want)) <= max(case["kw"]["eps"], 1e-10) * s[0]
 
 
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built")
+@pytest.mark.parametrize("m,n,k,method,eps", [(300, 200, 5, "hybrid", 1e-10), (200, 300, 4, "hybrid", 1e-12),
+                                              (300, 200, 4, "augmented", 1e-9), (200, 300, 3, "augmented", 1e-9)])
+def test_svds_two_stage_and_augmented_follow_reference(built, m, n, k, method, eps):
+    """Hybrid (normal equations, then [0 A'; A 0]) and the augmented operator alone for the largest
+    triplets; the hybrid runs reproduce the reference's counts exactly."""
+    A, csr = _rect(m, n)
+    s = np.linalg.svd(A, compute_uv=False)
+    out = {}
+    for be in ("hostcheck", "reference"):
+        r = svds(m, n, csr, numSvals=k, target="largest", eps=eps, method=method, methodStage1="GD_plusK", backend=be)
+        assert r.ret == 0 and r.initSize == k
+        assert np.max(np.abs(r.svals - s[:k])) <= max(eps, 1e-10) * s[0]
+        assert np.all(r.resNorms <= eps * r.params["aNorm"] * 2.0)
+        assert np.linalg.norm(A @ r.V - r.U * r.svals) <= 10 * eps * s[0] * np.sqrt(k)
+        assert np.linalg.norm(r.U.T @ r.U - np.eye(k)) <= 1e-7 and np.linalg.norm(r.V.T @ r.V - np.eye(k)) <= 1e-7
+        out[be] = r
+    h, r = out["hostcheck"], out["reference"]
+    if method == "hybrid":
+        for key in ("numOuterIterations", "numMatvecs", "numRestarts"):
+            assert h.stats[key] == r.stats[key], key
+    else:
+        assert abs(h.stats["numOuterIterations"] - r.stats["numOuterIterations"]) <= 0.1 * r.stats["numOuterIterations"]
+
+
 def test_svds_unsupported_methods_fail_loudly(built):
     A, csr = _rect(60, 40)
-    assert svds(60, 40, csr, numSvals=2, method="hybrid", backend="hostcheck").ret == -144
-    assert svds(60, 40, csr, numSvals=2, method="augmented", backend="hostcheck").ret == -144
+    # the augmented stage for the smallest triplets needs the refined extraction: not on the path
+    assert svds(60, 40, csr, numSvals=2, method="hybrid", target="smallest", backend="hostcheck").ret == -144
+    assert svds(60, 40, csr, numSvals=2, method="augmented", target="smallest", backend="hostcheck").ret == -144
     assert svds(60, 40, csr, numSvals=70, backend="hostcheck").ret == -10
