@@ -128,7 +128,7 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
    double *vr = malloc((size_t)k * 8), *wr = malloc((size_t)k * 8), *outv = malloc((size_t)njobs * 8);
    for (int q = 0; q < njobs; q++) if (jobs[q].kind == HIPK_JOB_RES && jobs[q].slot >= 0) nrm2[jobs[q].slot] = 0.0;
    for (int64_t i = 0; i < m; i++) {
-      for (int j = 0; j < k; j++) { vr[j] = ld_(dt, colp(dt, V, ld, j), i); wr[j] = ld_(dt, colp(dt, W, ld, j), i); }
+      for (int j = 0; j < k; j++) { vr[j] = ld_(dt, colp(dt, V, ld, j), i); wr[j] = W ? ld_(dt, colp(dt, W, ld, j), i) : 0.0; }
       for (int q = 0; q < njobs; q++) {
          const double *hc = h + (size_t)jobs[q].col * ldh;
          double xv = 0, yv = 0;

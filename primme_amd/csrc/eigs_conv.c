@@ -162,6 +162,9 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
 
 /* Put the first unconverged Ritz pairs in the block, computing X, R and the
  * residual norms for them; flag converged pairs on the way. */
+int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arbitraryVecs, double smallestResNorm,
+      const int *flags, int RRForAll);
+
 int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int computeXR,
       int *flags, int remainedEvals, double *blockNorms, int blockNormsSize, int maxBlockSize,
       int numLocked, double *evals, double *resNorms, int *iev, int *blockSize,
@@ -238,6 +241,9 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          lasti = iev[blki];
       }
 
+      /* refined extraction: well conditioned coefficient vectors for the next candidates */
+      if ((rc = pa_prepare_vecs(s, basisSize, lasti + 1, maxBlockSize - *blockSize, &s->numArbitraryVecs,
+                 *smallestResNorm, flags, 1))) goto out;
       /* next candidates after the last visited pair */
       blki = *blockSize;
       for (int i = lasti + 1; i < basisSize && blki < maxBlockSize; i++)

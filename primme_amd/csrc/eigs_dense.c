@@ -288,3 +288,59 @@ void pa_larnv_uniform11(int64_t iseed[4], int64_t n, double *x) {
    iseed[2] = (int64_t)((s >> 12) & 4095);
    iseed[3] = (int64_t)(s & 4095);
 }
+
+/* ---- singular value decomposition A = U diag(S) V' of a small square matrix ------------------
+ * One-sided Jacobi (Hestenes): columns of W = A V are rotated until mutually orthogonal; S are
+ * their norms, sorted descending like xGESVD (which the reference calls, blaslapack.c Num_gesvd).
+ * High relative accuracy also for the small singular values the refined extraction looks at. */
+int pa_svd(const double *A, int ldA, int n, double *U, int ldU, double *S, double *V, int ldV) {
+   if (n <= 0) return 0;
+   double *W = (double *)malloc(sizeof(double) * (size_t)n * n);
+   if (!W) return PRIMME_MALLOC_FAILURE;
+   for (int j = 0; j < n; j++)
+      for (int i = 0; i < n; i++) { W[i + (size_t)j * n] = A[i + (size_t)j * ldA]; V[i + (size_t)j * ldV] = (i == j) ? 1.0 : 0.0; }
+   for (int sweep = 0; sweep < 60; sweep++) {
+      int rotated = 0;
+      for (int p = 0; p < n - 1; p++)
+         for (int q = p + 1; q < n; q++) {
+            double a = 0.0, b = 0.0, g = 0.0;
+            const double *wp = W + (size_t)p * n, *wq = W + (size_t)q * n;
+            for (int i = 0; i < n; i++) { a += wp[i] * wp[i]; b += wq[i] * wq[i]; g += wp[i] * wq[i]; }
+            if (fabs(g) <= PA_EPS * sqrt(a * b) || g == 0.0) continue;
+            rotated = 1;
+            const double zeta = (b - a) / (2.0 * g);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+            double *xp = W + (size_t)p * n, *xq = W + (size_t)q * n;
+            for (int i = 0; i < n; i++) { const double u = xp[i], v = xq[i]; xp[i] = c * u - sn * v; xq[i] = sn * u + c * v; }
+            double *vp = V + (size_t)p * ldV, *vq = V + (size_t)q * ldV;
+            for (int i = 0; i < n; i++) { const double u = vp[i], v = vq[i]; vp[i] = c * u - sn * v; vq[i] = sn * u + c * v; }
+         }
+      if (!rotated) break;
+   }
+   int *perm = (int *)malloc(sizeof(int) * (size_t)n);
+   double *nrm = (double *)malloc(sizeof(double) * (size_t)n);
+   if (!perm || !nrm) { free(W); free(perm); free(nrm); return PRIMME_MALLOC_FAILURE; }
+   for (int j = 0; j < n; j++) {
+      double t = 0.0;
+      for (int i = 0; i < n; i++) t += W[i + (size_t)j * n] * W[i + (size_t)j * n];
+      nrm[j] = sqrt(t); perm[j] = j;
+   }
+   for (int i = 1; i < n; i++) {             /* insertion sort, descending */
+      const int pi = perm[i];
+      int j = i - 1;
+      while (j >= 0 && nrm[perm[j]] < nrm[pi]) { perm[j + 1] = perm[j]; j--; }
+      perm[j + 1] = pi;
+   }
+   double *Vc = (double *)malloc(sizeof(double) * (size_t)n * n);
+   if (!Vc) { free(W); free(perm); free(nrm); return PRIMME_MALLOC_FAILURE; }
+   for (int j = 0; j < n; j++) memcpy(Vc + (size_t)j * n, V + (size_t)perm[j] * ldV, sizeof(double) * (size_t)n);
+   for (int j = 0; j < n; j++) {
+      const int pj = perm[j];
+      S[j] = nrm[pj];
+      memcpy(V + (size_t)j * ldV, Vc + (size_t)j * n, sizeof(double) * (size_t)n);
+      for (int i = 0; i < n; i++) U[i + (size_t)j * ldU] = (nrm[pj] > 0.0) ? W[i + (size_t)pj * n] / nrm[pj] : (i == j ? 1.0 : 0.0);
+   }
+   free(W); free(perm); free(nrm); free(Vc);
+   return 0;
+}

@@ -157,6 +157,8 @@ int pa_dyn_leave_jdqmr(pa_solver *s, pa_cost_model *c);
 void pa_dyn_recommend(const pa_cost_model *c, primme_params *p);
 int pa_update_Q(pa_solver *s, double tau, int col0, int bs, int *nQ);
 int pa_update_QtV(pa_solver *s, int col0, int bs);
+int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arbitraryVecs, double smallestResNorm,
+      const int *flags, int RRForAll);
 int pa_evecs_hat_init(pa_solver *s);
 int pa_evecs_hat_update(pa_solver *s, int *numConvergedStored, int numConverged);
 int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double *blockNorms, const int *iev,
@@ -186,6 +188,7 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
          const int si = ilev[b];
          const double bn = blockNorms[b] * sqrt(p->stats.estimateInvBNorm);
          if (fabs(sorted[si] - targetShift) < bn) shifts[b] = targetShift;
+         else if (s->refined) shifts[b] = sorted[si];    /* |theta - tau| <= sigma: trust the Ritz value */
          else shifts[b] = sorted[si] + bn * (targetShift - sorted[si]) / fabs(targetShift - sorted[si]);
          olsen[b] = (si < s->numPrevRitzVals) ? fabs(s->prevRitzVals[si] - sorted[si]) : bn;
       }
@@ -390,6 +393,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
       CHK(pa_update_projection(s, 0, basisSize));
       CHK(pa_update_QtV(s, 0, basisSize));
       CHK(pa_solve_H(s, basisSize, numLocked, numConverged));
+      s->numArbitraryVecs = 0;
       maxRecentlyConverged = availableBlockSize = blockSize = 0;
       smallestResNorm = HUGE_VAL;
       p->stats.estimateResidualError = 0.0;
@@ -547,7 +551,16 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
             basisSize += blockSize;
             blockSize = 0;
             CHK(pa_solve_H(s, basisSize, numLocked, numConverged));
+            s->numArbitraryVecs = 0;
             candidates_prepared = 0;
+            /* the smallest singular value of R bounds |theta_0 - tau| from above; a clear violation
+             * means the factorisation has drifted: rebuild it (reference main_iter.c:858-884) */
+            if (s->refined && basisSize > 0 && restartsSinceReset > 1 && s->targetShiftIndex >= 0 &&
+                  fabs(p->targetShifts[s->targetShiftIndex] - s->hVals[0]) -
+                              PA_MAX(p->aNorm, p->stats.estimateLargestSVal) * s->mach_eps > s->hSVals[0]) {
+               reset = 2;
+               break;
+            }
          } /* main block Davidson loop */
 
          if (basisSize >= p->n - p->numOrthoConst - numLocked) {
@@ -603,6 +616,16 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                pa_permute_cols(s->hVals, 1, basisSize, 1, iwork);
                pa_permute_cols(s->hVecs, basisSize, basisSize, basisSize, iwork);
                pa_permute_ints(flags, basisSize, iwork);
+               if (s->hVecsRot) {
+                  for (int c = s->numArbitraryVecs; c < basisSize; c++) {
+                     for (int r = 0; r < s->K; r++) s->hVecsRot[r + (size_t)c * s->K] = 0.0;
+                     s->hVecsRot[c + (size_t)c * s->K] = 1.0;
+                  }
+                  pa_permute_cols(s->hVecsRot, basisSize, basisSize, s->K, iwork);
+                  int last = 0;
+                  for (i = 0; i < basisSize; i++) if (iwork[i] != i) last = i + 1;
+                  s->numArbitraryVecs = PA_MAX(s->numArbitraryVecs, last);
+               }
                s->coef_valid_k = -1;
                free(iwork);
             } else {
@@ -726,7 +749,7 @@ static void free_solver(pa_solver *s) {
       hipk_ctx_destroy(s->ctx);
    }
    free(s->H); free(s->hVecs); free(s->prevhVecs); free(s->hVals); free(s->prevRitzVals);
-   free(s->Mq); free(s->Mlu); free(s->Mpiv); free(s->R); free(s->QtV); free(s->hU);
+   free(s->Mq); free(s->Mlu); free(s->Mpiv); free(s->R); free(s->QtV); free(s->hU); free(s->hSVals); free(s->hVecsRot);
    free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol);
    free(s->flags); free(s->map); free(s->iev); free(s->perm); free(s->lockedFlags);
    free(s);
@@ -763,12 +786,13 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 
    /* what this build of the path covers; anything else must fail loudly */
    if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
-   const int harmonic = (p->projectionParams.projection == primme_proj_harmonic);
-   if (p->massMatrixMatvec || (p->projectionParams.projection != primme_proj_RR && !harmonic) ||
+   const int refined = (p->projectionParams.projection == primme_proj_refined);
+   const int harmonic = (p->projectionParams.projection == primme_proj_harmonic) || refined;
+   if (p->massMatrixMatvec ||
          (harmonic && (p->orth != primme_orth_implicit_I || p->target == primme_smallest ||
                        p->target == primme_largest || p->target == primme_largest_abs))) {
       if (p->printLevel > 0 && p->outputFile)
-         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / refined projection / harmonic "
+         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / harmonic or refined "
                "projection with explicit_I or an extremal target) is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
@@ -834,9 +858,13 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->blockNorms = (double *)calloc((size_t)K + b, 8); s->basisNorms = (double *)calloc((size_t)K, 8);
    s->spec_hcol = (double *)calloc((size_t)K + 2, 8);
    if (harmonic) {
-      s->R = (double *)calloc((size_t)K * K + 1, 8); s->QtV = (double *)calloc((size_t)K * K + 1, 8);
+      s->R = (double *)calloc((size_t)K * K + 1, 8);
       s->hU = (double *)calloc((size_t)K * K + 1, 8);
-      if (!s->R || !s->QtV || !s->hU) { free_solver(s); p->queue = user_queue; return PRIMME_MALLOC_FAILURE; }
+      if (refined) {
+         s->refined = 1;
+         s->hSVals = (double *)calloc((size_t)K + 1, 8); s->hVecsRot = (double *)calloc((size_t)K * K + 1, 8);
+      } else s->QtV = (double *)calloc((size_t)K * K + 1, 8);
+      if (!s->R || !s->hU || (refined ? (!s->hSVals || !s->hVecsRot) : !s->QtV)) { free_solver(s); p->queue = user_queue; return PRIMME_MALLOC_FAILURE; }
    }
    s->flags = (int *)calloc((size_t)K, sizeof(int)); s->map = (int *)calloc((size_t)K, sizeof(int));
    s->iev = (int *)calloc((size_t)K + b, sizeof(int)); s->perm = (int *)calloc((size_t)nev + 1, sizeof(int));

@@ -366,12 +366,14 @@ int pa_solve_H_RR(pa_solver *s, const double *H, int ldH, const double *VtBV, in
 }
 
 int pa_solve_H_harm(pa_solver *s, int k, const double *G, int ldG);
+int pa_solve_H_ref(pa_solver *s, int k, double *hVals_out);
 
 int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged) {
    primme_params *p = s->p;
    const int off = p->numOrthoConst + numLocked;
    const double *G = s->VtBV ? s->VtBV + (size_t)off * s->ldVtBV + off : NULL;
-   if (s->Q) CHK(pa_solve_H_harm(s, basisSize, G, s->ldVtBV));
+   if (s->refined) CHK(pa_solve_H_ref(s, basisSize, s->hVals));
+   else if (s->Q) CHK(pa_solve_H_harm(s, basisSize, G, s->ldVtBV));
    else CHK(pa_solve_H_RR(s, s->H, s->K, G, s->ldVtBV, s->hVecs, basisSize, s->hVals, basisSize, numConverged));
    for (int i = 0; i < basisSize; i++) {
       p->stats.estimateMinEVal = PA_MIN(p->stats.estimateMinEVal, s->hVals[i]);

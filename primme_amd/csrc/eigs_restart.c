@@ -35,6 +35,9 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
 
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
 int pa_restart_harmonic(pa_solver *s, int ldh, int restartSize, int basisSize, int numConverged);
+int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, int numConverged, int numPrevRetained,
+      int indexOfPreviousVecs, int indexOfPreviousVecsBeforeRestart, const int *restartPerm, const int *hVecsPerm,
+      int *numArbitraryVecs);
 int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged);
 int pa_update_cholesky(const double *G, int ldG, double *fG, int ldfG, int n0, int n);
 
@@ -511,6 +514,7 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
                                  (int)(p->n - restartSize - *numConverged - p->numOrthoConst)));
 
    int indexOfPreviousVecs = p->locking ? restartSize + *numConverged - *numLocked : restartSize;
+   const int indexOfPreviousVecsBeforeRestart = indexOfPreviousVecs;
    const int nLocked = p->numOrthoConst + *numLocked;
    const double *G = s->VtBV ? s->VtBV + (size_t)nLocked * s->ldVtBV + nLocked : NULL;
    CHK(ortho_coefficient_vectors(s, basisSize, ldh, indexOfPreviousVecs, G, s->ldVtBV, nprevhVecs, flags,
@@ -546,7 +550,15 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       s->numPrevRitzVals = restartSize;
    }
 
-   if (s->Q) {
+   if (s->refined) {
+      rc = pa_restart_refined(s, ldh, restartSize, basisSize, *numConverged, numPrevRetained, indexOfPreviousVecs,
+            indexOfPreviousVecsBeforeRestart, restartPerm, hVecsPerm, &s->numArbitraryVecs);
+      for (i = 0; i < restartSize && !rc; i++) {
+         p->stats.estimateMinEVal = PA_MIN(p->stats.estimateMinEVal, s->hVals[i]);
+         p->stats.estimateMaxEVal = PA_MAX(p->stats.estimateMaxEVal, s->hVals[i]);
+         p->stats.estimateLargestSVal = PA_MAX(p->stats.estimateLargestSVal, fabs(s->hVals[i]));
+      }
+   } else if (s->Q) {
       /* harmonic extraction: fresh QR of (A - tau I) V for the restarted basis, then the projected
        * problem from scratch (reference restart.c:2255-2326) */
       rc = pa_restart_harmonic(s, ldh, restartSize, basisSize, *numConverged);

@@ -38,6 +38,9 @@ typedef struct pa_solver {
    /* harmonic extraction: (A - tau I) V = Q R, with Q in HBM, R / Q'V / left vectors on the host */
    char *Q;
    double *R, *QtV, *hU;
+   int refined;            /* refined extraction: singular triplets of R instead of Q'V */
+   double *hSVals, *hVecsRot;
+   int numArbitraryVecs;   /* leading columns of hVecs that are Rayleigh-Ritz vectors of a cluster */
    /* K^-1-weighted (skew) right projector of the correction equation: evecsHat = K^-1 evecs for
     * the stored converged / constraint vectors, M = evecs' evecsHat and its LU factors (host) */
    char *evecsHat;

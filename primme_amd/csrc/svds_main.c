@@ -263,7 +263,7 @@ static int true_res_norm(primme_svds_params *ps, svds_side *sd, char *u, char *v
    if (!rc) {
       ip[0] = sqrt(ip[0]); ip[1] = sqrt(ip[1]);
       const double sval = ip[2] / ip[0] / ip[1];
-      if (sval < -0.0) *rNorm = 1.79e308;
+      if (!(sval >= 0.0) || !isfinite(sval)) *rNorm = 1.79e308;   /* negative, or a null vector of [0 A'; A 0] */
       else {
          double a;
          a = 1.0 / ip[1]; rc = hipk_scale_cols(sd->ctx, sd->dt, nL, Atu, nL, 1, &a);
@@ -347,14 +347,41 @@ static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double 
    }
    for (int i = 0; i < 4; i++) p->iseed[i] = ps->iseed[i];
    p->maxMatvecs = (stage == 0) ? ps->maxMatvecs / 2 : ps->maxMatvecs / 2 - ps->primme.stats.numMatvecs;
-   if (stage == 0 && ps->numTargetShifts > 0) {
+   if ((stage == 0 && ps->numTargetShifts > 0) ||
+         (stage == 1 && p->targetShifts == NULL && ps->target == primme_svds_closest_abs)) {
       p->numTargetShifts = ps->numTargetShifts;
-      if (normal) {
+      if (stage == 0 && normal) {
          p->targetShifts = (double *)malloc(sizeof(double) * (size_t)ps->numSvals);
          if (!p->targetShifts) return PRIMME_MALLOC_FAILURE;
          st->allocatedShifts = 1;
          for (int i = 0; i < p->numTargetShifts; i++) p->targetShifts[i] = ps->targetShifts[i] * ps->targetShifts[i];
       } else p->targetShifts = ps->targetShifts;
+   }
+
+   if (stage == 1 && p->targetShifts == NULL && ps->target == primme_svds_smallest) {
+      /* closest_geq to lower bounds of the singular values found by the normal equations:
+       * sqrt(max(s - |r|, 0) s), never below machEps |A| so that the |m - n| null vectors of the
+       * augmented operator are not returned (reference primme_svds_c.c:700-735) */
+      p->targetShifts = (double *)malloc(sizeof(double) * (size_t)ps->numSvals);
+      if (!p->targetShifts) return PRIMME_MALLOC_FAILURE;
+      st->allocatedShifts = 1;
+      const double min_val = ps->aNorm * PA_EPS;
+      int i = 0;
+      for (; i < ps->initSize; i++) p->targetShifts[i] = PA_MAX(sqrt(fabs(PA_MAX(svals[i] - rnorms[i], 0.0) * svals[i])), min_val);
+      for (; i < ps->numSvals; i++) p->targetShifts[i] = min_val;
+      for (int a = 1; a < ps->numSvals; a++) {          /* ascending */
+         const double v = p->targetShifts[a];
+         int b = a - 1;
+         while (b >= 0 && p->targetShifts[b] > v) { p->targetShifts[b + 1] = p->targetShifts[b]; b--; }
+         p->targetShifts[b + 1] = v;
+      }
+      p->numTargetShifts = ps->numSvals;
+   } else if (!normal && ps->target == primme_svds_smallest && p->targetShifts == NULL) {
+      p->targetShifts = (double *)malloc(sizeof(double));
+      if (!p->targetShifts) return PRIMME_MALLOC_FAILURE;
+      st->allocatedShifts = 1;
+      p->targetShifts[0] = 0.0;
+      p->numTargetShifts = 1;
    }
 
    /* augmented operator without guesses: start from [A'x; x] or [x; A x]  (reference :760-790) */
@@ -488,7 +515,7 @@ static int stage_end(primme_svds_params *ps, svds_side *sd, int stage, double *s
    }
    if (rc) return rc;
    for (int i = 0; i < 4; i++) ps->iseed[i] = p->iseed[i];
-   if (st->allocatedShifts) { free(p->targetShifts); p->targetShifts = NULL; }
+   if (st->allocatedShifts) { free(p->targetShifts); p->targetShifts = NULL; p->numTargetShifts = 0; st->allocatedShifts = 0; }
    if (normal) for (int i = 0; i < ps->initSize; i++) rnorms[i] = PA_MIN(rnorms[i] / svals[i], ps->aNorm);
    else for (int i = 0; i < ps->initSize; i++) rnorms[i] *= sqrt(2.0);
    if (st->own_monitor) p->monitorFun = NULL;
@@ -516,16 +543,9 @@ static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_
    int rc = check_input(svals_out, svecs_, resNorms_out, ps);
    if (rc) { ps->initSize = 0; return rc; }
 
-   /* The augmented operator is on the device path with Rayleigh-Ritz, i.e. for the largest
-    * triplets.  Smallest / closest_abs with it need the refined extraction: fail loudly. */
-   const int uses_aug = (ps->method == primme_svds_op_augmented || ps->methodStage2 == primme_svds_op_augmented);
-   if (ps->target == primme_svds_closest_abs || (uses_aug && ps->target != primme_svds_largest)) {
-      if (ps->printLevel > 0 && ps->outputFile)
-         fprintf(ps->outputFile, "primme_amd: svds closest_abs targets and the augmented stage for the smallest triplets "
-               "(refined extraction) are not on the device path; use primme_svds_normalequations\n");
-      ps->initSize = 0;
-      return PRIMME_FUNCTION_UNAVAILABLE - 100;
-   }
+   /* all methods and targets are on the device path; what the eigensolver itself does not cover
+    * (explicit_I with the refined extraction, i.e. blocks or single precision for interior
+    * targets) comes back from the stage as -44 - 100 / - 200 */
 
    if (!ps->convTestFun) {
       ps->convTestFun = pa_svds_default_conv_test;

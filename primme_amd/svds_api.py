@@ -34,7 +34,7 @@ def transpose_csr(m, n, rp, ci, va):
 
 def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", methodStage1="DEFAULT_METHOD",
          eps=1e-8, aNorm=0.0, backend="hip", dtype=np.float64, maxBlockSize=0, maxBasisSize=0, locking=None,
-         maxMatvecs=0, v0=None, iseed=None, printLevel=0, return_vectors=True):
+         maxMatvecs=0, v0=None, iseed=None, printLevel=0, return_vectors=True, targetShifts=None):
     dtype = np.dtype(dtype)
     dt = F.HIPK_F64 if dtype == np.float64 else F.HIPK_F32
     ctype = C.c_double if dtype == np.float64 else C.c_float
@@ -53,6 +53,10 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
     if maxBasisSize: ps.maxBasisSize = maxBasisSize
     if locking is not None: ps.locking = locking
     if maxMatvecs: ps.maxMatvecs = maxMatvecs
+    if targetShifts is not None:
+        ts = (C.c_double * len(targetShifts))(*targetShifts)
+        keep.append(ts)
+        ps.targetShifts, ps.numTargetShifts = ts, len(targetShifts)
     if iseed is not None:
         for i in range(4): ps.iseed[i] = iseed[i]
     v0 = None if v0 is None else np.asarray(v0, dtype=dtype).reshape(n, -1)

@@ -58,6 +58,12 @@ CASES = {
     "harm_closest_geq": ((20, 21), dict(numEvals=3, target="closest_geq", targetShifts=[2.0], eps=1e-9, aNorm=8.0, projection="harmonic")),
     "harm_closest_leq_jdqmr": ((20, 21), dict(numEvals=3, target="closest_leq", targetShifts=[2.0], eps=1e-9, aNorm=8.0, projection="harmonic", method="JDQMR")),
     "harm_two_shifts": ((20, 21), dict(numEvals=4, target="closest_abs", targetShifts=[1.0, 3.0], eps=1e-9, aNorm=8.0, projection="harmonic")),
+    # refined extraction (row f4)
+    "ref_closest_abs": ((20, 21), dict(numEvals=4, target="closest_abs", targetShifts=[1.0], eps=1e-9, aNorm=8.0, projection="refined")),
+    "ref_closest_geq": ((20, 21), dict(numEvals=3, target="closest_geq", targetShifts=[2.0], eps=1e-9, aNorm=8.0, projection="refined")),
+    "ref_closest_leq_jdqmr": ((20, 21), dict(numEvals=3, target="closest_leq", targetShifts=[2.0], eps=1e-9, aNorm=8.0, projection="refined", method="JDQMR")),
+    "ref_soft": ((20, 21), dict(numEvals=3, target="closest_abs", targetShifts=[2.0], eps=1e-9, aNorm=8.0, projection="refined", locking=0)),
+    "ref_two_shifts": ((20, 21), dict(numEvals=4, target="closest_abs", targetShifts=[1.0, 3.0], eps=1e-9, aNorm=8.0, projection="refined")),
     # JDQMR inner-outer iteration (row a11 / f1)
     "jdqmr_bs1": ((30, 31), dict(numEvals=4, method="JDQMR", eps=1e-10, aNorm=8.0)),
     "jdqmr_etol_bs1": ((30, 31), dict(numEvals=4, method="JDQMR_ETol", eps=1e-10, aNorm=8.0)),

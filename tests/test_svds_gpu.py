@@ -50,9 +50,9 @@ def test_hip_svds_float(built):
 
 @pytest.mark.parametrize("name", sorted(RD.SVDS_CASES))
 def test_hip_svds_reference_driver_case(built, name):
-    rp, ci, va, m, n = RD.rect()
-    rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
     case = RD.SVDS_CASES[name]
+    rp, ci, va, m, n = RD.svds_matrix(case.get("matrix", "rect.mtx"))
+    rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
     r = svds(m, n, (rp, ci, va), backend="hip", **{"methodStage1": "GD_plusK", **case["kw"]})
     assert r.ret == 0 and r.initSize == case["kw"]["numSvals"]
     XU, _ = RD.read_sol_svds(case["sol"], m, n)
@@ -64,7 +64,7 @@ def test_hip_svds_reference_driver_case(built, name):
 
 def test_hip_svds_unsupported_fails_loudly(built):
     A, csr = _rect(60, 40)
-    assert svds(60, 40, csr, numSvals=2, method="hybrid", target="smallest", backend="hip").ret == -144
+    assert svds(60, 40, csr, numSvals=2, target="closest_abs", targetShifts=[7.0], maxBlockSize=2, backend="hip").ret == -144
 
 
 def test_hip_svds_config5_shape(built):

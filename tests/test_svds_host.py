@@ -75,9 +75,9 @@ def test_svds_hostcheck_follows_reference(built, m, n, k, target):
 def test_svds_reference_driver_case(built, name, backend):
     """tests/tests/test_20N on rect.mtx, accepted by the driver's check_solution_svds against the
     reference's stored singular vectors (the `reference` leg pins the checker itself)."""
-    rp, ci, va, m, n = RD.rect()
-    rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
     case = RD.SVDS_CASES[name]
+    rp, ci, va, m, n = RD.svds_matrix(case.get("matrix", "rect.mtx"))
+    rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
     r = svds(m, n, (rp, ci, va), backend=backend, **{"methodStage1": "GD_plusK", **case["kw"]})
     assert r.ret == 0 and r.initSize == case["kw"]["numSvals"]
     XU, _ = RD.read_sol_svds(case["sol"], m, n)
@@ -118,9 +118,29 @@ def test_svds_two_stage_and_augmented_follow_reference(built, m, n, k, method, e
         assert abs(h.stats["numOuterIterations"] - r.stats["numOuterIterations"]) <= 0.1 * r.stats["numOuterIterations"]
 
 
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built")
+@pytest.mark.parametrize("m,n,k,method,target", [(300, 200, 3, "hybrid", "smallest"), (200, 300, 3, "default", "smallest"),
+                                                 (300, 200, 3, "normalequations", "closest_abs"), (300, 200, 3, "hybrid", "closest_abs")])
+def test_svds_refined_stages_follow_reference(built, m, n, k, method, target):
+    """Smallest and interior triplets: the stages that use the refined extraction (normal equations for
+    closest_abs; the augmented second stage for smallest / closest_abs)."""
+    A, csr = _rect(m, n)
+    s = np.linalg.svd(A, compute_uv=False)
+    kw = dict(targetShifts=[8.0]) if target == "closest_abs" else {}
+    want = s[::-1][:k] if target == "smallest" else s[np.argsort(np.abs(s - 8.0))][:k]
+    out = {}
+    for be in ("hostcheck", "reference"):
+        r = svds(m, n, csr, numSvals=k, target=target, eps=1e-10, method=method, methodStage1="GD_plusK", backend=be,
+                 maxMatvecs=60000, **kw)
+        assert r.ret == 0 and r.initSize == k
+        assert np.max(np.abs(np.sort(r.svals) - np.sort(want))) <= 1e-9 * s[0]
+        out[be] = r
+    h, r = out["hostcheck"], out["reference"]
+    assert abs(h.stats["numOuterIterations"] - r.stats["numOuterIterations"]) <= 0.05 * r.stats["numOuterIterations"] + 2
+
+
 def test_svds_unsupported_methods_fail_loudly(built):
     A, csr = _rect(60, 40)
-    # the augmented stage for the smallest triplets needs the refined extraction: not on the path
-    assert svds(60, 40, csr, numSvals=2, method="hybrid", target="smallest", backend="hostcheck").ret == -144
-    assert svds(60, 40, csr, numSvals=2, method="augmented", target="smallest", backend="hostcheck").ret == -144
+    # interior targets with blocks need explicit_I + refined extraction in the eigensolver: -44 - 100
+    assert svds(60, 40, csr, numSvals=2, target="closest_abs", targetShifts=[7.0], maxBlockSize=2, backend="hostcheck").ret == -144
     assert svds(60, 40, csr, numSvals=70, backend="hostcheck").ret == -10
