@@ -198,6 +198,15 @@ int hipk_jacobi_apply(void *hip_stream, hipk_dtype dt, int64_t m, const void *di
 hipk_dtype hipk_csr_dtype(const hipk_csr *A);
 int64_t hipk_csr_nrows(const hipk_csr *A);
 
+/* ---- Rayleigh-Ritz small solve on the device (reference solve_projection.c:188-331 calls xHEEVX,
+ * blaslapack.c:1024-1143).  Symmetric n x n (n <= 64), upper triangle of A_host referenced;
+ * eigenvalues ascending in evals_host, orthonormal eigenvectors in Z_host.  One workgroup, parallel
+ * cyclic Jacobi in LDS (round-robin pairing, n/2 rotations per step).  The solver uses the host QL
+ * solver by default and this kernel when PRIMME_AMD_DEVICE_RR is set: the projected matrix is
+ * assembled on the host anyway and a k <= 41 problem is latency, not throughput. */
+int hipk_sym_eig(hipk_ctx *ctx, int n, const double *A_host, int lda, double *evals_host,
+      double *Z_host, int ldz);
+
 /* ---- measurement helpers ------------------------------------------------------- */
 /* device copy bandwidth probe: copies `bytes` src->dst `reps` times, returns GB/s (read+write) */
 int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);

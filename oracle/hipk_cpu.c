@@ -380,3 +380,41 @@ int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps) { 
 int hipk_prof_enable(int on) { (void)on; return 0; }
 int hipk_prof_reset(void) { return 0; }
 int hipk_prof_get(int cls, double *ms, long *launches, double *alg_bytes) { (void)cls; *ms = 0; *launches = 0; *alg_bytes = 0; return 0; }
+
+/* symmetric eigenproblem by cyclic Jacobi (the device kernel's algorithm, sequential pairing) */
+int hipk_sym_eig(hipk_ctx *ctx, int n, const double *A_in, int lda, double *evals, double *Z, int ldz) {
+   (void)ctx;
+   if (n <= 0) return 0;
+   double *A = malloc(sizeof(double) * (size_t)n * n), *V = malloc(sizeof(double) * (size_t)n * n);
+   for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+      A[i + (size_t)j * n] = (i <= j) ? A_in[i + (size_t)j * lda] : A_in[j + (size_t)i * lda];
+      V[i + (size_t)j * n] = (i == j);
+   }
+   for (int sweep = 0; sweep < 60; sweep++) {
+      double off = 0, dia = 0;
+      for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) { double v = A[i + (size_t)j * n]; if (i == j) dia += v * v; else off += v * v; }
+      if (off <= 1e-34 * dia || off == 0.0) break;
+      for (int p = 0; p < n - 1; p++) for (int q = p + 1; q < n; q++) {
+         double apq = A[p + (size_t)q * n];
+         if (fabs(apq) < 1e-300) continue;
+         double tau = (A[q + (size_t)q * n] - A[p + (size_t)p * n]) / (2 * apq);
+         double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau)), c = 1 / sqrt(1 + t * t), s = t * c;
+         for (int r = 0; r < n; r++) {
+            double ap = A[r + (size_t)p * n], aq = A[r + (size_t)q * n];
+            A[r + (size_t)p * n] = c * ap - s * aq; A[r + (size_t)q * n] = s * ap + c * aq;
+            double vp = V[r + (size_t)p * n], vq = V[r + (size_t)q * n];
+            V[r + (size_t)p * n] = c * vp - s * vq; V[r + (size_t)q * n] = s * vp + c * vq;
+         }
+         for (int r = 0; r < n; r++) {
+            double ap = A[p + (size_t)r * n], aq = A[q + (size_t)r * n];
+            A[p + (size_t)r * n] = c * ap - s * aq; A[q + (size_t)r * n] = s * ap + c * aq;
+         }
+      }
+   }
+   int *perm = malloc(sizeof(int) * (size_t)n);
+   for (int i = 0; i < n; i++) perm[i] = i;
+   for (int i = 1; i < n; i++) { int pi = perm[i], j = i - 1; while (j >= 0 && A[perm[j] + (size_t)perm[j] * n] > A[pi + (size_t)pi * n]) { perm[j + 1] = perm[j]; j--; } perm[j + 1] = pi; }
+   for (int j = 0; j < n; j++) { evals[j] = A[perm[j] + (size_t)perm[j] * n]; for (int i = 0; i < n; i++) Z[i + (size_t)j * ldz] = V[i + (size_t)perm[j] * n]; }
+   free(A); free(V); free(perm);
+   return 0;
+}

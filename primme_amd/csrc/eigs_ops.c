@@ -321,13 +321,15 @@ int pa_solve_H_RR(pa_solver *s, const double *H, int ldH, const double *VtBV, in
       if (!Hn) return PRIMME_MALLOC_FAILURE;
       for (int j = 0; j < n; j++)
          for (int i = 0; i <= j; i++) Hn[i + (size_t)j * n] = -H[i + (size_t)j * ldH];
-      int rc = pa_sym_eig_gen(n, Hn, n, VtBV, ldVtBV, hVals, hVecs, ldhVecs);
+      int rc = (s->device_rr && !VtBV && n <= 64) ? hipk_sym_eig(s->ctx, n, Hn, n, hVals, hVecs, ldhVecs)
+                                                   : pa_sym_eig_gen(n, Hn, n, VtBV, ldVtBV, hVals, hVecs, ldhVecs);
       free(Hn);
       if (rc) return rc;
       for (int i = 0; i < n; i++) hVals[i] = -hVals[i];
       return 0;
    }
-   CHK(pa_sym_eig_gen(n, H, ldH, VtBV, ldVtBV, hVals, hVecs, ldhVecs));
+   if (s->device_rr && !VtBV && n <= 64) CHK(hipk_sym_eig(s->ctx, n, H, ldH, hVals, hVecs, ldhVecs));
+   else CHK(pa_sym_eig_gen(n, H, ldH, VtBV, ldVtBV, hVals, hVecs, ldhVecs));
    if (p->target == primme_smallest) return 0;
 
    /* interior targets: permutation by closeness to the first unlocked shift */

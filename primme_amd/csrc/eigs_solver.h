@@ -78,6 +78,7 @@ typedef struct pa_solver {
    /* speculative tail of the block-size-1 GD iteration: the new basis vector was normalised with
     * the device-resident norm, multiplied by the operator and projected before the host looked
     * at anything; accepted by the orthogonaliser if Daniel's test passes on the first pass */
+   int device_rr;          /* PRIMME_AMD_DEVICE_RR: small Rayleigh-Ritz solve by the device Jacobi kernel */
    int spec2_enabled;      /* off with PRIMME_AMD_NO_SPEC2 (measurement knob, read once per solve) */
    int spec2_valid, spec2_k;
    double *spec_hcol;      /* K+1 entries: V(:,0:k+1)' W(:,k) */

@@ -255,3 +255,133 @@ extern "C" int hipk_prof_get(int cls, double *ms, long *launches, double *alg_by
    *ms = g_prof.ms[cls]; *launches = g_prof.launches[cls]; *alg_bytes = g_prof.bytes[cls];
    return 0;
 }
+
+
+/* ======================= Rayleigh-Ritz small solve: parallel cyclic Jacobi ===================== */
+#define EIG_MAXN 64
+__global__ void __launch_bounds__(HIPK_BLOCK)
+sym_eig_jacobi_kernel(const double *__restrict__ Ain, int n, int np, double *__restrict__ evals,
+      double *__restrict__ Zout, int *__restrict__ sweeps_out) {
+   extern __shared__ double sh[];
+   double *A = sh, *V = sh + (size_t)np * np;
+   __shared__ int top[EIG_MAXN / 2], bot[EIG_MAXN / 2];
+   __shared__ double cs[EIG_MAXN / 2], sn[EIG_MAXN / 2];
+   __shared__ double offd[HIPK_BLOCK / HIPK_WAVE], dia[HIPK_BLOCK / HIPK_WAVE];
+   __shared__ int done;
+   const int tid = threadIdx.x, half = np / 2;
+   for (int idx = tid; idx < np * np; idx += HIPK_BLOCK) {
+      const int i = idx % np, j = idx / np;
+      double v = 0.0;
+      if (i < n && j < n) v = (i <= j) ? Ain[i + (size_t)j * n] : Ain[j + (size_t)i * n];
+      A[idx] = v;
+      V[idx] = (i == j) ? 1.0 : 0.0;
+   }
+   if (tid < half) { top[tid] = 2 * tid; bot[tid] = 2 * tid + 1; }
+   if (tid == 0) done = 0;
+   __syncthreads();
+   int sweep = 0;
+   for (; sweep < 40; sweep++) {
+      /* off-diagonal weight against the diagonal: stop when it is rounding noise */
+      double o = 0.0, d = 0.0;
+      for (int idx = tid; idx < np * np; idx += HIPK_BLOCK) {
+         const int i = idx % np, j = idx / np;
+         const double v = A[idx];
+         if (i == j) d += v * v; else o += v * v;
+      }
+      o = hipk_wave_sum(o); d = hipk_wave_sum(d);
+      if ((tid & 63) == 0) { offd[tid >> 6] = o; dia[tid >> 6] = d; }
+      __syncthreads();
+      if (tid == 0) {
+         const double ot = (offd[0] + offd[1]) + (offd[2] + offd[3]), dt = (dia[0] + dia[1]) + (dia[2] + dia[3]);
+         done = (ot <= 1e-34 * dt) || (ot == 0.0);
+      }
+      __syncthreads();
+      if (done) break;
+      for (int step = 0; step < np - 1; step++) {
+         if (tid < half) {
+            const int p = min(top[tid], bot[tid]), q = max(top[tid], bot[tid]);
+            const double apq = A[p + (size_t)q * np], app = A[p + (size_t)p * np], aqq = A[q + (size_t)q * np];
+            double c = 1.0, s = 0.0;
+            if (fabs(apq) > 1e-300 && fabs(apq) > 1e-20 * sqrt(fabs(app * aqq)) ) {
+               const double tau = (aqq - app) / (2.0 * apq);
+               const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+               c = 1.0 / sqrt(1.0 + t * t);
+               s = t * c;
+            }
+            cs[tid] = c; sn[tid] = s;
+         }
+         __syncthreads();
+         /* A <- A J, V <- V J (columns p, q of every pair) */
+         for (int idx = tid; idx < half * np; idx += HIPK_BLOCK) {
+            const int k = idx / np, r = idx % np;
+            const int p = min(top[k], bot[k]), q = max(top[k], bot[k]);
+            const double c = cs[k], s = sn[k];
+            const double ap = A[r + (size_t)p * np], aq = A[r + (size_t)q * np];
+            A[r + (size_t)p * np] = c * ap - s * aq;
+            A[r + (size_t)q * np] = s * ap + c * aq;
+            const double vp = V[r + (size_t)p * np], vq = V[r + (size_t)q * np];
+            V[r + (size_t)p * np] = c * vp - s * vq;
+            V[r + (size_t)q * np] = s * vp + c * vq;
+         }
+         __syncthreads();
+         /* A <- J' A (rows p, q) */
+         for (int idx = tid; idx < half * np; idx += HIPK_BLOCK) {
+            const int k = idx / np, r = idx % np;
+            const int p = min(top[k], bot[k]), q = max(top[k], bot[k]);
+            const double c = cs[k], s = sn[k];
+            const double ap = A[p + (size_t)r * np], aq = A[q + (size_t)r * np];
+            A[p + (size_t)r * np] = c * ap - s * aq;
+            A[q + (size_t)r * np] = s * ap + c * aq;
+         }
+         __syncthreads();
+         if (tid == 0) {            /* round robin: top[0] stays, the others move one seat */
+            const int tlast = top[half - 1], b0 = bot[0];
+            for (int i = half - 1; i > 1; i--) top[i] = top[i - 1];
+            for (int i = 0; i < half - 1; i++) bot[i] = bot[i + 1];
+            if (half > 1) { top[1] = b0; bot[half - 1] = tlast; }
+         }
+         __syncthreads();
+      }
+   }
+   for (int i = tid; i < n; i += HIPK_BLOCK) evals[i] = A[i + (size_t)i * np];
+   for (int idx = tid; idx < n * n; idx += HIPK_BLOCK) { const int i = idx % n, j = idx / n; Zout[idx] = V[i + (size_t)j * np]; }
+   if (tid == 0) *sweeps_out = sweep;
+}
+
+extern "C" int hipk_sym_eig(hipk_ctx *ctx, int n, const double *A_host, int lda, double *evals_host,
+      double *Z_host, int ldz) {
+   if (n <= 0) return 0;
+   if (n > EIG_MAXN) return -1;
+   const int np = (n + 1) & ~1;
+   double *buf = NULL;
+   const size_t nn = (size_t)n * n;
+   HIPK_CHECK(hipMalloc((void **)&buf, (2 * nn + n + 2) * sizeof(double)));
+   double *dA = buf, *dZ = buf + nn, *dE = dZ + nn;
+   int *dS = (int *)(dE + n);
+   double *tight = (double *)malloc(nn * sizeof(double));
+   if (!tight) { hipFree(buf); return -2; }
+   for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) tight[i + (size_t)j * n] = (i <= j) ? A_host[i + (size_t)j * lda] : 0.0;
+   hipError_t e = hipMemcpyAsync(dA, tight, nn * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+   if (e == hipSuccess) {
+      hipLaunchKernelGGL(sym_eig_jacobi_kernel, dim3(1), dim3(HIPK_BLOCK), 2 * (size_t)np * np * sizeof(double), ctx->stream,
+            dA, n, np, dE, dZ, dS);
+      e = hipGetLastError();
+   }
+   double *ev = (double *)malloc(n * sizeof(double)), *Z = (double *)malloc(nn * sizeof(double));
+   if (e == hipSuccess) e = hipMemcpyAsync(ev, dE, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+   if (e == hipSuccess) e = hipMemcpyAsync(Z, dZ, nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+   hipFree(buf);
+   free(tight);
+   if (e != hipSuccess) { free(ev); free(Z); fprintf(stderr, "primme_amd: hipk_sym_eig: %s\n", hipGetErrorString(e)); return -1; }
+   /* ascending order, like the host solver */
+   int perm[EIG_MAXN];
+   for (int i = 0; i < n; i++) perm[i] = i;
+   for (int i = 1; i < n; i++) { const int pi = perm[i]; int j = i - 1; while (j >= 0 && ev[perm[j]] > ev[pi]) { perm[j + 1] = perm[j]; j--; } perm[j + 1] = pi; }
+   for (int j = 0; j < n; j++) {
+      evals_host[j] = ev[perm[j]];
+      for (int i = 0; i < n; i++) Z_host[i + (size_t)j * ldz] = Z[i + (size_t)perm[j] * n];
+   }
+   free(ev); free(Z);
+   return 0;
+}

@@ -221,3 +221,19 @@ def test_hip_skew_projectors_and_exact_olsen(built, kw):
     assert np.max(np.abs(np.sort(r.evals) - np.sort(h.evals))) <= 1e-10 * r.params["aNorm"]
     assert np.all(r.resNorms <= 1e-10 * r.params["aNorm"] * (1 + 1e-6))
     assert abs(r.stats["numOuterIterations"] - h.stats["numOuterIterations"]) <= max(3, 0.1 * h.stats["numOuterIterations"])
+
+
+def test_hip_device_rayleigh_ritz_option(built, monkeypatch):
+    """PRIMME_AMD_DEVICE_RR: the small projected eigenproblem solved by the device Jacobi kernel
+    instead of the host QL solver; same eigenpairs."""
+    dims = (30, 31, 32)
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    op = Operator(n, csr=(rp, ci, va))
+    kw = dict(numEvals=6, eps=1e-9, aNorm=12.0, v0=problems.start_vector(n))
+    a = eigsh(op, backend="hip", **kw)
+    monkeypatch.setenv("PRIMME_AMD_DEVICE_RR", "1")
+    b = eigsh(op, backend="hip", **kw)
+    assert a.ret == 0 and b.ret == 0
+    assert np.max(np.abs(a.evals - b.evals)) <= 1e-10 * 12.0
+    assert np.max(np.abs(b.evals - problems.laplacian_eigenvalues(dims, 6))) <= 1e-10 * 12.0
+    assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= 0.05 * a.stats["numOuterIterations"] + 2
