@@ -237,3 +237,22 @@ def test_hip_device_rayleigh_ritz_option(built, monkeypatch):
     assert np.max(np.abs(a.evals - b.evals)) <= 1e-10 * 12.0
     assert np.max(np.abs(b.evals - problems.laplacian_eigenvalues(dims, 6))) <= 1e-10 * 12.0
     assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= 0.05 * a.stats["numOuterIterations"] + 2
+
+
+@pytest.mark.parametrize("projection", ["RR", "harmonic", "refined"])
+def test_hip_interior_pairs_medium_size(built, projection):
+    """Interior eigenvalues of a 3-D Laplacian (analytic spectrum) with the three extractions, JDQMR
+    as the correction: right values, residuals under the threshold, orthonormal."""
+    dims = (20, 21, 19)
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    i, j, k = np.meshgrid(*(np.arange(1, d + 1) for d in dims), indexing="ij")
+    w = (6 - 2 * np.cos(i * np.pi / (dims[0] + 1)) - 2 * np.cos(j * np.pi / (dims[1] + 1)) - 2 * np.cos(k * np.pi / (dims[2] + 1))).ravel()
+    shift = 1.0
+    want = np.sort(w[np.argsort(np.abs(w - shift))][:4])
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hip", numEvals=4, target="closest_abs", targetShifts=[shift], eps=1e-8,
+              aNorm=12.0, method="JDQMR", projection=projection, v0=problems.start_vector(n), maxMatvecs=200000)
+    assert r.ret == 0
+    assert np.max(np.abs(np.sort(r.evals) - want)) <= 1e-8 * 12.0
+    assert np.all(r.resNorms <= 1e-8 * 12.0 * (1 + 1e-6))
+    X = np.asarray(r.evecs, dtype=np.float64)
+    assert np.linalg.norm(X.T @ X - np.eye(4)) <= 1e-7
