@@ -152,10 +152,28 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
       int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
       int *lockedFlags, double *lockedNorms, primme_event event) {
    primme_params *p = s->p;
-   if (!p->monitorFun) return;
+   p->stats.elapsedTime = pa_wtime() - s->startTime;
+   if (!p->monitorFun) {
+      /* the reference's default report (primme_c.c:602-700), same lines so that logs stay comparable */
+      if (!p->outputFile || p->procID != 0 || p->printLevel < 2) return;
+      const int found = p->locking ? numLocked : numConverged;
+      if (event == primme_event_outer_iteration && p->printLevel >= 3) {
+         for (int i = 0; i < blockSize; i++)
+            fprintf(p->outputFile, "OUT %lld conv %d blk %d MV %lld Sec %E EV %13E |r| %.3E\n",
+                  (long long)p->stats.numOuterIterations, found, i, (long long)p->stats.numMatvecs, p->stats.elapsedTime,
+                  basisEvals[iblock[i]], basisNorms[iblock[i]]);
+      } else if (event == primme_event_converged && ((!p->locking && p->printLevel >= 2) || (p->locking && p->printLevel >= 5))) {
+         fprintf(p->outputFile, "#Converged %d eval[ %d ]= %13E norm %e Mvecs %lld Time %g\n", numConverged, iblock[0],
+               basisEvals[iblock[0]], basisNorms[iblock[0]], (long long)p->stats.numMatvecs, p->stats.elapsedTime);
+      } else if (event == primme_event_locked) {
+         fprintf(p->outputFile, "Lock epair[ %d ]= %13E norm %.4e Mvecs %lld Time %.4e Flag %d\n", numLocked,
+               lockedEvals[numLocked - 1], lockedNorms[numLocked - 1], (long long)p->stats.numMatvecs, p->stats.elapsedTime,
+               lockedFlags[numLocked - 1]);
+      }
+      return;
+   }
    int err = 0;
    double time = 0.0;
-   p->stats.elapsedTime = pa_wtime() - s->startTime;
    p->monitorFun(basisEvals, &basisSize, basisFlags, iblock, &blockSize, basisNorms, &numConverged,
          lockedEvals, &numLocked, lockedFlags, lockedNorms, NULL, NULL, NULL, &time, &event, p, &err);
 }
