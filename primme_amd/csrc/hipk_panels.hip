@@ -148,6 +148,72 @@ dots_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int64_t 
    }
 }
 
+/* Several right-hand columns (block methods): one WAVE per chunk of NC basis columns, all waves of
+ * a workgroup walk the SAME rows, so the NX right-hand columns are fetched from HBM once per
+ * workgroup (the other waves hit the CU's L1) instead of once per column chunk.  Each wave reduces
+ * its own NC x NX block of the result; no cross-wave reduction is needed. */
+template <typename T, int NC, int NX, int VW, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+dots_wide_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int64_t m,
+      double *__restrict__ partials) {
+   typedef lanevec<T, VW> LV;
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+   const int j0 = (blockIdx.y * WAVES + wv) * NC;
+   const int c0 = blockIdx.z * NX;
+   const int ncv = min(NC, segs.total - j0);     /* <= 0: this wave has no columns (still walks along) */
+   const int nxv = min(NX, nx - c0);
+   const T *cp[NC];
+#pragma unroll
+   for (int jj = 0; jj < NC; jj++) cp[jj] = seg_col<T>(segs, (jj < ncv) ? j0 + jj : 0);
+   const T *xp = X + (size_t)c0 * (size_t)ldX;
+   double acc[NC][NX];
+#pragma unroll
+   for (int jj = 0; jj < NC; jj++)
+#pragma unroll
+      for (int c = 0; c < NX; c++) acc[jj][c] = 0.0;
+   const int64_t stride = (int64_t)gridDim.x * 64;
+   const int64_t mg = m / VW;
+   if (ncv > 0) {
+      for (int64_t g = (int64_t)blockIdx.x * 64 + lane; g < mg; g += stride) {
+         LV xv[NX], a[NC];
+#pragma unroll
+         for (int c = 0; c < NX; c++)
+            if (c < nxv) xv[c] = ((const LV *)(xp + (size_t)c * ldX))[g];
+#pragma unroll
+         for (int jj = 0; jj < NC; jj++)
+            if (jj < ncv) a[jj] = ((const LV *)cp[jj])[g];
+#pragma unroll
+         for (int jj = 0; jj < NC; jj++)
+            if (jj < ncv) {
+#pragma unroll
+               for (int c = 0; c < NX; c++)
+                  if (c < nxv) {
+#pragma unroll
+                     for (int r = 0; r < VW; r++) acc[jj][c] = fma((double)a[jj].e[r], (double)xv[c].e[r], acc[jj][c]);
+                  }
+            }
+      }
+      if (VW > 1 && blockIdx.x == 0 && lane < (int)(m - mg * VW)) {
+         const int64_t i = mg * VW + lane;
+#pragma unroll
+         for (int jj = 0; jj < NC; jj++)
+            if (jj < ncv) {
+#pragma unroll
+               for (int c = 0; c < NX; c++)
+                  if (c < nxv) acc[jj][c] = fma((double)cp[jj][i], (double)xp[i + (size_t)c * ldX], acc[jj][c]);
+            }
+      }
+#pragma unroll
+      for (int jj = 0; jj < NC; jj++)
+#pragma unroll
+         for (int c = 0; c < NX; c++) {
+            const double v = hipk_wave_sum(acc[jj][c]);
+            if (lane == 0 && jj < ncv && c < nxv)
+               partials[(size_t)blockIdx.x * ((size_t)segs.total * nx) + (size_t)(j0 + jj) + (size_t)(c0 + c) * segs.total] = v;
+         }
+   }
+}
+
 template <typename T, int VW>
 static void dots_launch(hipk_ctx *ctx, dim3 grid, int nxt, const SegArgs &sa, const T *X, int64_t ldX,
       int nx, int64_t m) {
@@ -173,10 +239,23 @@ static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X,
    /* keep the chip full when the chunk grid is already wide */
    while (gx > 1 && (int64_t)gx * gy * gz > (int64_t)ctx->num_cu * 8) gx = (gx + 1) / 2;
    size_t nout = (size_t)sa.total * nx;
+   /* blocks of right-hand columns against more than one chunk of basis columns: wave-per-chunk
+    * kernel, the right-hand columns are read once per workgroup */
+   const bool wide = (nx >= 4 && sa.total > NC && vec);
+   if (wide) {
+      const int WAVES = 4;
+      gx = hipk_grid_for_rows(ctx, m / VWm + 1, 64 * 4, 8);
+      gy = (sa.total + NC * WAVES - 1) / (NC * WAVES);
+      nxt = (nx <= 4) ? 4 : 8;
+      gz = (nx + nxt - 1) / nxt;
+   }
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    dim3 grid(gx, gy, gz);
    const int pslot = hipk_prof_begin(HIPK_PROF_DOTS, ctx->stream, (double)m * sizeof(T) * (sa.total + nx));
-   if (vec) dots_launch<T, vecwidth<T>::value>(ctx, grid, nxt, sa, X, ldX, nx, m);
+   if (wide) {
+      if (nxt == 4) hipLaunchKernelGGL((dots_wide_kernel<T, 8, 4, vecwidth<T>::value, 4>), grid, dim3(256), 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials);
+      else hipLaunchKernelGGL((dots_wide_kernel<T, 8, 8, vecwidth<T>::value, 4>), grid, dim3(256), 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials);
+   } else if (vec) dots_launch<T, vecwidth<T>::value>(ctx, grid, nxt, sa, X, ldX, nx, m);
    else dots_launch<T, 1>(ctx, grid, nxt, sa, X, ldX, nx, m);
    hipk_prof_end(pslot, ctx->stream);
    HIPK_CHECK(hipGetLastError());
