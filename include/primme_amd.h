@@ -193,7 +193,11 @@ int  primme_params_destroy(primme_params *primme);
  *   returns 0, or <0 (codes above); primme->initSize = converged pairs returned;
  *   primme->stats filled; primme->aNorm back-filled when it was <= 0.
  * Requires the GPU: there is no CPU fallback; a missing/failed device returns
- * PRIMME_UNEXPECTED_FAILURE. */
+ * PRIMME_UNEXPECTED_FAILURE.
+ * hip_zprimme / hip_cprimme (Hermitian problems; evecs and the callbacks' vectors are DEVICE
+ * arrays of (re, im) pairs, leading dimensions in complex elements exactly as for
+ * cublas_zprimme) run on the real-equivalent form of the problem (csrc/eigs_complex.c): same
+ * eigenpairs and residual norms as zprimme, about twice its operator applications. */
 int hip_dprimme(double *evals, double *evecs, double *resNorms, primme_params *primme);
 int hip_zprimme(double *evals, void *evecs, double *resNorms, primme_params *primme);
 int hip_sprimme(float *evals, float *evecs, float *resNorms, primme_params *primme);

@@ -44,6 +44,10 @@ int primme_amd_operator_destroy(primme_amd_operator *op);
  * diag(A) - ShiftsForPreconditioner[c] (reference tests/COMMON/mat.c:187-193, examples/
  * ex_eigs_dseq.c:187-202); fixed = 1 by diag(A) - shift (mat.c:137-147, :166-170) */
 int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double shift);
+/* on = 1: the matrix is the real-equivalent form (primme_amd_csr_complex_to_real) of a Hermitian
+ * matrix and primme_amd_matvec / primme_amd_jacobi_precond are called by hip_zprimme /
+ * hip_cprimme with leading dimensions counted in complex elements */
+int primme_amd_operator_set_complex(primme_amd_operator *op, int on);
 hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op);
 /* y = A x on `hip_stream` including the halo exchange */
 int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stream, const void *x, int64_t ldx,

@@ -8,6 +8,9 @@
  *   primme_amd_csr_tile_block_diagonal   block-diagonal tiling, tile t scaled by
  *                        scale0 + scale_step * t (BASELINE configs[2] from tests/LUNDA.mtx)
  *   primme_amd_csr_transpose             explicit transpose (singular value operator)
+ *   primme_amd_csr_complex_to_real       2n x 2n real-equivalent form of a complex matrix in the
+ *                        interleaved (re, im) ordering: the operator hip_zprimme / hip_cprimme
+ *                        are given for a Hermitian CSR matrix (primme_amd.h)
  *
  * 0-based int32 indices; values double (complex: re, im interleaved).  Returned arrays are
  * malloc'ed by the library: release them with primme_amd_host_free.  Return 0 on success,
@@ -26,6 +29,8 @@ int primme_amd_csr_transpose(int64_t m, int64_t n, const int32_t *rowptr, const 
 int primme_amd_csr_tile_block_diagonal(int64_t n0, const int32_t *rowptr, const int32_t *colind,
       const double *values, int64_t ntiles, int64_t first_tile, double scale0, double scale_step,
       int32_t **rowptr_out, int32_t **colind_out, double **values_out);
+int primme_amd_csr_complex_to_real(int64_t n, const int32_t *rowptr, const int32_t *colind,
+      const double *values_re_im, int32_t **rowptr_out, int32_t **colind_out, double **values_out);
 void primme_amd_host_free(void *p);
 #ifdef __cplusplus
 }

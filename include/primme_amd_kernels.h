@@ -129,6 +129,11 @@ int hipk_xpay_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_
       const void *X, int64_t ldX, void *Y, int64_t ldY, int nx);
 int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
       void *Y, int64_t ldY, int nx);
+/* Y = i * X for columns of npairs (re, im) pairs stored as 2*npairs reals: (re, im) -> (-im, re).
+ * The one kernel the real-equivalent treatment of Hermitian problems needs beyond the real
+ * panel kernels (eigs_complex.c); dt is the REAL type of the parts.  X and Y distinct. */
+int hipk_pair_rotate(hipk_ctx *ctx, hipk_dtype dt, int64_t npairs, const void *X, int64_t ldX,
+      void *Y, int64_t ldY, int nx);
 /* Y(:,i) = X(:,perm[i]) for i < n, X and Y distinct panels */
 int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
       const int *perm_host, int n, void *Y, int64_t ldY);

@@ -196,6 +196,19 @@ int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64
    for (int c = 0; c < nx; c++) memmove((void *)colp(dt, Y, ldY, c), colp(dt, X, ldX, c), (size_t)m * esz(dt));
    return 0;
 }
+int hipk_pair_rotate(hipk_ctx *ctx, hipk_dtype dt, int64_t npairs, const void *X, int64_t ldX, void *Y, int64_t ldY, int nx) {
+   (void)ctx;
+   for (int c = 0; c < nx; c++) {
+      if (dt == HIPK_F64) {
+         const double *x = (const double *)colp(dt, X, ldX, c); double *y = (double *)colp(dt, Y, ldY, c);
+         for (int64_t i = 0; i < npairs; i++) { double re = x[2 * i], im = x[2 * i + 1]; y[2 * i] = -im; y[2 * i + 1] = re; }
+      } else {
+         const float *x = (const float *)colp(dt, X, ldX, c); float *y = (float *)colp(dt, Y, ldY, c);
+         for (int64_t i = 0; i < npairs; i++) { float re = x[2 * i], im = x[2 * i + 1]; y[2 * i] = -im; y[2 * i + 1] = re; }
+      }
+   }
+   return 0;
+}
 int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const int *perm, int n,
       void *Y, int64_t ldY) {
    (void)ctx;

@@ -9,10 +9,11 @@
 #include "primme_amd_svds.h"
 #include "primme_amd_io.h"
 
-struct primme_amd_operator { hipk_csr *A; int jacobi_fixed; double jacobi_shift; };
+struct primme_amd_operator { hipk_csr *A; int jacobi_fixed; double jacobi_shift; int ldscale; };
+int primme_amd_operator_set_complex(primme_amd_operator *op, int on) { op->ldscale = on ? 2 : 1; return 0; }
 int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double shift) { op->jacobi_fixed = fixed; op->jacobi_shift = shift; return 0; }
 int primme_amd_operator_create(primme_amd_operator **op, hipk_csr *A, primme_amd_comm *c) {
-   (void)c; *op = calloc(1, sizeof(**op)); (*op)->A = A; return 0;
+   (void)c; *op = calloc(1, sizeof(**op)); (*op)->A = A; (*op)->ldscale = 1; return 0;
 }
 int primme_amd_operator_destroy(primme_amd_operator *op) { free(op); return 0; }
 hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op) { return op->A; }
@@ -20,7 +21,8 @@ int primme_amd_operator_apply(primme_amd_operator *op, void *st, const void *x, 
    return hipk_csr_matvec(op->A, st, x, ldx, y, ldy, nc);
 }
 void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
-   *ierr = primme_amd_operator_apply((primme_amd_operator *)p->matrix, NULL, x, *ldx, y, *ldy, *bs);
+   primme_amd_operator *op = (primme_amd_operator *)p->matrix;
+   *ierr = primme_amd_operator_apply(op, NULL, x, *ldx * op->ldscale, y, *ldy * op->ldscale, *bs);
 }
 void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)p->preconditioner;
@@ -28,7 +30,7 @@ void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ld
    for (int c = 0; c < *bs && c < 64; c++) fixed[c] = op->jacobi_shift;
    *ierr = hipk_jacobi_apply(NULL, hipk_csr_dtype(op->A), hipk_csr_nrows(op->A), hipk_csr_diag(op->A),
          op->jacobi_fixed ? fixed : p->ShiftsForPreconditioner, 1e-14 * (p->aNorm >= 0.0 ? p->aNorm : 1.0),
-         x, *ldx, y, *ldy, *bs);
+         x, *ldx * op->ldscale, y, *ldy * op->ldscale, *bs);
 }
 void primme_amd_global_sum(void *s, void *r, int *c, struct primme_params *p, int *ierr) {
    (void)s; (void)r; (void)c; (void)p; *ierr = 1; /* RCCL only exists in the product library */

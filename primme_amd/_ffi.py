@@ -169,10 +169,11 @@ def _declare_solver(lib, prefix):
     lib.primme_svds_initialize.restype = None
     lib.primme_svds_set_method.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(PrimmeSvdsParams)]
     lib.primme_svds_set_method.restype = C.c_int
-    for t in "ds":
+    for t in "dszc":
         f = getattr(lib, f"{prefix}{t}primme", None)
         if f is not None:
             f.argtypes = [_vp, _vp, _vp, C.POINTER(PrimmeParams)]
+            f.restype = C.c_int
         f = getattr(lib, f"{prefix}{t}primme_svds", None)
         if f is not None:
             f.argtypes = [_vp, _vp, _vp, C.POINTER(PrimmeSvdsParams)]
@@ -219,6 +220,9 @@ def _declare_kernels(lib):
         "primme_amd_csr_transpose": [_i64, _i64, _vp, _vp, _vp, C.c_size_t, P(_vp), P(_vp), P(_vp)],
         "primme_amd_csr_tile_block_diagonal": [_i64, _vp, _vp, _vp, _i64, _i64, C.c_double, C.c_double, P(_vp), P(_vp), P(_vp)],
         "primme_amd_operator_apply": [_vp, _vp, _vp, _i64, _vp, _i64, _i],
+        "primme_amd_csr_complex_to_real": [_i64, _vp, _vp, _vp, P(_vp), P(_vp), P(_vp)],
+        "primme_amd_operator_set_complex": [_vp, _i],
+        "hipk_pair_rotate": [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i],
     }
     for name, args in sig.items():
         f = getattr(lib, name)

@@ -38,6 +38,7 @@ class Operator:
             d = len([x for x in self.stencil if x and x > 1])
             return np.full(self.nrows, 2.0 * max(d, 1))
         rp, ci, va = self.csr
+        va = np.real(va)
         rows = np.repeat(np.arange(self.nrows), np.diff(rp))
         dg = np.zeros(self.nrows)
         m = ci == rows + self.row0
@@ -60,7 +61,10 @@ class Session:
     def __init__(self, op, comm=None, dtype=np.float64, backend="hip"):
         self.op, self.comm, self.backend = op, comm, backend
         self.dtype = np.dtype(dtype)
-        self.dt = F.HIPK_F64 if self.dtype == np.float64 else F.HIPK_F32
+        # Hermitian problems: complex vectors, solved in the real-equivalent form (csrc/eigs_complex.c)
+        self.cplx = self.dtype.kind == "c"
+        self.rdtype = np.dtype(np.float64 if self.dtype in (np.float64, np.complex128) else np.float32)
+        self.dt = F.HIPK_F64 if self.rdtype == np.float64 else F.HIPK_F32
         self.handles = []
         self.keep = []
         self._v0_cache = None
@@ -83,9 +87,21 @@ class Session:
             rp, ci, va = op.csr
             rp = np.ascontiguousarray(rp, dtype=np.int32)
             ci = np.ascontiguousarray(ci, dtype=np.int32)
-            va = np.ascontiguousarray(va, dtype=self.dtype)
-            rc = lib.hipk_csr_create(ctx, self.dt, op.nrows, op.n, op.row0, rp.ctypes.data_as(C.c_void_p),
-                                     ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), C.byref(A))
+            if self.cplx:
+                vz = np.ascontiguousarray(va, dtype=np.complex128)
+                rp2, ci2, va2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+                rc = lib.primme_amd_csr_complex_to_real(op.nrows, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                                        vz.ctypes.data_as(C.c_void_p), C.byref(rp2), C.byref(ci2), C.byref(va2))
+                if rc:
+                    raise RuntimeError(f"real-equivalent expansion failed: {rc}")
+                nnz2 = 4 * int(rp[-1])
+                v2 = np.ctypeslib.as_array(C.cast(va2, C.POINTER(C.c_double)), shape=(max(nnz2, 1),)).astype(self.rdtype)
+                rc = lib.hipk_csr_create(ctx, self.dt, 2 * op.nrows, 2 * op.n, 2 * op.row0, rp2, ci2, v2.ctypes.data_as(C.c_void_p), C.byref(A))
+                for h in (rp2, ci2, va2): lib.primme_amd_host_free(h)
+            else:
+                va = np.ascontiguousarray(va, dtype=self.dtype)
+                rc = lib.hipk_csr_create(ctx, self.dt, op.nrows, op.n, op.row0, rp.ctypes.data_as(C.c_void_p),
+                                         ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), C.byref(A))
         else:
             nx, ny, nz = (list(op.stencil) + [1, 1])[:3]
             rc = lib.hipk_stencil_create(ctx, self.dt, nx, ny or 1, nz or 1, op.row0, op.nrows, C.byref(A))
@@ -96,6 +112,7 @@ class Session:
         if lib.primme_amd_operator_create(C.byref(oph), A, comm):
             raise RuntimeError("operator handle creation failed")
         self.handles.append(("op", oph))
+        if self.cplx: lib.primme_amd_operator_set_complex(oph, 1)
         self.oph = oph
 
     def close(self):
@@ -109,7 +126,8 @@ class Session:
               maxBlockSize=0, maxBasisSize=0, minRestartSize=0, maxPrevRetain=None, locking=None,
               maxMatvecs=0, maxOuterIterations=0, targetShifts=None, precond=None, printLevel=0,
               initBasisMode=None, global_sum=None, numProcs=1, procID=0, orth=None, iseed=None,
-              profile=False, return_evecs=True, monitor=None, user_matvec=None, projection=None):
+              profile=False, return_evecs=True, monitor=None, user_matvec=None, projection=None,
+              constraints=None):
         lib, op, dtype, backend = self.lib, self.op, self.dtype, self.backend
         keep = []
         p = F.PrimmeParams()
@@ -141,19 +159,28 @@ class Session:
             keep.append(ts)
             p.targetShifts, p.numTargetShifts = ts, len(targetShifts)
         p.initSize = initSize
+        # orthogonality constraints: the first numOrthoConst columns of evecs (primme_eigs.h:266-269)
+        cons = None if constraints is None else np.asarray(constraints, dtype=dtype).reshape(nLocal, -1)
+        nOC = 0 if cons is None else cons.shape[1]
+        p.numOrthoConst = nOC
         if initBasisMode is not None: p.initBasisMode = initBasisMode
         p.numProcs, p.procID, p.nLocal = numProcs, procID, nLocal
         m = F.METHODS[method] if isinstance(method, str) else method
-        ncols = max(numEvals, initSize)
-        ctype = C.c_double if dtype == np.float64 else C.c_float
+        ncols = nOC + max(numEvals, initSize)
+        ctype = C.c_double if self.rdtype == np.float64 else C.c_float
+        cplx = self.cplx
         evecs_t = None
+
+        def view(ptr, nb, ld):
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(nb, ld * (2 if cplx else 1)))
+            return a.view(dtype) if cplx else a
 
         if backend == "reference":
             def mv(x, ldx, y, ldy, bs, pp, ierr):
                 nb, lx, ly = bs[0], ldx[0], ldy[0]
-                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
-                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
-                Y[:, :nLocal] = op.apply_numpy(X[:, :nLocal].T.astype(np.float64)).T
+                X = view(x, nb, lx)
+                Y = view(y, nb, ly)
+                Y[:, :nLocal] = op.apply_numpy(X[:, :nLocal].T.astype(np.complex128 if cplx else np.float64)).T
                 ierr[0] = 0
             cb = F.BLOCK_OP(mv)
             keep.append(cb)
@@ -167,8 +194,8 @@ class Session:
                     if nb <= 0 or not x or not y:
                         ierr[0] = 0
                         return
-                    X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
-                    Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
+                    X = view(x, nb, lx)
+                    Y = view(y, nb, ly)
                     sh = pp[0].ShiftsForPreconditioner
                     an = pp[0].aNorm
                     mind = 1e-14 * (an if an >= 0 else 1.0)
@@ -183,10 +210,12 @@ class Session:
                 p.applyPreconditioner = C.cast(pcb, C.c_void_p)
                 p.correctionParams.precondition = 1
             evecs = np.zeros((ncols, nLocal), dtype=dtype)  # row-major (ncols x n) == col-major n x ncols
+            if cons is not None:
+                evecs[:nOC] = cons.T
             if v0 is not None:
-                evecs[:initSize] = v0.T
+                evecs[nOC:nOC + initSize] = v0.T
             evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
-            solver = lib.dprimme if dtype == np.float64 else lib.sprimme
+            solver = {"float64": lib.dprimme, "float32": lib.sprimme, "complex128": lib.zprimme, "complex64": lib.cprimme}[dtype.name]
         else:
             p.matrix = self.oph
             p.matrixMatvec = C.cast(lib.primme_amd_matvec, C.c_void_p)
@@ -207,22 +236,26 @@ class Session:
                 p.profile = b"phases"
             if backend == "hip":
                 import torch
-                tdt = torch.float64 if dtype == np.float64 else torch.float32
+                tdt = {"float64": torch.float64, "float32": torch.float32, "complex128": torch.complex128, "complex64": torch.complex64}[dtype.name]
                 evecs_t = torch.zeros((ncols, nLocal), dtype=tdt, device="cuda")
                 if v0 is not None:
                     # the start vectors are uploaded once per Session and stay in HBM
                     key = (v0.shape, float(v0.ravel()[0]), float(v0.ravel()[-1]))
                     if self._v0_cache is None or self._v0_cache[0] != key:
                         self._v0_cache = (key, torch.from_numpy(np.ascontiguousarray(v0.T)).to("cuda"))
-                    evecs_t[:initSize] = self._v0_cache[1]
+                    evecs_t[nOC:nOC + initSize] = self._v0_cache[1]
+                if cons is not None:
+                    evecs_t[:nOC] = torch.from_numpy(np.ascontiguousarray(cons.T)).to("cuda")
                 torch.cuda.synchronize()
                 evecs_ptr = C.c_void_p(evecs_t.data_ptr())
             else:
                 evecs = np.zeros((ncols, nLocal), dtype=dtype)
+                if cons is not None:
+                    evecs[:nOC] = cons.T
                 if v0 is not None:
-                    evecs[:initSize] = v0.T
+                    evecs[nOC:nOC + initSize] = v0.T
                 evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
-            solver = lib.hip_dprimme if dtype == np.float64 else lib.hip_sprimme
+            solver = {"float64": lib.hip_dprimme, "float32": lib.hip_sprimme, "complex128": lib.hip_zprimme, "complex64": lib.hip_cprimme}[dtype.name]
 
         if global_sum is not None:
             def gs(send, recv, count, pp, ierr):
@@ -240,14 +273,14 @@ class Session:
 
         if lib.primme_set_method(m, C.byref(p)):
             raise ValueError("unknown method")
-        evals = np.zeros(numEvals, dtype=dtype)
-        resNorms = np.zeros(numEvals, dtype=dtype)
+        evals = np.zeros(numEvals, dtype=self.rdtype)
+        resNorms = np.zeros(numEvals, dtype=self.rdtype)
         ret = solver(evals.ctypes.data_as(C.c_void_p), evecs_ptr, resNorms.ctypes.data_as(C.c_void_p), C.byref(p))
         if backend == "hip":
             import torch
             torch.cuda.synchronize()
             evecs = evecs_t.cpu().numpy() if return_evecs else None
-        return Result(ret, evals, None if evecs is None else evecs[:numEvals].T.copy(), resNorms, p)
+        return Result(ret, evals, None if evecs is None else evecs[nOC:nOC + numEvals].T.copy(), resNorms, p)
 
 
 def eigsh(op, backend="hip", comm=None, dtype=np.float64, **kw):

@@ -20,6 +20,8 @@ struct primme_amd_operator {
    int64_t row0, nrows, n;
    int jacobi_fixed;         /* 1: K = diag(A) - jacobi_shift, 0: per-vector shifts of the solver */
    double jacobi_shift;
+   int ldscale;              /* 2 when A is the real-equivalent form of a Hermitian matrix and the
+                                callbacks are handed leading dimensions in complex elements */
 };
 
 static size_t op_elem(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : dt == HIPK_F32 ? 4 : 16; }
@@ -27,7 +29,7 @@ static size_t op_elem(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : dt == HIPK_F3
 extern "C" int primme_amd_operator_create(primme_amd_operator **out, hipk_csr *A, primme_amd_comm *comm) {
    primme_amd_operator *op = (primme_amd_operator *)calloc(1, sizeof(*op));
    if (!op) return -2;
-   op->A = A; op->comm = comm;
+   op->A = A; op->comm = comm; op->ldscale = 1;
    op->lo = hipk_csr_halo_lo(A); op->hi = hipk_csr_halo_hi(A);
    op->nrows = hipk_csr_nrows(A);
    if ((op->lo > 0 || op->hi > 0) && !comm) {
@@ -124,7 +126,7 @@ extern "C" void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT 
       struct primme_params *primme, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)primme->matrix;
    void *stream = primme->queue ? (void *)*(hipStream_t *)primme->queue : NULL;
-   *ierr = op ? primme_amd_operator_apply(op, stream, x, *ldx, y, *ldy, *blockSize) : 1;
+   *ierr = op ? primme_amd_operator_apply(op, stream, x, *ldx * op->ldscale, y, *ldy * op->ldscale, *blockSize) : 1;
 }
 
 extern "C" void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy,
@@ -136,7 +138,13 @@ extern "C" void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRI
    for (int c = 0; c < *blockSize; c++) fixed[c] = op->jacobi_shift;
    *ierr = hipk_jacobi_apply(stream, hipk_csr_dtype(op->A), hipk_csr_nrows(op->A), hipk_csr_diag(op->A),
          op->jacobi_fixed ? fixed : primme->ShiftsForPreconditioner,
-         1e-14 * (primme->aNorm >= 0.0 ? primme->aNorm : 1.0), x, *ldx, y, *ldy, *blockSize);
+         1e-14 * (primme->aNorm >= 0.0 ? primme->aNorm : 1.0), x, *ldx * op->ldscale, y, *ldy * op->ldscale, *blockSize);
+}
+
+extern "C" int primme_amd_operator_set_complex(primme_amd_operator *op, int on) {
+   if (!op) return -1;
+   op->ldscale = on ? 2 : 1;
+   return 0;
 }
 
 extern "C" int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double shift) {

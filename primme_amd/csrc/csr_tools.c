@@ -5,6 +5,7 @@
  *                                    symmetric / Hermitian / skew expansion, sorted rows)
  *   primme_amd_csr_tile_block_diagonal  the tiler that builds BASELINE configs[2] from LUNDA.mtx
  *   primme_amd_csr_transpose      explicit A' for the singular value operator
+ *   primme_amd_csr_complex_to_real  Hermitian matrix -> symmetric real-equivalent form
  *
  * Indices are 0-based int32 (the device kernels' format); values are double, complex as
  * (re, im) pairs.  Everything returned is malloc'ed; release with primme_amd_host_free. */
@@ -130,5 +131,36 @@ int primme_amd_csr_tile_block_diagonal(int64_t n0, const int32_t *rp, const int3
       }
    }
    *rp_out = trp; *ci_out = tci; *val_out = tva;
+   return 0;
+}
+
+/* Real-equivalent form of a complex CSR matrix in the interleaved ordering: entry a + ib at
+ * (i, j) becomes the 2x2 block [a -b; b a] at rows 2i, 2i+1 and columns 2j, 2j+1, so that the
+ * 2n real vector (re0, im0, re1, im1, ...) -- the memory of the complex n-vector -- is mapped to
+ * the memory of A x.  A Hermitian gives a symmetric matrix whose eigenvalues are those of A, each
+ * twice (eigs_complex.c).  values: (re, im) pairs of double. */
+int primme_amd_csr_complex_to_real(int64_t n, const int32_t *rp, const int32_t *ci, const double *val,
+      int32_t **rp_out, int32_t **ci_out, double **val_out) {
+   const int64_t nnz = rp[n];
+   if (2 * n >= 2147483647LL || 4 * nnz >= 2147483647LL) return -4;
+   int32_t *rp2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * n + 1));
+   int32_t *ci2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(4 * nnz > 0 ? 4 * nnz : 1));
+   double *va2 = (double *)malloc(sizeof(double) * (size_t)(4 * nnz > 0 ? 4 * nnz : 1));
+   if (!rp2 || !ci2 || !va2) { free(rp2); free(ci2); free(va2); return -5; }
+   int64_t o = 0;
+   rp2[0] = 0;
+   for (int64_t i = 0; i < n; i++) {
+      for (int32_t k = rp[i]; k < rp[i + 1]; k++) {   /* row 2i: (a, -b) */
+         ci2[o] = 2 * ci[k];     va2[o++] = val[2 * (size_t)k];
+         ci2[o] = 2 * ci[k] + 1; va2[o++] = -val[2 * (size_t)k + 1];
+      }
+      rp2[2 * i + 1] = (int32_t)o;
+      for (int32_t k = rp[i]; k < rp[i + 1]; k++) {   /* row 2i+1: (b, a) */
+         ci2[o] = 2 * ci[k];     va2[o++] = val[2 * (size_t)k + 1];
+         ci2[o] = 2 * ci[k] + 1; va2[o++] = val[2 * (size_t)k];
+      }
+      rp2[2 * i + 2] = (int32_t)o;
+   }
+   *rp_out = rp2; *ci_out = ci2; *val_out = va2;
    return 0;
 }

@@ -911,12 +911,7 @@ int hip_dprimme(double *evals, double *evecs, double *resNorms, primme_params *p
 int hip_sprimme(float *evals, float *evecs, float *resNorms, primme_params *primme) {
    return solve(evals, evecs, resNorms, primme, HIPK_F32, 0);
 }
-int hip_zprimme(double *evals, void *evecs, double *resNorms, primme_params *primme) {
-   return solve(evals, evecs, resNorms, primme, HIPK_C64, 0);
-}
-int hip_cprimme(float *evals, void *evecs, float *resNorms, primme_params *primme) {
-   return solve(evals, evecs, resNorms, primme, HIPK_C32, 0);
-}
+/* hip_zprimme / hip_cprimme: eigs_complex.c */
 
 /* internal entry for the svds front end: eigenvalues and residual norms always in double */
 int pa_eigs_solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double) {

@@ -858,6 +858,23 @@ scale_rsqrt_kernel(T *__restrict__ X, int64_t ldX, int nx, const double *__restr
    }
 }
 
+/* Y = i * X for columns holding (re, im) pairs: (re, im) -> (-im, re).  One pair per lane
+ * visit, 16- or 8-byte accesses. */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+pair_rotate_kernel(const T *__restrict__ X, int64_t ldX, T *__restrict__ Y, int64_t ldY, int nx, int64_t npairs) {
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *x = X + (size_t)c * ldX;
+      T *y = Y + (size_t)c * ldY;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < npairs; i += stride) {
+         const T re = x[2 * i], im = x[2 * i + 1];
+         y[2 * i] = -im;
+         y[2 * i + 1] = re;
+      }
+   }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 axpy_kernel(ColScal sc, const T *__restrict__ X, int64_t ldX, T *__restrict__ Y, int64_t ldY,
@@ -1064,6 +1081,17 @@ extern "C" int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const dou
             hipLaunchKernelGGL(axpy_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sc, (const T *)X + (size_t)c0 * ldX, ldX, (T *)Y + (size_t)c0 * ldY, ldY, n, m));
       HIPK_CHECK(hipGetLastError());
    }
+   return 0;
+}
+
+extern "C" int hipk_pair_rotate(hipk_ctx *ctx, hipk_dtype dt, int64_t npairs, const void *X, int64_t ldX,
+      void *Y, int64_t ldY, int nx) {
+   if (nx <= 0 || npairs <= 0) return 0;
+   int gx = hipk_grid_for_rows(ctx, npairs, HIPK_BLOCK * 4, 8);
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(pair_rotate_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (T *)Y, ldY, nx, npairs),
+         hipLaunchKernelGGL(pair_rotate_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (T *)Y, ldY, nx, npairs));
+   HIPK_CHECK(hipGetLastError());
    return 0;
 }
 

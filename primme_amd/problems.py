@@ -73,13 +73,15 @@ def start_vector(n, row0=0, nrows=None, j=0, dtype=np.float64):
 
 
 def read_matrix_market(path):
-    """Minimal Matrix-Market coordinate reader (real / symmetric / general), returns scipy-free
+    """Minimal Matrix-Market coordinate reader (real or complex; general / symmetric / Hermitian), returns scipy-free
     CSR (rowptr int32, colind int32, values float64, nrows, ncols).  Restates what the
     reference's test driver does with tests/COMMON/mmio.c + csr.c:46-265 (COO -> CSR,
     symmetric expansion)."""
     with open(path) as f:
         header = f.readline().lower().split()
         symmetric = "symmetric" in header
+        hermitian = "hermitian" in header
+        cplx = "complex" in header
         pattern = "pattern" in header
         line = f.readline()
         while line.startswith("%"):
@@ -89,9 +91,12 @@ def read_matrix_market(path):
     r = data[:, 0].astype(np.int64) - 1
     c = data[:, 1].astype(np.int64) - 1
     v = np.ones(len(r)) if pattern else data[:, 2].astype(np.float64)
-    if symmetric:
+    if cplx:
+        v = data[:, 2] + 1j * data[:, 3]
+    if symmetric or hermitian:
         off = r != c
-        r, c, v = np.concatenate([r, c[off]]), np.concatenate([c, r[off]]), np.concatenate([v, v[off]])
+        vm = np.conj(v[off]) if hermitian else v[off]
+        r, c, v = np.concatenate([r, c[off]]), np.concatenate([c, r[off]]), np.concatenate([v, vm])
     order = np.lexsort((c, r))
     r, c, v = r[order], c[order], v[order]
     rowptr = np.zeros(nr + 1, dtype=np.int64)
@@ -127,7 +132,11 @@ def csr_matvec_numpy(rowptr, colind, values, x):
     rows = np.repeat(np.arange(nrows), np.diff(rowptr.astype(np.int64)))
     y = np.zeros((nrows, xr.shape[1]), dtype=np.result_type(values, xr))
     for c in range(xr.shape[1]):
-        y[:, c] = np.bincount(rows, weights=values * xr[colind, c], minlength=nrows)
+        w = values * xr[colind, c]
+        if np.iscomplexobj(w):
+            y[:, c] = np.bincount(rows, weights=w.real, minlength=nrows) + 1j * np.bincount(rows, weights=w.imag, minlength=nrows)
+        else:
+            y[:, c] = np.bincount(rows, weights=w, minlength=nrows)
     return y.reshape((len(rowptr) - 1,) + x.shape[1:])
 
 
@@ -156,3 +165,21 @@ def svds_synthetic_csr(m, n, row0=0, nrows=None):
     rowptr = np.zeros(nrows + 1, dtype=np.int64)
     rowptr[1:] = np.cumsum(keep.sum(axis=1))
     return rowptr.astype(np.int32), cols[keep].astype(np.int32), vals[keep]
+
+
+def hermitian_banded_csr(n, row0=0, nrows=None, hbw=3):
+    """BASELINE configs[3]: complex Hermitian band matrix, diagonal
+    d_j = 2 + (j mod 97)/97, off-diagonals a_{j,j+q} = exp(0.37 i q)/(q+1), q = 1..hbw.
+    Rows [row0, row0+nrows) with global column numbers; returns (rowptr, colind, values complex128)."""
+    nrows = n - row0 if nrows is None else nrows
+    j = np.arange(row0, row0 + nrows, dtype=np.int64)
+    offs = np.arange(-hbw, hbw + 1)
+    cols = j[:, None] + offs[None, :]
+    ok = (cols >= 0) & (cols < n)
+    q = np.abs(offs)
+    band = np.where(offs > 0, np.exp(0.37j * q) / (q + 1.0), np.exp(-0.37j * q) / (q + 1.0))
+    vals = np.broadcast_to(band[None, :], cols.shape).copy()
+    vals[:, hbw] = 2.0 + (j % 97) / 97.0
+    rp = np.zeros(nrows + 1, dtype=np.int64)
+    rp[1:] = np.cumsum(ok.sum(axis=1))
+    return rp.astype(np.int32), cols[ok].astype(np.int32), vals[ok]

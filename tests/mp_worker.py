@@ -87,6 +87,20 @@ def run(rank, world, port, case, out_path):
         r = s.solve(numEvals=5, eps=1e-10, aNorm=8.0, v0=v0, numProcs=world, procID=rank, global_sum=global_sum,
                     user_matvec=cb)
         s.close()
+    elif case == "hermitian":
+        # complex Hermitian band matrix (BASELINE configs[3] in small) cut into independent diagonal
+        # blocks, one per rank: hip_zprimme's real-equivalent solve and its final complex
+        # Gram-Schmidt sweep both reduce through the user's globalSumReal
+        nloc = 150
+        n = nloc * world
+        rp, ci, va = problems.hermitian_banded_csr(nloc)
+        va = va * (1.0 + 0.21 * rank)
+        op = Operator(n, csr=(rp, (ci + rank * nloc).astype(np.int32), va), row0=rank * nloc, nrows=nloc)
+        s = Session(op, backend="hostcheck", dtype=np.complex128)
+        r = s.solve(numEvals=4, target="largest", eps=1e-10, numProcs=world, procID=rank, global_sum=global_sum,
+                    iseed=(5 + rank, 1, 2, 3))
+        s.close()
+        r.evecs = np.concatenate([r.evecs.real, r.evecs.imag])
     elif case == "svds":
         # A (m x n) split by rows, n-vectors split in equal slabs: y = A x needs an all-gather of x,
         # y = A' x a reduce-scatter of the local products (BASELINE configs[4] in small)

@@ -45,6 +45,35 @@ CASES = {
 }
 
 
+# tests/tests/test_10N: the complex Hermitian cases on mhd1280b.mtx (stored vectors sol_10N_doublecomplex).
+# hip_zprimme works on the real-equivalent form and needs about twice the operator applications of
+# zprimme, so test_101's cap of 140 (its "unrestarted" point: maxBasisSize = maxMatvecs) is lifted;
+# everything else is the file's setting.  test_102 / test_103 (27 / 50 pairs) are left to the real cases.
+CASES_Z = {
+    "test_101": dict(sol="sol_101_doublecomplex", kw=dict(numEvals=5, eps=1e-12, maxBasisSize=140, minRestartSize=1,
+                     maxBlockSize=1, target="largest", locking=1, method="GD_Olsen_plusK")),
+    "test_104": dict(sol="sol_104_doublecomplex", kw=dict(numEvals=2, eps=1e-8, maxMatvecs=100000, target="closest_abs",
+                     targetShifts=[1e-2], method="DEFAULT_MIN_TIME")),
+    # (the real form needs ~9000 outer iterations where zprimme needs ~3300: the file's cap of 4000 is lifted)
+    "test_105": dict(sol="sol_105_doublecomplex", kw=dict(numEvals=2, eps=1e-8, maxOuterIterations=40000, target="closest_abs",
+                     targetShifts=[1e-2], method="GD_Olsen_plusK", precond=("jacobi", -1e-2))),
+    "test_106": dict(sol="sol_106_doublecomplex", kw=dict(numEvals=5, eps=1e-12, maxOuterIterations=200, target="largest",
+                     method="DEFAULT_MIN_TIME", precond=("jacobi", 3e8))),
+}
+
+
+def mhd():
+    rp, ci, va, n, _ = problems.read_matrix_market(os.path.join(DATA, "mhd1280b.mtx"))
+    return rp, ci, va, n
+
+
+def read_sol_z(name, n):
+    d = np.fromfile(os.path.join(DATA, name), dtype=np.complex128)
+    assert int(round(-d[0].real)) == 16 and int(d[1].real) == n
+    cols = int(d[2].real)
+    return d[3:3 + n * cols].reshape(cols, n).T.copy()
+
+
 def lunda():
     rp, ci, va, n, _ = problems.read_matrix_market(os.path.join(DATA, "LUNDA.mtx"))
     return rp, ci, va, n
@@ -68,13 +97,13 @@ def check_solution(A_apply, evals, evecs, rnorms, aNorm, eps, X):
     meps = np.finfo(np.float64).eps
     for i in range(k):
         v = evecs[:, i]
-        h = evecs[:, :i + 1].T @ v
+        h = evecs[:, :i + 1].conj().T @ v
         if np.linalg.norm(h[:i]) > 1e-7:
             bad.append(f"ortho[{i}]={np.linalg.norm(h[:i]):.2e}")
-        if abs(np.sqrt(h[i]) - 1) > 1e-7:
+        if abs(np.sqrt(abs(h[i])) - 1) > 1e-7:
             bad.append(f"norm[{i}]")
         Ax = A_apply(v)
-        eval0 = v @ Ax
+        eval0 = np.vdot(v, Ax)
         if abs(evals[i] - eval0) > max(rnorms[i], aNorm * eps):
             bad.append(f"rayleigh[{i}]={abs(evals[i] - eval0):.2e}")
         r = Ax - evals[i] * v
@@ -82,11 +111,11 @@ def check_solution(A_apply, evals, evecs, rnorms, aNorm, eps, X):
         if abs(rnorms[i] - rnorm0) > max(2 * rnorm0, 10 * max(aNorm, abs(evals[i])) * meps):
             bad.append(f"resnorm[{i}] {rnorms[i]:.2e} vs {rnorm0:.2e}")
         # residual after projecting out the returned vectors (one Gram-Schmidt pass)
-        rp = r - evecs @ (evecs.T @ r)
+        rp = r - evecs @ (evecs.conj().T @ r)
         if aNorm > 0 and np.linalg.norm(rp) > eps * aNorm * 2:
             bad.append(f"rr_residual[{i}]={np.linalg.norm(rp):.2e}")
         # angle against the stored invariant subspace
-        prod = float(np.sum((X.T @ v) ** 2))
+        prod = float(np.sum(np.abs(X.conj().T @ v) ** 2))
         bound = aNorm * eps / delta
         s2 = np.sqrt(2.0)
         if (s2 * prod + 1.0) / (s2 * bound + 1.0) < (s2 * prod - 1.0) / (1.0 - s2 * bound):

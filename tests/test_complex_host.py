@@ -1,0 +1,168 @@
+"""Hermitian problems (hip_zprimme / hip_cprimme, csrc/eigs_complex.c) on the CPU checker back end:
+the product's host code over oracle/hipk_cpu.c, compared with dense truth, with the live reference
+zprimme / cprimme (oracle/_ref) and with the reference driver's complex regression cases
+(tests/tests/test_10N on mhd1280b.mtx, stored vectors sol_10N_doublecomplex)."""
+import os
+import numpy as np
+import pytest
+
+from primme_amd import _ffi as F
+from primme_amd import problems
+from primme_amd.api import Operator, eigsh
+import reference_driver_cases as RD
+
+
+def hermitian_band(n, seed=0, band=4):
+    rng = np.random.default_rng(seed)
+    A = np.zeros((n, n), dtype=np.complex128)
+    for k in range(1, band):
+        v = (rng.standard_normal(n - k) + 1j * rng.standard_normal(n - k)) * 0.3
+        A += np.diag(v, k) + np.diag(v.conj(), -k)
+    A += np.diag(np.arange(1, n + 1) * 0.5 + rng.standard_normal(n) * 0.1)
+    rows, cols = np.nonzero(A)
+    rp = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(rp, rows + 1, 1)
+    return A, (np.cumsum(rp).astype(np.int32), cols.astype(np.int32), A[rows, cols])
+
+
+def test_real_equivalent_expansion(built):
+    """primme_amd_csr_complex_to_real: M [re,im interleaved] = A z, M symmetric, spectrum doubled."""
+    import ctypes as C
+    lib = F.load_hostcheck()
+    n = 40
+    A, (rp, ci, va) = hermitian_band(n, seed=3)
+    o = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+    assert lib.primme_amd_csr_complex_to_real(n, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                              va.ctypes.data_as(C.c_void_p), *[C.byref(x) for x in o]) == 0
+    rp2 = np.ctypeslib.as_array(C.cast(o[0], C.POINTER(C.c_int32)), shape=(2 * n + 1,)).copy()
+    nnz2 = int(rp2[-1])
+    assert nnz2 == 4 * len(va)
+    ci2 = np.ctypeslib.as_array(C.cast(o[1], C.POINTER(C.c_int32)), shape=(nnz2,)).copy()
+    va2 = np.ctypeslib.as_array(C.cast(o[2], C.POINTER(C.c_double)), shape=(nnz2,)).copy()
+    for h in o: lib.primme_amd_host_free(h)
+    M = np.zeros((2 * n, 2 * n))
+    M[np.repeat(np.arange(2 * n), np.diff(rp2)), ci2] = va2
+    assert np.array_equal(M, M.T)
+    z = np.random.default_rng(0).standard_normal(n) + 1j * np.random.default_rng(1).standard_normal(n)
+    assert np.allclose((M @ z.view(np.float64)).view(np.complex128), A @ z, rtol=0, atol=1e-12)
+    assert np.allclose(np.linalg.eigvalsh(M)[::2], np.linalg.eigvalsh(A), atol=1e-11)
+    for i in range(2 * n):
+        assert np.all(np.diff(ci2[rp2[i]:rp2[i + 1]]) > 0)     # sorted rows, as the kernels expect
+
+
+@pytest.mark.parametrize("dtype,eps,tol", [(np.complex128, 1e-10, 1e-10), (np.complex64, 1e-4, 2e-4)])
+@pytest.mark.parametrize("target", ["smallest", "largest"])
+def test_hermitian_against_dense_truth(built, dtype, eps, tol, target):
+    n = 300
+    A, csr = hermitian_band(n, seed=1)
+    w = np.linalg.eigvalsh(A)
+    r = eigsh(Operator(n, csr=csr), backend="hostcheck", dtype=dtype, numEvals=4, eps=eps, target=target, iseed=(1, 2, 3, 5))
+    assert r.ret == 0 and r.initSize == 4
+    want = w[:4] if target == "smallest" else w[::-1][:4]
+    aN = r.params["aNorm"]
+    assert np.max(np.abs(r.evals - want)) <= tol * aN
+    X = r.evecs.astype(np.complex128)
+    assert np.max(np.abs(X.conj().T @ X - np.eye(4))) <= (1e-9 if dtype == np.complex128 else 1e-4)
+    res = np.linalg.norm(A @ X - X * r.evals.astype(np.float64), axis=0)
+    assert np.all(res <= 1.5 * eps * aN + 10 * np.finfo(r.evals.dtype).eps * aN)
+    assert np.allclose(res, r.resNorms, rtol=0.5, atol=20 * np.finfo(r.evals.dtype).eps * aN)
+
+
+def test_degenerate_hermitian_spectrum(built):
+    """Multiplicity-2 eigenvalues of A are multiplicity 4 of the real form: the final complex
+    Gram-Schmidt sweep must still hand back numEvals independent, orthonormal eigenvectors."""
+    n = 120
+    A1, _ = hermitian_band(n // 2, seed=5)
+    A = np.kron(np.eye(2), A1)                                    # every eigenvalue twice
+    rows, cols = np.nonzero(A)
+    rp = np.zeros(n + 1, dtype=np.int32); np.add.at(rp, rows + 1, 1)
+    csr = (np.cumsum(rp).astype(np.int32), cols.astype(np.int32), A[rows, cols])
+    w = np.linalg.eigvalsh(A)
+    r = eigsh(Operator(n, csr=csr), backend="hostcheck", dtype=np.complex128, numEvals=6, eps=1e-10, maxBlockSize=2, iseed=(7, 7, 7, 7))
+    assert r.ret == 0 and r.initSize == 6
+    assert np.max(np.abs(np.sort(r.evals) - w[:6])) <= 1e-9 * r.params["aNorm"]
+    X = r.evecs
+    assert np.max(np.abs(X.conj().T @ X - np.eye(6))) <= 1e-8
+    assert np.max(np.linalg.norm(A @ X - X * r.evals, axis=0)) <= 1e-8 * r.params["aNorm"]
+
+
+@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("method,extra", [("GD_plusK", {}), ("JDQMR", {}), ("GD_Olsen_plusK", dict(precond="jacobi")),
+                                          ("DEFAULT_MIN_TIME", dict(target="closest_abs", targetShifts=[40.3]))])
+def test_hermitian_against_live_reference(built, method, extra):
+    """Same eigenvalues and residual norms as zprimme (the iteration counts differ by design:
+    the real-equivalent form carries every eigenvalue twice)."""
+    n = 240
+    A, csr = hermitian_band(n, seed=2)
+    kw = dict(numEvals=3, eps=1e-10, method=method, iseed=(3, 1, 4, 1))
+    kw.update(extra)
+    ref = eigsh(Operator(n, csr=csr), backend="reference", dtype=np.complex128, **kw)
+    got = eigsh(Operator(n, csr=csr), backend="hostcheck", dtype=np.complex128, **kw)
+    assert ref.ret == 0 and got.ret == 0 and got.initSize == 3
+    aN = ref.params["aNorm"]
+    assert np.max(np.abs(np.sort(got.evals) - np.sort(ref.evals))) <= 1e-10 * aN
+    assert np.all(got.resNorms <= 1e-10 * aN * 1.01)
+    # the eigenvectors span the same lines
+    order_g, order_r = np.argsort(got.evals), np.argsort(ref.evals)
+    for a, b in zip(order_g, order_r):
+        assert abs(abs(np.vdot(got.evecs[:, a], ref.evecs[:, b])) - 1.0) <= 1e-7
+
+
+def test_constraints_and_initial_guesses(built):
+    """numOrthoConst complex constraint vectors become [Q | iQ] of the real problem."""
+    n = 200
+    A, csr = hermitian_band(n, seed=4)
+    w, U = np.linalg.eigh(A)
+    Q = U[:, :2] * np.exp(1j * np.array([0.3, 1.1]))             # arbitrary complex phases
+    v0 = U[:, 2:5] * np.exp(1j * np.array([0.0, 2.0, -1.0]))     # the wanted vectors themselves
+    r = eigsh(Operator(n, csr=csr), backend="hostcheck", dtype=np.complex128, numEvals=3, eps=1e-10, constraints=Q, v0=v0)
+    assert r.ret == 0 and r.initSize == 3
+    assert np.max(np.abs(r.evals - w[2:5])) <= 1e-9 * r.params["aNorm"]
+    assert np.max(np.abs(Q.conj().T @ r.evecs)) <= 1e-8
+    # the guesses [X0 | iX0] are the whole wanted invariant subspace of the real form: nothing to iterate
+    assert r.stats["numMatvecs"] <= 8
+    r2 = eigsh(Operator(n, csr=csr), backend="hostcheck", dtype=np.complex128, numEvals=3, eps=1e-10, constraints=Q, iseed=(1, 1, 1, 1))
+    assert r2.ret == 0 and np.max(np.abs(r2.evals - w[2:5])) <= 1e-9 * r2.params["aNorm"]
+    assert np.max(np.abs(Q.conj().T @ r2.evecs)) <= 1e-8
+
+
+def _run_z_case(name, backend):
+    rp, ci, va, n = RD.mhd()
+    case = RD.CASES_Z[name]
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend=backend, dtype=np.complex128, **case["kw"])
+    X = RD.read_sol_z(case["sol"], n)
+    bad = RD.check_solution(lambda v: problems.csr_matvec_numpy(rp, ci, va, v.reshape(-1, 1)).ravel(),
+                            r.evals, r.evecs, r.resNorms, r.params["aNorm"], case["kw"]["eps"], X)
+    return r, bad
+
+
+@pytest.mark.parametrize("name", sorted(RD.CASES_Z))
+def test_reference_driver_complex_case(built, name):
+    """tests/tests/test_10N through hip_zprimme's host code; accepted by the reference driver's
+    check_solution against the reference's stored eigenvectors."""
+    r, bad = _run_z_case(name, "hostcheck")
+    assert r.ret == 0 and r.initSize == RD.CASES_Z[name]["kw"]["numEvals"]
+    assert not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", ["test_101", "test_106"])
+def test_reference_driver_complex_case_pins_the_checker(built, name):
+    r, bad = _run_z_case(name, "reference")
+    assert r.ret == 0 and not bad, bad
+    h, _ = _run_z_case(name, "hostcheck")
+    assert np.max(np.abs(np.sort(h.evals) - np.sort(r.evals))) <= 1e-10 * r.params["aNorm"]
+
+
+def test_complex_unsupported_and_argument_errors(built):
+    import ctypes as C
+    lib = F.load_hostcheck()
+    p = F.PrimmeParams()
+    lib.primme_initialize(C.byref(p))
+    p.n, p.numEvals = 10, 2
+    ev, rn, vec = np.zeros(2), np.zeros(2), np.zeros(40)
+    # no matvec
+    assert lib.hip_zprimme(ev.ctypes.data_as(C.c_void_p), vec.ctypes.data_as(C.c_void_p), rn.ctypes.data_as(C.c_void_p), C.byref(p)) == -6
+    assert lib.hip_zprimme(None, vec.ctypes.data_as(C.c_void_p), rn.ctypes.data_as(C.c_void_p), C.byref(p)) == -30
+    # defaults query, as dprimme(NULL, NULL, NULL, primme)
+    assert lib.hip_cprimme(None, None, None, C.byref(p)) == 0 and p.maxBasisSize > 0 and p.nLocal == 10

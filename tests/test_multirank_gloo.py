@@ -78,3 +78,21 @@ def test_svds_two_ranks(built, tmp_path):
     assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"]
     assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - k) < 1e-8
     assert abs(res[0]["u_norm2"] + res[1]["u_norm2"] - k) < 1e-8
+
+
+def test_hermitian_two_ranks(built, tmp_path):
+    """hip_zprimme with the rows of a complex Hermitian matrix on two ranks: the real-equivalent
+    solve and the complex Gram-Schmidt sweep after it reduce through globalSumReal."""
+    res = _launch("hermitian", tmp_path)
+    nloc = 150
+    rp, ci, va = problems.hermitian_banded_csr(nloc)
+    A1 = np.zeros((nloc, nloc), dtype=np.complex128)
+    A1[np.repeat(np.arange(nloc), np.diff(rp)), ci] = va
+    assert np.allclose(A1, A1.conj().T)
+    w = np.sort(np.concatenate([np.linalg.eigvalsh(A1), 1.21 * np.linalg.eigvalsh(A1)]))[::-1][:4]
+    for r in res:
+        assert r["ret"] == 0
+        assert np.max(np.abs(np.array(r["evals"]) - w)) <= 1e-10 * 1.21 * 4
+        assert r["numGlobalSum"] > 0
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"]
+    assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - 4.0) < 1e-8
