@@ -91,8 +91,8 @@ static int right_multiply(pa_solver *s, char *X, int64_t ldX, int nX, const doub
       memcpy(s->h_coef + (size_t)j * s->K, M + (size_t)j * nX, (size_t)nX * sizeof(double));
    CHK(hipk_h2d(s->ctx, s->d_coef, s->h_coef, (size_t)s->K * nX * sizeof(double)));
    s->coef_valid_k = -1;
-   hipk_job jobs[64];
-   if (nX > 64) return PRIMME_UNEXPECTED_FAILURE;
+   hipk_job jobs[HIPK_MAX_JOBS];
+   if (nX > HIPK_MAX_JOBS) return PRIMME_FUNCTION_UNAVAILABLE;
    for (int c = 0; c < nX; c++) jobs[c] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, X, ldX, c), -1};
    /* the panel X plays the role of "V" (k = nX columns); W is not touched */
    return hipk_ritz_update(s->ctx, s->dt, s->m, X, X, ldX, nX, s->d_coef, s->K, s->d_theta, jobs, nX, NULL);

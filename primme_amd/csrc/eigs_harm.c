@@ -267,6 +267,7 @@ int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arb
             }
          for (int c = 0; c < an; c++) memcpy(s->hVecs + (size_t)(j + c) * ldh, aH + (size_t)c * basisSize, sizeof(double) * (size_t)basisSize);
          free(aH); free(ah); free(av);
+         s->coef_valid_k = -1;      /* the copy of hVecs in HBM is stale now */
          *arbitraryVecs = i;
       }
    }

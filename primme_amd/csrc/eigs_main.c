@@ -324,13 +324,26 @@ static int copy_back_candidates(pa_solver *s, int basisSize, double *evals, doub
 
 /* in-place column permutation of a device panel: new column i = old column perm[i] */
 static int permute_dev_cols(pa_solver *s, char *base, int64_t ldb, int n, const int *perm) {
+   /* new column i = old column perm[i], in place along the cycles with one scratch column */
    int moved = 0;
    for (int i = 0; i < n; i++) if (perm[i] != i) moved = 1;
    if (!moved) return 0;
-   if (n > s->nT) return PRIMME_UNEXPECTED_FAILURE;
-   for (int i = 0; i < n; i++)
-      CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, perm[i]), ldb, TCOL(s, i), s->ld, 1));
-   CHK(hipk_copy_cols(s->ctx, s->dt, s->m, s->T, s->ld, base, ldb, n));
+   unsigned char *done = (unsigned char *)calloc((size_t)n, 1);
+   if (!done) return PRIMME_MALLOC_FAILURE;
+   for (int i = 0; i < n; i++) {
+      if (done[i] || perm[i] == i) continue;
+      int rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, i), ldb, TCOL(s, 0), s->ld, 1);
+      int j = i;
+      while (!rc && perm[j] != i) {
+         rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, perm[j]), ldb, PCOL(s, base, ldb, j), ldb, 1);
+         done[j] = 1;
+         j = perm[j];
+      }
+      if (!rc) rc = hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, PCOL(s, base, ldb, j), ldb, 1);
+      done[j] = 1;
+      if (rc) { free(done); return rc < 0 ? rc : PRIMME_UNEXPECTED_FAILURE; }
+   }
+   free(done);
    return 0;
 }
 
@@ -797,7 +810,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
-   if (p->maxBasisSize > 255) {
+   /* the basis never grows beyond the space itself, whatever maxBasisSize says */
+   if (PA_MIN((int64_t)p->maxBasisSize, p->n - p->numOrthoConst) > 255) {
       if (p->printLevel > 0 && p->outputFile)
          fprintf(p->outputFile, "primme_amd: maxBasisSize > 255 is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;

@@ -65,6 +65,12 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
 
 /* global sum of a few host scalars (cost-model ratios): through the same path as the
  * device partials so that every communicator flavour is covered */
+int pa_trace_errors(void) {
+   static int on = -1;
+   if (on < 0) on = getenv("PRIMME_AMD_TRACE_ERRORS") != NULL;
+   return on;
+}
+
 int pa_reduce_host(pa_solver *s, double *buf, int count) {
    primme_params *p = s->p;
    if (count <= 0 || !s->parallel) return 0;

