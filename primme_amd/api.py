@@ -237,7 +237,9 @@ class Session:
             if backend == "hip":
                 import torch
                 tdt = {"float64": torch.float64, "float32": torch.float32, "complex128": torch.complex128, "complex64": torch.complex64}[dtype.name]
-                evecs_t = torch.zeros((ncols, nLocal), dtype=tdt, device="cuda")
+                # (a zero-sized problem still gets a valid device pointer)
+                evecs_buf = torch.zeros(max(ncols * nLocal, 1), dtype=tdt, device="cuda")
+                evecs_t = evecs_buf[:ncols * nLocal].view(ncols, nLocal)
                 if v0 is not None:
                     # the start vectors are uploaded once per Session and stay in HBM
                     key = (v0.shape, float(v0.ravel()[0]), float(v0.ravel()[-1]))
@@ -247,7 +249,7 @@ class Session:
                 if cons is not None:
                     evecs_t[:nOC] = torch.from_numpy(np.ascontiguousarray(cons.T)).to("cuda")
                 torch.cuda.synchronize()
-                evecs_ptr = C.c_void_p(evecs_t.data_ptr())
+                evecs_ptr = C.c_void_p(evecs_buf.data_ptr())
             else:
                 evecs = np.zeros((ncols, nLocal), dtype=dtype)
                 if cons is not None:

@@ -133,12 +133,20 @@ extern "C" void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRI
       int *blockSize, struct primme_params *primme, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)primme->preconditioner;
    void *stream = primme->queue ? (void *)*(hipStream_t *)primme->queue : NULL;
-   if (!op || *blockSize > 64) { *ierr = 1; return; }
-   double fixed[64];
-   for (int c = 0; c < *blockSize; c++) fixed[c] = op->jacobi_shift;
-   *ierr = hipk_jacobi_apply(stream, hipk_csr_dtype(op->A), hipk_csr_nrows(op->A), hipk_csr_diag(op->A),
-         op->jacobi_fixed ? fixed : primme->ShiftsForPreconditioner,
-         1e-14 * (primme->aNorm >= 0.0 ? primme->aNorm : 1.0), x, *ldx * op->ldscale, y, *ldy * op->ldscale, *blockSize);
+   if (!op) { *ierr = 1; return; }
+   const hipk_dtype dt = hipk_csr_dtype(op->A);
+   const size_t es = op_elem(dt);
+   const int64_t lx = *ldx * op->ldscale, ly = *ldy * op->ldscale;
+   *ierr = 0;
+   for (int c0 = 0; c0 < *blockSize && !*ierr; c0 += 64) {
+      const int n = *blockSize - c0 < 64 ? *blockSize - c0 : 64;
+      double fixed[64];
+      for (int c = 0; c < n; c++) fixed[c] = op->jacobi_shift;
+      *ierr = hipk_jacobi_apply(stream, dt, hipk_csr_nrows(op->A), hipk_csr_diag(op->A),
+            op->jacobi_fixed ? fixed : primme->ShiftsForPreconditioner + c0,
+            1e-14 * (primme->aNorm >= 0.0 ? primme->aNorm : 1.0), (const char *)x + (size_t)c0 * lx * es, lx,
+            (char *)y + (size_t)c0 * ly * es, ly, n);
+   }
 }
 
 extern "C" int primme_amd_operator_set_complex(primme_amd_operator *op, int on) {

@@ -277,7 +277,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    const int adaptive = (p->correctionParams.convTest == primme_adaptive ||
                          p->correctionParams.convTest == primme_adaptive_ETolerance);
    int i, isConv;
-   if (blockSize > 64) return PRIMME_UNEXPECTED_FAILURE;
+   if (blockSize > 64) return PRIMME_FUNCTION_UNAVAILABLE;   /* inner solves with more than 64 right-hand sides */
 
    for (i = 0; i < blockSize; i++) tau_prev[i] = tau_init[i] = rnorm[i];
    double LTolerance = s->mach_eps * pa_problem_norm(1, p), LTolerance_factor = 1.0, ETolerance = 0.0,
@@ -490,7 +490,7 @@ int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double
    }
 
    double evalb[64], rn[64];
-   if (blockSize > 64) return PRIMME_UNEXPECTED_FAILURE;
+   if (blockSize > 64) return PRIMME_FUNCTION_UNAVAILABLE;   /* inner solves with more than 64 right-hand sides */
    for (int i = 0; i < blockSize; i++) { evalb[i] = s->hVals[iev[i]]; rn[i] = blockNorms[i]; }
    p->ShiftsForPreconditioner = shifts;
    const int touch0 = *touch;

@@ -422,39 +422,41 @@ int pa_ritz_update(pa_solver *s, int basisSize, const hipk_job *jobs, int njobs,
    if (!work) return PRIMME_MALLOC_FAILURE;
    double *d_n = s->d_red;
    int slot_base = 0;
+   /* The kernel takes at most 16 residual jobs per launch.  With more (block sizes > 16), the
+    * residual jobs are run first, 16 at a time: they only READ V and W, so this is the same
+    * "all inputs before any output" semantics; the ones that also store the residual go through
+    * the scratch panel T and are copied to their destinations after the main launch. */
+   int *slot_of = (int *)malloc((size_t)(nslots > 0 ? nslots : 1) * sizeof(int)); /* slot -> position in d_n */
+   char **final_dst = (char **)calloc((size_t)njobs + 1, sizeof(char *));
+   if (!slot_of || !final_dst) { free(work); free(slot_of); free(final_dst); return PRIMME_MALLOC_FAILURE; }
+   for (int i = 0; i < nslots; i++) slot_of[i] = -1;
+   int nstaged = 0;
    if (nres > 16) {
-      /* norm-only jobs first, 16 at a time (pure reads, so splitting is safe) */
       int cnt = 0;
-      for (int q = 0; q < njobs; q++) {
-         if (jobs[q].kind == HIPK_JOB_RES && jobs[q].dst == NULL) {
+      for (int q = 0; q <= njobs; q++) {
+         if (q < njobs && jobs[q].kind == HIPK_JOB_RES) {
             work[cnt] = jobs[q];
-            work[cnt].slot = cnt;
-            cnt++;
-            if (cnt == 16) {
-               int rc = hipk_ritz_update(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef, s->K, s->d_theta, work, cnt, d_n + slot_base);
-               if (rc) { free(work); return rc; }
-               /* remember where each original slot landed */
-               slot_base += cnt; cnt = 0;
+            if (jobs[q].dst) {
+               if (nstaged >= s->nT) { free(work); free(slot_of); free(final_dst); return PRIMME_FUNCTION_UNAVAILABLE; }
+               final_dst[nstaged] = (char *)jobs[q].dst;
+               work[cnt].dst = TCOL(s, nstaged);
+               nstaged++;
             }
+            if (jobs[q].slot >= 0) { slot_of[jobs[q].slot] = slot_base + cnt; work[cnt].slot = cnt; }
+            else work[cnt].slot = cnt;   /* the norm is computed anyway; nobody reads it */
+            cnt++;
+         }
+         if (cnt == 16 || (q == njobs && cnt > 0)) {
+            int rc = hipk_ritz_update(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef, s->K, s->d_theta, work, cnt, d_n + slot_base);
+            if (rc) { free(work); free(slot_of); free(final_dst); return rc; }
+            slot_base += cnt; cnt = 0;
          }
       }
-      if (cnt) {
-         int rc = hipk_ritz_update(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef, s->K, s->d_theta, work, cnt, d_n + slot_base);
-         if (rc) { free(work); return rc; }
-         slot_base += cnt;
-      }
    }
-   /* main launch: everything that writes, plus norm-only jobs not yet done */
+   /* main launch: everything else */
    int cnt = 0, nmain_slots = 0;
-   int *slot_of = (int *)malloc((size_t)(nslots > 0 ? nslots : 1) * sizeof(int)); /* slot -> position in d_n */
-   for (int i = 0; i < nslots; i++) slot_of[i] = -1;
-   if (nres > 16) {
-      int pos = 0;
-      for (int q = 0; q < njobs; q++)
-         if (jobs[q].kind == HIPK_JOB_RES && jobs[q].dst == NULL) { if (jobs[q].slot >= 0) slot_of[jobs[q].slot] = pos; pos++; }
-   }
    for (int q = 0; q < njobs; q++) {
-      if (nres > 16 && jobs[q].kind == HIPK_JOB_RES && jobs[q].dst == NULL) continue;
+      if (nres > 16 && jobs[q].kind == HIPK_JOB_RES) continue;
       work[cnt] = jobs[q];
       if (jobs[q].kind == HIPK_JOB_RES) {
          if (jobs[q].slot >= 0) slot_of[jobs[q].slot] = slot_base + nmain_slots;
@@ -464,8 +466,13 @@ int pa_ritz_update(pa_solver *s, int basisSize, const hipk_job *jobs, int njobs,
    }
    if (cnt) {
       int rc = hipk_ritz_update(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef, s->K, s->d_theta, work, cnt, d_n + slot_base);
-      if (rc) { free(work); free(slot_of); return rc; }
+      if (rc) { free(work); free(slot_of); free(final_dst); return rc; }
    }
+   for (int t = 0; t < nstaged; t++) {
+      int rc = hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, t), s->ld, final_dst[t], s->ld, 1);
+      if (rc) { free(work); free(slot_of); free(final_dst); return rc; }
+   }
+   free(final_dst);
    const int total_slots = slot_base + nmain_slots;
    if (total_slots > 0) {
       int rc = pa_reduce(s, d_n, total_slots, 0, 0);

@@ -1133,17 +1133,23 @@ extern "C" int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const vo
 
 extern "C" int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
       int64_t ldX, void *Wr, int64_t ldW, int nx, const double *theta_host, double *nrm2_dev) {
-   if (nx <= 0) return 0;
-   if (nx > UTIL_MAXCOLS) return -1;
-   ColScal th;
-   for (int c = 0; c < nx; c++) th.a[c] = theta_host[c];
-   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
-   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
-   DISPATCH_RT(dt,
-         hipLaunchKernelGGL(residual_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (T *)Wr, ldW, nx, th, m, ctx->partials),
-         hipLaunchKernelGGL(residual_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (T *)Wr, ldW, nx, th, m, ctx->partials));
-   HIPK_CHECK(hipGetLastError());
-   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, nrm2_dev);
+   const size_t es = (dt == HIPK_F64) ? 8 : 4;
+   for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
+      const int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
+      ColScal th;
+      for (int c = 0; c < n; c++) th.a[c] = theta_host[c0 + c];
+      const char *Xc = (const char *)X + (size_t)c0 * ldX * es;
+      char *Wc = (char *)Wr + (size_t)c0 * ldW * es;
+      int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+      if (hipk_reserve_partials(ctx, (size_t)gx * n)) return -2;
+      DISPATCH_RT(dt,
+            hipLaunchKernelGGL(residual_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)Xc, ldX, (T *)Wc, ldW, n, th, m, ctx->partials),
+            hipLaunchKernelGGL(residual_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)Xc, ldX, (T *)Wc, ldW, n, th, m, ctx->partials));
+      HIPK_CHECK(hipGetLastError());
+      int rc = hipk_finalize_partials(ctx, ctx->partials, gx, n, nrm2_dev + c0);
+      if (rc) return rc;
+   }
+   return 0;
 }
 
 extern "C" int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
