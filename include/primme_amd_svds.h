@@ -129,6 +129,15 @@ void primme_amd_svds_global_sum(void *sendBuf, void *recvBuf, int *count,
       struct primme_svds_params *primme_svds, int *ierr);
 void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       int *transpose, struct primme_svds_params *primme_svds, int *ierr);
+/* Ready-made applyPreconditioner: the diagonal preconditioner of the reference's test driver for
+ * singular value problems (tests/COMMON/mat.c:353-426, driver.PrecChoice = jacobi): y = x ./
+ * (diag(A'A) - shift^2) for the A'A operator, x ./ (diag(AA') - shift^2) for AA', both halves for the
+ * augmented operator.  set_jacobi builds the two diagonals from the host CSR arrays the operator
+ * was created from (single-rank operators); primme_svds->preconditioner = the operator handle. */
+int primme_amd_svds_operator_set_jacobi(primme_amd_svds_operator *op, const int32_t *rowptr_host,
+      const int32_t *colind_host, const void *values_host, double shift);
+void primme_amd_svds_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
+      int *mode, struct primme_svds_params *primme_svds, int *ierr);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@
 #include "primme_amd_comm.h"
 #include "primme_amd_svds.h"
 #include "primme_amd_io.h"
+#include <math.h>
 
 struct primme_amd_operator { hipk_csr *A; int jacobi_fixed; double jacobi_shift; int ldscale; };
 int primme_amd_operator_set_complex(primme_amd_operator *op, int on) { op->ldscale = on ? 2 : 1; return 0; }
@@ -38,7 +39,7 @@ void primme_amd_global_sum(void *s, void *r, int *c, struct primme_params *p, in
 int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) { (void)ci; (void)d; (void)n; (void)st; return -43; }
 
 /* singular value operator on host memory */
-struct primme_amd_svds_operator { hipk_csr *A, *At; };
+struct primme_amd_svds_operator { hipk_csr *A, *At; void *jac_r, *jac_c; };
 int primme_amd_svds_operator_create(primme_amd_svds_operator **out, struct hipk_ctx *ctx, int dt, int64_t m, int64_t n,
       const int32_t *rp, const int32_t *ci, const void *val) {
    primme_amd_svds_operator *op = calloc(1, sizeof(*op));
@@ -51,13 +52,56 @@ int primme_amd_svds_operator_create(primme_amd_svds_operator **out, struct hipk_
    return rc;
 }
 int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op) {
-   if (op) { hipk_csr_destroy(op->A); hipk_csr_destroy(op->At); free(op); }
+   if (op) { hipk_csr_destroy(op->A); hipk_csr_destroy(op->At); free(op->jac_r); free(op->jac_c); free(op); }
    return 0;
 }
 void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, int *transpose,
       struct primme_svds_params *ps, int *ierr) {
    primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->matrix;
    *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, NULL, x, *ldx, y, *ldy, *bs);
+}
+
+int primme_amd_svds_operator_set_jacobi(primme_amd_svds_operator *op, const int32_t *rp, const int32_t *ci,
+      const void *val, double shift) {
+   const int64_t m = hipk_csr_nrows(op->A), n = hipk_csr_nrows(op->At);
+   const hipk_dtype dt = hipk_csr_dtype(op->A);
+   const size_t es = dt == HIPK_F64 ? 8 : 4;
+   double *sum = calloc((size_t)(m + n) + 1, sizeof(double));
+   for (int64_t i = 0; i < m; i++)
+      for (int32_t k = rp[i]; k < rp[i + 1]; k++) {
+         const double v = dt == HIPK_F64 ? ((const double *)val)[k] : (double)((const float *)val)[k];
+         sum[i] += v * v; sum[m + ci[k]] += v * v;
+      }
+   free(op->jac_r); free(op->jac_c);
+   op->jac_r = malloc(es * (size_t)(m + 1)); op->jac_c = malloc(es * (size_t)(n + 1));
+   for (int64_t i = 0; i < m + n; i++) {
+      double d = sum[i] - shift * shift;
+      if (fabs(d) < 1e-14) d = copysign(1e-14, d);
+      void *dst = i < m ? op->jac_r : op->jac_c;
+      const int64_t j = i < m ? i : i - m;
+      if (dt == HIPK_F64) ((double *)dst)[j] = d; else ((float *)dst)[j] = (float)d;
+   }
+   free(sum);
+   return 0;
+}
+void primme_amd_svds_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, int *mode,
+      struct primme_svds_params *ps, int *ierr) {
+   primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->preconditioner;
+   const hipk_dtype dt = hipk_csr_dtype(op->A);
+   const size_t es = dt == HIPK_F64 ? 8 : 4;
+   const double md = 1e-14 * (ps->aNorm >= 0.0 ? ps->aNorm : 1.0);
+   const int64_t m = ps->mLocal, n = ps->nLocal;
+   double *zeros = calloc((size_t)*bs + 1, sizeof(double));
+   int rc = 1;
+   if (*mode == primme_svds_op_AtA) rc = hipk_jacobi_apply(NULL, dt, n, op->jac_c, zeros, md, x, *ldx, y, *ldy, *bs);
+   else if (*mode == primme_svds_op_AAt) rc = hipk_jacobi_apply(NULL, dt, m, op->jac_r, zeros, md, x, *ldx, y, *ldy, *bs);
+   else if (*mode == primme_svds_op_augmented) {
+      rc = hipk_jacobi_apply(NULL, dt, n, op->jac_c, zeros, md, x, *ldx, y, *ldy, *bs);
+      if (!rc) rc = hipk_jacobi_apply(NULL, dt, m, op->jac_r, zeros, md, (const char *)x + (size_t)n * es, *ldx,
+                                      (char *)y + (size_t)n * es, *ldy, *bs);
+   }
+   free(zeros);
+   *ierr = rc ? 1 : 0;
 }
 
 int primme_amd_svds_operator_create_dist(primme_amd_svds_operator **op, struct hipk_ctx *ctx, int dt, int64_t mLocal,

@@ -215,6 +215,7 @@ def _declare_kernels(lib):
         "primme_amd_operator_create": [P(_vp), _vp, _vp], "primme_amd_operator_destroy": [_vp],
         "primme_amd_svds_operator_create": [P(_vp), _vp, _i, _i64, _i64, _vp, _vp, _vp],
         "primme_amd_svds_operator_destroy": [_vp],
+        "primme_amd_svds_operator_set_jacobi": [_vp, _vp, _vp, _vp, C.c_double],
         "hipk_csr_create_rect": [_vp, _i, _i64, _i64, _vp, _vp, _vp, P(_vp)],
         "primme_amd_mm_read": [C.c_char_p, P(_i64), P(_i64), P(_i64), P(_vp), P(_vp), P(_vp), P(_i)],
         "primme_amd_csr_transpose": [_i64, _i64, _vp, _vp, _vp, C.c_size_t, P(_vp), P(_vp), P(_vp)],

@@ -172,6 +172,7 @@ struct primme_amd_svds_operator {
    void *full;                   /* n-vector staging (all-gather target / reduce-scatter source) */
    size_t full_cap;
    hipk_dtype dt;
+   void *jac_r, *jac_c;          /* Jacobi for the normal equations: row / column sums of squares - shift^2 */
 };
 
 extern "C" int primme_amd_svds_operator_create(primme_amd_svds_operator **out, hipk_ctx *ctx, int dt,
@@ -202,10 +203,71 @@ extern "C" int primme_amd_svds_operator_create_dist(primme_amd_svds_operator **o
 extern "C" int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op) {
    if (!op) return 0;
    if (op->full) hipFree(op->full);
+   if (op->jac_r) hipFree(op->jac_r);
+   if (op->jac_c) hipFree(op->jac_c);
    hipk_csr_destroy(op->A); hipk_csr_destroy(op->At);
    free(op);
    return 0;
 }
+/* diag(A A') - shift^2 and diag(A'A) - shift^2 (reference tests/COMMON/mat.c:353-393, the driver's
+ * "jacobi" choice for singular value problems); single-rank operators */
+extern "C" int primme_amd_svds_operator_set_jacobi(primme_amd_svds_operator *op, const int32_t *rp,
+      const int32_t *ci, const void *val, double shift) {
+   if (!op || op->comm) return -44;
+   const int64_t m = hipk_csr_nrows(op->A), n = hipk_csr_nrows(op->At);
+   const hipk_dtype dt = hipk_csr_dtype(op->A);
+   const size_t es = (dt == HIPK_F64) ? 8 : 4;
+   double *sum = (double *)calloc((size_t)(m + n) + 1, sizeof(double));
+   char *packed = (char *)malloc(es * (size_t)(m + n) + 1);
+   if (!sum || !packed) { free(sum); free(packed); return -2; }
+   for (int64_t i = 0; i < m; i++)
+      for (int32_t k = rp[i]; k < rp[i + 1]; k++) {
+         const double v = (dt == HIPK_F64) ? ((const double *)val)[k] : (double)((const float *)val)[k];
+         sum[i] += v * v;
+         sum[m + ci[k]] += v * v;
+      }
+   for (int64_t i = 0; i < m + n; i++) {
+      double d = sum[i] - shift * shift;
+      if (fabs(d) < 1e-14) d = copysign(1e-14, d);
+      if (dt == HIPK_F64) ((double *)packed)[i] = d; else ((float *)packed)[i] = (float)d;
+   }
+   free(sum);
+   if (!op->jac_r && hipMalloc(&op->jac_r, es * (size_t)(m > 0 ? m : 1)) != hipSuccess) { free(packed); return -2; }
+   if (!op->jac_c && hipMalloc(&op->jac_c, es * (size_t)(n > 0 ? n : 1)) != hipSuccess) { free(packed); return -2; }
+   hipError_t e1 = hipMemcpy(op->jac_r, packed, es * (size_t)m, hipMemcpyHostToDevice);
+   hipError_t e2 = hipMemcpy(op->jac_c, packed + es * (size_t)m, es * (size_t)n, hipMemcpyHostToDevice);
+   free(packed);
+   return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
+}
+
+/* applyPreconditioner of primme_svds_params for the operator's Jacobi data: y = x / diag(A'A),
+ * x / diag(AA') or both halves for the augmented operator (mat.c:395-426) */
+extern "C" void primme_amd_svds_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
+      int *mode, struct primme_svds_params *ps, int *ierr) {
+   primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->preconditioner;
+   *ierr = 1;
+   if (!op || !op->jac_r || !op->jac_c) return;
+   void *stream = ps->queue ? (void *)*(hipStream_t *)ps->queue : NULL;
+   const hipk_dtype dt = hipk_csr_dtype(op->A);
+   const size_t es = (dt == HIPK_F64) ? 8 : 4;
+   const double min_den = 1e-14 * (ps->aNorm >= 0.0 ? ps->aNorm : 1.0);
+   const int64_t m = ps->mLocal, n = ps->nLocal;
+   int rc = 0;
+   for (int c0 = 0; c0 < *blockSize && !rc; c0 += 64) {
+      const int nb = *blockSize - c0 < 64 ? *blockSize - c0 : 64;
+      double zeros[64] = {0};
+      const char *xc = (const char *)x + (size_t)c0 * *ldx * es;
+      char *yc = (char *)y + (size_t)c0 * *ldy * es;
+      if (*mode == primme_svds_op_AtA) rc = hipk_jacobi_apply(stream, dt, n, op->jac_c, zeros, min_den, xc, *ldx, yc, *ldy, nb);
+      else if (*mode == primme_svds_op_AAt) rc = hipk_jacobi_apply(stream, dt, m, op->jac_r, zeros, min_den, xc, *ldx, yc, *ldy, nb);
+      else if (*mode == primme_svds_op_augmented) {
+         rc = hipk_jacobi_apply(stream, dt, n, op->jac_c, zeros, min_den, xc, *ldx, yc, *ldy, nb);
+         if (!rc) rc = hipk_jacobi_apply(stream, dt, m, op->jac_r, zeros, min_den, xc + (size_t)n * es, *ldx, yc + (size_t)n * es, *ldy, nb);
+      } else rc = 1;
+   }
+   *ierr = rc ? 1 : 0;
+}
+
 extern "C" void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       int *transpose, struct primme_svds_params *ps, int *ierr) {
    primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->matrix;

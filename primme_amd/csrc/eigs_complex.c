@@ -100,6 +100,24 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
    if (!sd) return PRIMME_MALLOC_FAILURE;
    sd->user = primme;
    sd->q = *primme;                               /* before defaults: unset sizes stay unset */
+   {
+      /* basis sizes the caller's primme_set_method derived from the complex problem's n are derived
+       * again for the real problem; sizes the caller (or a preset) chose explicitly are kept */
+      primme_params t = *primme;
+      if (t.numProcs <= 1) t.nLocal = t.n;
+      t.maxBasisSize = 0; t.minRestartSize = 0;
+      primme_set_defaults(&t);
+      if (t.maxBasisSize == primme->maxBasisSize) {
+         sd->q.maxBasisSize = 0;
+         if (t.minRestartSize == primme->minRestartSize) sd->q.minRestartSize = 0;
+      } else {
+         t = *primme;
+         if (t.numProcs <= 1) t.nLocal = t.n;
+         t.minRestartSize = 0;
+         primme_set_defaults(&t);
+         if (t.minRestartSize == primme->minRestartSize) sd->q.minRestartSize = 0;
+      }
+   }
    if (primme->numProcs <= 1) { primme->nLocal = primme->n; primme->procID = 0; }
    primme_set_defaults(primme);
    if (primme->ldOPs == -1) primme->ldOPs = primme->nLocal;
@@ -114,7 +132,8 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
    q->numEvals = 2 * nev; q->numOrthoConst = 2 * nOC; q->initSize = 2 * init;
    /* the reference's own rule for the default (primme_interface.c:601-607: lock when the wanted
     * pairs do not fit in the restarted basis), re-applied to the doubled count */
-   if (q->locking == 0 && q->minRestartSize > 0 && q->numEvals > q->minRestartSize) q->locking = 1;
+   primme_set_defaults(q);
+   if (q->locking == 0 && q->numEvals > q->minRestartSize) q->locking = 1;
    q->matrixMatvec = cx_matvec;
    if (primme->applyPreconditioner) q->applyPreconditioner = cx_precond;
    if (primme->globalSumReal && primme->globalSumReal != primme_amd_global_sum) q->globalSumReal = cx_global_sum;
@@ -203,7 +222,33 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
       free(used);
       if (hipk_sync(ctx)) { ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
       primme->initSize = acc;
-      if (ret == 0 && acc < nev) ret = PRIMME_MAIN_ITER_FAILURE;
+      /* (fewer than numEvals with ret = 0: the real solver exhausted the space, as dprimme does
+       * for closest_geq / closest_leq when fewer eigenvalues exist on the wanted side) */
+
+      /* the sweep may have changed the vectors (components along pairs already taken removed):
+       * report the residual norms of what is returned, ||A z - lambda z|| */
+      if (acc > 0) {
+         int ierr = 0, nb = acc, cnt = acc;
+         PRIMME_INT ldc = ldu;
+         double *theta = (double *)malloc(sizeof(double) * (size_t)acc);
+         if (!theta) { ret = PRIMME_MALLOC_FAILURE; goto done; }
+         for (int i = 0; i < acc; i++) theta[i] = (dtr == HIPK_F64) ? ((double *)evals_out)[i] : (double)((float *)evals_out)[i];
+         primme->queue = q->queue;
+         primme->matrixMatvec(Z, &ldc, work, &ldc, &nb, primme, &ierr);
+         if (ierr) { free(theta); ret = PRIMME_USER_FAILURE; goto done; }
+         primme->stats.numMatvecs += acc;
+         if (hipk_residual_cols(ctx, dtr, mr, Z, ldr, work, ldr, acc, theta, d_s) ||
+             hipk_d2h(ctx, h_s, d_s, sizeof(double) * (size_t)acc) || hipk_sync(ctx)) { free(theta); ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
+         free(theta);
+         if (primme->numProcs > 1 && primme->globalSumReal) {
+            primme->globalSumReal(h_s, h_s, &cnt, primme, &ierr);
+            if (ierr) { ret = PRIMME_USER_FAILURE; goto done; }
+         }
+         for (int i = 0; i < acc; i++) {
+            if (dtr == HIPK_F64) ((double *)resNorms_out)[i] = sqrt(h_s[i]);
+            else ((float *)resNorms_out)[i] = (float)sqrt(h_s[i]);
+         }
+      }
    }
 
 done:

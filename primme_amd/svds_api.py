@@ -34,7 +34,7 @@ def transpose_csr(m, n, rp, ci, va):
 
 def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", methodStage1="DEFAULT_METHOD",
          eps=1e-8, aNorm=0.0, backend="hip", dtype=np.float64, maxBlockSize=0, maxBasisSize=0, locking=None,
-         maxMatvecs=0, v0=None, iseed=None, printLevel=0, return_vectors=True, targetShifts=None):
+         maxMatvecs=0, v0=None, iseed=None, printLevel=0, return_vectors=True, targetShifts=None, precond=None):
     dtype = np.dtype(dtype)
     dt = F.HIPK_F64 if dtype == np.float64 else F.HIPK_F32
     ctype = C.c_double if dtype == np.float64 else C.c_float
@@ -79,6 +79,40 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
         cb = F.SVDS_BLOCK_OP(mv)
         keep.append(cb)
         ps.matrixMatvec = C.cast(cb, C.c_void_p)
+        if precond is not None:
+            # the test driver's "jacobi" for singular value problems (tests/COMMON/mat.c:353-426)
+            shift = 0.0 if precond == "jacobi" else float(precond[1])
+            rows = np.repeat(np.arange(m), np.diff(rp))
+            sumr = np.bincount(rows, weights=va.astype(np.float64) ** 2, minlength=m) - shift * shift
+            sumc = np.bincount(ci, weights=va.astype(np.float64) ** 2, minlength=n) - shift * shift
+            for d in (sumr, sumc):
+                small = np.abs(d) < 1e-14
+                d[small] = np.copysign(1e-14, d[small])
+
+            def pc(x, ldx, y, ldy, bs, mode, pp, ierr):
+                nb, lx, ly = bs[0], ldx[0], ldy[0]
+                if nb <= 0 or not x or not y:
+                    ierr[0] = 0
+                    return
+                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
+                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
+                an = pp[0].aNorm
+                md = 1e-14 * (an if an >= 0 else 1.0)
+
+                def div(d):
+                    d = d.copy()
+                    small = ~(np.abs(d) > md)
+                    d[small] = np.copysign(md, d[small])
+                    return d
+                if mode[0] == 1: Y[:, :n] = X[:, :n] / div(sumc)
+                elif mode[0] == 2: Y[:, :m] = X[:, :m] / div(sumr)
+                else:
+                    Y[:, :n] = X[:, :n] / div(sumc)
+                    Y[:, n:n + m] = X[:, n:n + m] / div(sumr)
+                ierr[0] = 0
+            pcb = F.SVDS_BLOCK_OP(pc)
+            keep.append(pcb)
+            ps.applyPreconditioner = C.cast(pcb, C.c_void_p)
         solver = lib.dprimme_svds if dtype == np.float64 else lib.sprimme_svds
     else:
         ctx = C.c_void_p()
@@ -93,6 +127,13 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
         handles.append(("op", oph))
         ps.matrix = oph
         ps.matrixMatvec = C.cast(lib.primme_amd_svds_matvec, C.c_void_p)
+        if precond is not None:
+            shift = 0.0 if precond == "jacobi" else float(precond[1])
+            if lib.primme_amd_svds_operator_set_jacobi(oph, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                                       va.ctypes.data_as(C.c_void_p), shift):
+                raise RuntimeError("svds Jacobi set-up failed")
+            ps.preconditioner = oph
+            ps.applyPreconditioner = C.cast(lib.primme_amd_svds_jacobi_precond, C.c_void_p)
         solver = lib.hip_dprimme_svds if dtype == np.float64 else lib.hip_sprimme_svds
 
     mset = getattr(F, "PRIMME_" + methodStage1) if isinstance(methodStage1, str) and hasattr(F, "PRIMME_" + methodStage1) \

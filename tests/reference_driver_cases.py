@@ -133,12 +133,17 @@ SVDS_CASES = {
     "test_202_hybrid": dict(sol="sol_202svds_double", kw=dict(numSvals=5, eps=1e-12, target="largest", method="default")),
     # test_207: the augmented operator alone
     "test_207": dict(sol="sol_207svds_double", kw=dict(numSvals=5, eps=1e-6, target="largest", method="augmented")),
+    # test_205 / test_206: the smallest triplet with the driver's diagonal preconditioner (PrecChoice = jacobi:
+    # 1 / diag(A'A), 1 / diag(AA'), tests/COMMON/mat.c:353-426), the driver's default hybrid method
+    "test_205": dict(sol="sol_205svds_double", matrix="lund_b.mtx",
+                     kw=dict(numSvals=1, eps=1e-12, target="smallest", method="default", precond="jacobi", methodStage1="DEFAULT_METHOD")),
+    "test_206": dict(sol="sol_206svds_double", matrix="rect.mtx",
+                     kw=dict(numSvals=1, eps=1e-12, target="smallest", method="default", precond="jacobi", methodStage1="DEFAULT_METHOD")),
 }
 # test_203 / test_204 (5 smallest triplets of lund_b.mtx / rect.mtx, sigma_min ~ 1e-9 |A|, eps 7e-12,
 # no preconditioner) need more than 1e5 operator applications in the reference itself (it returns
 # -103 / -203 under that cap); the smallest-triplet path (hybrid with the refined extraction in the
 # augmented stage) is covered on well conditioned matrices in tests/test_svds_host.py instead.
-# test_205 / test_206 use the driver's own preconditioner, which is not part of this library.
 
 
 def svds_matrix(name="rect.mtx"):
@@ -230,21 +235,22 @@ def laplace1d(n):
     return np.array(rp, np.int32), np.array(ci, np.int32), np.array(va, np.float64)
 
 
-def read_sol_testi(n, nev, target):
-    d = np.fromfile(os.path.join(DATA, "testi", f"sol_testi-{n}-{nev}-primme_{target}_double"), dtype=np.float64)
-    cols = int(d[2])
-    return d[3:3 + n * cols].reshape(cols, n).T.copy() if n * cols else np.zeros((n, 0))
+def read_sol_testi(n, nev, target, cplx=False):
+    d = np.fromfile(os.path.join(DATA, "testi", f"sol_testi-{n}-{nev}-primme_{target}_double" + ("complex" if cplx else "")),
+                    dtype=np.complex128 if cplx else np.float64)
+    cols = int(d[2].real)
+    return d[3:3 + n * cols].reshape(cols, n).T.copy() if n * cols else np.zeros((n, 0), dtype=d.dtype)
 
 
-def run_testi_case(eigsh, Operator, methods, backend, method, n, nev, target, proj):
+def run_testi_case(eigsh, Operator, methods, backend, method, n, nev, target, proj, dtype=np.float64):
     """One interface case with the test files' settings (eps 1e-6, shift 0.5, maxMatvecs 50000);
     returns (ret, list of violated checks)."""
     rp, ci, va = laplace1d(n)
     r = eigsh(Operator(n, csr=(rp, ci, va)), backend=backend, numEvals=nev, eps=1e-6, target=target, targetShifts=[0.5],
-              projection=proj, maxMatvecs=50000, method=methods.get(method, 0))
+              projection=proj, maxMatvecs=50000, method=methods.get(method, 0), dtype=dtype)
     if r.ret != 0 or nev == 0 or n == 0:
         return r.ret, []
-    X = read_sol_testi(n, nev, target)
+    X = read_sol_testi(n, nev, target, cplx=np.dtype(dtype).kind == "c")
     k = r.initSize
     with np.errstate(divide="ignore"):
         bad = check_solution(lambda v: problems.csr_matvec_numpy(rp, ci, va, v.reshape(-1, 1)).ravel(), r.evals[:k],

@@ -120,7 +120,7 @@ def test_constraints_and_initial_guesses(built):
     assert np.max(np.abs(r.evals - w[2:5])) <= 1e-9 * r.params["aNorm"]
     assert np.max(np.abs(Q.conj().T @ r.evecs)) <= 1e-8
     # the guesses [X0 | iX0] are the whole wanted invariant subspace of the real form: nothing to iterate
-    assert r.stats["numMatvecs"] <= 8
+    assert r.stats["numMatvecs"] <= 12     # 2 x 3 to verify the guesses, 3 for the final residual norms
     r2 = eigsh(Operator(n, csr=csr), backend="hostcheck", dtype=np.complex128, numEvals=3, eps=1e-10, constraints=Q, iseed=(1, 1, 1, 1))
     assert r2.ret == 0 and np.max(np.abs(r2.evals - w[2:5])) <= 1e-9 * r2.params["aNorm"]
     assert np.max(np.abs(Q.conj().T @ r2.evecs)) <= 1e-8
