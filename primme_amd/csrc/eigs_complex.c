@@ -133,6 +133,7 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
    /* the reference's own rule for the default (primme_interface.c:601-607: lock when the wanted
     * pairs do not fit in the restarted basis), re-applied to the doubled count */
    primme_set_defaults(q);
+   if (q->minRestartSize <= 0 && q->n > 2) q->minRestartSize = 1;   /* presets with fixed tiny bases */
    if (q->locking == 0 && q->numEvals > q->minRestartSize) q->locking = 1;
    q->matrixMatvec = cx_matvec;
    if (primme->applyPreconditioner) q->applyPreconditioner = cx_precond;

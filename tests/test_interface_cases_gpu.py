@@ -25,3 +25,16 @@ def test_hip_interface_cases(built, method):
         if ret != 0 or bad:
             failures.append((n, nev, target, proj, ret, bad[:2]))
     assert ran >= 100 and not failures, failures[:10]
+
+
+def test_hip_interface_cases_complex(built):
+    """hip_zprimme on the same degenerate sizes (see test_interface_cases_complex)."""
+    import numpy as np
+    failures = []
+    for n, nev, target, proj in RD.testi_cases("DEFAULT_MIN_TIME"):
+        if (n, nev, target) == (100, 100, "closest_geq"):
+            continue
+        ret, bad = RD.run_testi_case(eigsh, Operator, F.METHODS, "hip", "DEFAULT_MIN_TIME", n, nev, target, proj, dtype=np.complex128)
+        if ret != 0 or bad:
+            failures.append((n, nev, target, proj, ret, bad[:2]))
+    assert not failures, failures[:10]
