@@ -108,10 +108,15 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
  * over V, W and Q (hcol_host: k coefficients on the HOST, passed in the kernel arguments; theta by value).  Replaces
  * Num_update_VWXR (auxiliary_eigs_normal.c:155-388) + the Num_gemv_ddh/Num_dot of the first
  * CGS pass (ortho.c:229-249) when the residual itself is the new basis vector (GD without
- * preconditioner).  k <= 32, L <= 32. */
+ * preconditioner).  k <= 32, L <= 32.
+ * want_wtr != 0 (k, L <= HIPK_WTR_MAX_K): out_dev[k+L+1 .. k+L+1+k) = W' dst as well, from the W
+ * columns the pass holds in registers anyway.  With A symmetric and W = A V this is V' A dst, from
+ * which the host forms the new column of the projected matrix without another pass over V
+ * (update_projection.c:99-122 reads V again for it): see eigs_conv.c. */
+#define HIPK_WTR_MAX_K 16
 int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
       const void *W, int64_t ldVW, int k, const double *hcol_host, double theta, void *dst,
-      const void *Q, int64_t ldQ, int L, double *out_dev);
+      const void *Q, int64_t ldQ, int L, int want_wtr, double *out_dev);
 
 /* ---- column utilities ---------------------------------------------------------
  * Num_scal (cublas_wrapper.c:678), Num_axpy (:616), Num_copy_matrix (:739),

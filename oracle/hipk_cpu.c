@@ -153,9 +153,11 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
 /* r = W h - theta V h; out = [V'r | Q'r | r'r]  (Num_update_VWXR + first CGS pass dots) */
 int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
       int64_t ld, int k, const double *hcol, double theta, void *dst, const void *Q, int64_t ldQ, int L,
-      double *out) {
+      int want_wtr, double *out) {
    (void)ctx; g_cnt[3]++;
-   for (int j = 0; j < k + L + 1; j++) out[j] = 0.0;
+   if (want_wtr && (k > HIPK_WTR_MAX_K || L > HIPK_WTR_MAX_K)) return -1;
+   const int nout = k + L + 1 + (want_wtr ? k : 0);
+   for (int j = 0; j < nout; j++) out[j] = 0.0;
    for (int64_t i = 0; i < m; i++) {
       double x = 0, y = 0;
       for (int j = 0; j < k; j++) { x += ld_(dt, colp(dt, V, ld, j), i) * hcol[j]; y += ld_(dt, colp(dt, W, ld, j), i) * hcol[j]; }
@@ -166,8 +168,9 @@ int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
       for (int j = 0; j < k; j++) out[j] += ld_(dt, colp(dt, V, ld, j), i) * r;
       for (int q = 0; q < L; q++) out[k + q] += ld_(dt, colp(dt, Q, ldQ, q), i) * r;
       out[k + L] += r * r;
+      if (want_wtr) for (int j = 0; j < k; j++) out[k + L + 1 + j] += ld_(dt, colp(dt, W, ld, j), i) * r;
    }
-   mirror(out, (size_t)k + L + 1);
+   mirror(out, (size_t)nout);
    return 0;
 }
 

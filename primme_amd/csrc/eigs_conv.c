@@ -278,8 +278,6 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          const int col = iev[*blockSize];
          char *dstc = PCOL(s, R, s->ld, *blockSize);
          double t0 = pa_wtime();
-         if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
-                    s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, s->d_fov))) goto out;
          /* Speculation: candidates are almost never converged (10 of 3287 iterations in
           * config 2), so the first Gram-Schmidt update v -= [V Q]*overlaps and |v|^2 are
           * enqueued right away and the host synchronises ONCE for |r|, the overlaps and |v|^2.
@@ -295,32 +293,59 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
           * synchronisation.  Needs in-stream reductions (single rank or the RCCL communicator). */
          const int speculate2 = speculate && !parallel_host && !s->phase_timing && dstc == VCOL(s, basisSize) &&
                                 basisSize + 1 <= p->maxBasisSize && s->spec2_enabled;
+         /* EXPERIMENTAL (PRIMME_AMD_WTR=1, off by default).  With A symmetric and W = A V, the new
+          * column of H = V'AV is W't for the new basis vector t = (r - [V Q] c) / |.|, i.e.
+          * (W'r - H c_V - (W'Q) c_Q) / |.|: W'r comes out of the residual pass (W is in registers
+          * there), H c_V is host arithmetic, only t'At needs the new W column: no separate pass over V
+          * for the projection (update_projection.c:99-122), 6.5 % less time per outer iteration on
+          * BASELINE configs[1].  The (W'Q) c_Q term is dropped here; it is first order in the locked
+          * pairs' residual norms (W'Q = V'R_Q, c_Q = R_Q'x, divided by |r|), which lets the Ritz values
+          * drift to ~1e-11 |A| from the Rayleigh quotients of the returned vectors (1e-14 with the
+          * reference's formula).  Making it exact needs G = W'Q tracked through restarts: DESIGN.md §4d. */
+         const int wtr = speculate2 && s->wtr_enabled && !s->Q && basisSize <= HIPK_WTR_MAX_K && nLk <= HIPK_WTR_MAX_K;   /* (RR extraction only) */
+         const int nfov = nov + 1 + (wtr ? basisSize : 0);      /* [V'r | Q'r | r'r | W'r] */
+         if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
+                    s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, wtr, s->d_fov))) goto out;
          if (speculate) {
-            if ((rc = pa_reduce(s, s->d_fov, nov + 1, 1, parallel_host ? 0 : 1))) goto out;
+            if ((rc = pa_reduce(s, s->d_fov, nfov, 1, parallel_host ? 0 : 1))) goto out;
             hipk_seg segs[2] = {{s->V, s->ld, basisSize}, {s->evecs, s->ldevecs, nLk}};
             if ((rc = hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, dstc, s->ld, 1,
-                       s->d_fov + nov + 1))) goto out;
+                       s->d_fov + nfov))) goto out;
             if (speculate2) {
-               if ((rc = pa_reduce(s, s->d_fov + nov + 1, 1, 1, 1))) goto out;
-               if ((rc = hipk_scale_cols_rsqrt_dev(s->ctx, s->dt, s->m, dstc, s->ld, 1, s->d_fov + nov + 1))) goto out;
+               if ((rc = pa_reduce(s, s->d_fov + nfov, 1, 1, 1))) goto out;
+               if ((rc = hipk_scale_cols_rsqrt_dev(s->ctx, s->dt, s->m, dstc, s->ld, 1, s->d_fov + nfov))) goto out;
                int one = 1, ierr = 0;
                PRIMME_INT ldx = s->ld;
                p->matrixMatvec(dstc, &ldx, WCOL(s, basisSize), &ldx, &one, p, &ierr);
                if (ierr) { rc = PRIMME_USER_FAILURE; goto out; }
-               hipk_seg vseg = {s->V, s->ld, basisSize + 1};
-               if ((rc = hipk_panel_dots(s->ctx, s->dt, s->m, &vseg, 1, WCOL(s, basisSize), s->ld, 1, s->d_red, basisSize + 1))) goto out;
-               if ((rc = pa_reduce(s, s->d_red, basisSize + 1, 0, 0))) goto out;      /* the one synchronisation */
-               memcpy(s->spec_hcol, s->h_red, (size_t)(basisSize + 1) * sizeof(double));
+               if (wtr) {
+                  if ((rc = hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red))) goto out;
+                  if ((rc = pa_reduce(s, s->d_red, 1, 0, 0))) goto out;                 /* the one synchronisation */
+                  const double *cV = s->h_fov, *wr = s->h_fov + nov + 1;
+                  const double inv = 1.0 / sqrt(s->h_fov[nfov]);
+                  for (int j = 0; j < basisSize; j++) {
+                     double hc = 0.0;
+                     for (int i = 0; i < basisSize; i++)
+                        hc += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * cV[i];
+                     s->spec_hcol[j] = (wr[j] - hc) * inv;
+                  }
+                  s->spec_hcol[basisSize] = s->h_red[0];
+               } else {
+                  hipk_seg vseg = {s->V, s->ld, basisSize + 1};
+                  if ((rc = hipk_panel_dots(s->ctx, s->dt, s->m, &vseg, 1, WCOL(s, basisSize), s->ld, 1, s->d_red, basisSize + 1))) goto out;
+                  if ((rc = pa_reduce(s, s->d_red, basisSize + 1, 0, 0))) goto out;      /* the one synchronisation */
+                  memcpy(s->spec_hcol, s->h_red, (size_t)(basisSize + 1) * sizeof(double));
+               }
                s->spec2_valid = 1; s->spec2_k = basisSize;
             } else {
-               if ((rc = pa_reduce(s, s->d_fov + nov + 1, 1, 0, 0))) goto out;
+               if ((rc = pa_reduce(s, s->d_fov + nfov, 1, 0, 0))) goto out;
             }
             s->fov_projected = 1;
          } else {
-            if ((rc = pa_reduce(s, s->d_fov, nov + 1, 1, 0))) goto out;
+            if ((rc = pa_reduce(s, s->d_fov, nfov, 1, 0))) goto out;
          }
          blockNorms[*blockSize] = sqrt(s->h_fov[basisSize + nLk]);
-         s->fov_valid = 1; s->fov_k = basisSize; s->fov_L = nLk; s->fov_col = dstc;
+         s->fov_valid = 1; s->fov_k = basisSize; s->fov_L = nLk; s->fov_col = dstc; s->fov_s1_off = nfov;
          p->stats.timeDense += pa_wtime() - t0;
          p->stats.flopsDense += (double)s->m * 2.0 * basisSize;
       } else {

@@ -186,7 +186,8 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
                              i == s->fov_k && numLocked == s->fov_L && (numLocked == 0 || locked == s->evecs);
          double *dbase = use_fov ? s->d_fov : s->d_red;
          double *hbase = use_fov ? s->h_fov : s->h_red;
-         double *d_ov = dbase, *d_s1 = dbase + nov + 1;
+         const int s1_off = use_fov ? s->fov_s1_off : nov + 1;
+         double *d_ov = dbase, *d_s1 = dbase + s1_off;
          if (first) s->fov_valid = 0;
          if (!use_fov) {
             CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segs, 3, v, ldV, 1, d_ov, ndot));
@@ -212,7 +213,7 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
          if (updateR)
             for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += hbase[i + j];
          if (first) { s02 = hbase[nov]; s0 = sqrt(s02); }
-         s12 = hbase[nov + 1];
+         s12 = hbase[s1_off];
          s1 = sqrt(s12);
 
          if (!isfinite(s0) || !isfinite(s1) || s1 <= eps_orth * s0) {

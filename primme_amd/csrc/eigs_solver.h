@@ -73,6 +73,7 @@ typedef struct pa_solver {
    /* first-pass CGS overlaps produced by the fused residual kernel (block size 1) */
    double *d_fov, *h_fov;
    int fov_valid, fov_k, fov_L;
+   int fov_s1_off;         /* where |v|^2 after the first update sits in d_fov / h_fov */
    int fov_projected;      /* the first pass' update + norm were already run speculatively */
    char *fov_col;
    /* speculative tail of the block-size-1 GD iteration: the new basis vector was normalised with
@@ -80,6 +81,7 @@ typedef struct pa_solver {
     * at anything; accepted by the orthogonaliser if Daniel's test passes on the first pass */
    int device_rr;          /* PRIMME_AMD_DEVICE_RR: small Rayleigh-Ritz solve by the device Jacobi kernel */
    int spec2_enabled;      /* off with PRIMME_AMD_NO_SPEC2 (measurement knob, read once per solve) */
+   int wtr_enabled;        /* projection column from W'r (PRIMME_AMD_WTR=1; experimental: DESIGN.md §4d) */
    int spec2_valid, spec2_k;
    double *spec_hcol;      /* K+1 entries: V(:,0:k+1)' W(:,k) */
    int parallel;           /* reductions cross ranks (numProcs > 1 and a globalSumReal installed) */

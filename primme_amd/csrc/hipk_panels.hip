@@ -737,7 +737,7 @@ extern "C" int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
  * per outer iteration; the locked vectors Q are streamed here instead of in the dots launch.
  */
 struct HCol { double h[32]; };   /* the coefficient vector travels in the kernel arguments */
-template <typename T, int NK, int NL>
+template <typename T, int NK, int NL, bool WT>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
       HCol hcol, double theta, T *__restrict__ dst, const T *__restrict__ Q,
@@ -745,7 +745,9 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
    __shared__ double hs[NK];
    if (threadIdx.x < NK) hs[threadIdx.x] = (threadIdx.x < k) ? hcol.h[threadIdx.x] : 0.0;
    __syncthreads();
-   double ov[NK], oq[NL > 0 ? NL : 1], n2 = 0.0;
+   double ov[NK], oq[NL > 0 ? NL : 1], ow[WT ? NK : 1], n2 = 0.0;
+#pragma unroll
+   for (int j = 0; j < (WT ? NK : 1); j++) ow[j] = 0.0;
 #pragma unroll
    for (int j = 0; j < NK; j++) ov[j] = 0.0;
 #pragma unroll
@@ -768,32 +770,41 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
       n2 = fma(r, r, n2);
 #pragma unroll
       for (int j = 0; j < NK; j++) ov[j] = fma(v[j], r, ov[j]);
+      if (WT) {
+#pragma unroll
+         for (int j = 0; j < NK; j++) ow[j] = fma(w[j], r, ow[j]);
+      }
 #pragma unroll
       for (int q = 0; q < NL; q++) oq[q] = fma(qv[q], r, oq[q]);
    }
-   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NK + NL + 1];
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NK + NL + 1 + (WT ? NK : 0)];
    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
    for (int j = 0; j < NK; j++) { double t = hipk_wave_sum(ov[j]); if (lane == 0) sm[wv][j] = t; }
 #pragma unroll
    for (int q = 0; q < NL; q++) { double t = hipk_wave_sum(oq[q]); if (lane == 0) sm[wv][NK + q] = t; }
    { double t = hipk_wave_sum(n2); if (lane == 0) sm[wv][NK + NL] = t; }
+   if (WT) {
+#pragma unroll
+      for (int j = 0; j < NK; j++) { double t = hipk_wave_sum(ow[j]); if (lane == 0) sm[wv][NK + NL + 1 + j] = t; }
+   }
    __syncthreads();
-   const int nout = k + L + 1;
+   const int nout = k + L + 1 + (WT ? k : 0);
    if (threadIdx.x < nout) {
-      const int src = threadIdx.x < k ? threadIdx.x : (threadIdx.x < k + L ? NK + (threadIdx.x - k) : NK + NL);
+      const int src = threadIdx.x < k ? threadIdx.x : (threadIdx.x < k + L ? NK + (threadIdx.x - k)
+                      : (threadIdx.x == k + L ? NK + NL : NK + NL + 1 + (threadIdx.x - k - L - 1)));
       partials[(size_t)blockIdx.x * nout + threadIdx.x] = (sm[0][src] + sm[1][src]) + (sm[2][src] + sm[3][src]);
    }
 }
 
-template <typename T, int NK>
+template <typename T, int NK, bool WT>
 static int ritz_cgs_nk(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
       double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m) {
    dim3 g(gx), b(HIPK_BLOCK);
-   if (L == 0) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 0>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
-   else if (L <= 8) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 8>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
-   else if (L <= 16) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 16>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
-   else if (L <= 32) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 32>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+   if (L == 0) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 0, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+   else if (L <= 8) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 8, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+   else if (L <= 16) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 16, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+   else if (L <= 32) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 32, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
    else return -1;
    HIPK_CHECK(hipGetLastError());
    return 0;
@@ -801,19 +812,23 @@ static int ritz_cgs_nk(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld
 
 template <typename T>
 static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
-      const double *hcol_host, double theta, T *dst, const T *Q, int64_t ldQ, int L, double *out_dev) {
+      const double *hcol_host, double theta, T *dst, const T *Q, int64_t ldQ, int L, int want_wtr, double *out_dev) {
    if (k <= 0 || k > 32 || L < 0 || L > 32) return -1;
+   if (want_wtr && (k > 16 || L > 16)) return -1;      /* register budget: see HIPK_WTR_MAX_K */
    HCol hcol;
    for (int j = 0; j < 32; j++) hcol.h[j] = (j < k) ? hcol_host[j] : 0.0;
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4);
-   const int nout = k + L + 1;
+   const int nout = k + L + 1 + (want_wtr ? k : 0);
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + 1));
    int rc;
-   if (k <= 8) rc = ritz_cgs_nk<T, 8>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   else if (k <= 16) rc = ritz_cgs_nk<T, 16>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   else if (k <= 24) rc = ritz_cgs_nk<T, 24>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   else rc = ritz_cgs_nk<T, 32>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   if (want_wtr) {
+      if (k <= 8) rc = ritz_cgs_nk<T, 8, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+      else rc = ritz_cgs_nk<T, 16, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   } else if (k <= 8) rc = ritz_cgs_nk<T, 8, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   else if (k <= 16) rc = ritz_cgs_nk<T, 16, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   else if (k <= 24) rc = ritz_cgs_nk<T, 24, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   else rc = ritz_cgs_nk<T, 32, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
    hipk_prof_end(pslot, ctx->stream);
    if (rc) return rc;
    return hipk_finalize_partials(ctx, ctx->partials, gx, nout, out_dev);
@@ -821,10 +836,10 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
 
 extern "C" int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
       const void *W, int64_t ldVW, int k, const double *hcol_host, double theta, void *dst,
-      const void *Q, int64_t ldQ, int L, double *out_dev) {
+      const void *Q, int64_t ldQ, int L, int want_wtr, double *out_dev) {
    switch (dt) {
-   case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, hcol_host, theta, (double *)dst, (const double *)Q, ldQ, L, out_dev);
-   case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, hcol_host, theta, (float *)dst, (const float *)Q, ldQ, L, out_dev);
+   case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, hcol_host, theta, (double *)dst, (const double *)Q, ldQ, L, want_wtr, out_dev);
+   case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, hcol_host, theta, (float *)dst, (const float *)Q, ldQ, L, want_wtr, out_dev);
    default: return -44;
    }
 }

@@ -145,9 +145,10 @@ def test_ritz_update_many_residuals(built, dt):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
-@pytest.mark.parametrize("m,k,L", [(1001, 1, 0), (70001, 7, 3), (250000, 15, 10), (99999, 30, 20)])
-def test_ritz_residual_overlaps(built, dt, m, k, L):
-    """fused residual + first Gram-Schmidt pass: r = W h - theta V h, out = [V'r | Q'r | r'r]"""
+@pytest.mark.parametrize("m,k,L,wtr", [(1001, 1, 0, 0), (70001, 7, 3, 0), (250000, 15, 10, 0), (99999, 30, 20, 0),
+                                       (1001, 1, 0, 1), (70001, 7, 3, 1), (250000, 15, 10, 1), (120000, 16, 16, 1)])
+def test_ritz_residual_overlaps(built, dt, m, k, L, wtr):
+    """fused residual + first Gram-Schmidt pass: r = W h - theta V h, out = [V'r | Q'r | r'r (| W'r)]"""
     rng = np.random.default_rng(m + k + L)
     npdt = NPDT[dt]
     ld, ldq = m + 2, m + 5
@@ -159,13 +160,16 @@ def test_ritz_residual_overlaps(built, dt, m, k, L):
     res = []
     for side in (Dev(), Host()):
         v, w, q, hh = side.arr(V), side.arr(W), side.arr(Q), side.arr(h)
-        out = side.arr(np.zeros(k + L + 1))
+        out = side.arr(np.zeros(k + L + 1 + (k if wtr else 0)))
         hhost = np.ascontiguousarray(h)
         rc = side.lib.hipk_ritz_residual_overlaps(side.ctx, dt, m, side.ptr(v), side.ptr(w), ld, k, hhost.ctypes.data_as(C.c_void_p),
-                                                  C.c_double(theta), side.ptr(v, k * ld), side.ptr(q), ldq, L, side.ptr(out))
+                                                  C.c_double(theta), side.ptr(v, k * ld), side.ptr(q), ldq, L, wtr, side.ptr(out))
         assert rc == 0
         res.append((side.get(v)[k, :m], side.get(out)))
         side.close()
+    if wtr:
+        r = res[1][0].astype(np.float64)
+        assert np.allclose(res[1][1][k + L + 1:], W[:k, :m].astype(np.float64) @ r, rtol=1e-3 if dt == F.HIPK_F32 else 1e-9, atol=1e-6 * np.sqrt(m))
     tol = 1e-12 if dt == F.HIPK_F64 else 1e-4
     assert np.max(np.abs(res[0][0] - res[1][0])) <= tol * 10
     scale = np.sqrt(m) * 4

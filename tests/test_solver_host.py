@@ -46,8 +46,15 @@ def _run(name, backend):
     return eigsh(op, backend=backend, **kw), g
 
 
+@pytest.mark.parametrize("projection_column", ["default", "experimental_wtr"])
 @pytest.mark.parametrize("name", sorted(GOLD))
-def test_against_reference_fixture(built, name):
+def test_against_reference_fixture(built, name, projection_column, monkeypatch):
+    """Two legs.  "default": the new column of H is V'(A t) computed with a pass over V as
+    update_projection.c:99-122 does: iteration / matvec / restart counts must equal the reference's.
+    "experimental_wtr" (PRIMME_AMD_WTR=1): block size 1 GD forms that column from W'r of the fused
+    residual pass: same eigenpairs to the parity bar, counts within 2 %."""
+    if projection_column == "experimental_wtr":
+        monkeypatch.setenv("PRIMME_AMD_WTR", "1")
     r, g = _run(name, "hostcheck")
     aN = g["params"]["aNorm"] if g["params"]["aNorm"] > 0 else max(abs(np.array(g["evals"])))
     assert r.ret == g["ret"] == 0
@@ -64,6 +71,8 @@ def test_against_reference_fixture(built, name):
         assert np.all(r.resNorms <= thr * (1 + 1e-6)) and np.all(np.array(g["resNorms"]) <= thr * (1 + 1e-6))
     its, itsg = r.stats["numOuterIterations"], g["stats"]["numOuterIterations"]
     tol = LOOSE.get(name, 0.0)
+    if projection_column == "experimental_wtr":
+        tol = max(tol, 0.02)
     assert abs(its - itsg) <= tol * itsg, (its, itsg)
     if tol == 0.0:
         assert r.stats["numMatvecs"] == g["stats"]["numMatvecs"]
@@ -141,11 +150,16 @@ def test_dynamic_method_leaves_a_recommendation(built):
     assert np.all(r.resNorms <= 1e-9 * 4.0 * (1 + 1e-6))
 
 
-def test_launch_structure_block_size_one(built):
+@pytest.mark.parametrize("wtr", [False, True])
+def test_launch_structure_block_size_one(built, wtr, monkeypatch):
     """GD+k, block size 1, no preconditioner: per outer iteration ONE fused residual+overlaps
-    pass, ONE Gram-Schmidt update (speculative, reused by the orthogonaliser), ONE projection
-    inner-product pass; a separate overlaps pass only after restarts / for second passes."""
+    pass, ONE Gram-Schmidt update (speculative, reused by the orthogonaliser), and for the
+    projection ONE inner-product pass over V (the reference's formula) or, with the experimental
+    PRIMME_AMD_WTR=1, none: the column comes from W'r of the fused pass and only t'At is a
+    (two-vector) inner product."""
     import ctypes as C
+    if wtr:
+        monkeypatch.setenv("PRIMME_AMD_WTR", "1")
     lib = F.load_hostcheck()
     cnt = (C.c_long * 8)()
     lib.hipk_cpu_counts(cnt, 1)
@@ -155,9 +169,12 @@ def test_launch_structure_block_size_one(built):
     lib.hipk_cpu_counts(cnt, 1)
     its, rst = r.stats["numOuterIterations"], r.stats["numRestarts"]
     dots, project, ritz_cgs = cnt[0], cnt[1], cnt[3]
-    assert r.ret == 0 and its == 490
+    assert r.ret == 0 and (its == 490 if not wtr else abs(its - 490) <= 10)
     assert ritz_cgs >= its - rst - 15 and ritz_cgs <= its
-    assert dots <= its + rst + 25            # projection pass each iteration + CGS dots after restarts
+    if not wtr:
+        assert dots <= its + rst + 25         # projection pass each iteration + CGS dots after restarts
+    else:
+        assert dots <= 3 * rst + 40           # panel inner products only around restarts / second passes
     assert project <= its + 25               # one update per new vector (+ rare second passes)
 
 
