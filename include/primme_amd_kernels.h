@@ -109,8 +109,9 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
  * Num_update_VWXR (auxiliary_eigs_normal.c:155-388) + the Num_gemv_ddh/Num_dot of the first
  * CGS pass (ortho.c:229-249) when the residual itself is the new basis vector (GD without
  * preconditioner).  k <= 32, L <= 32.
- * want_wtr != 0 (k, L <= HIPK_WTR_MAX_K): out_dev[k+L+1 .. k+L+1+k) = W' dst as well, from the W
- * columns the pass holds in registers anyway.  With A symmetric and W = A V this is V' A dst, from
+ * want_wtr != 0 (k, L <= HIPK_WTR_MAX_K): out_dev[k+L+1 .. 2k+L+1) = W' dst and
+ * out_dev[2k+L+1 .. 2k+2L+1) = W(:,k-1)' Q as well, from the W and Q columns the pass holds in
+ * registers anyway.  With A symmetric and W = A V this is V' A dst, from
  * which the host forms the new column of the projected matrix without another pass over V
  * (update_projection.c:99-122 reads V again for it): see eigs_conv.c. */
 #define HIPK_WTR_MAX_K 16

@@ -156,7 +156,7 @@ int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
       int want_wtr, double *out) {
    (void)ctx; g_cnt[3]++;
    if (want_wtr && (k > HIPK_WTR_MAX_K || L > HIPK_WTR_MAX_K)) return -1;
-   const int nout = k + L + 1 + (want_wtr ? k : 0);
+   const int nout = k + L + 1 + (want_wtr ? k + L : 0);
    for (int j = 0; j < nout; j++) out[j] = 0.0;
    for (int64_t i = 0; i < m; i++) {
       double x = 0, y = 0;
@@ -168,7 +168,10 @@ int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
       for (int j = 0; j < k; j++) out[j] += ld_(dt, colp(dt, V, ld, j), i) * r;
       for (int q = 0; q < L; q++) out[k + q] += ld_(dt, colp(dt, Q, ldQ, q), i) * r;
       out[k + L] += r * r;
-      if (want_wtr) for (int j = 0; j < k; j++) out[k + L + 1 + j] += ld_(dt, colp(dt, W, ld, j), i) * r;
+      if (want_wtr) {
+         for (int j = 0; j < k; j++) out[k + L + 1 + j] += ld_(dt, colp(dt, W, ld, j), i) * r;
+         for (int q = 0; q < L; q++) out[2 * k + L + 1 + q] += ld_(dt, colp(dt, W, ld, k - 1), i) * ld_(dt, colp(dt, Q, ldQ, q), i);
+      }
    }
    mirror(out, (size_t)nout);
    return 0;

@@ -293,17 +293,18 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
           * synchronisation.  Needs in-stream reductions (single rank or the RCCL communicator). */
          const int speculate2 = speculate && !parallel_host && !s->phase_timing && dstc == VCOL(s, basisSize) &&
                                 basisSize + 1 <= p->maxBasisSize && s->spec2_enabled;
-         /* EXPERIMENTAL (PRIMME_AMD_WTR=1, off by default).  With A symmetric and W = A V, the new
+         /* Opt-in (PRIMME_AMD_WTR=1).  With A symmetric and W = A V, the new
           * column of H = V'AV is W't for the new basis vector t = (r - [V Q] c) / |.|, i.e.
           * (W'r - H c_V - (W'Q) c_Q) / |.|: W'r comes out of the residual pass (W is in registers
           * there), H c_V is host arithmetic, only t'At needs the new W column: no separate pass over V
-          * for the projection (update_projection.c:99-122), 6.5 % less time per outer iteration on
-          * BASELINE configs[1].  The (W'Q) c_Q term is dropped here; it is first order in the locked
-          * pairs' residual norms (W'Q = V'R_Q, c_Q = R_Q'x, divided by |r|), which lets the Ritz values
-          * drift to ~1e-11 |A| from the Rayleigh quotients of the returned vectors (1e-14 with the
-          * reference's formula).  Making it exact needs G = W'Q tracked through restarts: DESIGN.md §4d. */
-         const int wtr = speculate2 && s->wtr_enabled && !s->Q && basisSize <= HIPK_WTR_MAX_K && nLk <= HIPK_WTR_MAX_K;   /* (RR extraction only) */
-         const int nfov = nov + 1 + (wtr ? basisSize : 0);      /* [V'r | Q'r | r'r | W'r] */
+          * for the projection (update_projection.c:99-122).  G = W'Q (first order in the locked pairs' residual norms: W'Q = V'R_Q)
+          * is kept on the host: recomputed after every restart (pa_refresh_wtq, one panel product),
+          * its row for the newest basis vector comes out of this same pass (W(:,k-1) and Q are both
+          * in registers).  DESIGN.md §4d. */
+         /* G = W'Q must be known for every basis vector but the newest, whose row this pass delivers */
+         const int wtr = speculate2 && s->wtr_enabled && !s->Q && basisSize <= HIPK_WTR_MAX_K && nLk <= HIPK_WTR_MAX_K &&
+                         (nLk == 0 || (s->wtq_L == nLk && s->wtq_rows >= basisSize - 1));   /* (RR extraction only) */
+         const int nfov = nov + 1 + (wtr ? basisSize + nLk : 0);      /* [V'r | Q'r | r'r | W'r | W(:,k-1)'Q] */
          if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
                     s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, wtr, s->d_fov))) goto out;
          if (speculate) {
@@ -321,12 +322,17 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
                if (wtr) {
                   if ((rc = hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red))) goto out;
                   if ((rc = pa_reduce(s, s->d_red, 1, 0, 0))) goto out;                 /* the one synchronisation */
-                  const double *cV = s->h_fov, *wr = s->h_fov + nov + 1;
+                  const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
                   const double inv = 1.0 / sqrt(s->h_fov[nfov]);
+                  if (nLk > 0 && s->wtq_rows == basisSize - 1) {
+                     for (int l = 0; l < nLk; l++) s->wtq[(basisSize - 1) + (size_t)l * s->K] = wr[basisSize + l];
+                     s->wtq_rows = basisSize;
+                  }
                   for (int j = 0; j < basisSize; j++) {
                      double hc = 0.0;
                      for (int i = 0; i < basisSize; i++)
                         hc += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * cV[i];
+                     for (int l = 0; l < nLk; l++) hc += s->wtq[j + (size_t)l * s->K] * cQ[l];
                      s->spec_hcol[j] = (wr[j] - hc) * inv;
                   }
                   s->spec_hcol[basisSize] = s->h_red[0];

@@ -22,6 +22,7 @@
 
 double pa_problem_norm(int overrideUser, const primme_params *p);
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
+int pa_refresh_wtq(pa_solver *s, int basisSize, int nLk);
 int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0, int nc);
 int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc);
 int pa_random_col(pa_solver *s, char *col);
@@ -691,6 +692,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
          p->stats.numRestarts++;
          p->initSize = numConverged;
+         if (s->wtr_enabled && s->fuse_gd && !s->Q) CHK(pa_refresh_wtq(s, basisSize, p->numOrthoConst + numLocked));
          if (p->dynamicMethodSwitch == 1) {
             /* few eigenpairs: GD+k is judged after each restart, restart cost included */
             CHK(hipk_sync(s->ctx));
@@ -763,7 +765,7 @@ static void free_solver(pa_solver *s) {
    }
    free(s->H); free(s->hVecs); free(s->prevhVecs); free(s->hVals); free(s->prevRitzVals);
    free(s->Mq); free(s->Mlu); free(s->Mpiv); free(s->R); free(s->QtV); free(s->hU); free(s->hSVals); free(s->hVecsRot);
-   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol);
+   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol); free(s->wtq);
    free(s->flags); free(s->map); free(s->iev); free(s->perm); free(s->lockedFlags);
    free(s);
 }
@@ -828,7 +830,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    /* PRIMME_AMD_FORCE_COMM: run the cross-rank reduction path with a one-rank communicator, which is
     * how the RCCL calls are exercised on a single-GPU box (tests/test_comm_gpu.py) */
    s->spec2_enabled = getenv("PRIMME_AMD_NO_SPEC2") == NULL;
-   s->wtr_enabled = getenv("PRIMME_AMD_WTR") != NULL;   /* experimental, see DESIGN.md §4d */
+   s->wtr_enabled = getenv("PRIMME_AMD_WTR") != NULL;   /* opt-in: exact but not faster yet, DESIGN.md §4d */
    s->device_rr = getenv("PRIMME_AMD_DEVICE_RR") != NULL;
    s->parallel = ((p->numProcs > 1 || getenv("PRIMME_AMD_FORCE_COMM")) && p->globalSumReal != NULL);
    s->dev_comm = (s->parallel && p->globalSumReal == primme_amd_global_sum);
@@ -873,6 +875,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->prevRitzVals = (double *)calloc((size_t)K + nev, 8);
    s->blockNorms = (double *)calloc((size_t)K + b, 8); s->basisNorms = (double *)calloc((size_t)K, 8);
    s->spec_hcol = (double *)calloc((size_t)K + 2, 8);
+   s->wtq = (double *)calloc((size_t)K * HIPK_WTR_MAX_K + 1, 8);
+   s->wtq_rows = -1;
    if (harmonic) {
       s->R = (double *)calloc((size_t)K * K + 1, 8);
       s->hU = (double *)calloc((size_t)K * K + 1, 8);

@@ -65,6 +65,23 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
 
 /* global sum of a few host scalars (cost-model ratios): through the same path as the
  * device partials so that every communicator flavour is covered */
+/* G = W(:,0:k)' Q for the locked / constraint vectors Q (experimental PRIMME_AMD_WTR path,
+ * eigs_conv.c): one TN panel product after a restart. */
+int pa_refresh_wtq(pa_solver *s, int basisSize, int nLk) {
+   s->wtq_rows = -1; s->wtq_L = nLk;
+   if (!s->wtr_enabled || !s->wtq || basisSize > HIPK_WTR_MAX_K || nLk > HIPK_WTR_MAX_K) return 0;
+   if (nLk > 0 && basisSize > 0) {
+      if (basisSize * nLk > s->red_cap) return 0;
+      hipk_seg seg = {s->W, s->ld, basisSize};
+      CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, s->evecs, s->ldevecs, nLk, s->d_red, basisSize));
+      CHK(pa_reduce(s, s->d_red, basisSize * nLk, 0, 0));
+      for (int l = 0; l < nLk; l++)
+         for (int j = 0; j < basisSize; j++) s->wtq[j + (size_t)l * s->K] = s->h_red[j + (size_t)l * basisSize];
+   }
+   s->wtq_rows = basisSize;
+   return 0;
+}
+
 int pa_trace_errors(void) {
    static int on = -1;
    if (on < 0) on = getenv("PRIMME_AMD_TRACE_ERRORS") != NULL;

@@ -745,9 +745,11 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
    __shared__ double hs[NK];
    if (threadIdx.x < NK) hs[threadIdx.x] = (threadIdx.x < k) ? hcol.h[threadIdx.x] : 0.0;
    __syncthreads();
-   double ov[NK], oq[NL > 0 ? NL : 1], ow[WT ? NK : 1], n2 = 0.0;
+   double ov[NK], oq[NL > 0 ? NL : 1], ow[WT ? NK : 1], og[(WT && NL > 0) ? NL : 1], n2 = 0.0;
 #pragma unroll
    for (int j = 0; j < (WT ? NK : 1); j++) ow[j] = 0.0;
+#pragma unroll
+   for (int q = 0; q < ((WT && NL > 0) ? NL : 1); q++) og[q] = 0.0;
 #pragma unroll
    for (int j = 0; j < NK; j++) ov[j] = 0.0;
 #pragma unroll
@@ -773,11 +775,18 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
       if (WT) {
 #pragma unroll
          for (int j = 0; j < NK; j++) ow[j] = fma(w[j], r, ow[j]);
+         if (NL > 0) {           /* W(:,k-1)' Q: the newest W column against the locked vectors */
+            double wl = 0.0;
+#pragma unroll
+            for (int j = 0; j < NK; j++) wl = (j == k - 1) ? w[j] : wl;
+#pragma unroll
+            for (int q = 0; q < NL; q++) og[q] = fma(wl, qv[q], og[q]);
+         }
       }
 #pragma unroll
       for (int q = 0; q < NL; q++) oq[q] = fma(qv[q], r, oq[q]);
    }
-   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NK + NL + 1 + (WT ? NK : 0)];
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NK + NL + 1 + (WT ? NK + NL : 0)];
    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
    for (int j = 0; j < NK; j++) { double t = hipk_wave_sum(ov[j]); if (lane == 0) sm[wv][j] = t; }
@@ -787,12 +796,15 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
    if (WT) {
 #pragma unroll
       for (int j = 0; j < NK; j++) { double t = hipk_wave_sum(ow[j]); if (lane == 0) sm[wv][NK + NL + 1 + j] = t; }
+#pragma unroll
+      for (int q = 0; q < NL; q++) { double t = hipk_wave_sum(og[q]); if (lane == 0) sm[wv][NK + NL + 1 + NK + q] = t; }
    }
    __syncthreads();
-   const int nout = k + L + 1 + (WT ? k : 0);
+   const int nout = k + L + 1 + (WT ? k + L : 0);
    if (threadIdx.x < nout) {
-      const int src = threadIdx.x < k ? threadIdx.x : (threadIdx.x < k + L ? NK + (threadIdx.x - k)
-                      : (threadIdx.x == k + L ? NK + NL : NK + NL + 1 + (threadIdx.x - k - L - 1)));
+      const int o = threadIdx.x;
+      const int src = o < k ? o : (o < k + L ? NK + (o - k) : (o == k + L ? NK + NL
+                      : (o < 2 * k + L + 1 ? NK + NL + 1 + (o - k - L - 1) : NK + NL + 1 + NK + (o - 2 * k - L - 1))));
       partials[(size_t)blockIdx.x * nout + threadIdx.x] = (sm[0][src] + sm[1][src]) + (sm[2][src] + sm[3][src]);
    }
 }
@@ -818,7 +830,7 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
    HCol hcol;
    for (int j = 0; j < 32; j++) hcol.h[j] = (j < k) ? hcol_host[j] : 0.0;
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4);
-   const int nout = k + L + 1 + (want_wtr ? k : 0);
+   const int nout = k + L + 1 + (want_wtr ? k + L : 0);
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + 1));
    int rc;

@@ -42,6 +42,8 @@ for k in (6, 10, 15):
     jobs = (F.HipkJob * 1)(); jobs[0].kind = F.HIPK_JOB_RES; jobs[0].col = 0; jobs[0].dst = V[k].data_ptr(); jobs[0].slot = 0
     timeit(lambda: lib.hipk_ritz_update(ctx, dt, m, V.data_ptr(), W.data_ptr(), ld, k, h.data_ptr(), K, th.data_ptr(), jobs, 1, red.data_ptr()), (2 * k + 1) * m * 8, f"ritz RES k={k}")
     timeit(lambda: lib.hipk_ritz_residual_overlaps(ctx, dt, m, V.data_ptr(), W.data_ptr(), ld, k, hhost.ctypes.data_as(C.c_void_p), C.c_double(0.3), V[k].data_ptr(), Q.data_ptr(), ld, L, 0, red.data_ptr()), (2 * k + L + 1) * m * 8, f"ritz+overlaps k={k} L={L}")
+    timeit(lambda: lib.hipk_ritz_residual_overlaps(ctx, dt, m, V.data_ptr(), W.data_ptr(), ld, k, hhost.ctypes.data_as(C.c_void_p), C.c_double(0.3), V[k].data_ptr(), Q.data_ptr(), ld, L, 1, red.data_ptr()), (2 * k + L + 1) * m * 8, f"ritz+overlaps+W'r k={k} L={L}")
+    timeit(lambda: lib.hipk_pair_dots(ctx, dt, m, V[k].data_ptr(), ld, W[k].data_ptr(), ld, 1, red.data_ptr()), 2 * m * 8, "pair dot t'w")
 rp, ci, va, n = problems.laplacian_csr((125, 126, 127))
 A = C.c_void_p()
 assert lib.hipk_csr_create(ctx, dt, n, n, 0, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), C.byref(A)) == 0

@@ -160,7 +160,7 @@ def test_ritz_residual_overlaps(built, dt, m, k, L, wtr):
     res = []
     for side in (Dev(), Host()):
         v, w, q, hh = side.arr(V), side.arr(W), side.arr(Q), side.arr(h)
-        out = side.arr(np.zeros(k + L + 1 + (k if wtr else 0)))
+        out = side.arr(np.zeros(k + L + 1 + (k + L if wtr else 0)))
         hhost = np.ascontiguousarray(h)
         rc = side.lib.hipk_ritz_residual_overlaps(side.ctx, dt, m, side.ptr(v), side.ptr(w), ld, k, hhost.ctypes.data_as(C.c_void_p),
                                                   C.c_double(theta), side.ptr(v, k * ld), side.ptr(q), ldq, L, wtr, side.ptr(out))
@@ -169,7 +169,8 @@ def test_ritz_residual_overlaps(built, dt, m, k, L, wtr):
         side.close()
     if wtr:
         r = res[1][0].astype(np.float64)
-        assert np.allclose(res[1][1][k + L + 1:], W[:k, :m].astype(np.float64) @ r, rtol=1e-3 if dt == F.HIPK_F32 else 1e-9, atol=1e-6 * np.sqrt(m))
+        assert np.allclose(res[1][1][2 * k + L + 1:], Q[:L, :m].astype(np.float64) @ W[k - 1, :m].astype(np.float64), rtol=1e-3 if dt == F.HIPK_F32 else 1e-9, atol=1e-6 * np.sqrt(m))
+        assert np.allclose(res[1][1][k + L + 1:2 * k + L + 1], W[:k, :m].astype(np.float64) @ r, rtol=1e-3 if dt == F.HIPK_F32 else 1e-9, atol=1e-6 * np.sqrt(m))
     tol = 1e-12 if dt == F.HIPK_F64 else 1e-4
     assert np.max(np.abs(res[0][0] - res[1][0])) <= tol * 10
     scale = np.sqrt(m) * 4
