@@ -325,15 +325,37 @@ static int copy_back_candidates(pa_solver *s, int basisSize, double *evals, doub
 
 /* in-place column permutation of a device panel: new column i = old column perm[i] */
 static int permute_dev_cols(pa_solver *s, char *base, int64_t ldb, int n, const int *perm) {
-   /* new column i = old column perm[i], in place along the cycles with one scratch column */
+   /* new column i = old column perm[i] */
    int moved = 0;
    for (int i = 0; i < n; i++) if (perm[i] != i) moved = 1;
    if (!moved) return 0;
    unsigned char *done = (unsigned char *)calloc((size_t)n, 1);
    if (!done) return PRIMME_MALLOC_FAILURE;
-   for (int i = 0; i < n; i++) {
+   int is_perm = 1;
+   for (int i = 0; i < n && is_perm; i++) {
+      if (perm[i] < 0 || perm[i] >= n || done[perm[i]]) is_perm = 0;
+      else done[perm[i]] = 1;
+   }
+   int rc = 0;
+   if (!is_perm) {
+      /* a gather with repeated sources: through a copy of the columns */
+      free(done);
+      for (int i = 0; i < n; i++) if (perm[i] < 0 || perm[i] >= n) return PRIMME_UNEXPECTED_FAILURE;
+      char *tmp = NULL;
+      const size_t colB = (size_t)ldb * s->es;
+      if (n <= s->nT && ldb == s->ld) tmp = s->T;
+      else if (hipk_malloc(s->ctx, colB * (size_t)n, (void **)&tmp)) return PRIMME_MALLOC_FAILURE;
+      rc = hipk_copy_cols(s->ctx, s->dt, s->m, base, ldb, tmp, ldb, n);
+      for (int i = 0; i < n && !rc; i++)
+         rc = hipk_copy_cols(s->ctx, s->dt, s->m, tmp + colB * (size_t)perm[i], ldb, PCOL(s, base, ldb, i), ldb, 1);
+      if (tmp != s->T) { if (!rc) rc = hipk_sync(s->ctx); hipk_free(s->ctx, tmp); }
+      return rc ? (rc < 0 ? rc : PRIMME_UNEXPECTED_FAILURE) : 0;
+   }
+   /* a permutation: in place along its cycles with one scratch column */
+   memset(done, 0, (size_t)n);
+   for (int i = 0; i < n && !rc; i++) {
       if (done[i] || perm[i] == i) continue;
-      int rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, i), ldb, TCOL(s, 0), s->ld, 1);
+      rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, i), ldb, TCOL(s, 0), s->ld, 1);
       int j = i;
       while (!rc && perm[j] != i) {
          rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, perm[j]), ldb, PCOL(s, base, ldb, j), ldb, 1);
@@ -342,10 +364,9 @@ static int permute_dev_cols(pa_solver *s, char *base, int64_t ldb, int n, const 
       }
       if (!rc) rc = hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, PCOL(s, base, ldb, j), ldb, 1);
       done[j] = 1;
-      if (rc) { free(done); return rc < 0 ? rc : PRIMME_UNEXPECTED_FAILURE; }
    }
    free(done);
-   return 0;
+   return rc ? (rc < 0 ? rc : PRIMME_UNEXPECTED_FAILURE) : 0;
 }
 
 /* ================================ main iteration ================================ */
