@@ -377,6 +377,8 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
        restartLimitReached, nprevhVecs = 0, reset = 0, restartsSinceReset = 0, wholeSpace = 0, touch = 0,
        numConvergedStored = 0;
    const int maxNumRandoms = 10;
+   int idleRestarts = 0, idleOuter = 0;
+   PRIMME_INT mvAtLastRestart = -1, mvAtLastOuter = -1;
    double smallestResNorm = HUGE_VAL;
    int *flags = s->flags, *map = s->map, *iev = s->iev, *perm = s->perm;
    /* re-evaluated at every use: the dynamic method changes maxInnerIterations on the way */
@@ -441,6 +443,12 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
          /* ------------------ main block Davidson loop ------------------ */
          while (basisSize < p->maxBasisSize && OUTER_LIMITS_OK()) {
+            /* same guard inside the loop: the basis already spans the space left (it can not reach a
+             * maxBasisSize above it) and outer iterations go by without an operator application */
+            if (p->stats.numMatvecs == mvAtLastOuter) {
+               if (++idleOuter >= 8 && basisSize + numLocked + p->numOrthoConst >= p->n) { wholeSpace = 1; break; }
+            } else idleOuter = 0;
+            mvAtLastOuter = p->stats.numMatvecs;
             p->stats.numOuterIterations++;
             if (p->numTargetShifts > numConverged + 1 && s->Q) {
                /* a QR per target shift: one pair at a time (reference main_iter.c:527-530) */
@@ -713,6 +721,14 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
          p->stats.numRestarts++;
          p->initSize = numConverged;
+         /* Three restarts in a row without a single operator application: the basis cannot grow (it
+          * spans what is left of the space) and the pairs in it do not meet the tolerance -- e.g. single
+          * precision, a block that is a sizeable fraction of n.  The reference restarts the same
+          * basis forever there (seen with n = 88, block 20, 3 constraints, float); this solver hands
+          * back what it has, as it does when the basis fills the space (wholeSpace). */
+         if (p->stats.numMatvecs == mvAtLastRestart) { if (++idleRestarts >= 3) wholeSpace = 1; }
+         else idleRestarts = 0;
+         mvAtLastRestart = p->stats.numMatvecs;
          if (s->wtr_enabled && s->fuse_gd && !s->Q) CHK(pa_refresh_wtq(s, basisSize, p->numOrthoConst + numLocked));
          if (p->dynamicMethodSwitch == 1) {
             /* few eigenpairs: GD+k is judged after each restart, restart cost included */

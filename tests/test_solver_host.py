@@ -332,3 +332,20 @@ def test_skew_projector_single_pair_against_live_reference(built):
     assert a.ret == 0 and b.ret == 0 and abs(a.evals[0] - b.evals[0]) <= 1e-10 * a.params["aNorm"]
     for key in ("numOuterIterations", "numMatvecs", "numPreconds", "numRestarts"):
         assert a.stats[key] == b.stats[key], key
+
+
+def test_returns_instead_of_spinning_when_the_space_is_exhausted(built):
+    """n = 88 with 3 constraints, block size 20, single precision: after two outer iterations the basis
+    spans everything that is left, nothing more can be added and the pairs do not meet the tolerance.
+    The reference restarts the same basis forever here (and with maxBasisSize above the space it never
+    leaves the inner loop); this solver must come back with PRIMME_MAIN_ITER_FAILURE."""
+    rp, ci, va, n = problems.laplacian_csr((11, 8))
+    rng = np.random.default_rng(5)
+    Q = np.linalg.qr(rng.standard_normal((n, 3)))[0]
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", dtype=np.float32, method="GD_plusK", numEvals=20, eps=1e-4,
+              iseed=(3200, 3490, 3396, 3989), target="largest", maxBlockSize=20, constraints=Q, maxMatvecs=15000)
+    assert r.ret in (0, -3) and r.stats["numMatvecs"] <= 15000
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", dtype=np.float32, method="JD_Olsen_plusK", numEvals=30, eps=1e-4,
+              iseed=(938, 3511, 1144, 2009), target="largest", maxBlockSize=6, maxBasisSize=150, precond=("jacobi", 0.2033),
+              constraints=Q, maxMatvecs=15000)
+    assert r.ret in (0, -3) and r.stats["numMatvecs"] <= 15000
