@@ -73,9 +73,9 @@ extern "C" int primme_amd_operator_create(primme_amd_operator **out, hipk_csr *A
 
 extern "C" int primme_amd_operator_destroy(primme_amd_operator *op) {
    if (!op) return 0;
-   if (op->buf_lo) hipFree(op->buf_lo);
-   if (op->buf_hi) hipFree(op->buf_hi);
-   if (op->xfull) hipFree(op->xfull);
+   if (op->buf_lo) (void)hipFree(op->buf_lo);
+   if (op->buf_hi) (void)hipFree(op->buf_hi);
+   if (op->xfull) (void)hipFree(op->xfull);
    free(op);
    return 0;
 }
@@ -202,9 +202,9 @@ extern "C" int primme_amd_svds_operator_create_dist(primme_amd_svds_operator **o
 
 extern "C" int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op) {
    if (!op) return 0;
-   if (op->full) hipFree(op->full);
-   if (op->jac_r) hipFree(op->jac_r);
-   if (op->jac_c) hipFree(op->jac_c);
+   if (op->full) (void)hipFree(op->full);
+   if (op->jac_r) (void)hipFree(op->jac_r);
+   if (op->jac_c) (void)hipFree(op->jac_c);
    hipk_csr_destroy(op->A); hipk_csr_destroy(op->At);
    free(op);
    return 0;

@@ -64,8 +64,8 @@ extern "C" int primme_amd_comm_destroy(primme_amd_comm *c) {
    if (!c) return 0;
    hipStreamSynchronize(c->stream);
    ncclCommDestroy(c->comm);
-   hipFree(c->dbuf);
-   hipStreamDestroy(c->stream);
+   (void)hipFree(c->dbuf);
+   (void)hipStreamDestroy(c->stream);
    free(c);
    return 0;
 }
@@ -88,7 +88,7 @@ extern "C" void primme_amd_global_sum(void *sendBuf, void *recvBuf, int *count,
    const size_t n = (size_t)*count;
    if (n == 0) { *ierr = 0; return; }
    if (n > c->dbuf_cap) {
-      hipFree(c->dbuf);
+      (void)hipFree(c->dbuf);
       c->dbuf_cap = 2 * n;
       if (hipMalloc((void **)&c->dbuf, c->dbuf_cap * sizeof(double)) != hipSuccess) return;
    }
@@ -156,6 +156,6 @@ extern "C" int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *
    NCCL_CHECK(ncclAllGather(d + (size_t)c->nranks * n, d, (size_t)n * sizeof(int64_t), ncclChar, c->comm, c->stream));
    HIPK_CHECK(hipMemcpyAsync(all, d, (size_t)c->nranks * n * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
    HIPK_CHECK(hipStreamSynchronize(c->stream));
-   hipFree(d);
+   (void)hipFree(d);
    return 0;
 }

@@ -89,7 +89,6 @@ int pa_trace_errors(void) {
 }
 
 int pa_reduce_host(pa_solver *s, double *buf, int count) {
-   primme_params *p = s->p;
    if (count <= 0 || !s->parallel) return 0;
    CHK(hipk_sync(s->ctx));
    memcpy(s->h_red, buf, (size_t)count * sizeof(double));

@@ -34,11 +34,11 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
 extern "C" int hipk_ctx_destroy(hipk_ctx *ctx) {
    if (!ctx) return 0;
    hipStreamSynchronize(ctx->stream);
-   if (ctx->partials) hipFree(ctx->partials);
-   if (ctx->jobtab) hipFree(ctx->jobtab);
-   hipEventDestroy(ctx->ev0);
-   hipEventDestroy(ctx->ev1);
-   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+   if (ctx->partials) (void)hipFree(ctx->partials);
+   if (ctx->jobtab) (void)hipFree(ctx->jobtab);
+   (void)hipEventDestroy(ctx->ev0);
+   (void)hipEventDestroy(ctx->ev1);
+   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
    free(ctx);
    return 0;
 }
@@ -359,7 +359,7 @@ extern "C" int hipk_sym_eig(hipk_ctx *ctx, int n, const double *A_host, int lda,
    double *dA = buf, *dZ = buf + nn, *dE = dZ + nn;
    int *dS = (int *)(dE + n);
    double *tight = (double *)malloc(nn * sizeof(double));
-   if (!tight) { hipFree(buf); return -2; }
+   if (!tight) { (void)hipFree(buf); return -2; }
    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) tight[i + (size_t)j * n] = (i <= j) ? A_host[i + (size_t)j * lda] : 0.0;
    hipError_t e = hipMemcpyAsync(dA, tight, nn * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
    if (e == hipSuccess) {
@@ -371,7 +371,7 @@ extern "C" int hipk_sym_eig(hipk_ctx *ctx, int n, const double *A_host, int lda,
    if (e == hipSuccess) e = hipMemcpyAsync(ev, dE, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
    if (e == hipSuccess) e = hipMemcpyAsync(Z, dZ, nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-   hipFree(buf);
+   (void)hipFree(buf);
    free(tight);
    if (e != hipSuccess) { free(ev); free(Z); fprintf(stderr, "primme_amd: hipk_sym_eig: %s\n", hipGetErrorString(e)); return -1; }
    /* ascending order, like the host solver */

@@ -361,11 +361,11 @@ extern "C" int hipk_stencil_create(hipk_ctx *ctx, hipk_dtype dt, int nx, int ny,
 extern "C" int hipk_csr_destroy(hipk_csr *A) {
    if (!A) return 0;
    hipStreamSynchronize(A->ctx->stream);
-   if (A->rowptr) hipFree(A->rowptr);
-   if (A->colind) hipFree(A->colind);
-   if (A->values) hipFree(A->values);
-   if (A->tiles) hipFree(A->tiles);
-   if (A->diag) hipFree(A->diag);
+   if (A->rowptr) (void)hipFree(A->rowptr);
+   if (A->colind) (void)hipFree(A->colind);
+   if (A->values) (void)hipFree(A->values);
+   if (A->tiles) (void)hipFree(A->tiles);
+   if (A->diag) (void)hipFree(A->diag);
    free(A);
    return 0;
 }
