@@ -377,7 +377,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
        restartLimitReached, nprevhVecs = 0, reset = 0, restartsSinceReset = 0, wholeSpace = 0, touch = 0,
        numConvergedStored = 0;
    const int maxNumRandoms = 10;
-   int idleRestarts = 0, idleOuter = 0;
+   int idleRestarts = 0, idleOuter = 0, stalled = 0, bsAtLastRestart = -1, ncAtLastRestart = -1, nlAtLastRestart = -1;
    PRIMME_INT mvAtLastRestart = -1, mvAtLastOuter = -1;
    double smallestResNorm = HUGE_VAL;
    int *flags = s->flags, *map = s->map, *iev = s->iev, *perm = s->perm;
@@ -446,7 +446,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
             /* same guard inside the loop: the basis already spans the space left (it can not reach a
              * maxBasisSize above it) and outer iterations go by without an operator application */
             if (p->stats.numMatvecs == mvAtLastOuter) {
-               if (++idleOuter >= 8 && basisSize + numLocked + p->numOrthoConst >= p->n) { wholeSpace = 1; break; }
+               if (++idleOuter >= 8 && basisSize + numLocked + p->numOrthoConst >= p->n) { stalled = wholeSpace = 1; break; }
             } else idleOuter = 0;
             mvAtLastOuter = p->stats.numMatvecs;
             p->stats.numOuterIterations++;
@@ -724,11 +724,14 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
          /* Three restarts in a row without a single operator application: the basis cannot grow (it
           * spans what is left of the space) and the pairs in it do not meet the tolerance -- e.g. single
           * precision, a block that is a sizeable fraction of n.  The reference restarts the same
-          * basis forever there (seen with n = 88, block 20, 3 constraints, float); this solver hands
-          * back what it has, as it does when the basis fills the space (wholeSpace). */
-         if (p->stats.numMatvecs == mvAtLastRestart) { if (++idleRestarts >= 3) wholeSpace = 1; }
+          * basis forever there (seen with n = 88, block 20, 3 constraints, float); this solver leaves
+          * the loops with what it has and returns PRIMME_MAIN_ITER_FAILURE.  "Idle" = five restarts
+          * in a row with the same basis size, the same converged / locked counts and no operator
+          * application in between. */
+         if (p->stats.numMatvecs == mvAtLastRestart && basisSize == bsAtLastRestart && numConverged == ncAtLastRestart &&
+               numLocked == nlAtLastRestart) { if (++idleRestarts >= 5) stalled = wholeSpace = 1; }
          else idleRestarts = 0;
-         mvAtLastRestart = p->stats.numMatvecs;
+         mvAtLastRestart = p->stats.numMatvecs; bsAtLastRestart = basisSize; ncAtLastRestart = numConverged; nlAtLastRestart = numLocked;
          if (s->wtr_enabled && s->fuse_gd && !s->Q) CHK(pa_refresh_wtq(s, basisSize, p->numOrthoConst + numLocked));
          if (p->dynamicMethodSwitch == 1) {
             /* few eigenpairs: GD+k is judged after each restart, restart cost included */
@@ -752,7 +755,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
          if (*numRet < numConverged) *numRet = numConverged;
          pa_dyn_recommend(&cost, p);
          p->stats.lockingIssue = 0;
-         *ret = (numConverged == p->numEvals || wholeSpace) ? 0 : PRIMME_MAIN_ITER_FAILURE;
+         *ret = (numConverged == p->numEvals || (wholeSpace && !stalled)) ? 0 : PRIMME_MAIN_ITER_FAILURE;
          goto clean;
       } else {
          restartLimitReached = OUTER_LIMITS_OK() ? 0 : 1;
