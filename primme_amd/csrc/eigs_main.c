@@ -844,11 +844,10 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    const int refined = (p->projectionParams.projection == primme_proj_refined);
    const int harmonic = (p->projectionParams.projection == primme_proj_harmonic) || refined;
    if (p->massMatrixMatvec ||
-         (harmonic && (p->orth != primme_orth_implicit_I || p->target == primme_smallest ||
-                       p->target == primme_largest || p->target == primme_largest_abs))) {
+         (harmonic && (p->target == primme_smallest || p->target == primme_largest || p->target == primme_largest_abs))) {
       if (p->printLevel > 0 && p->outputFile)
          fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / harmonic or refined "
-               "projection with explicit_I or an extremal target) is not on the device path\n");
+               "projection with an extremal target) is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 

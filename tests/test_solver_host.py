@@ -349,3 +349,30 @@ def test_returns_instead_of_spinning_when_the_space_is_exhausted(built):
               iseed=(938, 3511, 1144, 2009), target="largest", maxBlockSize=6, maxBasisSize=150, precond=("jacobi", 0.2033),
               constraints=Q, maxMatvecs=15000)
     assert r.ret in (0, -3) and r.stats["numMatvecs"] <= 15000
+
+
+@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("projection", ["harmonic", "refined"])
+@pytest.mark.parametrize("dtype,block,eps", [(np.float64, 3, 1e-9), (np.float32, 1, 1e-4), (np.float32, 3, 1e-4)])
+def test_interior_extractions_with_explicit_I_against_live_reference(built, projection, dtype, block, eps):
+    """Harmonic / refined extraction when the basis is kept with a tracked Gram matrix (blocks, single
+    precision: orth = explicit_I).  The reference tracks Q'Q as well (solve_projection.c:431-520,
+    :542-560); here Q stays orthonormal by Gram-Schmidt with reorthogonalisation and only V'V enters
+    the coefficient vectors.  Same eigenpairs, similar iteration counts."""
+    rp, ci, va, n = problems.laplacian_csr((20, 21))
+    A = np.zeros((n, n)); A[np.repeat(np.arange(n), np.diff(rp)), ci] = va
+    w = np.linalg.eigvalsh(A)
+    kw = dict(dtype=dtype, numEvals=4, target="closest_abs", targetShifts=[3.3], projection=projection, maxBlockSize=block,
+              eps=eps, method="GD_Olsen_plusK", iseed=(1, 2, 3, 4), maxMatvecs=30000)
+    ref = eigsh(Operator(n, csr=(rp, ci, va)), backend="reference", **kw)
+    got = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", **kw)
+    assert ref.ret == 0 and got.ret == 0 and got.initSize == 4
+    assert got.params["orth"] == ref.params["orth"] == 2          # primme_orth_explicit_I
+    aN = got.params["aNorm"]
+    X = got.evecs.astype(np.float64)
+    res = np.linalg.norm(A @ X - X * got.evals.astype(np.float64), axis=0)
+    assert np.all(res <= 1.5 * eps * aN + 50 * np.finfo(dtype).eps * aN)
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    assert all(np.min(np.abs(w - ev)) <= tol * aN for ev in got.evals)
+    assert np.max(np.abs(np.sort(got.evals) - np.sort(ref.evals))) <= (1e-8 if dtype == np.float64 else 5e-3) * aN
+    assert abs(got.stats["numOuterIterations"] - ref.stats["numOuterIterations"]) <= 0.25 * ref.stats["numOuterIterations"]
