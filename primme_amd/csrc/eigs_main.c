@@ -565,8 +565,9 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                }
                free(Rlocked);
                Rlocked = NULL;
-               if (numConverged > numLocked && p->target != primme_smallest && p->target != primme_largest)
-                  break;
+               if (numConverged > numLocked && p->target != primme_smallest && p->target != primme_largest &&
+                     (!s->Q || p->target == primme_closest_geq || p->target == primme_closest_leq))
+                  break;   /* (reference main_iter.c:789-796: with harmonic / refined only for closest_geq / leq) */
             }
 
             if (s->spec2_valid && s->spec2_k == basisSize && blockSize == 1) {

@@ -263,7 +263,7 @@ def test_hip_interior_pairs_medium_size(built, projection):
 def test_hip_interior_extractions_with_explicit_I(built, projection, dtype, block, eps):
     """Harmonic / refined extraction with blocks and in single precision (orth = explicit_I) on the
     device, against the checker run and the analytic spectrum."""
-    dims = (20, 21, 19)
+    dims = (12, 13, 11)
     rp, ci, va, n = problems.laplacian_csr(dims)
     i, j, k = np.meshgrid(*(np.arange(1, d + 1) for d in dims), indexing="ij")
     w = (6 - 2 * np.cos(i * np.pi / (dims[0] + 1)) - 2 * np.cos(j * np.pi / (dims[1] + 1)) - 2 * np.cos(k * np.pi / (dims[2] + 1))).ravel()
