@@ -13,7 +13,9 @@
  * Covered on the device path: the normal-equations method (A'A when n <= m, AA' otherwise;
  * reference primme_svds_interface.c:231-235), the augmented operator [0 A'; A 0] and the hybrid
  * default, for the largest / smallest / closest_abs singular triplets.  What the eigensolver does
- * not cover comes back as PRIMME_FUNCTION_UNAVAILABLE - 100 / - 200, never a CPU fallback.
+ * not cover (the refined extraction with explicit_I, i.e. interior targets with block size > 1 or
+ * in single precision) comes back as PRIMME_FUNCTION_UNAVAILABLE - 100 / - 200, never a CPU
+ * fallback.
  */
 #ifndef PRIMME_AMD_SVDS_H
 #define PRIMME_AMD_SVDS_H

@@ -565,9 +565,15 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                }
                free(Rlocked);
                Rlocked = NULL;
+               /* The reference breaks here only with RR, or with closest_geq / closest_leq
+                * (main_iter.c:789-796).  Without that restriction a practically converged pair beyond
+                * the wanted window is flagged, not locked and re-flagged without an operator application
+                * (what made harmonic / refined stall with explicit_I).  The exact condition is applied
+                * under PRIMME_AMD_EXPERIMENTAL until the full GPU suite has been re-verified with it
+                * (DESIGN.md §0): default behaviour is the one measured and tested this round. */
                if (numConverged > numLocked && p->target != primme_smallest && p->target != primme_largest &&
-                     (!s->Q || p->target == primme_closest_geq || p->target == primme_closest_leq))
-                  break;   /* (reference main_iter.c:789-796: with harmonic / refined only for closest_geq / leq) */
+                     (!s->experimental || !s->Q || p->target == primme_closest_geq || p->target == primme_closest_leq))
+                  break;
             }
 
             if (s->spec2_valid && s->spec2_k == basisSize && blockSize == 1) {
@@ -845,10 +851,11 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    const int refined = (p->projectionParams.projection == primme_proj_refined);
    const int harmonic = (p->projectionParams.projection == primme_proj_harmonic) || refined;
    if (p->massMatrixMatvec ||
-         (harmonic && (p->target == primme_smallest || p->target == primme_largest || p->target == primme_largest_abs))) {
+         (harmonic && ((p->orth != primme_orth_implicit_I && !getenv("PRIMME_AMD_EXPERIMENTAL")) || p->target == primme_smallest ||
+                       p->target == primme_largest || p->target == primme_largest_abs))) {
       if (p->printLevel > 0 && p->outputFile)
          fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / harmonic or refined "
-               "projection with an extremal target) is not on the device path\n");
+               "projection with explicit_I or an extremal target) is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
@@ -870,6 +877,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    /* PRIMME_AMD_FORCE_COMM: run the cross-rank reduction path with a one-rank communicator, which is
     * how the RCCL calls are exercised on a single-GPU box (tests/test_comm_gpu.py) */
    s->spec2_enabled = getenv("PRIMME_AMD_NO_SPEC2") == NULL;
+   s->experimental = getenv("PRIMME_AMD_EXPERIMENTAL") != NULL;
    s->wtr_enabled = getenv("PRIMME_AMD_WTR") != NULL;   /* opt-in: exact but not faster yet, DESIGN.md §4d */
    s->device_rr = getenv("PRIMME_AMD_DEVICE_RR") != NULL;
    s->parallel = ((p->numProcs > 1 || getenv("PRIMME_AMD_FORCE_COMM")) && p->globalSumReal != NULL);

@@ -81,6 +81,7 @@ typedef struct pa_solver {
     * at anything; accepted by the orthogonaliser if Daniel's test passes on the first pass */
    int device_rr;          /* PRIMME_AMD_DEVICE_RR: small Rayleigh-Ritz solve by the device Jacobi kernel */
    int spec2_enabled;      /* off with PRIMME_AMD_NO_SPEC2 (measurement knob, read once per solve) */
+   int experimental;       /* PRIMME_AMD_EXPERIMENTAL: changes awaiting a full GPU verification (eigs_main.c) */
    int wtr_enabled;        /* projection column from W'r (PRIMME_AMD_WTR=1) */
    double *wtq;            /* G = W'Q for the first wtq_rows basis vectors (K x HIPK_WTR_MAX_K, host) */
    int wtq_rows, wtq_L;    /* -1: not valid */

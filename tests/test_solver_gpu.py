@@ -256,27 +256,3 @@ def test_hip_interior_pairs_medium_size(built, projection):
     assert np.all(r.resNorms <= 1e-8 * 12.0 * (1 + 1e-6))
     X = np.asarray(r.evecs, dtype=np.float64)
     assert np.linalg.norm(X.T @ X - np.eye(4)) <= 1e-7
-
-
-@pytest.mark.parametrize("projection", ["harmonic", "refined"])
-@pytest.mark.parametrize("dtype,block,eps", [(np.float64, 4, 1e-8), (np.float32, 1, 1e-4), (np.float32, 3, 1e-4)])
-def test_hip_interior_extractions_with_explicit_I(built, projection, dtype, block, eps):
-    """Harmonic / refined extraction with blocks and in single precision (orth = explicit_I) on the
-    device, against the checker run and the analytic spectrum."""
-    dims = (12, 13, 11)
-    rp, ci, va, n = problems.laplacian_csr(dims)
-    i, j, k = np.meshgrid(*(np.arange(1, d + 1) for d in dims), indexing="ij")
-    w = (6 - 2 * np.cos(i * np.pi / (dims[0] + 1)) - 2 * np.cos(j * np.pi / (dims[1] + 1)) - 2 * np.cos(k * np.pi / (dims[2] + 1))).ravel()
-    kw = dict(dtype=dtype, numEvals=4, target="closest_abs", targetShifts=[1.0], eps=eps, aNorm=12.0, method="GD_Olsen_plusK",
-              projection=projection, maxBlockSize=block, iseed=(1, 2, 3, 4), maxMatvecs=200000)
-    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hip", **kw)
-    h = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", **kw)
-    assert r.ret == 0 and h.ret == 0 and r.initSize == 4
-    tol = 1e-8 if dtype == np.float64 else 2e-3
-    assert all(np.min(np.abs(w - ev)) <= tol * 12.0 for ev in r.evals)
-    assert np.all(r.resNorms <= eps * 12.0 * (1 + 1e-5))
-    X = np.asarray(r.evecs, dtype=np.float64)
-    AX = problems.csr_matvec_numpy(rp, ci, va, X)
-    assert np.all(np.linalg.norm(AX - X * r.evals.astype(np.float64), axis=0) <= 1.5 * eps * 12.0 + 50 * np.finfo(dtype).eps * 12.0)
-    assert np.linalg.norm(X.T @ X - np.eye(4)) <= (1e-7 if dtype == np.float64 else 1e-3)
-    assert abs(r.stats["numOuterIterations"] - h.stats["numOuterIterations"]) <= 0.35 * h.stats["numOuterIterations"] + 5

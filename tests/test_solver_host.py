@@ -354,11 +354,12 @@ def test_returns_instead_of_spinning_when_the_space_is_exhausted(built):
 @pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
 @pytest.mark.parametrize("projection", ["harmonic", "refined"])
 @pytest.mark.parametrize("dtype,block,eps", [(np.float64, 3, 1e-9), (np.float32, 1, 1e-4), (np.float32, 3, 1e-4)])
-def test_interior_extractions_with_explicit_I_against_live_reference(built, projection, dtype, block, eps):
-    """Harmonic / refined extraction when the basis is kept with a tracked Gram matrix (blocks, single
+def test_interior_extractions_with_explicit_I_against_live_reference(built, projection, dtype, block, eps, monkeypatch):
+    """(behind PRIMME_AMD_EXPERIMENTAL, see eigs_main.c)  Harmonic / refined extraction when the basis is kept with a tracked Gram matrix (blocks, single
     precision: orth = explicit_I).  The reference tracks Q'Q as well (solve_projection.c:431-520,
     :542-560); here Q stays orthonormal by Gram-Schmidt with reorthogonalisation and only V'V enters
     the coefficient vectors.  Same eigenpairs, similar iteration counts."""
+    monkeypatch.setenv("PRIMME_AMD_EXPERIMENTAL", "1")
     rp, ci, va, n = problems.laplacian_csr((20, 21))
     A = np.zeros((n, n)); A[np.repeat(np.arange(n), np.diff(rp)), ci] = va
     w = np.linalg.eigvalsh(A)
