@@ -9,6 +9,8 @@ by bench.py's cpu_baseline leg:
 The product path (backend="hip") never touches either of them.
 """
 import ctypes as C
+import hashlib
+
 import numpy as np
 
 from . import _ffi as F
@@ -242,7 +244,7 @@ class Session:
                 evecs_t = evecs_buf[:ncols * nLocal].view(ncols, nLocal)
                 if v0 is not None:
                     # the start vectors are uploaded once per Session and stay in HBM
-                    key = (v0.shape, float(v0.ravel()[0]), float(v0.ravel()[-1]))
+                    key = (v0.shape, v0.dtype.str, hashlib.sha1(np.ascontiguousarray(v0).tobytes()).hexdigest())
                     if self._v0_cache is None or self._v0_cache[0] != key:
                         self._v0_cache = (key, torch.from_numpy(np.ascontiguousarray(v0.T)).to("cuda"))
                     evecs_t[nOC:nOC + initSize] = self._v0_cache[1]
@@ -261,9 +263,12 @@ class Session:
 
         if global_sum is not None:
             def gs(send, recv, count, pp, ierr):
+                # operands arrive in the declared type: float for the single-precision entry points
+                # unless the application set globalSumReal_type (reference primme_c.c:170-183)
                 n_ = count[0]
-                a = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(n_,)).copy()
-                np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(n_,))[:] = global_sum(a)
+                ct = C.c_float if pp[0].globalSumReal_type == F.primme_op_float else C.c_double
+                a = np.ctypeslib.as_array(C.cast(send, C.POINTER(ct)), shape=(n_,)).astype(np.float64)
+                np.ctypeslib.as_array(C.cast(recv, C.POINTER(ct)), shape=(n_,))[:] = global_sum(a)
                 ierr[0] = 0
             gcb = F.GLOBAL_SUM(gs)
             keep.append(gcb)

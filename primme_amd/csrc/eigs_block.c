@@ -87,15 +87,19 @@ int pa_update_cholesky(const double *G, int ldG, double *fG, int ldfG, int n0, i
 
 /* X(:, 0:nX) <- X * M (M nX x nX on the host), in place, one pass over X */
 static int right_multiply(pa_solver *s, char *X, int64_t ldX, int nX, const double *M) {
-   for (int j = 0; j < nX; j++)
-      memcpy(s->h_coef + (size_t)j * s->K, M + (size_t)j * nX, (size_t)nX * sizeof(double));
-   CHK(hipk_h2d(s->ctx, s->d_coef, s->h_coef, (size_t)s->K * nX * sizeof(double)));
+   /* M travels tightly packed (leading dimension nX): the block can be wider than maxBasisSize
+    * (numOrthoConst > maxBasisSize in init_basis), the coefficient buffers hold max(K, numOrthoConst)^2 */
+   if ((size_t)nX * nX > s->coef_cap) return PRIMME_UNEXPECTED_FAILURE;
+   memcpy(s->h_coef, M, (size_t)nX * nX * sizeof(double));
+   CHK(hipk_h2d(s->ctx, s->d_coef, s->h_coef, (size_t)nX * nX * sizeof(double)));
    s->coef_valid_k = -1;
    hipk_job jobs[HIPK_MAX_JOBS];
+   /* wider than one launch's job table: column chunks read the whole row first, so they would see
+    * already-updated columns -> go through the scratch panel */
    if (nX > HIPK_MAX_JOBS) return PRIMME_FUNCTION_UNAVAILABLE;
    for (int c = 0; c < nX; c++) jobs[c] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, X, ldX, c), -1};
    /* the panel X plays the role of "V" (k = nX columns); W is not touched */
-   return hipk_ritz_update(s->ctx, s->dt, s->m, X, X, ldX, nX, s->d_coef, s->K, s->d_theta, jobs, nX, NULL);
+   return hipk_ritz_update(s->ctx, s->dt, s->m, X, X, ldX, nX, s->d_coef, nX, s->d_theta, jobs, nX, NULL);
 }
 
 /* Orthonormalise Vp(:, b1..b2) against locked (numLocked columns), Vp(:, 0..b1) and among
@@ -125,6 +129,10 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
    double *M = (double *)malloc((size_t)nX * nX * sizeof(double));
    if (!D || !N || !GdA || !Y || !Cm || !M) return PRIMME_MALLOC_FAILURE;
    int rc = 0;
+   if ((size_t)nrowsA * nX > (size_t)s->red_cap || (size_t)nVL * nX > (size_t)s->red_cap || nrowsA > ldG) {
+      free(r); free(D); free(N); free(GdA); free(Y); free(Cm); free(M);
+      return PRIMME_UNEXPECTED_FAILURE;
+   }
 
    *b2_out = b2;
    const int maxits = 5;

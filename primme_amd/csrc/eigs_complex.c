@@ -28,6 +28,7 @@
 #include <string.h>
 #include "primme_amd.h"
 #include "primme_amd_kernels.h"
+#include "eigs_internal.h"
 
 int pa_eigs_solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double);
 
@@ -59,7 +60,8 @@ static void cx_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *
 }
 static void cx_global_sum(void *s, void *r, int *count, primme_params *qp, int *ierr) {
    cplx_side *sd = SIDE_OF(qp);
-   sd->user->globalSumReal(s, r, count, sd->user, ierr);
+   if (s != r) memcpy(r, s, sizeof(double) * (size_t)*count);
+   *ierr = pa_call_global_sum(sd->user, (double *)r, *count) ? 1 : 0;
 }
 static void cx_broadcast(void *buf, int *count, primme_params *qp, int *ierr) {
    cplx_side *sd = SIDE_OF(qp);
@@ -68,7 +70,7 @@ static void cx_broadcast(void *buf, int *count, primme_params *qp, int *ierr) {
 static void cx_conv_test(double *eval, void *evec, double *rNorm, int *isconv, primme_params *qp, int *ierr) {
    cplx_side *sd = SIDE_OF(qp);
    sync_user(sd);
-   sd->user->convTestFun(eval, evec, rNorm, isconv, sd->user, ierr);
+   *ierr = pa_call_conv_test(sd->user, *eval, evec, *rNorm, isconv) ? 1 : 0;
 }
 static void cx_monitor(void *basisEvals, int *basisSize, int *basisFlags, int *iblock, int *blockSize,
       void *basisNorms, int *numConverged, void *lockedEvals, int *numLocked, int *lockedFlags,
@@ -137,10 +139,10 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
    if (q->locking == 0 && q->numEvals > q->minRestartSize) q->locking = 1;
    q->matrixMatvec = cx_matvec;
    if (primme->applyPreconditioner) q->applyPreconditioner = cx_precond;
-   if (primme->globalSumReal && primme->globalSumReal != primme_amd_global_sum) q->globalSumReal = cx_global_sum;
+   if (primme->globalSumReal && primme->globalSumReal != primme_amd_global_sum) { q->globalSumReal = cx_global_sum; q->globalSumReal_type = primme_op_double; }
    if (primme->broadcastReal) q->broadcastReal = cx_broadcast;
-   if (primme->convTestFun) q->convTestFun = cx_conv_test;
-   if (primme->monitorFun) q->monitorFun = cx_monitor;
+   if (primme->convTestFun) { q->convTestFun = cx_conv_test; q->convTestFun_type = primme_op_double; }
+   if (primme->monitorFun) { q->monitorFun = cx_monitor; q->monitorFun_type = primme_op_double; }
 
    int ret = 0;
    hipk_ctx *ctx = NULL;
@@ -190,20 +192,18 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
             double nrm2 = 1.0;
             if (acc > 0) {
                hipk_seg segs[2] = {{Z, ldr, acc}, {rot, ldr, acc}};
-               int cnt = 2 * acc, ierr = 0;
+               int cnt = 2 * acc;
                if (hipk_panel_dots(ctx, dtr, mr, segs, 2, u, ldr, 1, d_s, cnt) ||
                    hipk_d2h(ctx, h_s, d_s, sizeof(double) * (size_t)cnt) || hipk_sync(ctx)) { free(used); ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
                if (primme->numProcs > 1 && primme->globalSumReal) {
-                  primme->globalSumReal(h_s, h_s, &cnt, primme, &ierr);
-                  if (ierr) { free(used); ret = PRIMME_USER_FAILURE; goto done; }
+                  if (pa_call_global_sum(primme, h_s, cnt)) { free(used); ret = PRIMME_USER_FAILURE; goto done; }
                }
                cnt = 1;
                if (hipk_h2d(ctx, d_s, h_s, sizeof(double) * (size_t)(2 * acc)) ||
                    hipk_panel_project(ctx, dtr, mr, segs, 2, d_s, 2 * acc, u, ldr, 1, d_s + 2 * acc) ||
                    hipk_d2h(ctx, h_s, d_s + 2 * acc, sizeof(double)) || hipk_sync(ctx)) { free(used); ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
                if (primme->numProcs > 1 && primme->globalSumReal) {
-                  primme->globalSumReal(h_s, h_s, &cnt, primme, &ierr);
-                  if (ierr) { free(used); ret = PRIMME_USER_FAILURE; goto done; }
+                  if (pa_call_global_sum(primme, h_s, cnt)) { free(used); ret = PRIMME_USER_FAILURE; goto done; }
                }
                nrm2 = h_s[0];
             }
@@ -242,8 +242,7 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
              hipk_d2h(ctx, h_s, d_s, sizeof(double) * (size_t)acc) || hipk_sync(ctx)) { free(theta); ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
          free(theta);
          if (primme->numProcs > 1 && primme->globalSumReal) {
-            primme->globalSumReal(h_s, h_s, &cnt, primme, &ierr);
-            if (ierr) { ret = PRIMME_USER_FAILURE; goto done; }
+            if (pa_call_global_sum(primme, h_s, cnt)) { ret = PRIMME_USER_FAILURE; goto done; }
          }
          for (int i = 0; i < acc; i++) {
             if (dtr == HIPK_F64) ((double *)resNorms_out)[i] = sqrt(h_s[i]);

@@ -29,13 +29,11 @@ void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv,
 
 static int call_conv_test(pa_solver *s, double eval, void *evec, double rnorm, int *isconv) {
    primme_params *p = s->p;
-   int ierr = 0;
    if (p->convTestFun == pa_conv_test_absolute) {
       *isconv = rnorm < PA_MAX(p->eps, s->mach_eps * 2) * pa_problem_norm(0, p);
       return 0;
    }
-   p->convTestFun(&eval, evec, &rnorm, isconv, p, &ierr);
-   return ierr ? PRIMME_UNEXPECTED_FAILURE : 0;
+   return pa_call_conv_test(p, eval, evec, rnorm, isconv);
 }
 
 /* X(:,inX) <- (I - Q Q') X(:,inX), norms of the result (one projector pass) */
@@ -172,10 +170,8 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
       }
       return;
    }
-   int err = 0;
-   double time = 0.0;
-   p->monitorFun(basisEvals, &basisSize, basisFlags, iblock, &blockSize, basisNorms, &numConverged,
-         lockedEvals, &numLocked, lockedFlags, lockedNorms, NULL, NULL, NULL, &time, &event, p, &err);
+   (void)pa_call_monitor(p, basisEvals, basisSize, basisFlags, iblock, blockSize, basisNorms, numConverged,
+         lockedEvals, numLocked, lockedFlags, lockedNorms, event);
 }
 
 /* Put the first unconverged Ritz pairs in the block, computing X, R and the

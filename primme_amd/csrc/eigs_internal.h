@@ -24,6 +24,17 @@ void pa_submatrix(const double *X, int nx, int ldx, const double *H, int nh, int
       int ldr);
 void pa_larnv_uniform11(int64_t iseed[4], int64_t n, double *x);
 
+/* user callbacks called with the operand type they declare (eigs_callbacks.c) */
+struct primme_svds_params;
+int pa_call_global_sum(primme_params *p, double *buf, int count);
+int pa_call_conv_test(primme_params *p, double eval, void *evec, double rnorm, int *isconv);
+int pa_call_monitor(primme_params *p, double *basisEvals, int basisSize, int *basisFlags, int *iblock, int blockSize,
+      double *basisNorms, int numConverged, double *lockedEvals, int numLocked, int *lockedFlags, double *lockedNorms,
+      primme_event event);
+int pa_svds_call_global_sum(struct primme_svds_params *ps, double *buf, int count);
+int pa_svds_call_conv_test(struct primme_svds_params *ps, double sval, void *leftsvec, void *rightsvec, double rnorm,
+      int *method, int *isconv);
+
 /* parameter handling (eigs_params.c) */
 int pa_check_input(const void *evals, const void *evecs, const void *resNorms,
       const primme_params *primme, double machine_eps);

@@ -44,9 +44,7 @@ static int conv_test(pa_solver *s, double eval, double rnorm, int *isconv) {
       *isconv = rnorm < PA_MAX(p->eps, s->mach_eps * 2) * pa_problem_norm(0, p);
       return 0;
    }
-   int ierr = 0;
-   p->convTestFun(&eval, NULL, &rnorm, isconv, p, &ierr);
-   return ierr ? PRIMME_UNEXPECTED_FAILURE : 0;
+   return pa_call_conv_test(p, eval, NULL, rnorm, isconv);
 }
 
 /* v(:, 0:nb) <- (I - Qhat Q') v for a panel Q (numCols columns), orthogonal form */

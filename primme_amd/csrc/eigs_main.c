@@ -566,13 +566,11 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                free(Rlocked);
                Rlocked = NULL;
                /* The reference breaks here only with RR, or with closest_geq / closest_leq
-                * (main_iter.c:789-796).  Without that restriction a practically converged pair beyond
-                * the wanted window is flagged, not locked and re-flagged without an operator application
-                * (what made harmonic / refined stall with explicit_I).  The exact condition is applied
-                * under PRIMME_AMD_EXPERIMENTAL until the full GPU suite has been re-verified with it
-                * (DESIGN.md §0): default behaviour is the one measured and tested this round. */
+                * (main_iter.c:789-796): with harmonic / refined extraction and closest_abs a practically
+                * converged pair beyond the wanted window would otherwise be flagged, not locked and
+                * re-flagged without an operator application in between. */
                if (numConverged > numLocked && p->target != primme_smallest && p->target != primme_largest &&
-                     (!s->experimental || !s->Q || p->target == primme_closest_geq || p->target == primme_closest_leq))
+                     (!s->Q || p->target == primme_closest_geq || p->target == primme_closest_leq))
                   break;
             }
 
@@ -838,6 +836,18 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    if (p->iseed[1] < 0 || p->iseed[1] > 4095) p->iseed[1] = (int)(p->procID / 4096 + 1) % 4096;
    if (p->iseed[2] < 0 || p->iseed[2] > 4095) p->iseed[2] = (int)((p->procID / 4096) / 4096 + 2) % 4096;
    if (p->iseed[3] < 0 || p->iseed[3] > 4095) p->iseed[3] = (2 * (int)(((p->procID / 4096) / 4096) / 4096) + 1) % 4096;
+   /* callbacks without a declared operand type get the entry point's precision, like the reference
+    * (primme_c.c:170-183); the library's own callbacks work on doubles.  eigs_callbacks.c converts. */
+   {
+      const primme_op_datatype scalar_t = work_is_float ? primme_op_float : primme_op_double;
+      if (p->matrixMatvec && p->matrixMatvec_type == primme_op_default) p->matrixMatvec_type = scalar_t;
+      if (p->applyPreconditioner && p->applyPreconditioner_type == primme_op_default) p->applyPreconditioner_type = scalar_t;
+      if (p->globalSumReal && p->globalSumReal_type == primme_op_default)
+         p->globalSumReal_type = (p->globalSumReal == primme_amd_global_sum) ? primme_op_double : scalar_t;
+      if (p->broadcastReal && p->broadcastReal_type == primme_op_default) p->broadcastReal_type = scalar_t;
+      if (p->convTestFun && p->convTestFun_type == primme_op_default) p->convTestFun_type = scalar_t;
+      if (p->monitorFun && p->monitorFun_type == primme_op_default) p->monitorFun_type = scalar_t;
+   }
    if (!p->convTestFun) {
       p->convTestFun = pa_conv_test_absolute;
       p->convTestFun_type = (dt == HIPK_F32 || dt == HIPK_C32) ? primme_op_float : primme_op_double;
@@ -851,11 +861,10 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    const int refined = (p->projectionParams.projection == primme_proj_refined);
    const int harmonic = (p->projectionParams.projection == primme_proj_harmonic) || refined;
    if (p->massMatrixMatvec ||
-         (harmonic && ((p->orth != primme_orth_implicit_I && !getenv("PRIMME_AMD_EXPERIMENTAL")) || p->target == primme_smallest ||
-                       p->target == primme_largest || p->target == primme_largest_abs))) {
+         (harmonic && (p->target == primme_smallest || p->target == primme_largest || p->target == primme_largest_abs))) {
       if (p->printLevel > 0 && p->outputFile)
          fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / harmonic or refined "
-               "projection with explicit_I or an extremal target) is not on the device path\n");
+               "projection with an extremal target) is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
@@ -877,7 +886,6 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    /* PRIMME_AMD_FORCE_COMM: run the cross-rank reduction path with a one-rank communicator, which is
     * how the RCCL calls are exercised on a single-GPU box (tests/test_comm_gpu.py) */
    s->spec2_enabled = getenv("PRIMME_AMD_NO_SPEC2") == NULL;
-   s->experimental = getenv("PRIMME_AMD_EXPERIMENTAL") != NULL;
    s->wtr_enabled = getenv("PRIMME_AMD_WTR") != NULL;   /* opt-in: exact but not faster yet, DESIGN.md §4d */
    s->device_rr = getenv("PRIMME_AMD_DEVICE_RR") != NULL;
    s->parallel = ((p->numProcs > 1 || getenv("PRIMME_AMD_FORCE_COMM")) && p->globalSumReal != NULL);
@@ -896,7 +904,10 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 
    const int K = s->K, nev = p->numEvals, b = p->maxBlockSize;
    s->nT = K + 2 * b + 2;
-   s->red_cap = PA_MAX((s->maxRank + 16) * (b + 8) + 64, K * K + 64);
+   /* widest block ever orthonormalised at once: the constraints (init_basis) or the whole basis */
+   const int Kc = PA_MAX(K, p->numOrthoConst);
+   s->coef_cap = (size_t)Kc * Kc;
+   s->red_cap = PA_MAX(PA_MAX((s->maxRank + 16) * (b + 8) + 64, K * K + 64), PA_MAX(s->maxRank * K, Kc * Kc) + 64);
    const size_t colBytes = (size_t)(s->ld > 0 ? s->ld : 1) * s->es;
    /* K^-1-weighted right projector (reference main_iter.c:324-333) */
    const int maxEvecs = p->numOrthoConst + nev;
@@ -915,9 +926,9 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
         hipk_malloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->d_red) ||
         (harmonic && hipk_malloc(s->ctx, colBytes * K, (void **)&s->Q)) ||
         (need_hat && hipk_malloc(s->ctx, (size_t)(s->ldevecs > 0 ? s->ldevecs : 1) * s->es * maxEvecs, (void **)&s->evecsHat)) ||
-        hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
+        hipk_malloc(s->ctx, s->coef_cap * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
         hipk_host_alloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->h_red) ||
-        hipk_host_alloc(s->ctx, (size_t)K * K * 8, (void **)&s->h_coef) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta);
+        hipk_host_alloc(s->ctx, s->coef_cap * 8, (void **)&s->h_coef) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta);
    s->H = (double *)calloc((size_t)K * K, 8); s->hVecs = (double *)calloc((size_t)K * K, 8);
    s->prevhVecs = (double *)calloc((size_t)K * K, 8); s->hVals = (double *)calloc((size_t)K, 8);
    s->prevRitzVals = (double *)calloc((size_t)K + nev, 8);

@@ -36,6 +36,8 @@ double pa_problem_norm(int overrideUser, const primme_params *p) {
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync) {
    primme_params *p = s->p;
    if (count <= 0) return 0;
+   /* d_buf lies in [d_red, d_red + 2*red_cap): the second half holds the fused kernel's overlaps */
+   if (d_buf < s->d_red || (size_t)(d_buf - s->d_red) + (size_t)count > 2 * (size_t)s->red_cap) return PRIMME_UNEXPECTED_FAILURE;
    const int parallel = s->parallel;
    double t0 = parallel ? pa_wtime() : 0.0;
    if (parallel && s->dev_comm) {
@@ -46,10 +48,8 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
       /* the reduction kernels already stored the local sums in h_red (zero-copy mirror) */
       if (parallel) {
          CHK(hipk_sync(s->ctx));
-         int ierr = 0, cnt = count;
          double *hb = s->h_red + (d_buf - s->d_red);
-         p->globalSumReal(hb, hb, &cnt, p, &ierr);
-         if (ierr) return PRIMME_USER_FAILURE;
+         CHK(pa_call_global_sum(p, hb, count));
          if (keep_dev) CHK(hipk_h2d(s->ctx, d_buf, hb, (size_t)count * sizeof(double)));
       } else if (!defer_sync) {
          CHK(hipk_sync(s->ctx));

@@ -55,7 +55,8 @@ typedef struct pa_solver {
    double *d_red;          /* reduction results / projection coefficients */
    double *d_coef;         /* K x K Ritz coefficient vectors */
    double *d_theta;        /* K Ritz values */
-   int red_cap;
+   int red_cap;            /* doubles in d_red / h_red (twice that is allocated: second half = d_fov) */
+   size_t coef_cap;        /* doubles in d_coef / h_coef: max(K, numOrthoConst)^2 */
    /* pinned host mirrors */
    double *h_red, *h_coef, *h_theta;
 
@@ -81,7 +82,6 @@ typedef struct pa_solver {
     * at anything; accepted by the orthogonaliser if Daniel's test passes on the first pass */
    int device_rr;          /* PRIMME_AMD_DEVICE_RR: small Rayleigh-Ritz solve by the device Jacobi kernel */
    int spec2_enabled;      /* off with PRIMME_AMD_NO_SPEC2 (measurement knob, read once per solve) */
-   int experimental;       /* PRIMME_AMD_EXPERIMENTAL: changes awaiting a full GPU verification (eigs_main.c) */
    int wtr_enabled;        /* projection column from W'r (PRIMME_AMD_WTR=1) */
    double *wtq;            /* G = W'Q for the first wtq_rows basis vectors (K x HIPK_WTR_MAX_K, host) */
    int wtq_rows, wtq_L;    /* -1: not valid */

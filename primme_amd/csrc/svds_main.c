@@ -13,8 +13,8 @@
  * HBM (allocated once per solve, not per call as the reference does), U = A V / sigma is one SpMM
  * plus a column scaling, and the [U | V] layout shuffles are device-to-device copies.
  *
- * Augmented / hybrid methods and closest_abs targets (refined extraction) are not on the device
- * path: they return PRIMME_FUNCTION_UNAVAILABLE (-44) offset by -100 like any first-stage error.
+ * Every method (normal equations, augmented, hybrid) and target runs on the device path; an error of
+ * the eigensolver stage comes back offset by -100 / -200 like in the reference.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -137,8 +137,8 @@ void pa_svds_conv_test_ata(double *eval, void *evec, double *rNorm, int *isConv,
    double sval = eval ? sqrt(fabs(*eval)) : 0.0;
    double srNorm = (rNorm && eval) ? *rNorm / sval : 0.0;
    int method = (int)op;
-   ps->convTestFun(&sval, (op == primme_svds_op_AAt) ? evec : NULL, (op == primme_svds_op_AtA) ? evec : NULL,
-         &srNorm, &method, isConv, ps, ierr);
+   *ierr = pa_svds_call_conv_test(ps, sval, (op == primme_svds_op_AAt) ? evec : NULL, (op == primme_svds_op_AtA) ? evec : NULL,
+         srNorm, &method, isConv) ? 1 : 0;
    ps->aNorm = old;
 }
 
@@ -172,8 +172,15 @@ static void monitor_single_stage(void *basisEvals_, int *basisSize, int *basisFl
       ln[i] = lockedNorms_ ? ((double *)lockedNorms_)[i] / PA_MAX(ls[i], 1e-300) : 0.0;
    }
    int stage = 0;
-   ps->monitorFun(nb ? bs : NULL, basisSize, basisFlags, iblock, blockSize, nb ? bn : NULL, numConverged,
-         nl ? ls : NULL, numLocked, lockedFlags, nl ? ln : NULL, inner_its, LSRes, msg, time, event, &stage, ps, err);
+   void *pbs = bs, *pbn = bn, *pls = ls, *pln = ln;
+   if (ps->monitorFun_type == primme_op_float) {
+      /* the user's monitor declared float operands: narrow in place, front to back */
+      float *f = (float *)bs;
+      for (int i = 0; i < 2 * nb + 2 * nl; i++) f[i] = (float)bs[i];
+      pbs = f; pbn = f + nb; pls = f + 2 * nb; pln = f + 2 * nb + nl;
+   }
+   ps->monitorFun(nb ? pbs : NULL, basisSize, basisFlags, iblock, blockSize, nb ? pbn : NULL, numConverged,
+         nl ? pls : NULL, numLocked, lockedFlags, nl ? pln : NULL, inner_its, LSRes, msg, time, event, &stage, ps, err);
    free(bs);
 }
 
@@ -228,11 +235,7 @@ static int scale_inverse(primme_svds_params *ps, svds_side *sd, char *x, PRIMME_
       if (!rc) rc = hipk_sync(sd->ctx);
       hipk_free(sd->ctx, d_n);
       if (rc) { free(f); free(norms); return rc; }
-      if (ps->globalSumReal) {
-         int cnt = ncols, ierr = 0;
-         ps->globalSumReal(norms, norms, &cnt, ps, &ierr);
-         if (ierr) { free(f); free(norms); return PRIMME_USER_FAILURE; }
-      }
+      if (pa_svds_call_global_sum(ps, norms, ncols)) { free(f); free(norms); return PRIMME_USER_FAILURE; }
    }
    for (int i = 0; i < ncols; i++)
       f[i] = 1.0 / ((factors[i] > 0.0 && 1.0 / factors[i] < 1.79e308) ? factors[i] : sqrt(norms[i]));
@@ -259,7 +262,7 @@ static int true_res_norm(primme_svds_params *ps, svds_side *sd, char *u, char *v
    if (!rc) rc = hipk_pair_dots(sd->ctx, sd->dt, mL, u, mL, Av, mL, 1, d_ip + 2);
    if (!rc) rc = hipk_d2h(sd->ctx, ip, d_ip, 3 * sizeof(double));
    if (!rc) rc = hipk_sync(sd->ctx);
-   if (!rc && ps->globalSumReal) { int c = 3, e = 0; ps->globalSumReal(ip, ip, &c, ps, &e); if (e) rc = PRIMME_USER_FAILURE; }
+   if (!rc) rc = pa_svds_call_global_sum(ps, ip, 3);
    if (!rc) {
       ip[0] = sqrt(ip[0]); ip[1] = sqrt(ip[1]);
       const double sval = ip[2] / ip[0] / ip[1];
@@ -273,7 +276,7 @@ static int true_res_norm(primme_svds_params *ps, svds_side *sd, char *u, char *v
          if (!rc) rc = hipk_col_norms2(sd->ctx, sd->dt, mL + nL, Atu, mL + nL, 1, d_ip);
          if (!rc) rc = hipk_d2h(sd->ctx, ip, d_ip, sizeof(double));
          if (!rc) rc = hipk_sync(sd->ctx);
-         if (!rc && ps->globalSumReal) { int c = 1, e = 0; ps->globalSumReal(ip, ip, &c, ps, &e); if (e) rc = PRIMME_USER_FAILURE; }
+         if (!rc) rc = pa_svds_call_global_sum(ps, ip, 1);
          if (!rc) *rNorm = sqrt(ip[0]);
       }
    }
@@ -292,7 +295,7 @@ void pa_svds_conv_test_aug(double *eval, void *evec, double *rNorm, int *isConv,
    int method = (int)primme_svds_op_augmented;
    svds_side *sd = side_of(ps);
    const size_t es = sd ? es_of(sd->dt) : 8;
-   ps->convTestFun(&sval, evec ? (char *)evec + (size_t)ps->nLocal * es : NULL, evec, &srNorm, &method, isConv, ps, ierr);
+   *ierr = pa_svds_call_conv_test(ps, sval, evec ? (char *)evec + (size_t)ps->nLocal * es : NULL, evec, srNorm, &method, isConv) ? 1 : 0;
    ps->aNorm = old;
 }
 
@@ -303,7 +306,6 @@ static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double 
       void **stream_slot, svds_stage *st) {
    primme_params *p = stage == 0 ? &ps->primme : &ps->primmeStage2;
    const primme_svds_operator op = stage == 0 ? ps->method : ps->methodStage2;
-   const primme_op_datatype scalar_t = sd->dt == HIPK_F32 ? primme_op_float : primme_op_double;
    const size_t es = es_of(sd->dt);
    const PRIMME_INT mL = ps->mLocal, nL = ps->nLocal, tot = mL + nL;
    st->p = p; st->op = op; st->eig_vecs = svecs; st->allocatedShifts = 0; st->own_monitor = 0;
@@ -316,7 +318,7 @@ static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double 
    }
    if (ps->aNorm > 0.0) p->aNorm = normal ? ps->aNorm * ps->aNorm : ps->aNorm;
    p->convTestFun = normal ? pa_svds_conv_test_ata : pa_svds_conv_test_aug;
-   p->convTestFun_type = scalar_t;
+   p->convTestFun_type = primme_op_double;   /* this glue takes doubles; the user's own type is honoured inside */
    p->initSize = ps->initSize;
    p->numOrthoConst = ps->numOrthoConst;
    const int n0 = ps->initSize + ps->numOrthoConst;
@@ -407,7 +409,7 @@ static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double 
       if (!rc) rc = hipk_d2h(sd->ctx, n2, d_n, 2 * sizeof(double));
       if (!rc) rc = hipk_sync(sd->ctx);
       hipk_free(sd->ctx, d_n);
-      if (!rc && ps->globalSumReal) { int c = 2, e = 0; ps->globalSumReal(n2, n2, &c, ps, &e); if (e) rc = PRIMME_USER_FAILURE; }
+      if (!rc) rc = pa_svds_call_global_sum(ps, n2, 2);
       if (rc) return rc;
       double f = 1.0 / sqrt(n2[0]);
       CHK(hipk_scale_cols(sd->ctx, sd->dt, nL, v0, nL, 1, &f));
@@ -421,17 +423,15 @@ static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double 
    /* second stage: triplets that already pass the criterion become constraints (reference :795-826) */
    if (stage == 1) {
       for (int i = 0; p->initSize > 0; i++) {
-         int isConv = 0, ierr = 0, method = (int)op;
-         double sv = svals[i], rn = rnorms[i];
+         int isConv = 0, method = (int)op;
          char *vi = svecs + (size_t)p->numOrthoConst * tot * es;
-         ps->convTestFun(&sv, vi + (size_t)nL * es, vi, &rn, &method, &isConv, ps, &ierr);
-         if (ierr) return PRIMME_USER_FAILURE;
+         if (pa_svds_call_conv_test(ps, svals[i], vi + (size_t)nL * es, vi, rnorms[i], &method, &isConv)) return PRIMME_USER_FAILURE;
          if (!isConv) break;
          p->numOrthoConst++; p->initSize--; p->numEvals--;
       }
    }
    if (ps->locking >= 0) p->locking = ps->locking;
-   if (!p->monitorFun && ps->monitorFun) { p->monitorFun = monitor_single_stage; p->monitorFun_type = scalar_t; st->own_monitor = 1; }
+   if (!p->monitorFun && ps->monitorFun) { p->monitorFun = monitor_single_stage; p->monitorFun_type = primme_op_double; st->own_monitor = 1; }
    p->queue = stream_slot;
    p->profile = ps->profile;
    /* the library's own communicator: let the eigensolver reduce its device partials in stream */
@@ -543,13 +543,9 @@ static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_
    int rc = check_input(svals_out, svecs_, resNorms_out, ps);
    if (rc) { ps->initSize = 0; return rc; }
 
-   /* all methods and targets are on the device path; what the eigensolver itself does not cover
-    * (explicit_I with the refined extraction, i.e. blocks or single precision for interior
-    * targets) comes back from the stage as -44 - 100 / - 200 */
-
    if (!ps->convTestFun) {
       ps->convTestFun = pa_svds_default_conv_test;
-      ps->convTestFun_type = scalar_t;
+      ps->convTestFun_type = primme_op_double;   /* the library's own test reads doubles */
       if (ps->eps == 0.0) ps->eps = meps * 1e4;
    }
    memset(&ps->stats, 0, sizeof(ps->stats));

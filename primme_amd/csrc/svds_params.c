@@ -9,9 +9,14 @@
 #include <stdlib.h>
 #include "primme_amd_svds.h"
 
+int pa_svds_call_global_sum(primme_svds_params *ps, double *buf, int count);
+
 static void sum_via_svds(void *sendBuf, void *recvBuf, int *count, primme_params *primme, int *ierr) {
+   /* installed with globalSumReal_type = double (the eigensolver reduces doubles); the user's own
+    * declared type is honoured here */
    primme_svds_params *ps = (primme_svds_params *)primme->matrix;
-   ps->globalSumReal(sendBuf, recvBuf, count, ps, ierr);
+   if (sendBuf != recvBuf) for (int i = 0; i < *count; i++) ((double *)recvBuf)[i] = ((const double *)sendBuf)[i];
+   *ierr = pa_svds_call_global_sum(ps, (double *)recvBuf, *count) ? 1 : 0;
 }
 static void bcast_via_svds(void *buffer, int *count, primme_params *primme, int *ierr) {
    primme_svds_params *ps = (primme_svds_params *)primme->matrix;
@@ -83,7 +88,7 @@ static void stage_from_svds(primme_svds_params *ps, int stage) {
    p->outputFile = ps->outputFile;
    p->numOrthoConst = ps->numOrthoConst;
    if (ps->numProcs > 1) { p->procID = ps->procID; p->numProcs = ps->numProcs; p->commInfo = ps->commInfo; }
-   if (ps->globalSumReal) p->globalSumReal = sum_via_svds;
+   if (ps->globalSumReal) { p->globalSumReal = sum_via_svds; p->globalSumReal_type = primme_op_double; }
    if (ps->broadcastReal) p->broadcastReal = bcast_via_svds;
 
    if (op == primme_svds_op_AtA) {

@@ -8,7 +8,6 @@ import pytest
 from primme_amd import _ffi as F
 from primme_amd.api import Operator, eigsh
 import reference_driver_cases as RD
-from test_interface_cases_host import _expected_unavailable
 
 pytestmark = pytest.mark.gpu
 
@@ -19,9 +18,6 @@ def test_hip_interface_cases(built, method):
     for n, nev, target, proj in RD.testi_cases(method):
         ret, bad = RD.run_testi_case(eigsh, Operator, F.METHODS, "hip", method, n, nev, target, proj)
         ran += 1
-        if _expected_unavailable(method, proj) and nev > 1:
-            if ret not in (0, -44): failures.append((n, nev, target, proj, ret))
-            continue
         if ret != 0 or bad:
             failures.append((n, nev, target, proj, ret, bad[:2]))
     assert ran >= 100 and not failures, failures[:10]

@@ -11,11 +11,6 @@ from primme_amd.api import Operator, eigsh
 import reference_driver_cases as RD
 
 
-def _expected_unavailable(method, proj):
-    # the refined extraction with explicit_I (block methods) is not on the device path: -44, no fallback
-    return proj == "refined" and method.startswith("LOBPCG")
-
-
 @pytest.mark.parametrize("method", RD.TESTI_METHODS)
 def test_interface_cases(built, method):
     ran = 0
@@ -23,9 +18,6 @@ def test_interface_cases(built, method):
     for n, nev, target, proj in RD.testi_cases(method):
         ret, bad = RD.run_testi_case(eigsh, Operator, F.METHODS, "hostcheck", method, n, nev, target, proj)
         ran += 1
-        if _expected_unavailable(method, proj) and nev > 1:
-            if ret not in (0, -44): failures.append((n, nev, target, proj, ret))
-            continue
         if ret != 0 or bad:
             failures.append((n, nev, target, proj, ret, bad[:2]))
     assert ran >= 100 and not failures, failures[:10]
@@ -61,9 +53,6 @@ def test_interface_cases_complex(built, method):
         if (n, nev, target) == (100, 100, "closest_geq"):
             continue
         ret, bad = RD.run_testi_case(eigsh, Operator, F.METHODS, "hostcheck", method, n, nev, target, proj, dtype=np.complex128)
-        if _expected_unavailable(method, proj) and nev > 1:
-            if ret not in (0, -44): failures.append((n, nev, target, proj, ret))
-            continue
         if ret != 0 or bad:
             failures.append((n, nev, target, proj, ret, bad[:2]))
     assert not failures, failures[:10]

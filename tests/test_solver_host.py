@@ -75,6 +75,10 @@ def test_against_reference_fixture(built, name, projection_column, monkeypatch):
     if tol == 0.0:
         assert r.stats["numMatvecs"] == g["stats"]["numMatvecs"]
         assert r.stats["numRestarts"] == g["stats"]["numRestarts"]
+    if its == itsg and r.stats["numMatvecs"] == g["stats"]["numMatvecs"]:
+        # same convergence history: the residual norms themselves must be the reference's (north
+        # star: eigenvalues AND residual norms within 1e-10 |A| in double, 1e-4 |A| in float)
+        assert np.max(np.abs(np.array(r.resNorms, dtype=np.float64) - np.array(g["resNorms"]))) <= rel * aN
 
 
 @pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
@@ -355,11 +359,10 @@ def test_returns_instead_of_spinning_when_the_space_is_exhausted(built):
 @pytest.mark.parametrize("projection", ["harmonic", "refined"])
 @pytest.mark.parametrize("dtype,block,eps", [(np.float64, 3, 1e-9), (np.float32, 1, 1e-4), (np.float32, 3, 1e-4)])
 def test_interior_extractions_with_explicit_I_against_live_reference(built, projection, dtype, block, eps, monkeypatch):
-    """(behind PRIMME_AMD_EXPERIMENTAL, see eigs_main.c)  Harmonic / refined extraction when the basis is kept with a tracked Gram matrix (blocks, single
+    """Harmonic / refined extraction when the basis is kept with a tracked Gram matrix (blocks, single
     precision: orth = explicit_I).  The reference tracks Q'Q as well (solve_projection.c:431-520,
     :542-560); here Q stays orthonormal by Gram-Schmidt with reorthogonalisation and only V'V enters
     the coefficient vectors.  Same eigenpairs, similar iteration counts."""
-    monkeypatch.setenv("PRIMME_AMD_EXPERIMENTAL", "1")
     rp, ci, va, n = problems.laplacian_csr((20, 21))
     A = np.zeros((n, n)); A[np.repeat(np.arange(n), np.diff(rp)), ci] = va
     w = np.linalg.eigvalsh(A)
@@ -377,3 +380,48 @@ def test_interior_extractions_with_explicit_I_against_live_reference(built, proj
     assert all(np.min(np.abs(w - ev)) <= tol * aN for ev in got.evals)
     assert np.max(np.abs(np.sort(got.evals) - np.sort(ref.evals))) <= (1e-8 if dtype == np.float64 else 5e-3) * aN
     assert abs(got.stats["numOuterIterations"] - ref.stats["numOuterIterations"]) <= 0.25 * ref.stats["numOuterIterations"]
+
+
+@pytest.mark.parametrize("dtype,eps", [(np.float64, 1e-9), (np.float32, 1e-4)])
+def test_more_constraints_than_basis_columns_with_explicit_I(built, dtype, eps):
+    """numOrthoConst > maxBasisSize with orth = explicit_I: init_basis orthonormalises the constraint
+    block in one CholQR sweep, so the coefficient / reduction buffers must be sized for
+    max(maxBasisSize, numOrthoConst), not for maxBasisSize (advisor finding, round 1: heap overflow)."""
+    n, nc = 600, 20
+    rp, ci, va, _ = problems.laplacian_csr((n,))
+    j = np.arange(1, n + 1)
+    Q = np.stack([np.sin(np.pi * k * j / (n + 1)) for k in range(1, nc + 1)], axis=1)
+    Q /= np.linalg.norm(Q, axis=0)
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", dtype=dtype, numEvals=3, eps=eps, aNorm=4.0,
+              maxBasisSize=15, orth=F.primme_orth_explicit_I, constraints=Q, v0=problems.start_vector(n))
+    assert r.ret == 0 and r.initSize == 3
+    exact = 2 - 2 * np.cos(np.pi * np.arange(nc + 1, nc + 4) / (n + 1))
+    assert np.max(np.abs(r.evals - exact)) <= (1e-10 if dtype == np.float64 else 1e-4) * 4.0
+
+
+def test_single_precision_callbacks_get_float_operands(built, monkeypatch):
+    """hip_sprimme hands globalSumReal / monitorFun operands of *_type, defaulted to float like the
+    reference's sprimme (primme_c.c:170-183): an application whose callback reduces MPI_FLOAT keeps
+    working (advisor finding, round 1: the callbacks used to receive doubles tagged as float)."""
+    import ctypes as C
+    monkeypatch.setenv("PRIMME_AMD_FORCE_COMM", "1")      # one rank, but every reduction goes through the callback
+    rp, ci, va, n = problems.laplacian_csr((24, 25))
+    seen = {"types": set(), "calls": 0, "mon": set()}
+
+    def gsum(a):
+        seen["calls"] += 1
+        assert np.all(np.isfinite(a)) and np.all(np.abs(a) < 1e6)     # doubles read as floats would be garbage
+        return a
+
+    def mon(bev, bsz, bfl, ibl, blk, bno, ncv, lev, nlk, lfl, lno, inner, lsres, msg, tm, ev, pp, ierr):
+        seen["mon"].add(pp[0].monitorFun_type)
+        if bev and bsz[0] > 0:
+            v = np.ctypeslib.as_array(C.cast(bev, C.POINTER(C.c_float)), shape=(bsz[0],))
+            assert np.all(np.isfinite(v)) and np.all(np.abs(v) <= 8.0 * 1.01)
+        ierr[0] = 0
+
+    kw = dict(dtype=np.float32, numEvals=3, eps=1e-4, aNorm=8.0, v0=problems.start_vector(n))
+    a = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", global_sum=gsum, monitor=mon, **kw)
+    b = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", **kw)
+    assert a.ret == 0 and b.ret == 0 and seen["calls"] > 10 and seen["mon"] == {F.primme_op_float}
+    assert np.max(np.abs(a.evals - b.evals)) <= 1e-4 * 8.0

@@ -62,9 +62,14 @@ def test_hip_svds_reference_driver_case(built, name):
     assert not bad, bad
 
 
-def test_hip_svds_unsupported_fails_loudly(built):
+def test_hip_svds_interior_target_with_blocks(built):
+    """closest_abs singular values with a block: explicit_I + refined extraction in the eigensolver stage."""
     A, csr = _rect(60, 40)
-    assert svds(60, 40, csr, numSvals=2, target="closest_abs", targetShifts=[7.0], maxBlockSize=2, backend="hip").ret == -144
+    s = np.linalg.svd(A, compute_uv=False)
+    r = svds(60, 40, csr, numSvals=2, target="closest_abs", targetShifts=[7.0], maxBlockSize=2, eps=1e-9, backend="hip")
+    assert r.ret == 0 and r.initSize == 2
+    want = s[np.argsort(np.abs(s - 7.0))][:2]
+    assert np.max(np.abs(np.sort(r.svals) - np.sort(want))) <= 1e-8 * s[0]
 
 
 def test_hip_svds_config5_shape(built):

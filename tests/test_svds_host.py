@@ -139,8 +139,12 @@ def test_svds_refined_stages_follow_reference(built, m, n, k, method, target):
     assert abs(h.stats["numOuterIterations"] - r.stats["numOuterIterations"]) <= 0.05 * r.stats["numOuterIterations"] + 2
 
 
-def test_svds_unsupported_methods_fail_loudly(built):
+def test_svds_interior_blocks_and_input_checks(built):
     A, csr = _rect(60, 40)
-    # interior targets with blocks need explicit_I + refined extraction in the eigensolver: -44 - 100
-    assert svds(60, 40, csr, numSvals=2, target="closest_abs", targetShifts=[7.0], maxBlockSize=2, backend="hostcheck").ret == -144
+    s = np.linalg.svd(A, compute_uv=False)
+    # interior targets with blocks: explicit_I + refined extraction in the eigensolver
+    r = svds(60, 40, csr, numSvals=2, target="closest_abs", targetShifts=[7.0], maxBlockSize=2, eps=1e-9, backend="hostcheck")
+    assert r.ret == 0 and r.initSize == 2
+    want = s[np.argsort(np.abs(s - 7.0))][:2]
+    assert np.max(np.abs(np.sort(r.svals) - np.sort(want))) <= 1e-8 * s[0]
     assert svds(60, 40, csr, numSvals=70, backend="hostcheck").ret == -10
