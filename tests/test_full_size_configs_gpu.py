@@ -1,0 +1,101 @@
+"""BASELINE.json configs[2], configs[3] and configs[4] at FULL size on one MI355X (configs[1] at full
+size is in test_solver_gpu.py), checked through size-independent properties: the dense truth of the
+tile (configs[2]), true residuals recomputed on the host with scipy.sparse (test-only dependency),
+orthonormality, ordering, and the residual threshold.  The 8-GPU layouts of configs[3] / configs[4]
+are the same solves with rows split (tests/test_multigpu_rccl.py when >= 2 GPUs are visible)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from primme_amd import problems, _ffi as F
+from primme_amd.api import Operator, Session
+from primme_amd.svds_api import svds
+import reference_driver_cases as RD
+import ingest_c
+
+pytestmark = pytest.mark.gpu
+
+# configs[2]: SURVEY §8(d) places the shift at 1.0e6, where neither the reference nor this solver
+# converges a single pair (5e6 eigenvalues ~25 apart under |A| = 4.5e8, diag(A) - shift indefinite;
+# DESIGN.md §6).  The documented shift of this build is 4.4764e8: 20 closest values 6.6e3 apart.
+CONFIG3_SHIFT = 4.4764e8
+
+
+def test_config3_full_size_lunda_tiles_jdqmr_block8(built):
+    """configs[2]: LUNDA.mtx read by the C Matrix-Market reader, tiled 34 014 times block-diagonally
+    by the C tiler (tile t scaled by 1 + t/T) -> n = 5 000 058, 83.3 M nonzeros; JDQMR, block size 8,
+    20 eigenvalues closest to the shift, Jacobi K = diag(A) - shift, eps 1e-8 |A|."""
+    lib = F.load_product()
+    rp0, ci0, va0, n0, _ = ingest_c.mm_read(lib, os.path.join(RD.DATA, "LUNDA.mtx"))
+    T = 34014
+    rp, ci, va = ingest_c.tile_block_diagonal(lib, rp0, ci0, va0, T, 1.0, 1.0 / T)
+    n = n0 * T
+    assert n == 5_000_058 and len(va) == 2449 * T
+    A0 = np.zeros((n0, n0)); A0[np.repeat(np.arange(n0), np.diff(rp0)), ci0] = va0
+    w = (np.linalg.eigvalsh(A0)[None, :] * (1.0 + np.arange(T) / T)[:, None]).ravel()
+    aN = float(np.abs(w).max())
+    want = np.sort(w[np.argsort(np.abs(w - CONFIG3_SHIFT))][:20])
+    s = Session(Operator(n, csr=(rp, ci, va)), backend="hip")
+    try:
+        r = s.solve(numEvals=20, target="closest_abs", targetShifts=[CONFIG3_SHIFT], method="JDQMR", maxBlockSize=8,
+                    eps=1e-8, aNorm=aN, precond=("jacobi", CONFIG3_SHIFT))
+    finally:
+        s.close()
+    assert r.ret == 0 and r.initSize == 20 and r.params["maxBlockSize"] == 8 and r.params["maxBasisSize"] == 41
+    assert np.max(np.abs(np.sort(r.evals) - want)) <= 1e-10 * aN
+    assert np.all(r.resNorms <= 1e-8 * aN * (1 + 1e-6))
+    X = np.asarray(r.evecs)
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    res = np.linalg.norm(A @ X - X * r.evals, axis=0)
+    assert np.all(res <= 1e-8 * aN * 1.05) and np.allclose(res, r.resNorms, rtol=0.2, atol=1e-12 * aN)
+    assert np.max(np.abs(X.T @ X - np.eye(20))) <= 1e-7
+    print(f"configs[2] full size: {r.stats['elapsedTime']:.2f} s, {r.stats['numOuterIterations']} outer, {r.stats['numMatvecs']} matvecs")
+
+
+def test_config4_full_size_hermitian_band_block4(built):
+    """configs[3] on one GPU: complex Hermitian band n = 4 000 000 (half-bandwidth 3), 6 largest,
+    block size 4, GD+k (basis 20, restart 8) through hip_zprimme."""
+    n = 4_000_000
+    rp, ci, va = problems.hermitian_banded_csr(n)
+    s = Session(Operator(n, csr=(rp, ci, va)), dtype=np.complex128, backend="hip")
+    try:
+        r = s.solve(numEvals=6, target="largest", eps=1e-8, maxBlockSize=4, maxBasisSize=20, minRestartSize=8,
+                    method="GD_plusK", iseed=(2, 3, 5, 7))
+    finally:
+        s.close()
+    assert r.ret == 0 and r.initSize == 6
+    aN = r.params["aNorm"]
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    X = np.asarray(r.evecs)
+    res = np.linalg.norm(A @ X - X * r.evals, axis=0)
+    assert np.all(res <= 1.5e-8 * aN) and np.allclose(res, r.resNorms, rtol=0.2, atol=1e-12 * aN)
+    assert np.max(np.abs(X.conj().T @ X - np.eye(6))) <= 1e-8
+    assert np.all(np.diff(r.evals) <= 1e-12)
+    # Gershgorin: every eigenvalue lies below max d_j + 2 sum_q 1/(q+1); the largest ones are close to it
+    bound = 3.0 + 2 * (1 / 2 + 1 / 3 + 1 / 4)
+    assert np.all(r.evals <= bound) and r.evals[0] >= bound - 1.5
+    print(f"configs[3] full size, one GPU: {r.stats['elapsedTime']:.2f} s, {r.stats['numMatvecs']} matvecs")
+
+
+def test_config5_full_size_svds_normal_equations(built):
+    """configs[4] on one GPU: A 8 000 000 x 2 000 000 with 5 nonzeros per row, 10 largest singular
+    triplets through the normal equations (GD+k on A'A)."""
+    m, n, k = 8_000_000, 2_000_000, 10
+    rp, ci, va = problems.svds_synthetic_csr(m, n)
+    r = svds(m, n, (rp, ci, va), numSvals=k, eps=1e-8, methodStage1="GD_plusK", backend="hip")
+    assert r.ret == 0 and r.initSize == k
+    A = sp.csr_matrix((va, ci, rp), shape=(m, n))
+    AV, AtU = A @ r.V, A.T @ r.U
+    res = np.sqrt(np.sum((AV - r.U * r.svals) ** 2, axis=0) + np.sum((AtU - r.V * r.svals) ** 2, axis=0))
+    tol = 1e-8 * r.params["aNorm"]
+    assert np.all(res <= 10 * tol) and np.all(r.resNorms <= tol * (1 + 1e-6))
+    assert np.linalg.norm(r.U.T @ r.U - np.eye(k)) <= 1e-8 and np.linalg.norm(r.V.T @ r.V - np.eye(k)) <= 1e-8
+    assert np.all(np.diff(r.svals) <= 1e-12 * r.svals[0])
+    x = np.ones(n)
+    for _ in range(5):
+        x = A.T @ (A @ x)
+        x /= np.linalg.norm(x)
+    assert r.svals[0] >= np.linalg.norm(A @ x) * (1 - 1e-12)
+    print(f"configs[4] full size, one GPU: {r.stats['elapsedTime']:.2f} s, {r.stats['numMatvecs']} matvecs")

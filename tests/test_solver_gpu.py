@@ -203,10 +203,14 @@ def test_hip_tiled_lunda_block_jdqmr(built):
     """BASELINE configs[2] in small: block-diagonal tiles of LUNDA.mtx (tile t scaled by
     1 + t/1000, so the spectrum stays simple), JDQMR, block size 8, 20 eigenvalues closest to a
     shift; truth = union of the scaled dense spectra."""
-    rp, ci, va, n0 = RD.lunda()
+    import ingest_c
+    lib = F.load_product()
+    rp, ci, va, n0, _ = ingest_c.mm_read(lib, os.path.join(RD.DATA, "LUNDA.mtx"))      # the C reader and tiler (row f3)
     T = 64
     scale = lambda t: 1.0 + t / 1000.0
-    trp, tci, tva = problems.tile_block_diagonal(rp, ci, va, T, scale)
+    trp, tci, tva = ingest_c.tile_block_diagonal(lib, rp, ci, va, T, 1.0, 1.0 / 1000.0)
+    ptrp, ptci, ptva = problems.tile_block_diagonal(rp, ci, va, T, scale)
+    assert np.array_equal(trp, ptrp) and np.array_equal(tci, ptci) and np.allclose(tva, ptva, rtol=1e-15)
     n = n0 * T
     A = np.zeros((n0, n0))
     A[np.repeat(np.arange(n0), np.diff(rp)), ci] = va
