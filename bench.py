@@ -36,6 +36,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))   # checkers.py: test infrastructure
 
 WORKLOADS = {
     "lap3d_2m": dict(dims=(125, 126, 127), aNorm=12.0, desc="3-D 7-pt Laplacian 125x126x127 CSR"),
@@ -195,7 +196,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cmd = [sys.executable, "-m", "primme_amd.cpu_baseline", "--dims", *[str(d) for d in dims],
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--dims", *[str(d) for d in dims],
                    "--num-evals", str(args.num_evals), "--eps", str(args.eps), "--anorm", str(wl["aNorm"]),
                    "--max-matvecs", "60" if n > 5_000_000 else "150",
                    "--total-iterations", str(last.stats["numOuterIterations"])]

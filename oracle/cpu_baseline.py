@@ -2,9 +2,9 @@
 PRIMME 3.2 built from /root/reference by oracle/Makefile, BLAS/LAPACK = the image's MKL)
 on the host cores, on a bounded sample of the bench workload.
 
-Run as a subprocess (`python -m primme_amd.cpu_baseline ...`) so that the thread
+Run as a subprocess (`python oracle/cpu_baseline.py ...`) so that the thread
 settings are in the environment before MKL loads.  Prints one JSON object.
-This module is measurement/test infrastructure: the product path never imports it.
+This module is measurement/test infrastructure under oracle/: the product package cannot import it.
 """
 import argparse
 import ctypes as C
@@ -34,11 +34,13 @@ def main():
 
     import numpy as np
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import checkers
     from primme_amd import _ffi as F
     from primme_amd import problems
 
-    ref = F.load_reference()
-    cb = C.CDLL(os.path.join(os.path.dirname(F.HOSTCHECK_LIB), "librefcb.so"))
+    ref = checkers.load_reference()
+    cb = C.CDLL(os.path.join(os.path.dirname(checkers.HOSTCHECK_LIB), "librefcb.so"))
     rp, ci, va, n = problems.laplacian_csr(tuple(a.dims))
 
     class RefCsr(C.Structure):

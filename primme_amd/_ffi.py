@@ -1,10 +1,9 @@
 """ctypes view of the C ABI in include/primme_amd.h / primme_amd_kernels.h / primme_amd_comm.h.
 
-The structures mirror reference include/primme_eigs.h:109-253 field for field, so the
-same `PrimmeParams` object can be handed to the product library
-(primme_amd/libprimme_amd.so, GPU only), to the test-only host-check build
-(oracle/_build/libprimme_hostcheck.so) and to the real reference
-(oracle/_ref/libprimme_ref.so).
+The structures mirror reference include/primme_eigs.h:109-253 field for field.  This module
+loads ONE library: the product, primme_amd/libprimme_amd.so (GPU only).  The test-only checker
+builds are loaded by oracle/checkers.py, which declares the same signatures through
+declare_solver / declare_kernels.
 """
 import ctypes as C
 import os
@@ -154,13 +153,11 @@ class HipkJob(C.Structure):
 
 
 PRODUCT_LIB = os.path.join(_HERE, "libprimme_amd.so")
-HOSTCHECK_LIB = os.path.join(_ROOT, "oracle", "_build", "libprimme_hostcheck.so")
-REFERENCE_LIB = os.path.join(_ROOT, "oracle", "_ref", "libprimme_ref.so")
 
 _vp, _i, _i64, _dp = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double)
 
 
-def _declare_solver(lib, prefix):
+def declare_solver(lib, prefix):
     lib.primme_initialize.argtypes = [C.POINTER(PrimmeParams)]
     lib.primme_initialize.restype = None
     lib.primme_set_method.argtypes = [C.c_int, C.POINTER(PrimmeParams)]
@@ -181,7 +178,7 @@ def _declare_solver(lib, prefix):
             f.restype = C.c_int
 
 
-def _declare_kernels(lib):
+def declare_kernels(lib):
     P = C.POINTER
     sig = {
         "hipk_ctx_create": [P(_vp), _vp], "hipk_ctx_destroy": [_vp], "hipk_sync": [_vp],
@@ -260,26 +257,7 @@ def load_product():
         except ImportError:
             pass
         lib = C.CDLL(PRODUCT_LIB)
-        _declare_solver(lib, "hip_")
-        _declare_kernels(lib)
+        declare_solver(lib, "hip_")
+        declare_kernels(lib)
         _cache["product"] = lib
     return _cache["product"]
-
-
-def load_hostcheck():
-    """TEST ONLY: product host solver linked over oracle/hipk_cpu.c."""
-    if "hostcheck" not in _cache:
-        lib = C.CDLL(HOSTCHECK_LIB)
-        _declare_solver(lib, "hip_")
-        _declare_kernels(lib)
-        _cache["hostcheck"] = lib
-    return _cache["hostcheck"]
-
-
-def load_reference():
-    """TEST/BASELINE ONLY: the real reference built by oracle/Makefile from /root/reference."""
-    if "reference" not in _cache:
-        lib = C.CDLL(REFERENCE_LIB)
-        _declare_solver(lib, "")
-        _cache["reference"] = lib
-    return _cache["reference"]

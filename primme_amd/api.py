@@ -1,12 +1,10 @@
 """Thin Python driver over the C ABI (plumbing only: memory, handles, parameter block).
 
-`Session` keeps a sparse operator resident (in HBM for backend="hip") and runs
-hip_dprimme / hip_sprimme solves on it; `eigsh(...)` is the one-shot form.
-The same parameter plumbing can target the two CHECKER back ends used by tests and
-by bench.py's cpu_baseline leg:
-   backend="hostcheck"  product host solver over oracle/hipk_cpu.c (host memory)
-   backend="reference"  the real reference library oracle/_ref/libprimme_ref.so
-The product path (backend="hip") never touches either of them.
+`Session` keeps a sparse operator resident in HBM and runs hip_dprimme / hip_sprimme /
+hip_zprimme / hip_cprimme solves on it; `eigsh(...)` is the one-shot form.  This package loads the
+product library only (primme_amd/libprimme_amd.so).  Test code can drive the very same parameter
+plumbing over another library by passing a *backend object* (see `HipBackend` for the interface);
+the checker back ends live under oracle/ (oracle/checkers.py) and are never imported from here.
 """
 import ctypes as C
 import hashlib
@@ -59,26 +57,48 @@ class Result:
         self.params["maxPrevRetain"] = params.restartingParams.maxPrevRetain
 
 
+class HipBackend:
+    """The product: libprimme_amd.so, vectors in HBM (torch tensors hold the device memory)."""
+    name = "hip"
+    device = True            # evecs live in HBM
+    native_operator = True   # the library's own operator handle / ready-made callbacks are used
+
+    def __init__(self):
+        self.lib = F.load_product()
+
+    def solver(self, dtype_name):
+        return getattr(self.lib, {"float64": "hip_dprimme", "float32": "hip_sprimme", "complex128": "hip_zprimme",
+                                  "complex64": "hip_cprimme"}[dtype_name])
+
+    def svds_solver(self, dtype_name):
+        return getattr(self.lib, {"float64": "hip_dprimme_svds", "float32": "hip_sprimme_svds"}[dtype_name])
+
+
+def _resolve_backend(backend):
+    if backend == "hip":
+        return HipBackend()
+    if isinstance(backend, str):
+        raise ValueError(f"backend {backend!r}: primme_amd has one back end, the MI355X library; the CPU checkers "
+                         "used by the tests are constructed by oracle/checkers.py")
+    return backend
+
+
 class Session:
     def __init__(self, op, comm=None, dtype=np.float64, backend="hip"):
-        self.op, self.comm, self.backend = op, comm, backend
+        self.op, self.comm = op, comm
+        self.be = _resolve_backend(backend)
+        self.backend = self.be.name
         self.dtype = np.dtype(dtype)
-        # Hermitian problems: complex vectors, solved in the real-equivalent form (csrc/eigs_complex.c)
+        # Hermitian problems: complex vectors (csrc/eigs_complex.c)
         self.cplx = self.dtype.kind == "c"
         self.rdtype = np.dtype(np.float64 if self.dtype in (np.float64, np.complex128) else np.float32)
         self.dt = F.HIPK_F64 if self.rdtype == np.float64 else F.HIPK_F32
         self.handles = []
         self.keep = []
         self._v0_cache = None
-        if backend == "hip":
-            self.lib = F.load_product()
-        elif backend == "hostcheck":
-            self.lib = F.load_hostcheck()
-        elif backend == "reference":
-            self.lib = F.load_reference()
+        self.lib = self.be.lib
+        if not self.be.native_operator:
             return
-        else:
-            raise ValueError(backend)
         lib = self.lib
         ctx = C.c_void_p()
         if lib.hipk_ctx_create(C.byref(ctx), None):
@@ -130,7 +150,7 @@ class Session:
               initBasisMode=None, global_sum=None, numProcs=1, procID=0, orth=None, iseed=None,
               profile=False, return_evecs=True, monitor=None, user_matvec=None, projection=None,
               constraints=None):
-        lib, op, dtype, backend = self.lib, self.op, self.dtype, self.backend
+        lib, op, dtype = self.lib, self.op, self.dtype
         keep = []
         p = F.PrimmeParams()
         nLocal = op.nrows
@@ -177,47 +197,10 @@ class Session:
             a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(nb, ld * (2 if cplx else 1)))
             return a.view(dtype) if cplx else a
 
-        if backend == "reference":
-            def mv(x, ldx, y, ldy, bs, pp, ierr):
-                nb, lx, ly = bs[0], ldx[0], ldy[0]
-                X = view(x, nb, lx)
-                Y = view(y, nb, ly)
-                Y[:, :nLocal] = op.apply_numpy(X[:, :nLocal].T.astype(np.complex128 if cplx else np.float64)).T
-                ierr[0] = 0
-            cb = F.BLOCK_OP(mv)
-            keep.append(cb)
-            p.matrixMatvec = C.cast(cb, C.c_void_p)
-            if precond is not None:
-                dg = op.diagonal()
-                jfixed = None if precond == "jacobi" else float(precond[1])
-
-                def pc(x, ldx, y, ldy, bs, pp, ierr):
-                    nb, lx, ly = bs[0], ldx[0], ldy[0]
-                    if nb <= 0 or not x or not y:
-                        ierr[0] = 0
-                        return
-                    X = view(x, nb, lx)
-                    Y = view(y, nb, ly)
-                    sh = pp[0].ShiftsForPreconditioner
-                    an = pp[0].aNorm
-                    mind = 1e-14 * (an if an >= 0 else 1.0)
-                    for c in range(nb):
-                        d = dg - (jfixed if jfixed is not None else (sh[c] if sh else 0.0))
-                        small = ~(np.abs(d) > mind)
-                        d[small] = np.copysign(mind, d[small])
-                        Y[c, :nLocal] = X[c, :nLocal] / d
-                    ierr[0] = 0
-                pcb = F.BLOCK_OP(pc)
-                keep.append(pcb)
-                p.applyPreconditioner = C.cast(pcb, C.c_void_p)
-                p.correctionParams.precondition = 1
-            evecs = np.zeros((ncols, nLocal), dtype=dtype)  # row-major (ncols x n) == col-major n x ncols
-            if cons is not None:
-                evecs[:nOC] = cons.T
-            if v0 is not None:
-                evecs[nOC:nOC + initSize] = v0.T
-            evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
-            solver = {"float64": lib.dprimme, "float32": lib.sprimme, "complex128": lib.zprimme, "complex64": lib.cprimme}[dtype.name]
+        if not self.be.native_operator:
+            # a checker that brings its own operator callbacks (oracle/checkers.py)
+            evecs, evecs_ptr = self.be.setup_operator(self, p, keep, precond, view, ncols, nLocal, cons, nOC, v0, initSize)
+            solver = self.be.solver(dtype.name)
         else:
             p.matrix = self.oph
             p.matrixMatvec = C.cast(lib.primme_amd_matvec, C.c_void_p)
@@ -236,7 +219,7 @@ class Session:
                 p.globalSumReal = C.cast(lib.primme_amd_global_sum, C.c_void_p)
             if profile:
                 p.profile = b"phases"
-            if backend == "hip":
+            if self.be.device:
                 import torch
                 tdt = {"float64": torch.float64, "float32": torch.float32, "complex128": torch.complex128, "complex64": torch.complex64}[dtype.name]
                 # (a zero-sized problem still gets a valid device pointer)
@@ -259,7 +242,7 @@ class Session:
                 if v0 is not None:
                     evecs[nOC:nOC + initSize] = v0.T
                 evecs_ptr = evecs.ctypes.data_as(C.c_void_p)
-            solver = {"float64": lib.hip_dprimme, "float32": lib.hip_sprimme, "complex128": lib.hip_zprimme, "complex64": lib.hip_cprimme}[dtype.name]
+            solver = self.be.solver(dtype.name)
 
         if global_sum is not None:
             def gs(send, recv, count, pp, ierr):
@@ -283,7 +266,7 @@ class Session:
         evals = np.zeros(numEvals, dtype=self.rdtype)
         resNorms = np.zeros(numEvals, dtype=self.rdtype)
         ret = solver(evals.ctypes.data_as(C.c_void_p), evecs_ptr, resNorms.ctypes.data_as(C.c_void_p), C.byref(p))
-        if backend == "hip":
+        if self.be.native_operator and self.be.device:
             import torch
             torch.cuda.synchronize()
             evecs = evecs_t.cpu().numpy() if return_evecs else None

@@ -1,15 +1,15 @@
 """Python driver over the singular value C ABI (include/primme_amd_svds.h): plumbing only.
 
-    svds(m, n, (rowptr, colind, values), numSvals=..., backend="hip" | "hostcheck" | "reference")
+    svds(m, n, (rowptr, colind, values), numSvals=...)
 
-backend="hip" runs hip_dprimme_svds / hip_sprimme_svds of primme_amd/libprimme_amd.so with the
-matrix and its transpose resident in HBM; the two checker back ends are the same as in api.py
-(tests and bench baselines only)."""
+hip_dprimme_svds / hip_sprimme_svds of primme_amd/libprimme_amd.so with the matrix and its
+transpose resident in HBM.  `backend` is "hip" or a backend object (see api.HipBackend); the CPU
+checkers of the tests are built by oracle/checkers.py, never from here."""
 import ctypes as C
 import numpy as np
 
 from . import _ffi as F
-from .problems import csr_matvec_numpy
+from .api import _resolve_backend
 
 
 class SvdsResult:
@@ -42,7 +42,8 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
     rp = np.ascontiguousarray(rp, dtype=np.int32)
     ci = np.ascontiguousarray(ci, dtype=np.int32)
     va = np.ascontiguousarray(va, dtype=dtype)
-    lib = {"hip": F.load_product, "hostcheck": F.load_hostcheck, "reference": F.load_reference}[backend]()
+    be = _resolve_backend(backend)
+    lib = be.lib
     keep = []
     ps = F.PrimmeSvdsParams()
     lib.primme_svds_initialize(C.byref(ps))
@@ -64,56 +65,8 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
     ncols = max(numSvals, ps.initSize)
     handles = []
 
-    if backend == "reference":
-        rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
-
-        def mv(x, ldx, y, ldy, bs, tr, pp, ierr):
-            nb, lx, ly = bs[0], ldx[0], ldy[0]
-            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
-            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
-            if tr[0]:
-                Y[:, :n] = csr_matvec_numpy(rpT, ciT, vaT, X[:, :m].T.astype(np.float64)).T
-            else:
-                Y[:, :m] = csr_matvec_numpy(rp, ci, va, X[:, :n].T.astype(np.float64)).T
-            ierr[0] = 0
-        cb = F.SVDS_BLOCK_OP(mv)
-        keep.append(cb)
-        ps.matrixMatvec = C.cast(cb, C.c_void_p)
-        if precond is not None:
-            # the test driver's "jacobi" for singular value problems (tests/COMMON/mat.c:353-426)
-            shift = 0.0 if precond == "jacobi" else float(precond[1])
-            rows = np.repeat(np.arange(m), np.diff(rp))
-            sumr = np.bincount(rows, weights=va.astype(np.float64) ** 2, minlength=m) - shift * shift
-            sumc = np.bincount(ci, weights=va.astype(np.float64) ** 2, minlength=n) - shift * shift
-            for d in (sumr, sumc):
-                small = np.abs(d) < 1e-14
-                d[small] = np.copysign(1e-14, d[small])
-
-            def pc(x, ldx, y, ldy, bs, mode, pp, ierr):
-                nb, lx, ly = bs[0], ldx[0], ldy[0]
-                if nb <= 0 or not x or not y:
-                    ierr[0] = 0
-                    return
-                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
-                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
-                an = pp[0].aNorm
-                md = 1e-14 * (an if an >= 0 else 1.0)
-
-                def div(d):
-                    d = d.copy()
-                    small = ~(np.abs(d) > md)
-                    d[small] = np.copysign(md, d[small])
-                    return d
-                if mode[0] == 1: Y[:, :n] = X[:, :n] / div(sumc)
-                elif mode[0] == 2: Y[:, :m] = X[:, :m] / div(sumr)
-                else:
-                    Y[:, :n] = X[:, :n] / div(sumc)
-                    Y[:, n:n + m] = X[:, n:n + m] / div(sumr)
-                ierr[0] = 0
-            pcb = F.SVDS_BLOCK_OP(pc)
-            keep.append(pcb)
-            ps.applyPreconditioner = C.cast(pcb, C.c_void_p)
-        solver = lib.dprimme_svds if dtype == np.float64 else lib.sprimme_svds
+    if not be.native_operator:
+        solver = be.setup_svds_operator(ps, keep, m, n, rp, ci, va, ctype, precond, dtype)
     else:
         ctx = C.c_void_p()
         if lib.hipk_ctx_create(C.byref(ctx), None):
@@ -134,7 +87,7 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
                 raise RuntimeError("svds Jacobi set-up failed")
             ps.preconditioner = oph
             ps.applyPreconditioner = C.cast(lib.primme_amd_svds_jacobi_precond, C.c_void_p)
-        solver = lib.hip_dprimme_svds if dtype == np.float64 else lib.hip_sprimme_svds
+        solver = be.svds_solver(dtype.name)
 
     mset = getattr(F, "PRIMME_" + methodStage1) if isinstance(methodStage1, str) and hasattr(F, "PRIMME_" + methodStage1) \
         else F.METHODS.get(methodStage1, 0) if isinstance(methodStage1, str) else methodStage1
@@ -144,7 +97,7 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
     rnorms = np.zeros(numSvals, dtype=dtype)
     total = (m + n) * ncols
     sv_t = None
-    if backend == "hip":
+    if be.native_operator and be.device:
         import torch
         sv_t = torch.zeros(total, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
         if v0 is not None:
@@ -161,7 +114,7 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
     k = ps.initSize
     U = V = None
     if return_vectors and k > 0:
-        if backend == "hip":
+        if be.native_operator and be.device:
             import torch
             torch.cuda.synchronize()
             sv = sv_t.cpu().numpy()

@@ -7,7 +7,7 @@ K = diag(A) - shift.  Truth: union of the scaled dense spectra of the 147 x 147 
 import argparse, ctypes as C, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def main():
@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--max-matvecs", type=int, default=0)
     args = ap.parse_args()
     from primme_amd import problems, _ffi as F
-    from primme_amd.api import Operator, Session
+    from checkers import Operator, Session
     import reference_driver_cases as RD
     rp, ci, va, n0 = RD.lunda()
     T = args.tiles

@@ -3,9 +3,10 @@
 csrc/eigs_complex.c).  Writes gpurun_out/config4_run.json."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from primme_amd import problems
-from primme_amd.api import Operator, Session
+from checkers import Operator, Session
 
 n = int(os.environ.get("N", 4_000_000))
 rp, ci, va = problems.hermitian_banded_csr(n)

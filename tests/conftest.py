@@ -5,6 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))   # checkers.py: test infrastructure
 
 
 def pytest_configure(config):

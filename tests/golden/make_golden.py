@@ -12,8 +12,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))   # checkers.py: test infrastructure
 from primme_amd import eigsh, Operator, problems  # noqa: E402
 from primme_amd import _ffi as F  # noqa: E402
+import checkers
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -107,7 +109,7 @@ def main():
     json.dump(out, open(os.path.join(HERE, "reference_solves.json"), "w"), indent=1)
 
     # ---- struct layout + defaults as the reference computes them ----
-    ref = F.load_reference()
+    ref = checkers.load_reference()
     abi = {"sizeof_primme_params": C.sizeof(F.PrimmeParams), "sizeof_primme_stats": C.sizeof(F.PrimmeStats),
            "offsets": {f[0]: getattr(F.PrimmeParams, f[0]).offset for f in F.PrimmeParams._fields_}}
     # the reference's own view: primme_get_member through labels is not needed; instead record the

@@ -5,6 +5,8 @@ import numpy as np
 
 from primme_amd import _ffi as F
 
+import checkers
+
 NPDT = {F.HIPK_F64: np.float64, F.HIPK_F32: np.float32}
 
 
@@ -43,7 +45,7 @@ class Host:
     name = "oracle"
 
     def __init__(self):
-        self.lib = F.load_hostcheck()
+        self.lib = checkers.load_hostcheck()
         self.ctx = C.c_void_p()
         assert self.lib.hipk_ctx_create(C.byref(self.ctx), None) == 0
         self.keep = []

@@ -10,6 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))   # checkers.py: test infrastructure
 
 
 def run(rank, world, port, case, out_path):
@@ -19,9 +20,11 @@ def run(rank, world, port, case, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from primme_amd import Operator, problems
-    from primme_amd.api import Session
+    from primme_amd import problems
+    from checkers import Operator
+    from checkers import Session
     from primme_amd import _ffi as F
+    import checkers
 
     def global_sum(a):
         t = torch.from_numpy(a.copy())
@@ -48,7 +51,7 @@ def run(rank, world, port, case, out_path):
         rp, ci, va, _ = problems.laplacian_csr(dims, row0=row0, nrows=nloc)
         lo = row0 - max(0, min(ci.min(), row0)) if row0 > 0 else 0
         hi = max(0, int(ci.max()) - (row0 + nloc) + 1)
-        lib = F.load_hostcheck()
+        lib = checkers.load_hostcheck()
         s = Session(Operator(n, csr=(rp, ci, va), row0=row0, nrows=nloc), backend="hostcheck")
         A = [h for k, h in s.handles if k == "csr"][0]
         assert lib.hipk_csr_halo_lo(A) == lo and lib.hipk_csr_halo_hi(A) == hi
@@ -112,7 +115,7 @@ def run(rank, world, port, case, out_path):
         lrp = (rp[r0:r0 + mloc + 1] - rp[r0]).astype(np.int32)
         lci, lva = ci[rp[r0]:rp[r0 + mloc]], va[rp[r0]:rp[r0 + mloc]]
         trp, tci, tva = transpose_csr(mloc, n, lrp, lci, lva)
-        lib = F.load_hostcheck()
+        lib = checkers.load_hostcheck()
 
         def mv(x, ldx, y, ldy, bs, tr, pp, ierr):
             nb, lx, ly = bs[0], ldx[0], ldy[0]

@@ -8,6 +8,8 @@ import pytest
 
 from primme_amd import _ffi as F
 
+import checkers
+
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_abi.json")))
 
 # offsets probed from the reference headers with gcc
@@ -44,7 +46,7 @@ def test_c_header_layout_matches_ctypes(built, tmp_path):
 
 
 def _lib():
-    return F.load_hostcheck()   # same eigs_params.c as the product library, loadable without a GPU
+    return checkers.load_hostcheck()   # same eigs_params.c as the product library, loadable without a GPU
 
 
 def test_initialize_bytes_identical_to_reference(built):

@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 from primme_amd import _ffi as F
-from primme_amd import eigsh, Operator, problems
+from primme_amd import problems
+from checkers import eigsh, Operator
 
 pytestmark = pytest.mark.gpu
 

@@ -7,7 +7,7 @@ import pytest
 
 from primme_amd import _ffi as F
 from primme_amd import problems
-from primme_amd.api import Operator, eigsh
+from checkers import Operator, eigsh
 import reference_driver_cases as RD
 from test_complex_host import hermitian_band
 

@@ -7,8 +7,10 @@ import numpy as np
 import pytest
 
 from primme_amd import _ffi as F
+
+import checkers
 from primme_amd import problems
-from primme_amd.api import Operator, eigsh
+from checkers import Operator, eigsh
 import reference_driver_cases as RD
 
 
@@ -28,7 +30,7 @@ def hermitian_band(n, seed=0, band=4):
 def test_real_equivalent_expansion(built):
     """primme_amd_csr_complex_to_real: M [re,im interleaved] = A z, M symmetric, spectrum doubled."""
     import ctypes as C
-    lib = F.load_hostcheck()
+    lib = checkers.load_hostcheck()
     n = 40
     A, (rp, ci, va) = hermitian_band(n, seed=3)
     o = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
@@ -86,7 +88,7 @@ def test_degenerate_hermitian_spectrum(built):
     assert np.max(np.linalg.norm(A @ X - X * r.evals, axis=0)) <= 1e-8 * r.params["aNorm"]
 
 
-@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
 @pytest.mark.parametrize("method,extra", [("GD_plusK", {}), ("JDQMR", {}), ("GD_Olsen_plusK", dict(precond="jacobi")),
                                           ("DEFAULT_MIN_TIME", dict(target="closest_abs", targetShifts=[40.3]))])
 def test_hermitian_against_live_reference(built, method, extra):
@@ -145,7 +147,7 @@ def test_reference_driver_complex_case(built, name):
     assert not bad, bad
 
 
-@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
 @pytest.mark.parametrize("name", ["test_101", "test_106"])
 def test_reference_driver_complex_case_pins_the_checker(built, name):
     r, bad = _run_z_case(name, "reference")
@@ -156,7 +158,7 @@ def test_reference_driver_complex_case_pins_the_checker(built, name):
 
 def test_complex_unsupported_and_argument_errors(built):
     import ctypes as C
-    lib = F.load_hostcheck()
+    lib = checkers.load_hostcheck()
     p = F.PrimmeParams()
     lib.primme_initialize(C.byref(p))
     p.n, p.numEvals = 10, 2

@@ -9,10 +9,12 @@ import pytest
 
 from primme_amd import _ffi as F
 
+import checkers
+
 
 @pytest.fixture(scope="module")
 def lib(built):
-    l = C.CDLL(F.HOSTCHECK_LIB)
+    l = C.CDLL(checkers.HOSTCHECK_LIB)
     return l
 
 

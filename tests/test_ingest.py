@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 
 from primme_amd import _ffi as F
+
+import checkers
 from primme_amd import problems
 import reference_driver_cases as RD
 
@@ -38,7 +40,7 @@ def _dense(m, n, rp, ci, va):
 
 @pytest.mark.parametrize("name", ["LUNDA.mtx", "rect.mtx"])
 def test_mm_read_reference_files(built, name):
-    lib = F.load_hostcheck()
+    lib = checkers.load_hostcheck()
     path = os.path.join(RD.DATA, name)
     rc, (m, n, rp, ci, va) = _mm_read(lib, path)
     assert rc == 0
@@ -54,7 +56,7 @@ def test_mm_read_reference_files(built, name):
 
 
 def test_mm_read_variants(built, tmp_path):
-    lib = F.load_hostcheck()
+    lib = checkers.load_hostcheck()
     cases = {
         "general": ("%%MatrixMarket matrix coordinate real general\n% c\n3 4 4\n1 1 1.5\n3 4 -2\n2 2 3\n1 3 4e0\n",
                     np.array([[1.5, 0, 4, 0], [0, 3, 0, 0], [0, 0, 0, -2]])),
@@ -81,7 +83,7 @@ def test_mm_read_variants(built, tmp_path):
 
 
 def test_tiler_and_transpose(built):
-    lib = F.load_hostcheck()
+    lib = checkers.load_hostcheck()
     rp, ci, va, n0 = RD.lunda()
     T, first = 5, 3
     orp, oci, ova = C.c_void_p(), C.c_void_p(), C.c_void_p()

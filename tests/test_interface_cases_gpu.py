@@ -6,7 +6,7 @@ of the host logic)."""
 import pytest
 
 from primme_amd import _ffi as F
-from primme_amd.api import Operator, eigsh
+from checkers import Operator, eigsh
 import reference_driver_cases as RD
 
 pytestmark = pytest.mark.gpu

@@ -7,7 +7,9 @@ import numpy as np
 import pytest
 
 from primme_amd import _ffi as F
-from primme_amd.api import Operator, eigsh
+
+import checkers
+from checkers import Operator, eigsh
 import reference_driver_cases as RD
 
 
@@ -23,7 +25,7 @@ def test_interface_cases(built, method):
     assert ran >= 100 and not failures, failures[:10]
 
 
-@pytest.mark.skipif(not os.path.exists(F.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
 @pytest.mark.parametrize("method", ["DEFAULT_MIN_TIME", "GD_Olsen_plusK", "LOBPCG_OrthoBasis"])
 def test_interface_cases_pin_the_harness(built, method):
     """The same loop over the live reference build: pins the case enumeration, the data files and

@@ -9,7 +9,8 @@ import sys
 import numpy as np
 import pytest
 
-from primme_amd import eigsh, Operator, problems
+from primme_amd import problems
+from checkers import eigsh, Operator
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from primme_amd import problems
-from primme_amd.svds_api import svds, transpose_csr
+from checkers import svds, transpose_csr
 import reference_driver_cases as RD
 from test_svds_host import _rect
 

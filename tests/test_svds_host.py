@@ -8,11 +8,13 @@ import numpy as np
 import pytest
 
 from primme_amd import _ffi as F
+
+import checkers
 from primme_amd import problems
-from primme_amd.svds_api import svds, transpose_csr
+from checkers import svds, transpose_csr
 import reference_driver_cases as RD
 
-HAVE_REF = os.path.exists(F.REFERENCE_LIB)
+HAVE_REF = os.path.exists(checkers.REFERENCE_LIB)
 
 
 def _rect(m, n, seed=0):
@@ -36,7 +38,7 @@ def test_svds_params_abi():
 
 @pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built")
 def test_svds_defaults_byte_identical_to_reference(built):
-    lib, ref = F.load_hostcheck(), F.load_reference()
+    lib, ref = checkers.load_hostcheck(), checkers.load_reference()
     a, b = F.PrimmeSvdsParams(), F.PrimmeSvdsParams()
     for (m, n, k, meth, tgt, stage1) in [(1000, 500, 5, 2, 0, 0), (500, 1000, 3, 2, 1, F.METHODS["GD_plusK"]),
                                          (800, 800, 10, 2, 0, F.METHODS["JDQMR"]), (900, 700, 4, 1, 0, 0),
