@@ -114,7 +114,7 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
  * registers anyway.  With A symmetric and W = A V this is V' A dst, from
  * which the host forms the new column of the projected matrix without another pass over V
  * (update_projection.c:99-122 reads V again for it): see eigs_conv.c. */
-#define HIPK_WTR_MAX_K 16
+#define HIPK_WTR_MAX_K 32
 int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
       const void *W, int64_t ldVW, int k, const double *hcol_host, double theta, void *dst,
       const void *Q, int64_t ldQ, int L, int want_wtr, double *out_dev);

@@ -289,7 +289,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
           * synchronisation.  Needs in-stream reductions (single rank or the RCCL communicator). */
          const int speculate2 = speculate && !parallel_host && !s->phase_timing && dstc == VCOL(s, basisSize) &&
                                 basisSize + 1 <= p->maxBasisSize && s->spec2_enabled;
-         /* Opt-in (PRIMME_AMD_WTR=1).  With A symmetric and W = A V, the new
+         /* Default (PRIMME_AMD_NO_WTR=1 switches it off).  With A symmetric and W = A V, the new
           * column of H = V'AV is W't for the new basis vector t = (r - [V Q] c) / |.|, i.e.
           * (W'r - H c_V - (W'Q) c_Q) / |.|: W'r comes out of the residual pass (W is in registers
           * there), H c_V is host arithmetic, only t'At needs the new W column: no separate pass over V

@@ -886,7 +886,9 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    /* PRIMME_AMD_FORCE_COMM: run the cross-rank reduction path with a one-rank communicator, which is
     * how the RCCL calls are exercised on a single-GPU box (tests/test_comm_gpu.py) */
    s->spec2_enabled = getenv("PRIMME_AMD_NO_SPEC2") == NULL;
-   s->wtr_enabled = getenv("PRIMME_AMD_WTR") != NULL;   /* opt-in: exact but not faster yet, DESIGN.md §4d */
+   /* projection column from W'r of the fused residual pass: default; PRIMME_AMD_NO_WTR
+    * switches back to the separate pass over V (measurement knob, read once per solve) */
+   s->wtr_enabled = getenv("PRIMME_AMD_NO_WTR") == NULL;
    s->device_rr = getenv("PRIMME_AMD_DEVICE_RR") != NULL;
    s->parallel = ((p->numProcs > 1 || getenv("PRIMME_AMD_FORCE_COMM")) && p->globalSumReal != NULL);
    s->dev_comm = (s->parallel && p->globalSumReal == primme_amd_global_sum);

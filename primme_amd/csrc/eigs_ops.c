@@ -65,7 +65,7 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
 
 /* global sum of a few host scalars (cost-model ratios): through the same path as the
  * device partials so that every communicator flavour is covered */
-/* G = W(:,0:k)' Q for the locked / constraint vectors Q (experimental PRIMME_AMD_WTR path,
+/* G = W(:,0:k)' Q for the locked / constraint vectors Q (projection column from W'r,
  * eigs_conv.c): one TN panel product after a restart. */
 int pa_refresh_wtq(pa_solver *s, int basisSize, int nLk) {
    s->wtq_rows = -1; s->wtq_L = nLk;

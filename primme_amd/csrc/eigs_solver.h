@@ -82,7 +82,7 @@ typedef struct pa_solver {
     * at anything; accepted by the orthogonaliser if Daniel's test passes on the first pass */
    int device_rr;          /* PRIMME_AMD_DEVICE_RR: small Rayleigh-Ritz solve by the device Jacobi kernel */
    int spec2_enabled;      /* off with PRIMME_AMD_NO_SPEC2 (measurement knob, read once per solve) */
-   int wtr_enabled;        /* projection column from W'r (PRIMME_AMD_WTR=1) */
+   int wtr_enabled;        /* projection column from W'r (default; PRIMME_AMD_NO_WTR=1 disables) */
    double *wtq;            /* G = W'Q for the first wtq_rows basis vectors (K x HIPK_WTR_MAX_K, host) */
    int wtq_rows, wtq_L;    /* -1: not valid */
    int spec2_valid, spec2_k;

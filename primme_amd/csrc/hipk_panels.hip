@@ -38,6 +38,7 @@ static int pack_segs(const hipk_seg *segs, int nseg, SegArgs *a) {
 template <typename T, int VW> struct lanevec { T e[VW]; };
 template <> struct __attribute__((aligned(16))) lanevec<double, 2> { double e[2]; };
 template <> struct __attribute__((aligned(16))) lanevec<float, 4> { float e[4]; };
+template <> struct __attribute__((aligned(8))) lanevec<float, 2> { float e[2]; };
 template <typename T> struct vecwidth { enum { value = 16 / sizeof(T) }; };
 
 static inline bool aligned16(const void *p, int64_t ld, size_t es) {
@@ -729,118 +730,230 @@ extern "C" int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
 }
 
 /* ============ fused Ritz residual + first-pass Gram-Schmidt overlaps (b = 1) ============
- * r = W h - theta V h (written to dst), out = [ V' r | Q' r | r' r ].
+ * r = W h - theta V h (written to dst), out = [ V' r | Q' r | r' r ] (+ [ W' r | W(:,k-1)' Q ]).
  * In Generalized Davidson without preconditioner the residual IS the new basis vector, and
  * the V and W rows needed for r are exactly the rows the first classical Gram-Schmidt pass
  * would stream again for V' r (reference: Num_update_VWXR, auxiliary_eigs_normal.c:155-388,
  * followed by Num_gemv_ddh in ortho.c:236-246).  Fusing them removes one full pass over V
  * per outer iteration; the locked vectors Q are streamed here instead of in the dots launch.
+ *
+ * Column-split layout: the four waves of a workgroup walk the SAME rows (64*VW per step); wave w
+ * owns the basis columns [w*CPW, (w+1)*CPW) of V and W and the locked columns [w*QPW, (w+1)*QPW).
+ * Each wave forms its part of x = V h and y = W h, the parts meet in LDS (one barrier per step,
+ * double-buffered), every wave then knows r for its rows and accumulates the overlaps of ITS
+ * columns only.  A lane therefore holds 2*CPW + QPW loaded values and as many accumulators
+ * instead of 2k + L of each (206 VGPRs at k = 16, L = 16 in the one-lane-per-row form, i.e. two
+ * waves per SIMD): occupancy no longer falls with the basis size, every column is still read
+ * exactly once, and the W' r accumulators that make the projection column free
+ * cost CPW registers instead of k.
  */
 struct HCol { double h[32]; };   /* the coefficient vector travels in the kernel arguments */
-template <typename T, int NK, int NL, bool WT>
+
+template <typename T, int CPW, int QPW, int VW, bool WT>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
       HCol hcol, double theta, T *__restrict__ dst, const T *__restrict__ Q,
       int64_t ldQ, int L, int64_t m, double *__restrict__ partials) {
-   __shared__ double hs[NK];
-   if (threadIdx.x < NK) hs[threadIdx.x] = (threadIdx.x < k) ? hcol.h[threadIdx.x] : 0.0;
-   __syncthreads();
-   double ov[NK], oq[NL > 0 ? NL : 1], ow[WT ? NK : 1], og[(WT && NL > 0) ? NL : 1], n2 = 0.0;
+   typedef lanevec<T, VW> LV;
+   constexpr int QN = QPW > 0 ? QPW : 1;
+   __shared__ double sxy[2][2][VW][4][64];       /* [buffer][x|y][row in lane][wave][lane] */
+   const int lane = threadIdx.x & 63;
+   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const int j0 = wv * CPW, q0 = wv * QPW;
+   double hj[CPW];
+   const T *vp[CPW], *wp[CPW], *qp[QN];
 #pragma unroll
-   for (int j = 0; j < (WT ? NK : 1); j++) ow[j] = 0.0;
+   for (int jj = 0; jj < CPW; jj++) {
+      const int j = j0 + jj;
+      hj[jj] = (j < k) ? hcol.h[j < 32 ? j : 0] : 0.0;
+      vp[jj] = V + (size_t)(j < k ? j : 0) * ld;
+      wp[jj] = W + (size_t)(j < k ? j : 0) * ld;
+   }
 #pragma unroll
-   for (int q = 0; q < ((WT && NL > 0) ? NL : 1); q++) og[q] = 0.0;
+   for (int qq = 0; qq < QN; qq++) qp[qq] = (QPW > 0 && L > 0) ? Q + (size_t)(q0 + qq < L ? q0 + qq : 0) * ldQ : (const T *)V;
+   const T *wlast = W + (size_t)(k - 1) * ld;    /* newest W column, for W(:,k-1)' Q */
+   double ov[CPW], ow[WT ? CPW : 1], oq[QN], og[WT ? QN : 1], n2 = 0.0;
 #pragma unroll
-   for (int j = 0; j < NK; j++) ov[j] = 0.0;
+   for (int jj = 0; jj < CPW; jj++) ov[jj] = 0.0;
 #pragma unroll
-   for (int q = 0; q < NL; q++) oq[q] = 0.0;
-   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
-   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
-      double v[NK], w[NK], qv[NL > 0 ? NL : 1];
+   for (int jj = 0; jj < (WT ? CPW : 1); jj++) ow[jj] = 0.0;
 #pragma unroll
-      for (int j = 0; j < NK; j++) v[j] = (j < k) ? (double)V[i + (size_t)j * ld] : 0.0;
+   for (int qq = 0; qq < QN; qq++) oq[qq] = 0.0;
 #pragma unroll
-      for (int j = 0; j < NK; j++) w[j] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+   for (int qq = 0; qq < (WT ? QN : 1); qq++) og[qq] = 0.0;
+
+   const int64_t ngroups = m / (64 * VW);         /* full steps of 64*VW rows */
+   int buf = 0;
+   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x, buf ^= 1) {
+      const int64_t e = g * 64 + lane;            /* index in LV units */
+      LV v[CPW], w[CPW], q[QN], wl;
 #pragma unroll
-      for (int q = 0; q < NL; q++) qv[q] = (q < L) ? (double)Q[i + (size_t)q * ldQ] : 0.0;
-      double x = 0.0, y = 0.0;
+      for (int jj = 0; jj < CPW; jj++)
+         if (j0 + jj < k) { v[jj] = ((const LV *)vp[jj])[e]; w[jj] = ((const LV *)wp[jj])[e]; }
+      if (QPW > 0) {
 #pragma unroll
-      for (int j = 0; j < NK; j++) { x = fma(v[j], hs[j], x); y = fma(w[j], hs[j], y); }
-      const T rt = (T)fma(-theta, x, y);
-      dst[i] = rt;
-      const double r = (double)rt;
-      n2 = fma(r, r, n2);
+         for (int qq = 0; qq < QN; qq++)
+            if (q0 + qq < L) q[qq] = ((const LV *)qp[qq])[e];
+         if (WT && q0 < L) wl = ((const LV *)wlast)[e];
+      }
+      double px[VW], py[VW];
 #pragma unroll
-      for (int j = 0; j < NK; j++) ov[j] = fma(v[j], r, ov[j]);
-      if (WT) {
+      for (int r = 0; r < VW; r++) { px[r] = 0.0; py[r] = 0.0; }
 #pragma unroll
-         for (int j = 0; j < NK; j++) ow[j] = fma(w[j], r, ow[j]);
-         if (NL > 0) {           /* W(:,k-1)' Q: the newest W column against the locked vectors */
-            double wl = 0.0;
+      for (int jj = 0; jj < CPW; jj++)
+         if (j0 + jj < k) {
 #pragma unroll
-            for (int j = 0; j < NK; j++) wl = (j == k - 1) ? w[j] : wl;
-#pragma unroll
-            for (int q = 0; q < NL; q++) og[q] = fma(wl, qv[q], og[q]);
+            for (int r = 0; r < VW; r++) {
+               px[r] = fma((double)v[jj].e[r], hj[jj], px[r]);
+               py[r] = fma((double)w[jj].e[r], hj[jj], py[r]);
+            }
          }
+#pragma unroll
+      for (int r = 0; r < VW; r++) { sxy[buf][0][r][wv][lane] = px[r]; sxy[buf][1][r][wv][lane] = py[r]; }
+      __syncthreads();
+      double rr[VW];
+      LV rt;
+#pragma unroll
+      for (int r = 0; r < VW; r++) {
+         const double x = (sxy[buf][0][r][0][lane] + sxy[buf][0][r][1][lane]) + (sxy[buf][0][r][2][lane] + sxy[buf][0][r][3][lane]);
+         const double y = (sxy[buf][1][r][0][lane] + sxy[buf][1][r][1][lane]) + (sxy[buf][1][r][2][lane] + sxy[buf][1][r][3][lane]);
+         rt.e[r] = (T)fma(-theta, x, y);
+         rr[r] = (double)rt.e[r];
+      }
+      if (wv == 0) {
+         ((LV *)dst)[e] = rt;
+#pragma unroll
+         for (int r = 0; r < VW; r++) n2 = fma(rr[r], rr[r], n2);
       }
 #pragma unroll
-      for (int q = 0; q < NL; q++) oq[q] = fma(qv[q], r, oq[q]);
+      for (int jj = 0; jj < CPW; jj++)
+         if (j0 + jj < k) {
+#pragma unroll
+            for (int r = 0; r < VW; r++) {
+               ov[jj] = fma((double)v[jj].e[r], rr[r], ov[jj]);
+               if (WT) ow[WT ? jj : 0] = fma((double)w[jj].e[r], rr[r], ow[WT ? jj : 0]);
+            }
+         }
+      if (QPW > 0) {
+#pragma unroll
+         for (int qq = 0; qq < QN; qq++)
+            if (q0 + qq < L) {
+#pragma unroll
+               for (int r = 0; r < VW; r++) {
+                  oq[qq] = fma((double)q[qq].e[r], rr[r], oq[qq]);
+                  if (WT) og[WT ? qq : 0] = fma((double)wl.e[r], (double)q[qq].e[r], og[WT ? qq : 0]);
+               }
+            }
+      }
    }
-   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NK + NL + 1 + (WT ? NK + NL : 0)];
-   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+   /* ragged tail (fewer than 64*VW rows): the last workgroup, one row per lane, same scheme */
+   if (blockIdx.x == gridDim.x - 1) {
+      for (int64_t i0 = ngroups * 64 * VW; i0 < m; i0 += 64, buf ^= 1) {
+         const int64_t i = i0 + lane;
+         const bool live = i < m;
+         double tv[CPW], tw[CPW], tq[QN], twl = 0.0, px = 0.0, py = 0.0;
 #pragma unroll
-   for (int j = 0; j < NK; j++) { double t = hipk_wave_sum(ov[j]); if (lane == 0) sm[wv][j] = t; }
+         for (int jj = 0; jj < CPW; jj++) {
+            const bool on = live && (j0 + jj < k);
+            tv[jj] = on ? (double)vp[jj][i] : 0.0;
+            tw[jj] = on ? (double)wp[jj][i] : 0.0;
+            px = fma(tv[jj], hj[jj], px);
+            py = fma(tw[jj], hj[jj], py);
+         }
 #pragma unroll
-   for (int q = 0; q < NL; q++) { double t = hipk_wave_sum(oq[q]); if (lane == 0) sm[wv][NK + q] = t; }
-   { double t = hipk_wave_sum(n2); if (lane == 0) sm[wv][NK + NL] = t; }
-   if (WT) {
+         for (int qq = 0; qq < QN; qq++) tq[qq] = (QPW > 0 && live && q0 + qq < L) ? (double)qp[qq][i] : 0.0;
+         if (WT && QPW > 0 && live && q0 < L) twl = (double)wlast[i];
+         sxy[buf][0][0][wv][lane] = px; sxy[buf][1][0][wv][lane] = py;
+         __syncthreads();
+         const double x = (sxy[buf][0][0][0][lane] + sxy[buf][0][0][1][lane]) + (sxy[buf][0][0][2][lane] + sxy[buf][0][0][3][lane]);
+         const double y = (sxy[buf][1][0][0][lane] + sxy[buf][1][0][1][lane]) + (sxy[buf][1][0][2][lane] + sxy[buf][1][0][3][lane]);
+         const T rt = (T)fma(-theta, x, y);
+         const double r = live ? (double)rt : 0.0;
+         if (wv == 0 && live) { dst[i] = rt; n2 = fma(r, r, n2); }
 #pragma unroll
-      for (int j = 0; j < NK; j++) { double t = hipk_wave_sum(ow[j]); if (lane == 0) sm[wv][NK + NL + 1 + j] = t; }
+         for (int jj = 0; jj < CPW; jj++) {
+            ov[jj] = fma(tv[jj], r, ov[jj]);
+            if (WT) ow[WT ? jj : 0] = fma(tw[jj], r, ow[WT ? jj : 0]);
+         }
 #pragma unroll
-      for (int q = 0; q < NL; q++) { double t = hipk_wave_sum(og[q]); if (lane == 0) sm[wv][NK + NL + 1 + NK + q] = t; }
+         for (int qq = 0; qq < QN; qq++) {
+            oq[qq] = fma(tq[qq], r, oq[qq]);
+            if (WT) og[WT ? qq : 0] = fma(twl, tq[qq], og[WT ? qq : 0]);
+         }
+      }
    }
-   __syncthreads();
+   /* every output belongs to exactly one wave: wave sums go straight to the block's partial row
+    * [ V'r (k) | Q'r (L) | r'r | W'r (k) | W(:,k-1)'Q (L) ] */
    const int nout = k + L + 1 + (WT ? k + L : 0);
-   if (threadIdx.x < nout) {
-      const int o = threadIdx.x;
-      const int src = o < k ? o : (o < k + L ? NK + (o - k) : (o == k + L ? NK + NL
-                      : (o < 2 * k + L + 1 ? NK + NL + 1 + (o - k - L - 1) : NK + NL + 1 + NK + (o - 2 * k - L - 1))));
-      partials[(size_t)blockIdx.x * nout + threadIdx.x] = (sm[0][src] + sm[1][src]) + (sm[2][src] + sm[3][src]);
+   double *prow = partials + (size_t)blockIdx.x * nout;
+#pragma unroll
+   for (int jj = 0; jj < CPW; jj++) {
+      const double t = hipk_wave_sum(ov[jj]);
+      if (lane == 0 && j0 + jj < k) prow[j0 + jj] = t;
+      if (WT) {
+         const double u = hipk_wave_sum(ow[WT ? jj : 0]);
+         if (lane == 0 && j0 + jj < k) prow[k + L + 1 + j0 + jj] = u;
+      }
    }
+   if (QPW > 0) {
+#pragma unroll
+      for (int qq = 0; qq < QN; qq++) {
+         const double t = hipk_wave_sum(oq[qq]);
+         if (lane == 0 && q0 + qq < L) prow[k + q0 + qq] = t;
+         if (WT) {
+            const double u = hipk_wave_sum(og[WT ? qq : 0]);
+            if (lane == 0 && q0 + qq < L) prow[2 * k + L + 1 + q0 + qq] = u;
+         }
+      }
+   }
+   { const double t = hipk_wave_sum(n2); if (lane == 0 && wv == 0) prow[k + L] = t; }
 }
 
-template <typename T, int NK, bool WT>
-static int ritz_cgs_nk(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
+template <typename T, int CPW, int VW, bool WT>
+static int ritz_cgs_q(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
       double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m) {
    dim3 g(gx), b(HIPK_BLOCK);
-   if (L == 0) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 0, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
-   else if (L <= 8) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 8, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
-   else if (L <= 16) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 16, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
-   else if (L <= 32) hipLaunchKernelGGL((ritz_cgs_kernel<T, NK, 32, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials);
+#define RCGS(QPWV) hipLaunchKernelGGL((ritz_cgs_kernel<T, CPW, QPWV, VW, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials)
+   if (L == 0) RCGS(0);
+   else if (L <= 8) RCGS(2);
+   else if (L <= 16) RCGS(4);
+   else if (L <= 32) RCGS(8);
    else return -1;
+#undef RCGS
    HIPK_CHECK(hipGetLastError());
    return 0;
+}
+
+template <typename T, int VW, bool WT>
+static int ritz_cgs_k(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
+      double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m) {
+   if (k <= 8) return ritz_cgs_q<T, 2, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   if (k <= 16) return ritz_cgs_q<T, 4, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   if (k <= 24) return ritz_cgs_q<T, 6, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   return ritz_cgs_q<T, 8, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
 }
 
 template <typename T>
 static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
       const double *hcol_host, double theta, T *dst, const T *Q, int64_t ldQ, int L, int want_wtr, double *out_dev) {
    if (k <= 0 || k > 32 || L < 0 || L > 32) return -1;
-   if (want_wtr && (k > 16 || L > 16)) return -1;      /* register budget: see HIPK_WTR_MAX_K */
    HCol hcol;
    for (int j = 0; j < 32; j++) hcol.h[j] = (j < k) ? hcol_host[j] : 0.0;
-   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4);
+   constexpr int VWT = 2;   /* two rows per lane: 16-byte loads in double, 8-byte in float (register budget) */
+   const bool vec = aligned16(V, ld, sizeof(T)) && aligned16(W, ld, sizeof(T)) && aligned16(dst, ld, sizeof(T)) &&
+                    (L == 0 || aligned16(Q, ldQ, sizeof(T)));
+   const int rows_per_step = 64 * (vec ? VWT : 1);
+   static int bpc = -1;                        /* HIPK_RCGS_BPC: workgroups per CU (measurement knob, read once) */
+   if (bpc < 0) { const char *env = getenv("HIPK_RCGS_BPC"); bpc = env ? atoi(env) : 8; if (bpc < 1) bpc = 8; }
+   int gx = hipk_grid_for_rows(ctx, m, rows_per_step, bpc);
    const int nout = k + L + 1 + (want_wtr ? k + L : 0);
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + 1));
    int rc;
-   if (want_wtr) {
-      if (k <= 8) rc = ritz_cgs_nk<T, 8, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-      else rc = ritz_cgs_nk<T, 16, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   } else if (k <= 8) rc = ritz_cgs_nk<T, 8, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   else if (k <= 16) rc = ritz_cgs_nk<T, 16, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   else if (k <= 24) rc = ritz_cgs_nk<T, 24, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   else rc = ritz_cgs_nk<T, 32, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   if (vec) rc = want_wtr ? ritz_cgs_k<T, VWT, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m)
+                          : ritz_cgs_k<T, VWT, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   else rc = want_wtr ? ritz_cgs_k<T, 1, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m)
+                      : ritz_cgs_k<T, 1, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
    hipk_prof_end(pslot, ctx->stream);
    if (rc) return rc;
    return hipk_finalize_partials(ctx, ctx->partials, gx, nout, out_dev);

@@ -145,13 +145,16 @@ def test_ritz_update_many_residuals(built, dt):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
-@pytest.mark.parametrize("m,k,L,wtr", [(1001, 1, 0, 0), (70001, 7, 3, 0), (250000, 15, 10, 0), (99999, 30, 20, 0),
-                                       (1001, 1, 0, 1), (70001, 7, 3, 1), (250000, 15, 10, 1), (120000, 16, 16, 1)])
-def test_ritz_residual_overlaps(built, dt, m, k, L, wtr):
-    """fused residual + first Gram-Schmidt pass: r = W h - theta V h, out = [V'r | Q'r | r'r (| W'r)]"""
+@pytest.mark.parametrize("m,k,L,wtr,pads", [(1001, 1, 0, 0, (2, 5)), (70001, 7, 3, 0, (2, 5)), (250000, 15, 10, 0, (2, 5)), (99999, 30, 20, 0, (2, 5)),
+                                            (1001, 1, 0, 1, (2, 5)), (70001, 7, 3, 1, (2, 5)), (250000, 15, 10, 1, (2, 5)), (120000, 16, 16, 1, (2, 5)),
+                                            # 16-byte aligned columns (two rows per lane), ragged tails, every column-per-wave width
+                                            (250000, 15, 10, 1, (2, 6)), (99999, 30, 20, 1, (1, 3)), (64 * 2 * 5 + 77, 9, 0, 1, (1, 1)),
+                                            (130001, 21, 32, 1, (1, 5)), (130001, 32, 5, 0, (3, 3)), (50, 3, 2, 1, (0, 0)), (128, 6, 9, 0, (0, 0))])
+def test_ritz_residual_overlaps(built, dt, m, k, L, wtr, pads):
+    """fused residual + first Gram-Schmidt pass: r = W h - theta V h, out = [V'r | Q'r | r'r (| W'r | W(:,k-1)'Q)]"""
     rng = np.random.default_rng(m + k + L)
     npdt = NPDT[dt]
-    ld, ldq = m + 2, m + 5
+    ld, ldq = m + pads[0], m + pads[1]
     V = rng.standard_normal((k + 1, ld)).astype(npdt)
     W = rng.standard_normal((k + 1, ld)).astype(npdt)
     Q = rng.standard_normal((max(L, 1), ldq)).astype(npdt)

@@ -48,15 +48,15 @@ def _run(name, backend):
     return eigsh(op, backend=backend, **kw), g
 
 
-@pytest.mark.parametrize("projection_column", ["default", "from_Wtr"])
+@pytest.mark.parametrize("projection_column", ["from_Wtr", "pass_over_V"])
 @pytest.mark.parametrize("name", sorted(GOLD))
 def test_against_reference_fixture(built, name, projection_column, monkeypatch):
-    """Two legs.  "default": the new column of H is V'(A t) from a pass over V, as
-    update_projection.c:99-122 computes it.  "from_Wtr" (PRIMME_AMD_WTR=1): block size 1 GD forms it
-    from W'r of the fused residual pass, H c and G = W'Q.  Both must reproduce the
+    """Two legs.  "from_Wtr" (the default): block size 1 GD forms the new column of H from W'r of the
+    fused residual pass, H c and G = W'Q.  "pass_over_V" (PRIMME_AMD_NO_WTR=1): V'(A t)
+    from a pass over V, as update_projection.c:99-122 computes it.  Both must reproduce the
     reference's iteration / matvec / restart counts."""
-    if projection_column == "from_Wtr":
-        monkeypatch.setenv("PRIMME_AMD_WTR", "1")
+    if projection_column == "pass_over_V":
+        monkeypatch.setenv("PRIMME_AMD_NO_WTR", "1")
     r, g = _run(name, "hostcheck")
     aN = g["params"]["aNorm"] if g["params"]["aNorm"] > 0 else max(abs(np.array(g["evals"])))
     assert r.ret == g["ret"] == 0
@@ -158,12 +158,12 @@ def test_dynamic_method_leaves_a_recommendation(built):
 def test_launch_structure_block_size_one(built, wtr, monkeypatch):
     """GD+k, block size 1, no preconditioner: per outer iteration ONE fused residual+overlaps
     pass, ONE Gram-Schmidt update (speculative, reused by the orthogonaliser), and for the
-    projection either ONE inner-product pass over V (default, the reference's formula) or, with
-    PRIMME_AMD_WTR=1, none: the column comes from W'r of the fused pass and only t'At is a (two-vector)
-    inner product; panel inner products remain around restarts (G = W'Q, second passes)."""
+    projection either none (default): the column comes from W'r of the fused pass and only t'At is a
+    (two-vector) inner product, panel inner products remain around restarts (G = W'Q, second passes);
+    or, with PRIMME_AMD_NO_WTR=1, ONE inner-product pass over V (the reference's formula)."""
     import ctypes as C
-    if wtr:
-        monkeypatch.setenv("PRIMME_AMD_WTR", "1")
+    if not wtr:
+        monkeypatch.setenv("PRIMME_AMD_NO_WTR", "1")
     lib = checkers.load_hostcheck()
     cnt = (C.c_long * 8)()
     lib.hipk_cpu_counts(cnt, 1)
