@@ -33,6 +33,12 @@ int primme_amd_comm_allgather(primme_amd_comm *c, void *hip_stream, const void *
 /* recv[0:count) = sum over ranks of send[rank*count : (rank+1)*count), count elements per rank */
 int primme_amd_comm_reduce_scatter(primme_amd_comm *c, void *hip_stream, const void *send, void *recv,
       size_t count_per_rank, int is_double);
+/* a block of columns in one grouped exchange: column c of `send` (ld_send elements apart) to column c
+ * of `recv` (examples/ex_eigs_mpi.c issues one MPI call per vector) */
+int primme_amd_comm_allgather_cols(primme_amd_comm *c, void *hip_stream, const void *send, int64_t ld_send,
+      void *recv, int64_t ld_recv, size_t bytes_per_rank, size_t elem, int ncols);
+int primme_amd_comm_reduce_scatter_cols(primme_amd_comm *c, void *hip_stream, const void *send, int64_t ld_send,
+      void *recv, int64_t ld_recv, size_t count_per_rank, int is_double, int ncols);
 int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n, int64_t *all);
 
 /* Operator handle for primme->matrix / primme->preconditioner: a local sparse
@@ -49,6 +55,12 @@ int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double sh
  * hip_cprimme with leading dimensions counted in complex elements */
 int primme_amd_operator_set_complex(primme_amd_operator *op, int on);
 hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op);
+/* y = A (a x), xout = a x, dot_dev[0] = xout' y, a = 1/sqrt(norm2_dev[0]), halo exchange included: the
+ * fused tail of the solver's one-synchronisation iteration (one column; CSR operators).
+ * primme_amd_operator_can_fuse tells whether the operator supports it. */
+int primme_amd_operator_can_fuse(const primme_amd_operator *op);
+int primme_amd_operator_apply_scaled(primme_amd_operator *op, void *hip_stream, const void *x,
+      const double *norm2_dev, void *xout, void *y, double *dot_dev);
 /* y = A x on `hip_stream` including the halo exchange */
 int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stream, const void *x, int64_t ldx,
       void *y, int64_t ldy, int ncols);

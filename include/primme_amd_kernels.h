@@ -83,6 +83,13 @@ int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *seg
 int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
       const double *coef_dev, int ldcoef, void *X, int64_t ldX, int nx, double *nrm2_dev);
 
+/* out-of-place form: Xout(:,c) = X(:,c) - [segs] * coef(:,c) (X is only read; Xout may equal X).
+ * Lets the next launch consume the projected vector from a scratch column while it rebuilds the
+ * basis column itself (hipk_csr_matvec_scaled below). */
+int hipk_panel_project_to(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
+      const double *coef_dev, int ldcoef, const void *X, int64_t ldX, void *Xout, int64_t ldXout, int nx,
+      double *nrm2_dev);
+
 /* ---- fused Ritz / residual / restart update ----------------------------------
  * The multi-output panel op of reference auxiliary_eigs_normal.c:155-388
  * (Num_update_VWXR) and restart.c:1233-1294.  V, W: m x k panels (ld ldVW).
@@ -182,6 +189,11 @@ int hipk_csr_destroy(hipk_csr *A);
  * the creating context when NULL */
 int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int64_t ldx, void *y, int64_t ldy,
       int ncols);
+/* y = A (a x), xout = a x (xout != x), dot_dev[0] = xout' y with a = 1/sqrt(norm2_dev[0]) read from HBM:
+ * normalisation (Num_scal, cublas_wrapper.c:678), operator and the inner product t'At in one launch. */
+int hipk_csr_matvec_scaled(hipk_csr *A, void *hip_stream, const void *x, const double *norm2_dev,
+      void *xout, void *y, double *dot_dev);
+int hipk_csr_kind(const hipk_csr *A);    /* 0 CSR, 1 stencil */
 /* diagonal of A (device array of nrows_local elements of dtype) */
 const void *hipk_csr_diag(hipk_csr *A);
 int64_t hipk_csr_nnz(const hipk_csr *A);
@@ -200,6 +212,8 @@ int64_t hipk_csr_halo_hi(const hipk_csr *A);
 /* halo buffers (device, halo_lo / halo_hi elements per column, column stride =
  * halo length) the communicator fills before each matvec */
 int hipk_csr_set_halo(hipk_csr *A, const void *lo, const void *hi);
+/* the same with explicit column strides (halos that live inside a gathered full-length block) */
+int hipk_csr_set_halo_ld(hipk_csr *A, const void *lo, int64_t ld_lo, const void *hi, int64_t ld_hi);
 
 /* y(:,c) = x(:,c) / (d - shift[c])  (Jacobi), shifts on host; |d - shift| is kept above
  * min_denominator with its sign (reference tests/COMMON/mat.c:149-165) */

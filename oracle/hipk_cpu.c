@@ -99,24 +99,29 @@ int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *seg
 }
 
 /* X(:,c) -= [segs]*coef(:,c); nrm2[c] = |X(:,c)|^2   (Num_gemv_dhd "N" + Num_dot) */
-int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
-      const double *coef, int ldcoef, void *X, int64_t ldX, int nx, double *nrm2) {
+int hipk_panel_project_to(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
+      const double *coef, int ldcoef, const void *X, int64_t ldX, void *Xout, int64_t ldXout, int nx, double *nrm2) {
    (void)ctx; g_cnt[1]++;
    const int tot = seg_total(segs, nseg);
    for (int c = 0; c < nx; c++) {
-      void *x = (void *)colp(dt, X, ldX, c);
+      const void *x = colp(dt, X, ldX, c);
+      void *o = (void *)colp(dt, Xout, ldXout, c);
       double n2 = 0.0;
       for (int64_t i = 0; i < m; i++) {
          double v = ld_(dt, x, i);
          for (int j = 0; j < tot; j++) v -= ld_(dt, seg_col(dt, segs, nseg, j), i) * coef[j + (size_t)c * ldcoef];
-         st_(dt, x, i, v);
-         double w = ld_(dt, x, i);
+         st_(dt, o, i, v);
+         double w = ld_(dt, o, i);
          n2 += w * w;
       }
       if (nrm2) nrm2[c] = n2;
    }
    if (nrm2) mirror(nrm2, nx);
    return 0;
+}
+int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
+      const double *coef, int ldcoef, void *X, int64_t ldX, int nx, double *nrm2) {
+   return hipk_panel_project_to(ctx, dt, m, segs, nseg, coef, ldcoef, X, ldX, X, ldX, nx, nrm2);
 }
 
 /* Num_update_VWXR restated row by row (all reads of a row precede its writes) */
@@ -287,7 +292,7 @@ int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const doubl
 struct hipk_csr {
    hipk_dtype dt; int kind; int64_t nrows, ncols, row0, nnz, x0, xlen;
    int32_t *rowptr, *colind; void *values; void *diag;
-   int64_t halo_lo, halo_hi; const void *xlo, *xhi; int sx, sy, sz;
+   int64_t halo_lo, halo_hi; const void *xlo, *xhi; int64_t ld_lo, ld_hi; int sx, sy, sz;
 };
 static double fetch(const hipk_csr *A, const void *x, const void *xlo, const void *xhi, int64_t g) {
    int64_t l = g - A->x0;
@@ -345,7 +350,9 @@ const void *hipk_csr_diag(hipk_csr *A) { return A->diag; }
 int64_t hipk_csr_nnz(const hipk_csr *A) { return A->nnz; }
 int64_t hipk_csr_halo_lo(const hipk_csr *A) { return A->halo_lo; }
 int64_t hipk_csr_halo_hi(const hipk_csr *A) { return A->halo_hi; }
-int hipk_csr_set_halo(hipk_csr *A, const void *lo, const void *hi) { A->xlo = lo; A->xhi = hi; return 0; }
+int hipk_csr_set_halo(hipk_csr *A, const void *lo, const void *hi) { A->xlo = lo; A->xhi = hi; A->ld_lo = A->halo_lo; A->ld_hi = A->halo_hi; return 0; }
+int hipk_csr_set_halo_ld(hipk_csr *A, const void *lo, int64_t ld_lo, const void *hi, int64_t ld_hi) { A->xlo = lo; A->xhi = hi; A->ld_lo = ld_lo; A->ld_hi = ld_hi; return 0; }
+int hipk_csr_kind(const hipk_csr *A) { return A->kind; }
 hipk_dtype hipk_csr_dtype(const hipk_csr *A) { return A->dt; }
 int64_t hipk_csr_nrows(const hipk_csr *A) { return A->nrows; }
 
@@ -354,8 +361,8 @@ int hipk_csr_matvec(hipk_csr *A, void *stream, const void *x, int64_t ldx, void 
    const hipk_dtype dt = A->dt;
    for (int c = 0; c < ncols; c++) {
       const void *xc = colp(dt, x, ldx, c);
-      const void *lo = A->xlo ? (const char *)A->xlo + (size_t)c * A->halo_lo * esz(dt) : NULL;
-      const void *hi = A->xhi ? (const char *)A->xhi + (size_t)c * A->halo_hi * esz(dt) : NULL;
+      const void *lo = A->xlo ? (const char *)A->xlo + (size_t)c * A->ld_lo * esz(dt) : NULL;
+      const void *hi = A->xhi ? (const char *)A->xhi + (size_t)c * A->ld_hi * esz(dt) : NULL;
       void *yc = (void *)colp(dt, y, ldy, c);
       if (A->kind == 0) {
          for (int64_t i = 0; i < A->nrows; i++) {
@@ -378,6 +385,33 @@ int hipk_csr_matvec(hipk_csr *A, void *stream, const void *x, int64_t ldx, void 
          }
       }
    }
+   return 0;
+}
+
+/* y = A (a x), xout = a x, dot[0] = xout' y, a = 1/sqrt(norm2[0]): the normalisation, the operator and
+ * the two-vector inner product of the one-synchronisation GD iteration in one call */
+int hipk_csr_matvec_scaled(hipk_csr *A, void *stream, const void *x, const double *norm2, void *xout, void *y, double *dot) {
+   (void)stream; g_cnt[5]++;
+   if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout) return -1;
+   const hipk_dtype dt = A->dt;
+   const double a = 1.0 / sqrt(norm2[0]);
+   double d = 0.0;
+   for (int64_t i = 0; i < A->nrows; i++) {
+      double s = 0;
+      for (int32_t p = A->rowptr[i]; p < A->rowptr[i + 1]; p++) {
+         /* the gathered entry rounded to the panel type after scaling, as if read from the scaled vector */
+         double xv = a * fetch(A, x, A->xlo, A->xhi, A->colind[p]);
+         if (dt == HIPK_F32) xv = (double)(float)xv;
+         s += ld_(dt, A->values, p) * xv;
+      }
+      st_(dt, y, i, s);
+   }
+   for (int64_t i = 0; i < A->nrows; i++) {
+      st_(dt, xout, i, a * ld_(dt, x, i));
+      d += ld_(dt, xout, i) * ld_(dt, y, i);
+   }
+   dot[0] = d;
+   mirror(dot, 1);
    return 0;
 }
 

@@ -205,6 +205,9 @@ def declare_kernels(lib):
         "hipk_stencil_create": [_vp, _i, _i, _i, _i, _i64, _i64, P(_vp)],
         "hipk_csr_destroy": [_vp], "hipk_csr_matvec": [_vp, _vp, _vp, _i64, _vp, _i64, _i],
         "hipk_csr_set_halo": [_vp, _vp, _vp],
+        "hipk_csr_set_halo_ld": [_vp, _vp, _i64, _vp, _i64],
+        "hipk_csr_matvec_scaled": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
+        "hipk_panel_project_to": [_vp, _i, _i64, P(HipkSeg), _i, _vp, _i, _vp, _i64, _vp, _i64, _i, _vp],
         "hipk_jacobi_apply": [_vp, _i, _i64, _vp, _dp, C.c_double, _vp, _i64, _vp, _i64, _i],
         "primme_amd_operator_set_jacobi": [_vp, _i, C.c_double],
         "hipk_bandwidth_probe": [_vp, C.c_size_t, _i, _dp],

@@ -102,23 +102,45 @@ extern "C" int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stre
       hipk_csr_set_halo(op->A, op->buf_lo, op->buf_hi);
       return hipk_csr_matvec(op->A, hip_stream, x, ldx, y, ldy, ncols);
    } else if (op->mode == 2) {
-      /* gather the whole vector once per column; lo = everything below my slab,
-       * hi = everything above */
-      if (grow(&op->xfull, &op->cap_full, (size_t)op->n * es)) return -2;
-      for (int c = 0; c < ncols; c++) {
-         int rc = primme_amd_comm_allgather(op->comm, hip_stream, (const char *)x + (size_t)c * ldx * es,
-               op->xfull, (size_t)op->nrows * es);
-         if (rc) return rc;
-         /* halo buffers are addressed relative to (row0 - lo) and (row0 + nrows) */
-         hipk_csr_set_halo(op->A, (const char *)op->xfull + (size_t)(op->row0 - op->lo) * es,
-               (const char *)op->xfull + (size_t)(op->row0 + op->nrows) * es);
-         rc = hipk_csr_matvec(op->A, hip_stream, (const char *)x + (size_t)c * ldx * es, ldx,
-               (char *)y + (size_t)c * ldy * es, ldy, 1);
-         if (rc) return rc;
-      }
-      return 0;
+      /* unstructured columns: gather the whole block [n x ncols] in ONE grouped exchange (a column per
+       * all-gather inside an RCCL group = one launch), then one SpMM; lo = everything below my slab,
+       * hi = everything above, both addressed inside the gathered block with column stride n */
+      if (grow(&op->xfull, &op->cap_full, (size_t)op->n * ncols * es)) return -2;
+      int rc = primme_amd_comm_allgather_cols(op->comm, hip_stream, x, ldx, op->xfull, op->n, (size_t)op->nrows * es, es, ncols);
+      if (rc) return rc;
+      hipk_csr_set_halo_ld(op->A, (const char *)op->xfull + (size_t)(op->row0 - op->lo) * es, op->n,
+            (const char *)op->xfull + (size_t)(op->row0 + op->nrows) * es, op->n);
+      return hipk_csr_matvec(op->A, hip_stream, x, ldx, y, ldy, ncols);
    }
    return hipk_csr_matvec(op->A, hip_stream, x, ldx, y, ldy, ncols);
+}
+
+/* One-synchronisation GD iteration (eigs_conv.c): y = A (a x), xout = a x, dot_dev[0] = xout' y with
+ * a = 1/sqrt(norm2_dev[0]) in ONE launch (hipk_csr_matvec_scaled), halo exchange included.  Only for the
+ * solver's own use with this ready-made operator: a user matvec callback is a black box and gets the
+ * separate normalisation / operator / inner-product launches instead. */
+extern "C" int primme_amd_operator_can_fuse(const primme_amd_operator *op) {
+   return op && op->ldscale == 1 && hipk_csr_kind(op->A) == 0;
+}
+extern "C" int primme_amd_operator_apply_scaled(primme_amd_operator *op, void *hip_stream, const void *x,
+      const double *norm2_dev, void *xout, void *y, double *dot_dev) {
+   if (!primme_amd_operator_can_fuse(op)) return -1;
+   const size_t es = op_elem(hipk_csr_dtype(op->A));
+   if (op->mode == 1) {
+      if (grow(&op->buf_lo, &op->cap_lo, (size_t)(op->lo > 0 ? op->lo : 1) * es)) return -2;
+      if (grow(&op->buf_hi, &op->cap_hi, (size_t)(op->hi > 0 ? op->hi : 1) * es)) return -2;
+      int rc = primme_amd_comm_halo(op->comm, hip_stream, x, op->nrows, op->nrows, 1, es, op->send_lo,
+            op->send_hi, op->buf_lo, op->lo, op->buf_hi, op->hi);
+      if (rc) return rc;
+      hipk_csr_set_halo(op->A, op->buf_lo, op->buf_hi);
+   } else if (op->mode == 2) {
+      if (grow(&op->xfull, &op->cap_full, (size_t)op->n * es)) return -2;
+      int rc = primme_amd_comm_allgather(op->comm, hip_stream, x, op->xfull, (size_t)op->nrows * es);
+      if (rc) return rc;
+      hipk_csr_set_halo(op->A, (const char *)op->xfull + (size_t)(op->row0 - op->lo) * es,
+            (const char *)op->xfull + (size_t)(op->row0 + op->nrows) * es);
+   }
+   return hipk_csr_matvec_scaled(op->A, hip_stream, x, norm2_dev, xout, y, dot_dev);
 }
 
 /* ---- the callbacks ---------------------------------------------------------- */
@@ -278,19 +300,18 @@ extern "C" void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME
       *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, stream, x, *ldx, y, *ldy, *blockSize);
       return;
    }
-   /* row-partitioned A: one column at a time through the n-vector staging buffer */
+   /* row-partitioned A: the block goes through the [n x blockSize] staging panel with ONE grouped
+    * collective (a column per call inside an RCCL group) and ONE SpMM per application */
    const size_t es = (op->dt == HIPK_F64) ? 8 : 4;
-   if (grow(&op->full, &op->full_cap, (size_t)op->n * es)) return;
-   for (int c = 0; c < *blockSize; c++) {
-      const char *xc = (const char *)x + (size_t)c * (size_t)*ldx * es;
-      char *yc = (char *)y + (size_t)c * (size_t)*ldy * es;
-      if (!*transpose) {
-         if (primme_amd_comm_allgather(op->comm, stream, xc, op->full, (size_t)op->nLocal * es)) return;
-         if (hipk_csr_matvec(op->A, stream, op->full, op->n, yc, op->mLocal, 1)) return;
-      } else {
-         if (hipk_csr_matvec(op->At, stream, xc, op->mLocal, op->full, op->n, 1)) return;
-         if (primme_amd_comm_reduce_scatter(op->comm, stream, op->full, yc, (size_t)op->nLocal, op->dt == HIPK_F64)) return;
-      }
+   const int nb = *blockSize;
+   if (nb <= 0) { *ierr = 0; return; }
+   if (grow(&op->full, &op->full_cap, (size_t)op->n * nb * es)) return;
+   if (!*transpose) {
+      if (primme_amd_comm_allgather_cols(op->comm, stream, x, *ldx, op->full, op->n, (size_t)op->nLocal * es, es, nb)) return;
+      if (hipk_csr_matvec(op->A, stream, op->full, op->n, y, *ldy, nb)) return;
+   } else {
+      if (hipk_csr_matvec(op->At, stream, x, *ldx, op->full, op->n, nb)) return;
+      if (primme_amd_comm_reduce_scatter_cols(op->comm, stream, op->full, op->n, y, *ldy, (size_t)op->nLocal, op->dt == HIPK_F64, nb)) return;
    }
    *ierr = 0;
 }

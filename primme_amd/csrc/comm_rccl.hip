@@ -138,6 +138,28 @@ extern "C" int primme_amd_comm_reduce_scatter(primme_amd_comm *c, void *hip_stre
    return 0;
 }
 
+/* block forms: column c of the send panel (ld_send elements apart) -> column c of the receive panel.
+ * The calls are issued inside one RCCL group, i.e. one launch for the whole block. */
+extern "C" int primme_amd_comm_allgather_cols(primme_amd_comm *c, void *hip_stream, const void *send, int64_t ld_send,
+      void *recv, int64_t ld_recv, size_t bytes_per_rank, size_t elem, int ncols) {
+   NCCL_CHECK(ncclGroupStart());
+   for (int col = 0; col < ncols; col++)
+      NCCL_CHECK(ncclAllGather((const char *)send + (size_t)col * ld_send * elem, (char *)recv + (size_t)col * ld_recv * elem,
+            bytes_per_rank, ncclChar, c->comm, (hipStream_t)hip_stream));
+   NCCL_CHECK(ncclGroupEnd());
+   return 0;
+}
+extern "C" int primme_amd_comm_reduce_scatter_cols(primme_amd_comm *c, void *hip_stream, const void *send, int64_t ld_send,
+      void *recv, int64_t ld_recv, size_t count_per_rank, int is_double, int ncols) {
+   const size_t elem = is_double ? 8 : 4;
+   NCCL_CHECK(ncclGroupStart());
+   for (int col = 0; col < ncols; col++)
+      NCCL_CHECK(ncclReduceScatter((const char *)send + (size_t)col * ld_send * elem, (char *)recv + (size_t)col * ld_recv * elem,
+            count_per_rank, is_double ? ncclDouble : ncclFloat, ncclSum, c->comm, (hipStream_t)hip_stream));
+   NCCL_CHECK(ncclGroupEnd());
+   return 0;
+}
+
 /* globalSumReal with the primme_svds signature (host buffers), same communicator */
 #include "primme_amd_svds.h"
 extern "C" void primme_amd_svds_global_sum(void *sendBuf, void *recvBuf, int *count,

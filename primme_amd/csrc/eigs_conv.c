@@ -7,6 +7,7 @@
  *   pa_prepare_candidates  <- reference src/eigs/main_iter.c:1470-1709
  */
 #include "eigs_solver.h"
+#include "primme_amd_comm.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -306,17 +307,33 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          if (speculate) {
             if ((rc = pa_reduce(s, s->d_fov, nfov, 1, parallel_host ? 0 : 1))) goto out;
             hipk_seg segs[2] = {{s->V, s->ld, basisSize}, {s->evecs, s->ldevecs, nLk}};
-            if ((rc = hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, dstc, s->ld, 1,
-                       s->d_fov + nfov))) goto out;
+            /* with the fused tail the projected vector goes to the scratch column T(:,0): the operator
+             * launch gathers from it while it writes the normalised vector into V(:,k) */
+            const int fuse_tail = speculate2 && wtr && s->nT >= 1 && p->matrixMatvec == primme_amd_matvec && p->matrix &&
+                                  s->ld == s->m && primme_amd_operator_can_fuse((const primme_amd_operator *)p->matrix) &&
+                                  hipk_csr_dtype(primme_amd_operator_matrix((primme_amd_operator *)p->matrix)) == s->dt;
+            s->spec_fused = 0;
+            if ((rc = hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, dstc, s->ld,
+                       fuse_tail ? TCOL(s, 0) : dstc, s->ld, 1, s->d_fov + nfov))) goto out;
             if (speculate2) {
                if ((rc = pa_reduce(s, s->d_fov + nfov, 1, 1, 1))) goto out;
-               if ((rc = hipk_scale_cols_rsqrt_dev(s->ctx, s->dt, s->m, dstc, s->ld, 1, s->d_fov + nfov))) goto out;
-               int one = 1, ierr = 0;
-               PRIMME_INT ldx = s->ld;
-               p->matrixMatvec(dstc, &ldx, WCOL(s, basisSize), &ldx, &one, p, &ierr);
-               if (ierr) { rc = PRIMME_USER_FAILURE; goto out; }
+               if (fuse_tail) {
+                  /* the library's own operator: normalisation, A t and t'At in one launch, reading the
+                   * un-normalised vector from the scratch column and rebuilding V(:,k) on the way */
+                  void *st = hipk_ctx_stream(s->ctx);
+                  rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, st, TCOL(s, 0), s->d_fov + nfov, dstc,
+                        WCOL(s, basisSize), s->d_red);
+                  if (rc) { rc = rc < 0 ? rc : PRIMME_USER_FAILURE; goto out; }
+                  s->spec_fused = 1;
+               } else {
+                  if ((rc = hipk_scale_cols_rsqrt_dev(s->ctx, s->dt, s->m, dstc, s->ld, 1, s->d_fov + nfov))) goto out;
+                  int one = 1, ierr = 0;
+                  PRIMME_INT ldx = s->ld;
+                  p->matrixMatvec(dstc, &ldx, WCOL(s, basisSize), &ldx, &one, p, &ierr);
+                  if (ierr) { rc = PRIMME_USER_FAILURE; goto out; }
+               }
                if (wtr) {
-                  if ((rc = hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red))) goto out;
+                  if (!fuse_tail && (rc = hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red))) goto out;
                   if ((rc = pa_reduce(s, s->d_red, 1, 0, 0))) goto out;                 /* the one synchronisation */
                   const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
                   const double inv = 1.0 / sqrt(s->h_fov[nfov]);

@@ -225,6 +225,10 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
           * first pass is the last one */
          const int tail_done = speculated && s->spec2_valid && s->spec2_k == i && b1 == b2;
          if (!tail_done) s->spec2_valid = 0;
+         /* fused tail (eigs_conv.c): v holds the NORMALISED vector, the projected un-normalised one is in
+          * T(:,0); whenever the tail is not accepted as it stands it goes back into v first */
+         const int fused_pending = speculated && s->spec_fused;
+         s->spec_fused = 0;
 
          if (updateR)
             for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += hbase[i + j];
@@ -236,10 +240,14 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
             nOrth = maxNumOrthos;             /* lost all significant digits: randomise */
          } else if (s1 <= tol * s0) {
             s0 = s1; s02 = s12;               /* another pass */
+            if (fused_pending) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, v, ldV, 1));
          } else {
             double inv = 1.0 / s1;
             if (isfinite(inv)) {
-               if (!tail_done) CHK(hipk_scale_cols(s->ctx, s->dt, s->m, v, ldV, 1, &inv));
+               if (!tail_done) {
+                  if (fused_pending) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, v, ldV, 1));
+                  CHK(hipk_scale_cols(s->ctx, s->dt, s->m, v, ldV, 1, &inv));
+               }
                break;
             }
             nOrth = maxNumOrthos;

@@ -86,6 +86,8 @@ typedef struct pa_solver {
    double *wtq;            /* G = W'Q for the first wtq_rows basis vectors (K x HIPK_WTR_MAX_K, host) */
    int wtq_rows, wtq_L;    /* -1: not valid */
    int spec2_valid, spec2_k;
+   int spec_fused;         /* the tail ran through the fused operator launch: the projected, un-normalised
+                              vector sits in T(:,0), V(:,k) already holds the normalised one */
    double *spec_hcol;      /* K+1 entries: V(:,0:k+1)' W(:,k) */
    int parallel;           /* reductions cross ranks (numProcs > 1 and a globalSumReal installed) */
    int fuse_gd;            /* GD without preconditioner/Olsen: residual written straight into V */

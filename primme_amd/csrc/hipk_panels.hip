@@ -283,8 +283,8 @@ extern "C" int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hi
 #define PROJ_MAXCOLS 192
 template <typename T, int NX, int VW>
 __global__ void __launch_bounds__(HIPK_BLOCK)
-project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__restrict__ X,
-      int64_t ldX, int nx, int c0, int64_t m, double *__restrict__ partials) {
+project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *X,
+      int64_t ldX, T *Xout, int64_t ldXout, int nx, int c0, int64_t m, double *__restrict__ partials) {
    typedef lanevec<T, VW> LV;
    __shared__ double scoef[PROJ_MAXCOLS * NX];
    __shared__ const T *sptr[PROJ_MAXCOLS];
@@ -298,6 +298,7 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__r
    __syncthreads();
 
    T *xp = X + (size_t)c0 * (size_t)ldX;
+   T *op = Xout + (size_t)c0 * (size_t)ldXout;      /* == xp for the in-place form */
    double n2[NX];
 #pragma unroll
    for (int c = 0; c < NX; c++) n2[c] = 0.0;
@@ -349,7 +350,7 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__r
                o.e[r] = (T)xv[c][r];
                n2[c] = fma((double)o.e[r], (double)o.e[r], n2[c]);
             }
-            ((LV *)(xp + (size_t)c * ldX))[g] = o;
+            ((LV *)(op + (size_t)c * ldXout))[g] = o;
          }
    }
    if (VW > 1 && blockIdx.x == 0 && threadIdx.x < (unsigned)(m - mg * VW)) {   /* ragged tail rows */
@@ -358,7 +359,7 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__r
          double v = (double)xp[i + (size_t)c * ldX];
          for (int j = 0; j < total; j++) v = fma(-(double)sptr[j][i], scoef[j * NX + c], v);
          T o = (T)v;
-         xp[i + (size_t)c * ldX] = o;
+         op[i + (size_t)c * ldXout] = o;
 #pragma unroll
          for (int cc = 0; cc < NX; cc++) if (cc == c) n2[cc] = fma((double)o, (double)o, n2[cc]);
       }
@@ -380,7 +381,7 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__r
 
 template <typename T, int VW>
 static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const double *coef,
-      int ldcoef, T *X, int64_t ldX, int nx, double *nrm2_dev) {
+      int ldcoef, T *X, int64_t ldX, T *Xout, int64_t ldXout, int nx, double *nrm2_dev) {
    int gx = hipk_grid_for_rows(ctx, m / VW + 1, HIPK_BLOCK * 2, 4);
    if (nrm2_dev && hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
    double *part = nrm2_dev ? ctx->partials : NULL;
@@ -389,10 +390,10 @@ static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
    for (int c0 = 0; c0 < nx;) {
       int rem = nx - c0;
       int step;
-      if (rem >= 8) { step = 8; hipLaunchKernelGGL((project_kernel<T, 8, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
-      else if (rem >= 4) { step = 4; hipLaunchKernelGGL((project_kernel<T, 4, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
-      else if (rem >= 2) { step = 2; hipLaunchKernelGGL((project_kernel<T, 2, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
-      else { step = 1; hipLaunchKernelGGL((project_kernel<T, 1, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, nx, c0, m, part); }
+      if (rem >= 8) { step = 8; hipLaunchKernelGGL((project_kernel<T, 8, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part); }
+      else if (rem >= 4) { step = 4; hipLaunchKernelGGL((project_kernel<T, 4, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part); }
+      else if (rem >= 2) { step = 2; hipLaunchKernelGGL((project_kernel<T, 2, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part); }
+      else { step = 1; hipLaunchKernelGGL((project_kernel<T, 1, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part); }
       HIPK_CHECK(hipGetLastError());
       c0 += step;
    }
@@ -403,22 +404,23 @@ static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
 
 template <typename T>
 static int panel_project_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const double *coef,
-      int ldcoef, T *X, int64_t ldX, int nx, double *nrm2_dev) {
+      int ldcoef, T *X, int64_t ldX, T *Xout, int64_t ldXout, int nx, double *nrm2_dev) {
    if (sa.total > PROJ_MAXCOLS) return -1;
-   if (segs_aligned16(sa, sizeof(T)) && aligned16(X, ldX, sizeof(T)))
-      return panel_project_v<T, vecwidth<T>::value>(ctx, m, sa, coef, ldcoef, X, ldX, nx, nrm2_dev);
-   return panel_project_v<T, 1>(ctx, m, sa, coef, ldcoef, X, ldX, nx, nrm2_dev);
+   if (segs_aligned16(sa, sizeof(T)) && aligned16(X, ldX, sizeof(T)) && aligned16(Xout, ldXout, sizeof(T)))
+      return panel_project_v<T, vecwidth<T>::value>(ctx, m, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, nrm2_dev);
+   return panel_project_v<T, 1>(ctx, m, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, nrm2_dev);
 }
 
-extern "C" int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs,
-      int nseg, const double *coef_dev, int ldcoef, void *X, int64_t ldX, int nx,
-      double *nrm2_dev) {
+extern "C" int hipk_panel_project_to(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs,
+      int nseg, const double *coef_dev, int ldcoef, const void *X, int64_t ldX, void *Xout, int64_t ldXout,
+      int nx, double *nrm2_dev) {
    SegArgs sa;
    if (pack_segs(segs, nseg, &sa)) return -1;
    if (nx <= 0) return 0;
    if (sa.total > PROJ_MAXCOLS) {
       /* more columns than one launch stages in LDS: project window by window (the operation
-       * is a sum over columns); the norms come from the last window */
+       * is a sum over columns); the first window reads X, the later ones update Xout in place;
+       * the norms come from the last window */
       const size_t es = (dt == HIPK_F64) ? 8 : 4;
       for (int w0 = 0; w0 < sa.total; w0 += PROJ_MAXCOLS) {
          const int wn = sa.total - w0 < PROJ_MAXCOLS ? sa.total - w0 : PROJ_MAXCOLS;
@@ -432,17 +434,23 @@ extern "C" int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const
             }
             c += sa.n[q];
          }
-         int rc = hipk_panel_project(ctx, dt, m, sub, ns, coef_dev + w0, ldcoef, X, ldX, nx,
-               (w0 + wn >= sa.total) ? nrm2_dev : NULL);
+         int rc = hipk_panel_project_to(ctx, dt, m, sub, ns, coef_dev + w0, ldcoef, w0 == 0 ? X : Xout, w0 == 0 ? ldX : ldXout,
+               Xout, ldXout, nx, (w0 + wn >= sa.total) ? nrm2_dev : NULL);
          if (rc) return rc;
       }
       return 0;
    }
    switch (dt) {
-   case HIPK_F64: return panel_project_t<double>(ctx, m, sa, coef_dev, ldcoef, (double *)X, ldX, nx, nrm2_dev);
-   case HIPK_F32: return panel_project_t<float>(ctx, m, sa, coef_dev, ldcoef, (float *)X, ldX, nx, nrm2_dev);
+   case HIPK_F64: return panel_project_t<double>(ctx, m, sa, coef_dev, ldcoef, (double *)X, ldX, (double *)Xout, ldXout, nx, nrm2_dev);
+   case HIPK_F32: return panel_project_t<float>(ctx, m, sa, coef_dev, ldcoef, (float *)X, ldX, (float *)Xout, ldXout, nx, nrm2_dev);
    default: return -44;
    }
+}
+
+extern "C" int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs,
+      int nseg, const double *coef_dev, int ldcoef, void *X, int64_t ldX, int nx,
+      double *nrm2_dev) {
+   return hipk_panel_project_to(ctx, dt, m, segs, nseg, coef_dev, ldcoef, X, ldX, X, ldX, nx, nrm2_dev);
 }
 
 /* ================= fused Ritz / residual / restart update ===================== */
@@ -753,7 +761,7 @@ template <typename T, int CPW, int QPW, int VW, bool WT>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
       HCol hcol, double theta, T *__restrict__ dst, const T *__restrict__ Q,
-      int64_t ldQ, int L, int64_t m, double *__restrict__ partials) {
+      int64_t ldQ, int L, int64_t m, double *__restrict__ partials, int blocked) {
    typedef lanevec<T, VW> LV;
    constexpr int QN = QPW > 0 ? QPW : 1;
    __shared__ double sxy[2][2][VW][4][64];       /* [buffer][x|y][row in lane][wave][lane] */
@@ -784,7 +792,13 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
 
    const int64_t ngroups = m / (64 * VW);         /* full steps of 64*VW rows */
    int buf = 0;
-   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x, buf ^= 1) {
+   /* blocked: each workgroup walks one contiguous range of rows (sequential DRAM pages per column
+    * stream) instead of striding through the panel with the whole grid */
+   const int64_t gpb = (ngroups + gridDim.x - 1) / gridDim.x;
+   const int64_t gbeg = blocked ? (int64_t)blockIdx.x * gpb : blockIdx.x;
+   const int64_t gend = blocked ? (gbeg + gpb < ngroups ? gbeg + gpb : ngroups) : ngroups;
+   const int64_t gstep = blocked ? 1 : gridDim.x;
+   for (int64_t g = gbeg; g < gend; g += gstep, buf ^= 1) {
       const int64_t e = g * 64 + lane;            /* index in LV units */
       LV v[CPW], w[CPW], q[QN], wl;
 #pragma unroll
@@ -909,11 +923,17 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
    { const double t = hipk_wave_sum(n2); if (lane == 0 && wv == 0) prow[k + L] = t; }
 }
 
+static int rcgs_blocked(void) {               /* HIPK_RCGS_BLOCKED: measurement knob, read once */
+   static int v = -1;
+   if (v < 0) { const char *env = getenv("HIPK_RCGS_BLOCKED"); v = env ? atoi(env) : 0; }
+   return v;
+}
+
 template <typename T, int CPW, int VW, bool WT>
 static int ritz_cgs_q(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
       double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m) {
    dim3 g(gx), b(HIPK_BLOCK);
-#define RCGS(QPWV) hipLaunchKernelGGL((ritz_cgs_kernel<T, CPW, QPWV, VW, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials)
+#define RCGS(QPWV) hipLaunchKernelGGL((ritz_cgs_kernel<T, CPW, QPWV, VW, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials, rcgs_blocked())
    if (L == 0) RCGS(0);
    else if (L <= 8) RCGS(2);
    else if (L <= 16) RCGS(4);

@@ -30,21 +30,25 @@ struct hipk_csr {
    int32_t *rowptr, *colind;   /* device */
    void *values;               /* device */
    int32_t *tiles;             /* device: ntiles+1 row offsets */
+   int4 *tileinfo;             /* device: {first row, end row, first nonzero, end nonzero} per tile */
    int ntiles;
    void *diag;                 /* device, nrows elements */
    int64_t halo_lo, halo_hi;   /* extent of off-rank columns below / above */
    const void *xlo, *xhi;      /* device halo buffers for the current matvec */
+   int64_t ld_lo, ld_hi;       /* their column strides (default: halo_lo / halo_hi, packed) */
    int sx, sy, sz;             /* stencil grid */
 };
 
-/* x element for global column g: owned slab, or the lo / hi halo buffers */
+/* x element for global column g: owned slab, or the lo / hi halo buffers.  The address is
+ * selected, the load itself is unconditional (a branch per gather would serialise the gathers). */
 template <typename T>
 __device__ __forceinline__ double fetch_x(const T *__restrict__ x, const T *__restrict__ xlo,
       const T *__restrict__ xhi, int64_t row0, int64_t nrows, int64_t halo_lo, int64_t g) {
-   int64_t l = g - row0;
-   if (l >= 0 && l < nrows) return (double)x[l];
-   if (l < 0) return (double)xlo[l + halo_lo];
-   return (double)xhi[l - nrows];
+   const int64_t l = g - row0;
+   const T *p = x + l;
+   if (l < 0) p = xlo + (l + halo_lo);
+   if (l >= nrows) p = xhi + (l - nrows);
+   return (double)*p;
 }
 
 /* XCD-aware tile order: block b -> tile ((b % 8) * per + b / 8) so that each XCD
@@ -54,56 +58,113 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
    return (b & 7) * per + (b >> 3);
 }
 
-template <typename T>
+#define TILE_PER_LANE (TILE_NNZ / HIPK_BLOCK)   /* nonzeros a lane handles per tile */
+
+/* CSR-stream, one column at a time.  The chain of dependent memory round trips per tile is what
+ * bounds this kernel, not the bytes: {r0,r1,p0,p1} come in one 16-byte load, a lane then issues
+ * ALL of its (value, column) loads of the tile before the first gather (indices clamped instead
+ * of predicated, so nothing branches around a load), all gathers before the first product, and
+ * the row pointers of the summing phase are fetched before the barrier.
+ * FUSED (one column): the input is the un-normalised new basis vector t and |t|^2 sits in HBM
+ * (norm2[0]); a = 1/sqrt(|t|^2) is applied to every gathered entry on the fly, the normalised
+ * vector is written to xout for the rows this tile owns (xout != x: other tiles still gather from
+ * x), and the tile's part of xout' y goes to partials[blockIdx.x].  Replaces the separate
+ * normalisation pass and the two-vector inner product t'At of the one-synchronisation GD
+ * iteration (eigs_conv.c); same arithmetic per element as scale_rsqrt_kernel + this kernel. */
+template <typename T, bool FUSED>
 __global__ void __launch_bounds__(HIPK_BLOCK)
-csr_stream_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ rowptr,
+csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *__restrict__ rowptr,
       const int32_t *__restrict__ colind, const T *__restrict__ val, const T *__restrict__ x,
       int64_t ldx, T *__restrict__ y, int64_t ldy, int ncols, int64_t row0, int64_t nrows,
-      int64_t halo_lo, int64_t halo_hi, const T *__restrict__ xlo, const T *__restrict__ xhi) {
+      int64_t halo_lo, int64_t halo_hi, const T *__restrict__ xlo, const T *__restrict__ xhi,
+      int64_t ld_lo, int64_t ld_hi, const double *__restrict__ norm2, T *__restrict__ xout,
+      double *__restrict__ partials) {
    __shared__ double prod[TILE_NNZ];
    const int tile = xcd_tile(blockIdx.x, ntiles);
-   if (tile >= ntiles) return;
-   const int r0 = tiles[tile], r1 = tiles[tile + 1];
-   const int p0 = rowptr[r0], p1 = rowptr[r1];
-   const int nz = p1 - p0;
-
-   if (nz <= TILE_NNZ) {
-      for (int c = 0; c < ncols; c++) {
-         const T *xc = x + (size_t)c * ldx;
-         const T *xloc = xlo ? xlo + (size_t)c * halo_lo : NULL;
-         const T *xhic = xhi ? xhi + (size_t)c * halo_hi : NULL;
-         for (int q = threadIdx.x; q < nz; q += HIPK_BLOCK)
-            prod[q] = (double)val[p0 + q] *
-                      fetch_x<T>(xc, xloc, xhic, row0, nrows, halo_lo, (int64_t)colind[p0 + q]);
-         __syncthreads();
+   double dotp = 0.0;
+   if (tile < ntiles) {
+      const int4 ti = tileinfo[tile];
+      const int r0 = ti.x, r1 = ti.y, p0 = ti.z, nz = ti.w - ti.z;
+      const bool local = (halo_lo == 0 && halo_hi == 0);
+      const double a = FUSED ? 1.0 / sqrt(norm2[0]) : 1.0;
+      if (nz <= TILE_NNZ) {
+         /* row segment of this lane's row: fetched now, used after the barrier */
          const int r = r0 + threadIdx.x;
-         if (r < r1) {
-            const int a = rowptr[r] - p0, b = rowptr[r + 1] - p0;
-            double s = 0.0;
-            for (int q = a; q < b; q++) s += prod[q];
-            y[r + (size_t)c * ldy] = (T)s;
+         const int rc = r < r1 ? r : r1 - 1;
+         const int sa = rowptr[rc] - p0, sb = rowptr[rc + 1] - p0;
+         /* the tile's (value, column) pairs: all loads in flight at once */
+         double v[TILE_PER_LANE];
+         int32_t cidx[TILE_PER_LANE];
+#pragma unroll
+         for (int u = 0; u < TILE_PER_LANE; u++) {
+            const int q = threadIdx.x + u * HIPK_BLOCK;
+            const int qc = q < nz ? q : nz - 1;
+            v[u] = (double)val[p0 + qc];
+            cidx[u] = colind[p0 + qc];
          }
-         __syncthreads();
-      }
-   } else {
-      /* a tile that is one long row: the whole workgroup reduces it */
-      for (int c = 0; c < ncols; c++) {
-         const T *xc = x + (size_t)c * ldx;
-         const T *xloc = xlo ? xlo + (size_t)c * halo_lo : NULL;
-         const T *xhic = xhi ? xhi + (size_t)c * halo_hi : NULL;
-         for (int r = r0; r < r1; r++) {
-            const int a = rowptr[r], b = rowptr[r + 1];
-            double s = 0.0;
-            for (int q = a + threadIdx.x; q < b; q += HIPK_BLOCK)
-               s = fma((double)val[q],
-                     fetch_x<T>(xc, xloc, xhic, row0, nrows, halo_lo, (int64_t)colind[q]), s);
-            s = hipk_wave_sum(s);
-            if ((threadIdx.x & 63) == 0) prod[threadIdx.x >> 6] = s;
+         for (int c = 0; c < ncols; c++) {
+            const T *xc = x + (size_t)c * ldx;
+            const T *xloc = xlo ? xlo + (size_t)c * ld_lo : xc;
+            const T *xhic = xhi ? xhi + (size_t)c * ld_hi : xc;
+            double xg[TILE_PER_LANE];
+            if (local) {
+#pragma unroll
+               for (int u = 0; u < TILE_PER_LANE; u++) xg[u] = (double)xc[(int64_t)cidx[u] - row0];
+            } else {
+#pragma unroll
+               for (int u = 0; u < TILE_PER_LANE; u++) xg[u] = fetch_x<T>(xc, xloc, xhic, row0, nrows, halo_lo, (int64_t)cidx[u]);
+            }
+            double xown = 0.0;
+            if (FUSED && r < r1) xown = (double)(T)(a * (double)xc[r]);    /* rows are local entries: r indexes the slab */
+#pragma unroll
+            for (int u = 0; u < TILE_PER_LANE; u++) {
+               const int q = threadIdx.x + u * HIPK_BLOCK;
+               const double xv = FUSED ? (double)(T)(a * xg[u]) : xg[u];
+               if (q < nz) prod[q] = v[u] * xv;
+            }
             __syncthreads();
-            if (threadIdx.x == 0) y[r + (size_t)c * ldy] = (T)((prod[0] + prod[1]) + (prod[2] + prod[3]));
-            __syncthreads();
+            if (r < r1) {
+               double s = 0.0;
+               for (int q = sa; q < sb; q++) s += prod[q];
+               const T yt = (T)s;
+               y[r + (size_t)c * ldy] = yt;
+               if (FUSED) { xout[r] = (T)xown; dotp = fma(xown, (double)yt, dotp); }
+            }
+            if (c + 1 < ncols) __syncthreads();
+         }
+      } else {
+         /* a tile that is one long row: the whole workgroup reduces it */
+         for (int c = 0; c < ncols; c++) {
+            const T *xc = x + (size_t)c * ldx;
+            const T *xloc = xlo ? xlo + (size_t)c * ld_lo : xc;
+            const T *xhic = xhi ? xhi + (size_t)c * ld_hi : xc;
+            for (int r = r0; r < r1; r++) {
+               const int qa = rowptr[r], qb = rowptr[r + 1];
+               double s = 0.0;
+               for (int q = qa + threadIdx.x; q < qb; q += HIPK_BLOCK) {
+                  const double xg = fetch_x<T>(xc, xloc, xhic, row0, nrows, halo_lo, (int64_t)colind[q]);
+                  s = fma((double)val[q], FUSED ? (double)(T)(a * xg) : xg, s);
+               }
+               s = hipk_wave_sum(s);
+               if ((threadIdx.x & 63) == 0) prod[threadIdx.x >> 6] = s;
+               __syncthreads();
+               if (threadIdx.x == 0) {
+                  const T yt = (T)((prod[0] + prod[1]) + (prod[2] + prod[3]));
+                  y[r + (size_t)c * ldy] = yt;
+                  if (FUSED) { const T xo = (T)(a * (double)xc[r]); xout[r] = xo; dotp = fma((double)xo, (double)yt, dotp); }
+               }
+               __syncthreads();
+            }
          }
       }
+   }
+   if (FUSED) {
+      __shared__ double red[HIPK_BLOCK / HIPK_WAVE];
+      __syncthreads();
+      const double t = hipk_wave_sum(dotp);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+      __syncthreads();
+      if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
    }
 }
 
@@ -117,7 +178,8 @@ __global__ void __launch_bounds__(HIPK_BLOCK)
 csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ rowptr,
       const int32_t *__restrict__ colind, const T *__restrict__ val, const T *__restrict__ x,
       int64_t ldx, T *__restrict__ y, int64_t ldy, int ncols, int64_t row0, int64_t nrows,
-      int64_t halo_lo, int64_t halo_hi, const T *__restrict__ xlo, const T *__restrict__ xhi) {
+      int64_t halo_lo, int64_t halo_hi, const T *__restrict__ xlo, const T *__restrict__ xhi,
+      int64_t ld_lo, int64_t ld_hi) {
    __shared__ T sval[TILE_NNZ];
    __shared__ int32_t scol[TILE_NNZ];
    __shared__ int rp[TILE_ROWS + 1];
@@ -167,8 +229,8 @@ csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32
 #pragma unroll
                for (int c = 0; c < NC; c++)
                   if (c0 + c < ncols)
-                     acc[c] = fma(v, fetch_x<T>(x + (size_t)(c0 + c) * ldx, xlo ? xlo + (size_t)(c0 + c) * halo_lo : NULL,
-                                                 xhi ? xhi + (size_t)(c0 + c) * halo_hi : NULL, row0, nrows, halo_lo, gcol), acc[c]);
+                     acc[c] = fma(v, fetch_x<T>(x + (size_t)(c0 + c) * ldx, xlo ? xlo + (size_t)(c0 + c) * ld_lo : x,
+                                                 xhi ? xhi + (size_t)(c0 + c) * ld_hi : x, row0, nrows, halo_lo, gcol), acc[c]);
             }
          }
 #pragma unroll
@@ -179,8 +241,8 @@ csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32
       __shared__ double red[HIPK_BLOCK / HIPK_WAVE];
       for (int c = 0; c < ncols; c++) {
          const T *xc = x + (size_t)c * ldx;
-         const T *xloc = xlo ? xlo + (size_t)c * halo_lo : NULL;
-         const T *xhic = xhi ? xhi + (size_t)c * halo_hi : NULL;
+         const T *xloc = xlo ? xlo + (size_t)c * ld_lo : xc;
+         const T *xhic = xhi ? xhi + (size_t)c * ld_hi : xc;
          for (int r = r0; r < r1; r++) {
             const int a = rowptr[r], b = rowptr[r + 1];
             double sum = 0.0;
@@ -201,14 +263,14 @@ template <typename T>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 stencil_kernel(int sx, int sy, int sz, int64_t row0, int64_t nrows, const T *__restrict__ x,
       int64_t ldx, T *__restrict__ y, int64_t ldy, int ncols, int64_t halo_lo, int64_t halo_hi,
-      const T *__restrict__ xlo, const T *__restrict__ xhi) {
+      const T *__restrict__ xlo, const T *__restrict__ xhi, int64_t ld_lo, int64_t ld_hi) {
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
    const int64_t plane = (int64_t)sx * sy;
    const double dg = (sz > 1) ? 6.0 : (sy > 1 ? 4.0 : 2.0);
    for (int c = 0; c < ncols; c++) {
       const T *xc = x + (size_t)c * ldx;
-      const T *xloc = xlo ? xlo + (size_t)c * halo_lo : NULL;
-      const T *xhic = xhi ? xhi + (size_t)c * halo_hi : NULL;
+      const T *xloc = xlo ? xlo + (size_t)c * ld_lo : xc;
+      const T *xhic = xhi ? xhi + (size_t)c * ld_hi : xc;
       T *yc = y + (size_t)c * ldy;
       for (int64_t l = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; l < nrows; l += stride) {
          const int64_t g = row0 + l;
@@ -300,19 +362,25 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
          if (g >= x0 + xlen && g - (x0 + xlen) + 1 > hi) hi = g - (x0 + xlen) + 1;
          if (g == row0 + i) memcpy(&dg[(size_t)i * es], (const char *)values_host + (size_t)p * es, es);
       }
-   A->halo_lo = lo; A->halo_hi = hi;
+   A->halo_lo = lo; A->halo_hi = hi; A->ld_lo = lo; A->ld_hi = hi;
    A->ntiles = (int)tiles.size() - 1;
+   std::vector<int4> tinfo((size_t)A->ntiles + 1);
+   for (int t = 0; t < A->ntiles; t++) tinfo[t] = make_int4(tiles[t], tiles[t + 1], rowptr_host[tiles[t]], rowptr_host[tiles[t + 1]]);
 
    if (hipk_malloc(ctx, (size_t)(nrows_local + 1) * 4, (void **)&A->rowptr) ||
-         hipk_malloc(ctx, (size_t)nnz * 4, (void **)&A->colind) ||
-         hipk_malloc(ctx, (size_t)nnz * es, &A->values) ||
+         hipk_malloc(ctx, (size_t)(nnz + 1) * 4, (void **)&A->colind) ||       /* +1: clamped loads of an empty tile */
+         hipk_malloc(ctx, (size_t)(nnz + 1) * es, &A->values) ||
          hipk_malloc(ctx, tiles.size() * 4, (void **)&A->tiles) ||
+         hipk_malloc(ctx, tinfo.size() * sizeof(int4), (void **)&A->tileinfo) ||
          hipk_malloc(ctx, (size_t)nrows_local * es, &A->diag))
       return -2;
    HIPK_CHECK(hipMemcpy(A->rowptr, rowptr_host, (size_t)(nrows_local + 1) * 4, hipMemcpyHostToDevice));
    HIPK_CHECK(hipMemcpy(A->colind, colind_host, (size_t)nnz * 4, hipMemcpyHostToDevice));
    HIPK_CHECK(hipMemcpy(A->values, values_host, (size_t)nnz * es, hipMemcpyHostToDevice));
    HIPK_CHECK(hipMemcpy(A->tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+   HIPK_CHECK(hipMemcpy(A->tileinfo, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice));
+   HIPK_CHECK(hipMemset((char *)A->colind + (size_t)nnz * 4, 0, 4));
+   HIPK_CHECK(hipMemset((char *)A->values + (size_t)nnz * es, 0, es));
    HIPK_CHECK(hipMemcpy(A->diag, dg.data(), (size_t)nrows_local * es, hipMemcpyHostToDevice));
    *out = A;
    return 0;
@@ -346,6 +414,7 @@ extern "C" int hipk_stencil_create(hipk_ctx *ctx, hipk_dtype dt, int nx, int ny,
    A->halo_lo = row0 > 0 ? (reach < row0 ? reach : row0) : 0;
    const int64_t above = n - (row0 + nrows_local);
    A->halo_hi = above > 0 ? (reach < above ? reach : above) : 0;
+   A->ld_lo = A->halo_lo; A->ld_hi = A->halo_hi;
    const size_t es = elem_size(dt);
    if (hipk_malloc(ctx, (size_t)nrows_local * es, &A->diag)) return -2;
    int gx = hipk_grid_for_rows(ctx, nrows_local, HIPK_BLOCK * 4, 8);
@@ -365,6 +434,7 @@ extern "C" int hipk_csr_destroy(hipk_csr *A) {
    if (A->colind) (void)hipFree(A->colind);
    if (A->values) (void)hipFree(A->values);
    if (A->tiles) (void)hipFree(A->tiles);
+   if (A->tileinfo) (void)hipFree(A->tileinfo);
    if (A->diag) (void)hipFree(A->diag);
    free(A);
    return 0;
@@ -375,7 +445,11 @@ extern "C" int64_t hipk_csr_nnz(const hipk_csr *A) { return A->nnz; }
 extern "C" int64_t hipk_csr_halo_lo(const hipk_csr *A) { return A->halo_lo; }
 extern "C" int64_t hipk_csr_halo_hi(const hipk_csr *A) { return A->halo_hi; }
 extern "C" int hipk_csr_set_halo(hipk_csr *A, const void *lo, const void *hi) {
-   A->xlo = lo; A->xhi = hi;
+   A->xlo = lo; A->xhi = hi; A->ld_lo = A->halo_lo; A->ld_hi = A->halo_hi;
+   return 0;
+}
+extern "C" int hipk_csr_set_halo_ld(hipk_csr *A, const void *lo, int64_t ld_lo, const void *hi, int64_t ld_hi) {
+   A->xlo = lo; A->xhi = hi; A->ld_lo = ld_lo; A->ld_hi = ld_hi;
    return 0;
 }
 
@@ -394,19 +468,19 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
       int gx = hipk_grid_for_rows(ctx, A->nrows, HIPK_BLOCK, 8);
       hipLaunchKernelGGL(stencil_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->sx,
             A->sy, A->sz, A->row0, A->nrows, x, ldx, y, ldy, ncols, A->halo_lo, A->halo_hi,
-            (const T *)A->xlo, (const T *)A->xhi);
+            (const T *)A->xlo, (const T *)A->xhi, A->ld_lo, A->ld_hi);
    } else {
       int gx = ((A->ntiles + 7) / 8) * 8;
 #define LAUNCH_ROWS(NCV) hipLaunchKernelGGL((csr_rows_block_kernel<T, NCV>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, \
                A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, \
-               ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo, (const T *)A->xhi)
+               ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo, (const T *)A->xhi, A->ld_lo, A->ld_hi)
       static int force = -1;                     /* HIPK_SPMM_NC: measurement knob, read once */
       if (force < 0) { const char *env = getenv("HIPK_SPMM_NC"); force = env ? atoi(env) : 0; }
       if (ncols == 1 && force == 0)
-         hipLaunchKernelGGL(csr_stream_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, stream,
-               A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
+         hipLaunchKernelGGL((csr_stream_kernel<T, false>), dim3(gx), dim3(HIPK_BLOCK), 0, stream,
+               A->tileinfo, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
                ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo,
-               (const T *)A->xhi);
+               (const T *)A->xhi, A->ld_lo, A->ld_hi, (const double *)NULL, (T *)NULL, (double *)NULL);
       else if (force == 1) LAUNCH_ROWS(1);
       else if (force == 2 || (force == 0 && ncols <= 2)) LAUNCH_ROWS(2);
       else LAUNCH_ROWS(4);
@@ -424,6 +498,34 @@ extern "C" int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int
    if (A->dt == HIPK_F64) return csr_matvec_t<double>(A, st, (const double *)x, ldx, (double *)y, ldy, ncols);
    return csr_matvec_t<float>(A, st, (const float *)x, ldx, (float *)y, ldy, ncols);
 }
+
+/* y = A (a x), xout = a x, dot_dev[0] = xout' y with a = 1/sqrt(norm2_dev[0]) — see csr_stream_kernel<T, true>.
+ * One column, CSR operators whose rows and input entries coincide (square, row-partitioned). */
+extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, void *hip_stream, const void *x, const double *norm2_dev,
+      void *xout, void *y, double *dot_dev) {
+   if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout) return -1;
+   hipk_ctx *ctx = A->ctx;
+   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+   if (st != ctx->stream) return -1;          /* the reduction scratch belongs to the context's stream */
+   if ((A->halo_lo > 0 && !A->xlo) || (A->halo_hi > 0 && !A->xhi)) return -1;
+   if (A->nrows == 0) { HIPK_CHECK(hipMemsetAsync(dot_dev, 0, sizeof(double), st)); return 0; }
+   const int gx = ((A->ntiles + 7) / 8) * 8;
+   if (hipk_reserve_partials(ctx, (size_t)gx)) return -2;
+   const double es = A->dt == HIPK_F64 ? 8 : 4;
+   const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
+   if (A->dt == HIPK_F64)
+      hipLaunchKernelGGL((csr_stream_kernel<double, true>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr,
+            A->colind, (const double *)A->values, (const double *)x, A->nrows, (double *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo,
+            A->halo_hi, (const double *)A->xlo, (const double *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (double *)xout, ctx->partials);
+   else
+      hipLaunchKernelGGL((csr_stream_kernel<float, true>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr,
+            A->colind, (const float *)A->values, (const float *)x, A->nrows, (float *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo,
+            A->halo_hi, (const float *)A->xlo, (const float *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (float *)xout, ctx->partials);
+   hipk_prof_end(pslot, st);
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, 1, dot_dev);
+}
+extern "C" int hipk_csr_kind(const hipk_csr *A) { return A->kind; }
 extern "C" hipk_dtype hipk_csr_dtype(const hipk_csr *A) { return A->dt; }
 extern "C" int64_t hipk_csr_nrows(const hipk_csr *A) { return A->nrows; }
 
@@ -434,9 +536,15 @@ extern "C" int hipk_jacobi_apply(void *hip_stream, hipk_dtype dt, int64_t m, con
    if (ncols > 64) return -1;
    JacShift sh;
    for (int c = 0; c < ncols; c++) sh.s[c] = shift_host ? shift_host[c] : 0.0;
-   hipk_ctx fake; fake.num_cu = 256; fake.stream = (hipStream_t)hip_stream;
-   hipk_ctx *ctx = &fake;
-   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
+   static int num_cu = 0;                      /* launch geometry only: read the device once */
+   if (num_cu == 0) {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) num_cu = n;
+      else num_cu = 256;
+   }
+   struct { hipStream_t stream; } ctx_ = {(hipStream_t)hip_stream}, *ctx = &ctx_;
+   int64_t need = (m + HIPK_BLOCK * 4 - 1) / (HIPK_BLOCK * 4);
+   int gx = (int)(need < 1 ? 1 : (need < (int64_t)num_cu * 8 ? need : (int64_t)num_cu * 8));
    if (dt == HIPK_F64)
       hipLaunchKernelGGL(jacobi_kernel<double>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const double *)diag, sh, min_den, (const double *)x, ldx, (double *)y, ldy, ncols, m);
    else if (dt == HIPK_F32)

@@ -296,6 +296,65 @@ def test_csr_matvec(built, dt, ncols):
         assert np.max(np.abs(res[1] - ref)) <= tol * (1 + np.abs(ref).max()), name
 
 
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+def test_csr_matvec_scaled_fused_tail(built, dt):
+    """y = A (a x), xout = a x, dot = xout' y with a = 1/sqrt(norm2) read from device memory: one launch for the
+    normalisation, the operator and t'At of the one-synchronisation iteration; against the oracle and against
+    the separate launches it replaces (same arithmetic per element)."""
+    npdt = NPDT[dt]
+    for name, rp, ci, va, n in _csr_cases():
+        rng = np.random.default_rng(n + 5)
+        X = rng.standard_normal(n).astype(npdt) * 3.0
+        n2 = np.array([float(np.sum(X.astype(np.float64) ** 2))])
+        res = []
+        for side in (Dev(), Host()):
+            A = C.c_void_p()
+            vv = np.ascontiguousarray(va, dtype=npdt)
+            assert side.lib.hipk_csr_create(side.ctx, dt, n, n, 0, rp.ctypes.data_as(C.c_void_p),
+                                            ci.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+            x = side.arr(X); xo = side.arr(np.zeros_like(X)); y = side.arr(np.zeros_like(X))
+            nn = side.arr(n2); dot = side.arr(np.zeros(1))
+            assert side.lib.hipk_csr_matvec_scaled(A, None, side.ptr(x), side.ptr(nn), side.ptr(xo), side.ptr(y), side.ptr(dot)) == 0
+            # the launches it replaces
+            x2 = side.arr(X); y2 = side.arr(np.zeros_like(X))
+            assert side.lib.hipk_scale_cols_rsqrt_dev(side.ctx, dt, n, side.ptr(x2), n, 1, side.ptr(nn)) == 0
+            assert side.lib.hipk_csr_matvec(A, None, side.ptr(x2), n, side.ptr(y2), n, 1) == 0
+            res.append([side.get(t) for t in (xo, y, dot, x2, y2)])
+            side.lib.hipk_csr_destroy(A)
+            side.close()
+        tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+        for a_, b_ in zip(res[0][:2], res[1][:2]):
+            assert np.max(np.abs(a_ - b_)) <= tol * (1 + np.abs(b_).max()), name
+        assert abs(res[0][2][0] - res[1][2][0]) <= tol * np.sqrt(n) * (1 + abs(res[1][2][0])), name
+        assert np.array_equal(res[0][0], res[0][3]), name          # normalised vector: bit-identical to the scale kernel
+        assert np.max(np.abs(res[0][1] - res[0][4])) <= tol * (1 + np.abs(res[0][4]).max()), name
+        assert abs(res[0][2][0] - float(res[0][0].astype(np.float64) @ res[0][1].astype(np.float64))) <= tol * np.sqrt(n) * (1 + abs(res[0][2][0])), name
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+def test_panel_project_out_of_place(built, dt):
+    """Xout = X - [segs] coef with X untouched (the form that leaves the projected vector in a scratch column)"""
+    rng = np.random.default_rng(3)
+    npdt = NPDT[dt]
+    m, ld, k, L = 70003, 70004, 9, 4
+    V = rng.standard_normal((k, ld)).astype(npdt); Q = rng.standard_normal((L, ld)).astype(npdt)
+    X = rng.standard_normal((1, ld)).astype(npdt); coef = rng.standard_normal(k + L)
+    res = []
+    for side in (Dev(), Host()):
+        v, q, x, o = side.arr(V), side.arr(Q), side.arr(X), side.arr(np.zeros_like(X))
+        cf = side.arr(coef); n2 = side.arr(np.zeros(1))
+        segs = segs_array(side, [(v, 0, ld, k), (q, 0, ld, L)])
+        assert side.lib.hipk_panel_project_to(side.ctx, dt, m, segs, 2, side.ptr(cf), k + L, side.ptr(x), ld, side.ptr(o), ld, 1, side.ptr(n2)) == 0
+        res.append((side.get(x), side.get(o), side.get(n2)))
+        side.close()
+    tol = 1e-12 if dt == F.HIPK_F64 else 1e-4
+    ref = X[0, :m].astype(np.float64) - coef[:k] @ V[:, :m].astype(np.float64) - coef[k:] @ Q[:, :m].astype(np.float64)
+    for r in res:
+        assert np.array_equal(r[0], X)
+        assert np.max(np.abs(r[1][0, :m] - ref)) <= tol * 10 * (1 + np.abs(ref).max())
+        assert abs(r[2][0] - np.sum(ref ** 2)) <= tol * 10 * np.sum(ref ** 2)
+
+
 @pytest.mark.parametrize("dims", [(1000,), (123, 77), (31, 29, 37)])
 def test_stencil_matches_csr(built, dims):
     dt = F.HIPK_F64

@@ -172,8 +172,10 @@ def test_launch_structure_block_size_one(built, wtr, monkeypatch):
               v0=problems.start_vector(n))
     lib.hipk_cpu_counts(cnt, 1)
     its, rst = r.stats["numOuterIterations"], r.stats["numRestarts"]
-    dots, project, ritz_cgs = cnt[0], cnt[1], cnt[3]
+    dots, project, ritz_cgs, fused_tail = cnt[0], cnt[1], cnt[3], cnt[5]
     assert r.ret == 0 and its == 490
+    # with the library's own operator the tail of the iteration (normalise, A t, t'At) is ONE launch
+    assert (fused_tail >= its - rst - 15 and fused_tail <= its) if wtr else fused_tail == 0
     assert ritz_cgs >= its - rst - 15 and ritz_cgs <= its
     if not wtr:
         assert dots <= its + rst + 25         # projection pass each iteration + CGS dots after restarts
