@@ -59,7 +59,7 @@ hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op);
  * fused tail of the solver's one-synchronisation iteration (one column; CSR operators).
  * primme_amd_operator_can_fuse tells whether the operator supports it. */
 int primme_amd_operator_can_fuse(const primme_amd_operator *op);
-int primme_amd_operator_apply_scaled(primme_amd_operator *op, void *hip_stream, const void *x,
+int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ctx *ctx /* the caller's context */, const void *x,
       const double *norm2_dev, void *xout, void *y, double *dot_dev);
 /* y = A x on `hip_stream` including the halo exchange */
 int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stream, const void *x, int64_t ldx,

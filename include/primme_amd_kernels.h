@@ -55,6 +55,11 @@ int  hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* asy
 int  hipk_d2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async  */
 int  hipk_memset0(hipk_ctx *ctx, void *dst, size_t bytes);
 int  hipk_sync(hipk_ctx *ctx);
+/* wait for the results of the LAST mirrored reduction enqueued on the context (see
+ * hipk_ctx_set_mirror) without a runtime call: the reduction's second stage publishes a completion
+ * flag in pinned memory and the host spins on it.  Only valid when that reduction was the last thing
+ * enqueued; falls back to hipk_sync otherwise. */
+int  hipk_wait_results(hipk_ctx *ctx);
 /* zero-copy results: every reduction whose output lies in [dev_base, dev_base+count) is also
  * written by the kernel into the pinned host array (same offsets); the host then needs only
  * hipk_sync, no device->host copy (the reference GPU backend does a blocking hipMemcpy per
@@ -191,8 +196,8 @@ int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int64_t ldx, v
       int ncols);
 /* y = A (a x), xout = a x (xout != x), dot_dev[0] = xout' y with a = 1/sqrt(norm2_dev[0]) read from HBM:
  * normalisation (Num_scal, cublas_wrapper.c:678), operator and the inner product t'At in one launch. */
-int hipk_csr_matvec_scaled(hipk_csr *A, void *hip_stream, const void *x, const double *norm2_dev,
-      void *xout, void *y, double *dot_dev);
+int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx /* the caller's: stream, scratch, result mirror */,
+      const void *x, const double *norm2_dev, void *xout, void *y, double *dot_dev);
 int hipk_csr_kind(const hipk_csr *A);    /* 0 CSR, 1 stencil */
 /* diagonal of A (device array of nrows_local elements of dtype) */
 const void *hipk_csr_diag(hipk_csr *A);

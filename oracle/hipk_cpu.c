@@ -77,6 +77,7 @@ static void mirror(const double *out, size_t cnt) {   /* keep the zero-copy cont
       memmove(g_mirror_host + (out - g_mirror_dev), out, cnt * sizeof(double));
 }
 int hipk_is_device_ptr(const void *p) { return p != NULL; }
+int hipk_wait_results(hipk_ctx *ctx) { (void)ctx; return 0; }
 int hipk_timer_start(hipk_ctx *c) { c->t0 = now(); return 0; }
 int hipk_timer_stop(hipk_ctx *c, float *ms) { *ms = (float)((now() - c->t0) * 1e3); return 0; }
 
@@ -390,8 +391,8 @@ int hipk_csr_matvec(hipk_csr *A, void *stream, const void *x, int64_t ldx, void 
 
 /* y = A (a x), xout = a x, dot[0] = xout' y, a = 1/sqrt(norm2[0]): the normalisation, the operator and
  * the two-vector inner product of the one-synchronisation GD iteration in one call */
-int hipk_csr_matvec_scaled(hipk_csr *A, void *stream, const void *x, const double *norm2, void *xout, void *y, double *dot) {
-   (void)stream; g_cnt[5]++;
+int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x, const double *norm2, void *xout, void *y, double *dot) {
+   (void)ctx; g_cnt[5]++;
    if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout) return -1;
    const hipk_dtype dt = A->dt;
    const double a = 1.0 / sqrt(norm2[0]);

@@ -22,10 +22,10 @@ int primme_amd_operator_apply(primme_amd_operator *op, void *st, const void *x, 
    return hipk_csr_matvec(op->A, st, x, ldx, y, ldy, nc);
 }
 int primme_amd_operator_can_fuse(const primme_amd_operator *op) { return op && op->ldscale == 1 && hipk_csr_kind(op->A) == 0; }
-int primme_amd_operator_apply_scaled(primme_amd_operator *op, void *st, const void *x, const double *norm2, void *xout,
+int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ctx *ctx, const void *x, const double *norm2, void *xout,
       void *y, double *dot) {
    if (!primme_amd_operator_can_fuse(op)) return -1;
-   return hipk_csr_matvec_scaled(op->A, st, x, norm2, xout, y, dot);
+   return hipk_csr_matvec_scaled(op->A, ctx, x, norm2, xout, y, dot);
 }
 void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)p->matrix;

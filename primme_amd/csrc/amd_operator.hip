@@ -122,9 +122,10 @@ extern "C" int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stre
 extern "C" int primme_amd_operator_can_fuse(const primme_amd_operator *op) {
    return op && op->ldscale == 1 && hipk_csr_kind(op->A) == 0;
 }
-extern "C" int primme_amd_operator_apply_scaled(primme_amd_operator *op, void *hip_stream, const void *x,
+extern "C" int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ctx *ctx, const void *x,
       const double *norm2_dev, void *xout, void *y, double *dot_dev) {
-   if (!primme_amd_operator_can_fuse(op)) return -1;
+   if (!primme_amd_operator_can_fuse(op) || !ctx) return -1;
+   void *hip_stream = hipk_ctx_stream(ctx);
    const size_t es = op_elem(hipk_csr_dtype(op->A));
    if (op->mode == 1) {
       if (grow(&op->buf_lo, &op->cap_lo, (size_t)(op->lo > 0 ? op->lo : 1) * es)) return -2;
@@ -140,7 +141,7 @@ extern "C" int primme_amd_operator_apply_scaled(primme_amd_operator *op, void *h
       hipk_csr_set_halo(op->A, (const char *)op->xfull + (size_t)(op->row0 - op->lo) * es,
             (const char *)op->xfull + (size_t)(op->row0 + op->nrows) * es);
    }
-   return hipk_csr_matvec_scaled(op->A, hip_stream, x, norm2_dev, xout, y, dot_dev);
+   return hipk_csr_matvec_scaled(op->A, ctx, x, norm2_dev, xout, y, dot_dev);
 }
 
 /* ---- the callbacks ---------------------------------------------------------- */

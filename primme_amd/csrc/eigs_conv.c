@@ -320,8 +320,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
                if (fuse_tail) {
                   /* the library's own operator: normalisation, A t and t'At in one launch, reading the
                    * un-normalised vector from the scratch column and rebuilding V(:,k) on the way */
-                  void *st = hipk_ctx_stream(s->ctx);
-                  rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, st, TCOL(s, 0), s->d_fov + nfov, dstc,
+                  rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, 0), s->d_fov + nfov, dstc,
                         WCOL(s, basisSize), s->d_red);
                   if (rc) { rc = rc < 0 ? rc : PRIMME_USER_FAILURE; goto out; }
                   s->spec_fused = 1;

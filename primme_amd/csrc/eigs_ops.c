@@ -52,7 +52,8 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
          CHK(pa_call_global_sum(p, hb, count));
          if (keep_dev) CHK(hipk_h2d(s->ctx, d_buf, hb, (size_t)count * sizeof(double)));
       } else if (!defer_sync) {
-         CHK(hipk_sync(s->ctx));
+         /* the reduction whose result is wanted was the last launch: wait for its completion flag */
+         CHK(hipk_wait_results(s->ctx));
       }
    }
    if (parallel) {

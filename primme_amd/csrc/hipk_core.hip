@@ -27,6 +27,18 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
    ctx->partials = NULL;
    ctx->partials_cap = 0;
    if (hipk_reserve_partials(ctx, (size_t)1 << 20)) return -2;
+   {
+      void *fh = NULL, *fd = NULL;
+      HIPK_CHECK(hipHostMalloc(&fh, 64, hipHostMallocDefault));
+      memset(fh, 0, 64);
+      HIPK_CHECK(hipHostGetDevicePointer(&fd, fh, 0));
+      ctx->flag_host = (volatile unsigned long long *)fh;
+      ctx->flag_dev = (unsigned long long *)fd;
+      HIPK_CHECK(hipMalloc((void **)&ctx->fin_counter, 64));
+      HIPK_CHECK(hipMemset(ctx->fin_counter, 0, 64));
+      ctx->seq_issued = 0;
+      ctx->spin_wait = getenv("HIPK_NO_SPINWAIT") == NULL;
+   }
    *out = ctx;
    return 0;
 }
@@ -36,6 +48,8 @@ extern "C" int hipk_ctx_destroy(hipk_ctx *ctx) {
    hipStreamSynchronize(ctx->stream);
    if (ctx->partials) (void)hipFree(ctx->partials);
    if (ctx->jobtab) (void)hipFree(ctx->jobtab);
+   if (ctx->fin_counter) (void)hipFree(ctx->fin_counter);
+   if (ctx->flag_host) (void)hipHostFree((void *)ctx->flag_host);
    (void)hipEventDestroy(ctx->ev0);
    (void)hipEventDestroy(ctx->ev1);
    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -99,6 +113,22 @@ extern "C" int hipk_sync(hipk_ctx *ctx) {
    HIPK_CHECK(hipStreamSynchronize(ctx->stream));
    return 0;
 }
+/* Wait until the results of the LAST mirrored reduction enqueued on the context are in the pinned
+ * mirror.  The caller guarantees that reduction was the last thing it enqueued and that it only needs
+ * those results (the stream is in order: everything before it has completed as well).  Spins on the
+ * completion flag the finalize kernel publishes; falls back to a stream synchronisation when no
+ * flagged launch is pending or the flag does not show up in time. */
+extern "C" int hipk_wait_results(hipk_ctx *ctx) {
+   if (ctx->spin_wait && ctx->flag_host && ctx->seq_issued > 0) {
+      const unsigned long long want = ctx->seq_issued;
+      for (long spins = 0; spins < 200000000L; spins++) {
+         if (*ctx->flag_host >= want) return 0;
+         __builtin_ia32_pause();
+      }
+   }
+   HIPK_CHECK(hipStreamSynchronize(ctx->stream));
+   return 0;
+}
 extern "C" int hipk_is_device_ptr(const void *p) {
    hipPointerAttribute_t attr;
    if (!p) return 0;
@@ -122,7 +152,7 @@ extern "C" int hipk_timer_stop(hipk_ctx *ctx, float *ms) {
 /* ---- stage 2 of every reduction: one block per output, fixed summation order -- */
 __global__ void __launch_bounds__(HIPK_BLOCK)
 hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
-      double *__restrict__ out, double *__restrict__ out_host) {
+      double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
    __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
    const int o = blockIdx.x;
    double s = 0.0;
@@ -134,6 +164,7 @@ hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
       const double v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
       out[o] = v;
       if (out_host) out_host[o] = v;
+      hipk_publish_flag(fin, gridDim.x);
    }
 }
 
@@ -141,7 +172,7 @@ int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, i
       double *out_dev) {
    if (nout <= 0) return 0;
    hipLaunchKernelGGL(hipk_finalize_kernel, dim3(nout), dim3(HIPK_BLOCK), 0, ctx->stream,
-         partials, nblocks, nout, out_dev, hipk_mirror_of(ctx, out_dev));
+         partials, nblocks, nout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
    return 0;
 }

@@ -26,6 +26,14 @@ struct hipk_ctx {
    double *mirror_dev, *mirror_host;
    size_t mirror_count;
    void *jobtab;         /* device copy of a large Ritz-update job table (basis sizes > 64) */
+   /* completion flag of the mirrored reductions: the finalize kernels, after their results reached the
+    * pinned mirror, store the launch's sequence number in pinned host memory; hipk_wait_results spins
+    * on it instead of going through hipStreamSynchronize (no runtime call, no interrupt wake-up) */
+   volatile unsigned long long *flag_host;   /* pinned, host address */
+   unsigned long long *flag_dev;             /* the same word, device address */
+   unsigned int *fin_counter;                /* device: blocks of the running finalize launch that are done */
+   unsigned long long seq_issued;            /* sequence number of the last finalize launch with a mirror */
+   int spin_wait;                            /* 0: always hipStreamSynchronize (HIPK_NO_SPINWAIT) */
 };
 
 static inline double *hipk_mirror_of(const hipk_ctx *ctx, const double *out_dev) {
@@ -51,6 +59,14 @@ enum { HIPK_PROF_DOTS = 0, HIPK_PROF_PROJECT = 1, HIPK_PROF_RITZ = 2, HIPK_PROF_
 int hipk_prof_begin(int cls, hipStream_t st, double alg_bytes); /* returns slot or -1 */
 void hipk_prof_end(int slot, hipStream_t st);
 
+/* arguments every finalize kernel takes for the completion flag (all NULL / 0: no flag) */
+struct hipk_fin_flag { unsigned long long *flag; unsigned int *counter; unsigned long long seq; };
+/* next sequence number for a finalize launch whose output lies in the mirror (else an empty record) */
+static inline hipk_fin_flag hipk_next_flag(hipk_ctx *ctx, const double *out_dev) {
+   hipk_fin_flag f = {NULL, NULL, 0};
+   if (ctx->flag_dev && hipk_mirror_of(ctx, out_dev)) { f.flag = ctx->flag_dev; f.counter = ctx->fin_counter; f.seq = ++ctx->seq_issued; }
+   return f;
+}
 /* make sure ctx->partials can hold n doubles */
 int hipk_reserve_partials(hipk_ctx *ctx, size_t n);
 /* out[o] = sum_b partials[b*nout + o], deterministic order */
@@ -70,6 +86,20 @@ static inline int hipk_grid_for_rows(const hipk_ctx *ctx, int64_t m, int rows_pe
 template <typename T> struct hipk_num;
 template <> struct hipk_num<double> { typedef double acc_t; enum { acc_doubles = 1 }; };
 template <> struct hipk_num<float>  { typedef double acc_t; enum { acc_doubles = 1 }; };
+
+/* called by thread 0 of every block of a finalize launch after its mirrored store: the block that
+ * finishes last publishes the sequence number (system-scope fence first: the pinned results must be
+ * visible to the host before the flag) */
+__device__ __forceinline__ void hipk_publish_flag(const hipk_fin_flag &f, unsigned nblocks) {
+   if (!f.flag) return;
+   __threadfence_system();
+   const unsigned t = atomicAdd(f.counter, 1u);
+   if (t == nblocks - 1) {
+      *f.counter = 0;
+      __threadfence_system();
+      *(volatile unsigned long long *)f.flag = f.seq;
+   }
+}
 
 __device__ __forceinline__ double hipk_wave_sum(double v) {
 #pragma unroll

@@ -60,7 +60,7 @@ __device__ __forceinline__ const T *seg_col(const SegArgs &s, int j) {
 /* finalize with an output leading dimension: out[(o % nrows) + (o / nrows)*ldout] */
 __global__ void __launch_bounds__(HIPK_BLOCK)
 finalize_ld_kernel(const double *__restrict__ partials, int nblocks, int nout, int nrows,
-      int ldout, double *__restrict__ out, double *__restrict__ out_host) {
+      int ldout, double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
    __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
    const int o = blockIdx.x;
    double s = 0.0;
@@ -73,6 +73,7 @@ finalize_ld_kernel(const double *__restrict__ partials, int nblocks, int nout, i
       const size_t at = (o % nrows) + (size_t)(o / nrows) * ldout;
       out[at] = v;
       if (out_host) out_host[at] = v;
+      hipk_publish_flag(fin, gridDim.x);
    }
 }
 
@@ -261,7 +262,7 @@ static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X,
    hipk_prof_end(pslot, ctx->stream);
    HIPK_CHECK(hipGetLastError());
    hipLaunchKernelGGL(finalize_ld_kernel, dim3((unsigned)nout), dim3(HIPK_BLOCK), 0, ctx->stream,
-         ctx->partials, gx, (int)nout, sa.total, ldout, out_dev, hipk_mirror_of(ctx, out_dev));
+         ctx->partials, gx, (int)nout, sa.total, ldout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
    return 0;
 }
@@ -964,7 +965,7 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
                     (L == 0 || aligned16(Q, ldQ, sizeof(T)));
    const int rows_per_step = 64 * (vec ? VWT : 1);
    static int bpc = -1;                        /* HIPK_RCGS_BPC: workgroups per CU (measurement knob, read once) */
-   if (bpc < 0) { const char *env = getenv("HIPK_RCGS_BPC"); bpc = env ? atoi(env) : 8; if (bpc < 1) bpc = 8; }
+   if (bpc < 0) { const char *env = getenv("HIPK_RCGS_BPC"); bpc = env ? atoi(env) : 2; if (bpc < 1) bpc = 2; }
    int gx = hipk_grid_for_rows(ctx, m, rows_per_step, bpc);
    const int nout = k + L + 1 + (want_wtr ? k + L : 0);
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;

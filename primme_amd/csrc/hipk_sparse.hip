@@ -501,12 +501,12 @@ extern "C" int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int
 
 /* y = A (a x), xout = a x, dot_dev[0] = xout' y with a = 1/sqrt(norm2_dev[0]) — see csr_stream_kernel<T, true>.
  * One column, CSR operators whose rows and input entries coincide (square, row-partitioned). */
-extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, void *hip_stream, const void *x, const double *norm2_dev,
+extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x, const double *norm2_dev,
       void *xout, void *y, double *dot_dev) {
-   if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout) return -1;
-   hipk_ctx *ctx = A->ctx;
-   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-   if (st != ctx->stream) return -1;          /* the reduction scratch belongs to the context's stream */
+   /* ctx: the CALLER's context (stream, reduction scratch, pinned mirror of the results) — the matrix may
+    * have been created under another one */
+   if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout || !ctx) return -1;
+   hipStream_t st = ctx->stream;
    if ((A->halo_lo > 0 && !A->xlo) || (A->halo_hi > 0 && !A->xhi)) return -1;
    if (A->nrows == 0) { HIPK_CHECK(hipMemsetAsync(dot_dev, 0, sizeof(double), st)); return 0; }
    const int gx = ((A->ntiles + 7) / 8) * 8;

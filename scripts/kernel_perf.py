@@ -50,7 +50,7 @@ A = C.c_void_p()
 assert lib.hipk_csr_create(ctx, dt, n, n, 0, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
 timeit(lambda: lib.hipk_csr_matvec(A, None, V[0].data_ptr(), ld, W[0].data_ptr(), ld, 1), len(va) * 12 + (n + 1) * 4 + 2 * n * 8, "csr spmv 7pt")
 nn = torch.tensor([float(m)], dtype=torch.float64, device="cuda")
-timeit(lambda: lib.hipk_csr_matvec_scaled(A, None, V[0].data_ptr(), nn.data_ptr(), V[1].data_ptr(), W[0].data_ptr(), red.data_ptr()), len(va) * 12 + (n + 1) * 4 + 3 * n * 8, "csr spmv 7pt fused tail (scale + A t + t'At)")
+timeit(lambda: lib.hipk_csr_matvec_scaled(A, ctx, V[0].data_ptr(), nn.data_ptr(), V[1].data_ptr(), W[0].data_ptr(), red.data_ptr()), len(va) * 12 + (n + 1) * 4 + 3 * n * 8, "csr spmv 7pt fused tail (scale + A t + t'At)")
 S = C.c_void_p(); lib.hipk_stencil_create(ctx, dt, 125, 126, 127, 0, n, C.byref(S))
 timeit(lambda: lib.hipk_csr_matvec(S, None, V[0].data_ptr(), ld, W[0].data_ptr(), ld, 1), 2 * n * 8, "stencil 7pt")
 a1 = (C.c_double * 1)(0.5)

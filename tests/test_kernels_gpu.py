@@ -314,7 +314,7 @@ def test_csr_matvec_scaled_fused_tail(built, dt):
                                             ci.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
             x = side.arr(X); xo = side.arr(np.zeros_like(X)); y = side.arr(np.zeros_like(X))
             nn = side.arr(n2); dot = side.arr(np.zeros(1))
-            assert side.lib.hipk_csr_matvec_scaled(A, None, side.ptr(x), side.ptr(nn), side.ptr(xo), side.ptr(y), side.ptr(dot)) == 0
+            assert side.lib.hipk_csr_matvec_scaled(A, side.ctx, side.ptr(x), side.ptr(nn), side.ptr(xo), side.ptr(y), side.ptr(dot)) == 0
             # the launches it replaces
             x2 = side.arr(X); y2 = side.arr(np.zeros_like(X))
             assert side.lib.hipk_scale_cols_rsqrt_dev(side.ctx, dt, n, side.ptr(x2), n, 1, side.ptr(nn)) == 0
