@@ -216,6 +216,124 @@ dots_wide_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int
    }
 }
 
+/* Blocks of right-hand columns on the matrix cores: G = [Q V]' X with v_mfma_f64_16x16x4_f64
+ * (reference: Num_gemm_ddh / Num_compute_gramm, cublas_wrapper.c:479-499, :898-987; the b >= 4 TN
+ * panels of Bortho_block_gen and update_projection).  A workgroup stages MF_ROWS rows of up to
+ * 16*NT basis columns and of the (<= 16) right-hand columns in LDS with fully coalesced 16-byte
+ * loads — each wave fetches whole columns, 1 KB per instruction — and then feeds the MFMA from
+ * LDS: for a 16x16x4 step the k index is a ROW of the panels, lane l supplies
+ * A[i = l & 15][k = l >> 4] = V(row, column i) and B[k = l >> 4][j = l & 15] = X(row, column j).
+ * The column stride in LDS is MF_ROWS + 2 doubles (= 2 mod 32), which makes the 32 lanes of a
+ * ds_read_b64 group hit 32 distinct bank pairs.  Wave w takes the k-steps of rows [32 w, 32 w + 32)
+ * of the staged tile for every (basis tile, X) pair; the 4-double accumulators (C/D layout of the
+ * f64 form: column = lane & 15, row = (lane >> 4) + 4 reg) stay in registers for the whole row
+ * range of the workgroup and the four waves' partial tiles are added in a fixed order at the end.
+ * An NT x 16-column tile of accumulators costs 8 NT VGPRs per lane where the FMA form
+ * (dots_wide_kernel<8, 8>) holds 64 accumulators in 128. */
+#define MF_ROWS 128
+#define MF_LDS_STRIDE (MF_ROWS + 2)
+typedef double mf_acc __attribute__((ext_vector_type(4)));
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+dots_mfma_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int64_t m,
+      double *__restrict__ partials) {
+   typedef lanevec<T, 2> LV;
+   extern __shared__ double mf_lds[];            /* [(16*NT + 16) columns][MF_LDS_STRIDE] */
+   const int lane = threadIdx.x & 63;
+   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const int j0 = blockIdx.y * 16 * NT;          /* first basis column of this workgroup */
+   const int ncv = min(16 * NT, segs.total - j0);
+   const int c0 = blockIdx.z * 16;               /* first right-hand column */
+   const int nxv = min(16, nx - c0);
+   double *sV = mf_lds, *sX = mf_lds + (size_t)16 * NT * MF_LDS_STRIDE;
+   mf_acc acc[NT];
+#pragma unroll
+   for (int t = 0; t < NT; t++) acc[t] = (mf_acc){0.0, 0.0, 0.0, 0.0};
+   const int ci = lane & 15, kg = lane >> 4;
+
+   const int64_t ntile = (m + MF_ROWS - 1) / MF_ROWS;
+   for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+      const int64_t r0 = tile * MF_ROWS;
+      const bool full = r0 + MF_ROWS <= m;
+      /* stage: wave w fetches columns w, w + 4, ... (2 rows per lane, 1 KB per column); every load is
+       * issued before the first LDS store, absent columns read a valid one and are zeroed afterwards */
+      constexpr int NCW = (16 * NT + 16) / 4;
+      LV tv[NCW];
+      if (full) {
+#pragma unroll
+         for (int q = 0; q < NCW; q++) {
+            const int c = wv + 4 * q;
+            const bool isx = c >= 16 * NT;
+            const int cc = isx ? c - 16 * NT : c;
+            const T *col = isx ? X + (size_t)(c0 + (cc < nxv ? cc : 0)) * ldX : seg_col<T>(segs, j0 + (cc < ncv ? cc : 0));
+            tv[q] = ((const LV *)(col + r0))[lane];
+         }
+      } else {
+#pragma unroll
+         for (int q = 0; q < NCW; q++) {
+            const int c = wv + 4 * q;
+            const bool isx = c >= 16 * NT;
+            const int cc = isx ? c - 16 * NT : c;
+            const T *col = isx ? X + (size_t)(c0 + (cc < nxv ? cc : 0)) * ldX : seg_col<T>(segs, j0 + (cc < ncv ? cc : 0));
+            const int64_t i = r0 + 2 * lane;
+            const T e0 = col[i < m ? i : m - 1], e1 = col[i + 1 < m ? i + 1 : m - 1];
+            tv[q].e[0] = i < m ? e0 : (T)0;
+            tv[q].e[1] = i + 1 < m ? e1 : (T)0;
+         }
+      }
+#pragma unroll
+      for (int q = 0; q < NCW; q++) {
+         const int c = wv + 4 * q;
+         const bool isx = c >= 16 * NT;
+         const int cc = isx ? c - 16 * NT : c;
+         const bool have = isx ? (cc < nxv) : (cc < ncv);
+         double *dstc = mf_lds + (size_t)c * MF_LDS_STRIDE + 2 * lane;
+         dstc[0] = have ? (double)tv[q].e[0] : 0.0;
+         dstc[1] = have ? (double)tv[q].e[1] : 0.0;
+      }
+      __syncthreads();
+      /* 8 k-steps of 4 rows for this wave */
+#pragma unroll
+      for (int st = 0; st < MF_ROWS / 16; st++) {
+         const int row = wv * (MF_ROWS / 4) + 4 * st + kg;
+         const double b = sX[(size_t)ci * MF_LDS_STRIDE + row];
+#pragma unroll
+         for (int t = 0; t < NT; t++) {
+            const double a = sV[(size_t)(16 * t + ci) * MF_LDS_STRIDE + row];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+         }
+      }
+      __syncthreads();
+   }
+   /* add the four waves' tiles in a fixed order: red[wave][tile][reg][lane] in the staging buffer */
+   double *red = mf_lds;
+#pragma unroll
+   for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[(((size_t)wv * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+   __syncthreads();
+   if (wv == 0) {
+      const size_t nout = (size_t)segs.total * nx;
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+         for (int r = 0; r < 4; r++) {
+            const size_t o = ((size_t)t * 4 + r) * 64 + lane;
+            const double v = (red[o] + red[(size_t)NT * 256 + o]) + (red[(size_t)2 * NT * 256 + o] + red[(size_t)3 * NT * 256 + o]);
+            const int i = 16 * t + kg + 4 * r, j = ci;     /* C/D layout of v_mfma_f64_16x16x4_f64 */
+            if (i < ncv && j < nxv)
+               partials[(size_t)blockIdx.x * nout + (size_t)(j0 + i) + (size_t)(c0 + j) * segs.total] = v;
+         }
+   }
+}
+
+static int dots_mfma_enabled(void) {             /* HIPK_NO_MFMA: measurement knob, read once */
+   static int v = -1;
+   if (v < 0) v = getenv("HIPK_NO_MFMA") == NULL;
+   return v;
+}
+
 template <typename T, int VW>
 static void dots_launch(hipk_ctx *ctx, dim3 grid, int nxt, const SegArgs &sa, const T *X, int64_t ldX,
       int nx, int64_t m) {
@@ -251,10 +369,24 @@ static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X,
       nxt = (nx <= 4) ? 4 : 8;
       gz = (nx + nxt - 1) / nxt;
    }
+   /* matrix cores for blocks of >= 4 right-hand columns (16-byte aligned panels) */
+   const bool mfma = (nx >= 4 && vec && dots_mfma_enabled());
+   int nt = 1;
+   if (mfma) {
+      nt = sa.total <= 16 ? 1 : 2;                 /* 2 tiles: 48 staged columns = 50 KB of LDS */
+      gy = (sa.total + 16 * nt - 1) / (16 * nt);
+      gz = (nx + 15) / 16;
+      gx = hipk_grid_for_rows(ctx, m, MF_ROWS, 2);
+      while (gx > 1 && (int64_t)gx * gy * gz > (int64_t)ctx->num_cu * 4) gx = (gx + 1) / 2;
+   }
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    dim3 grid(gx, gy, gz);
    const int pslot = hipk_prof_begin(HIPK_PROF_DOTS, ctx->stream, (double)m * sizeof(T) * (sa.total + nx));
-   if (wide) {
+   if (mfma) {
+      const size_t shm = (size_t)(16 * nt + 16) * MF_LDS_STRIDE * sizeof(double);
+      if (nt == 1) hipLaunchKernelGGL((dots_mfma_kernel<T, 1>), grid, dim3(HIPK_BLOCK), shm, ctx->stream, sa, X, ldX, nx, m, ctx->partials);
+      else hipLaunchKernelGGL((dots_mfma_kernel<T, 2>), grid, dim3(HIPK_BLOCK), shm, ctx->stream, sa, X, ldX, nx, m, ctx->partials);
+   } else if (wide) {
       if (nxt == 4) hipLaunchKernelGGL((dots_wide_kernel<T, 8, 4, vecwidth<T>::value, 4>), grid, dim3(256), 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials);
       else hipLaunchKernelGGL((dots_wide_kernel<T, 8, 8, vecwidth<T>::value, 4>), grid, dim3(256), 0, ctx->stream, sa, X, ldX, nx, m, ctx->partials);
    } else if (vec) dots_launch<T, vecwidth<T>::value>(ctx, grid, nxt, sa, X, ldX, nx, m);

@@ -47,6 +47,35 @@ def test_panel_dots(built, dt, m, k, L, nx):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("m,k,L,nx", [(128 * 7, 5, 0, 4), (100003, 12, 4, 8), (100003, 17, 0, 4), (70001, 24, 9, 8), (250000, 41, 8, 8),
+                                      (33333, 30, 40, 16), (50001, 9, 3, 20), (90, 6, 2, 5), (257, 16, 0, 16)])
+def test_panel_dots_matrix_cores(built, dt, m, k, L, nx, monkeypatch):
+    """Blocks of >= 4 right-hand columns with 16-byte aligned panels go through v_mfma_f64_16x16x4_f64
+    (dots_mfma_kernel): against the oracle, against numpy in float64 and against the FMA kernels
+    (HIPK_NO_MFMA is read once per process, so the FMA leg is the oracle + numpy comparison here).  The
+    operands are asymmetric (a row <-> column swap in the C/D layout would not cancel)."""
+    rng = np.random.default_rng(m + k + nx)
+    npdt = NPDT[dt]
+    ld = (m + 2) // 2 * 2 + 2                       # even: every column 16-byte aligned
+    V = rng.standard_normal((k + 1, ld)).astype(npdt) * np.linspace(0.5, 2.0, k + 1)[:, None].astype(npdt)
+    Q = rng.standard_normal((max(L, 1), ld)).astype(npdt)
+    X = (rng.standard_normal((nx, ld)) * np.linspace(1.0, 3.0, nx)[:, None]).astype(npdt)
+    outs = []
+    for side in (Dev(), Host()):
+        v, q, x = side.arr(V), side.arr(Q), side.arr(X)
+        out = side.arr(np.zeros((nx, k + L + 3)))
+        segs = segs_array(side, [(q, 0, ld, L), (v, 0, ld, k)])
+        assert side.lib.hipk_panel_dots(side.ctx, dt, m, segs, 2, side.ptr(x), ld, nx, side.ptr(out), k + L + 3) == 0
+        outs.append(side.get(out)[:, :k + L])
+        side.close()
+    ref = X[:, :m].astype(np.float64) @ np.concatenate([Q[:L, :m], V[:k, :m]]).astype(np.float64).T
+    scale = np.sqrt(m) * 8
+    tol = (1e-12 if dt == F.HIPK_F64 else 2e-5) * scale
+    assert np.max(np.abs(outs[0] - outs[1])) <= tol * max(1.0, np.abs(outs[1]).max() / scale)
+    assert np.max(np.abs(outs[0] - ref)) <= tol * max(1.0, np.abs(ref).max() / scale)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
 @pytest.mark.parametrize("m,k,L", SHAPES)
 @pytest.mark.parametrize("nx", [1, 2, 5, 8, 9])
 def test_panel_project(built, dt, m, k, L, nx):
