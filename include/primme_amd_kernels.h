@@ -95,6 +95,13 @@ int hipk_panel_project_to(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_se
       const double *coef_dev, int ldcoef, const void *X, int64_t ldX, void *Xout, int64_t ldXout, int nx,
       double *nrm2_dev);
 
+/* X <- (X - [segs] * coef) * M with M an nx x nx matrix (DEVICE, leading dimension nx), nx <= 8, in one
+ * pass over X and the basis: the whole device step of a CholQR / SVQB sweep (reference
+ * Num_ortho_kernel, ortho.c:963-1072).  Returns 1 if the shape is not covered (nx > 8): the caller
+ * then uses hipk_panel_project + hipk_ritz_update. */
+int hipk_panel_project_mul(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
+      const double *coef_dev, int ldcoef, const double *M_dev, void *X, int64_t ldX, int nx);
+
 /* ---- fused Ritz / residual / restart update ----------------------------------
  * The multi-output panel op of reference auxiliary_eigs_normal.c:155-388
  * (Num_update_VWXR) and restart.c:1233-1294.  V, W: m x k panels (ld ldVW).

@@ -125,6 +125,25 @@ int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *
    return hipk_panel_project_to(ctx, dt, m, segs, nseg, coef, ldcoef, X, ldX, X, ldX, nx, nrm2);
 }
 
+int hipk_panel_project_mul(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
+      const double *coef, int ldcoef, const double *M, void *X, int64_t ldX, int nx) {
+   (void)ctx;
+   if (nx <= 0) return 0;
+   if (nx > 8) return 1;
+   const int tot = seg_total(segs, nseg);
+   for (int64_t i = 0; i < m; i++) {
+      double xv[8], out[8];
+      for (int c = 0; c < nx; c++) {
+         double v = ld_(dt, colp(dt, X, ldX, c), i);
+         for (int j = 0; j < tot; j++) v -= ld_(dt, seg_col(dt, segs, nseg, j), i) * coef[j + (size_t)c * ldcoef];
+         xv[c] = v;
+      }
+      for (int c = 0; c < nx; c++) { double t = 0.0; for (int q = 0; q < nx; q++) t += xv[q] * M[q + (size_t)c * nx]; out[c] = t; }
+      for (int c = 0; c < nx; c++) st_(dt, (void *)colp(dt, X, ldX, c), i, out[c]);
+   }
+   return 0;
+}
+
 /* Num_update_VWXR restated row by row (all reads of a row precede its writes) */
 int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
       int64_t ld, int k, const double *h, int ldh, const double *theta, const hipk_job *jobs,

@@ -141,12 +141,7 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
    hipk_seg segsA[2] = {{locked, ldLocked, numLocked}, {Vp, ldV, b2}};
    for (int its = 0; its < maxits; its++) {
       if (its > 0) {
-         /* X <- (X - [Q V]*GdA) * Y' with Y' = Y*diag(1/D) (eigenvector form) or Y^-1 (Cholesky) */
-         if (nVL > 0) {
-            CHK(hipk_h2d(s->ctx, s->d_red, GdA, (size_t)nVL * nX * sizeof(double)));
-            CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, s->d_red, nVL, X, ldV, nX, NULL));
-            CHK(hipk_sync(s->ctx));   /* GdA is reused on the host below */
-         }
+         /* X <- (X - [Q V]*GdA) * M with M = Y*diag(1/D) (eigenvector form) or Y^-1 (Cholesky) */
          if (Yortho) {
             for (int c = 0; c < nX; c++) for (int i = 0; i < nX; i++) M[i + (size_t)c * nX] = Y[i + (size_t)c * nX] / D[c];
          } else {
@@ -154,7 +149,26 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
             for (int c = 0; c < nX; c++) for (int i = 0; i < nX; i++) M[i + (size_t)c * nX] = (i == c) ? 1.0 : 0.0;
             pa_trsm_left_upper(nX, nX, Y, nX, M, nX);
          }
-         CHK(right_multiply(s, X, ldV, nX, M));
+         /* coefficients and M travel through the pinned mirror (stream-ordered copies, no synchronisation):
+          * h_red is only rewritten by launches that come later in the stream */
+         const size_t ncoef = (size_t)nVL * nX, nM = (size_t)nX * nX;
+         int fused = 0;
+         if (nX <= 8 && ncoef + nM <= (size_t)s->red_cap) {
+            memcpy(s->h_red, GdA, ncoef * sizeof(double));
+            memcpy(s->h_red + ncoef, M, nM * sizeof(double));
+            CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, (ncoef + nM) * sizeof(double)));
+            int rcf = hipk_panel_project_mul(s->ctx, s->dt, s->m, segs, 2, s->d_red, nVL > 0 ? nVL : 1, s->d_red + ncoef, X, ldV, nX);
+            if (rcf < 0) return rcf;
+            fused = (rcf == 0);
+         }
+         if (!fused) {
+            if (nVL > 0) {
+               memcpy(s->h_red, GdA, ncoef * sizeof(double));
+               CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, ncoef * sizeof(double)));
+               CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, s->d_red, nVL, X, ldV, nX, NULL));
+            }
+            CHK(right_multiply(s, X, ldV, nX, M));
+         }
       }
       /* A = [Q V(0:b2)]' X */
       CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segsA, 2, X, ldV, nX, s->d_red, nrowsA));

@@ -512,6 +512,123 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *X,
    }
 }
 
+/* X <- (X - [segs] coef) * M in ONE pass over X and the basis (M: nx x nx, nx <= NX <= 8): the
+ * update and the right-multiplication of a CholQR / SVQB sweep (reference Num_ortho_kernel,
+ * ortho.c:963-1072: two GEMMs and a copy through an m x b temporary). */
+template <typename T, int NX, int VW>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+project_mul_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, const double *__restrict__ Mr,
+      T *X, int64_t ldX, int nx, int64_t m) {
+   typedef lanevec<T, VW> LV;
+   __shared__ double scoef[PROJ_MAXCOLS * NX];
+   __shared__ double sM[NX * NX];
+   __shared__ const T *sptr[PROJ_MAXCOLS];
+   const int total = segs.total;
+   for (int t = threadIdx.x; t < total * NX; t += HIPK_BLOCK) {
+      int j = t / NX, c = t % NX;
+      scoef[t] = (c < nx) ? coef[j + (size_t)c * ldcoef] : 0.0;
+   }
+   for (int t = threadIdx.x; t < NX * NX; t += HIPK_BLOCK) {
+      int i = t % NX, c = t / NX;                      /* sM[i + c*NX] = M(i, c) */
+      sM[t] = (i < nx && c < nx) ? Mr[i + (size_t)c * nx] : 0.0;
+   }
+   for (int j = threadIdx.x; j < total; j += HIPK_BLOCK) sptr[j] = seg_col<T>(segs, j);
+   __syncthreads();
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   const int64_t mg = m / VW;
+   for (int64_t g = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; g < mg; g += stride) {
+      double xv[NX][VW];
+#pragma unroll
+      for (int c = 0; c < NX; c++) {
+         const LV t = ((const LV *)(X + (size_t)(c < nx ? c : 0) * ldX))[g];
+#pragma unroll
+         for (int r = 0; r < VW; r++) xv[c][r] = c < nx ? (double)t.e[r] : 0.0;
+      }
+      int j = 0;
+      for (; j + 8 <= total; j += 8) {
+         LV a[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) a[u] = ((const LV *)sptr[j + u])[g];
+#pragma unroll
+         for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int c = 0; c < NX; c++) {
+               const double cf = scoef[(j + u) * NX + c];
+#pragma unroll
+               for (int r = 0; r < VW; r++) xv[c][r] = fma(-(double)a[u].e[r], cf, xv[c][r]);
+            }
+      }
+      for (; j < total; j++) {
+         LV a = ((const LV *)sptr[j])[g];
+#pragma unroll
+         for (int c = 0; c < NX; c++) {
+            const double cf = scoef[j * NX + c];
+#pragma unroll
+            for (int r = 0; r < VW; r++) xv[c][r] = fma(-(double)a.e[r], cf, xv[c][r]);
+         }
+      }
+#pragma unroll
+      for (int c = 0; c < NX; c++)
+         if (c < nx) {
+            LV o;
+#pragma unroll
+            for (int r = 0; r < VW; r++) {
+               double sacc = 0.0;
+#pragma unroll
+               for (int i = 0; i < NX; i++) sacc = fma(xv[i][r], sM[i + c * NX], sacc);
+               o.e[r] = (T)sacc;
+            }
+            ((LV *)(X + (size_t)c * ldX))[g] = o;
+         }
+   }
+   if (VW > 1 && blockIdx.x == 0 && threadIdx.x < (unsigned)(m - mg * VW)) {   /* ragged tail rows */
+      const int64_t i = mg * VW + threadIdx.x;
+      double xv[NX];
+      for (int c = 0; c < NX; c++) {
+         double v = c < nx ? (double)X[i + (size_t)c * ldX] : 0.0;
+         for (int j = 0; j < total; j++) v = fma(-(double)sptr[j][i], scoef[j * NX + c], v);
+         xv[c] = v;
+      }
+      for (int c = 0; c < nx; c++) {
+         double sacc = 0.0;
+         for (int q = 0; q < NX; q++) sacc = fma(xv[q], sM[q + c * NX], sacc);
+         X[i + (size_t)c * ldX] = (T)sacc;
+      }
+   }
+}
+
+template <typename T, int VW>
+static int panel_project_mul_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const double *coef, int ldcoef,
+      const double *Mr, T *X, int64_t ldX, int nx) {
+   int gx = hipk_grid_for_rows(ctx, m / VW + 1, HIPK_BLOCK * 2, 4);
+   dim3 block(HIPK_BLOCK);
+   const int pslot = hipk_prof_begin(HIPK_PROF_PROJECT, ctx->stream, (double)m * sizeof(T) * ((double)sa.total + 2.0 * nx));
+   if (nx <= 2) hipLaunchKernelGGL((project_mul_kernel<T, 2, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, Mr, X, ldX, nx, m);
+   else if (nx <= 4) hipLaunchKernelGGL((project_mul_kernel<T, 4, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, Mr, X, ldX, nx, m);
+   else hipLaunchKernelGGL((project_mul_kernel<T, 8, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, Mr, X, ldX, nx, m);
+   hipk_prof_end(pslot, ctx->stream);
+   HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
+/* X <- (X - [segs] coef) M; returns 1 when the shape is not covered (caller uses the two-pass form) */
+extern "C" int hipk_panel_project_mul(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
+      const double *coef_dev, int ldcoef, const double *M_dev, void *X, int64_t ldX, int nx) {
+   SegArgs sa;
+   if (pack_segs(segs, nseg, &sa)) return -1;
+   if (nx <= 0) return 0;
+   if (nx > 8 || sa.total > PROJ_MAXCOLS) return 1;
+   const size_t es = dt == HIPK_F64 ? 8 : 4;
+   const bool vec = segs_aligned16(sa, es) && aligned16(X, ldX, es);
+   switch (dt) {
+   case HIPK_F64: return vec ? panel_project_mul_v<double, 2>(ctx, m, sa, coef_dev, ldcoef, M_dev, (double *)X, ldX, nx)
+                             : panel_project_mul_v<double, 1>(ctx, m, sa, coef_dev, ldcoef, M_dev, (double *)X, ldX, nx);
+   case HIPK_F32: return vec ? panel_project_mul_v<float, 4>(ctx, m, sa, coef_dev, ldcoef, M_dev, (float *)X, ldX, nx)
+                             : panel_project_mul_v<float, 1>(ctx, m, sa, coef_dev, ldcoef, M_dev, (float *)X, ldX, nx);
+   default: return -44;
+   }
+}
+
 template <typename T, int VW>
 static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const double *coef,
       int ldcoef, T *X, int64_t ldX, T *Xout, int64_t ldXout, int nx, double *nrm2_dev) {

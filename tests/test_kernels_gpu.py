@@ -384,6 +384,38 @@ def test_panel_project_out_of_place(built, dt):
         assert abs(r[2][0] - np.sum(ref ** 2)) <= tol * 10 * np.sum(ref ** 2)
 
 
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("m,k,L,nx,pad", [(70003, 9, 4, 8, 1), (70002, 24, 0, 4, 2), (1000, 3, 2, 2, 0), (50001, 40, 20, 5, 3), (129, 0, 0, 3, 1)])
+def test_panel_project_mul_cholqr_sweep(built, dt, m, k, L, nx, pad):
+    """X <- (X - [Q V] coef) M in one pass (the device step of a CholQR / SVQB sweep)"""
+    rng = np.random.default_rng(m + nx)
+    npdt = NPDT[dt]
+    ld = m + pad
+    V = rng.standard_normal((max(k, 1), ld)).astype(npdt); Q = rng.standard_normal((max(L, 1), ld)).astype(npdt)
+    X = rng.standard_normal((nx, ld)).astype(npdt)
+    coef = rng.standard_normal((nx, k + L + 1)) / np.sqrt(k + L + 1); Mr = rng.standard_normal((nx, nx))
+    res = []
+    for side in (Dev(), Host()):
+        v, q, x = side.arr(V), side.arr(Q), side.arr(X)
+        cf, mm = side.arr(coef), side.arr(Mr)
+        segs = segs_array(side, [(q, 0, ld, L), (v, 0, ld, k)])
+        assert side.lib.hipk_panel_project_mul(side.ctx, dt, m, segs, 2, side.ptr(cf), k + L + 1, side.ptr(mm), side.ptr(x), ld, nx) == 0
+        res.append(side.get(x)[:, :m])
+        side.close()
+    B = np.concatenate([Q[:L, :m], V[:k, :m]]).astype(np.float64)
+    P = X[:, :m].astype(np.float64) - coef[:, :k + L] @ B                    # rows = columns of the panel
+    ref = Mr @ P                                                              # out col c = sum_q P(:,q) M(q,c); Mr[c, q] = M(q, c)
+    tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+    assert np.max(np.abs(res[0] - res[1])) <= tol * 10 * (1 + np.abs(ref).max())
+    assert np.max(np.abs(res[1] - ref)) <= tol * 10 * (1 + np.abs(ref).max())
+    # shapes the single-pass form does not cover are reported, not guessed
+    side = Dev()
+    x = side.arr(np.zeros((9, 16)))
+    segs = segs_array(side, [(x, 0, 16, 0), (x, 0, 16, 0)])
+    assert side.lib.hipk_panel_project_mul(side.ctx, dt, 8, segs, 2, side.ptr(x), 1, side.ptr(x), side.ptr(x), 16, 9) == 1
+    side.close()
+
+
 @pytest.mark.parametrize("dims", [(1000,), (123, 77), (31, 29, 37)])
 def test_stencil_matches_csr(built, dims):
     dt = F.HIPK_F64
