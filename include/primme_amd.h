@@ -8,7 +8,7 @@
  *
  * LAYOUT IS ABI.  Field order, widths and enum values below reproduce
  * reference include/primme_eigs.h:47-253 (sizeof(primme_params) == 640,
- * sizeof(primme_stats) == 200 on x86-64; tests/test_abi.py checks every offset
+ * sizeof(primme_stats) == 200 on x86-64; tests/test_abi_and_params.py checks every offset
  * against the table captured from the reference build).  Only declarations are
  * shared; every definition in this repository is new code.
  */
@@ -203,16 +203,29 @@ int hip_zprimme(double *evals, void *evecs, double *resNorms, primme_params *pri
 int hip_sprimme(float *evals, float *evecs, float *resNorms, primme_params *primme);
 int hip_cprimme(float *evals, void *evecs, float *resNorms, primme_params *primme);
 
+/* The reference's CPU entry points with their HOST-pointer contract (include/primme_eigs.h:386-393,
+ * src/eigs/primme_c.c:103-108): evecs is a host array [constraints | guesses], the callbacks get host
+ * pointers with leading dimension ldOPs, primme->queue must be NULL.  A program written against the
+ * CPU library (examples/ex_eigs_dseq.c) relinks unchanged; the solve runs on the device and every
+ * operator application is staged through pinned host memory (csrc/eigs_hostapi.c), so this is the
+ * plumbing path — use hip_?primme with a device callback for the device rate. */
+int dprimme(double *evals, double *evecs, double *resNorms, primme_params *primme);
+int zprimme(double *evals, void *evecs, double *resNorms, primme_params *primme);
+int sprimme(float *evals, float *evecs, float *resNorms, primme_params *primme);
+int cprimme(float *evals, void *evecs, float *resNorms, primme_params *primme);
+
 /* ---- ready-made callbacks (what examples/ex_eigs_dhipblas.c:239-264 and
  *      examples/ex_eigs_mpi.c:209-218 hand-write for every application) ------- */
 
 /* matrixMatvec for a device CSR matrix: set primme->matrix = handle returned by
- * primme_amd_csr_create()/..._stencil_create() (see primme_amd_kernels.h). */
+ * primme_amd_operator_create() over a hipk_csr_create() / hipk_stencil_create() matrix
+ * (primme_amd_comm.h, primme_amd_kernels.h). */
 void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       struct primme_params *primme, int *ierr);
 /* Jacobi (diagonal) preconditioner y = (diag(A) - shift)^-1 x with the shifts the
  * solver publishes in primme->ShiftsForPreconditioner; primme->preconditioner =
- * handle from primme_amd_jacobi_create() (cf. reference tests/COMMON/mat.c
+ * the same operator handle, flavour chosen with
+ * primme_amd_operator_set_jacobi() (cf. reference tests/COMMON/mat.c
  * createInvDiagPrecNative / examples/ex_eigs_dseq.c:187-202). */
 void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy,
       int *blockSize, struct primme_params *primme, int *ierr);

@@ -429,3 +429,58 @@ def test_single_precision_callbacks_get_float_operands(built, monkeypatch):
     b = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", **kw)
     assert a.ret == 0 and b.ret == 0 and seen["calls"] > 10 and seen["mon"] == {F.primme_op_float}
     assert np.max(np.abs(a.evals - b.evals)) <= 1e-4 * 8.0
+
+
+def test_host_pointer_entry_points(built):
+    """dprimme() with the reference's HOST-pointer contract (csrc/eigs_hostapi.c): host evecs, host
+    callbacks that receive the CALLER's primme_params (matrix, ShiftsForPreconditioner ...).  Same
+    solve as hip_dprimme with the ready-made operator: identical counts and eigenvalues (configs[0]:
+    the ex_eigs_dseq problem)."""
+    import ctypes as C
+    lib = checkers.load_hostcheck()
+    n, nev = 100, 10
+    rp, ci, va, _ = problems.laplacian_csr((n,))
+    seen = {"mv": 0, "pc": 0, "user_struct": True}
+    p = F.PrimmeParams()
+    lib.primme_initialize(C.byref(p))
+
+    def mv(x, ldx, y, ldy, bs, pp, ierr):
+        seen["mv"] += bs[0]
+        seen["user_struct"] &= (C.addressof(pp[0]) == C.addressof(p))
+        X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(bs[0], ldx[0]))
+        Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(bs[0], ldy[0]))
+        Y[:, :n] = problems.csr_matvec_numpy(rp, ci, va, X[:, :n].T).T
+        ierr[0] = 0
+
+    def pc(x, ldx, y, ldy, bs, pp, ierr):
+        seen["pc"] += bs[0]
+        X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(bs[0], ldx[0]))
+        Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(bs[0], ldy[0]))
+        sh = pp[0].ShiftsForPreconditioner
+        for c in range(bs[0]):
+            d = 2.0 - (sh[c] if sh else 0.0)
+            if not abs(d) > 1e-14 * 4.0: d = np.copysign(1e-14 * 4.0, d)
+            Y[c, :n] = X[c, :n] / d
+        ierr[0] = 0
+    cmv, cpc = F.BLOCK_OP(mv), F.BLOCK_OP(pc)
+    p.n, p.numEvals, p.eps, p.aNorm, p.printLevel, p.outputFile = n, nev, 1e-9, 4.0, 0, None
+    p.matrixMatvec = C.cast(cmv, C.c_void_p); p.applyPreconditioner = C.cast(cpc, C.c_void_p)
+    p.correctionParams.precondition = 1
+    p.initBasisMode = F.primme_init_user; p.initSize = 1
+    lib.primme_set_method(F.PRIMME_GD_plusK, C.byref(p))
+    evecs = np.zeros((nev, n)); evecs[0] = problems.start_vector(n)
+    evals, rn = np.zeros(nev), np.zeros(nev)
+    lib.dprimme.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(F.PrimmeParams)]
+    ret = lib.dprimme(evals.ctypes.data, evecs.ctypes.data, rn.ctypes.data, C.byref(p))
+    assert ret == 0 and p.initSize == nev and seen["user_struct"]
+    assert np.max(np.abs(evals - problems.laplacian_eigenvalues((n,), nev))) <= 1e-10 * 4.0
+    assert seen["mv"] == p.stats.numMatvecs and seen["pc"] == p.stats.numPreconds > 0
+    A = np.zeros((n, n)); A[np.repeat(np.arange(n), np.diff(rp)), ci] = va
+    X = evecs.T
+    assert np.all(np.linalg.norm(A @ X - X * evals, axis=0) <= 1e-9 * 4.0 * 1.05)
+    assert C.cast(p.matrixMatvec, C.c_void_p).value == C.cast(cmv, C.c_void_p).value and not p.queue   # caller's struct restored
+    # the device-pointer entry on the same problem, ready-made operator: same history
+    g = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", numEvals=nev, eps=1e-9, aNorm=4.0, precond="jacobi",
+              method="GD_plusK", v0=problems.start_vector(n))
+    assert g.ret == 0 and g.stats["numOuterIterations"] == p.stats.numOuterIterations and g.stats["numMatvecs"] == p.stats.numMatvecs
+    assert np.max(np.abs(g.evals - evals)) <= 1e-13
