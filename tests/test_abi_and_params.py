@@ -104,7 +104,7 @@ def test_library_exports_every_declared_symbol(built):
     for h in sorted(os.listdir(os.path.join(root, "include"))):
         txt = open(os.path.join(root, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        for m in re.finditer(r"\b((?:hipk|primme|hip)_\w+)\s*\(", txt):
+        for m in re.finditer(r"\b((?:hipk|primme|hip|Num)_\w+|[dszc]primme)\s*\(", txt):
             declared.add(m.group(1))
     declared -= {"primme_block_op", "primme_svds_block_op"}
     syms = subprocess.check_output(["nm", "-D", "--defined-only", F.PRODUCT_LIB], text=True)
@@ -131,3 +131,17 @@ def test_check_input_codes(built):
     assert lib.hip_dprimme(None, vec.ctypes.data_as(C.c_void_p), rn.ctypes.data_as(C.c_void_p), C.byref(p)) == -30
     p.target = F.primme_closest_abs
     assert lib.hip_dprimme(ev.ctypes.data_as(C.c_void_p), vec.ctypes.data_as(C.c_void_p), rn.ctypes.data_as(C.c_void_p), C.byref(p)) == -14
+
+
+def test_reference_named_backend_shim_on_the_cpu_checker(built, tmp_path):
+    """include/primme_amd_wrapper.h (Num_gemm_ddh / Num_gemm_dhd / ... for the double GPU instantiation):
+    the C test program of examples/ compiled against the CPU checker build runs every routine against
+    plain loops (the same program runs against libprimme_amd.so in tests/test_c_examples_gpu.py)."""
+    import subprocess
+    exe = str(tmp_path / "test_hip_wrapper_cpu")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build = os.path.join(root, "oracle", "_build")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "test_hip_wrapper.c"), "-o", exe,
+                           "-L" + build, "-lprimme_hostcheck", "-Wl,-rpath," + build, "-lm"])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert out.returncode == 0 and "returned 0" in out.stdout, out.stdout
