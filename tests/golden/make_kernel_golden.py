@@ -1,0 +1,21 @@
+"""Generates tests/golden/reference_kernels.json (fixture F6 of SURVEY.md §8(c)): inputs and outputs of the
+REFERENCE's own panel routines — update_projection_dprimme, Num_update_VWXR_dprimme, Bortho_gen_dprimme,
+Bortho_block_dprimme — called by oracle/ref_kernel_harness.c, which is compiled against the reference's
+headers where they lie and linked with oracle/_ref/libprimme_ref.so.  Run in the build container
+(needs /root/reference); the JSON travels, the reference does not.
+
+    python tests/golden/make_kernel_golden.py
+"""
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+subprocess.check_call(["make", "ref", "-j8"], cwd=os.path.join(ROOT, "oracle"))
+subprocess.check_call(["make", "kernel-fixture"], cwd=os.path.join(ROOT, "oracle"))
+out = subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_kernel_harness")], text=True)
+data = json.loads(out)
+data["generated_by"] = "tests/golden/make_kernel_golden.py -> oracle/ref_kernel_harness.c (reference PRIMME, double, MKL BLAS)"
+path = os.path.join(ROOT, "tests", "golden", "reference_kernels.json")
+json.dump(data, open(path, "w"))
+print("wrote", path, os.path.getsize(path), "bytes")
