@@ -61,6 +61,11 @@ hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op);
 int primme_amd_operator_can_fuse(const primme_amd_operator *op);
 int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ctx *ctx /* the caller's context */, const void *x,
       const double *norm2_dev, void *xout, void *y, double *dot_dev);
+/* y = A x - shifts[c] x(:,c) (single-rank CSR operators; returns 1 when not covered) and the data of the
+ * operator's Jacobi preconditioner, for the fused steps of the JDQMR inner iteration (eigs_jd.c) */
+int primme_amd_operator_apply_shifted(primme_amd_operator *op, void *hip_stream, const void *x, int64_t ldx,
+      void *y, int64_t ldy, int ncols, const double *shifts_host);
+int primme_amd_operator_jacobi_data(primme_amd_operator *op, const void **diag, int *fixed, double *shift);
 /* y = A x on `hip_stream` including the halo exchange */
 int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stream, const void *x, int64_t ldx,
       void *y, int64_t ldy, int ncols);

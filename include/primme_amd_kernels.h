@@ -186,6 +186,14 @@ int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const doubl
       const double *eta_host, const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol,
       int64_t ldSol, double *dotsol_dev);
 
+/* the same step together with the next Jacobi application: w = g ./ (diag - shift[c]) (|denominator| kept
+ * above min_denominator with its sign) and out_dev[nx + c] = g(:,c)' w(:,c), out_dev[c] = |sol(:,c)|^2:
+ * one pass instead of three (inner_solve.c:384-397 and :619-634) */
+int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gamma_host,
+      const double *eta_host, const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol,
+      const void *G, int64_t ldG, const void *diag, const double *shift_host, double min_denominator, void *W,
+      int64_t ldW, double *out_dev);
+
 /* ---- sparse operator: the user matvec ------------------------------------------
  * Replaces the hipsparseSpMM-based callback of examples/ex_eigs_dhipblas.c:239-264
  * and the SPARSKIT amux of tests/COMMON/mat.c:64-90.
@@ -206,6 +214,9 @@ int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int64_t ldx, v
 int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx /* the caller's: stream, scratch, result mirror */,
       const void *x, const double *norm2_dev, void *xout, void *y, double *dot_dev);
 int hipk_csr_kind(const hipk_csr *A);    /* 0 CSR, 1 stencil */
+/* y = A x - shift_host[c] x(:,c) in one launch; returns 1 when the operator is not covered (stencil, halo) */
+int hipk_csr_matvec_shifted(hipk_csr *A, void *hip_stream, const void *x, int64_t ldx, void *y, int64_t ldy,
+      int ncols, const double *shift_host);
 /* diagonal of A (device array of nrows_local elements of dtype) */
 const void *hipk_csr_diag(hipk_csr *A);
 int64_t hipk_csr_nnz(const hipk_csr *A);

@@ -435,6 +435,40 @@ int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x, const doub
    return 0;
 }
 
+int hipk_csr_matvec_shifted(hipk_csr *A, void *stream, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols,
+      const double *shift) {
+   if (ncols <= 0 || A->nrows == 0) return 0;
+   if (A->kind != 0 || A->halo_lo != 0 || A->halo_hi != 0 || A->x0 != A->row0 || A->xlen != A->nrows || ncols > 64 || !shift) return 1;
+   int rc = hipk_csr_matvec(A, stream, x, ldx, y, ldy, ncols);
+   for (int c = 0; c < ncols && !rc; c++)
+      for (int64_t i = 0; i < A->nrows; i++)
+         st_(A->dt, (void *)colp(A->dt, y, ldy, c), i, ld_(A->dt, colp(A->dt, y, ldy, c), i) - shift[c] * ld_(A->dt, colp(A->dt, x, ldx, c), i));
+   return rc;
+}
+int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gam, const double *eta,
+      const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G, int64_t ldG,
+      const void *diag, const double *shift, double min_den, void *W, int64_t ldW, double *out) {
+   (void)ctx;
+   if (!(min_den > 0.0)) min_den = 1e-300;
+   for (int c = 0; c < nx; c++) {
+      const void *d = colp(dt, D, ldD, c), *g = colp(dt, G, ldG, c);
+      void *de = (void *)colp(dt, Delta, ldDelta, c), *so = (void *)colp(dt, Sol, ldSol, c), *w = (void *)colp(dt, W, ldW, c);
+      double s1 = 0.0, s2 = 0.0;
+      for (int64_t i = 0; i < m; i++) {
+         st_(dt, de, i, ld_(dt, de, i) * gam[c] + ld_(dt, d, i) * eta[c]);
+         st_(dt, so, i, ld_(dt, de, i) + ld_(dt, so, i));
+         s1 += ld_(dt, so, i) * ld_(dt, so, i);
+         double den = ld_(dt, diag, i) - (shift ? shift[c] : 0.0);
+         if (!(fabs(den) > min_den)) den = copysign(min_den, den);
+         st_(dt, w, i, ld_(dt, g, i) / den);
+         s2 += ld_(dt, g, i) * ld_(dt, w, i);
+      }
+      out[c] = s1; out[nx + c] = s2;
+   }
+   mirror(out, (size_t)2 * nx);
+   return 0;
+}
+
 int hipk_jacobi_apply(void *stream, hipk_dtype dt, int64_t m, const void *diag, const double *shift,
       double min_den, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols) {
    (void)stream;

@@ -27,6 +27,16 @@ int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ctx *ctx, con
    if (!primme_amd_operator_can_fuse(op)) return -1;
    return hipk_csr_matvec_scaled(op->A, ctx, x, norm2, xout, y, dot);
 }
+int primme_amd_operator_apply_shifted(primme_amd_operator *op, void *st, const void *x, int64_t ldx, void *y, int64_t ldy,
+      int nc, const double *shifts) {
+   if (!op || op->ldscale != 1) return 1;
+   return hipk_csr_matvec_shifted(op->A, st, x, ldx, y, ldy, nc, shifts);
+}
+int primme_amd_operator_jacobi_data(primme_amd_operator *op, const void **diag, int *fixed, double *shift) {
+   if (!op || op->ldscale != 1) return 1;
+   *diag = hipk_csr_diag(op->A); *fixed = op->jacobi_fixed; *shift = op->jacobi_shift;
+   return 0;
+}
 void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)p->matrix;
    *ierr = primme_amd_operator_apply(op, NULL, x, *ldx * op->ldscale, y, *ldy * op->ldscale, *bs);

@@ -144,6 +144,17 @@ extern "C" int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ct
    return hipk_csr_matvec_scaled(op->A, ctx, x, norm2_dev, xout, y, dot_dev);
 }
 
+extern "C" int primme_amd_operator_apply_shifted(primme_amd_operator *op, void *hip_stream, const void *x, int64_t ldx,
+      void *y, int64_t ldy, int ncols, const double *shifts_host) {
+   if (!op || op->mode != 0 || op->ldscale != 1) return 1;
+   return hipk_csr_matvec_shifted(op->A, hip_stream, x, ldx, y, ldy, ncols, shifts_host);
+}
+extern "C" int primme_amd_operator_jacobi_data(primme_amd_operator *op, const void **diag, int *fixed, double *shift) {
+   if (!op || op->ldscale != 1) return 1;
+   *diag = hipk_csr_diag(op->A); *fixed = op->jacobi_fixed; *shift = op->jacobi_shift;
+   return 0;
+}
+
 /* ---- the callbacks ---------------------------------------------------------- */
 extern "C" void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       struct primme_params *primme, int *ierr) {

@@ -24,6 +24,7 @@
  * JDQR / JD_Olsen) return PRIMME_FUNCTION_UNAVAILABLE.
  */
 #include "eigs_solver.h"
+#include "primme_amd_comm.h"
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -204,14 +205,31 @@ static int skew_project_Q(pa_solver *s, const jd_proj *P, char *v, int64_t ldv, 
  * reference's separate Num_axpy / Num_dist_dots calls, two passes over the panels fewer. */
 static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const double *shift, const jd_proj *P,
       int nb, char *result, int64_t ldres, double *vdot) {
-   CHK(pa_matvec(s, v, ldv, result, ldres, 0, nb));
+   /* result = A v - shift v: in ONE launch when the operator is the library's own CSR matrix (the shift is
+    * applied in the SpMM epilogue), otherwise the callback followed by an axpy */
+   int shifted = 0;
+   if (nb > 1 && s->p->matrixMatvec == primme_amd_matvec && s->p->matrix) {
+      double t0 = pa_wtime();
+      const int rcs = primme_amd_operator_apply_shifted((primme_amd_operator *)s->p->matrix, hipk_ctx_stream(s->ctx), v, ldv,
+            result, ldres, nb, shift);
+      if (rcs < 0) return rcs;
+      if (rcs == 0) {
+         shifted = 1;
+         if (s->phase_timing) CHK(hipk_sync(s->ctx));
+         s->p->stats.timeMatvec += pa_wtime() - t0;
+         s->p->stats.numMatvecs += nb;
+      }
+   }
+   if (!shifted) CHK(pa_matvec(s, v, ldv, result, ldres, 0, nb));
    double ms[64];
    for (int i = 0; i < nb; i++) ms[i] = -shift[i];
    if (P->nLX > 0) {
       double t0 = pa_wtime();
       if (P->nLQ > 0) {
-         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
+         if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
          CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+         CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, result, ldres, nb, s->d_red));
+      } else if (shifted) {
          CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, result, ldres, nb, s->d_red));
       } else {
          /* result -= shift v  and  x' result */
@@ -227,7 +245,7 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
       s->p->stats.numOrthoInnerProds += nb;
       s->p->stats.timeOrtho += pa_wtime() - t0;
    } else {
-      CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
+      if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
       CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
       CHK(pair_dots_host(s, v, ldv, result, ldres, nb, vdot));
    }
@@ -271,6 +289,14 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    /* without preconditioner and right projectors the "preconditioned" vector is g itself: no
     * copy, and rho = g'g is the dot product already taken for Theta */
    const int plain_K = (!p->correctionParams.precondition && P->nRQ == 0 && P->nRX == 0);
+   /* block runs with the library's own Jacobi preconditioner and no right projectors: the QMR update, the
+    * next K^-1 g and the two reductions they need are ONE pass (hipk_qmr_update_jacobi) */
+   const void *jac_diag = NULL;
+   int jac_fixed = 0;
+   double jac_shift = 0.0, rho_new[64];
+   const int fuse_pk = (b0 > 1 && !plain_K && p->correctionParams.precondition && p->applyPreconditioner == primme_amd_jacobi_precond &&
+                        p->preconditioner && P->nRQ == 0 && P->nRX == 0 && !P->skewQ &&
+                        primme_amd_operator_jacobi_data((primme_amd_operator *)p->preconditioner, &jac_diag, &jac_fixed, &jac_shift) == 0);
    int pm[64], p0[64];
    const int adaptive = (p->correctionParams.convTest == primme_adaptive ||
                          p->correctionParams.convTest == primme_adaptive_ETolerance);
@@ -368,10 +394,24 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          gam_c[i] = gamma[q]; eta_c[i] = eta[q];
       }
       /* delta = gamma delta + eta d; sol += delta; |sol|^2 */
-      CHK(hipk_qmr_update(s->ctx, s->dt, s->m, blockSize, gam_c, eta_c, d, ld, delta, ld, sol, ld, s->d_red));
-      if (adaptive) {
-         CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
-         for (i = 0; i < blockSize; i++) dot_sol[i] = s->h_red[i];
+      int have_w = 0;
+      if (fuse_pk && numIts + 1 < maxIterations) {
+         double jsh[64];
+         for (i = 0; i < blockSize; i++) jsh[i] = jac_fixed ? jac_shift : (p->ShiftsForPreconditioner ? p->ShiftsForPreconditioner[i] : 0.0);
+         double t0 = pa_wtime();
+         CHK(hipk_qmr_update_jacobi(s->ctx, s->dt, s->m, blockSize, gam_c, eta_c, d, ld, delta, ld, sol, ld, g, ld, jac_diag, jsh,
+               1e-14 * (p->aNorm >= 0.0 ? p->aNorm : 1.0), w, ld, s->d_red));
+         CHK(pa_reduce(s, s->d_red, 2 * blockSize, 0, 0));
+         for (i = 0; i < blockSize; i++) { dot_sol[i] = s->h_red[i]; rho_new[i] = s->h_red[blockSize + i]; }
+         p->stats.numPreconds += blockSize;
+         p->stats.timePrecond += pa_wtime() - t0;
+         have_w = 1;
+      } else {
+         CHK(hipk_qmr_update(s->ctx, s->dt, s->m, blockSize, gam_c, eta_c, d, ld, delta, ld, sol, ld, s->d_red));
+         if (adaptive) {
+            CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
+            for (i = 0; i < blockSize; i++) dot_sol[i] = s->h_red[i];
+         }
       }
 
       conv = 0;
@@ -418,13 +458,20 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
             if (numIts > 0 && isConv) { perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue; }
          }
       }
+      if (have_w && conv > 0) {
+         CHK(permute_panel(s, w, ld, blockSize, p0));
+         pa_permute_cols(rho_new, 1, blockSize, 1, p0);
+      }
       SHRINK();
       if (blockSize <= 0) break;
 
       if (numIts + 1 < maxIterations) {
          if (!plain_K) {
-            CHK(apply_projected_preconditioner(s, g, ld, P, blockSize, w, ld));
-            CHK(pair_dots_host(s, g, ld, w, ld, blockSize, tmp));
+            if (have_w) { for (i = 0; i < blockSize; i++) tmp[i] = rho_new[i]; }
+            else {
+               CHK(apply_projected_preconditioner(s, g, ld, P, blockSize, w, ld));
+               CHK(pair_dots_host(s, g, ld, w, ld, blockSize, tmp));
+            }
          }
          double beta[64];
          for (i = 0; i < blockSize; i++) {

@@ -1446,6 +1446,47 @@ qmr_update_kernel(ColScal gam, ColScal eta, const T *__restrict__ D, int64_t ldD
    }
 }
 
+/* The QMR step and the next application of the Jacobi preconditioner in one pass (block QMR):
+ *    delta = gamma delta + eta d;  sol += delta;  out[c] = |sol(:,c)|^2
+ *    w = g ./ (diag - shift[c]);                  out[nx + c] = g(:,c)' w(:,c)
+ * Three launches of the unfused sequence (qmr_update, jacobi, pair_dots) read g twice and w once more
+ * than this does (reference inner_solve.c:384-397 fuses the first line on the CPU; :619-634 is the second). */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+qmr_update_jacobi_kernel(ColScal gam, ColScal eta, ColScal shf, double min_den, const T *__restrict__ D, int64_t ldD,
+      T *__restrict__ Delta, int64_t ldDelta, T *__restrict__ Sol, int64_t ldSol, const T *__restrict__ G, int64_t ldG,
+      const T *__restrict__ diag, T *__restrict__ Wp, int64_t ldW, int nx, int64_t m, double *__restrict__ partials) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][2];
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *d = D + (size_t)c * ldD, *g = G + (size_t)c * ldG;
+      T *de = Delta + (size_t)c * ldDelta, *so = Sol + (size_t)c * ldSol, *w = Wp + (size_t)c * ldW;
+      const double gm = gam.a[c], e = eta.a[c], sh = shf.a[c];
+      double s1 = 0.0, s2 = 0.0;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+         const T nd = (T)fma((double)de[i], gm, (double)d[i] * e);
+         de[i] = nd;
+         const T ns = (T)((double)nd + (double)so[i]);
+         so[i] = ns;
+         s1 = fma((double)ns, (double)ns, s1);
+         double den = (double)diag[i] - sh;
+         if (!(fabs(den) > min_den)) den = copysign(min_den, den);
+         const double gi = (double)g[i];
+         const T wi = (T)(gi / den);
+         w[i] = wi;
+         s2 = fma(gi, (double)wi, s2);
+      }
+      s1 = hipk_wave_sum(s1); s2 = hipk_wave_sum(s2);
+      if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = s1; sm[threadIdx.x >> 6][1] = s2; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+         partials[(size_t)blockIdx.x * 2 * nx + c] = (sm[0][0] + sm[1][0]) + (sm[2][0] + sm[3][0]);
+         partials[(size_t)blockIdx.x * 2 * nx + nx + c] = (sm[0][1] + sm[1][1]) + (sm[2][1] + sm[3][1]);
+      }
+      __syncthreads();
+   }
+}
+
 #define DISPATCH_RT(dt, CALL_D, CALL_F)         \
    switch (dt) {                                \
    case HIPK_F64: { typedef double T; CALL_D; } break; \
@@ -1618,4 +1659,22 @@ extern "C" int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, 
          hipLaunchKernelGGL(qmr_update_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, nx, m, ctx->partials));
    HIPK_CHECK(hipGetLastError());
    return hipk_finalize_partials(ctx, ctx->partials, gx, nx, dotsol_dev);
+}
+
+extern "C" int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gamma_host,
+      const double *eta_host, const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol,
+      const void *G, int64_t ldG, const void *diag, const double *shift_host, double min_den, void *W, int64_t ldW,
+      double *out_dev) {
+   if (nx <= 0) return 0;
+   if (nx > UTIL_MAXCOLS) return -1;
+   if (!(min_den > 0.0)) min_den = 1e-300;
+   ColScal g, e, sh;
+   for (int c = 0; c < nx; c++) { g.a[c] = gamma_host[c]; e.a[c] = eta_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * 2 * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(qmr_update_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, sh, min_den, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, (T *)W, ldW, nx, m, ctx->partials),
+         hipLaunchKernelGGL(qmr_update_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, sh, min_den, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, (T *)W, ldW, nx, m, ctx->partials));
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, 2 * nx, out_dev);
 }

@@ -16,6 +16,7 @@
  */
 #include "hipk_internal.h"
 #include <vector>
+#include <limits.h>
 
 #define TILE_NNZ 2048
 #define TILE_ROWS 256
@@ -31,6 +32,8 @@ struct hipk_csr {
    void *values;               /* device */
    int32_t *tiles;             /* device: ntiles+1 row offsets */
    int4 *tileinfo;             /* device: {first row, end row, first nonzero, end nonzero} per tile */
+   int2 *twin;                 /* device: {first column, window width} per tile; width 0 = not windowable */
+   int windowed;               /* most tiles have a narrow column window inside the owned slab */
    int ntiles;
    void *diag;                 /* device, nrows elements */
    int64_t halo_lo, halo_hi;   /* extent of off-rank columns below / above */
@@ -258,6 +261,111 @@ csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32
    }
 }
 
+/* The same with the x WINDOW of the tile staged in LDS.  For banded, block-diagonal and 2-D
+ * stencil matrices the column indices of a tile's nonzeros span a few hundred rows of x: that slice
+ * of the block of vectors ([cmin, cmin + cw) x ncols, at most XS_MAX values) is fetched from HBM
+ * with coalesced loads — every x entry the tile needs comes in ONCE per tile instead of once per
+ * nonzero through a scattered 8-byte L2 access — and the row walk gathers from LDS.  Tiles whose
+ * window is too wide or reaches outside the owned slab (twin.y == 0) use the global gathers.
+ * shift != NULL: y = A x - shift[c] x(:,c), the first update of the projected operator in the
+ * JDQMR inner iteration (reference inner_solve.c:853-858) fused into the operator. */
+#define XS_MAX 3072
+struct SpmmShift { double s[64]; int on; };
+template <typename T, int NC>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restrict__ twin, int ntiles,
+      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, const T *__restrict__ val,
+      const T *__restrict__ x, int64_t ldx, T *__restrict__ y, int64_t ldy, int ncols, int64_t row0,
+      SpmmShift sh) {
+   __shared__ T sval[TILE_NNZ];
+   __shared__ int32_t scol[TILE_NNZ];
+   __shared__ int rp[TILE_ROWS + 1];
+   __shared__ double xs[XS_MAX];                 /* xs[w * ncols + c] = x(cmin + w, c) */
+   const int tile = xcd_tile(blockIdx.x, ntiles);
+   if (tile >= ntiles) return;
+   const int4 ti = tileinfo[tile];
+   const int2 tw = twin[tile];
+   const int r0 = ti.x, r1 = ti.y, p0 = ti.z, nz = ti.w - ti.z, nr = r1 - r0;
+   const int cmin = tw.x, cw = tw.y;
+   const bool win = cw > 0 && cw * ncols <= XS_MAX && nz <= TILE_NNZ;
+   if (nz <= TILE_NNZ) {
+      for (int q = threadIdx.x; q < nz; q += HIPK_BLOCK) { sval[q] = val[p0 + q]; scol[q] = colind[p0 + q] - (win ? cmin : 0); }
+      for (int r = threadIdx.x; r <= nr; r += HIPK_BLOCK) rp[r] = rowptr[r0 + r] - p0;
+      if (win) {
+         /* coalesced along the window for each column; LDS rows are ncols apart */
+         for (int idx = threadIdx.x; idx < cw * ncols; idx += HIPK_BLOCK) {
+            const int c = idx / cw, w = idx - c * cw;
+            xs[w * ncols + c] = (double)x[(int64_t)cmin - row0 + w + (size_t)c * ldx];
+         }
+      }
+      __syncthreads();
+      const int ngroups = (ncols + NC - 1) / NC;
+      for (int idx = threadIdx.x; idx < nr * ngroups; idx += HIPK_BLOCK) {
+         const int g = idx / nr, r = idx - g * nr, c0 = g * NC;
+         double acc[NC];
+#pragma unroll
+         for (int c = 0; c < NC; c++) acc[c] = 0.0;
+         const int qa = rp[r], qb = rp[r + 1];
+         if (win) {
+            int cofs[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) cofs[c] = (c0 + c < ncols) ? c0 + c : ncols - 1;
+            for (int q = qa; q < qb; q++) {
+               const double v = (double)sval[q];
+               const double *xr = xs + scol[q] * ncols;
+#pragma unroll
+               for (int c = 0; c < NC; c++) acc[c] = fma(v, xr[cofs[c]], acc[c]);
+            }
+         } else {
+            const T *xg[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) xg[c] = x + (size_t)((c0 + c < ncols) ? c0 + c : ncols - 1) * ldx - row0;
+            const int64_t self = row0;
+            for (int q = qa; q < qb; q += 4) {
+               double v[4];
+               int64_t gc[4];
+#pragma unroll
+               for (int u = 0; u < 4; u++) {
+                  const bool ok = q + u < qb;
+                  v[u] = ok ? (double)sval[ok ? q + u : qa] : 0.0;
+                  gc[u] = ok ? (int64_t)scol[ok ? q + u : qa] : self;
+               }
+#pragma unroll
+               for (int u = 0; u < 4; u++)
+#pragma unroll
+                  for (int c = 0; c < NC; c++) acc[c] = fma(v[u], (double)xg[c][gc[u]], acc[c]);
+            }
+         }
+#pragma unroll
+         for (int c = 0; c < NC; c++)
+            if (c0 + c < ncols) {
+               double out = acc[c];
+               if (sh.on) out = fma(-sh.s[c0 + c], (double)x[(int64_t)(r0 + r) + (size_t)(c0 + c) * ldx], out);
+               y[r0 + r + (size_t)(c0 + c) * ldy] = (T)out;
+            }
+      }
+   } else {
+      __shared__ double red[HIPK_BLOCK / HIPK_WAVE];
+      for (int c = 0; c < ncols; c++) {
+         const T *xc = x + (size_t)c * ldx - row0;
+         for (int r = r0; r < r1; r++) {
+            const int a = rowptr[r], b = rowptr[r + 1];
+            double sum = 0.0;
+            for (int q = a + threadIdx.x; q < b; q += HIPK_BLOCK) sum = fma((double)val[q], (double)xc[colind[q]], sum);
+            sum = hipk_wave_sum(sum);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+               double out = (red[0] + red[1]) + (red[2] + red[3]);
+               if (sh.on) out = fma(-sh.s[c], (double)xc[row0 + r], out);
+               y[r + (size_t)c * ldy] = (T)out;
+            }
+            __syncthreads();
+         }
+      }
+   }
+}
+
 /* Laplacian stencil: diag 2*dims, -1 to each grid neighbour, Dirichlet boundary. */
 template <typename T>
 __global__ void __launch_bounds__(HIPK_BLOCK)
@@ -365,13 +473,29 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
    A->halo_lo = lo; A->halo_hi = hi; A->ld_lo = lo; A->ld_hi = hi;
    A->ntiles = (int)tiles.size() - 1;
    std::vector<int4> tinfo((size_t)A->ntiles + 1);
-   for (int t = 0; t < A->ntiles; t++) tinfo[t] = make_int4(tiles[t], tiles[t + 1], rowptr_host[tiles[t]], rowptr_host[tiles[t + 1]]);
+   std::vector<int2> twin((size_t)A->ntiles + 1);
+   int64_t narrow = 0;
+   for (int t = 0; t < A->ntiles; t++) {
+      tinfo[t] = make_int4(tiles[t], tiles[t + 1], rowptr_host[tiles[t]], rowptr_host[tiles[t + 1]]);
+      int64_t cmin = INT64_MAX, cmax = -1;
+      for (int32_t p = rowptr_host[tiles[t]]; p < rowptr_host[tiles[t + 1]]; p++) {
+         const int64_t g = colind_host[p];
+         if (g < cmin) cmin = g;
+         if (g > cmax) cmax = g;
+      }
+      /* the shifted product also reads x at the tile's own rows: they are local by construction */
+      const bool inside = cmax >= cmin && cmin >= x0 && cmax < x0 + xlen && cmax - cmin + 1 <= XS_MAX;
+      twin[t] = inside ? make_int2((int)cmin, (int)(cmax - cmin + 1)) : make_int2(0, 0);
+      if (inside && (cmax - cmin + 1) * 8 <= XS_MAX) narrow++;
+   }
+   A->windowed = (lo == 0 && hi == 0 && A->ntiles > 0 && narrow * 10 >= (int64_t)A->ntiles * 9);
 
    if (hipk_malloc(ctx, (size_t)(nrows_local + 1) * 4, (void **)&A->rowptr) ||
          hipk_malloc(ctx, (size_t)(nnz + 1) * 4, (void **)&A->colind) ||       /* +1: clamped loads of an empty tile */
          hipk_malloc(ctx, (size_t)(nnz + 1) * es, &A->values) ||
          hipk_malloc(ctx, tiles.size() * 4, (void **)&A->tiles) ||
          hipk_malloc(ctx, tinfo.size() * sizeof(int4), (void **)&A->tileinfo) ||
+         hipk_malloc(ctx, twin.size() * sizeof(int2), (void **)&A->twin) ||
          hipk_malloc(ctx, (size_t)nrows_local * es, &A->diag))
       return -2;
    HIPK_CHECK(hipMemcpy(A->rowptr, rowptr_host, (size_t)(nrows_local + 1) * 4, hipMemcpyHostToDevice));
@@ -379,6 +503,7 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
    HIPK_CHECK(hipMemcpy(A->values, values_host, (size_t)nnz * es, hipMemcpyHostToDevice));
    HIPK_CHECK(hipMemcpy(A->tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
    HIPK_CHECK(hipMemcpy(A->tileinfo, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice));
+   HIPK_CHECK(hipMemcpy(A->twin, twin.data(), twin.size() * sizeof(int2), hipMemcpyHostToDevice));
    HIPK_CHECK(hipMemset((char *)A->colind + (size_t)nnz * 4, 0, 4));
    HIPK_CHECK(hipMemset((char *)A->values + (size_t)nnz * es, 0, es));
    HIPK_CHECK(hipMemcpy(A->diag, dg.data(), (size_t)nrows_local * es, hipMemcpyHostToDevice));
@@ -435,6 +560,7 @@ extern "C" int hipk_csr_destroy(hipk_csr *A) {
    if (A->values) (void)hipFree(A->values);
    if (A->tiles) (void)hipFree(A->tiles);
    if (A->tileinfo) (void)hipFree(A->tileinfo);
+   if (A->twin) (void)hipFree(A->twin);
    if (A->diag) (void)hipFree(A->diag);
    free(A);
    return 0;
@@ -454,7 +580,8 @@ extern "C" int hipk_csr_set_halo_ld(hipk_csr *A, const void *lo, int64_t ld_lo, 
 }
 
 template <typename T>
-static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx, T *y, int64_t ldy, int ncols) {
+static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx, T *y, int64_t ldy, int ncols,
+      const double *shift_host = NULL) {
    hipk_ctx *ctx = A->ctx;
    if ((A->halo_lo > 0 && !A->xlo) || (A->halo_hi > 0 && !A->xhi)) {
       fprintf(stderr, "primme_amd: matvec needs halo data (rows outside the local slab) but none was set\n");
@@ -474,9 +601,22 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
 #define LAUNCH_ROWS(NCV) hipLaunchKernelGGL((csr_rows_block_kernel<T, NCV>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, \
                A->tiles, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, \
                ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo, (const T *)A->xhi, A->ld_lo, A->ld_hi)
-      static int force = -1;                     /* HIPK_SPMM_NC: measurement knob, read once */
+      static int force = -1, nowin = -1;         /* HIPK_SPMM_NC, HIPK_NO_WINDOW: measurement knobs, read once */
       if (force < 0) { const char *env = getenv("HIPK_SPMM_NC"); force = env ? atoi(env) : 0; }
-      if (ncols == 1 && force == 0)
+      if (nowin < 0) nowin = getenv("HIPK_NO_WINDOW") != NULL;
+      const bool use_win = A->kind == 0 && A->halo_lo == 0 && A->halo_hi == 0 && ncols <= 64 &&
+                           ((A->windowed && ncols >= 2 && !nowin) || shift_host);
+      if (use_win) {
+         SpmmShift sh;
+         sh.on = shift_host != NULL;
+         for (int c = 0; c < 64; c++) sh.s[c] = (shift_host && c < ncols) ? shift_host[c] : 0.0;
+         if (ncols <= 2)
+            hipLaunchKernelGGL((csr_window_block_kernel<T, 2>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->tileinfo, A->twin,
+                  A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, ncols, A->x0, sh);
+         else
+            hipLaunchKernelGGL((csr_window_block_kernel<T, 4>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->tileinfo, A->twin,
+                  A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, ncols, A->x0, sh);
+      } else if (ncols == 1 && force == 0)
          hipLaunchKernelGGL((csr_stream_kernel<T, false>), dim3(gx), dim3(HIPK_BLOCK), 0, stream,
                A->tileinfo, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
                ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo,
@@ -497,6 +637,17 @@ extern "C" int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int
    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : A->ctx->stream;
    if (A->dt == HIPK_F64) return csr_matvec_t<double>(A, st, (const double *)x, ldx, (double *)y, ldy, ncols);
    return csr_matvec_t<float>(A, st, (const float *)x, ldx, (float *)y, ldy, ncols);
+}
+
+/* y = A x - shift[c] x(:,c) in one launch (square CSR operators without halo; returns 1 when the
+ * operator is not covered and the caller should apply the shift itself) */
+extern "C" int hipk_csr_matvec_shifted(hipk_csr *A, void *hip_stream, const void *x, int64_t ldx, void *y, int64_t ldy,
+      int ncols, const double *shift_host) {
+   if (ncols <= 0 || A->nrows == 0) return 0;
+   if (A->kind != 0 || A->halo_lo != 0 || A->halo_hi != 0 || A->x0 != A->row0 || A->xlen != A->nrows || ncols > 64 || !shift_host) return 1;
+   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : A->ctx->stream;
+   if (A->dt == HIPK_F64) return csr_matvec_t<double>(A, st, (const double *)x, ldx, (double *)y, ldy, ncols, shift_host);
+   return csr_matvec_t<float>(A, st, (const float *)x, ldx, (float *)y, ldy, ncols, shift_host);
 }
 
 /* y = A (a x), xout = a x, dot_dev[0] = xout' y with a = 1/sqrt(norm2_dev[0]) — see csr_stream_kernel<T, true>.

@@ -289,6 +289,16 @@ def _csr_cases():
     yield "lap3d", rp, ci, va, n
     rp, ci, va, n = problems.laplacian_csr((300, 211))
     yield "lap2d", rp, ci, va, n
+    # banded, ~17 nonzeros per row inside a +-40 band: every tile's column window is narrow, which is the
+    # case the LDS-windowed block kernel takes (block-diagonal / banded matrices, BASELINE configs[2])
+    rng = np.random.default_rng(8)
+    n = 30011
+    rows = np.repeat(np.arange(n), 17)
+    cols = np.clip(rows + rng.integers(-40, 41, size=rows.size), 0, n - 1)
+    key = np.unique(rows.astype(np.int64) * n + cols)
+    rows, cols = (key // n).astype(np.int64), (key % n).astype(np.int32)
+    rp = np.zeros(n + 1, dtype=np.int64); np.add.at(rp, rows + 1, 1); rp = np.cumsum(rp)
+    yield "banded", rp.astype(np.int32), cols, rng.standard_normal(cols.size), n
     # ragged: empty rows, one very long row (> LDS tile), random short rows
     rng = np.random.default_rng(2)
     n = 5000
@@ -323,6 +333,65 @@ def test_csr_matvec(built, dt, ncols):
         tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
         assert np.max(np.abs(res[0] - res[1])) <= tol * (1 + np.abs(res[1]).max()), name
         assert np.max(np.abs(res[1] - ref)) <= tol * (1 + np.abs(ref).max()), name
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("ncols", [2, 8])
+def test_csr_matvec_shifted(built, dt, ncols):
+    """y = A x - shift[c] x(:,c) in one launch (the first update of the projected operator of the JDQMR inner
+    iteration fused into the SpMM), windowed and gather tiles alike"""
+    npdt = NPDT[dt]
+    for name, rp, ci, va, n in _csr_cases():
+        rng = np.random.default_rng(n + ncols)
+        ld = n + 2
+        X = rng.standard_normal((ncols, ld)).astype(npdt)
+        shifts = rng.standard_normal(ncols) * 3
+        res = []
+        for side in (Dev(), Host()):
+            A = C.c_void_p()
+            vv = np.ascontiguousarray(va, dtype=npdt)
+            assert side.lib.hipk_csr_create(side.ctx, dt, n, n, 0, rp.ctypes.data_as(C.c_void_p),
+                                            ci.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+            x = side.arr(X); y = side.arr(np.zeros_like(X))
+            sh = (C.c_double * ncols)(*shifts)
+            assert side.lib.hipk_csr_matvec_shifted(A, None, side.ptr(x), ld, side.ptr(y), ld, ncols, sh) == 0
+            res.append(side.get(y)[:, :n])
+            side.lib.hipk_csr_destroy(A)
+            side.close()
+        ref = problems.csr_matvec_numpy(rp, ci, va.astype(npdt).astype(np.float64), X[:, :n].T.astype(np.float64)).T - shifts[:, None] * X[:, :n]
+        tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+        assert np.max(np.abs(res[0] - res[1])) <= tol * (1 + np.abs(res[1]).max()), name
+        assert np.max(np.abs(res[1] - ref)) <= tol * (1 + np.abs(ref).max()), name
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+def test_qmr_update_with_jacobi(built, dt):
+    """delta = gamma delta + eta d; sol += delta; |sol|^2 and w = g ./ (diag - shift), g'w in one pass"""
+    rng = np.random.default_rng(21)
+    npdt = NPDT[dt]
+    m, ld, nx = 90001, 90004, 5
+    D, De, So, G = (rng.standard_normal((nx, ld)).astype(npdt) for _ in range(4))
+    diag = (2.0 + rng.random(m)).astype(npdt); diag[7] = 1.0     # shift 1.0 makes this denominator zero -> clamped
+    gam, eta, sh = rng.standard_normal(nx), rng.standard_normal(nx), np.array([1.0, 0.3, -2.0, 0.0, 1.5])
+    res = []
+    for side in (Dev(), Host()):
+        d, de, so, g = side.arr(D), side.arr(De), side.arr(So), side.arr(G)
+        dg = side.arr(diag); w = side.arr(np.zeros((nx, ld), dtype=npdt)); out = side.arr(np.zeros(2 * nx))
+        a = lambda v: (C.c_double * nx)(*v)
+        assert side.lib.hipk_qmr_update_jacobi(side.ctx, dt, m, nx, a(gam), a(eta), side.ptr(d), ld, side.ptr(de), ld, side.ptr(so), ld,
+                                               side.ptr(g), ld, side.ptr(dg), a(sh), C.c_double(1e-10), side.ptr(w), ld, side.ptr(out)) == 0
+        res.append([side.get(t) for t in (de, so, w, out)])
+        side.close()
+    tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+    de_ref = De[:, :m].astype(np.float64) * gam[:, None] + D[:, :m].astype(np.float64) * eta[:, None]
+    den = diag.astype(np.float64)[None, :] - sh[:, None]
+    den = np.where(np.abs(den) > 1e-10, den, np.copysign(1e-10, den))
+    w_ref = G[:, :m].astype(np.float64) / den
+    for a_, b_ in zip(res[0][:3], res[1][:3]):
+        assert np.max(np.abs(a_[:, :m] - b_[:, :m]) / (1 + np.abs(b_[:, :m]))) <= tol * 10
+    assert np.max(np.abs(res[1][0][:, :m] - de_ref)) <= tol * 10 * (1 + np.abs(de_ref).max())
+    assert np.max(np.abs(res[1][2][:, :m] - w_ref) / (1 + np.abs(w_ref))) <= tol * 10
+    assert np.max(np.abs(res[0][3] - res[1][3]) / (1 + np.abs(res[1][3]))) <= tol * np.sqrt(m)
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
