@@ -36,6 +36,7 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
       ctx->flag_dev = (unsigned long long *)fd;
       HIPK_CHECK(hipMalloc((void **)&ctx->fin_counter, 64));
       HIPK_CHECK(hipMemset(ctx->fin_counter, 0, 64));
+      ctx->arrive_counter = ctx->fin_counter + 8;
       ctx->seq_issued = 0;
       ctx->spin_wait = getenv("HIPK_NO_SPINWAIT") == NULL;
    }
@@ -166,6 +167,32 @@ hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
       if (out_host) out_host[o] = v;
       hipk_publish_flag(fin, gridDim.x);
    }
+}
+
+/* o-major partials: one block per output, coalesced reads */
+__global__ void __launch_bounds__(HIPK_BLOCK)
+hipk_finalize_t_kernel(const double *__restrict__ partials, int nblocks, int nout,
+      double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int o = blockIdx.x;
+   double s = 0.0;
+   for (int b = threadIdx.x; b < nblocks; b += HIPK_BLOCK) s += partials[(size_t)o * nblocks + b];
+   s = hipk_wave_sum(s);
+   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      const double v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      out[o] = v;
+      if (out_host) out_host[o] = v;
+      hipk_publish_flag(fin, gridDim.x);
+   }
+}
+int hipk_finalize_partials_t(hipk_ctx *ctx, const double *partials, int nblocks, int nout, double *out_dev) {
+   if (nout <= 0) return 0;
+   hipLaunchKernelGGL(hipk_finalize_t_kernel, dim3(nout), dim3(HIPK_BLOCK), 0, ctx->stream,
+         partials, nblocks, nout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
+   HIPK_CHECK(hipGetLastError());
+   return 0;
 }
 
 int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, int nout,

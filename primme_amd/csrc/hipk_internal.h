@@ -32,6 +32,7 @@ struct hipk_ctx {
    volatile unsigned long long *flag_host;   /* pinned, host address */
    unsigned long long *flag_dev;             /* the same word, device address */
    unsigned int *fin_counter;                /* device: blocks of the running finalize launch that are done */
+   unsigned int *arrive_counter;             /* device: arrival ticket of the in-kernel second stage (fin_counter + 16) */
    unsigned long long seq_issued;            /* sequence number of the last finalize launch with a mirror */
    int spin_wait;                            /* 0: always hipStreamSynchronize (HIPK_NO_SPINWAIT) */
 };
@@ -67,11 +68,37 @@ static inline hipk_fin_flag hipk_next_flag(hipk_ctx *ctx, const double *out_dev)
    if (ctx->flag_dev && hipk_mirror_of(ctx, out_dev)) { f.flag = ctx->flag_dev; f.counter = ctx->fin_counter; f.seq = ++ctx->seq_issued; }
    return f;
 }
+/* In-kernel second stage: the workgroup that arrives last adds the per-block partials itself (fixed
+ * order, so results stay bit-reproducible), stores the results in HBM and in the pinned mirror and
+ * publishes the completion flag — no separate finalize launch behind the hot kernels of the
+ * block-size-1 iteration.  Arguments a kernel needs for it; enabled == 0: the kernel only writes its
+ * partials (o-major: partials[o * nblocks + block]) and a finalize launch follows. */
+struct hipk_fin_args {
+   double *out, *out_host;          /* results (device) and their pinned mirror (device address, may be NULL) */
+   unsigned int *arrive;            /* device counter, zero between launches */
+   hipk_fin_flag flag;              /* completion flag record (flag == NULL: none) */
+   int enabled;
+};
+static inline int hipk_inkernel_fin_enabled(void) {   /* HIPK_NO_INKERNEL_FIN: measurement knob, read once */
+   static int v = -1;
+   if (v < 0) v = getenv("HIPK_NO_INKERNEL_FIN") == NULL;
+   return v;
+}
+static inline hipk_fin_args hipk_make_fin(hipk_ctx *ctx, double *out_dev) {
+   hipk_fin_args fa;
+   fa.out = out_dev; fa.out_host = hipk_mirror_of(ctx, out_dev); fa.arrive = ctx->arrive_counter;
+   fa.enabled = hipk_inkernel_fin_enabled() && ctx->arrive_counter != NULL;
+   fa.flag.flag = NULL; fa.flag.counter = NULL; fa.flag.seq = 0;
+   if (fa.enabled) fa.flag = hipk_next_flag(ctx, out_dev);
+   return fa;
+}
 /* make sure ctx->partials can hold n doubles */
 int hipk_reserve_partials(hipk_ctx *ctx, size_t n);
 /* out[o] = sum_b partials[b*nout + o], deterministic order */
 int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, int nout,
       double *out_dev);
+/* the same for o-major partials (partials[o * nblocks + b]) */
+int hipk_finalize_partials_t(hipk_ctx *ctx, const double *partials, int nblocks, int nout, double *out_dev);
 
 static inline int hipk_grid_for_rows(const hipk_ctx *ctx, int64_t m, int rows_per_block,
       int blocks_per_cu) {
@@ -101,11 +128,51 @@ __device__ __forceinline__ void hipk_publish_flag(const hipk_fin_flag &f, unsign
    }
 }
 
+__device__ __forceinline__ double hipk_wave_sum_fwd(double v);
+
+/* Called by EVERY thread of EVERY workgroup at the end of a kernel whose partials are o-major
+ * (partials[o * nblocks + block]); `s_last` is an int in LDS.  Hand-off as in cdna_hip_programming.md
+ * (in-launch split-K reduction): all stores drained, one agent-scope release per workgroup, relaxed
+ * ticket, the last arriver takes one agent-scope acquire and reads every slab with plain loads. */
+__device__ __forceinline__ void hipk_inkernel_finalize(const double *__restrict__ partials, int nout, unsigned nblocks,
+      const hipk_fin_args &fa, int *s_last) {
+   if (!fa.enabled) return;
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(fa.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_last = (t == nblocks - 1) ? 1 : 0;
+      if (t == nblocks - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+   }
+   __syncthreads();
+   if (!*s_last) return;
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+   for (int o = wv; o < nout; o += nw) {
+      const double *row = partials + (size_t)o * nblocks;
+      double acc = 0.0;
+      for (unsigned b = lane; b < nblocks; b += 64) acc += row[b];
+      acc = hipk_wave_sum_fwd(acc);
+      if (lane == 0) {
+         fa.out[o] = acc;
+         if (fa.out_host) fa.out_host[o] = acc;
+      }
+   }
+   __threadfence_system();            /* results (device + pinned) visible before the flag */
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      *fa.arrive = 0;
+      if (fa.flag.flag) *(volatile unsigned long long *)fa.flag.flag = fa.flag.seq;
+   }
+}
+
 __device__ __forceinline__ double hipk_wave_sum(double v) {
 #pragma unroll
    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
    return v;
 }
+__device__ __forceinline__ double hipk_wave_sum_fwd(double v) { return hipk_wave_sum(v); }
 #endif
 
 #endif

@@ -417,8 +417,9 @@ extern "C" int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hi
 template <typename T, int NX, int VW>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *X,
-      int64_t ldX, T *Xout, int64_t ldXout, int nx, int c0, int64_t m, double *__restrict__ partials) {
+      int64_t ldX, T *Xout, int64_t ldXout, int nx, int c0, int64_t m, double *__restrict__ partials, hipk_fin_args fa) {
    typedef lanevec<T, VW> LV;
+   __shared__ int s_last;
    __shared__ double scoef[PROJ_MAXCOLS * NX];
    __shared__ const T *sptr[PROJ_MAXCOLS];
    const int total = segs.total;
@@ -507,8 +508,9 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *X,
       }
       __syncthreads();
       if (threadIdx.x < nxv)
-         partials[(size_t)blockIdx.x * nx + c0 + threadIdx.x] =
+         partials[(size_t)(c0 + threadIdx.x) * gridDim.x + blockIdx.x] =
                (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+      hipk_inkernel_finalize(partials, nx, gridDim.x, fa, &s_last);
    }
 }
 
@@ -636,19 +638,23 @@ static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
    if (nrm2_dev && hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
    double *part = nrm2_dev ? ctx->partials : NULL;
    dim3 block(HIPK_BLOCK);
+   /* one launch covers all columns: its last workgroup finalises the norms itself */
+   hipk_fin_args fa;
+   memset(&fa, 0, sizeof(fa));
+   if (nrm2_dev && (nx == 1 || nx == 2 || nx == 4 || nx == 8)) fa = hipk_make_fin(ctx, nrm2_dev);
    const int pslot = hipk_prof_begin(HIPK_PROF_PROJECT, ctx->stream, (double)m * sizeof(T) * ((double)sa.total * ((nx + 7) / 8) + 2.0 * nx));
    for (int c0 = 0; c0 < nx;) {
       int rem = nx - c0;
       int step;
-      if (rem >= 8) { step = 8; hipLaunchKernelGGL((project_kernel<T, 8, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part); }
-      else if (rem >= 4) { step = 4; hipLaunchKernelGGL((project_kernel<T, 4, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part); }
-      else if (rem >= 2) { step = 2; hipLaunchKernelGGL((project_kernel<T, 2, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part); }
-      else { step = 1; hipLaunchKernelGGL((project_kernel<T, 1, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part); }
+      if (rem >= 8) { step = 8; hipLaunchKernelGGL((project_kernel<T, 8, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part, fa); }
+      else if (rem >= 4) { step = 4; hipLaunchKernelGGL((project_kernel<T, 4, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part, fa); }
+      else if (rem >= 2) { step = 2; hipLaunchKernelGGL((project_kernel<T, 2, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part, fa); }
+      else { step = 1; hipLaunchKernelGGL((project_kernel<T, 1, VW>), dim3(gx), block, 0, ctx->stream, sa, coef, ldcoef, X, ldX, Xout, ldXout, nx, c0, m, part, fa); }
       HIPK_CHECK(hipGetLastError());
       c0 += step;
    }
    hipk_prof_end(pslot, ctx->stream);
-   if (nrm2_dev) return hipk_finalize_partials(ctx, ctx->partials, gx, nx, nrm2_dev);
+   if (nrm2_dev && !fa.enabled) return hipk_finalize_partials_t(ctx, ctx->partials, gx, nx, nrm2_dev);
    return 0;
 }
 
@@ -1011,10 +1017,11 @@ template <typename T, int CPW, int QPW, int VW, bool WT>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
       HCol hcol, double theta, T *__restrict__ dst, const T *__restrict__ Q,
-      int64_t ldQ, int L, int64_t m, double *__restrict__ partials, int blocked) {
+      int64_t ldQ, int L, int64_t m, double *__restrict__ partials, int blocked, hipk_fin_args fa) {
    typedef lanevec<T, VW> LV;
    constexpr int QN = QPW > 0 ? QPW : 1;
    __shared__ double sxy[2][2][VW][4][64];       /* [buffer][x|y][row in lane][wave][lane] */
+   __shared__ int s_last;
    const int lane = threadIdx.x & 63;
    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const int j0 = wv * CPW, q0 = wv * QPW;
@@ -1146,31 +1153,33 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
          }
       }
    }
-   /* every output belongs to exactly one wave: wave sums go straight to the block's partial row
-    * [ V'r (k) | Q'r (L) | r'r | W'r (k) | W(:,k-1)'Q (L) ] */
+   /* every output belongs to exactly one wave: wave sums go straight to the block's partials, o-major
+    * (partials[o * nblocks + block]), o over [ V'r (k) | Q'r (L) | r'r | W'r (k) | W(:,k-1)'Q (L) ] */
    const int nout = k + L + 1 + (WT ? k + L : 0);
-   double *prow = partials + (size_t)blockIdx.x * nout;
+   const size_t nb = gridDim.x;
+   double *pcol = partials + blockIdx.x;
 #pragma unroll
    for (int jj = 0; jj < CPW; jj++) {
       const double t = hipk_wave_sum(ov[jj]);
-      if (lane == 0 && j0 + jj < k) prow[j0 + jj] = t;
+      if (lane == 0 && j0 + jj < k) pcol[(size_t)(j0 + jj) * nb] = t;
       if (WT) {
          const double u = hipk_wave_sum(ow[WT ? jj : 0]);
-         if (lane == 0 && j0 + jj < k) prow[k + L + 1 + j0 + jj] = u;
+         if (lane == 0 && j0 + jj < k) pcol[(size_t)(k + L + 1 + j0 + jj) * nb] = u;
       }
    }
    if (QPW > 0) {
 #pragma unroll
       for (int qq = 0; qq < QN; qq++) {
          const double t = hipk_wave_sum(oq[qq]);
-         if (lane == 0 && q0 + qq < L) prow[k + q0 + qq] = t;
+         if (lane == 0 && q0 + qq < L) pcol[(size_t)(k + q0 + qq) * nb] = t;
          if (WT) {
             const double u = hipk_wave_sum(og[WT ? qq : 0]);
-            if (lane == 0 && q0 + qq < L) prow[2 * k + L + 1 + q0 + qq] = u;
+            if (lane == 0 && q0 + qq < L) pcol[(size_t)(2 * k + L + 1 + q0 + qq) * nb] = u;
          }
       }
    }
-   { const double t = hipk_wave_sum(n2); if (lane == 0 && wv == 0) prow[k + L] = t; }
+   { const double t = hipk_wave_sum(n2); if (lane == 0 && wv == 0) pcol[(size_t)(k + L) * nb] = t; }
+   hipk_inkernel_finalize(partials, nout, gridDim.x, fa, &s_last);
 }
 
 static int rcgs_blocked(void) {               /* HIPK_RCGS_BLOCKED: measurement knob, read once */
@@ -1181,9 +1190,9 @@ static int rcgs_blocked(void) {               /* HIPK_RCGS_BLOCKED: measurement 
 
 template <typename T, int CPW, int VW, bool WT>
 static int ritz_cgs_q(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
-      double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m) {
+      double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m, const hipk_fin_args &fa) {
    dim3 g(gx), b(HIPK_BLOCK);
-#define RCGS(QPWV) hipLaunchKernelGGL((ritz_cgs_kernel<T, CPW, QPWV, VW, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials, rcgs_blocked())
+#define RCGS(QPWV) hipLaunchKernelGGL((ritz_cgs_kernel<T, CPW, QPWV, VW, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials, rcgs_blocked(), fa)
    if (L == 0) RCGS(0);
    else if (L <= 8) RCGS(2);
    else if (L <= 16) RCGS(4);
@@ -1196,11 +1205,11 @@ static int ritz_cgs_q(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld,
 
 template <typename T, int VW, bool WT>
 static int ritz_cgs_k(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
-      double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m) {
-   if (k <= 8) return ritz_cgs_q<T, 2, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   if (k <= 16) return ritz_cgs_q<T, 4, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   if (k <= 24) return ritz_cgs_q<T, 6, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   return ritz_cgs_q<T, 8, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+      double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m, const hipk_fin_args &fa) {
+   if (k <= 8) return ritz_cgs_q<T, 2, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
+   if (k <= 16) return ritz_cgs_q<T, 4, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
+   if (k <= 24) return ritz_cgs_q<T, 6, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
+   return ritz_cgs_q<T, 8, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
 }
 
 template <typename T>
@@ -1220,13 +1229,15 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + 1));
    int rc;
-   if (vec) rc = want_wtr ? ritz_cgs_k<T, VWT, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m)
-                          : ritz_cgs_k<T, VWT, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
-   else rc = want_wtr ? ritz_cgs_k<T, 1, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m)
-                      : ritz_cgs_k<T, 1, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m);
+   const hipk_fin_args fa = hipk_make_fin(ctx, out_dev);
+   if (vec) rc = want_wtr ? ritz_cgs_k<T, VWT, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa)
+                          : ritz_cgs_k<T, VWT, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
+   else rc = want_wtr ? ritz_cgs_k<T, 1, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa)
+                      : ritz_cgs_k<T, 1, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
    hipk_prof_end(pslot, ctx->stream);
    if (rc) return rc;
-   return hipk_finalize_partials(ctx, ctx->partials, gx, nout, out_dev);
+   if (fa.enabled) return 0;                    /* the last workgroup finalised */
+   return hipk_finalize_partials_t(ctx, ctx->partials, gx, nout, out_dev);
 }
 
 extern "C" int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,

@@ -81,8 +81,9 @@ csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *
       int64_t ldx, T *__restrict__ y, int64_t ldy, int ncols, int64_t row0, int64_t nrows,
       int64_t halo_lo, int64_t halo_hi, const T *__restrict__ xlo, const T *__restrict__ xhi,
       int64_t ld_lo, int64_t ld_hi, const double *__restrict__ norm2, T *__restrict__ xout,
-      double *__restrict__ partials) {
+      double *__restrict__ partials, hipk_fin_args fa) {
    __shared__ double prod[TILE_NNZ];
+   __shared__ int s_last;
    const int tile = xcd_tile(blockIdx.x, ntiles);
    double dotp = 0.0;
    if (tile < ntiles) {
@@ -168,6 +169,7 @@ csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
       __syncthreads();
       if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      hipk_inkernel_finalize(partials, 1, gridDim.x, fa, &s_last);
    }
 }
 
@@ -620,7 +622,7 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
          hipLaunchKernelGGL((csr_stream_kernel<T, false>), dim3(gx), dim3(HIPK_BLOCK), 0, stream,
                A->tileinfo, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
                ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo,
-               (const T *)A->xhi, A->ld_lo, A->ld_hi, (const double *)NULL, (T *)NULL, (double *)NULL);
+               (const T *)A->xhi, A->ld_lo, A->ld_hi, (const double *)NULL, (T *)NULL, (double *)NULL, hipk_fin_args());
       else if (force == 1) LAUNCH_ROWS(1);
       else if (force == 2 || (force == 0 && ncols <= 2)) LAUNCH_ROWS(2);
       else LAUNCH_ROWS(4);
@@ -663,17 +665,19 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    const int gx = ((A->ntiles + 7) / 8) * 8;
    if (hipk_reserve_partials(ctx, (size_t)gx)) return -2;
    const double es = A->dt == HIPK_F64 ? 8 : 4;
+   const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev);
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
    if (A->dt == HIPK_F64)
       hipLaunchKernelGGL((csr_stream_kernel<double, true>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr,
             A->colind, (const double *)A->values, (const double *)x, A->nrows, (double *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo,
-            A->halo_hi, (const double *)A->xlo, (const double *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (double *)xout, ctx->partials);
+            A->halo_hi, (const double *)A->xlo, (const double *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (double *)xout, ctx->partials, fa);
    else
       hipLaunchKernelGGL((csr_stream_kernel<float, true>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr,
             A->colind, (const float *)A->values, (const float *)x, A->nrows, (float *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo,
-            A->halo_hi, (const float *)A->xlo, (const float *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (float *)xout, ctx->partials);
+            A->halo_hi, (const float *)A->xlo, (const float *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (float *)xout, ctx->partials, fa);
    hipk_prof_end(pslot, st);
    HIPK_CHECK(hipGetLastError());
+   if (fa.enabled) return 0;
    return hipk_finalize_partials(ctx, ctx->partials, gx, 1, dot_dev);
 }
 extern "C" int hipk_csr_kind(const hipk_csr *A) { return A->kind; }
