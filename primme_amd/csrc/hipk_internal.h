@@ -70,18 +70,23 @@ static inline hipk_fin_flag hipk_next_flag(hipk_ctx *ctx, const double *out_dev)
 }
 /* In-kernel second stage: the workgroup that arrives last adds the per-block partials itself (fixed
  * order, so results stay bit-reproducible), stores the results in HBM and in the pinned mirror and
- * publishes the completion flag — no separate finalize launch behind the hot kernels of the
- * block-size-1 iteration.  Arguments a kernel needs for it; enabled == 0: the kernel only writes its
- * partials (o-major: partials[o * nblocks + block]) and a finalize launch follows. */
+ * publishes the completion flag — no separate finalize launch.  Arguments a kernel needs for it;
+ * enabled == 0 (the default, see below): the kernel only writes its partials (o-major:
+ * partials[o * nblocks + block]) and a finalize launch follows. */
 struct hipk_fin_args {
    double *out, *out_host;          /* results (device) and their pinned mirror (device address, may be NULL) */
    unsigned int *arrive;            /* device counter, zero between launches */
    hipk_fin_flag flag;              /* completion flag record (flag == NULL: none) */
    int enabled;
 };
-static inline int hipk_inkernel_fin_enabled(void) {   /* HIPK_NO_INKERNEL_FIN: measurement knob, read once */
+/* OFF by default (HIPK_INKERNEL_FIN=1 turns it on, read once): measured on the MI355X it LOSES — every
+ * workgroup pays an agent-scope release (L2 write-back) before its ticket, and with the thousands of
+ * workgroups of the streaming kernels that costs far more than the finalize launch it saves
+ * (configs[1]: 588 us per outer iteration with it, 258 us without; the fused SpMV 326 us instead of 45).
+ * Kept as a correct, tested alternative for kernels with few workgroups. */
+static inline int hipk_inkernel_fin_enabled(void) {
    static int v = -1;
-   if (v < 0) v = getenv("HIPK_NO_INKERNEL_FIN") == NULL;
+   if (v < 0) v = getenv("HIPK_INKERNEL_FIN") != NULL;
    return v;
 }
 static inline hipk_fin_args hipk_make_fin(hipk_ctx *ctx, double *out_dev) {

@@ -196,8 +196,25 @@ csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32
    const bool local = (halo_lo == 0 && halo_hi == 0);
 
    if (nz <= TILE_NNZ) {
-      for (int q = threadIdx.x; q < nz; q += HIPK_BLOCK) { sval[q] = val[p0 + q]; scol[q] = colind[p0 + q]; }
-      for (int r = threadIdx.x; r <= nr; r += HIPK_BLOCK) rp[r] = rowptr[r0 + r] - p0;
+      {  /* all of this lane's (value, column) loads in flight at once: indices clamped, not predicated */
+         T tv[TILE_PER_LANE];
+         int32_t tc[TILE_PER_LANE];
+#pragma unroll
+         for (int u = 0; u < TILE_PER_LANE; u++) {
+            const int q = threadIdx.x + u * HIPK_BLOCK;
+            const int qc = q < nz ? q : (nz > 0 ? nz - 1 : 0);
+            tv[u] = val[p0 + qc]; tc[u] = colind[p0 + qc];
+         }
+         const int rr = threadIdx.x <= nr ? threadIdx.x : nr;
+         const int rpv = rowptr[r0 + rr] - p0;
+#pragma unroll
+         for (int u = 0; u < TILE_PER_LANE; u++) {
+            const int q = threadIdx.x + u * HIPK_BLOCK;
+            if (q < nz) { sval[q] = tv[u]; scol[q] = tc[u]; }
+         }
+         if (threadIdx.x <= nr) rp[threadIdx.x] = rpv;
+         if (threadIdx.x == 0 && nr == TILE_ROWS) rp[TILE_ROWS] = rowptr[r0 + TILE_ROWS] - p0;
+      }
       __syncthreads();
       const int ngroups = (ncols + NC - 1) / NC;
       for (int idx = threadIdx.x; idx < nr * ngroups; idx += HIPK_BLOCK) {
@@ -291,13 +308,42 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
    const int cmin = tw.x, cw = tw.y;
    const bool win = cw > 0 && cw * ncols <= XS_MAX && nz <= TILE_NNZ;
    if (nz <= TILE_NNZ) {
-      for (int q = threadIdx.x; q < nz; q += HIPK_BLOCK) { sval[q] = val[p0 + q]; scol[q] = colind[p0 + q] - (win ? cmin : 0); }
-      for (int r = threadIdx.x; r <= nr; r += HIPK_BLOCK) rp[r] = rowptr[r0 + r] - p0;
-      if (win) {
-         /* coalesced along the window for each column; LDS rows are ncols apart */
-         for (int idx = threadIdx.x; idx < cw * ncols; idx += HIPK_BLOCK) {
-            const int c = idx / cw, w = idx - c * cw;
-            xs[w * ncols + c] = (double)x[(int64_t)cmin - row0 + w + (size_t)c * ldx];
+      {  /* every load of the tile — (value, column) pairs, row pointers, the x window — is issued before
+          * the first LDS store: indices clamped, not predicated, so nothing branches around a load */
+         T tv[TILE_PER_LANE];
+         int32_t tc[TILE_PER_LANE];
+         T xw[XS_MAX / HIPK_BLOCK];
+#pragma unroll
+         for (int u = 0; u < TILE_PER_LANE; u++) {
+            const int q = threadIdx.x + u * HIPK_BLOCK;
+            const int qc = q < nz ? q : (nz > 0 ? nz - 1 : 0);
+            tv[u] = val[p0 + qc]; tc[u] = colind[p0 + qc];
+         }
+         const int rr = threadIdx.x <= nr ? threadIdx.x : nr;
+         const int rpv = rowptr[r0 + rr] - p0;
+         const int nxw = win ? cw * ncols : 0;
+         if (win) {
+#pragma unroll
+            for (int u = 0; u < XS_MAX / HIPK_BLOCK; u++) {
+               const int idx = threadIdx.x + u * HIPK_BLOCK;
+               const int ic = idx < nxw ? idx : nxw - 1;
+               const int c = ic / cw, w = ic - c * cw;          /* coalesced along the window for each column */
+               xw[u] = x[(int64_t)cmin - row0 + w + (size_t)c * ldx];
+            }
+         }
+#pragma unroll
+         for (int u = 0; u < TILE_PER_LANE; u++) {
+            const int q = threadIdx.x + u * HIPK_BLOCK;
+            if (q < nz) { sval[q] = tv[u]; scol[q] = tc[u] - (win ? cmin : 0); }
+         }
+         if (threadIdx.x <= nr) rp[threadIdx.x] = rpv;
+         if (threadIdx.x == 0 && nr == TILE_ROWS) rp[TILE_ROWS] = rowptr[r0 + TILE_ROWS] - p0;
+         if (win) {
+#pragma unroll
+            for (int u = 0; u < XS_MAX / HIPK_BLOCK; u++) {
+               const int idx = threadIdx.x + u * HIPK_BLOCK;
+               if (idx < nxw) { const int c = idx / cw, w = idx - c * cw; xs[w * ncols + c] = (double)xw[u]; }   /* LDS rows are ncols apart */
+            }
          }
       }
       __syncthreads();
