@@ -194,6 +194,15 @@ int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, cons
       const void *G, int64_t ldG, const void *diag, const double *shift_host, double min_denominator, void *W,
       int64_t ldW, double *out_dev);
 
+/* out_dev[c] = x_c' w_c, out_dev[nx + c] = v_c' w_c, out_dev[2 nx + c] = v_c' x_c in one pass: with them
+ * sigma = v'(I - x x')w = v'w - (x'w)(v'x) is known before the projected w is formed */
+int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *V, int64_t ldV,
+      const void *W, int64_t ldW, int nx, double *out_dev);
+/* g_c -= alpha_c (w_c - xr_c x_c), out_dev[c] = |g_c|^2: projection of w against x and the residual update of the
+ * QMR step in one pass, the projected w is never stored (inner_solve.c:853-880 followed by :371-377) */
+int hipk_axpy_proj_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha_host, const double *xr_host,
+      const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, double *out_dev);
+
 /* ---- sparse operator: the user matvec ------------------------------------------
  * Replaces the hipsparseSpMM-based callback of examples/ex_eigs_dhipblas.c:239-264
  * and the SPARSKIT amux of tests/COMMON/mat.c:64-90.

@@ -435,6 +435,36 @@ int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x, const doub
    return 0;
 }
 
+int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *V, int64_t ldV,
+      const void *W, int64_t ldW, int nx, double *out) {
+   (void)ctx;
+   for (int c = 0; c < nx; c++) {
+      const void *x = colp(dt, X, ldX, c), *v = colp(dt, V, ldV, c), *w = colp(dt, W, ldW, c);
+      double a = 0, b = 0, d = 0;
+      for (int64_t i = 0; i < m; i++) { a += ld_(dt, x, i) * ld_(dt, w, i); b += ld_(dt, v, i) * ld_(dt, w, i); d += ld_(dt, v, i) * ld_(dt, x, i); }
+      out[c] = a; out[nx + c] = b; out[2 * nx + c] = d;
+   }
+   mirror(out, (size_t)3 * nx);
+   return 0;
+}
+int hipk_axpy_proj_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha, const double *xr, const void *W,
+      int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, double *out) {
+   (void)ctx;
+   for (int c = 0; c < nx; c++) {
+      const void *w = colp(dt, W, ldW, c), *x = colp(dt, X, ldX, c);
+      void *g = (void *)colp(dt, G, ldG, c);
+      double s = 0;
+      for (int64_t i = 0; i < m; i++) {
+         double wp = ld_(dt, w, i) - xr[c] * ld_(dt, x, i);
+         if (dt == HIPK_F32) wp = (double)(float)wp;
+         st_(dt, g, i, ld_(dt, g, i) - alpha[c] * wp);
+         s += ld_(dt, g, i) * ld_(dt, g, i);
+      }
+      out[c] = s;
+   }
+   mirror(out, (size_t)nx);
+   return 0;
+}
 int hipk_csr_matvec_shifted(hipk_csr *A, void *stream, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols,
       const double *shift) {
    if (ncols <= 0 || A->nrows == 0) return 0;

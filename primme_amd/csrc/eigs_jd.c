@@ -203,8 +203,11 @@ static int skew_project_Q(pa_solver *s, const jd_proj *P, char *v, int64_t ldv, 
 /* result = (I - Q Q')(I - x x')... (A - shift) v, and vdot[c] = v_c' result_c.  The axpy of every
  * step is fused with the dot product that follows it (hipk_axpy_dot): same arithmetic as the
  * reference's separate Num_axpy / Num_dist_dots calls, two passes over the panels fewer. */
+/* xr_out != NULL (blocks): the projection against x is NOT applied to `result`; xr_out[c] = x_c' result_c and
+ * vdot[c] = v'(I - x x') result = v'result - (x'result)(v'x) come from one pass of three inner products
+ * (hipk_triple_dots), and the caller folds the projection into its update of g (hipk_axpy_proj_dot). */
 static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const double *shift, const jd_proj *P,
-      int nb, char *result, int64_t ldres, double *vdot) {
+      int nb, char *result, int64_t ldres, double *vdot, double *xr_out) {
    /* result = A v - shift v: in ONE launch when the operator is the library's own CSR matrix (the shift is
     * applied in the SpMM epilogue), otherwise the callback followed by an axpy */
    int shifted = 0;
@@ -225,6 +228,19 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
    for (int i = 0; i < nb; i++) ms[i] = -shift[i];
    if (P->nLX > 0) {
       double t0 = pa_wtime();
+      if (xr_out) {
+         if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
+         if (P->nLQ > 0) CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+         CHK(hipk_triple_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, v, ldv, result, ldres, nb, s->d_red));
+         CHK(pa_reduce(s, s->d_red, 3 * nb, 0, 0));
+         for (int i = 0; i < nb; i++) {
+            xr_out[i] = s->h_red[i];
+            vdot[i] = s->h_red[nb + i] - s->h_red[i] * s->h_red[2 * nb + i];
+         }
+         s->p->stats.numOrthoInnerProds += 3 * nb;
+         s->p->stats.timeOrtho += pa_wtime() - t0;
+         return 0;
+      }
       if (P->nLQ > 0) {
          if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
          CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
@@ -336,7 +352,11 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    for (i = 0; i < blockSize; i++) pm[i] = i;
 
    for (int64_t numIts = 0; numIts < maxIterations && blockSize > 0; numIts++) {
-      CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld, tmp));
+      /* blocks: the x-projection of w is folded into the update of g below (one pass and one
+       * synchronisation fewer per step); block size 1 keeps the reference's operation order */
+      const int fold_x = (b0 > 1 && P->nLX > 0);
+      double xr[64];
+      CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld, tmp, fold_x ? xr : NULL));
       for (i = 0; i < blockSize; i++) sigma_prev[pm[i]] = tmp[i];
 
       int conv = 0;
@@ -357,6 +377,11 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          malpha[i] = -alpha_prev[q];
       }
       /* g -= alpha w (0 for dropped columns) and g'g in the same pass */
+      if (fold_x) {
+         double al[64];
+         for (i = 0; i < blockSize; i++) al[i] = -malpha[i];
+         CHK(hipk_axpy_proj_dot(s->ctx, s->dt, s->m, blockSize, al, xr, w, ld, P->LX, P->ldLX, g, ld, s->d_red));
+      } else
       CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, blockSize, malpha, w, ld, g, ld, NULL, 0, s->d_red));
       CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
       for (i = 0; i < blockSize; i++) gg[i] = s->h_red[i];

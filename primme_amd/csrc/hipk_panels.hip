@@ -1498,6 +1498,58 @@ qmr_update_jacobi_kernel(ColScal gam, ColScal eta, ColScal shf, double min_den, 
    }
 }
 
+/* out[c] = x_c' w_c, out[nx + c] = v_c' w_c, out[2 nx + c] = v_c' x_c in one pass over the three panels: what
+ * the block QMR step needs to form sigma = v'(I - x x')w = v'w - (x'w)(v'x) without first storing the projected w */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+triple_dots_kernel(const T *__restrict__ X, int64_t ldX, const T *__restrict__ Vv, int64_t ldV, const T *__restrict__ Wv,
+      int64_t ldW, int nx, int64_t m, double *__restrict__ partials) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][3];
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *x = X + (size_t)c * ldX, *v = Vv + (size_t)c * ldV, *w = Wv + (size_t)c * ldW;
+      double a = 0.0, b = 0.0, d = 0.0;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+         const double xi = (double)x[i], vi = (double)v[i], wi = (double)w[i];
+         a = fma(xi, wi, a); b = fma(vi, wi, b); d = fma(vi, xi, d);
+      }
+      a = hipk_wave_sum(a); b = hipk_wave_sum(b); d = hipk_wave_sum(d);
+      if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = a; sm[threadIdx.x >> 6][1] = b; sm[threadIdx.x >> 6][2] = d; }
+      __syncthreads();
+      if (threadIdx.x < 3)
+         partials[(size_t)blockIdx.x * 3 * nx + threadIdx.x * nx + c] =
+               (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+      __syncthreads();
+   }
+}
+
+/* g_c -= alpha_c (w_c - xr_c x_c), out[c] = g_c' g_c: the projection of w against x and the residual update of
+ * the QMR step in one pass; the projected w itself is never stored (inner_solve.c:853-880, :371-377) */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+axpy_proj_dot_kernel(ColScal alpha, ColScal xr, const T *__restrict__ Wv, int64_t ldW, const T *__restrict__ X, int64_t ldX,
+      T *__restrict__ G, int64_t ldG, int nx, int64_t m, double *__restrict__ partials) {
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int c = 0; c < nx; c++) {
+      const T *w = Wv + (size_t)c * ldW, *x = X + (size_t)c * ldX;
+      T *g = G + (size_t)c * ldG;
+      const double a = alpha.a[c], r = xr.a[c];
+      double s = 0.0;
+      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+         const T wp = (T)fma(-r, (double)x[i], (double)w[i]);          /* rounded like the stored projected w */
+         const T ng = (T)fma(-a, (double)wp, (double)g[i]);
+         g[i] = ng;
+         s = fma((double)ng, (double)ng, s);
+      }
+      s = hipk_wave_sum(s);
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * nx + c] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      __syncthreads();
+   }
+}
+
 #define DISPATCH_RT(dt, CALL_D, CALL_F)         \
    switch (dt) {                                \
    case HIPK_F64: { typedef double T; CALL_D; } break; \
@@ -1688,4 +1740,31 @@ extern "C" int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, i
          hipLaunchKernelGGL(qmr_update_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, sh, min_den, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, (T *)W, ldW, nx, m, ctx->partials));
    HIPK_CHECK(hipGetLastError());
    return hipk_finalize_partials(ctx, ctx->partials, gx, 2 * nx, out_dev);
+}
+
+extern "C" int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *V, int64_t ldV,
+      const void *W, int64_t ldW, int nx, double *out_dev) {
+   if (nx <= 0) return 0;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * 3 * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(triple_dots_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (const T *)V, ldV, (const T *)W, ldW, nx, m, ctx->partials),
+         hipLaunchKernelGGL(triple_dots_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (const T *)V, ldV, (const T *)W, ldW, nx, m, ctx->partials));
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, 3 * nx, out_dev);
+}
+
+extern "C" int hipk_axpy_proj_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha_host, const double *xr_host,
+      const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, double *out_dev) {
+   if (nx <= 0) return 0;
+   if (nx > UTIL_MAXCOLS) return -1;
+   ColScal a, r;
+   for (int c = 0; c < nx; c++) { a.a[c] = alpha_host[c]; r.a[c] = xr_host[c]; }
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL(axpy_proj_dot_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, a, r, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, nx, m, ctx->partials),
+         hipLaunchKernelGGL(axpy_proj_dot_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, a, r, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, nx, m, ctx->partials));
+   HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, out_dev);
 }

@@ -365,6 +365,36 @@ def test_csr_matvec_shifted(built, dt, ncols):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+def test_qmr_projection_folded_into_residual_update(built, dt):
+    """sigma = v'(I - x x')w from one pass of three inner products, then g -= alpha (w - (x'w) x), |g|^2 in one pass:
+    equal to projecting w first and updating g afterwards (the two passes and the extra synchronisation it replaces)"""
+    rng = np.random.default_rng(33)
+    npdt = NPDT[dt]
+    m, ld, nx = 80003, 80004, 6
+    X, Vv, W, G = (rng.standard_normal((nx, ld)).astype(npdt) for _ in range(4))
+    alpha = rng.standard_normal(nx)
+    res = []
+    for side in (Dev(), Host()):
+        x, v, w, g = side.arr(X), side.arr(Vv), side.arr(W), side.arr(G)
+        o3 = side.arr(np.zeros(3 * nx)); o1 = side.arr(np.zeros(nx))
+        assert side.lib.hipk_triple_dots(side.ctx, dt, m, side.ptr(x), ld, side.ptr(v), ld, side.ptr(w), ld, nx, side.ptr(o3)) == 0
+        d3 = side.get(o3).copy()
+        a = (C.c_double * nx)(*alpha); xr = (C.c_double * nx)(*d3[:nx])
+        assert side.lib.hipk_axpy_proj_dot(side.ctx, dt, m, nx, a, xr, side.ptr(w), ld, side.ptr(x), ld, side.ptr(g), ld, side.ptr(o1)) == 0
+        res.append((d3, side.get(g)[:, :m], side.get(o1)))
+        side.close()
+    X64, V64, W64, G64 = (t[:, :m].astype(np.float64) for t in (X, Vv, W, G))
+    tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+    ref3 = np.concatenate([np.sum(X64 * W64, axis=1), np.sum(V64 * W64, axis=1), np.sum(V64 * X64, axis=1)])
+    for r in res:
+        assert np.max(np.abs(r[0] - ref3)) <= tol * np.sqrt(m) * 4
+    xr = res[1][0][:nx]
+    gref = G64 - alpha[:, None] * (W64 - xr[:, None] * X64)
+    assert np.max(np.abs(res[1][1] - gref)) <= tol * 20 and np.max(np.abs(res[0][1] - res[1][1])) <= tol * 20
+    assert np.max(np.abs(res[0][2] - res[1][2]) / (1 + res[1][2])) <= tol * np.sqrt(m)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
 def test_qmr_update_with_jacobi(built, dt):
     """delta = gamma delta + eta d; sol += delta; |sol|^2 and w = g ./ (diag - shift), g'w in one pass"""
     rng = np.random.default_rng(21)
