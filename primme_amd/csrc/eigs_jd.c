@@ -88,9 +88,18 @@ static int permute_panel(pa_solver *s, char *base, int64_t ldb, int n, const int
    int moved = 0;
    for (int i = 0; i < n; i++) if (perm[i] != i) moved = 1;
    if (!moved || !base) return 0;
-   for (int i = 0; i < n; i++)
-      CHK(hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, perm[i]), ldb, TCOL(s, i), s->ld, 1));
-   CHK(hipk_copy_cols(s->ctx, s->dt, s->m, s->T, s->ld, base, ldb, n));
+   /* only the tail that actually moves: one gather launch into the scratch panel and one copy back
+    * (a column converging out of a block of 8 used to cost nine rectangular copies per panel) */
+   int first = 0;
+   while (first < n && perm[first] == first) first++;
+   const int cnt = n - first;
+   if (cnt > s->nT) return PRIMME_UNEXPECTED_FAILURE;
+   int rel[64];
+   if (cnt > 64) return PRIMME_FUNCTION_UNAVAILABLE;
+   for (int i = 0; i < cnt; i++) rel[i] = perm[first + i] - first;
+   for (int i = 0; i < cnt; i++) if (rel[i] < 0) return PRIMME_UNEXPECTED_FAILURE;   /* a permutation never reaches back over fixed points */
+   CHK(hipk_gather_cols(s->ctx, s->dt, s->m, PCOL(s, base, ldb, first), ldb, rel, cnt, s->T, s->ld));
+   CHK(hipk_copy_cols(s->ctx, s->dt, s->m, s->T, s->ld, PCOL(s, base, ldb, first), ldb, cnt));
    return 0;
 }
 

@@ -1466,35 +1466,46 @@ template <typename T>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 qmr_update_jacobi_kernel(ColScal gam, ColScal eta, ColScal shf, double min_den, const T *__restrict__ D, int64_t ldD,
       T *__restrict__ Delta, int64_t ldDelta, T *__restrict__ Sol, int64_t ldSol, const T *__restrict__ G, int64_t ldG,
-      const T *__restrict__ diag, T *__restrict__ Wp, int64_t ldW, int nx, int64_t m, double *__restrict__ partials) {
-   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][2];
+      const T *__restrict__ diag, T *__restrict__ Wp, int64_t ldW, int nx, int c0, int64_t m, double *__restrict__ partials) {
+   /* rows outside, (up to 8) columns inside: the diagonal is read once per row, not once per column */
+   constexpr int NXC = 8;
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][2 * NXC];
+   const int nc = min(NXC, nx - c0);
+   double s1[NXC], s2[NXC];
+#pragma unroll
+   for (int c = 0; c < NXC; c++) { s1[c] = 0.0; s2[c] = 0.0; }
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
-   for (int c = 0; c < nx; c++) {
-      const T *d = D + (size_t)c * ldD, *g = G + (size_t)c * ldG;
-      T *de = Delta + (size_t)c * ldDelta, *so = Sol + (size_t)c * ldSol, *w = Wp + (size_t)c * ldW;
-      const double gm = gam.a[c], e = eta.a[c], sh = shf.a[c];
-      double s1 = 0.0, s2 = 0.0;
-      for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
-         const T nd = (T)fma((double)de[i], gm, (double)d[i] * e);
-         de[i] = nd;
-         const T ns = (T)((double)nd + (double)so[i]);
-         so[i] = ns;
-         s1 = fma((double)ns, (double)ns, s1);
-         double den = (double)diag[i] - sh;
-         if (!(fabs(den) > min_den)) den = copysign(min_den, den);
-         const double gi = (double)g[i];
-         const T wi = (T)(gi / den);
-         w[i] = wi;
-         s2 = fma(gi, (double)wi, s2);
-      }
-      s1 = hipk_wave_sum(s1); s2 = hipk_wave_sum(s2);
-      if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = s1; sm[threadIdx.x >> 6][1] = s2; }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-         partials[(size_t)blockIdx.x * 2 * nx + c] = (sm[0][0] + sm[1][0]) + (sm[2][0] + sm[3][0]);
-         partials[(size_t)blockIdx.x * 2 * nx + nx + c] = (sm[0][1] + sm[1][1]) + (sm[2][1] + sm[3][1]);
-      }
-      __syncthreads();
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      const double dg = (double)diag[i];
+#pragma unroll
+      for (int c = 0; c < NXC; c++)
+         if (c < nc) {
+            const size_t cc = (size_t)(c0 + c);
+            const T nd = (T)fma((double)Delta[i + cc * ldDelta], gam.a[c0 + c], (double)D[i + cc * ldD] * eta.a[c0 + c]);
+            Delta[i + cc * ldDelta] = nd;
+            const T ns = (T)((double)nd + (double)Sol[i + cc * ldSol]);
+            Sol[i + cc * ldSol] = ns;
+            s1[c] = fma((double)ns, (double)ns, s1[c]);
+            double den = dg - shf.a[c0 + c];
+            if (!(fabs(den) > min_den)) den = copysign(min_den, den);
+            const double gi = (double)G[i + cc * ldG];
+            const T wi = (T)(gi / den);
+            Wp[i + cc * ldW] = wi;
+            s2[c] = fma(gi, (double)wi, s2[c]);
+         }
+   }
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+   for (int c = 0; c < NXC; c++) {
+      const double a = hipk_wave_sum(s1[c]), b = hipk_wave_sum(s2[c]);
+      if (lane == 0) { sm[wv][c] = a; sm[wv][NXC + c] = b; }
+   }
+   __syncthreads();
+   if (threadIdx.x < 2 * NXC) {
+      const int which = threadIdx.x / NXC, c = threadIdx.x % NXC;
+      if (c < nc)
+         partials[(size_t)blockIdx.x * 2 * nx + which * nx + c0 + c] =
+               (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
    }
 }
 
@@ -1735,10 +1746,12 @@ extern "C" int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, i
    for (int c = 0; c < nx; c++) { g.a[c] = gamma_host[c]; e.a[c] = eta_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
    if (hipk_reserve_partials(ctx, (size_t)gx * 2 * nx)) return -2;
-   DISPATCH_RT(dt,
-         hipLaunchKernelGGL(qmr_update_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, sh, min_den, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, (T *)W, ldW, nx, m, ctx->partials),
-         hipLaunchKernelGGL(qmr_update_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, sh, min_den, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, (T *)W, ldW, nx, m, ctx->partials));
-   HIPK_CHECK(hipGetLastError());
+   for (int c0 = 0; c0 < nx; c0 += 8) {
+      DISPATCH_RT(dt,
+            hipLaunchKernelGGL(qmr_update_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, sh, min_den, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, (T *)W, ldW, nx, c0, m, ctx->partials),
+            hipLaunchKernelGGL(qmr_update_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, sh, min_den, (const T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, (T *)W, ldW, nx, c0, m, ctx->partials));
+      HIPK_CHECK(hipGetLastError());
+   }
    return hipk_finalize_partials(ctx, ctx->partials, gx, 2 * nx, out_dev);
 }
 
