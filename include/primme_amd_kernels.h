@@ -218,7 +218,8 @@ int hipk_csr_destroy(hipk_csr *A);
  * the creating context when NULL */
 int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int64_t ldx, void *y, int64_t ldy,
       int ncols);
-/* y = A (a x), xout = a x (xout != x), dot_dev[0] = xout' y with a = 1/sqrt(norm2_dev[0]) read from HBM:
+/* y = A (a x), xout = a x (xout != x), dot_dev[0] = xout' y with a = 1/sqrt(norm2_dev[0]) read from HBM
+ * (norm2_dev == NULL: a = 1):
  * normalisation (Num_scal, cublas_wrapper.c:678), operator and the inner product t'At in one launch. */
 int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx /* the caller's: stream, scratch, result mirror */,
       const void *x, const double *norm2_dev, void *xout, void *y, double *dot_dev);

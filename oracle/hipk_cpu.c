@@ -414,7 +414,7 @@ int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x, const doub
    (void)ctx; g_cnt[5]++;
    if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout) return -1;
    const hipk_dtype dt = A->dt;
-   const double a = 1.0 / sqrt(norm2[0]);
+   const double a = norm2 ? 1.0 / sqrt(norm2[0]) : 1.0;
    double d = 0.0;
    for (int64_t i = 0; i < A->nrows; i++) {
       double s = 0;

@@ -315,7 +315,35 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
             s->spec_fused = 0;
             if ((rc = hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, dstc, s->ld,
                        fuse_tail ? TCOL(s, 0) : dstc, s->ld, 1, s->d_fov + nfov))) goto out;
-            if (speculate2) {
+            /* Row-partitioned runs on the library's communicator: |t|^2 and t'At travel in ONE all-reduce.
+             * The operator is applied to the un-normalised t (no scaling in the launch), both numbers are
+             * reduced together, and V(:,k), W(:,k) are scaled afterwards with the value the host then has:
+             * two all-reduces per outer iteration instead of three (each is latency, not bandwidth). */
+            const int merge_red = fuse_tail && s->parallel && s->dev_comm;
+            if (speculate2 && merge_red) {
+               rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, 0), NULL, dstc,
+                     WCOL(s, basisSize), s->d_fov + nfov + 1);
+               if (rc) { rc = rc < 0 ? rc : PRIMME_USER_FAILURE; goto out; }
+               s->spec_fused = 1;
+               if ((rc = pa_reduce(s, s->d_fov + nfov, 2, 0, 0))) goto out;             /* the one synchronisation */
+               const double inv = 1.0 / sqrt(s->h_fov[nfov]);
+               if ((rc = hipk_scale_cols(s->ctx, s->dt, s->m, dstc, s->ld, 1, &inv))) goto out;
+               if ((rc = hipk_scale_cols(s->ctx, s->dt, s->m, WCOL(s, basisSize), s->ld, 1, &inv))) goto out;
+               const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
+               if (nLk > 0 && s->wtq_rows == basisSize - 1) {
+                  for (int l = 0; l < nLk; l++) s->wtq[(basisSize - 1) + (size_t)l * s->K] = wr[basisSize + l];
+                  s->wtq_rows = basisSize;
+               }
+               for (int j = 0; j < basisSize; j++) {
+                  double hc = 0.0;
+                  for (int i = 0; i < basisSize; i++)
+                     hc += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * cV[i];
+                  for (int l = 0; l < nLk; l++) hc += s->wtq[j + (size_t)l * s->K] * cQ[l];
+                  s->spec_hcol[j] = (wr[j] - hc) * inv;
+               }
+               s->spec_hcol[basisSize] = s->h_fov[nfov + 1] * inv * inv;
+               s->spec2_valid = 1; s->spec2_k = basisSize;
+            } else if (speculate2) {
                if ((rc = pa_reduce(s, s->d_fov + nfov, 1, 1, 1))) goto out;
                if (fuse_tail) {
                   /* the library's own operator: normalisation, A t and t'At in one launch, reading the

@@ -90,7 +90,7 @@ csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *
       const int4 ti = tileinfo[tile];
       const int r0 = ti.x, r1 = ti.y, p0 = ti.z, nz = ti.w - ti.z;
       const bool local = (halo_lo == 0 && halo_hi == 0);
-      const double a = FUSED ? 1.0 / sqrt(norm2[0]) : 1.0;
+      const double a = (FUSED && norm2) ? 1.0 / sqrt(norm2[0]) : 1.0;   /* norm2 == NULL: no scaling (xout = x) */
       if (nz <= TILE_NNZ) {
          /* row segment of this lane's row: fetched now, used after the barrier */
          const int r = r0 + threadIdx.x;
