@@ -175,6 +175,122 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
          lockedEvals, numLocked, lockedFlags, lockedNorms, event);
 }
 
+/* the library's own operator can run the one-launch tail (scale + A t + t'At) on this solver's panels */
+int pa_fuse_tail_eligible(const pa_solver *s) {
+   const primme_params *p = s->p;
+   return s->nT >= 1 && p->matrixMatvec == primme_amd_matvec && p->matrix && s->ld == s->m &&
+          primme_amd_operator_can_fuse((const primme_amd_operator *)p->matrix) &&
+          hipk_csr_dtype(primme_amd_operator_matrix((primme_amd_operator *)p->matrix)) == s->dt;
+}
+
+/* The pre-restart convergence check may run through the fused residual kernel and hand its overlaps to the
+ * restart: block size 1, GD without preconditioner, Rayleigh-Ritz, in-stream reductions, the library's own
+ * operator, and G = W'Q known for all basis vectors but the newest. */
+int pa_restart_stash_eligible(const pa_solver *s, int basisSize, int nLk) {
+   const primme_params *p = s->p;
+   if (!s->fused_restart || !s->fuse_gd || p->maxBlockSize != 1 || !s->rst_y || s->nT < 3) return 0;
+   if (!s->wtr_enabled || !s->spec2_enabled || s->Q || s->VtBV || s->phase_timing || (s->parallel && !s->dev_comm)) return 0;
+   if (basisSize > HIPK_WTR_MAX_K || nLk > HIPK_WTR_MAX_K || basisSize > 32 || nLk > 32) return 0;
+   if (nLk > 0 && !(s->wtq_L == nLk && s->wtq_rows >= basisSize - 1)) return 0;
+   if (p->n <= (int64_t)p->maxBasisSize + nLk) return 0;      /* the practical-convergence test would read R */
+   return pa_fuse_tail_eligible(s);
+}
+
+/* The speculative tail of a block-size-1 GD iteration, enqueued right after the fused residual pass: the
+ * first Gram-Schmidt update with the device-resident overlaps, then (speculate2) normalisation, operator
+ * application and the new column of H, so that the host synchronises once.  `rsrc` holds the residual
+ * (the basis slot `dstc` itself, or a scratch column after a restart, which needs the fused operator
+ * launch); d_fov / h_fov hold [V'r | Q'r | r'r | W'r | ..] in `nfov` entries. */
+int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, char *dstc, int nfov, int wtr,
+      int speculate2, int parallel_host) {
+   primme_params *p = s->p;
+   const int nov = basisSize + nLk;
+   int rc = 0;
+   {
+   hipk_seg segs[2] = {{s->V, s->ld, basisSize}, {s->evecs, s->ldevecs, nLk}};
+   /* with the fused tail the projected vector goes to the scratch column T(:,0): the operator
+    * launch gathers from it while it writes the normalised vector into V(:,k) */
+   const int fuse_tail = speculate2 && wtr && pa_fuse_tail_eligible(s);
+   if (rsrc != dstc && !fuse_tail) return PRIMME_UNEXPECTED_FAILURE;
+   s->spec_fused = 0;
+   CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, rsrc, s->ld,
+              fuse_tail ? TCOL(s, 0) : dstc, s->ld, 1, s->d_fov + nfov));
+   /* Row-partitioned runs on the library's communicator: |t|^2 and t'At travel in ONE all-reduce.
+    * The operator is applied to the un-normalised t (no scaling in the launch), both numbers are
+    * reduced together, and V(:,k), W(:,k) are scaled afterwards with the value the host then has:
+    * two all-reduces per outer iteration instead of three (each is latency, not bandwidth). */
+   const int merge_red = fuse_tail && s->parallel && s->dev_comm;
+   if (speculate2 && merge_red) {
+      rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, 0), NULL, dstc,
+            WCOL(s, basisSize), s->d_fov + nfov + 1);
+      if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
+      s->spec_fused = 1;
+      CHK(pa_reduce(s, s->d_fov + nfov, 2, 0, 0));             /* the one synchronisation */
+      const double inv = 1.0 / sqrt(s->h_fov[nfov]);
+      CHK(hipk_scale_cols(s->ctx, s->dt, s->m, dstc, s->ld, 1, &inv));
+      CHK(hipk_scale_cols(s->ctx, s->dt, s->m, WCOL(s, basisSize), s->ld, 1, &inv));
+      const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
+      if (nLk > 0 && s->wtq_rows == basisSize - 1) {
+         for (int l = 0; l < nLk; l++) s->wtq[(basisSize - 1) + (size_t)l * s->K] = wr[basisSize + l];
+         s->wtq_rows = basisSize;
+      }
+      for (int j = 0; j < basisSize; j++) {
+         double hc = 0.0;
+         for (int i = 0; i < basisSize; i++)
+            hc += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * cV[i];
+         for (int l = 0; l < nLk; l++) hc += s->wtq[j + (size_t)l * s->K] * cQ[l];
+         s->spec_hcol[j] = (wr[j] - hc) * inv;
+      }
+      s->spec_hcol[basisSize] = s->h_fov[nfov + 1] * inv * inv;
+      s->spec2_valid = 1; s->spec2_k = basisSize;
+   } else if (speculate2) {
+      CHK(pa_reduce(s, s->d_fov + nfov, 1, 1, 1));
+      if (fuse_tail) {
+         /* the library's own operator: normalisation, A t and t'At in one launch, reading the
+          * un-normalised vector from the scratch column and rebuilding V(:,k) on the way */
+         rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, 0), s->d_fov + nfov, dstc,
+               WCOL(s, basisSize), s->d_red);
+         if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
+         s->spec_fused = 1;
+      } else {
+         CHK(hipk_scale_cols_rsqrt_dev(s->ctx, s->dt, s->m, dstc, s->ld, 1, s->d_fov + nfov));
+         int one = 1, ierr = 0;
+         PRIMME_INT ldx = s->ld;
+         p->matrixMatvec(dstc, &ldx, WCOL(s, basisSize), &ldx, &one, p, &ierr);
+         if (ierr) return PRIMME_USER_FAILURE;
+      }
+      if (wtr) {
+         if (!fuse_tail) CHK(hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red));
+         CHK(pa_reduce(s, s->d_red, 1, 0, 0));                 /* the one synchronisation */
+         const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
+         const double inv = 1.0 / sqrt(s->h_fov[nfov]);
+         if (nLk > 0 && s->wtq_rows == basisSize - 1) {
+            for (int l = 0; l < nLk; l++) s->wtq[(basisSize - 1) + (size_t)l * s->K] = wr[basisSize + l];
+            s->wtq_rows = basisSize;
+         }
+         for (int j = 0; j < basisSize; j++) {
+            double hc = 0.0;
+            for (int i = 0; i < basisSize; i++)
+               hc += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * cV[i];
+            for (int l = 0; l < nLk; l++) hc += s->wtq[j + (size_t)l * s->K] * cQ[l];
+            s->spec_hcol[j] = (wr[j] - hc) * inv;
+         }
+         s->spec_hcol[basisSize] = s->h_red[0];
+      } else {
+         hipk_seg vseg = {s->V, s->ld, basisSize + 1};
+         CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &vseg, 1, WCOL(s, basisSize), s->ld, 1, s->d_red, basisSize + 1));
+         CHK(pa_reduce(s, s->d_red, basisSize + 1, 0, 0));      /* the one synchronisation */
+         memcpy(s->spec_hcol, s->h_red, (size_t)(basisSize + 1) * sizeof(double));
+      }
+      s->spec2_valid = 1; s->spec2_k = basisSize;
+   } else {
+      CHK(pa_reduce(s, s->d_fov + nfov, 1, 0, 0));
+   }
+   s->fov_projected = 1;
+   }
+   return 0;
+}
+
 /* Put the first unconverged Ritz pairs in the block, computing X, R and the
  * residual norms for them; flag converged pairs on the way. */
 int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arbitraryVecs, double smallestResNorm,
@@ -194,8 +310,17 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
     * writes X and R and then copies R over X, correction.c:378 with no preconditioner) */
    const int fused = s->fuse_gd && computeXR;
    if (fused) { R = X; X = NULL; }
-   s->fov_valid = 0;   /* only overlaps computed in THIS call, for the candidate that stays, may be reused */
-   s->spec2_valid = 0;
+   /* overlaps (and the speculative tail) carried over a restart stay valid if the one candidate the restart
+    * left is still the block when this call returns */
+   const int carried = s->fov_carry && s->fov_valid && fused && blockNormsSize == 1 && maxBlockSize >= 1 &&
+                       basisSize == s->fov_k && R == s->fov_col;
+   const int carried_iev = carried ? iev[0] : -1;
+   int relaunched = 0;
+   s->fov_carry = 0;
+   if (!carried) {
+      s->fov_valid = 0;   /* only overlaps computed in THIS call, for the candidate that stays, may be reused */
+      s->spec2_valid = 0;
+   }
    int *flagsBlock = (int *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(int));
    double *hValsBlock = (double *)malloc((size_t)(maxBlockSize > 0 ? maxBlockSize : 1) * sizeof(double));
    hipk_job *jobs = (hipk_job *)malloc((size_t)(2 * maxBlockSize + 2) * sizeof(hipk_job));
@@ -269,6 +394,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
 
       /* X = V h, R = W h - X theta, norms — one fused pass over V and W */
       const int nLk = p->numOrthoConst + numLocked;
+      relaunched = 1;
       if (fused && p->maxBlockSize == 1 && blockNormsSize == 1 && basisSize <= 32 && nLk <= 32) {
          /* block size 1, GD without preconditioner: the residual is the next basis vector, so
           * the same pass also delivers the first Gram-Schmidt pass' overlaps [V'r | Q'r | r'r] */
@@ -306,92 +432,34 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
                     s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, wtr, s->d_fov))) goto out;
          if (speculate) {
             if ((rc = pa_reduce(s, s->d_fov, nfov, 1, parallel_host ? 0 : 1))) goto out;
-            hipk_seg segs[2] = {{s->V, s->ld, basisSize}, {s->evecs, s->ldevecs, nLk}};
-            /* with the fused tail the projected vector goes to the scratch column T(:,0): the operator
-             * launch gathers from it while it writes the normalised vector into V(:,k) */
-            const int fuse_tail = speculate2 && wtr && s->nT >= 1 && p->matrixMatvec == primme_amd_matvec && p->matrix &&
-                                  s->ld == s->m && primme_amd_operator_can_fuse((const primme_amd_operator *)p->matrix) &&
-                                  hipk_csr_dtype(primme_amd_operator_matrix((primme_amd_operator *)p->matrix)) == s->dt;
-            s->spec_fused = 0;
-            if ((rc = hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, dstc, s->ld,
-                       fuse_tail ? TCOL(s, 0) : dstc, s->ld, 1, s->d_fov + nfov))) goto out;
-            /* Row-partitioned runs on the library's communicator: |t|^2 and t'At travel in ONE all-reduce.
-             * The operator is applied to the un-normalised t (no scaling in the launch), both numbers are
-             * reduced together, and V(:,k), W(:,k) are scaled afterwards with the value the host then has:
-             * two all-reduces per outer iteration instead of three (each is latency, not bandwidth). */
-            const int merge_red = fuse_tail && s->parallel && s->dev_comm;
-            if (speculate2 && merge_red) {
-               rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, 0), NULL, dstc,
-                     WCOL(s, basisSize), s->d_fov + nfov + 1);
-               if (rc) { rc = rc < 0 ? rc : PRIMME_USER_FAILURE; goto out; }
-               s->spec_fused = 1;
-               if ((rc = pa_reduce(s, s->d_fov + nfov, 2, 0, 0))) goto out;             /* the one synchronisation */
-               const double inv = 1.0 / sqrt(s->h_fov[nfov]);
-               if ((rc = hipk_scale_cols(s->ctx, s->dt, s->m, dstc, s->ld, 1, &inv))) goto out;
-               if ((rc = hipk_scale_cols(s->ctx, s->dt, s->m, WCOL(s, basisSize), s->ld, 1, &inv))) goto out;
-               const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
-               if (nLk > 0 && s->wtq_rows == basisSize - 1) {
-                  for (int l = 0; l < nLk; l++) s->wtq[(basisSize - 1) + (size_t)l * s->K] = wr[basisSize + l];
-                  s->wtq_rows = basisSize;
-               }
-               for (int j = 0; j < basisSize; j++) {
-                  double hc = 0.0;
-                  for (int i = 0; i < basisSize; i++)
-                     hc += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * cV[i];
-                  for (int l = 0; l < nLk; l++) hc += s->wtq[j + (size_t)l * s->K] * cQ[l];
-                  s->spec_hcol[j] = (wr[j] - hc) * inv;
-               }
-               s->spec_hcol[basisSize] = s->h_fov[nfov + 1] * inv * inv;
-               s->spec2_valid = 1; s->spec2_k = basisSize;
-            } else if (speculate2) {
-               if ((rc = pa_reduce(s, s->d_fov + nfov, 1, 1, 1))) goto out;
-               if (fuse_tail) {
-                  /* the library's own operator: normalisation, A t and t'At in one launch, reading the
-                   * un-normalised vector from the scratch column and rebuilding V(:,k) on the way */
-                  rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, 0), s->d_fov + nfov, dstc,
-                        WCOL(s, basisSize), s->d_red);
-                  if (rc) { rc = rc < 0 ? rc : PRIMME_USER_FAILURE; goto out; }
-                  s->spec_fused = 1;
-               } else {
-                  if ((rc = hipk_scale_cols_rsqrt_dev(s->ctx, s->dt, s->m, dstc, s->ld, 1, s->d_fov + nfov))) goto out;
-                  int one = 1, ierr = 0;
-                  PRIMME_INT ldx = s->ld;
-                  p->matrixMatvec(dstc, &ldx, WCOL(s, basisSize), &ldx, &one, p, &ierr);
-                  if (ierr) { rc = PRIMME_USER_FAILURE; goto out; }
-               }
-               if (wtr) {
-                  if (!fuse_tail && (rc = hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red))) goto out;
-                  if ((rc = pa_reduce(s, s->d_red, 1, 0, 0))) goto out;                 /* the one synchronisation */
-                  const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
-                  const double inv = 1.0 / sqrt(s->h_fov[nfov]);
-                  if (nLk > 0 && s->wtq_rows == basisSize - 1) {
-                     for (int l = 0; l < nLk; l++) s->wtq[(basisSize - 1) + (size_t)l * s->K] = wr[basisSize + l];
-                     s->wtq_rows = basisSize;
-                  }
-                  for (int j = 0; j < basisSize; j++) {
-                     double hc = 0.0;
-                     for (int i = 0; i < basisSize; i++)
-                        hc += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * cV[i];
-                     for (int l = 0; l < nLk; l++) hc += s->wtq[j + (size_t)l * s->K] * cQ[l];
-                     s->spec_hcol[j] = (wr[j] - hc) * inv;
-                  }
-                  s->spec_hcol[basisSize] = s->h_red[0];
-               } else {
-                  hipk_seg vseg = {s->V, s->ld, basisSize + 1};
-                  if ((rc = hipk_panel_dots(s->ctx, s->dt, s->m, &vseg, 1, WCOL(s, basisSize), s->ld, 1, s->d_red, basisSize + 1))) goto out;
-                  if ((rc = pa_reduce(s, s->d_red, basisSize + 1, 0, 0))) goto out;      /* the one synchronisation */
-                  memcpy(s->spec_hcol, s->h_red, (size_t)(basisSize + 1) * sizeof(double));
-               }
-               s->spec2_valid = 1; s->spec2_k = basisSize;
-            } else {
-               if ((rc = pa_reduce(s, s->d_fov + nfov, 1, 0, 0))) goto out;
-            }
-            s->fov_projected = 1;
+            if ((rc = pa_speculative_tail(s, basisSize, nLk, dstc, dstc, nfov, wtr, speculate2, parallel_host))) goto out;
          } else {
             if ((rc = pa_reduce(s, s->d_fov, nfov, 1, 0))) goto out;
          }
          blockNorms[*blockSize] = sqrt(s->h_fov[basisSize + nLk]);
          s->fov_valid = 1; s->fov_k = basisSize; s->fov_L = nLk; s->fov_col = dstc; s->fov_s1_off = nfov;
+         p->stats.timeDense += pa_wtime() - t0;
+         p->stats.flopsDense += (double)s->m * 2.0 * basisSize;
+      } else if (!computeXR && blockNormsSize == 1 && pa_restart_stash_eligible(s, basisSize, nLk)) {
+         /* Full basis, the one candidate is tested before the restart (its norm is all the caller wants):
+          * the same fused pass as in every other iteration instead of a norm-only pass over V and W.  It
+          * costs L more columns and leaves, besides |r|, the residual itself (scratch column T(:,2)) and
+          * its overlaps with the OLD basis; if the pair is not converged the restart turns those into the
+          * overlaps with the restarted basis by a k x restartSize host product and the first iteration
+          * after the restart starts from them (eigs_restart.c). */
+         const int col = iev[*blockSize];
+         const int nov = basisSize + nLk, nfov = 2 * nov + 1;
+         double t0 = pa_wtime();
+         s->fov_valid = 0;
+         s->rst_valid = 0;
+         if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
+                    s->hVecs + (size_t)col * ldh, s->hVals[col], TCOL(s, 2), s->evecs, s->ldevecs, nLk, 1, s->d_fov))) goto out;
+         if ((rc = pa_reduce(s, s->d_fov, nfov, 0, 0))) goto out;
+         blockNorms[*blockSize] = sqrt(s->h_fov[nov]);
+         memcpy(s->rst_ov, s->h_fov, (size_t)nfov * sizeof(double));
+         memcpy(s->rst_y, s->hVecs + (size_t)col * ldh, (size_t)basisSize * sizeof(double));
+         s->rst_theta = s->hVals[col];
+         s->rst_k = basisSize; s->rst_L = nLk; s->rst_valid = 1;
          p->stats.timeDense += pa_wtime() - t0;
          p->stats.flopsDense += (double)s->m * 2.0 * basisSize;
       } else {
@@ -416,6 +484,10 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          blockNorms[i] = PA_MAX(blockNorms[i], p->stats.estimateResidualError);
    }
 out:
+   if (carried && !relaunched && !(rc == 0 && *blockSize == 1 && iev[0] == carried_iev && *recentlyConverged == 0)) {
+      s->fov_valid = 0;
+      s->spec2_valid = 0;
+   }
    free(flagsBlock);
    free(hValsBlock);
    free(jobs);

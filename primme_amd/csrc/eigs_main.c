@@ -694,6 +694,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
          CHK(pa_evecs_hat_update(s, &numConvergedStored, numConverged));
 
          if (numGuesses > 0) {
+            s->fov_valid = 0; s->spec2_valid = 0; s->fov_carry = 0;
             /* feed remaining initial guesses into the restarted basis */
             int numNew = PA_MAX(0, PA_MIN(p->minRestartSize + numConverged - (nextGuess - p->numOrthoConst), numGuesses));
             numNew = PA_MAX(0, PA_MIN(basisSize + numNew, p->maxBasisSize) - basisSize);
@@ -810,7 +811,7 @@ static void free_solver(pa_solver *s) {
    }
    free(s->H); free(s->hVecs); free(s->prevhVecs); free(s->hVals); free(s->prevRitzVals);
    free(s->Mq); free(s->Mlu); free(s->Mpiv); free(s->R); free(s->QtV); free(s->hU); free(s->hSVals); free(s->hVecsRot);
-   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol); free(s->wtq);
+   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol); free(s->wtq); free(s->rst_y); free(s->rst_ov); free(s->rst_c);
    free(s->flags); free(s->map); free(s->iev); free(s->perm); free(s->lockedFlags);
    free(s);
 }
@@ -937,6 +938,10 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->blockNorms = (double *)calloc((size_t)K + b, 8); s->basisNorms = (double *)calloc((size_t)K, 8);
    s->spec_hcol = (double *)calloc((size_t)K + 2, 8);
    s->wtq = (double *)calloc((size_t)K * HIPK_WTR_MAX_K + 1, 8);
+   s->rst_y = (double *)calloc((size_t)K + 1, 8);
+   s->rst_ov = (double *)calloc(4 * (size_t)HIPK_WTR_MAX_K + 4, 8);
+   s->rst_c = (double *)calloc(4 * (size_t)HIPK_WTR_MAX_K + 4, 8);
+   s->fused_restart = getenv("PRIMME_AMD_NO_FUSED_RESTART") == NULL;
    s->wtq_rows = -1;
    if (harmonic) {
       s->R = (double *)calloc((size_t)K * K + 1, 8);

@@ -69,6 +69,7 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
 /* G = W(:,0:k)' Q for the locked / constraint vectors Q (projection column from W'r,
  * eigs_conv.c): one TN panel product after a restart. */
 int pa_refresh_wtq(pa_solver *s, int basisSize, int nLk) {
+   if (s->fov_carry && s->wtq_rows == basisSize && s->wtq_L == nLk) return 0;   /* the restart transformed it */
    s->wtq_rows = -1; s->wtq_L = nLk;
    if (!s->wtr_enabled || !s->wtq || basisSize > HIPK_WTR_MAX_K || nLk > HIPK_WTR_MAX_K) return 0;
    if (nLk > 0 && basisSize > 0) {
@@ -179,6 +180,9 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
       for (int c = 0; c <= b2 - b1; c++)
          for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)c * ldRLocked] = 0.0;
    if (b2_out) *b2_out = b1;
+   /* overlaps left by the fused residual pass (or carried over a restart) belong to ONE column */
+   if (s->fov_valid && !(b1 == b2 && b1 == s->fov_k && Vp == s->V)) { s->fov_valid = 0; s->spec2_valid = 0; }
+   s->fov_carry = 0;
 
    for (int i = b1; i <= b2; i++) {
       int nOrth = 0, randomizations = 0, updateR = RLocked ? 1 : 0;

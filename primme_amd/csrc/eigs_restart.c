@@ -34,6 +34,8 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
       int *lockedFlags, double *lockedNorms, primme_event event);
 
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
+int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, char *dstc, int nfov, int wtr,
+      int speculate2, int parallel_host);
 int pa_restart_harmonic(pa_solver *s, int ldh, int restartSize, int basisSize, int numConverged);
 int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, int numConverged, int numPrevRetained,
       int indexOfPreviousVecs, int indexOfPreviousVecsBeforeRestart, const int *restartPerm, const int *hVecsPerm,
@@ -206,6 +208,46 @@ static int move_cols(pa_solver *s, char *base, const int *src, const int *dst, i
    return 0;
 }
 
+/* ---- fused restart ------------------------------------------------------
+ * The convergence check at a full basis left the candidate's residual in T(:,2) and its overlaps with
+ * the old basis in s->rst_ov (eigs_conv.c).  When the restart keeps that candidate as the next block and
+ * locks nothing, the residual job of the restart pass is dropped and the overlaps with the restarted
+ * basis V h, W h follow from a k x restartSize host product. */
+static int stash_matches(const pa_solver *s, int basisSize, int ldh, int col, int nLk) {
+   return s->rst_valid && s->rst_k == basisSize && s->rst_L == nLk && s->hVals[col] == s->rst_theta &&
+          memcmp(s->hVecs + (size_t)col * ldh, s->rst_y, (size_t)basisSize * sizeof(double)) == 0;
+}
+/* h = the rs leading coefficient columns just pushed (K-strided in h_coef) */
+static int stash_transform(pa_solver *s, int basisSize, int rs, int nLk) {
+   const int k = basisSize, nov = k + nLk, K = s->K;
+   const double *ovV = s->rst_ov, *ovQ = s->rst_ov + k, *ovW = s->rst_ov + nov + 1, *grow = s->rst_ov + nov + 1 + k;
+   double *c = s->rst_c;
+   for (int cc = 0; cc < rs; cc++) {
+      double a = 0.0, b = 0.0;
+      for (int j = 0; j < k; j++) { a += s->h_coef[j + (size_t)cc * K] * ovV[j]; b += s->h_coef[j + (size_t)cc * K] * ovW[j]; }
+      c[cc] = a; c[rs + nLk + 1 + cc] = b;
+   }
+   for (int l = 0; l < nLk; l++) c[rs + l] = ovQ[l];
+   c[rs + nLk] = s->rst_ov[nov];
+   if (nLk > 0) {
+      /* G = (W h)'Q = h'(W'Q): rows 0..k-2 of W'Q are on the host, row k-1 came out of the check pass */
+      double *g = (double *)malloc((size_t)rs * nLk * sizeof(double));
+      if (!g) return PRIMME_MALLOC_FAILURE;
+      for (int l = 0; l < nLk; l++)
+         for (int cc = 0; cc < rs; cc++) {
+            double a = s->h_coef[(k - 1) + (size_t)cc * K] * grow[l];
+            for (int j = 0; j < k - 1; j++) a += s->h_coef[j + (size_t)cc * K] * s->wtq[j + (size_t)l * K];
+            g[cc + (size_t)l * rs] = a;
+         }
+      for (int l = 0; l < nLk; l++)
+         for (int cc = 0; cc < rs; cc++) s->wtq[cc + (size_t)l * K] = g[cc + (size_t)l * rs];
+      free(g);
+   }
+   s->wtq_rows = rs; s->wtq_L = nLk;
+   s->rst_ready = 1; s->rst_rs = rs;
+   return 0;
+}
+
 static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, int ldh,
       int *restartPerm, int *flags, int *iev, int *ievSize, double *blockNorms, double *evals,
       double *resNorms, int *numConverged, int numPrevRetained, int *indexOfPreviousVecs,
@@ -256,11 +298,17 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
       for (int c = 0; c < nb; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, nc + c, VCOL(s, rs + c), -1};
    for (int c = 0; c < nc; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, ECOL(s, p->numOrthoConst + c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
-   for (int c = 0; c < nb; c++)
-      jobs[nj++] = (hipk_job){HIPK_JOB_RES, nc + c, s->fuse_gd ? VCOL(s, rs + c) : WCOL(s, rs + c), c};
-   int rc = pa_ritz_update(s, basisSize, jobs, nj, blockNorms, nb, (int64_t)2 * rs + 2 * nb + nc);
+   const int use_stash = (nb == 1 && s->fuse_gd && stash_matches(s, basisSize, ldh, nc, p->numOrthoConst));
+   if (!use_stash)
+      for (int c = 0; c < nb; c++)
+         jobs[nj++] = (hipk_job){HIPK_JOB_RES, nc + c, s->fuse_gd ? VCOL(s, rs + c) : WCOL(s, rs + c), c};
+   int rc = pa_ritz_update(s, basisSize, jobs, nj, blockNorms, use_stash ? 0 : nb, (int64_t)2 * rs + 2 * nb + nc);
    free(jobs);
    if (rc) return rc;
+   if (use_stash) {
+      blockNorms[0] = sqrt(s->rst_ov[basisSize + p->numOrthoConst]);
+      CHK(stash_transform(s, basisSize, rs, p->numOrthoConst));
+   }
    CHK(refresh_gram_after_restart(s, p->numOrthoConst, basisSize, rs, ldh));
 
    for (i = 0; i < basisSize; i++) hVecsPerm[restartPerm[i]] = i;
@@ -316,13 +364,21 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
       for (int c = 0; c < sizeBlockNorms; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, X, s->ld, c), -1};
    for (int c = 0; c < numPacked; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, left + c, ECOL(s, *numLocked + nOC + c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
-   for (int c = 0; c < sizeBlockNorms; c++)
-      jobs[nj++] = (hipk_job){HIPK_JOB_RES, c, s->fuse_gd ? PCOL(s, X, s->ld, c) : PCOL(s, R, s->ld, c), c};
+   const int use_stash = (sizeBlockNorms == 1 && numPacked == 0 && s->fuse_gd &&
+                          stash_matches(s, basisSize, ldh, 0, nOC + *numLocked));
+   if (!use_stash)
+      for (int c = 0; c < sizeBlockNorms; c++)
+         jobs[nj++] = (hipk_job){HIPK_JOB_RES, c, s->fuse_gd ? PCOL(s, X, s->ld, c) : PCOL(s, R, s->ld, c), c};
    for (int c = 0; c < numPacked; c++) jobs[nj++] = (hipk_job){HIPK_JOB_RES, left + c, NULL, sizeBlockNorms + c};
-   int rc = pa_ritz_update(s, basisSize, jobs, nj, norms, sizeBlockNorms + numPacked,
+   int rc = pa_ritz_update(s, basisSize, jobs, nj, norms, use_stash ? 0 : sizeBlockNorms + numPacked,
          (int64_t)2 * rs + 2 * sizeBlockNorms + 2 * numPacked);
    free(jobs);
    if (rc) { free(norms); return rc; }
+   if (use_stash) {
+      norms[0] = sqrt(s->rst_ov[basisSize + nOC + *numLocked]);
+      rc = stash_transform(s, basisSize, rs, nOC + *numLocked);
+      if (rc) { free(norms); return rc; }
+   }
    for (int c = 0; c < sizeBlockNorms; c++) blockNorms[c] = norms[c];
    for (int c = 0; c < numPacked; c++)
       lockedResNorms[c] = PA_MAX(norms[sizeBlockNorms + c], p->stats.estimateResidualError);
@@ -371,7 +427,7 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
     * the Ritz vector, R = W - theta*V), and compact the failed columns to
     * V(:,left..left+failed) / W(...).  (reference restart.c:1047-1052,
     * compute_residual_columns :2464-2538) */
-   {
+   if (!(use_stash && failed == 0)) {
       const int nd = maxBlockSize;
       /* stage the merged block in the scratch panel: X in T[0..nd), R in T[nd..2nd) */
       int io = 0, ifl = 0;
@@ -489,6 +545,8 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
    const int ldh = basisSize;
    int i, restartSize;
    s->fov_valid = 0;
+   s->fov_carry = 0;
+   s->rst_ready = 0;
 
    for (i = 0, *numConverged = *numLocked; i < basisSize; i++) {
       if (flags[i] == SKIP_RESTART) flags[i] = UNCONV;
@@ -580,9 +638,11 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       free(inv);
       free(ident);
       if (rc) { free(hVecsPerm); return rc; }
+      s->rst_ready = 0;      /* the basis columns moved */
    }
    free(hVecsPerm);
    *restartSizeOutput = restartSize;
+   s->rst_valid = 0;
 
    /* bound on the error accumulated in V and W (implicit_I branch of reference
     * restart.c:418-451; the explicit_I estimate from VtBV is added with that path) */
@@ -607,5 +667,21 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       p->stats.estimateResidualError =
             2 * sqrt((double)*restartsSinceReset) * s->mach_eps * pa_problem_norm(1, p);
    }
+   if (s->rst_ready && restartSize == s->rst_rs && *ievSize == 1 && restartSize + 1 <= p->maxBasisSize && numGuesses <= 0) {
+      /* first iteration after the restart: Gram-Schmidt update, operator and the new column of H from the
+       * transformed overlaps; the residual is still in T(:,2), the normalised vector lands in V(:,restartSize) */
+      const int rs = restartSize, nLk = p->numOrthoConst + *numLocked, nov = rs + nLk, nfov = 2 * nov + 1;
+      memcpy(s->h_fov, s->rst_c, (size_t)(2 * rs + nLk + 1) * sizeof(double));
+      for (i = 2 * rs + nLk + 1; i < nfov; i++) s->h_fov[i] = 0.0;
+      CHK(hipk_h2d(s->ctx, s->d_fov, s->h_fov, (size_t)(nov + 1) * sizeof(double)));
+      CHK(pa_speculative_tail(s, rs, nLk, TCOL(s, 2), VCOL(s, rs), nfov, 1, 1, 0));
+      s->fov_valid = 1; s->fov_k = rs; s->fov_L = nLk; s->fov_col = VCOL(s, rs); s->fov_s1_off = nfov;
+      s->fov_carry = 1;
+   } else if (s->rst_ready) {
+      /* the stash was used by the restart pass but the tail cannot follow: put the residual where the
+       * residual job would have left it */
+      CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 2), s->ld, VCOL(s, s->rst_rs), s->ld, 1));
+   }
+   s->rst_ready = 0;
    return 0;
 }

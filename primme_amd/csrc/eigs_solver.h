@@ -89,6 +89,17 @@ typedef struct pa_solver {
    int spec_fused;         /* the tail ran through the fused operator launch: the projected, un-normalised
                               vector sits in T(:,0), V(:,k) already holds the normalised one */
    double *spec_hcol;      /* K+1 entries: V(:,0:k+1)' W(:,k) */
+   /* Fused restart: the convergence check at a full basis runs through the fused residual
+    * kernel; its residual (scratch column T(:,2)) and overlaps with the old basis are kept here, the restart
+    * turns them into the overlaps with the restarted basis and the first iteration after it starts from them */
+   int fused_restart;      /* on by default; PRIMME_AMD_NO_FUSED_RESTART=1 disables (measurement knob) */
+   int rst_valid, rst_k, rst_L;
+   double rst_theta;
+   double *rst_y;          /* K: coefficient vector of the checked candidate */
+   double *rst_ov;         /* [V'r | Q'r | r'r | W'r | W(:,k-1)'Q] of that pass */
+   int rst_ready, rst_rs;  /* the restart used the stash: rst_c = [V_new'r (rs) | Q'r (L) | r'r | W_new'r (rs)] */
+   double *rst_c;
+   int fov_carry;          /* the overlaps in d_fov / h_fov come from a restart: survive the next candidate check */
    int parallel;           /* reductions cross ranks (numProcs > 1 and a globalSumReal installed) */
    int fuse_gd;            /* GD without preconditioner/Olsen: residual written straight into V */
    int coef_valid_k;       /* d_coef/d_theta currently hold hVecs/hVals of this size, or -1 */

@@ -2,6 +2,7 @@
  * deterministic second stage of every reduction, and the bandwidth probe.
  * See include/primme_amd_kernels.h for the reference routines each entry replaces. */
 #include "hipk_internal.h"
+#include <time.h>
 
 extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
    int ndev = 0;
@@ -39,6 +40,7 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
       ctx->arrive_counter = ctx->fin_counter + 8;
       ctx->seq_issued = 0;
       ctx->spin_wait = getenv("HIPK_NO_SPINWAIT") == NULL;
+      ctx->host_timing = getenv("HIPK_HOST_TIMING") != NULL;
    }
    *out = ctx;
    return 0;
@@ -47,6 +49,9 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
 extern "C" int hipk_ctx_destroy(hipk_ctx *ctx) {
    if (!ctx) return 0;
    hipStreamSynchronize(ctx->stream);
+   if (ctx->host_timing && ctx->ht_waits)
+      fprintf(stderr, "hipk host timing: %ld waits, %.2f us each; %ld turnarounds (wait return -> fused residual launch), %.2f us each\n",
+            ctx->ht_waits, 1e6 * ctx->ht_wait_s / ctx->ht_waits, ctx->ht_turns, ctx->ht_turns ? 1e6 * ctx->ht_turn_s / ctx->ht_turns : 0.0);
    if (ctx->partials) (void)hipFree(ctx->partials);
    if (ctx->jobtab) (void)hipFree(ctx->jobtab);
    if (ctx->fin_counter) (void)hipFree(ctx->fin_counter);
@@ -119,7 +124,29 @@ extern "C" int hipk_sync(hipk_ctx *ctx) {
  * those results (the stream is in order: everything before it has completed as well).  Spins on the
  * completion flag the finalize kernel publishes; falls back to a stream synchronisation when no
  * flagged launch is pending or the flag does not show up in time. */
+static double ht_now(void) {
+   struct timespec ts;
+   clock_gettime(CLOCK_MONOTONIC, &ts);
+   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static int wait_results_impl(hipk_ctx *ctx);
 extern "C" int hipk_wait_results(hipk_ctx *ctx) {
+   if (!ctx->host_timing) return wait_results_impl(ctx);
+   const double t0 = ht_now();
+   const int rc = wait_results_impl(ctx);
+   ctx->ht_t_ret = ht_now();
+   ctx->ht_wait_s += ctx->ht_t_ret - t0;
+   ctx->ht_waits++;
+   return rc;
+}
+/* called at the entry of the fused residual launch */
+void hipk_note_turnaround(hipk_ctx *ctx) {
+   if (!ctx->host_timing || ctx->ht_t_ret == 0.0) return;
+   ctx->ht_turn_s += ht_now() - ctx->ht_t_ret;
+   ctx->ht_turns++;
+   ctx->ht_t_ret = 0.0;
+}
+static int wait_results_impl(hipk_ctx *ctx) {
    if (ctx->spin_wait && ctx->flag_host && ctx->seq_issued > 0) {
       const unsigned long long want = ctx->seq_issued;
       for (long spins = 0; spins < 200000000L; spins++) {
@@ -151,45 +178,52 @@ extern "C" int hipk_timer_stop(hipk_ctx *ctx, float *ms) {
 }
 
 /* ---- stage 2 of every reduction: one block per output, fixed summation order -- */
-__global__ void __launch_bounds__(HIPK_BLOCK)
+#define FIN_MAXBLOCK 1024
+/* STRIDE_O = true: partial-major (partials[b * nout + o]); false: o-major (partials[o * nblocks + b]).
+ * Every lane issues four loads before the first add (the launch is pure latency: a few KB out of L2),
+ * and the block grows with the number of partials so that no lane makes more than a few rounds. */
+template <bool PARTIAL_MAJOR>
+__global__ void __launch_bounds__(FIN_MAXBLOCK)
 hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
       double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
-   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   __shared__ double sm[FIN_MAXBLOCK / HIPK_WAVE];
    const int o = blockIdx.x;
-   double s = 0.0;
-   for (int b = threadIdx.x; b < nblocks; b += HIPK_BLOCK) s += partials[(size_t)b * nout + o];
-   s = hipk_wave_sum(s);
+   const int nt = blockDim.x;
+   const size_t so = PARTIAL_MAJOR ? (size_t)o : (size_t)o * nblocks;
+   const size_t sb = PARTIAL_MAJOR ? (size_t)nout : 1;
+   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+   int b = threadIdx.x;
+   for (; b + 3 * nt < nblocks; b += 4 * nt) {
+      const double a0 = partials[so + (size_t)b * sb], a1 = partials[so + (size_t)(b + nt) * sb];
+      const double a2 = partials[so + (size_t)(b + 2 * nt) * sb], a3 = partials[so + (size_t)(b + 3 * nt) * sb];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+   }
+   {  /* up to three more, clamped instead of predicated so that they go out together */
+      const int last = nblocks - 1;
+      const int b0 = b, b1 = b + nt, b2 = b + 2 * nt;
+      const double a0 = partials[so + (size_t)(b0 < last ? b0 : last) * sb];
+      const double a1 = partials[so + (size_t)(b1 < last ? b1 : last) * sb];
+      const double a2 = partials[so + (size_t)(b2 < last ? b2 : last) * sb];
+      s0 += b0 < nblocks ? a0 : 0.0; s1 += b1 < nblocks ? a1 : 0.0; s2 += b2 < nblocks ? a2 : 0.0;
+   }
+   double s = hipk_wave_sum((s0 + s1) + (s2 + s3));
    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
    __syncthreads();
    if (threadIdx.x == 0) {
-      const double v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      double v = 0.0;
+      const int nw = nt >> 6;
+      for (int w = 0; w < nw; w++) v += sm[w];
       out[o] = v;
       if (out_host) out_host[o] = v;
       hipk_publish_flag(fin, gridDim.x);
    }
 }
-
-/* o-major partials: one block per output, coalesced reads */
-__global__ void __launch_bounds__(HIPK_BLOCK)
-hipk_finalize_t_kernel(const double *__restrict__ partials, int nblocks, int nout,
-      double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
-   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
-   const int o = blockIdx.x;
-   double s = 0.0;
-   for (int b = threadIdx.x; b < nblocks; b += HIPK_BLOCK) s += partials[(size_t)o * nblocks + b];
-   s = hipk_wave_sum(s);
-   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-   __syncthreads();
-   if (threadIdx.x == 0) {
-      const double v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-      out[o] = v;
-      if (out_host) out_host[o] = v;
-      hipk_publish_flag(fin, gridDim.x);
-   }
+static inline int fin_block_for(int nblocks) {
+   return nblocks <= 1024 ? HIPK_BLOCK : (nblocks <= 2048 ? 512 : FIN_MAXBLOCK);
 }
 int hipk_finalize_partials_t(hipk_ctx *ctx, const double *partials, int nblocks, int nout, double *out_dev) {
    if (nout <= 0) return 0;
-   hipLaunchKernelGGL(hipk_finalize_t_kernel, dim3(nout), dim3(HIPK_BLOCK), 0, ctx->stream,
+   hipLaunchKernelGGL(hipk_finalize_kernel<false>, dim3(nout), dim3(fin_block_for(nblocks)), 0, ctx->stream,
          partials, nblocks, nout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
    return 0;
@@ -198,7 +232,7 @@ int hipk_finalize_partials_t(hipk_ctx *ctx, const double *partials, int nblocks,
 int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, int nout,
       double *out_dev) {
    if (nout <= 0) return 0;
-   hipLaunchKernelGGL(hipk_finalize_kernel, dim3(nout), dim3(HIPK_BLOCK), 0, ctx->stream,
+   hipLaunchKernelGGL(hipk_finalize_kernel<true>, dim3(nout), dim3(fin_block_for(nblocks)), 0, ctx->stream,
          partials, nblocks, nout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
    return 0;

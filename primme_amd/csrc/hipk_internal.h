@@ -35,6 +35,11 @@ struct hipk_ctx {
    unsigned int *arrive_counter;             /* device: arrival ticket of the in-kernel second stage (fin_counter + 16) */
    unsigned long long seq_issued;            /* sequence number of the last finalize launch with a mirror */
    int spin_wait;                            /* 0: always hipStreamSynchronize (HIPK_NO_SPINWAIT) */
+   /* HIPK_HOST_TIMING=1 (measurement knob): time the host spends waiting for results, and from the return of
+    * a wait to the next fused-residual launch (the part of an outer iteration the device sits idle for) */
+   int host_timing;
+   double ht_wait_s, ht_turn_s, ht_t_ret;
+   long ht_waits, ht_turns;
 };
 
 static inline double *hipk_mirror_of(const hipk_ctx *ctx, const double *out_dev) {
@@ -79,24 +84,27 @@ struct hipk_fin_args {
    hipk_fin_flag flag;              /* completion flag record (flag == NULL: none) */
    int enabled;
 };
-/* OFF by default (HIPK_INKERNEL_FIN=1 turns it on, read once): measured on the MI355X it LOSES — every
+/* OFF by default (HIPK_INKERNEL_FIN=<mask> turns it on per kernel, read once; 7 = everywhere): measured on the MI355X it LOSES — every
  * workgroup pays an agent-scope release (L2 write-back) before its ticket, and with the thousands of
  * workgroups of the streaming kernels that costs far more than the finalize launch it saves
  * (configs[1]: 588 us per outer iteration with it, 258 us without; the fused SpMV 326 us instead of 45).
  * Kept as a correct, tested alternative for kernels with few workgroups. */
-static inline int hipk_inkernel_fin_enabled(void) {
+/* bit mask: 1 = fused residual kernel (2 workgroups per CU), 2 = Gram-Schmidt update, 4 = fused SpMV */
+enum { HIPK_FIN_RITZ = 1, HIPK_FIN_PROJECT = 2, HIPK_FIN_SPMV = 4 };
+static inline int hipk_inkernel_fin_mask(void) {
    static int v = -1;
-   if (v < 0) v = getenv("HIPK_INKERNEL_FIN") != NULL;
+   if (v < 0) { const char *e = getenv("HIPK_INKERNEL_FIN"); v = e ? atoi(e) : 0; }
    return v;
 }
-static inline hipk_fin_args hipk_make_fin(hipk_ctx *ctx, double *out_dev) {
+static inline hipk_fin_args hipk_make_fin(hipk_ctx *ctx, double *out_dev, int kind) {
    hipk_fin_args fa;
    fa.out = out_dev; fa.out_host = hipk_mirror_of(ctx, out_dev); fa.arrive = ctx->arrive_counter;
-   fa.enabled = hipk_inkernel_fin_enabled() && ctx->arrive_counter != NULL;
+   fa.enabled = (hipk_inkernel_fin_mask() & kind) && ctx->arrive_counter != NULL;
    fa.flag.flag = NULL; fa.flag.counter = NULL; fa.flag.seq = 0;
    if (fa.enabled) fa.flag = hipk_next_flag(ctx, out_dev);
    return fa;
 }
+void hipk_note_turnaround(hipk_ctx *ctx);
 /* make sure ctx->partials can hold n doubles */
 int hipk_reserve_partials(hipk_ctx *ctx, size_t n);
 /* out[o] = sum_b partials[b*nout + o], deterministic order */

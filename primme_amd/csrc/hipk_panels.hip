@@ -641,7 +641,7 @@ static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
    /* one launch covers all columns: its last workgroup finalises the norms itself */
    hipk_fin_args fa;
    memset(&fa, 0, sizeof(fa));
-   if (nrm2_dev && (nx == 1 || nx == 2 || nx == 4 || nx == 8)) fa = hipk_make_fin(ctx, nrm2_dev);
+   if (nrm2_dev && (nx == 1 || nx == 2 || nx == 4 || nx == 8)) fa = hipk_make_fin(ctx, nrm2_dev, HIPK_FIN_PROJECT);
    const int pslot = hipk_prof_begin(HIPK_PROF_PROJECT, ctx->stream, (double)m * sizeof(T) * ((double)sa.total * ((nx + 7) / 8) + 2.0 * nx));
    for (int c0 = 0; c0 < nx;) {
       int rem = nx - c0;
@@ -1229,7 +1229,7 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + 1));
    int rc;
-   const hipk_fin_args fa = hipk_make_fin(ctx, out_dev);
+   const hipk_fin_args fa = hipk_make_fin(ctx, out_dev, HIPK_FIN_RITZ);
    if (vec) rc = want_wtr ? ritz_cgs_k<T, VWT, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa)
                           : ritz_cgs_k<T, VWT, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
    else rc = want_wtr ? ritz_cgs_k<T, 1, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa)
@@ -1243,6 +1243,7 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
 extern "C" int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
       const void *W, int64_t ldVW, int k, const double *hcol_host, double theta, void *dst,
       const void *Q, int64_t ldQ, int L, int want_wtr, double *out_dev) {
+   hipk_note_turnaround(ctx);
    switch (dt) {
    case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, hcol_host, theta, (double *)dst, (const double *)Q, ldQ, L, want_wtr, out_dev);
    case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, hcol_host, theta, (float *)dst, (const float *)Q, ldQ, L, want_wtr, out_dev);

@@ -711,7 +711,7 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    const int gx = ((A->ntiles + 7) / 8) * 8;
    if (hipk_reserve_partials(ctx, (size_t)gx)) return -2;
    const double es = A->dt == HIPK_F64 ? 8 : 4;
-   const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev);
+   const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV);
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
    if (A->dt == HIPK_F64)
       hipLaunchKernelGGL((csr_stream_kernel<double, true>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr,

@@ -154,16 +154,22 @@ def test_dynamic_method_leaves_a_recommendation(built):
     assert np.all(r.resNorms <= 1e-9 * 4.0 * (1 + 1e-6))
 
 
-@pytest.mark.parametrize("wtr", [False, True])
-def test_launch_structure_block_size_one(built, wtr, monkeypatch):
+@pytest.mark.parametrize("mode", ["no_wtr", "no_fused_restart", "default"])
+def test_launch_structure_block_size_one(built, mode, monkeypatch):
     """GD+k, block size 1, no preconditioner: per outer iteration ONE fused residual+overlaps
     pass, ONE Gram-Schmidt update (speculative, reused by the orthogonaliser), and for the
     projection either none (default): the column comes from W'r of the fused pass and only t'At is a
-    (two-vector) inner product, panel inner products remain around restarts (G = W'Q, second passes);
-    or, with PRIMME_AMD_NO_WTR=1, ONE inner-product pass over V (the reference's formula)."""
+    (two-vector) inner product; or, with PRIMME_AMD_NO_WTR=1, ONE inner-product pass over V (the
+    reference's formula).  Default: the iteration after a restart has the same structure (the check at
+    the full basis runs through the fused pass and the restart transforms its overlaps), so panel inner
+    products remain only where pairs are locked; PRIMME_AMD_NO_FUSED_RESTART=1: three panel products
+    around every restart.  Iteration / restart counts are the same in all three modes."""
     import ctypes as C
-    if not wtr:
+    if mode == "no_wtr":
         monkeypatch.setenv("PRIMME_AMD_NO_WTR", "1")
+    if mode == "no_fused_restart":
+        monkeypatch.setenv("PRIMME_AMD_NO_FUSED_RESTART", "1")
+    wtr = mode != "no_wtr"
     lib = checkers.load_hostcheck()
     cnt = (C.c_long * 8)()
     lib.hipk_cpu_counts(cnt, 1)
@@ -173,14 +179,21 @@ def test_launch_structure_block_size_one(built, wtr, monkeypatch):
     lib.hipk_cpu_counts(cnt, 1)
     its, rst = r.stats["numOuterIterations"], r.stats["numRestarts"]
     dots, project, ritz_cgs, fused_tail = cnt[0], cnt[1], cnt[3], cnt[5]
-    assert r.ret == 0 and its == 490
-    # with the library's own operator the tail of the iteration (normalise, A t, t'At) is ONE launch
-    assert (fused_tail >= its - rst - 15 and fused_tail <= its) if wtr else fused_tail == 0
-    assert ritz_cgs >= its - rst - 15 and ritz_cgs <= its
-    if not wtr:
-        assert dots <= its + rst + 25         # projection pass each iteration + CGS dots after restarts
+    assert r.ret == 0 and its == 490 and rst == 69 and r.stats["numMatvecs"] == 490
+    if mode == "default":
+        # every iteration but the ones around a locked pair: fused pass (+ one per restart for the check),
+        # one-launch tail, no panel inner products
+        assert its - 15 <= fused_tail <= its
+        assert its <= ritz_cgs <= its + 25
+        assert dots <= 45
     else:
-        assert dots <= 3 * rst + 40           # panel inner products only around restarts / second passes
+        # with the library's own operator the tail of the iteration (normalise, A t, t'At) is ONE launch
+        assert (fused_tail >= its - rst - 15 and fused_tail <= its) if wtr else fused_tail == 0
+        assert ritz_cgs >= its - rst - 15 and ritz_cgs <= its
+        if not wtr:
+            assert dots <= its + rst + 25         # projection pass each iteration + CGS dots after restarts
+        else:
+            assert dots <= 3 * rst + 40           # panel inner products only around restarts / second passes
     assert project <= its + 25               # one update per new vector (+ rare second passes)
 
 
