@@ -122,6 +122,15 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
       int64_t ldVW, int k, const double *h_dev, int ldh, const double *theta_dev,
       const hipk_job *jobs, int njobs, double *nrm2_dev);
 
+/* hipk_ritz_update with exactly one residual job (the next candidate) that also returns, computed in the
+ * same pass, ov_dev = [ (V h)' r | Q' r | r' r | (W h)' r | W(:,k-1)' Q ] for the first `nbasis` XV and XW jobs
+ * (the restarted basis): the inner products the iteration after a restart starts from.  k <= 32,
+ * nbasis <= 16, L <= 32.  Replaces Num_update_VWXR (reference restart.c:1233-1294) followed by the
+ * Num_gemv_ddh of ortho.c:236-246 and the pass of update_projection.c:99-122 on the restarted basis. */
+int hipk_ritz_update_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
+      int64_t ldVW, int k, const double *h_dev, int ldh, const double *theta_dev, const hipk_job *jobs, int njobs,
+      double *nrm2_dev, int nbasis, const void *Q, int64_t ldQ, int L, double *ov_dev);
+
 /* ---- fused Ritz residual + first Gram-Schmidt pass (block size 1) -------------------
  * dst = W*h - theta*V*h  and  out_dev[0..k+L] = [ V' dst | Q' dst | dst' dst ]  in ONE pass
  * over V, W and Q (hcol_host: k coefficients on the HOST, passed in the kernel arguments; theta by value).  Replaces

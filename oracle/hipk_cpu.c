@@ -148,7 +148,7 @@ int hipk_panel_project_mul(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_s
 int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
       int64_t ld, int k, const double *h, int ldh, const double *theta, const hipk_job *jobs,
       int njobs, double *nrm2) {
-   (void)ctx;
+   (void)ctx; g_cnt[2]++;
    if (k <= 0 || njobs <= 0) return 0;
    double *vr = malloc((size_t)k * 8), *wr = malloc((size_t)k * 8), *outv = malloc((size_t)njobs * 8);
    for (int q = 0; q < njobs; q++) if (jobs[q].kind == HIPK_JOB_RES && jobs[q].slot >= 0) nrm2[jobs[q].slot] = 0.0;
@@ -172,6 +172,47 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
    free(vr); free(wr); free(outv);
    { int ns = 0; for (int q = 0; q < njobs; q++) if (jobs[q].kind == HIPK_JOB_RES && jobs[q].slot + 1 > ns) ns = jobs[q].slot + 1;
      if (ns > 0) mirror(nrm2, ns); }
+   return 0;
+}
+
+/* hipk_ritz_update with one residual job + the residual's inner products with the basis being written:
+ * the update first (row by row, reads before writes), then plain dot products with the STORED columns */
+int hipk_ritz_update_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
+      int64_t ld, int k, const double *h, int ldh, const double *theta, const hipk_job *jobs, int njobs,
+      double *nrm2, int nb, const void *Q, int64_t ldQ, int L, double *ov) {
+   int nres = 0, rq = -1, nxv = 0, nxw = 0;
+   const void *xv[16], *xw[16];
+   g_cnt[6]++; g_cnt[2]--;          /* counted as its own kind, not as the plain update it calls */
+   if (k <= 0 || k > 32 || nb <= 0 || nb > 16 || L < 0 || L > 32 || !ov) return -1;
+   for (int q = 0; q < njobs; q++) {
+      if (jobs[q].kind == HIPK_JOB_RES) { nres++; rq = q; }
+      else if (jobs[q].kind == HIPK_JOB_XV) { if (nxv < nb) xv[nxv] = jobs[q].dst; nxv++; }
+      else if (jobs[q].kind == HIPK_JOB_XW) { if (nxw < nb) xw[nxw] = jobs[q].dst; nxw++; }
+   }
+   if (nres != 1 || nxv < nb || nxw < nb) return -1;
+   /* W(:,k-1)'Q and the residual (which needs the OLD basis) before anything is overwritten */
+   const int nsl = 2 * nb + 2 * L + 1;
+   double *r = malloc((size_t)(m > 0 ? m : 1) * 8);
+   for (int j = 0; j < nsl; j++) ov[j] = 0.0;
+   const double *hc = h + (size_t)jobs[rq].col * ldh;
+   for (int64_t i = 0; i < m; i++) {
+      double x = 0, y = 0;
+      for (int j = 0; j < k; j++) { x += ld_(dt, colp(dt, V, ld, j), i) * hc[j]; y += ld_(dt, colp(dt, W, ld, j), i) * hc[j]; }
+      double v = y - theta[jobs[rq].col] * x;
+      if (dt == HIPK_F32) v = (double)(float)v;
+      r[i] = v;
+      for (int l = 0; l < L; l++) ov[2 * nb + L + 1 + l] += ld_(dt, colp(dt, W, ld, k - 1), i) * ld_(dt, colp(dt, Q, ldQ, l), i);
+   }
+   double dummy[64];
+   int rc = hipk_ritz_update(ctx, dt, m, V, W, ld, k, h, ldh, theta, jobs, njobs, nrm2 ? nrm2 : dummy);
+   if (rc) { free(r); return rc; }
+   for (int64_t i = 0; i < m; i++) {
+      for (int o = 0; o < nb; o++) { ov[o] += ld_(dt, xv[o], i) * r[i]; ov[nb + L + 1 + o] += ld_(dt, xw[o], i) * r[i]; }
+      for (int l = 0; l < L; l++) ov[nb + l] += ld_(dt, colp(dt, Q, ldQ, l), i) * r[i];
+      ov[nb + L] += r[i] * r[i];
+   }
+   free(r);
+   mirror(ov, (size_t)nsl);
    return 0;
 }
 

@@ -189,6 +189,7 @@ def declare_kernels(lib):
         "hipk_panel_project": [_vp, _i, _i64, P(HipkSeg), _i, _vp, _i, _vp, _i64, _i, _vp],
         "hipk_ritz_update": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, P(HipkJob), _i, _vp],
         "hipk_ritz_residual_overlaps": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, C.c_double, _vp, _vp, _i64, _i, _i, _vp],
+        "hipk_ritz_update_overlaps": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, P(HipkJob), _i, _vp, _i, _vp, _i64, _i, _vp],
         "hipk_pair_dots": [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i, _vp],
         "hipk_sym_eig": [_vp, _i, _vp, _i, _vp, _vp, _i],
         "hipk_xpay_cols": [_vp, _i, _i64, _dp, _vp, _i64, _vp, _i64, _i],

@@ -196,6 +196,52 @@ int pa_restart_stash_eligible(const pa_solver *s, int basisSize, int nLk) {
    return pa_fuse_tail_eligible(s);
 }
 
+/* Speculative restart (eigs_solver.h): at the full-basis check of candidate `col`, predict the restart's
+ * coefficient block by a dry run and, if the candidate leads it, run the restart pass NOW, out of place into
+ * V2 / W2: it forms the residual (scratch column T(:,2)), its norm and its inner products with the new basis in
+ * the same pass over V and W that the restart would make anyway; Q'r and W(:,k-1)'Q take one panel product with
+ * two right-hand sides.  Returns 1 (done, *norm2 set), 0 (not applicable: the caller runs the fused residual
+ * pass on the old basis) or a negative error. */
+int pa_restart_plan(pa_solver *s, int basisSize, const int *flags_in, const int *iev_in, int nblock, int numLocked,
+      int nprevhVecs, const int *map);
+static int try_speculative_restart(pa_solver *s, int basisSize, int nLk, const int *flags, const int *iev, int nblock,
+      int numLocked, int nprevhVecs, const int *map, int col, double *norm2) {
+   const int K = s->K, ldh = basisSize;
+   s->pl_launched = 0;
+   if (!s->V2 || !s->plan_allowed || 64 + 2 * nLk > s->red_cap) return 0;
+   if (pa_restart_plan(s, basisSize, flags, iev, nblock, numLocked, nprevhVecs, map)) return 0;
+   const int rs = s->pl_rs;
+   if (s->pl_L != nLk || rs < 1 || 8 + 2 * rs + 1 > 64 || s->h_theta2[0] != s->hVals[col] ||
+         memcmp(s->h_coef2, s->hVecs + (size_t)col * ldh, (size_t)basisSize * sizeof(double)))
+      return 0;                                  /* the candidate is not what the restart would continue with */
+   CHK(hipk_h2d(s->ctx, s->d_coef2, s->h_coef2, (size_t)K * (rs + 1) * sizeof(double)));
+   CHK(hipk_h2d(s->ctx, s->d_theta2, s->h_theta2, (size_t)basisSize * sizeof(double)));
+   hipk_job jobs[2 * 16 + 2];
+   int nj = 0;
+   for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, s->V2, s->ld, c), -1};
+   for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, PCOL(s, s->W2, s->ld, c), -1};
+   jobs[nj++] = (hipk_job){HIPK_JOB_XW, rs, TCOL(s, 3), -1};            /* the unit column: W(:,k-1) next to r */
+   jobs[nj++] = (hipk_job){HIPK_JOB_RES, 0, TCOL(s, 2), 0};
+   CHK(hipk_ritz_update_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef2, K, s->d_theta2, jobs, nj,
+         s->d_red, rs, NULL, 0, 0, s->d_red + 8));
+   if (nLk > 0) {
+      hipk_seg seg = {s->evecs, s->ldevecs, nLk};
+      CHK(pa_reduce(s, s->d_red + 8, 2 * rs + 1, 0, 1));
+      CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, TCOL(s, 2), s->ld, 2, s->d_red + 64, nLk));
+      CHK(pa_reduce(s, s->d_red + 64, 2 * nLk, 0, 0));
+   } else {
+      CHK(pa_reduce(s, s->d_red + 8, 2 * rs + 1, 0, 0));
+   }
+   const double *o = s->h_red + 8, *q = s->h_red + 64;
+   double *c = s->rst_c;                          /* [V_new'r (rs) | Q'r (L) | r'r | W_new'r (rs)] */
+   for (int j = 0; j < rs; j++) { c[j] = o[j]; c[rs + nLk + 1 + j] = o[rs + 1 + j]; }
+   for (int l = 0; l < nLk; l++) { c[rs + l] = q[l]; s->rst_grow[l] = q[nLk + l]; }
+   c[rs + nLk] = o[rs];
+   *norm2 = o[rs];
+   s->pl_launched = 1;
+   return 1;
+}
+
 /* The speculative tail of a block-size-1 GD iteration, enqueued right after the fused residual pass: the
  * first Gram-Schmidt update with the device-resident overlaps, then (speculate2) normalisation, operator
  * application and the new column of H, so that the host synchronises once.  `rsrc` holds the residual
@@ -452,6 +498,14 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          double t0 = pa_wtime();
          s->fov_valid = 0;
          s->rst_valid = 0;
+         double n2spec = 0.0;
+         const int spec = try_speculative_restart(s, basisSize, nLk, flags, iev, *blockSize + 1, numLocked, nprevhVecs, map, col, &n2spec);
+         if (spec < 0) { rc = spec; goto out; }
+         if (spec == 1) {
+            blockNorms[*blockSize] = sqrt(n2spec);
+            p->stats.timeDense += pa_wtime() - t0;
+            p->stats.flopsDense += (double)s->m * 2.0 * basisSize * (s->pl_rs + 1);
+         } else {
          if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
                     s->hVecs + (size_t)col * ldh, s->hVals[col], TCOL(s, 2), s->evecs, s->ldevecs, nLk, 1, s->d_fov))) goto out;
          if ((rc = pa_reduce(s, s->d_fov, nfov, 0, 0))) goto out;
@@ -462,6 +516,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          s->rst_k = basisSize; s->rst_L = nLk; s->rst_valid = 1;
          p->stats.timeDense += pa_wtime() - t0;
          p->stats.flopsDense += (double)s->m * 2.0 * basisSize;
+         }
       } else {
          s->fov_valid = 0;
          if ((rc = pa_push_coefficients(s, basisSize, ldh))) goto out;

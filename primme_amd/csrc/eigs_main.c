@@ -23,6 +23,7 @@
 double pa_problem_norm(int overrideUser, const primme_params *p);
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
 int pa_refresh_wtq(pa_solver *s, int basisSize, int nLk);
+int pa_block_first_reorder(pa_solver *s, int basisSize, int *flags, const int *iev, int blockSize, int numConverged, int numLocked);
 int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0, int nc);
 int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc);
 int pa_random_col(pa_solver *s, char *col);
@@ -639,9 +640,15 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                double dummyZero = 0.0;
                double *srn = (p->target == primme_closest_abs || p->target == primme_largest_abs)
                                    ? &dummyZero : &smallestResNorm;
-               CHK(pa_prepare_candidates(s, basisSize, NULL, NULL, 0, flags, maxRecentlyConverged, s->blockNorms,
-                     blockSize, availableBlockSize, numLocked, evals, resNorms, iev, &blockSize,
-                     &recentlyConverged, srn, numConverged, s->basisNorms, &reset, nprevhVecs, 0, map));
+               s->plan_allowed = (numGuesses <= 0 && p->dynamicMethodSwitch <= 0);
+               s->pl_launched = 0;
+               {
+                  int rcp = pa_prepare_candidates(s, basisSize, NULL, NULL, 0, flags, maxRecentlyConverged, s->blockNorms,
+                        blockSize, availableBlockSize, numLocked, evals, resNorms, iev, &blockSize,
+                        &recentlyConverged, srn, numConverged, s->basisNorms, &reset, nprevhVecs, 0, map);
+                  s->plan_allowed = 0;
+                  CHK(rcp);
+               }
 
                if (s->Q && numConverged + recentlyConverged > numLocked && p->numTargetShifts > numLocked + 1)
                   blockSize = 0;   /* the next pair may belong to a different target shift */
@@ -651,31 +658,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                               p->target == primme_closest_leq))
                      numConverged++;
 
-               /* converged pairs and the block first */
-               int *iwork = (int *)malloc((size_t)basisSize * sizeof(int));
-               if (!iwork) return PRIMME_MALLOC_FAILURE;
-               int j, k, l, mm;
-               for (i = k = l = mm = 0; i < basisSize; i++) {
-                  int inIev = 0;
-                  for (j = 0; j < blockSize; j++) if (iev[j] == i) inIev = 1;
-                  if ((flags[i] != UNCONV && mm++ < numConverged - numLocked) || inIev) iwork[k++] = i;
-                  else iwork[numConverged - numLocked + blockSize + l++] = i;
-               }
-               pa_permute_cols(s->hVals, 1, basisSize, 1, iwork);
-               pa_permute_cols(s->hVecs, basisSize, basisSize, basisSize, iwork);
-               pa_permute_ints(flags, basisSize, iwork);
-               if (s->hVecsRot) {
-                  for (int c = s->numArbitraryVecs; c < basisSize; c++) {
-                     for (int r = 0; r < s->K; r++) s->hVecsRot[r + (size_t)c * s->K] = 0.0;
-                     s->hVecsRot[c + (size_t)c * s->K] = 1.0;
-                  }
-                  pa_permute_cols(s->hVecsRot, basisSize, basisSize, s->K, iwork);
-                  int last = 0;
-                  for (i = 0; i < basisSize; i++) if (iwork[i] != i) last = i + 1;
-                  s->numArbitraryVecs = PA_MAX(s->numArbitraryVecs, last);
-               }
-               s->coef_valid_k = -1;
-               free(iwork);
+               CHK(pa_block_first_reorder(s, basisSize, flags, iev, blockSize, numConverged, numLocked));
             } else {
                blockSize = availableBlockSize;
                for (i = 0; i < blockSize; i++) iev[i] = i;
@@ -804,6 +787,8 @@ static void free_solver(pa_solver *s) {
    if (s->ctx) {
       hipk_sync(s->ctx);
       hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T); hipk_free(s->ctx, s->Jw);
+      hipk_free(s->ctx, s->V2); hipk_free(s->ctx, s->W2); hipk_free(s->ctx, s->d_coef2); hipk_free(s->ctx, s->d_theta2);
+      hipk_host_free(s->ctx, s->h_coef2); hipk_host_free(s->ctx, s->h_theta2);
       hipk_free(s->ctx, s->evecsHat); hipk_free(s->ctx, s->Q);
       hipk_free(s->ctx, s->d_red); hipk_free(s->ctx, s->d_coef); hipk_free(s->ctx, s->d_theta);
       hipk_host_free(s->ctx, s->h_red); hipk_host_free(s->ctx, s->h_coef); hipk_host_free(s->ctx, s->h_theta);
@@ -811,7 +796,7 @@ static void free_solver(pa_solver *s) {
    }
    free(s->H); free(s->hVecs); free(s->prevhVecs); free(s->hVals); free(s->prevRitzVals);
    free(s->Mq); free(s->Mlu); free(s->Mpiv); free(s->R); free(s->QtV); free(s->hU); free(s->hSVals); free(s->hVecsRot);
-   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol); free(s->wtq); free(s->rst_y); free(s->rst_ov); free(s->rst_c);
+   free(s->VtBV); free(s->fVtBV); free(s->blockNorms); free(s->basisNorms); free(s->spec_hcol); free(s->wtq); free(s->rst_y); free(s->rst_ov); free(s->rst_c); free(s->rst_grow);
    free(s->flags); free(s->map); free(s->iev); free(s->perm); free(s->lockedFlags);
    free(s);
 }
@@ -941,6 +926,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->rst_y = (double *)calloc((size_t)K + 1, 8);
    s->rst_ov = (double *)calloc(4 * (size_t)HIPK_WTR_MAX_K + 4, 8);
    s->rst_c = (double *)calloc(4 * (size_t)HIPK_WTR_MAX_K + 4, 8);
+   s->rst_grow = (double *)calloc((size_t)HIPK_WTR_MAX_K + 1, 8);
    s->fused_restart = getenv("PRIMME_AMD_NO_FUSED_RESTART") == NULL;
    s->wtq_rows = -1;
    if (harmonic) {
@@ -963,6 +949,17 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    }
    if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap * 2);
    if (!rc) { s->d_fov = s->d_red + s->red_cap; s->h_fov = s->h_red + s->red_cap; }
+   if (!rc && s->fused_restart && s->fuse_gd && b == 1 && p->locking && !harmonic && K <= 32 && s->nT >= 4 &&
+         s->red_cap >= 64 + 2 * HIPK_WTR_MAX_K && getenv("PRIMME_AMD_NO_SPEC_RESTART") == NULL) {
+      /* alternate panels of the speculative restart (eigs_solver.h); without them the restart runs in place */
+      if (hipk_malloc(s->ctx, colBytes * K, (void **)&s->V2) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W2) ||
+            hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef2) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta2) ||
+            hipk_host_alloc(s->ctx, (size_t)K * K * 8, (void **)&s->h_coef2) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta2)) {
+         hipk_free(s->ctx, s->V2); hipk_free(s->ctx, s->W2); hipk_free(s->ctx, s->d_coef2); hipk_free(s->ctx, s->d_theta2);
+         hipk_host_free(s->ctx, s->h_coef2); hipk_host_free(s->ctx, s->h_theta2);
+         s->V2 = s->W2 = NULL; s->d_coef2 = s->d_theta2 = s->h_coef2 = s->h_theta2 = NULL;
+      }
+   }
    if (rc || !s->H || !s->hVecs || !s->prevhVecs || !s->hVals || !s->prevRitzVals || !s->blockNorms ||
          !s->basisNorms || !s->flags || !s->map || !s->iev || !s->perm || !s->lockedFlags) {
       free_solver(s);

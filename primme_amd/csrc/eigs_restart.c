@@ -208,6 +208,40 @@ static int move_cols(pa_solver *s, char *base, const int *src, const int *dst, i
    return 0;
 }
 
+/* Before a restart: converged pairs and the block first (coefficient vectors, Ritz values and flags alike;
+ * reference main_iter.c:971-998) */
+int pa_block_first_reorder(pa_solver *s, int basisSize, int *flags, const int *iev, int blockSize, int numConverged,
+      int numLocked) {
+   int *iwork = (int *)malloc((size_t)(basisSize > 0 ? basisSize : 1) * sizeof(int));
+   if (!iwork) return PRIMME_MALLOC_FAILURE;
+   int i, j, k, l, mm;
+   for (i = k = l = mm = 0; i < basisSize; i++) {
+      int inIev = 0;
+      for (j = 0; j < blockSize; j++) if (iev[j] == i) inIev = 1;
+      if ((flags[i] != UNCONV && mm++ < numConverged - numLocked) || inIev) iwork[k++] = i;
+      else iwork[numConverged - numLocked + blockSize + l++] = i;
+   }
+   pa_permute_cols(s->hVals, 1, basisSize, 1, iwork);
+   pa_permute_cols(s->hVecs, basisSize, basisSize, basisSize, iwork);
+   pa_permute_ints(flags, basisSize, iwork);
+   if (s->hVecsRot) {
+      for (int c = s->numArbitraryVecs; c < basisSize; c++) {
+         for (int r = 0; r < s->K; r++) s->hVecsRot[r + (size_t)c * s->K] = 0.0;
+         s->hVecsRot[c + (size_t)c * s->K] = 1.0;
+      }
+      pa_permute_cols(s->hVecsRot, basisSize, basisSize, s->K, iwork);
+      int last = 0;
+      for (i = 0; i < basisSize; i++) if (iwork[i] != i) last = i + 1;
+      s->numArbitraryVecs = PA_MAX(s->numArbitraryVecs, last);
+   }
+   s->coef_valid_k = -1;
+   free(iwork);
+   return 0;
+}
+
+#define PA_PLANNED 7701     /* dry run of the restart: stopped where the pass would start */
+#define PA_PLAN_NONE 7702   /* dry run: this restart is not one the speculative pass covers */
+
 /* ---- fused restart ------------------------------------------------------
  * The convergence check at a full basis left the candidate's residual in T(:,2) and its overlaps with
  * the old basis in s->rst_ov (eigs_conv.c).  When the restart keeps that candidate as the next block and
@@ -216,6 +250,26 @@ static int move_cols(pa_solver *s, char *base, const int *src, const int *dst, i
 static int stash_matches(const pa_solver *s, int basisSize, int ldh, int col, int nLk) {
    return s->rst_valid && s->rst_k == basisSize && s->rst_L == nLk && s->hVals[col] == s->rst_theta &&
           memcmp(s->hVecs + (size_t)col * ldh, s->rst_y, (size_t)basisSize * sizeof(double)) == 0;
+}
+/* G = (W h)'Q = h'(W'Q) for the restarted basis: rows 0..k-2 of W'Q are on the host, row k-1 (`grow`) came out of
+ * the pass; h = rs coefficient columns, K-strided */
+static int transform_wtq(pa_solver *s, const double *h, int k, int rs, int nLk, const double *grow) {
+   const int K = s->K;
+   if (nLk > 0) {
+      double *g = (double *)malloc((size_t)rs * nLk * sizeof(double));
+      if (!g) return PRIMME_MALLOC_FAILURE;
+      for (int l = 0; l < nLk; l++)
+         for (int cc = 0; cc < rs; cc++) {
+            double a = h[(k - 1) + (size_t)cc * K] * grow[l];
+            for (int j = 0; j < k - 1; j++) a += h[j + (size_t)cc * K] * s->wtq[j + (size_t)l * K];
+            g[cc + (size_t)l * rs] = a;
+         }
+      for (int l = 0; l < nLk; l++)
+         for (int cc = 0; cc < rs; cc++) s->wtq[cc + (size_t)l * K] = g[cc + (size_t)l * rs];
+      free(g);
+   }
+   s->wtq_rows = rs; s->wtq_L = nLk;
+   return 0;
 }
 /* h = the rs leading coefficient columns just pushed (K-strided in h_coef) */
 static int stash_transform(pa_solver *s, int basisSize, int rs, int nLk) {
@@ -229,21 +283,7 @@ static int stash_transform(pa_solver *s, int basisSize, int rs, int nLk) {
    }
    for (int l = 0; l < nLk; l++) c[rs + l] = ovQ[l];
    c[rs + nLk] = s->rst_ov[nov];
-   if (nLk > 0) {
-      /* G = (W h)'Q = h'(W'Q): rows 0..k-2 of W'Q are on the host, row k-1 came out of the check pass */
-      double *g = (double *)malloc((size_t)rs * nLk * sizeof(double));
-      if (!g) return PRIMME_MALLOC_FAILURE;
-      for (int l = 0; l < nLk; l++)
-         for (int cc = 0; cc < rs; cc++) {
-            double a = s->h_coef[(k - 1) + (size_t)cc * K] * grow[l];
-            for (int j = 0; j < k - 1; j++) a += s->h_coef[j + (size_t)cc * K] * s->wtq[j + (size_t)l * K];
-            g[cc + (size_t)l * rs] = a;
-         }
-      for (int l = 0; l < nLk; l++)
-         for (int cc = 0; cc < rs; cc++) s->wtq[cc + (size_t)l * K] = g[cc + (size_t)l * rs];
-      free(g);
-   }
-   s->wtq_rows = rs; s->wtq_L = nLk;
+   CHK(transform_wtq(s, s->h_coef, k, rs, nLk, grow));
    s->rst_ready = 1; s->rst_rs = rs;
    return 0;
 }
@@ -254,6 +294,7 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
       int *hVecsPerm) {
    primme_params *p = s->p;
    int i, j, k;
+   if (s->plan_only) return PA_PLAN_NONE;
 
    /* a previously converged pair whose Ritz value drifted more than its residual
     * norm is targeted again */
@@ -348,8 +389,31 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
 
    pa_permute_cols(s->hVals, 1, basisSize, 1, restartPerm);
    pa_permute_cols(s->hVecs, basisSize, basisSize, ldh, restartPerm);
+   if (s->plan_only) {
+      /* dry run: this is the coefficient block the pass would get.  One more column, a unit vector, makes the
+       * pass copy W(:,k-1) next to the residual (its inner products with Q are needed, eigs_conv.c) */
+      const int rs0 = *restartSize, K = s->K;
+      if (sizeBlockNorms != 1 || numPacked != 0 || rs0 > 16 || rs0 + 1 > K || !s->h_coef2) return PA_PLAN_NONE;
+      for (int c = 0; c < rs0; c++) {
+         memcpy(s->h_coef2 + (size_t)c * K, s->hVecs + (size_t)c * ldh, (size_t)basisSize * sizeof(double));
+         for (int r2 = basisSize; r2 < K; r2++) s->h_coef2[r2 + (size_t)c * K] = 0.0;
+      }
+      for (int r2 = 0; r2 < K; r2++) s->h_coef2[r2 + (size_t)rs0 * K] = (r2 == basisSize - 1) ? 1.0 : 0.0;
+      memcpy(s->h_theta2, s->hVals, (size_t)basisSize * sizeof(double));
+      s->pl_rs = rs0; s->pl_k = basisSize; s->pl_L = nOC + *numLocked;
+      return PA_PLANNED;
+   }
+   /* the speculative pass already ran with exactly this block (eigs_conv.c): adopt its panels */
+   int use_plan = 0;
+   if (s->pl_launched && sizeBlockNorms == 1 && numPacked == 0 && s->fuse_gd && s->V2 && *restartSize == s->pl_rs &&
+         basisSize == s->pl_k && nOC + *numLocked == s->pl_L && s->hVals[0] == s->h_theta2[0]) {
+      use_plan = 1;
+      for (int c = 0; c < *restartSize && use_plan; c++)
+         if (memcmp(s->hVecs + (size_t)c * ldh, s->h_coef2 + (size_t)c * s->K, (size_t)basisSize * sizeof(double))) use_plan = 0;
+   }
+   s->pl_launched = 0;
    s->coef_valid_k = -1;
-   CHK(pa_push_coefficients(s, basisSize, ldh));
+   if (!use_plan) CHK(pa_push_coefficients(s, basisSize, ldh));
 
    /* one fused pass over V and W */
    double *lockedResNorms = &resNorms[*numLocked];
@@ -364,8 +428,19 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
       for (int c = 0; c < sizeBlockNorms; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, X, s->ld, c), -1};
    for (int c = 0; c < numPacked; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, left + c, ECOL(s, *numLocked + nOC + c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
-   const int use_stash = (sizeBlockNorms == 1 && numPacked == 0 && s->fuse_gd &&
+   if (use_plan) {
+      /* nothing to run: V2 / W2 hold V h, W h; the residual is in T(:,2); rst_c has its overlaps */
+      char *t = s->V; s->V = s->V2; s->V2 = t;
+      t = s->W; s->W = s->W2; s->W2 = t;
+      blockNorms[0] = sqrt(s->rst_c[rs + nOC + *numLocked]);
+      CHK(transform_wtq(s, s->h_coef2, basisSize, rs, nOC + *numLocked, s->rst_grow));
+      s->rst_ready = 1; s->rst_rs = rs;
+      free(jobs); free(norms);
+      jobs = NULL; norms = NULL;
+   }
+   const int use_stash = use_plan || (sizeBlockNorms == 1 && numPacked == 0 && s->fuse_gd &&
                           stash_matches(s, basisSize, ldh, 0, nOC + *numLocked));
+   if (use_plan) goto pass_done;
    if (!use_stash)
       for (int c = 0; c < sizeBlockNorms; c++)
          jobs[nj++] = (hipk_job){HIPK_JOB_RES, c, s->fuse_gd ? PCOL(s, X, s->ld, c) : PCOL(s, R, s->ld, c), c};
@@ -383,6 +458,7 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
    for (int c = 0; c < numPacked; c++)
       lockedResNorms[c] = PA_MAX(norms[sizeBlockNorms + c], p->stats.estimateResidualError);
    free(norms);
+pass_done:
 
    CHK(refresh_gram_after_restart(s, *numLocked + nOC, basisSize, rs, ldh));
 
@@ -544,9 +620,11 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
    primme_params *p = s->p;
    const int ldh = basisSize;
    int i, restartSize;
-   s->fov_valid = 0;
-   s->fov_carry = 0;
-   s->rst_ready = 0;
+   if (!s->plan_only) {
+      s->fov_valid = 0;
+      s->fov_carry = 0;
+      s->rst_ready = 0;
+   }
 
    for (i = 0, *numConverged = *numLocked; i < basisSize; i++) {
       if (flags[i] == SKIP_RESTART) flags[i] = UNCONV;
@@ -684,4 +762,51 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
    }
    s->rst_ready = 0;
    return 0;
+}
+
+/* Dry run of what the main loop and pa_restart do between the convergence check at a full basis and the restart
+ * pass, under the assumption that the candidate iev_in[nblock-1] is NOT converged: on success (0) h_coef2 /
+ * h_theta2 hold the coefficient block and Ritz values the pass would be called with, pl_rs its width.  The real
+ * functions run on the live coefficient data, which is saved and put back. */
+int pa_restart_plan(pa_solver *s, int basisSize, const int *flags_in, const int *iev_in, int nblock, int numLocked,
+      int nprevhVecs, const int *map) {
+   primme_params *p = s->p;
+   const int K = s->K;
+   if (!s->V2 || !s->plan_allowed || !p->locking || basisSize > K || nblock < 1) return 1;
+   const size_t kk = (size_t)K * K;
+   double *sv = (double *)malloc((2 * kk + K) * sizeof(double));
+   int *fl = (int *)malloc((size_t)(2 * K + 2) * sizeof(int));
+   if (!sv || !fl) { free(sv); free(fl); return 1; }
+   int *iv = fl + K;
+   memcpy(sv, s->hVecs, kk * sizeof(double));
+   memcpy(sv + kk, s->prevhVecs, kk * sizeof(double));
+   memcpy(sv + 2 * kk, s->hVals, (size_t)K * sizeof(double));
+   memcpy(fl, flags_in, (size_t)basisSize * sizeof(int));
+   memcpy(iv, iev_in, (size_t)nblock * sizeof(int));
+   const primme_stats st = p->stats;
+   PRIMME_INT seed[4];
+   memcpy(seed, p->iseed, sizeof(seed));
+   const int cvk = s->coef_valid_k, nav = s->numArbitraryVecs;
+
+   int numConverged = numLocked;
+   for (int i = 0; i < basisSize; i++)
+      if (fl[i] != UNCONV && numConverged < p->numEvals &&
+            (i < p->numEvals - numLocked || p->target == primme_closest_geq || p->target == primme_closest_leq))
+         numConverged++;
+   int rc = pa_block_first_reorder(s, basisSize, fl, iv, nblock, numConverged, numLocked);
+   if (!rc) {
+      pa_permute_cols(s->prevhVecs, basisSize, nprevhVecs, K, map);
+      int nc = numConverged, nl = numLocked, ievSize = nblock, rsOut = 0, rsr = 1;
+      s->plan_only = 1;
+      rc = pa_restart(s, basisSize, fl, iv, &ievSize, NULL, NULL, NULL, NULL, &nc, &nl, NULL, nprevhVecs, 0, &rsOut, &rsr);
+      s->plan_only = 0;
+   }
+   memcpy(s->hVecs, sv, kk * sizeof(double));
+   memcpy(s->prevhVecs, sv + kk, kk * sizeof(double));
+   memcpy(s->hVals, sv + 2 * kk, (size_t)K * sizeof(double));
+   p->stats = st;
+   memcpy(p->iseed, seed, sizeof(seed));
+   s->coef_valid_k = cvk; s->numArbitraryVecs = nav;
+   free(sv); free(fl);
+   return rc == PA_PLANNED ? 0 : 1;
 }

@@ -100,6 +100,17 @@ typedef struct pa_solver {
    int rst_ready, rst_rs;  /* the restart used the stash: rst_c = [V_new'r (rs) | Q'r (L) | r'r | W_new'r (rs)] */
    double *rst_c;
    int fov_carry;          /* the overlaps in d_fov / h_fov come from a restart: survive the next candidate check */
+   /* Speculative restart (second half): with locking, the check at the full basis IS the
+    * restart pass, run out of place into the alternate panels V2 / W2 with the coefficient block a dry run of the
+    * restart (plan_only) predicts for "candidate not converged"; the real restart adopts the result (swaps the
+    * panels) if it arrives at the same coefficients bit for bit, and otherwise runs its own pass on V, W */
+   char *V2, *W2;
+   double *d_coef2, *d_theta2, *h_coef2, *h_theta2;   /* the predicted block, device + pinned staging */
+   int plan_allowed;       /* set by the main loop around the full-basis check (no guesses pending ...) */
+   int plan_only;          /* pa_restart runs as a dry run: stops where the pass would start */
+   int pl_k, pl_rs, pl_L;  /* the prediction */
+   int pl_launched;        /* the pass ran with it: rst_c holds the overlaps with the new basis, rst_grow W(:,k-1)'Q */
+   double *rst_grow;
    int parallel;           /* reductions cross ranks (numProcs > 1 and a globalSumReal installed) */
    int fuse_gd;            /* GD without preconditioner/Olsen: residual written straight into V */
    int coef_valid_k;       /* d_coef/d_theta currently hold hVecs/hVals of this size, or -1 */

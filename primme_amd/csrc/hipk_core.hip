@@ -184,13 +184,13 @@ extern "C" int hipk_timer_stop(hipk_ctx *ctx, float *ms) {
  * and the block grows with the number of partials so that no lane makes more than a few rounds. */
 template <bool PARTIAL_MAJOR>
 __global__ void __launch_bounds__(FIN_MAXBLOCK)
-hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
+hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout, int pstride,
       double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
    __shared__ double sm[FIN_MAXBLOCK / HIPK_WAVE];
    const int o = blockIdx.x;
    const int nt = blockDim.x;
    const size_t so = PARTIAL_MAJOR ? (size_t)o : (size_t)o * nblocks;
-   const size_t sb = PARTIAL_MAJOR ? (size_t)nout : 1;
+   const size_t sb = PARTIAL_MAJOR ? (size_t)pstride : 1;
    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
    int b = threadIdx.x;
    for (; b + 3 * nt < nblocks; b += 4 * nt) {
@@ -224,16 +224,21 @@ static inline int fin_block_for(int nblocks) {
 int hipk_finalize_partials_t(hipk_ctx *ctx, const double *partials, int nblocks, int nout, double *out_dev) {
    if (nout <= 0) return 0;
    hipLaunchKernelGGL(hipk_finalize_kernel<false>, dim3(nout), dim3(fin_block_for(nblocks)), 0, ctx->stream,
-         partials, nblocks, nout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
+         partials, nblocks, nout, nout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
    return 0;
 }
 
 int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, int nout,
       double *out_dev) {
+   return hipk_finalize_partials_strided(ctx, partials, nblocks, nout, nout, out_dev);
+}
+/* nout results out of rows of `pstride` partials (partials[b * pstride + o], o < nout) */
+int hipk_finalize_partials_strided(hipk_ctx *ctx, const double *partials, int nblocks, int pstride, int nout,
+      double *out_dev) {
    if (nout <= 0) return 0;
    hipLaunchKernelGGL(hipk_finalize_kernel<true>, dim3(nout), dim3(fin_block_for(nblocks)), 0, ctx->stream,
-         partials, nblocks, nout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
+         partials, nblocks, nout, pstride, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
    return 0;
 }

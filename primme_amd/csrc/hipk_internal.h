@@ -110,6 +110,8 @@ int hipk_reserve_partials(hipk_ctx *ctx, size_t n);
 /* out[o] = sum_b partials[b*nout + o], deterministic order */
 int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, int nout,
       double *out_dev);
+int hipk_finalize_partials_strided(hipk_ctx *ctx, const double *partials, int nblocks, int pstride, int nout,
+      double *out_dev);
 /* the same for o-major partials (partials[o * nblocks + b]) */
 int hipk_finalize_partials_t(hipk_ctx *ctx, const double *partials, int nblocks, int nout, double *out_dev);
 

@@ -993,6 +993,188 @@ extern "C" int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
    }
 }
 
+/* ============ restart update + residual of the next candidate + its overlaps ============
+ * The restart pass (X = V h_c, Y = W h_c, any destinations) that also forms the residual r of ONE candidate
+ * and, in registers, its inner products with the basis it is writing: out = [ (V h)' r | Q' r | r' r |
+ * (W h)' r | W(:,k-1)' Q ] for the first nb XV / XW outputs -- what hipk_ritz_residual_overlaps delivers for the
+ * old basis, here for the restarted one, so that the iteration after a restart needs no pass of its own
+ * (reference: Num_update_VWXR in restart.c:1233-1294, then ortho.c:236-246 and update_projection.c:99-122 on the
+ * restarted basis).  One lane per row like ritz_kernel (the whole V and W row in registers before the first
+ * store, so the update may be in place); NB / QM bound the accumulators a lane carries. */
+template <typename T, int NK, int NB, int QM>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+ritz_ov_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
+      const double *__restrict__ h, int ldh, int nh, const double *__restrict__ theta,
+      RitzArgs ja, int nb, const T *__restrict__ Q, int64_t ldQ, int L, int64_t m, double *__restrict__ partials) {
+   extern __shared__ double hs[];   /* hs[c*NK + j], zero padded rows j >= k */
+   constexpr int QN = QM > 0 ? QM : 1;
+   for (int t = threadIdx.x; t < NK * nh; t += HIPK_BLOCK) {
+      int c = t / NK, j = t % NK;
+      hs[t] = (j < k) ? h[j + (size_t)c * ldh] : 0.0;
+   }
+   __syncthreads();
+   const int rcol = ja.res_col[0];
+   const double th = theta[rcol];
+   const double *hr = hs + rcol * NK;
+   T *rdst = (T *)ja.res_dst[0];
+   const T *wlast = W + (size_t)(k - 1) * ld;
+   double ov[NB], ow[NB], oq[QN], og[QN], n2 = 0.0;
+#pragma unroll
+   for (int o = 0; o < NB; o++) { ov[o] = 0.0; ow[o] = 0.0; }
+#pragma unroll
+   for (int l = 0; l < QN; l++) { oq[l] = 0.0; og[l] = 0.0; }
+
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      double row[NK], roww[NK], qv[QN];
+#pragma unroll
+      for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)V[i + (size_t)j * ld] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NK; j++) roww[j] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+      double wl = 0.0;
+      if (QM > 0) {
+#pragma unroll
+         for (int l = 0; l < QN; l++) qv[l] = (l < L) ? (double)Q[i + (size_t)l * ldQ] : 0.0;
+         wl = (double)wlast[i];
+      }
+      double xr = 0.0, yr = 0.0;
+#pragma unroll
+      for (int j = 0; j < NK; j++) xr = fma(row[j], hr[j], xr);
+#pragma unroll
+      for (int j = 0; j < NK; j++) yr = fma(roww[j], hr[j], yr);
+      const T res = (T)fma(-th, xr, yr);
+      const double r = (double)res;
+      n2 = fma(r, r, n2);
+      /* the new basis columns: stored and multiplied with r as stored */
+#pragma unroll
+      for (int o = 0; o < NB; o++)
+         if (o < nb) {
+            const double *hv = hs + (int)ja.xv_col[o] * NK;
+            const double *hw = hs + (int)ja.xw_col[o] * NK;
+            double sv = 0.0, sw = 0.0;
+#pragma unroll
+            for (int j = 0; j < NK; j++) sv = fma(row[j], hv[j], sv);
+#pragma unroll
+            for (int j = 0; j < NK; j++) sw = fma(roww[j], hw[j], sw);
+            const T tv = (T)sv, tw = (T)sw;
+            ((T *)ja.xv_dst[o])[i] = tv;
+            ((T *)ja.xw_dst[o])[i] = tw;
+            ov[o] = fma((double)tv, r, ov[o]);
+            ow[o] = fma((double)tw, r, ow[o]);
+         }
+      for (int o = nb; o < ja.nxv; o++) {
+         const double *hc = hs + (int)ja.xv_col[o] * NK;
+         double sv = 0.0;
+#pragma unroll
+         for (int j = 0; j < NK; j++) sv = fma(row[j], hc[j], sv);
+         ((T *)ja.xv_dst[o])[i] = (T)sv;
+      }
+      for (int o = nb; o < ja.nxw; o++) {
+         const double *hc = hs + (int)ja.xw_col[o] * NK;
+         double sw = 0.0;
+#pragma unroll
+         for (int j = 0; j < NK; j++) sw = fma(roww[j], hc[j], sw);
+         ((T *)ja.xw_dst[o])[i] = (T)sw;
+      }
+      if (rdst) rdst[i] = res;
+      if (QM > 0) {
+#pragma unroll
+         for (int l = 0; l < QN; l++) { oq[l] = fma(qv[l], r, oq[l]); og[l] = fma(wl, qv[l], og[l]); }
+      }
+   }
+   /* block sums, partial-major: partials[block * nsl + slot], slots [ (Vh)'r | Q'r | r'r | (Wh)'r | W(:,k-1)'Q ] */
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][2 * NB + 2 * QN + 1];
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+   const int nsl = 2 * nb + 2 * L + 1;
+#pragma unroll
+   for (int o = 0; o < NB; o++) {
+      const double a = hipk_wave_sum(ov[o]), b = hipk_wave_sum(ow[o]);
+      if (lane == 0 && o < nb) { sm[wv][o] = a; sm[wv][nb + L + 1 + o] = b; }
+   }
+#pragma unroll
+   for (int l = 0; l < QN; l++) {
+      const double a = hipk_wave_sum(oq[l]), b = hipk_wave_sum(og[l]);
+      if (lane == 0 && QM > 0 && l < L) { sm[wv][nb + l] = a; sm[wv][2 * nb + L + 1 + l] = b; }
+   }
+   { const double a = hipk_wave_sum(n2); if (lane == 0) sm[wv][nb + L] = a; }
+   __syncthreads();
+   if ((int)threadIdx.x < nsl)
+      partials[(size_t)blockIdx.x * nsl + threadIdx.x] =
+            (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+template <typename T, int NK, int NB>
+static int ritz_ov_q(hipk_ctx *ctx, int gx, size_t shm, const T *V, const T *W, int64_t ld, int k, const double *h, int ldh, int nh,
+      const double *theta, const RitzArgs &ja, int nb, const T *Q, int64_t ldQ, int L, int64_t m) {
+#define ROV(QMV) hipLaunchKernelGGL((ritz_ov_kernel<T, NK, NB, QMV>), dim3(gx), dim3(HIPK_BLOCK), shm, ctx->stream, V, W, ld, k, h, ldh, nh, theta, ja, nb, Q, ldQ, L, m, ctx->partials)
+   if (L == 0) ROV(0);
+   else if (L <= 8) ROV(8);
+   else if (L <= 16) ROV(16);
+   else if (L <= 32) ROV(32);
+   else return -1;
+#undef ROV
+   HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
+template <typename T>
+static int ritz_ov_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k, const double *h, int ldh,
+      const double *theta, const hipk_job *jobs, int njobs, double *nrm2_dev, int nb, const T *Q, int64_t ldQ, int L,
+      double *ov_dev) {
+   if (k <= 0 || k > 32 || nb <= 0 || nb > 16 || L < 0 || L > 32 || !ov_dev) return -1;
+   RitzArgs ja;
+   memset(&ja, 0, sizeof(ja));
+   int nh = 0, res_slot = -1;
+   for (int q = 0; q < njobs; q++) {
+      const hipk_job &jb = jobs[q];
+      if (jb.col < 0 || jb.col > 255) return -1;
+      if (jb.col + 1 > nh) nh = jb.col + 1;
+      if (jb.kind == HIPK_JOB_XV) {
+         if (ja.nxv >= RITZ_MAXOUT) return -1;
+         ja.xv_col[ja.nxv] = (unsigned char)jb.col; ja.xv_dst[ja.nxv++] = jb.dst;
+      } else if (jb.kind == HIPK_JOB_XW) {
+         if (ja.nxw >= RITZ_MAXOUT) return -1;
+         ja.xw_col[ja.nxw] = (unsigned char)jb.col; ja.xw_dst[ja.nxw++] = jb.dst;
+      } else if (jb.kind == HIPK_JOB_RES) {
+         if (ja.nres >= 1) return -1;             /* one candidate */
+         ja.res_col[0] = (unsigned char)jb.col; ja.res_dst[0] = jb.dst; ja.res_slot[0] = (short)jb.slot; ja.nres = 1;
+         res_slot = jb.slot;
+      } else return -1;
+   }
+   if (ja.nres != 1 || ja.nxv < nb || ja.nxw < nb) return -1;
+   const int nsl = 2 * nb + 2 * L + 1;
+   const int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 2, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * nsl)) return -2;
+   const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + ja.nxv + ja.nxw + (ja.res_dst[0] ? 1 : 0)));
+   int rc;
+   if (k <= 16) {
+      const size_t shm = (size_t)16 * nh * sizeof(double);
+      rc = nb <= 8 ? ritz_ov_q<T, 16, 8>(ctx, gx, shm, V, W, ld, k, h, ldh, nh, theta, ja, nb, Q, ldQ, L, m)
+                   : ritz_ov_q<T, 16, 16>(ctx, gx, shm, V, W, ld, k, h, ldh, nh, theta, ja, nb, Q, ldQ, L, m);
+   } else {
+      const size_t shm = (size_t)32 * nh * sizeof(double);
+      rc = nb <= 8 ? ritz_ov_q<T, 32, 8>(ctx, gx, shm, V, W, ld, k, h, ldh, nh, theta, ja, nb, Q, ldQ, L, m)
+                   : ritz_ov_q<T, 32, 16>(ctx, gx, shm, V, W, ld, k, h, ldh, nh, theta, ja, nb, Q, ldQ, L, m);
+   }
+   hipk_prof_end(pslot, ctx->stream);
+   if (rc) return rc;
+   if (nrm2_dev && res_slot >= 0) {
+      rc = hipk_finalize_partials_strided(ctx, ctx->partials + (nb + L), gx, nsl, 1, nrm2_dev + res_slot);
+      if (rc) return rc;
+   }
+   return hipk_finalize_partials_strided(ctx, ctx->partials, gx, nsl, nsl, ov_dev);
+}
+
+extern "C" int hipk_ritz_update_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W,
+      int64_t ldVW, int k, const double *h_dev, int ldh, const double *theta_dev, const hipk_job *jobs, int njobs,
+      double *nrm2_dev, int nbasis, const void *Q, int64_t ldQ, int L, double *ov_dev) {
+   switch (dt) {
+   case HIPK_F64: return ritz_ov_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev, nbasis, (const double *)Q, ldQ, L, ov_dev);
+   case HIPK_F32: return ritz_ov_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev, nbasis, (const float *)Q, ldQ, L, ov_dev);
+   default: return -44;
+   }
+}
+
 /* ============ fused Ritz residual + first-pass Gram-Schmidt overlaps (b = 1) ============
  * r = W h - theta V h (written to dst), out = [ V' r | Q' r | r' r ] (+ [ W' r | W(:,k-1)' Q ]).
  * In Generalized Davidson without preconditioner the residual IS the new basis vector, and

@@ -11,8 +11,8 @@ ctx = C.c_void_p(); assert lib.hipk_ctx_create(C.byref(ctx), None) == 0
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 m = 2000250; ld = m; K = 16; L = 10
 dt = F.HIPK_F64
-V = torch.randn((K, ld), dtype=torch.float64, device="cuda")
-W = torch.randn((K, ld), dtype=torch.float64, device="cuda")
+V = torch.randn((26, ld), dtype=torch.float64, device="cuda")
+W = torch.randn((26, ld), dtype=torch.float64, device="cuda")
 Q = torch.randn((L, ld), dtype=torch.float64, device="cuda")
 red = torch.zeros(4096, dtype=torch.float64, device="cuda")
 h = torch.randn((K, K), dtype=torch.float64, device="cuda")
@@ -45,6 +45,23 @@ for k in (6, 10, 15):
     timeit(lambda: lib.hipk_ritz_residual_overlaps(ctx, dt, m, V.data_ptr(), W.data_ptr(), ld, k, hhost.ctypes.data_as(C.c_void_p), C.c_double(0.3), V[k].data_ptr(), Q.data_ptr(), ld, L, 0, red.data_ptr()), (2 * k + L + 1) * m * 8, f"ritz+overlaps k={k} L={L}")
     timeit(lambda: lib.hipk_ritz_residual_overlaps(ctx, dt, m, V.data_ptr(), W.data_ptr(), ld, k, hhost.ctypes.data_as(C.c_void_p), C.c_double(0.3), V[k].data_ptr(), Q.data_ptr(), ld, L, 1, red.data_ptr()), (2 * k + L + 1) * m * 8, f"ritz+overlaps+W'r k={k} L={L}")
     timeit(lambda: lib.hipk_pair_dots(ctx, dt, m, V[k].data_ptr(), ld, W[k].data_ptr(), ld, 1, red.data_ptr()), 2 * m * 8, "pair dot t'w")
+# the restart of configs[1]: basis 15 -> 8 columns of V and W, residual of the next candidate
+def restart_jobs(rs, k, out_of_place):
+    off = 16 if out_of_place else 0
+    jb = (F.HipkJob * (2 * rs + 1))()
+    for c in range(rs):
+        jb[c].kind, jb[c].col, jb[c].dst, jb[c].slot = F.HIPK_JOB_XV, c, V[off + c].data_ptr(), -1
+        jb[rs + c].kind, jb[rs + c].col, jb[rs + c].dst, jb[rs + c].slot = F.HIPK_JOB_XW, c, W[off + c].data_ptr(), -1
+    jb[2 * rs].kind, jb[2 * rs].col, jb[2 * rs].dst, jb[2 * rs].slot = F.HIPK_JOB_RES, rs, V[off + rs].data_ptr(), 0
+    return jb
+if V.shape[0] >= 26:
+    for (k, rs) in ((15, 8),):
+        jb = restart_jobs(rs, k, False)
+        timeit(lambda: lib.hipk_ritz_update(ctx, dt, m, V.data_ptr(), W.data_ptr(), ld, k, h.data_ptr(), K, th.data_ptr(), jb, 2 * rs + 1, red.data_ptr()), (2 * k + 2 * rs + 1) * m * 8, f"restart pass k={k} -> {rs} (+ residual)")
+        for LL in (0, 5, 10):
+            for oop in (False, True):
+                jb2 = restart_jobs(rs, k, oop)
+                timeit(lambda: lib.hipk_ritz_update_overlaps(ctx, dt, m, V.data_ptr(), W.data_ptr(), ld, k, h.data_ptr(), K, th.data_ptr(), jb2, 2 * rs + 1, red.data_ptr(), rs, Q.data_ptr(), ld, LL, red.data_ptr() + 8 * 64), (2 * k + LL + 2 * rs + 1) * m * 8, f"restart pass + overlaps k={k} -> {rs} L={LL} {'out of place' if oop else 'in place'}")
 rp, ci, va, n = problems.laplacian_csr((125, 126, 127))
 A = C.c_void_p()
 assert lib.hipk_csr_create(ctx, dt, n, n, 0, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), C.byref(A)) == 0

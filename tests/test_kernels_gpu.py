@@ -210,6 +210,52 @@ def test_ritz_residual_overlaps(built, dt, m, k, L, wtr, pads):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("m,k,nb,L,inplace", [(70001, 15, 8, 0, True), (70001, 15, 8, 5, True), (250003, 15, 8, 10, False),
+                                              (33333, 7, 3, 2, True), (50001, 30, 16, 20, False), (20000, 16, 9, 32, True),
+                                              (999, 2, 1, 1, True)])
+def test_ritz_update_overlaps(built, dt, m, k, nb, L, inplace):
+    """restart pass + residual of the next candidate + its inner products with the basis being written:
+    ov = [(V h)'r | Q'r | r'r | (W h)'r | W(:,k-1)'Q], in place (the restart) and out of place"""
+    rng = np.random.default_rng(m + 7 * k + L)
+    npdt = NPDT[dt]
+    ld, ldq = m + 2, m + 5
+    V = (rng.standard_normal((2 * k + 2, ld)) / np.sqrt(m)).astype(npdt)
+    W = (rng.standard_normal((2 * k + 2, ld)) / np.sqrt(m)).astype(npdt)
+    Q = (rng.standard_normal((max(L, 1), ldq)) / np.sqrt(m)).astype(npdt)
+    h = rng.standard_normal((k, k)) / np.sqrt(k)
+    theta = rng.standard_normal(k)
+    off = 0 if inplace else k + 1            # destination columns
+    rescol = nb if nb < k else k - 1
+    jobs = [(F.HIPK_JOB_XV, c, ("V", off + c), -1) for c in range(nb)]
+    jobs += [(F.HIPK_JOB_XV, k - 1, ("V", 2 * k + 1), -1)]                      # one more output that is not a basis column
+    jobs += [(F.HIPK_JOB_XW, c, ("W", off + c), -1) for c in range(nb)]
+    jobs += [(F.HIPK_JOB_RES, rescol, ("W", 2 * k), 0)]
+    res = []
+    for side in (Dev(), Host()):
+        v, w, q, hh, th = side.arr(V), side.arr(W), side.arr(Q), side.arr(h), side.arr(theta)
+        n2 = side.arr(np.zeros(2)); ov = side.arr(np.zeros(2 * nb + 2 * L + 1))
+        arr = (F.HipkJob * len(jobs))()
+        for i, (kind, col, dst, slot) in enumerate(jobs):
+            arr[i].kind, arr[i].col, arr[i].slot = kind, col, slot
+            arr[i].dst = side.ptr(v if dst[0] == "V" else w, dst[1] * ld).value
+        rc = side.lib.hipk_ritz_update_overlaps(side.ctx, dt, m, side.ptr(v), side.ptr(w), ld, k, side.ptr(hh), k, side.ptr(th),
+                                                arr, len(jobs), side.ptr(n2), nb, side.ptr(q), ldq, L, side.ptr(ov))
+        assert rc == 0
+        res.append((side.get(v)[:, :m], side.get(w)[:, :m], side.get(n2), side.get(ov)))
+        side.close()
+    # the checker against numpy on the same inputs
+    Vd, Wd, Qd = V[:, :m].astype(np.float64), W[:, :m].astype(np.float64), Q[:L, :m].astype(np.float64)
+    r = res[1][1][2 * k]
+    assert np.allclose(r, (h[rescol] @ Wd[:k]) - theta[rescol] * (h[rescol] @ Vd[:k]), atol=1e-5 if dt == F.HIPK_F32 else 1e-13)   # column c of the C array = h[c]
+    exp = np.concatenate([res[1][0][off:off + nb] @ r, Qd @ r, [r @ r], res[1][1][off:off + nb] @ r, Qd @ Wd[k - 1]])
+    assert np.allclose(res[1][3], exp, rtol=1e-3 if dt == F.HIPK_F32 else 1e-9, atol=1e-7)
+    tol = 1e-12 if dt == F.HIPK_F64 else 1e-4
+    assert np.max(np.abs(res[0][0] - res[1][0])) <= tol and np.max(np.abs(res[0][1] - res[1][1])) <= tol
+    assert np.allclose(res[0][2][0], res[1][2][0], rtol=tol * 100)
+    assert np.max(np.abs(res[0][3] - res[1][3])) <= tol * 10 * max(1.0, np.abs(res[1][3]).max())
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
 def test_column_utilities(built, dt):
     rng = np.random.default_rng(11)
     npdt = NPDT[dt]

@@ -154,21 +154,23 @@ def test_dynamic_method_leaves_a_recommendation(built):
     assert np.all(r.resNorms <= 1e-9 * 4.0 * (1 + 1e-6))
 
 
-@pytest.mark.parametrize("mode", ["no_wtr", "no_fused_restart", "default"])
+@pytest.mark.parametrize("mode", ["no_wtr", "no_fused_restart", "no_spec_restart", "default"])
 def test_launch_structure_block_size_one(built, mode, monkeypatch):
     """GD+k, block size 1, no preconditioner: per outer iteration ONE fused residual+overlaps
     pass, ONE Gram-Schmidt update (speculative, reused by the orthogonaliser), and for the
     projection either none (default): the column comes from W'r of the fused pass and only t'At is a
     (two-vector) inner product; or, with PRIMME_AMD_NO_WTR=1, ONE inner-product pass over V (the
-    reference's formula).  Default: the iteration after a restart has the same structure (the check at
-    the full basis runs through the fused pass and the restart transforms its overlaps), so panel inner
-    products remain only where pairs are locked; PRIMME_AMD_NO_FUSED_RESTART=1: three panel products
-    around every restart.  Iteration / restart counts are the same in all three modes."""
+    reference's formula).  Default: the iteration after a restart has the same structure and the check at
+    the full basis is the restart pass itself (eigs_solver.h: speculative restart);
+    PRIMME_AMD_NO_FUSED_RESTART=1: a norm-only pass before and three panel products after every restart.
+    Iteration / restart counts are the same in all modes."""
     import ctypes as C
     if mode == "no_wtr":
         monkeypatch.setenv("PRIMME_AMD_NO_WTR", "1")
     if mode == "no_fused_restart":
         monkeypatch.setenv("PRIMME_AMD_NO_FUSED_RESTART", "1")
+    if mode == "no_spec_restart":
+        monkeypatch.setenv("PRIMME_AMD_NO_SPEC_RESTART", "1")
     wtr = mode != "no_wtr"
     lib = checkers.load_hostcheck()
     cnt = (C.c_long * 8)()
@@ -178,14 +180,20 @@ def test_launch_structure_block_size_one(built, mode, monkeypatch):
               v0=problems.start_vector(n))
     lib.hipk_cpu_counts(cnt, 1)
     its, rst = r.stats["numOuterIterations"], r.stats["numRestarts"]
-    dots, project, ritz_cgs, fused_tail = cnt[0], cnt[1], cnt[3], cnt[5]
+    dots, project, ritz_upd, ritz_cgs, fused_tail, ritz_ov = cnt[0], cnt[1], cnt[2], cnt[3], cnt[5], cnt[6]
     assert r.ret == 0 and its == 490 and rst == 69 and r.stats["numMatvecs"] == 490
     if mode == "default":
-        # every iteration but the ones around a locked pair: fused pass (+ one per restart for the check),
-        # one-launch tail, no panel inner products
+        # every iteration but the ones around a locked pair: one-launch tail, fused pass; the check at the full
+        # basis IS the restart pass (speculative, out of place; with locked pairs plus one panel product for
+        # Q'r and W(:,k-1)'Q): a separate restart pass remains only where a pair gets locked
         assert its - 15 <= fused_tail <= its
-        assert its <= ritz_cgs <= its + 25
-        assert dots <= 45
+        assert rst - 12 <= ritz_ov <= rst and ritz_upd <= 30
+        assert its - rst - 15 <= ritz_cgs <= its - rst + 30
+        assert dots <= rst + 45
+    elif mode == "no_spec_restart":
+        # the check at the full basis is a fused residual pass on the old basis, the restart pass follows
+        assert its - 15 <= fused_tail <= its and ritz_ov == 0
+        assert its <= ritz_cgs <= its + 25 and dots <= 45
     else:
         # with the library's own operator the tail of the iteration (normalise, A t, t'At) is ONE launch
         assert (fused_tail >= its - rst - 15 and fused_tail <= its) if wtr else fused_tail == 0
