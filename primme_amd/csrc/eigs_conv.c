@@ -221,9 +221,9 @@ static int try_speculative_restart(pa_solver *s, int basisSize, int nLk, const i
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, s->V2, s->ld, c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, PCOL(s, s->W2, s->ld, c), -1};
    jobs[nj++] = (hipk_job){HIPK_JOB_XW, rs, TCOL(s, 3), -1};            /* the unit column: W(:,k-1) next to r */
-   jobs[nj++] = (hipk_job){HIPK_JOB_RES, 0, TCOL(s, 2), 0};
+   jobs[nj++] = (hipk_job){HIPK_JOB_RES, 0, TCOL(s, 2), -1};            /* its squared norm is part of the overlaps */
    CHK(hipk_ritz_update_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef2, K, s->d_theta2, jobs, nj,
-         s->d_red, rs, NULL, 0, 0, s->d_red + 8));
+         NULL, rs, NULL, 0, 0, s->d_red + 8));
    if (nLk > 0) {
       hipk_seg seg = {s->evecs, s->ldevecs, nLk};
       CHK(pa_reduce(s, s->d_red + 8, 2 * rs + 1, 0, 1));

@@ -9,7 +9,7 @@ from primme_amd import _ffi as F, problems
 lib = F.load_product()
 ctx = C.c_void_p(); assert lib.hipk_ctx_create(C.byref(ctx), None) == 0
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-m = 2000250; ld = m; K = 16; L = 10
+m = int(os.environ.get("KP_M", "2000250")); ld = m; K = 16; L = 10
 dt = F.HIPK_F64
 V = torch.randn((26, ld), dtype=torch.float64, device="cuda")
 W = torch.randn((26, ld), dtype=torch.float64, device="cuda")
