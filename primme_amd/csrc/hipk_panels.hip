@@ -1803,12 +1803,42 @@ extern "C" int hipk_pair_rotate(hipk_ctx *ctx, hipk_dtype dt, int64_t npairs, co
    return 0;
 }
 
+/* column copy: 16 bytes per lane when the columns allow it (the runtime's 2-D copy reaches 2.4 TB/s) */
+template <typename U>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+copy_cols_kernel(const char *__restrict__ X, size_t ldx_bytes, char *__restrict__ Y, size_t ldy_bytes, size_t n) {
+   const U *x = (const U *)(X + (size_t)blockIdx.y * ldx_bytes);
+   U *y = (U *)(Y + (size_t)blockIdx.y * ldy_bytes);
+   const size_t stride = (size_t)gridDim.x * HIPK_BLOCK;
+   size_t i = (size_t)blockIdx.x * HIPK_BLOCK + threadIdx.x;
+   for (; i + 3 * stride < n; i += 4 * stride) {
+      const U a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+      y[i] = a; y[i + stride] = b; y[i + 2 * stride] = c; y[i + 3 * stride] = d;
+   }
+   for (; i < n; i += stride) y[i] = x[i];
+}
+
 extern "C" int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
       int64_t ldX, void *Y, int64_t ldY, int nx) {
    size_t es = (dt == HIPK_F64) ? 8 : (dt == HIPK_F32) ? 4 : (dt == HIPK_C64) ? 16 : 8;
    if (nx <= 0 || m <= 0) return 0;
-   HIPK_CHECK(hipMemcpy2DAsync(Y, (size_t)ldY * es, X, (size_t)ldX * es, (size_t)m * es, (size_t)nx,
-         hipMemcpyDeviceToDevice, ctx->stream));
+   const size_t bytes = (size_t)m * es, lx = (size_t)ldX * es, ly = (size_t)ldY * es;
+   if (nx > 65535 || bytes < 4096) {
+      HIPK_CHECK(hipMemcpy2DAsync(Y, ly, X, lx, bytes, (size_t)nx, hipMemcpyDeviceToDevice, ctx->stream));
+      return 0;
+   }
+   const bool v16 = ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0) && (nx == 1 || (lx % 16 == 0 && ly % 16 == 0));
+   const size_t us = v16 ? 16 : (es == 4 ? 4 : 8);             /* bytes per lane visit */
+   const size_t n = bytes / us, head = n * us;
+   int gx = hipk_grid_for_rows(ctx, (int64_t)n, HIPK_BLOCK * 4, 8);
+   if (nx > 1) { gx = (gx + nx - 1) / nx; if (gx < 1) gx = 1; }
+   dim3 grid(gx, nx);
+   if (v16) hipLaunchKernelGGL(copy_cols_kernel<uint4>, grid, dim3(HIPK_BLOCK), 0, ctx->stream, (const char *)X, lx, (char *)Y, ly, n);
+   else if (es == 4) hipLaunchKernelGGL(copy_cols_kernel<unsigned int>, grid, dim3(HIPK_BLOCK), 0, ctx->stream, (const char *)X, lx, (char *)Y, ly, n);
+   else hipLaunchKernelGGL(copy_cols_kernel<unsigned long long>, grid, dim3(HIPK_BLOCK), 0, ctx->stream, (const char *)X, lx, (char *)Y, ly, n);
+   HIPK_CHECK(hipGetLastError());
+   if (head < bytes)    /* fewer than 16 bytes per column left over */
+      HIPK_CHECK(hipMemcpy2DAsync((char *)Y + head, ly, (const char *)X + head, lx, bytes - head, (size_t)nx, hipMemcpyDeviceToDevice, ctx->stream));
    return 0;
 }
 
