@@ -193,6 +193,7 @@ int pa_restart_stash_eligible(const pa_solver *s, int basisSize, int nLk) {
    if (basisSize > HIPK_WTR_MAX_K || nLk > HIPK_WTR_MAX_K || basisSize > 32 || nLk > 32) return 0;
    if (nLk > 0 && !(s->wtq_L == nLk && s->wtq_rows >= basisSize - 1)) return 0;
    if (p->n <= (int64_t)p->maxBasisSize + nLk) return 0;      /* the practical-convergence test would read R */
+   if (p->maxMatvecs > 0 && p->stats.numMatvecs + 2 >= p->maxMatvecs) return 0;   /* the tail applies the operator ahead of time */
    return pa_fuse_tail_eligible(s);
 }
 
@@ -460,8 +461,10 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          /* second stage of the speculation: normalise with the norm still on the device, apply
           * the operator and project, so that the whole outer iteration costs ONE host
           * synchronisation.  Needs in-stream reductions (single rank or the RCCL communicator). */
+         /* (not when the application could be the one beyond maxMatvecs: a discarded tail is not counted) */
          const int speculate2 = speculate && !parallel_host && !s->phase_timing && dstc == VCOL(s, basisSize) &&
-                                basisSize + 1 <= p->maxBasisSize && s->spec2_enabled;
+                                basisSize + 1 <= p->maxBasisSize && s->spec2_enabled &&
+                                (p->maxMatvecs <= 0 || p->stats.numMatvecs + 1 < p->maxMatvecs);
          /* Default (PRIMME_AMD_NO_WTR=1 switches it off).  With A symmetric and W = A V, the new
           * column of H = V'AV is W't for the new basis vector t = (r - [V Q] c) / |.|, i.e.
           * (W'r - H c_V - (W'Q) c_Q) / |.|: W'r comes out of the residual pass (W is in registers

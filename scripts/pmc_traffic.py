@@ -1,0 +1,46 @@
+"""HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected SEPARATELY, each with
+--kernel-trace only), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: the counters report KiB and
+FETCH_SIZE counts half of the bytes of a wide coalesced streaming read (x2).  Writes the per-kernel table and the
+launch-weighted figure of the dominant (ritz) class that bench.py reports as roofline.traffic.
+usage: python scripts/pmc_traffic.py <fetch.db> <write.db> <out.md> <out.json> [bench_line.json] [tag]"""
+import json, re, sqlite3, sys
+
+def load(path, ctr):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, count(*), avg(counter_value), avg(duration) from pmc_events where counter_name = ? group by name", (ctr,)).fetchall()
+    return {re.sub(r"\(.*", "", n): (c, v, d) for n, c, v, d in rows}
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+tag = sys.argv[6] if len(sys.argv) > 6 else "r02"
+alg = None
+if len(sys.argv) > 5:
+    try:
+        alg = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])["roofline"]["alg_bytes_per_launch"]
+    except Exception:
+        alg = None
+lines = [f"# {tag} — HBM traffic from PMC counters (BASELINE configs[1], one solve, separate --pmc passes)", "",
+         "Collected by `scripts/profile_round.sh` with `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `rocprofv3 --pmc WRITE_SIZE --kernel-trace`",
+         "on `python scripts/one_solve.py csr` (gpurun, 1xMI355X).  The counters report KiB.  Correction as `MI355X_MICROARCH.md` §HBM prescribes for gfx950:",
+         "FETCH_SIZE counts half of the bytes of a wide coalesced streaming read, so fetched bytes = FETCH_SIZE x 1024 x 2; WRITE_SIZE x 1024 is used as reported.", "",
+         "| kernel | launches | avg us | FETCH_SIZE KiB (avg) | fetched MB (x2) | WRITE_SIZE KiB (avg) | written MB | HBM MB / launch |", "|---|---|---|---|---|---|---|---|"]
+tot_b = tot_n = 0.0
+for k, (n, f, d) in sorted(fetch.items(), key=lambda kv: -kv[1][0] * kv[1][2]):
+    w = write.get(k, (0, 0.0, 0.0))[1]
+    fmb, wmb = f * 1024 * 2 / 1e6, w * 1024 / 1e6
+    lines.append(f"| `{k}` | {n} | {d/1e3:.1f} | {f:.4g} | {fmb:.1f} | {w:.4g} | {wmb:.1f} | {fmb + wmb:.1f} |")
+    if re.search(r"ritz_(cgs_|ov_|big_)?kernel", k):
+        tot_b += n * (fmb + wmb) * 1e6
+        tot_n += n
+per = tot_b / tot_n if tot_n else None
+lines.append("")
+if per:
+    s = f"ritz class (ritz_cgs_kernel + ritz_kernel + ritz_ov_kernel), launch-weighted: **{per/1e6:.1f} MB per launch** over {int(tot_n)} launches"
+    if alg:
+        s += f"; algorithmic bytes per launch of the same class reported by bench.py: {alg/1e6:.1f} MB -> traffic / algorithmic = {per/alg:.3f}"
+    lines.append(s + ".")
+    lines.append("(The memory-side counters include what the 256 MiB Infinity Cache still holds from the previous kernel; a ratio near 1 means no re-reads.)")
+open(sys.argv[3], "w").write("\n".join(lines) + "\n")
+json.dump({"workload": "lap3d_2m", "ritz_class_hbm_bytes_per_launch": per, "launches": int(tot_n),
+           "source": f"profiles/{tag}_pmc_traffic.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md, bytes per launch)"},
+          open(sys.argv[4], "w"), indent=1)
+print("\n".join(lines[-3:]))

@@ -10,6 +10,7 @@ python -m pytest tests -m gpu -q -p no:cacheprovider > $O/${TAG}_gpu_tests.log 2
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; tail -c 400 $O/${TAG}_bench.json; echo
 rocprofv3 --kernel-trace -d $O/${TAG}_prof_bench -o bench -- python bench.py --no-cpu-baseline --no-north-star > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_prof_bench.log
 python scripts/rocpd_summary.py $O/${TAG}_prof_bench/bench_results.db $O/${TAG}_bench_kernel_stats.md > /dev/null; head -14 $O/${TAG}_bench_kernel_stats.md; tail -1 $O/${TAG}_bench_kernel_stats.md
+python scripts/gap_analysis.py $O/${TAG}_prof_bench/bench_results.db $O/${TAG}_bench_gap_analysis.md > /dev/null; tail -1 $O/${TAG}_bench_gap_analysis.md
 rocprofv3 --kernel-trace -d $O/${TAG}_prof_c3 -o c3 -- python scripts/config3_run.py --prof > $O/${TAG}_config3_run.log 2> $O/${TAG}_prof_c3.log
 python scripts/rocpd_summary.py $O/${TAG}_prof_c3/c3_results.db $O/${TAG}_config3_kernel_stats.md > /dev/null; tail -2 $O/${TAG}_config3_run.log | cut -c1-600; head -16 $O/${TAG}_config3_kernel_stats.md; tail -1 $O/${TAG}_config3_kernel_stats.md
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $O/${TAG}_pmc_mfma -o p -- python scripts/config3_run.py --tiles 8000 > $O/${TAG}_pmc_mfma_run.log 2> $O/${TAG}_pmc_mfma.log
@@ -17,5 +18,6 @@ python scripts/pmc_summary.py $O/${TAG}_pmc_mfma/p_results.db $O/${TAG}_pmc_mfma
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pmc_fetch -o p -- python scripts/one_solve.py csr > /dev/null 2> $O/${TAG}_pmc_fetch.log
 python scripts/pmc_summary.py $O/${TAG}_pmc_fetch/p_results.db $O/${TAG}_pmc_fetch.md > /dev/null
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_pmc_write -o p -- python scripts/one_solve.py csr > /dev/null 2> $O/${TAG}_pmc_write.log
-python scripts/pmc_summary.py $O/${TAG}_pmc_write/p_results.db $O/${TAG}_pmc_write.md > /dev/null; head -8 $O/${TAG}_pmc_fetch.md; head -8 $O/${TAG}_pmc_write.md
+python scripts/pmc_summary.py $O/${TAG}_pmc_write/p_results.db $O/${TAG}_pmc_write.md > /dev/null
+python scripts/pmc_traffic.py $O/${TAG}_pmc_fetch/p_results.db $O/${TAG}_pmc_write/p_results.db $O/${TAG}_pmc_traffic.md $O/${TAG}_pmc_traffic.json $O/${TAG}_bench.json ${TAG}
 rm -rf $O/${TAG}_prof_bench $O/${TAG}_prof_c3 $O/${TAG}_pmc_mfma $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write
