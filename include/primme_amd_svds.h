@@ -102,6 +102,10 @@ void primme_svds_free(primme_svds_params *primme_svds);
  * device pointers and runs on the stream in *primme_svds->queue (set by the solver when NULL). */
 int hip_dprimme_svds(double *svals, double *svecs, double *resNorms, primme_svds_params *primme_svds);
 int hip_sprimme_svds(float *svals, float *svecs, float *resNorms, primme_svds_params *primme_svds);
+/* complex matrices (reference primme_svds.h:242-243, :268-271: cublas_zprimme_svds / cublas_cprimme_svds): svecs holds
+ * complex vectors (re, im interleaved); through the real-equivalent form, csrc/svds_complex.c */
+int hip_zprimme_svds(double *svals, void *svecs, double *resNorms, primme_svds_params *primme_svds);
+int hip_cprimme_svds(float *svals, void *svecs, float *resNorms, primme_svds_params *primme_svds);
 
 /* ---- ready-made matvec for a device-resident CSR matrix and its transpose ----------------
  * primme_svds->matrix = handle from primme_amd_svds_operator_create (A and A' are both kept in
@@ -122,6 +126,10 @@ int primme_amd_svds_operator_create_dist(primme_amd_svds_operator **op, struct h
       int64_t mLocal, int64_t n, int64_t nLocal, const int32_t *rowptr_host, const int32_t *colind_host,
       const void *values_host, void *comm);
 int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op);
+/* on = 1: the matrix is the real-equivalent form (2m x 2n, primme_amd_csr_complex_to_real) of a complex one and
+ * primme_amd_svds_matvec is called by hip_zprimme_svds / hip_cprimme_svds with leading dimensions counted in
+ * complex elements (single rank) */
+int primme_amd_svds_operator_set_complex(primme_amd_svds_operator *op, int on);
 /* globalSumReal with the primme_svds signature over the same communicator
  * (primme_svds->commInfo = primme_amd_comm*).  When hip_dprimme_svds sees this function installed
  * it gives the eigensolver the in-stream RCCL reduction of primme_amd_global_sum. */

@@ -72,7 +72,8 @@ class HostcheckBackend:
                                   "complex64": "hip_cprimme"}[dtype_name])
 
     def svds_solver(self, dtype_name):
-        return getattr(self.lib, {"float64": "hip_dprimme_svds", "float32": "hip_sprimme_svds"}[dtype_name])
+        return getattr(self.lib, {"float64": "hip_dprimme_svds", "float32": "hip_sprimme_svds", "complex128": "hip_zprimme_svds",
+                                  "complex64": "hip_cprimme_svds"}[dtype_name])
 
 
 class ReferenceBackend:
@@ -132,16 +133,24 @@ class ReferenceBackend:
         return evecs, evecs.ctypes.data_as(C.c_void_p)
 
     def setup_svds_operator(self, ps, keep, m, n, rp, ci, va, ctype, precond, dtype):
+        cplx = np.dtype(dtype).kind == "c"
         rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
+        if cplx:
+            vaT = np.conj(vaT)                    # the callback's transpose flag means A^H
+        wide = np.complex128 if cplx else np.float64
 
         def mv(x, ldx, y, ldy, bs, tr, pp, ierr):
             nb, lx, ly = bs[0], ldx[0], ldy[0]
-            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
-            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
-            if tr[0]:
-                Y[:, :n] = csr_matvec_numpy(rpT, ciT, vaT, X[:, :m].T.astype(np.float64)).T
+            if cplx:
+                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, 2 * lx)).view(dtype)
+                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, 2 * ly)).view(dtype)
             else:
-                Y[:, :m] = csr_matvec_numpy(rp, ci, va, X[:, :n].T.astype(np.float64)).T
+                X = np.ctypeslib.as_array(C.cast(x, C.POINTER(ctype)), shape=(nb, lx))
+                Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(ctype)), shape=(nb, ly))
+            if tr[0]:
+                Y[:, :n] = csr_matvec_numpy(rpT, ciT, vaT, X[:, :m].T.astype(wide)).T
+            else:
+                Y[:, :m] = csr_matvec_numpy(rp, ci, va, X[:, :n].T.astype(wide)).T
             ierr[0] = 0
         cb = F.SVDS_BLOCK_OP(mv)
         keep.append(cb)
@@ -180,7 +189,10 @@ class ReferenceBackend:
             pcb = F.SVDS_BLOCK_OP(pc)
             keep.append(pcb)
             ps.applyPreconditioner = C.cast(pcb, C.c_void_p)
-        return self.lib.dprimme_svds if dtype == np.float64 else self.lib.sprimme_svds
+        if cplx and precond is not None:
+            raise ValueError("the test preconditioner is for real matrices")
+        return getattr(self.lib, {"float64": "dprimme_svds", "float32": "sprimme_svds", "complex128": "zprimme_svds",
+                                  "complex64": "cprimme_svds"}[np.dtype(dtype).name])
 
 
 def backend_object(backend):

@@ -55,7 +55,7 @@ void primme_amd_global_sum(void *s, void *r, int *c, struct primme_params *p, in
 int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) { (void)ci; (void)d; (void)n; (void)st; return -43; }
 
 /* singular value operator on host memory */
-struct primme_amd_svds_operator { hipk_csr *A, *At; void *jac_r, *jac_c; };
+struct primme_amd_svds_operator { hipk_csr *A, *At; void *jac_r, *jac_c; int cplx; };
 int primme_amd_svds_operator_create(primme_amd_svds_operator **out, struct hipk_ctx *ctx, int dt, int64_t m, int64_t n,
       const int32_t *rp, const int32_t *ci, const void *val) {
    primme_amd_svds_operator *op = calloc(1, sizeof(*op));
@@ -74,8 +74,10 @@ int primme_amd_svds_operator_destroy(primme_amd_svds_operator *op) {
 void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, int *transpose,
       struct primme_svds_params *ps, int *ierr) {
    primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->matrix;
-   *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, NULL, x, *ldx, y, *ldy, *bs);
+   const int64_t f = op->cplx ? 2 : 1;
+   *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, NULL, x, f * *ldx, y, f * *ldy, *bs);
 }
+int primme_amd_svds_operator_set_complex(primme_amd_svds_operator *op, int on) { if (!op) return -1; op->cplx = on ? 1 : 0; return 0; }
 
 int primme_amd_svds_operator_set_jacobi(primme_amd_svds_operator *op, const int32_t *rp, const int32_t *ci,
       const void *val, double shift) {

@@ -71,7 +71,8 @@ class HipBackend:
                                   "complex64": "hip_cprimme"}[dtype_name])
 
     def svds_solver(self, dtype_name):
-        return getattr(self.lib, {"float64": "hip_dprimme_svds", "float32": "hip_sprimme_svds"}[dtype_name])
+        return getattr(self.lib, {"float64": "hip_dprimme_svds", "float32": "hip_sprimme_svds", "complex128": "hip_zprimme_svds",
+                                  "complex64": "hip_cprimme_svds"}[dtype_name])
 
 
 def _resolve_backend(backend):

@@ -207,6 +207,7 @@ struct primme_amd_svds_operator {
    size_t full_cap;
    hipk_dtype dt;
    void *jac_r, *jac_c;          /* Jacobi for the normal equations: row / column sums of squares - shift^2 */
+   int cplx;                     /* real-equivalent form of a complex matrix: leading dimensions arrive in complex elements */
 };
 
 extern "C" int primme_amd_svds_operator_create(primme_amd_svds_operator **out, hipk_ctx *ctx, int dt,
@@ -302,6 +303,12 @@ extern "C" void primme_amd_svds_jacobi_precond(void *x, PRIMME_INT *ldx, void *y
    *ierr = rc ? 1 : 0;
 }
 
+extern "C" int primme_amd_svds_operator_set_complex(primme_amd_svds_operator *op, int on) {
+   if (!op) return -1;
+   op->cplx = on ? 1 : 0;
+   return 0;
+}
+
 extern "C" void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       int *transpose, struct primme_svds_params *ps, int *ierr) {
    primme_amd_svds_operator *op = (primme_amd_svds_operator *)ps->matrix;
@@ -309,9 +316,11 @@ extern "C" void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME
    *ierr = 1;
    if (!op) return;
    if (!op->comm) {
-      *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, stream, x, *ldx, y, *ldy, *blockSize);
+      const int64_t f = op->cplx ? 2 : 1;
+      *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, stream, x, f * *ldx, y, f * *ldy, *blockSize);
       return;
    }
+   if (op->cplx) return;
    /* row-partitioned A: the block goes through the [n x blockSize] staging panel with ONE grouped
     * collective (a column per call inside an RCCL group) and ONE SpMM per application */
    const size_t es = (op->dt == HIPK_F64) ? 8 : 4;

@@ -82,6 +82,52 @@ static void cx_monitor(void *basisEvals, int *basisSize, int *basisFlags, int *i
          lockedEvals, numLocked, lockedFlags, lockedNorms, inner_its, LSRes, msg, time, event, sd->user, ierr);
 }
 
+/* Complex Gram-Schmidt sweep: out of `ncand` real 2n-vectors (columns of `cand`, leading dimension ldr, in
+ * order) take up to `nwant` that are independent as COMPLEX vectors -- u and i u span the same complex line, and the
+ * real solver returns both.  An accepted vector is orthonormalised (complex sense) against the ones taken before,
+ * stored in Z(:,a) and its i-multiple in rot(:,a); picked[a] = its candidate index.  z^H u = dot(z,u) + i dot(iz,u),
+ * u - c z = u - Re(c) z - Im(c) (iz): real TN / NN panel kernels.  d_s / h_s: 4 nwant + 8 doubles (device / pinned). */
+int pa_complex_sweep(hipk_ctx *ctx, hipk_dtype dtr, int64_t mr, int64_t ldr, char *cand, int ncand, char *Z, char *rot,
+      int nwant, double *d_s, double *h_s, pa_sum_fn sum, void *who, int *picked, int *nacc) {
+   const size_t colB = (size_t)(ldr > 0 ? ldr : 1) * ((dtr == HIPK_F64) ? 8 : 4);
+   int acc = 0;
+   unsigned char *used = (unsigned char *)calloc((size_t)ncand + 1, 1);
+   if (!used) return PRIMME_MALLOC_FAILURE;
+   const double thresholds[2] = {0.25, 1e-6};
+   for (int pass = 0; pass < 2 && acc < nwant; pass++) {
+      for (int j = 0; j < ncand && acc < nwant; j++) {
+         if (used[j]) continue;
+         char *u = cand + colB * (size_t)j;
+         double nrm2 = 1.0;
+         if (acc > 0) {
+            hipk_seg segs[2] = {{Z, ldr, acc}, {rot, ldr, acc}};
+            int cnt = 2 * acc;
+            if (hipk_panel_dots(ctx, dtr, mr, segs, 2, u, ldr, 1, d_s, cnt) ||
+                hipk_d2h(ctx, h_s, d_s, sizeof(double) * (size_t)cnt) || hipk_sync(ctx)) { free(used); return PRIMME_UNEXPECTED_FAILURE; }
+            if (sum && sum(who, h_s, cnt)) { free(used); return PRIMME_USER_FAILURE; }
+            if (hipk_h2d(ctx, d_s, h_s, sizeof(double) * (size_t)(2 * acc)) ||
+                hipk_panel_project(ctx, dtr, mr, segs, 2, d_s, 2 * acc, u, ldr, 1, d_s + 2 * acc) ||
+                hipk_d2h(ctx, h_s, d_s + 2 * acc, sizeof(double)) || hipk_sync(ctx)) { free(used); return PRIMME_UNEXPECTED_FAILURE; }
+            if (sum && sum(who, h_s, 1)) { free(used); return PRIMME_USER_FAILURE; }
+            nrm2 = h_s[0];
+         }
+         if (!(nrm2 > thresholds[pass])) continue;     /* i times (a combination of) vectors already taken */
+         used[j] = 1;
+         if (acc > 0) {
+            const double a = 1.0 / sqrt(nrm2);
+            if (hipk_scale_cols(ctx, dtr, mr, u, ldr, 1, &a)) { free(used); return PRIMME_UNEXPECTED_FAILURE; }
+         }
+         if (hipk_copy_cols(ctx, dtr, mr, u, ldr, Z + colB * (size_t)acc, ldr, 1) ||
+             hipk_pair_rotate(ctx, dtr, mr / 2, u, ldr, rot + colB * (size_t)acc, ldr, 1)) { free(used); return PRIMME_UNEXPECTED_FAILURE; }
+         picked[acc++] = j;
+      }
+   }
+   free(used);
+   *nacc = acc;
+   return 0;
+}
+static int sum_eigs(void *who, double *buf, int count) { return pa_call_global_sum((primme_params *)who, buf, count); }
+
 #define CX(call) do { int rc__ = (call); if (rc__) { ret = rc__ < 0 ? rc__ : PRIMME_UNEXPECTED_FAILURE; goto done; } } while (0)
 
 static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primme_params *primme, hipk_dtype dtr) {
@@ -182,45 +228,16 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
       const int nconv = q->initSize;
       char *Z = (char *)evecs + colB * (size_t)nOC;      /* accepted vectors, in place in the caller's array */
       int acc = 0;
-      unsigned char *used = (unsigned char *)calloc((size_t)nconv + 1, 1);
-      if (!used) { ret = PRIMME_MALLOC_FAILURE; goto done; }
-      const double thresholds[2] = {0.25, 1e-6};
-      for (int pass = 0; pass < 2 && acc < nev; pass++) {
-         for (int j = 0; j < nconv && acc < nev; j++) {
-            if (used[j]) continue;
-            char *u = work + colB * (size_t)(2 * nOC + j);
-            double nrm2 = 1.0;
-            if (acc > 0) {
-               hipk_seg segs[2] = {{Z, ldr, acc}, {rot, ldr, acc}};
-               int cnt = 2 * acc;
-               if (hipk_panel_dots(ctx, dtr, mr, segs, 2, u, ldr, 1, d_s, cnt) ||
-                   hipk_d2h(ctx, h_s, d_s, sizeof(double) * (size_t)cnt) || hipk_sync(ctx)) { free(used); ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
-               if (primme->numProcs > 1 && primme->globalSumReal) {
-                  if (pa_call_global_sum(primme, h_s, cnt)) { free(used); ret = PRIMME_USER_FAILURE; goto done; }
-               }
-               cnt = 1;
-               if (hipk_h2d(ctx, d_s, h_s, sizeof(double) * (size_t)(2 * acc)) ||
-                   hipk_panel_project(ctx, dtr, mr, segs, 2, d_s, 2 * acc, u, ldr, 1, d_s + 2 * acc) ||
-                   hipk_d2h(ctx, h_s, d_s + 2 * acc, sizeof(double)) || hipk_sync(ctx)) { free(used); ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
-               if (primme->numProcs > 1 && primme->globalSumReal) {
-                  if (pa_call_global_sum(primme, h_s, cnt)) { free(used); ret = PRIMME_USER_FAILURE; goto done; }
-               }
-               nrm2 = h_s[0];
-            }
-            if (!(nrm2 > thresholds[pass])) continue;     /* i times (a combination of) vectors already taken */
-            used[j] = 1;
-            if (acc > 0) {
-               const double a = 1.0 / sqrt(nrm2);
-               if (hipk_scale_cols(ctx, dtr, mr, u, ldr, 1, &a)) { free(used); ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
-            }
-            if (hipk_copy_cols(ctx, dtr, mr, u, ldr, Z + colB * (size_t)acc, ldr, 1) ||
-                hipk_pair_rotate(ctx, dtr, mr / 2, u, ldr, rot + colB * (size_t)acc, ldr, 1)) { free(used); ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
-            if (dtr == HIPK_F64) { ((double *)evals_out)[acc] = evr[j]; ((double *)resNorms_out)[acc] = rnr[j]; }
-            else { ((float *)evals_out)[acc] = (float)evr[j]; ((float *)resNorms_out)[acc] = (float)rnr[j]; }
-            acc++;
-         }
+      int *picked = (int *)calloc((size_t)nev + 1, sizeof(int));
+      if (!picked) { ret = PRIMME_MALLOC_FAILURE; goto done; }
+      const int rcs = pa_complex_sweep(ctx, dtr, mr, ldr, work + colB * (size_t)(2 * nOC), nconv, Z, rot, nev, d_s, h_s,
+            (primme->numProcs > 1 && primme->globalSumReal) ? sum_eigs : NULL, primme, picked, &acc);
+      if (rcs) { free(picked); ret = rcs; goto done; }
+      for (int a = 0; a < acc; a++) {
+         if (dtr == HIPK_F64) { ((double *)evals_out)[a] = evr[picked[a]]; ((double *)resNorms_out)[a] = rnr[picked[a]]; }
+         else { ((float *)evals_out)[a] = (float)evr[picked[a]]; ((float *)resNorms_out)[a] = (float)rnr[picked[a]]; }
       }
-      free(used);
+      free(picked);
       if (hipk_sync(ctx)) { ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
       primme->initSize = acc;
       /* (fewer than numEvals with ret = 0: the real solver exhausted the space, as dprimme does

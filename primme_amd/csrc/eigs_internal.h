@@ -35,6 +35,11 @@ int pa_svds_call_global_sum(struct primme_svds_params *ps, double *buf, int coun
 int pa_svds_call_conv_test(struct primme_svds_params *ps, double sval, void *leftsvec, void *rightsvec, double rnorm,
       int *method, int *isconv);
 
+/* complex-independence sweep shared by hip_zprimme and hip_zprimme_svds (eigs_complex.c) */
+typedef int (*pa_sum_fn)(void *who, double *buf, int count);
+int pa_complex_sweep(hipk_ctx *ctx, hipk_dtype dtr, int64_t mr, int64_t ldr, char *cand, int ncand, char *Z, char *rot,
+      int nwant, double *d_s, double *h_s, pa_sum_fn sum, void *who, int *picked, int *nacc);
+
 /* parameter handling (eigs_params.c) */
 int pa_check_input(const void *evals, const void *evecs, const void *resNorms,
       const primme_params *primme, double machine_eps);

@@ -24,6 +24,26 @@ class SvdsResult:
                            eig_n=ps.primme.n, eig_target=ps.primme.target)
 
 
+def complex_csr_to_real(m, rp, ci, va, rdtype):
+    """real-equivalent form of a complex CSR matrix for vectors stored (re0, im0, re1, im1, ...): every entry
+    a + ib at (i, j) becomes the block [[a, -b], [b, a]] at rows (2i, 2i+1), columns (2j, 2j+1)"""
+    cnt = np.diff(rp).astype(np.int64)
+    rp2 = np.zeros(2 * m + 1, dtype=np.int64)
+    rp2[1::2] = 2 * cnt
+    rp2[2::2] = 2 * cnt
+    rp2 = np.cumsum(rp2)
+    nnz = len(va)
+    ci2 = np.empty(4 * nnz, dtype=np.int32)
+    va2 = np.empty(4 * nnz, dtype=rdtype)
+    rows = np.repeat(np.arange(m, dtype=np.int64), cnt)
+    pos = np.arange(nnz, dtype=np.int64) - np.asarray(rp, dtype=np.int64)[rows]       # position inside the row
+    e = rp2[2 * rows] + 2 * pos
+    o = rp2[2 * rows + 1] + 2 * pos
+    ci2[e], ci2[e + 1], va2[e], va2[e + 1] = 2 * ci, 2 * ci + 1, va.real, -va.imag
+    ci2[o], ci2[o + 1], va2[o], va2[o + 1] = 2 * ci, 2 * ci + 1, va.imag, va.real
+    return rp2.astype(np.int32), ci2, va2
+
+
 def transpose_csr(m, n, rp, ci, va):
     order = np.argsort(ci, kind="stable")
     rows = np.repeat(np.arange(m, dtype=np.int64), np.diff(rp))
@@ -36,8 +56,10 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
          eps=1e-8, aNorm=0.0, backend="hip", dtype=np.float64, maxBlockSize=0, maxBasisSize=0, locking=None,
          maxMatvecs=0, v0=None, iseed=None, printLevel=0, return_vectors=True, targetShifts=None, precond=None):
     dtype = np.dtype(dtype)
-    dt = F.HIPK_F64 if dtype == np.float64 else F.HIPK_F32
-    ctype = C.c_double if dtype == np.float64 else C.c_float
+    cplx = dtype.kind == "c"                       # hip_zprimme_svds / hip_cprimme_svds (csrc/svds_complex.c)
+    rdtype = np.dtype(np.float64 if dtype in (np.float64, np.complex128) else np.float32)
+    dt = F.HIPK_F64 if rdtype == np.float64 else F.HIPK_F32
+    ctype = C.c_double if rdtype == np.float64 else C.c_float
     rp, ci, va = csr
     rp = np.ascontiguousarray(rp, dtype=np.int32)
     ci = np.ascontiguousarray(ci, dtype=np.int32)
@@ -73,11 +95,20 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
             raise RuntimeError("hipk_ctx_create failed: no HIP device (primme_amd has no CPU path)")
         handles.append(("ctx", ctx))
         oph = C.c_void_p()
-        rc = lib.primme_amd_svds_operator_create(C.byref(oph), ctx, dt, m, n, rp.ctypes.data_as(C.c_void_p),
-                                                 ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p))
+        if cplx:
+            rp2, ci2, va2 = complex_csr_to_real(m, rp, ci, va, rdtype)
+            rc = lib.primme_amd_svds_operator_create(C.byref(oph), ctx, dt, 2 * m, 2 * n, rp2.ctypes.data_as(C.c_void_p),
+                                                     ci2.ctypes.data_as(C.c_void_p), va2.ctypes.data_as(C.c_void_p))
+        else:
+            rc = lib.primme_amd_svds_operator_create(C.byref(oph), ctx, dt, m, n, rp.ctypes.data_as(C.c_void_p),
+                                                     ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p))
         if rc:
             raise RuntimeError(f"svds operator creation failed: {rc}")
         handles.append(("op", oph))
+        if cplx:
+            lib.primme_amd_svds_operator_set_complex(oph, 1)
+            if precond is not None:
+                raise ValueError("the library's Jacobi preconditioner is for real matrices")
         ps.matrix = oph
         ps.matrixMatvec = C.cast(lib.primme_amd_svds_matvec, C.c_void_p)
         if precond is not None:
@@ -93,13 +124,14 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
         else F.METHODS.get(methodStage1, 0) if isinstance(methodStage1, str) else methodStage1
     lib.primme_svds_set_method(F.SVDS_METHODS[method], mset, 0, C.byref(ps))
 
-    svals = np.zeros(numSvals, dtype=dtype)
-    rnorms = np.zeros(numSvals, dtype=dtype)
+    svals = np.zeros(numSvals, dtype=rdtype)
+    rnorms = np.zeros(numSvals, dtype=rdtype)
     total = (m + n) * ncols
     sv_t = None
     if be.native_operator and be.device:
         import torch
-        sv_t = torch.zeros(total, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
+        tdt = {"float64": torch.float64, "float32": torch.float32, "complex128": torch.complex128, "complex64": torch.complex64}[dtype.name]
+        sv_t = torch.zeros(total, dtype=tdt, device="cuda")
         if v0 is not None:
             # [U0 (m x initSize) | V0 (n x initSize)]: only V0 is used by A'A, U0 by AA'
             sv_t[m * ps.initSize: m * ps.initSize + n * ps.initSize] = torch.from_numpy(np.ascontiguousarray(v0.T).ravel()).cuda()

@@ -7,7 +7,7 @@ import pytest
 from primme_amd import problems
 from checkers import svds, transpose_csr
 import reference_driver_cases as RD
-from test_svds_host import _rect
+from test_svds_host import _rect, _rect_complex
 
 pytestmark = pytest.mark.gpu
 
@@ -96,3 +96,24 @@ def test_hip_svds_config5_shape(built):
         x /= np.linalg.norm(x)
     lower = np.linalg.norm(problems.csr_matvec_numpy(rp, ci, va, x))
     assert r.svals[0] >= lower * (1 - 1e-12)
+
+
+@pytest.mark.parametrize("m,n,k,target,method,dtype,eps", [(1200, 800, 4, "largest", "normalequations", np.complex128, 1e-10),
+                                                           (800, 1200, 3, "largest", "hybrid", np.complex128, 1e-10),
+                                                           (600, 400, 3, "smallest", "hybrid", np.complex128, 1e-9),
+                                                           (900, 700, 3, "largest", "normalequations", np.complex64, 1e-4)])
+def test_hip_complex_svds(built, m, n, k, target, method, dtype, eps):
+    """hip_zprimme_svds / hip_cprimme_svds: complex singular triplets on the device (real-equivalent form,
+    csrc/svds_complex.c) against numpy's dense SVD and the checker run of the same call"""
+    Z, csr = _rect_complex(m, n)
+    s = np.linalg.svd(Z, compute_uv=False)
+    want = s[:k] if target == "largest" else s[::-1][:k]
+    r = svds(m, n, csr, numSvals=k, target=target, eps=eps, method=method, backend="hip", dtype=dtype)
+    assert r.ret == 0 and r.initSize == k
+    tol = 10 * eps * s[0]
+    assert np.max(np.abs(np.sort(r.svals) - np.sort(want))) <= tol
+    assert np.linalg.norm(Z @ r.V - r.U * r.svals) <= 100 * tol and np.linalg.norm(Z.conj().T @ r.U - r.V * r.svals) <= 100 * tol
+    assert np.linalg.norm(r.V.conj().T @ r.V - np.eye(k)) <= 1e3 * eps and np.linalg.norm(r.U.conj().T @ r.U - np.eye(k)) <= 1e4 * eps
+    if dtype == np.complex128:
+        h = svds(m, n, csr, numSvals=k, target=target, eps=eps, method=method, backend="hostcheck", dtype=dtype)
+        assert h.ret == 0 and np.max(np.abs(np.sort(r.svals) - np.sort(h.svals))) <= tol

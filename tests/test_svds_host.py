@@ -150,3 +150,44 @@ def test_svds_interior_blocks_and_input_checks(built):
     want = s[np.argsort(np.abs(s - 7.0))][:2]
     assert np.max(np.abs(np.sort(r.svals) - np.sort(want))) <= 1e-8 * s[0]
     assert svds(60, 40, csr, numSvals=70, backend="hostcheck").ret == -10
+
+
+def _rect_complex(m, n, seed=0):
+    A, _ = _rect(m, n, seed)
+    rng = np.random.default_rng(seed + 100)
+    Z = A.astype(np.complex128)
+    r, c = np.nonzero(A)
+    Z[r, c] *= np.exp(1j * rng.uniform(0, 2 * np.pi, size=len(r)))          # same pattern, complex phases
+    rp = np.zeros(m + 1, dtype=np.int64)
+    np.add.at(rp, r + 1, 1)
+    return Z, (np.cumsum(rp).astype(np.int32), c.astype(np.int32), Z[r, c])
+
+
+def test_complex_svds_single_precision(built):
+    Z, csr = _rect_complex(150, 90)
+    s = np.linalg.svd(Z, compute_uv=False)
+    r = svds(150, 90, csr, numSvals=3, eps=1e-4, method="normalequations", backend="hostcheck", dtype=np.complex64)
+    assert r.ret == 0 and r.initSize == 3 and r.V.dtype == np.complex64
+    assert np.max(np.abs(np.sort(r.svals)[::-1] - s[:3])) <= 1e-3 * s[0]
+    assert np.linalg.norm(Z @ r.V - r.U * r.svals) <= 1e-2 * s[0]
+
+
+@pytest.mark.parametrize("m,n,k,target,method", [(120, 80, 4, "largest", "normalequations"), (80, 120, 3, "largest", "hybrid"),
+                                                 (120, 80, 3, "smallest", "hybrid")])
+def test_complex_svds_through_the_real_equivalent_form(built, m, n, k, target, method):
+    """hip_zprimme_svds (csrc/svds_complex.c): complex singular triplets; against numpy's dense SVD, and the values /
+    residual level against the reference's zprimme_svds on the same inputs (the operator-application counts are
+    not comparable: the real-equivalent problem has every singular value twice)."""
+    Z, csr = _rect_complex(m, n)
+    s = np.linalg.svd(Z, compute_uv=False)
+    want = s[:k] if target == "largest" else s[::-1][:k]
+    backends = ["hostcheck"] + (["reference"] if HAVE_REF else [])
+    for be in backends:
+        r = svds(m, n, csr, numSvals=k, target=target, eps=1e-10, method=method, backend=be, dtype=np.complex128)
+        assert r.ret == 0 and r.initSize == k, (be, r.ret, r.initSize)
+        assert np.max(np.abs(np.sort(r.svals) - np.sort(want))) <= 1e-9 * s[0], be
+        assert np.all(r.resNorms <= 1e-10 * r.params["aNorm"] * 3), be
+        assert r.U.dtype == np.complex128 and r.V.dtype == np.complex128
+        assert np.linalg.norm(Z @ r.V - r.U * r.svals) <= 1e-8 * s[0], be
+        assert np.linalg.norm(Z.conj().T @ r.U - r.V * r.svals) <= 1e-8 * s[0], be
+        assert np.linalg.norm(r.V.conj().T @ r.V - np.eye(k)) <= 1e-8 and np.linalg.norm(r.U.conj().T @ r.U - np.eye(k)) <= 1e-7, be
