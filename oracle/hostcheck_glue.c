@@ -77,6 +77,7 @@ void primme_amd_svds_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, 
    const int64_t f = op->cplx ? 2 : 1;
    *ierr = hipk_csr_matvec(*transpose ? op->At : op->A, NULL, x, f * *ldx, y, f * *ldy, *bs);
 }
+int primme_amd_svds_operator_is_local(const void *op) { return op != NULL; }
 int primme_amd_svds_operator_set_complex(primme_amd_svds_operator *op, int on) { if (!op) return -1; op->cplx = on ? 1 : 0; return 0; }
 
 int primme_amd_svds_operator_set_jacobi(primme_amd_svds_operator *op, const int32_t *rp, const int32_t *ci,

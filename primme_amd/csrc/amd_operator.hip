@@ -303,6 +303,8 @@ extern "C" void primme_amd_svds_jacobi_precond(void *x, PRIMME_INT *ldx, void *y
    *ierr = rc ? 1 : 0;
 }
 
+extern "C" int primme_amd_svds_operator_is_local(const void *op) { return op && ((const primme_amd_svds_operator *)op)->comm == NULL; }
+
 extern "C" int primme_amd_svds_operator_set_complex(primme_amd_svds_operator *op, int on) {
    if (!op) return -1;
    op->cplx = on ? 1 : 0;

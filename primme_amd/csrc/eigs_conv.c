@@ -176,11 +176,23 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
 }
 
 /* the library's own operator can run the one-launch tail (scale + A t + t'At) on this solver's panels */
+int pa_svds_can_fuse(const primme_params *primme);
+int pa_svds_apply_scaled(primme_params *primme, hipk_ctx *ctx, const void *t, const double *norm2_dev, void *xout, void *y,
+      double *dot_dev);
 int pa_fuse_tail_eligible(const pa_solver *s) {
    const primme_params *p = s->p;
-   return s->nT >= 1 && p->matrixMatvec == primme_amd_matvec && p->matrix && s->ld == s->m &&
-          primme_amd_operator_can_fuse((const primme_amd_operator *)p->matrix) &&
-          hipk_csr_dtype(primme_amd_operator_matrix((primme_amd_operator *)p->matrix)) == s->dt;
+   if (s->nT < 1 || s->ld != s->m) return 0;
+   if (p->matrixMatvec == primme_amd_matvec)
+      return p->matrix && primme_amd_operator_can_fuse((const primme_amd_operator *)p->matrix) &&
+             hipk_csr_dtype(primme_amd_operator_matrix((primme_amd_operator *)p->matrix)) == s->dt;
+   return pa_svds_can_fuse(p) && !s->parallel;      /* normal equations of the singular value front end, one rank */
+}
+/* xout = a t, y = A xout, dot = xout'y through the operator that made the tail eligible */
+static int fused_apply(pa_solver *s, const void *t, const double *norm2_dev, void *xout, void *y, double *dot_dev) {
+   primme_params *p = s->p;
+   if (p->matrixMatvec == primme_amd_matvec)
+      return primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, t, norm2_dev, xout, y, dot_dev);
+   return pa_svds_apply_scaled(p, s->ctx, t, norm2_dev, xout, y, dot_dev);
 }
 
 /* The pre-restart convergence check may run through the fused residual kernel and hand its overlaps to the
@@ -268,8 +280,7 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
     * two all-reduces per outer iteration instead of three (each is latency, not bandwidth). */
    const int merge_red = fuse_tail && s->parallel && s->dev_comm;
    if (speculate2 && merge_red) {
-      rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, 0), NULL, dstc,
-            WCOL(s, basisSize), s->d_fov + nfov + 1);
+      rc = fused_apply(s, TCOL(s, 0), NULL, dstc, WCOL(s, basisSize), s->d_fov + nfov + 1);
       if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
       s->spec_fused = 1;
       CHK(pa_reduce(s, s->d_fov + nfov, 2, 0, 0));             /* the one synchronisation */
@@ -295,8 +306,7 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
       if (fuse_tail) {
          /* the library's own operator: normalisation, A t and t'At in one launch, reading the
           * un-normalised vector from the scratch column and rebuilding V(:,k) on the way */
-         rc = primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, 0), s->d_fov + nfov, dstc,
-               WCOL(s, basisSize), s->d_red);
+         rc = fused_apply(s, TCOL(s, 0), s->d_fov + nfov, dstc, WCOL(s, basisSize), s->d_red);
          if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
          s->spec_fused = 1;
       } else {

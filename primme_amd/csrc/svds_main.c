@@ -96,6 +96,41 @@ void pa_svds_matvec_eigs(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int
    *ierr = 0;
 }
 
+/* The one-synchronisation tail of the eigensolver's block-size-1 iteration (eigs_conv.c) for the normal equations
+ * with the library's own operator on one rank: xout = a t (a = 1/sqrt(norm2_dev[0]), or t itself), u = A xout,
+ * dot_dev[0] = xout'(A'A xout) = u'u, y = A'u -- everything enqueued, nothing waited for. */
+int primme_amd_svds_operator_is_local(const void *op);
+int pa_svds_can_fuse(const primme_params *primme) {
+   if (primme->matrixMatvec != pa_svds_matvec_eigs || !primme->matrix) return 0;
+   primme_svds_params *ps = (primme_svds_params *)primme->matrix;
+   const primme_svds_operator op = (&ps->primme == primme) ? ps->method : ps->methodStage2;
+   if (op != primme_svds_op_AtA && op != primme_svds_op_AAt) return 0;
+   return ps->matrixMatvec == primme_amd_svds_matvec && ps->matrix && primme_amd_svds_operator_is_local(ps->matrix) &&
+          side_of(ps) != NULL;
+}
+int pa_svds_apply_scaled(primme_params *primme, hipk_ctx *ctx, const void *t, const double *norm2_dev, void *xout, void *y,
+      double *dot_dev) {
+   primme_svds_params *ps = (primme_svds_params *)primme->matrix;
+   svds_side *sd = side_of(ps);
+   const primme_svds_operator op = (&ps->primme == primme) ? ps->method : ps->methodStage2;
+   if (!sd) return PRIMME_UNEXPECTED_FAILURE;
+   const size_t es = es_of(sd->dt);
+   PRIMME_INT nin = (op == primme_svds_op_AtA) ? ps->nLocal : ps->mLocal, mid = (op == primme_svds_op_AtA) ? ps->mLocal : ps->nLocal;
+   int first = (op == primme_svds_op_AtA) ? 0 : 1, second = 1 - first, one = 1, e = 0;
+   if (sd->aux_cols < 1) {
+      if (hipk_malloc(sd->ctx, (size_t)mid * es, (void **)&sd->aux)) return PRIMME_MALLOC_FAILURE;
+      sd->aux_cols = 1;
+   }
+   CHK(hipk_copy_cols(ctx, sd->dt, nin, t, nin, xout, nin, 1));
+   if (norm2_dev) CHK(hipk_scale_cols_rsqrt_dev(ctx, sd->dt, nin, xout, nin, 1, norm2_dev));
+   ps->matrixMatvec(xout, &nin, sd->aux, &mid, &one, &first, ps, &e);
+   if (e) return PRIMME_USER_FAILURE;
+   ps->matrixMatvec(sd->aux, &mid, y, &nin, &one, &second, ps, &e);
+   if (e) return PRIMME_USER_FAILURE;
+   CHK(hipk_col_norms2(ctx, sd->dt, mid, sd->aux, mid, 1, dot_dev));     /* last: its second stage carries the completion flag */
+   return 0;
+}
+
 /* the eigensolver's preconditioner: the user's, told which operator it is for (reference :1405-1416) */
 static void pa_svds_precond_eigs(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       primme_params *primme, int *ierr) {
