@@ -216,25 +216,28 @@ int pa_restart_stash_eligible(const pa_solver *s, int basisSize, int nLk) {
  * two right-hand sides.  Returns 1 (done, *norm2 set), 0 (not applicable: the caller runs the fused residual
  * pass on the old basis) or a negative error. */
 int pa_restart_plan(pa_solver *s, int basisSize, const int *flags_in, const int *iev_in, int nblock, int numLocked,
-      int nprevhVecs, const int *map);
+      int nprevhVecs, const int *map, double *evals, double *resNorms);
 static int try_speculative_restart(pa_solver *s, int basisSize, int nLk, const int *flags, const int *iev, int nblock,
-      int numLocked, int nprevhVecs, const int *map, int col, double *norm2) {
+      int numLocked, int nprevhVecs, const int *map, int col, double *evals, double *resNorms, double *norm2) {
    const int K = s->K, ldh = basisSize;
    s->pl_launched = 0;
    if (!s->V2 || !s->plan_allowed || 64 + 2 * nLk > s->red_cap) return 0;
-   if (pa_restart_plan(s, basisSize, flags, iev, nblock, numLocked, nprevhVecs, map)) return 0;
+   if (pa_restart_plan(s, basisSize, flags, iev, nblock, numLocked, nprevhVecs, map, evals, resNorms)) return 0;
    const int rs = s->pl_rs;
-   if (s->pl_L != nLk || rs < 1 || 8 + 2 * rs + 1 > 64 || s->h_theta2[0] != s->hVals[col] ||
-         memcmp(s->h_coef2, s->hVecs + (size_t)col * ldh, (size_t)basisSize * sizeof(double)))
+   const int cc = s->pl_cand, ncv = s->pl_nc;
+   if (s->pl_L != nLk || rs < 1 || 8 + 2 * rs + 1 > 64 || ncv > 30 || s->h_theta2[cc] != s->hVals[col] ||
+         memcmp(s->h_coef2 + (size_t)cc * K, s->hVecs + (size_t)col * ldh, (size_t)basisSize * sizeof(double)))
       return 0;                                  /* the candidate is not what the restart would continue with */
    CHK(hipk_h2d(s->ctx, s->d_coef2, s->h_coef2, (size_t)K * (rs + 1) * sizeof(double)));
    CHK(hipk_h2d(s->ctx, s->d_theta2, s->h_theta2, (size_t)basisSize * sizeof(double)));
-   hipk_job jobs[2 * 16 + 2];
+   hipk_job jobs[2 * 16 + 32 + 2];
    int nj = 0;
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, s->V2, s->ld, c), -1};
+   for (int c = 0; c < ncv; c++)                                        /* soft locking: converged Ritz vectors out to evecs */
+      jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, ECOL(s, s->p->numOrthoConst + c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, PCOL(s, s->W2, s->ld, c), -1};
    jobs[nj++] = (hipk_job){HIPK_JOB_XW, rs, TCOL(s, 3), -1};            /* the unit column: W(:,k-1) next to r */
-   jobs[nj++] = (hipk_job){HIPK_JOB_RES, 0, TCOL(s, 2), -1};            /* its squared norm is part of the overlaps */
+   jobs[nj++] = (hipk_job){HIPK_JOB_RES, cc, TCOL(s, 2), -1};           /* its squared norm is part of the overlaps */
    CHK(hipk_ritz_update_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef2, K, s->d_theta2, jobs, nj,
          NULL, rs, NULL, 0, 0, s->d_red + 8));
    if (nLk > 0) {
@@ -512,7 +515,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          s->fov_valid = 0;
          s->rst_valid = 0;
          double n2spec = 0.0;
-         const int spec = try_speculative_restart(s, basisSize, nLk, flags, iev, *blockSize + 1, numLocked, nprevhVecs, map, col, &n2spec);
+         const int spec = try_speculative_restart(s, basisSize, nLk, flags, iev, *blockSize + 1, numLocked, nprevhVecs, map, col, evals, resNorms, &n2spec);
          if (spec < 0) { rc = spec; goto out; }
          if (spec == 1) {
             blockNorms[*blockSize] = sqrt(n2spec);

@@ -949,7 +949,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    }
    if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap * 2);
    if (!rc) { s->d_fov = s->d_red + s->red_cap; s->h_fov = s->h_red + s->red_cap; }
-   if (!rc && s->fused_restart && s->fuse_gd && b == 1 && p->locking && !harmonic && K <= 32 && s->nT >= 4 &&
+   if (!rc && s->fused_restart && s->fuse_gd && b == 1 && !harmonic && K <= 32 && s->nT >= 4 &&
          s->red_cap >= 64 + 2 * HIPK_WTR_MAX_K && getenv("PRIMME_AMD_NO_SPEC_RESTART") == NULL) {
       /* alternate panels of the speculative restart (eigs_solver.h); without them the restart runs in place */
       if (hipk_malloc(s->ctx, colBytes * K, (void **)&s->V2) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W2) ||

@@ -294,7 +294,6 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
       int *hVecsPerm) {
    primme_params *p = s->p;
    int i, j, k;
-   if (s->plan_only) return PA_PLAN_NONE;
 
    /* a previously converged pair whose Ritz value drifted more than its residual
     * norm is targeted again */
@@ -325,7 +324,43 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
    }
    pa_permute_cols(s->hVals, 1, basisSize, 1, restartPerm);
    pa_permute_cols(s->hVecs, basisSize, basisSize, ldh, restartPerm);
+   if (s->plan_only) {        /* dry run (see restart_locking): the candidate is column numConverged */
+      const int rs0 = *restartSize, K = s->K, nc0 = *numConverged;
+      if (*ievSize != 1 || rs0 > 16 || rs0 + 1 > K || !s->h_coef2 || nc0 >= rs0) return PA_PLAN_NONE;
+      for (int c = 0; c < rs0; c++) {
+         memcpy(s->h_coef2 + (size_t)c * K, s->hVecs + (size_t)c * ldh, (size_t)basisSize * sizeof(double));
+         for (int r2 = basisSize; r2 < K; r2++) s->h_coef2[r2 + (size_t)c * K] = 0.0;
+      }
+      for (int r2 = 0; r2 < K; r2++) s->h_coef2[r2 + (size_t)rs0 * K] = (r2 == basisSize - 1) ? 1.0 : 0.0;
+      memcpy(s->h_theta2, s->hVals, (size_t)basisSize * sizeof(double));
+      s->pl_rs = rs0; s->pl_k = basisSize; s->pl_L = p->numOrthoConst; s->pl_cand = nc0; s->pl_nc = nc0;
+      return PA_PLANNED;
+   }
+   int use_plan = 0;
+   if (s->pl_launched && *ievSize == 1 && s->fuse_gd && s->V2 && *restartSize == s->pl_rs && basisSize == s->pl_k &&
+         p->numOrthoConst == s->pl_L && *numConverged == s->pl_nc && s->pl_cand == *numConverged &&
+         s->hVals[*numConverged] == s->h_theta2[*numConverged]) {
+      use_plan = 1;
+      for (int c = 0; c < *restartSize && use_plan; c++)
+         if (memcmp(s->hVecs + (size_t)c * ldh, s->h_coef2 + (size_t)c * s->K, (size_t)basisSize * sizeof(double))) use_plan = 0;
+   }
+   s->pl_launched = 0;
    s->coef_valid_k = -1;
+   if (use_plan) {
+      /* the speculative pass already wrote V h, W h (and the converged Ritz vectors) with exactly this block */
+      const int rs = *restartSize;
+      char *t = s->V; s->V = s->V2; s->V2 = t;
+      t = s->W; s->W = s->W2; s->W2 = t;
+      blockNorms[0] = sqrt(s->rst_c[rs + p->numOrthoConst]);
+      CHK(transform_wtq(s, s->h_coef2, basisSize, rs, p->numOrthoConst, s->rst_grow));
+      s->rst_ready = 1; s->rst_rs = rs;
+      CHK(refresh_gram_after_restart(s, p->numOrthoConst, basisSize, rs, ldh));
+      for (i = 0; i < basisSize; i++) hVecsPerm[restartPerm[i]] = i;
+      for (i = 0; i < *ievSize; i++)
+         for (j = 0; j < *restartSize; j++)
+            if (hVecsPerm[j] == *numConverged + i) iev[i] = j;
+      return 0;
+   }
    CHK(pa_push_coefficients(s, basisSize, ldh));
 
    /* one pass: V, W <- V h, W h (in place); X, R for the next block; converged
@@ -400,13 +435,13 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
       }
       for (int r2 = 0; r2 < K; r2++) s->h_coef2[r2 + (size_t)rs0 * K] = (r2 == basisSize - 1) ? 1.0 : 0.0;
       memcpy(s->h_theta2, s->hVals, (size_t)basisSize * sizeof(double));
-      s->pl_rs = rs0; s->pl_k = basisSize; s->pl_L = nOC + *numLocked;
+      s->pl_rs = rs0; s->pl_k = basisSize; s->pl_L = nOC + *numLocked; s->pl_cand = 0; s->pl_nc = 0;
       return PA_PLANNED;
    }
    /* the speculative pass already ran with exactly this block (eigs_conv.c): adopt its panels */
    int use_plan = 0;
    if (s->pl_launched && sizeBlockNorms == 1 && numPacked == 0 && s->fuse_gd && s->V2 && *restartSize == s->pl_rs &&
-         basisSize == s->pl_k && nOC + *numLocked == s->pl_L && s->hVals[0] == s->h_theta2[0]) {
+         basisSize == s->pl_k && nOC + *numLocked == s->pl_L && s->pl_cand == 0 && s->pl_nc == 0 && s->hVals[0] == s->h_theta2[0]) {
       use_plan = 1;
       for (int c = 0; c < *restartSize && use_plan; c++)
          if (memcmp(s->hVecs + (size_t)c * ldh, s->h_coef2 + (size_t)c * s->K, (size_t)basisSize * sizeof(double))) use_plan = 0;
@@ -769,10 +804,10 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
  * h_theta2 hold the coefficient block and Ritz values the pass would be called with, pl_rs its width.  The real
  * functions run on the live coefficient data, which is saved and put back. */
 int pa_restart_plan(pa_solver *s, int basisSize, const int *flags_in, const int *iev_in, int nblock, int numLocked,
-      int nprevhVecs, const int *map) {
+      int nprevhVecs, const int *map, double *evals, double *resNorms) {
    primme_params *p = s->p;
    const int K = s->K;
-   if (!s->V2 || !s->plan_allowed || !p->locking || basisSize > K || nblock < 1) return 1;
+   if (!s->V2 || !s->plan_allowed || basisSize > K || nblock < 1) return 1;
    const size_t kk = (size_t)K * K;
    double *sv = (double *)malloc((2 * kk + K) * sizeof(double));
    int *fl = (int *)malloc((size_t)(2 * K + 2) * sizeof(int));
@@ -798,7 +833,7 @@ int pa_restart_plan(pa_solver *s, int basisSize, const int *flags_in, const int 
       pa_permute_cols(s->prevhVecs, basisSize, nprevhVecs, K, map);
       int nc = numConverged, nl = numLocked, ievSize = nblock, rsOut = 0, rsr = 1;
       s->plan_only = 1;
-      rc = pa_restart(s, basisSize, fl, iv, &ievSize, NULL, NULL, NULL, NULL, &nc, &nl, NULL, nprevhVecs, 0, &rsOut, &rsr);
+      rc = pa_restart(s, basisSize, fl, iv, &ievSize, NULL, NULL, evals, resNorms, &nc, &nl, NULL, nprevhVecs, 0, &rsOut, &rsr);
       s->plan_only = 0;
    }
    memcpy(s->hVecs, sv, kk * sizeof(double));

@@ -109,6 +109,7 @@ typedef struct pa_solver {
    int plan_allowed;       /* set by the main loop around the full-basis check (no guesses pending ...) */
    int plan_only;          /* pa_restart runs as a dry run: stops where the pass would start */
    int pl_k, pl_rs, pl_L;  /* the prediction */
+   int pl_cand, pl_nc;     /* coefficient column of the candidate; converged pairs copied out by the pass (soft locking) */
    int pl_launched;        /* the pass ran with it: rst_c holds the overlaps with the new basis, rst_grow W(:,k-1)'Q */
    double *rst_grow;
    int parallel;           /* reductions cross ranks (numProcs > 1 and a globalSumReal installed) */
