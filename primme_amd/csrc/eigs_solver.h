@@ -100,7 +100,7 @@ typedef struct pa_solver {
    int rst_ready, rst_rs;  /* the restart used the stash: rst_c = [V_new'r (rs) | Q'r (L) | r'r | W_new'r (rs)] */
    double *rst_c;
    int fov_carry;          /* the overlaps in d_fov / h_fov come from a restart: survive the next candidate check */
-   /* Speculative restart (second half): with locking, the check at the full basis IS the
+   /* Speculative restart (second half): the check at the full basis IS the
     * restart pass, run out of place into the alternate panels V2 / W2 with the coefficient block a dry run of the
     * restart (plan_only) predicts for "candidate not converged"; the real restart adopts the result (swaps the
     * panels) if it arrives at the same coefficients bit for bit, and otherwise runs its own pass on V, W */
