@@ -49,10 +49,37 @@ void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ld
          op->jacobi_fixed ? fixed : p->ShiftsForPreconditioner, 1e-14 * (p->aNorm >= 0.0 ? p->aNorm : 1.0),
          x, *ldx * op->ldscale, y, *ldy * op->ldscale, *bs);
 }
-void primme_amd_global_sum(void *s, void *r, int *c, struct primme_params *p, int *ierr) {
-   (void)s; (void)r; (void)c; (void)p; *ierr = 1; /* RCCL only exists in the product library */
+/* Stand-in for the RCCL communicator (comm_rccl.hip): the all-reduce is a callback of the test (gloo), applied in
+ * place to the "device" buffer, which is host memory here.  With it installed the solver runs the SAME code path as
+ * on several GPUs -- reductions inside the stream of launches, |t|^2 and t'At in one all-reduce, the fused /
+ * speculative restart with reduced overlaps -- in the world_size-2 CPU tests (tests/test_multirank_gloo.py). */
+typedef void (*hostcheck_allreduce_fn)(double *buf, int count);
+struct primme_amd_comm { hostcheck_allreduce_fn cb; int rank, size; long calls; };
+int primme_amd_hostcheck_comm_create(primme_amd_comm **out, hostcheck_allreduce_fn cb, int rank, int size) {
+   primme_amd_comm *c = calloc(1, sizeof(*c));
+   if (!c) return -2;
+   c->cb = cb; c->rank = rank; c->size = size;
+   *out = c;
+   return 0;
 }
-int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) { (void)ci; (void)d; (void)n; (void)st; return -43; }
+int primme_amd_comm_destroy(primme_amd_comm *c) { free(c); return 0; }
+int primme_amd_comm_rank(const primme_amd_comm *c) { return c ? c->rank : 0; }
+int primme_amd_comm_size(const primme_amd_comm *c) { return c ? c->size : 1; }
+long primme_amd_hostcheck_comm_calls(const primme_amd_comm *c) { return c ? c->calls : 0; }
+void primme_amd_global_sum(void *s, void *r, int *c, struct primme_params *p, int *ierr) {
+   primme_amd_comm *cm = (primme_amd_comm *)p->commInfo;
+   if (!cm || !cm->cb) { *ierr = 1; return; }
+   if (s != r) for (int i = 0; i < *c; i++) ((double *)r)[i] = ((const double *)s)[i];
+   cm->cb((double *)r, *c); cm->calls++;
+   *ierr = 0;
+}
+int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) {
+   primme_amd_comm *cm = (primme_amd_comm *)ci;
+   (void)st;
+   if (!cm || !cm->cb) return -43;
+   cm->cb(d, n); cm->calls++;
+   return 0;
+}
 
 /* singular value operator on host memory */
 struct primme_amd_svds_operator { hipk_csr *A, *At; void *jac_r, *jac_c; int cplx; };

@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))   # checkers.py: test infrastru
 def run(rank, world, port, case, out_path):
     import ctypes as C
     import torch
+    extra = {}
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -41,6 +42,40 @@ def run(rank, world, port, case, out_path):
         v0 = problems.start_vector(n, row0=rank * n0, nrows=n0)
         s = Session(op, backend="hostcheck")
         r = s.solve(numEvals=6, eps=1e-10, aNorm=8.0 * 1.37, v0=v0, numProcs=world, procID=rank, global_sum=global_sum)
+        s.close()
+    elif case.startswith("devcomm"):
+        # The path the GPUs take: the library's own operator and communicator (reductions inside the stream of
+        # launches, |t|^2 and t'At in one all-reduce, fused / speculative restart on reduced overlaps).  The
+        # all-reduce of the stand-in communicator (oracle/hostcheck_glue.c) is gloo; block-diagonal matrix, so
+        # the operator itself needs no exchange.  devcomm_lock: locking (10 pairs), devcomm_soft: 4 pairs.
+        dims = (15, 16)
+        rp, ci, va, n0 = problems.laplacian_csr(dims)
+        rpt, cit, vat = problems.tile_block_diagonal(rp, ci, va, 1, scale_fn=lambda t: 1.0 + 0.37 * t, row0_tile=rank)
+        n = n0 * world
+        lib = checkers.load_hostcheck()
+        AR = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int)
+
+        def allreduce(buf, count):
+            a = np.ctypeslib.as_array(buf, shape=(count,))
+            t = torch.from_numpy(a.copy())
+            dist.all_reduce(t)
+            a[:] = t.numpy()
+        arcb = AR(allreduce)
+        comm = C.c_void_p()
+        lib.primme_amd_hostcheck_comm_create.argtypes = [C.POINTER(C.c_void_p), AR, C.c_int, C.c_int]
+        assert lib.primme_amd_hostcheck_comm_create(C.byref(comm), arcb, rank, world) == 0
+        op = Operator(n, csr=(rpt, cit, vat), row0=rank * n0, nrows=n0)
+        v0 = problems.start_vector(n, row0=rank * n0, nrows=n0)
+        s = Session(op, comm=comm, backend="hostcheck")
+        nev = 10 if case == "devcomm_lock" else 4
+        counts = (C.c_long * 8)()
+        lib.hipk_cpu_counts(counts, 1)
+        r = s.solve(numEvals=nev, eps=1e-10, aNorm=8.0 * 1.37, v0=v0, numProcs=world, procID=rank)
+        lib.hipk_cpu_counts(counts, 1)
+        lib.primme_amd_hostcheck_comm_calls.restype = C.c_long
+        lib.primme_amd_hostcheck_comm_calls.argtypes = [C.c_void_p]
+        extra = dict(allreduces=int(lib.primme_amd_hostcheck_comm_calls(comm)), fused_tail=int(counts[5]), ritz_cgs=int(counts[3]),
+                     ritz_ov=int(counts[6]), dots=int(counts[0]), locking=int(r.params["locking"]))
         s.close()
     elif case == "halo":
         # one 2-D Laplacian split by rows; the callback matvec exchanges one grid line with the neighbour
@@ -164,7 +199,10 @@ def run(rank, world, port, case, out_path):
     else:
         raise ValueError(case)
     res = dict(rank=rank, ret=r.ret, evals=r.evals.tolist(), resNorms=r.resNorms.tolist(), its=r.stats["numOuterIterations"],
-               numGlobalSum=r.stats["numGlobalSum"], evecs_norm2=float(np.sum(r.evecs ** 2)))
+               numGlobalSum=r.stats["numGlobalSum"], evecs_norm2=float(np.sum(r.evecs ** 2)), restarts=r.stats["numRestarts"],
+               matvecs=r.stats["numMatvecs"])
+    if case.startswith("devcomm"):
+        res.update(extra)
     json.dump(res, open(f"{out_path}.{rank}", "w"))
     dist.barrier()
     dist.destroy_process_group()

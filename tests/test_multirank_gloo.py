@@ -97,3 +97,31 @@ def test_hermitian_two_ranks(built, tmp_path):
         assert r["numGlobalSum"] > 0
     assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"]
     assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - 4.0) < 1e-8
+
+
+@pytest.mark.parametrize("case,nev", [("devcomm_lock", 10), ("devcomm_soft", 4)])
+def test_device_communicator_path_two_ranks(built, tmp_path, case, nev):
+    """The code path of a multi-GPU run -- the library's own operator AND communicator: all-reduces inside the stream of
+    launches, |t|^2 and t'At in one all-reduce, fused and speculative restart working on reduced overlaps -- with
+    world_size 2 on CPU: the communicator is the stand-in of oracle/hostcheck_glue.c whose all-reduce is gloo."""
+    res = _launch(case, tmp_path)
+    dims = (15, 16)
+    rp, ci, va, n0 = problems.laplacian_csr(dims)
+    rpt, cit, vat = problems.tile_block_diagonal(rp, ci, va, 2, scale_fn=lambda t: 1.0 + 0.37 * t)
+    n = 2 * n0
+    single = eigsh(Operator(n, csr=(rpt, cit, vat)), backend="hostcheck", numEvals=nev, eps=1e-10, aNorm=8.0 * 1.37,
+                   v0=problems.start_vector(n))
+    ex = np.sort(np.concatenate([problems.laplacian_eigenvalues(dims, nev), 1.37 * problems.laplacian_eigenvalues(dims, nev)]))[:nev]
+    for r in res:
+        assert r["ret"] == 0 and r["locking"] == (1 if case == "devcomm_lock" else 0)
+        assert np.max(np.abs(np.array(r["evals"]) - ex)) <= 1e-10 * 8 * 1.37
+        assert np.max(np.abs(np.array(r["evals"]) - single.evals)) <= 1e-10 * 8 * 1.37
+        assert np.all(np.array(r["resNorms"]) <= 1e-10 * 8 * 1.37 * 1.001)
+        # the single-rank launch structure survives: one-launch tail in (almost) every iteration, the check at the full
+        # basis is the restart pass, panel products only around locked pairs; two all-reduces per iteration + change
+        assert r["fused_tail"] >= r["its"] - 20 and r["ritz_ov"] >= r["restarts"] - 12
+        assert r["dots"] <= r["restarts"] + 60
+        assert 2 * r["its"] <= r["allreduces"] <= 2 * r["its"] + 3 * r["restarts"] + 80
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]
+    assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - nev) < 1e-8
+    assert abs(res[0]["its"] - single.stats["numOuterIterations"]) <= max(3, 0.05 * single.stats["numOuterIterations"])
