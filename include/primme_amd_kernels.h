@@ -60,6 +60,10 @@ int  hipk_sync(hipk_ctx *ctx);
  * flag in pinned memory and the host spins on it.  Only valid when that reduction was the last thing
  * enqueued; falls back to hipk_sync otherwise. */
 int  hipk_wait_results(hipk_ctx *ctx);
+/* copy `count` results that some other producer (an RCCL all-reduce) left at `dev` (inside the mirrored range) into the
+ * pinned mirror and publish the completion flag: hipk_wait_results instead of a stream synchronisation; returns 1 when
+ * the buffer is not mirrored (the caller then copies and synchronises) */
+int  hipk_publish_results(hipk_ctx *ctx, const double *dev, int count);
 /* zero-copy results: every reduction whose output lies in [dev_base, dev_base+count) is also
  * written by the kernel into the pinned host array (same offsets); the host then needs only
  * hipk_sync, no device->host copy (the reference GPU backend does a blocking hipMemcpy per

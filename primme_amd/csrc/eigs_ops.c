@@ -42,8 +42,18 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
    double t0 = parallel ? pa_wtime() : 0.0;
    if (parallel && s->dev_comm) {
       CHK(pa_comm_allreduce_device(p->commInfo, d_buf, count, hipk_ctx_stream(s->ctx)));
-      CHK(hipk_d2h(s->ctx, s->h_red + (d_buf - s->d_red), d_buf, (size_t)count * sizeof(double)));
-      if (!defer_sync) CHK(hipk_sync(s->ctx));
+      /* the global sums reach the pinned mirror through a one-block launch that also publishes the completion flag
+       * (the wait is then a spin on pinned memory, as on one rank); fallback: copy + stream synchronisation */
+      static int no_publish = -1;      /* PRIMME_AMD_NO_PUBLISH=1: measurement knob, read once */
+      if (no_publish < 0) no_publish = getenv("PRIMME_AMD_NO_PUBLISH") != NULL;
+      const int rcp = no_publish ? 1 : hipk_publish_results(s->ctx, d_buf, count);
+      if (rcp < 0) return PRIMME_UNEXPECTED_FAILURE;
+      if (rcp == 0) {
+         if (!defer_sync) CHK(hipk_wait_results(s->ctx));
+      } else {
+         CHK(hipk_d2h(s->ctx, s->h_red + (d_buf - s->d_red), d_buf, (size_t)count * sizeof(double)));
+         if (!defer_sync) CHK(hipk_sync(s->ctx));
+      }
    } else {
       /* the reduction kernels already stored the local sums in h_red (zero-copy mirror) */
       if (parallel) {

@@ -243,6 +243,22 @@ int hipk_finalize_partials_strided(hipk_ctx *ctx, const double *partials, int nb
    return 0;
 }
 
+/* results produced by something else than our reductions (an all-reduce): into the mirror, then the flag */
+__global__ void __launch_bounds__(HIPK_BLOCK)
+hipk_publish_kernel(const double *__restrict__ src, double *__restrict__ dst_host, int n, hipk_fin_flag fin) {
+   for (int i = threadIdx.x; i < n; i += HIPK_BLOCK) dst_host[i] = src[i];
+   __syncthreads();
+   if (threadIdx.x == 0) hipk_publish_flag(fin, 1);
+}
+extern "C" int hipk_publish_results(hipk_ctx *ctx, const double *dev, int count) {
+   if (count <= 0) return 0;
+   double *mh = hipk_mirror_of(ctx, dev);
+   if (!mh || !ctx->flag_dev || !ctx->spin_wait || !hipk_mirror_of(ctx, dev + count - 1)) return 1;
+   hipLaunchKernelGGL(hipk_publish_kernel, dim3(1), dim3(HIPK_BLOCK), 0, ctx->stream, dev, mh, count, hipk_next_flag(ctx, dev));
+   HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
 extern "C" int hipk_ctx_set_mirror(hipk_ctx *ctx, double *dev_base, double *pinned_host_base, size_t count) {
    ctx->mirror_dev = dev_base;
    ctx->mirror_count = count;
