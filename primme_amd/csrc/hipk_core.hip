@@ -3,6 +3,8 @@
  * See include/primme_amd_kernels.h for the reference routines each entry replaces. */
 #include "hipk_internal.h"
 #include <time.h>
+static double g_alloc_s = 0.0;      /* HIPK_HOST_TIMING: seconds spent in hipMalloc / hipFree */
+static long g_alloc_n = 0;
 
 extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
    int ndev = 0;
@@ -49,6 +51,7 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
 extern "C" int hipk_ctx_destroy(hipk_ctx *ctx) {
    if (!ctx) return 0;
    hipStreamSynchronize(ctx->stream);
+   if (ctx->host_timing && g_alloc_n) { fprintf(stderr, "hipk host timing: %ld hipMalloc/hipFree calls so far, %.2f ms\n", g_alloc_n, 1e3 * g_alloc_s); }
    if (ctx->host_timing && ctx->ht_waits)
       fprintf(stderr, "hipk host timing: %ld waits, %.2f us each; %ld turnarounds (wait return -> fused residual launch), %.2f us each\n",
             ctx->ht_waits, 1e6 * ctx->ht_wait_s / ctx->ht_waits, ctx->ht_turns, ctx->ht_turns ? 1e6 * ctx->ht_turn_s / ctx->ht_turns : 0.0);
@@ -75,16 +78,19 @@ int hipk_reserve_partials(hipk_ctx *ctx, size_t n) {
    return 0;
 }
 
+static double alloc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 extern "C" int hipk_malloc(hipk_ctx *ctx, size_t bytes, void **dptr) {
-   (void)ctx;
    if (bytes == 0) bytes = 8;
+   const double t0 = (ctx && ctx->host_timing) ? alloc_now() : 0.0;
    hipError_t e = hipMalloc(dptr, bytes);
+   if (ctx && ctx->host_timing) { g_alloc_s += alloc_now() - t0; g_alloc_n++; }
    if (e != hipSuccess) { *dptr = NULL; return -2; }
    return 0;
 }
 extern "C" int hipk_free(hipk_ctx *ctx, void *dptr) {
-   (void)ctx;
+   const double t0 = (ctx && ctx->host_timing) ? alloc_now() : 0.0;
    if (dptr) HIPK_CHECK(hipFree(dptr));
+   if (ctx && ctx->host_timing && dptr) { g_alloc_s += alloc_now() - t0; g_alloc_n++; }
    return 0;
 }
 extern "C" int hipk_host_alloc(hipk_ctx *ctx, size_t bytes, void **hptr) {
