@@ -181,7 +181,7 @@ int pa_svds_apply_scaled(primme_params *primme, hipk_ctx *ctx, const void *t, co
       double *dot_dev);
 int pa_fuse_tail_eligible(const pa_solver *s) {
    const primme_params *p = s->p;
-   if (s->nT < 1 || s->ld != s->m) return 0;
+   if (s->nT < 1) return 0;                      /* (single columns: the leading dimension does not enter) */
    if (p->matrixMatvec == primme_amd_matvec)
       return p->matrix && primme_amd_operator_can_fuse((const primme_amd_operator *)p->matrix) &&
              hipk_csr_dtype(primme_amd_operator_matrix((primme_amd_operator *)p->matrix)) == s->dt;

@@ -1299,39 +1299,57 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
             }
       }
    }
-   /* ragged tail (fewer than 64*VW rows): the last workgroup, one row per lane, same scheme */
-   if (blockIdx.x == gridDim.x - 1) {
-      for (int64_t i0 = ngroups * 64 * VW; i0 < m; i0 += 64, buf ^= 1) {
-         const int64_t i = i0 + lane;
-         const bool live = i < m;
-         double tv[CPW], tw[CPW], tq[QN], twl = 0.0, px = 0.0, py = 0.0;
+   /* Ragged tail (fewer than 64*VW rows): ONE more step of the same shape with element-wise guarded loads, done by
+    * the workgroup that has the fewest full steps (with the strided assignment the first one behind the remainder):
+    * as two one-row-per-lane steps on the last workgroup it was the tail of the whole launch -- 132.6 us against
+    * 122.6 us for 31 k more rows that divide evenly (k = 15, L = 10, m = 2 000 250). */
+   const int tailwg = blocked ? (int)gridDim.x - 1 : (int)(ngroups % gridDim.x);
+   if ((int)blockIdx.x == tailwg && ngroups * 64 * VW < m) {
+      const int64_t i0 = ngroups * 64 * VW + (int64_t)lane * VW;
+      double tv[CPW][VW], tw[CPW][VW], tq[QN][VW], twl[VW], px[VW], py[VW];
+      bool live[VW];
 #pragma unroll
-         for (int jj = 0; jj < CPW; jj++) {
-            const bool on = live && (j0 + jj < k);
-            tv[jj] = on ? (double)vp[jj][i] : 0.0;
-            tw[jj] = on ? (double)wp[jj][i] : 0.0;
-            px = fma(tv[jj], hj[jj], px);
-            py = fma(tw[jj], hj[jj], py);
+      for (int r = 0; r < VW; r++) { live[r] = i0 + r < m; px[r] = 0.0; py[r] = 0.0; twl[r] = 0.0; }
+#pragma unroll
+      for (int jj = 0; jj < CPW; jj++) {
+#pragma unroll
+         for (int r = 0; r < VW; r++) {
+            const bool on = live[r] && (j0 + jj < k);
+            tv[jj][r] = on ? (double)vp[jj][i0 + r] : 0.0;
+            tw[jj][r] = on ? (double)wp[jj][i0 + r] : 0.0;
          }
+      }
 #pragma unroll
-         for (int qq = 0; qq < QN; qq++) tq[qq] = (QPW > 0 && live && q0 + qq < L) ? (double)qp[qq][i] : 0.0;
-         if (WT && QPW > 0 && live && q0 < L) twl = (double)wlast[i];
-         sxy[buf][0][0][wv][lane] = px; sxy[buf][1][0][wv][lane] = py;
-         __syncthreads();
-         const double x = (sxy[buf][0][0][0][lane] + sxy[buf][0][0][1][lane]) + (sxy[buf][0][0][2][lane] + sxy[buf][0][0][3][lane]);
-         const double y = (sxy[buf][1][0][0][lane] + sxy[buf][1][0][1][lane]) + (sxy[buf][1][0][2][lane] + sxy[buf][1][0][3][lane]);
+      for (int qq = 0; qq < QN; qq++)
+#pragma unroll
+         for (int r = 0; r < VW; r++) tq[qq][r] = (QPW > 0 && live[r] && q0 + qq < L) ? (double)qp[qq][i0 + r] : 0.0;
+      if (WT && QPW > 0 && q0 < L) {
+#pragma unroll
+         for (int r = 0; r < VW; r++) twl[r] = live[r] ? (double)wlast[i0 + r] : 0.0;
+      }
+#pragma unroll
+      for (int jj = 0; jj < CPW; jj++)
+#pragma unroll
+         for (int r = 0; r < VW; r++) { px[r] = fma(tv[jj][r], hj[jj], px[r]); py[r] = fma(tw[jj][r], hj[jj], py[r]); }
+#pragma unroll
+      for (int r = 0; r < VW; r++) { sxy[buf][0][r][wv][lane] = px[r]; sxy[buf][1][r][wv][lane] = py[r]; }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < VW; r++) {
+         const double x = (sxy[buf][0][r][0][lane] + sxy[buf][0][r][1][lane]) + (sxy[buf][0][r][2][lane] + sxy[buf][0][r][3][lane]);
+         const double y = (sxy[buf][1][r][0][lane] + sxy[buf][1][r][1][lane]) + (sxy[buf][1][r][2][lane] + sxy[buf][1][r][3][lane]);
          const T rt = (T)fma(-theta, x, y);
-         const double r = live ? (double)rt : 0.0;
-         if (wv == 0 && live) { dst[i] = rt; n2 = fma(r, r, n2); }
+         const double rr = live[r] ? (double)rt : 0.0;
+         if (wv == 0 && live[r]) { dst[i0 + r] = rt; n2 = fma(rr, rr, n2); }
 #pragma unroll
          for (int jj = 0; jj < CPW; jj++) {
-            ov[jj] = fma(tv[jj], r, ov[jj]);
-            if (WT) ow[WT ? jj : 0] = fma(tw[jj], r, ow[WT ? jj : 0]);
+            ov[jj] = fma(tv[jj][r], rr, ov[jj]);
+            if (WT) ow[WT ? jj : 0] = fma(tw[jj][r], rr, ow[WT ? jj : 0]);
          }
 #pragma unroll
          for (int qq = 0; qq < QN; qq++) {
-            oq[qq] = fma(tq[qq], r, oq[qq]);
-            if (WT) og[WT ? qq : 0] = fma(twl, tq[qq], og[WT ? qq : 0]);
+            oq[qq] = fma(tq[qq][r], rr, oq[qq]);
+            if (WT) og[WT ? qq : 0] = fma(twl[r], tq[qq][r], og[WT ? qq : 0]);
          }
       }
    }

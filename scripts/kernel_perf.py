@@ -9,7 +9,8 @@ from primme_amd import _ffi as F, problems
 lib = F.load_product()
 ctx = C.c_void_p(); assert lib.hipk_ctx_create(C.byref(ctx), None) == 0
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-m = int(os.environ.get("KP_M", "2000250")); ld = m; K = 16; L = 10
+m = int(os.environ.get("KP_M", "2000250")); K = 16; L = 10
+ld = (m + 15) // 16 * 16 if os.environ.get("KP_LDPAD") else m          # columns on 128-byte boundaries
 dt = F.HIPK_F64
 V = torch.randn((26, ld), dtype=torch.float64, device="cuda")
 W = torch.randn((26, ld), dtype=torch.float64, device="cuda")
