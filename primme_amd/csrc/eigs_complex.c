@@ -20,7 +20,7 @@
  *
  * Cost: twice the eigenpairs on vectors of the same byte length as the complex ones, i.e. the
  * iteration counts are NOT those of the reference's zprimme (the eigenvalues, eigenvectors and
- * residual norms are, to the tolerance).  Native complex kernels are the follow-up (DESIGN.md §9).
+ * residual norms are, to the tolerance).  Native complex kernels are the follow-up (DESIGN.md section 8).
  */
 #include <math.h>
 #include <stddef.h>
