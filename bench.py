@@ -46,7 +46,7 @@ WORKLOADS = {
     "lap3d_small": dict(dims=(60, 61, 62), aNorm=12.0, desc="3-D 7-pt Laplacian 60x61x62 CSR (dev)"),
 }
 KERNEL_CLASSES = ["dots_kernel (TN inner products: CGS overlaps + V'W)", "project_kernel (CGS update + norm)",
-                  "ritz_kernel (fused X=Vh, R=Wh-X*theta, norms, restart)", "csr_stream_kernel (CSR SpMV)"]
+                  "ritz_kernel class = ritz_cgs_kernel + ritz_ov_kernel + ritz_kernel (fused R=Wh-theta Vh with its overlaps; restart X=Vh, Y=Wh)", "csr_stream_kernel (CSR SpMV)"]
 HBM_PEAK_GBS = 8000.0
 
 
