@@ -206,7 +206,7 @@ int pa_restart_stash_eligible(const pa_solver *s, int basisSize, int nLk) {
    if (nLk > 0 && !(s->wtq_L == nLk && s->wtq_rows >= basisSize - 1)) return 0;
    if (p->n <= (int64_t)p->maxBasisSize + nLk) return 0;      /* the practical-convergence test would read R */
    if (p->maxMatvecs > 0 && p->stats.numMatvecs + 2 >= p->maxMatvecs) return 0;   /* the tail applies the operator ahead of time */
-   return pa_fuse_tail_eligible(s);
+   return 1;      /* any operator: with an application callback the tail is project / scale / callback / t'At (eigs_conv.c) */
 }
 
 /* Speculative restart (eigs_solver.h): at the full-basis check of candidate `col`, predict the restart's
@@ -261,8 +261,8 @@ static int try_speculative_restart(pa_solver *s, int basisSize, int nLk, const i
 /* The speculative tail of a block-size-1 GD iteration, enqueued right after the fused residual pass: the
  * first Gram-Schmidt update with the device-resident overlaps, then (speculate2) normalisation, operator
  * application and the new column of H, so that the host synchronises once.  `rsrc` holds the residual
- * (the basis slot `dstc` itself, or a scratch column after a restart, which needs the fused operator
- * launch); d_fov / h_fov hold [V'r | Q'r | r'r | W'r | ..] in `nfov` entries. */
+ * (the basis slot `dstc` itself, or a scratch column after a restart: the update is out of place either
+ * way); d_fov / h_fov hold [V'r | Q'r | r'r | W'r | ..] in `nfov` entries. */
 int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, char *dstc, int nfov, int wtr,
       int speculate2, int parallel_host) {
    primme_params *p = s->p;
@@ -273,7 +273,6 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
    /* with the fused tail the projected vector goes to the scratch column T(:,0): the operator
     * launch gathers from it while it writes the normalised vector into V(:,k) */
    const int fuse_tail = speculate2 && wtr && pa_fuse_tail_eligible(s);
-   if (rsrc != dstc && !fuse_tail) return PRIMME_UNEXPECTED_FAILURE;
    s->spec_fused = 0;
    CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, rsrc, s->ld,
               fuse_tail ? TCOL(s, 0) : dstc, s->ld, 1, s->d_fov + nfov));

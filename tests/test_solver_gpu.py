@@ -275,3 +275,34 @@ def test_hip_interior_pairs_medium_size(built, projection):
     assert np.all(r.resNorms <= 1e-8 * 12.0 * (1 + 1e-6))
     X = np.asarray(r.evecs, dtype=np.float64)
     assert np.linalg.norm(X.T @ X - np.eye(4)) <= 1e-7
+
+
+def test_hip_application_matvec_callback_keeps_the_restart_paths(built):
+    """An application's own device callback instead of primme_amd_matvec (the drop-in case of
+    examples/ex_eigs_dhipblas.c): the iteration tail is project / scale / callback / t'At instead of the one-launch
+    form, the fused and speculative restart still apply; iteration, matvec and restart counts are the reference's."""
+    import ctypes as C
+    from checkers import Session
+    from primme_amd import _ffi as F
+    dims = (40, 41)
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    s = Session(Operator(n, csr=(rp, ci, va)), backend="hip")
+    A = [h for k, h in s.handles if k == "csr"][0]
+    calls = [0]
+
+    def matvec(x, ldx, y, ldy, bs, pp, ierr):
+        calls[0] += bs[0]
+        ierr[0] = s.lib.hipk_csr_matvec(A, None, x, ldx[0], y, ldy[0], bs[0])
+    cb = F.BLOCK_OP(matvec)
+    kw = dict(numEvals=10, eps=1e-10, aNorm=8.0, v0=problems.start_vector(n), method="GD_plusK")
+    r = s.solve(user_matvec=cb, **kw)
+    own = s.solve(**kw)
+    s.close()
+    h = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", **kw)
+    assert r.ret == 0 and own.ret == 0 and h.ret == 0
+    assert np.max(np.abs(r.evals - problems.laplacian_eigenvalues(dims, 10))) <= 1e-10 * 8.0
+    for key in ("numOuterIterations", "numMatvecs", "numRestarts"):
+        assert abs(r.stats[key] - h.stats[key]) <= max(2, 0.02 * h.stats[key]), key
+        assert abs(own.stats[key] - h.stats[key]) <= max(2, 0.02 * h.stats[key]), key
+    # (speculative applications that were discarded are not counted by the solver)
+    assert r.stats["numMatvecs"] <= calls[0] <= r.stats["numMatvecs"] + 30

@@ -205,6 +205,34 @@ def test_launch_structure_block_size_one(built, mode, monkeypatch):
     assert project <= its + 25               # one update per new vector (+ rare second passes)
 
 
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("dims,nev", [((20, 21), 10), ((20, 21), 4), ((9, 10, 11), 7)])
+def test_application_matvec_callback_keeps_the_restart_paths(built, dims, nev):
+    """with an application's matvec callback the one-launch tail is not available, the fused / speculative restart is:
+    counts are the reference's, the restart pass is the speculative one, no fused-tail launches"""
+    import ctypes as C
+    lib = checkers.load_hostcheck()
+    rp, ci, va, n = problems.laplacian_csr(dims)
+
+    def matvec(x, ldx, y, ldy, bs, pp, ierr):
+        nb, lx, ly = bs[0], ldx[0], ldy[0]
+        X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(nb, lx))
+        Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(nb, ly))
+        Y[:, :n] = problems.csr_matvec_numpy(rp, ci, va, X[:, :n].T).T
+        ierr[0] = 0
+    cb = F.BLOCK_OP(matvec)
+    cnt = (C.c_long * 8)()
+    kw = dict(numEvals=nev, eps=1e-10, aNorm=4.0 * len(dims), v0=problems.start_vector(n), method="GD_plusK")
+    lib.hipk_cpu_counts(cnt, 1)
+    h = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", user_matvec=cb, **kw)
+    lib.hipk_cpu_counts(cnt, 1)
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="reference", **kw)
+    assert h.ret == 0 and r.ret == 0
+    for key in ("numOuterIterations", "numMatvecs", "numRestarts"):
+        assert h.stats[key] == r.stats[key], key
+    assert cnt[5] == 0 and cnt[6] >= r.stats["numRestarts"] - 12 and cnt[0] <= r.stats["numRestarts"] + 45
+
+
 # ---- the reference's own driver regression cases on LUNDA.mtx -----------------------------
 import reference_driver_cases as RD
 
