@@ -292,7 +292,8 @@ def test_hip_application_matvec_callback_keeps_the_restart_paths(built):
 
     def matvec(x, ldx, y, ldy, bs, pp, ierr):
         calls[0] += bs[0]
-        ierr[0] = s.lib.hipk_csr_matvec(A, None, x, ldx[0], y, ldy[0], bs[0])
+        stream = C.cast(pp[0].queue, C.POINTER(C.c_void_p))[0]      # the solver's stream (primme->queue), like the reference's handle
+        ierr[0] = s.lib.hipk_csr_matvec(A, stream, x, ldx[0], y, ldy[0], bs[0])
     cb = F.BLOCK_OP(matvec)
     kw = dict(numEvals=10, eps=1e-10, aNorm=8.0, v0=problems.start_vector(n), method="GD_plusK")
     r = s.solve(user_matvec=cb, **kw)
