@@ -600,3 +600,60 @@ def test_device_rayleigh_ritz_kernel(built, n):
         assert np.linalg.norm(Z.T @ Z - np.eye(n)) <= 1e-13 * n
         assert np.linalg.norm(A @ Z - Z * ev) <= 1e-12 * scale * n
         side.close()
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("dims,nslabs", [((60, 70), 2), ((23, 19, 17), 3), ((5000,), 4)])
+def test_csr_row_slabs_with_halo(built, dt, dims, nslabs):
+    """What a row-partitioned run asks of the SpMV kernels, on ONE device: every slab of rows is its own hipk_csr with
+    GLOBAL column numbers, its input vector is the local slab plus the two halo buffers the neighbours would send
+    (filled by hand here), in the plain form (1 and 3 columns) and in the fused form (scale + A t + t'At) of the
+    iteration tail; against the whole-matrix product in numpy and against the oracle's slabs."""
+    rng = np.random.default_rng(sum(dims) + nslabs)
+    npdt = NPDT[dt]
+    n = int(np.prod(dims))
+    rp0, ci0, va0, _ = problems.laplacian_csr(dims)
+    X = rng.standard_normal((3, n))
+    Yref = problems.csr_matvec_numpy(rp0, ci0, va0, X.T).T                     # (3, n)
+    tol = 1e-12 if dt == F.HIPK_F64 else 2e-5
+    base, rem = divmod(n, nslabs)
+    for sidx in range(nslabs):
+        nloc = base + (1 if sidx < rem else 0)
+        row0 = sidx * base + min(sidx, rem)
+        rp, ci, va, _ = problems.laplacian_csr(dims, row0=row0, nrows=nloc)
+        outs = []
+        for side in (Dev(), Host()):
+            A = C.c_void_p()
+            assert side.lib.hipk_csr_create(side.ctx, dt, nloc, n, row0, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                            np.ascontiguousarray(va, dtype=npdt).ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+            lo, hi = int(side.lib.hipk_csr_halo_lo(A)), int(side.lib.hipk_csr_halo_hi(A))
+            assert lo == (row0 - int(ci.min()) if row0 > 0 else 0) and hi == max(0, int(ci.max()) - (row0 + nloc) + 1)
+            xl = side.arr(X[:, row0:row0 + nloc].astype(npdt))                    # 3 local columns, ld = nloc
+            xlo = side.arr(np.ascontiguousarray(X[:, row0 - lo:row0]).astype(npdt) if lo else np.zeros((3, 1), npdt))
+            xhi = side.arr(np.ascontiguousarray(X[:, row0 + nloc:row0 + nloc + hi]).astype(npdt) if hi else np.zeros((3, 1), npdt))
+            y = side.arr(np.zeros((3, nloc), npdt))
+            assert side.lib.hipk_csr_set_halo_ld(A, side.ptr(xlo), max(lo, 1), side.ptr(xhi), max(hi, 1)) == 0
+            assert side.lib.hipk_csr_matvec(A, None, side.ptr(xl), nloc, side.ptr(y), nloc, 3) == 0
+            y3 = side.get(y).astype(np.float64)
+            y1 = side.arr(np.zeros((1, nloc), npdt))
+            assert side.lib.hipk_csr_matvec(A, None, side.ptr(xl), nloc, side.ptr(y1), nloc, 1) == 0
+            y1v = side.get(y1).astype(np.float64)
+            # fused tail on column 0: a = 1/sqrt(norm2), xout = a x, y = A(a x) with the halo entries scaled inside
+            red = side.arr(np.array([7.5, 0.0, 0.0]))
+            if hasattr(side.lib, "hipk_ctx_set_mirror"):
+                pass
+            xout = side.arr(np.zeros((1, nloc), npdt)); yf = side.arr(np.zeros((1, nloc), npdt))
+            rcf = side.lib.hipk_csr_matvec_scaled(A, side.ctx, side.ptr(xl), side.ptr(red), side.ptr(xout), side.ptr(yf), side.ptr(red, 1))
+            assert rcf == 0
+            outs.append((y3, y1v, side.get(xout).astype(np.float64), side.get(yf).astype(np.float64), float(side.get(red)[1])))
+            side.lib.hipk_csr_destroy(A)
+            side.close()
+        scale = max(1.0, np.abs(Yref).max())
+        a = 1.0 / np.sqrt(7.5)
+        for (y3, y1v, xo, yf, dot) in outs:
+            assert np.max(np.abs(y3 - Yref[:, row0:row0 + nloc])) <= 50 * tol * scale
+            assert np.max(np.abs(y1v[0] - Yref[0, row0:row0 + nloc])) <= 50 * tol * scale
+            assert np.max(np.abs(xo[0] - a * X[0, row0:row0 + nloc])) <= 10 * tol * scale
+            assert np.max(np.abs(yf[0] - a * Yref[0, row0:row0 + nloc])) <= 50 * tol * scale
+            assert abs(dot - a * a * float(X[0, row0:row0 + nloc] @ Yref[0, row0:row0 + nloc])) <= 500 * tol * scale * np.sqrt(nloc)
+        assert np.max(np.abs(outs[0][0] - outs[1][0])) <= 50 * tol * scale
