@@ -107,6 +107,17 @@ int hip_sprimme_svds(float *svals, float *svecs, float *resNorms, primme_svds_pa
 int hip_zprimme_svds(double *svals, void *svecs, double *resNorms, primme_svds_params *primme_svds);
 int hip_cprimme_svds(float *svals, void *svecs, float *resNorms, primme_svds_params *primme_svds);
 
+/* The reference's CPU entry points with their HOST-pointer contract (reference include/primme_svds.h:236-243,
+ * src/svds/primme_svds_c.c:113-118; BASELINE configs[4] is worded with dprimme_svds): svecs is a host array
+ * [Uc U | Vc V], the callbacks get host pointers, primme_svds->queue must be NULL.  A program written against the
+ * CPU library (examples/ex_svds_dseq.c) relinks unchanged; the solve runs on the device and every operator
+ * application is staged through pinned host memory (csrc/svds_hostapi.c) — the plumbing path; hand
+ * hip_?primme_svds a device callback or the library's CSR operator for the device rate. */
+int dprimme_svds(double *svals, double *svecs, double *resNorms, primme_svds_params *primme_svds);
+int sprimme_svds(float *svals, float *svecs, float *resNorms, primme_svds_params *primme_svds);
+int zprimme_svds(double *svals, void *svecs, double *resNorms, primme_svds_params *primme_svds);
+int cprimme_svds(float *svals, void *svecs, float *resNorms, primme_svds_params *primme_svds);
+
 /* ---- ready-made matvec for a device-resident CSR matrix and its transpose ----------------
  * primme_svds->matrix = handle from primme_amd_svds_operator_create (A and A' are both kept in
  * CSR: the transposed product is then the same coalesced row-tile kernel instead of a scatter

@@ -120,7 +120,11 @@ extern "C" int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stre
  * solver's own use with this ready-made operator: a user matvec callback is a black box and gets the
  * separate normalisation / operator / inner-product launches instead. */
 extern "C" int primme_amd_operator_can_fuse(const primme_amd_operator *op) {
-   return op && op->ldscale == 1 && hipk_csr_kind(op->A) == 0;
+   /* every precondition of hipk_csr_matvec_scaled, so that an eligible tail cannot fail with "not applicable":
+    * a CSR matrix whose input entries are its own row slab, and halo data this operator knows how to fetch */
+   if (!op || op->ldscale != 1 || !hipk_csr_fusable(op->A)) return 0;
+   if (op->mode == 0 && (hipk_csr_halo_lo(op->A) > 0 || hipk_csr_halo_hi(op->A) > 0)) return 0;
+   return 1;
 }
 extern "C" int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ctx *ctx, const void *x,
       const double *norm2_dev, void *xout, void *y, double *dot_dev) {
@@ -269,10 +273,13 @@ extern "C" int primme_amd_svds_operator_set_jacobi(primme_amd_svds_operator *op,
    free(sum);
    if (!op->jac_r && hipMalloc(&op->jac_r, es * (size_t)(m > 0 ? m : 1)) != hipSuccess) { free(packed); return -2; }
    if (!op->jac_c && hipMalloc(&op->jac_c, es * (size_t)(n > 0 ? n : 1)) != hipSuccess) { free(packed); return -2; }
-   hipError_t e1 = hipMemcpy(op->jac_r, packed, es * (size_t)m, hipMemcpyHostToDevice);
-   hipError_t e2 = hipMemcpy(op->jac_c, packed + es * (size_t)m, es * (size_t)n, hipMemcpyHostToDevice);
+   /* on the stream the operator's kernels run on, then drained (never the NULL stream: see csr_create_impl) */
+   hipStream_t st = (hipStream_t)hipk_ctx_stream(hipk_csr_ctx(op->A));
+   hipError_t e1 = m > 0 ? hipMemcpyAsync(op->jac_r, packed, es * (size_t)m, hipMemcpyHostToDevice, st) : hipSuccess;
+   hipError_t e2 = n > 0 ? hipMemcpyAsync(op->jac_c, packed + es * (size_t)m, es * (size_t)n, hipMemcpyHostToDevice, st) : hipSuccess;
+   hipError_t e3 = hipStreamSynchronize(st);
    free(packed);
-   return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
+   return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -1;
 }
 
 /* applyPreconditioner of primme_svds_params for the operator's Jacobi data: y = x / diag(A'A),

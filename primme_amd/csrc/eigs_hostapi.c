@@ -20,7 +20,8 @@ typedef struct {
    primme_params q;        /* the shadow handed to the device solver */
    hipk_ctx *ctx;          /* staging copies run on the solver's stream (published in q.queue) */
    size_t es;              /* bytes per vector element */
-   char *hx, *hy;          /* pinned staging panels, nLocal x cap columns */
+   char *hx, *hy;          /* pinned staging panels, ldh x cap columns */
+   PRIMME_INT ldh;         /* the CALLER's ldOPs (>= nLocal): what its callbacks may index with (primme_c.c:333-337) */
    int cap;
 } host_side;
 
@@ -28,7 +29,7 @@ typedef struct {
 
 static int stage_reserve(host_side *sd, int ncols) {
    if (ncols <= sd->cap) return 0;
-   const size_t bytes = (size_t)(sd->q.nLocal > 0 ? sd->q.nLocal : 1) * sd->es * (size_t)ncols;
+   const size_t bytes = (size_t)(sd->ldh > 0 ? sd->ldh : 1) * sd->es * (size_t)ncols;
    void *a = NULL, *b = NULL;
    if (hipk_host_alloc(sd->ctx, bytes, &a) || hipk_host_alloc(sd->ctx, bytes, &b)) return -1;
    if (sd->hx) hipk_host_free(sd->ctx, sd->hx);
@@ -58,17 +59,17 @@ static void bridge_block_op(void (*fn)(void *, PRIMME_INT *, void *, PRIMME_INT 
    *ierr = 1;
    if (nb <= 0) { *ierr = 0; return; }
    if (side_stream(sd) || stage_reserve(sd, nb)) return;
-   const size_t colB = (size_t)m * sd->es;
+   const size_t colB = (size_t)m * sd->es, colH = (size_t)sd->ldh * sd->es;
    for (int c = 0; c < nb; c++)
-      if (hipk_d2h(sd->ctx, sd->hx + colB * c, (char *)x + (size_t)c * (size_t)*ldx * sd->es, colB)) return;
+      if (hipk_d2h(sd->ctx, sd->hx + colH * c, (char *)x + (size_t)c * (size_t)*ldx * sd->es, colB)) return;
    if (hipk_sync(sd->ctx)) return;
    mirror_user(sd);
-   PRIMME_INT ldh = m;
+   PRIMME_INT ldh = sd->ldh;
    int e = 0;
    fn(sd->hx, &ldh, sd->hy, &ldh, blockSize, sd->user, &e);
    if (e) return;
    for (int c = 0; c < nb; c++)
-      if (hipk_h2d(sd->ctx, (char *)y + (size_t)c * (size_t)*ldy * sd->es, sd->hy + colB * c, colB)) return;
+      if (hipk_h2d(sd->ctx, (char *)y + (size_t)c * (size_t)*ldy * sd->es, sd->hy + colH * c, colB)) return;
    if (hipk_sync(sd->ctx)) return;      /* hy is reused by the next application */
    *ierr = 0;
 }
@@ -131,6 +132,7 @@ static int solve_host(void *evals, void *evecs, void *resNorms, primme_params *p
    if (primme->numProcs <= 1) { primme->nLocal = primme->n; primme->procID = 0; }
    primme_set_defaults(primme);
    if (primme->ldOPs == -1 || primme->ldOPs == 0) primme->ldOPs = primme->nLocal;
+   sd->ldh = primme->ldOPs >= primme->nLocal ? primme->ldOPs : primme->nLocal;
    sd->q = *primme;
    primme_params *q = &sd->q;
    const PRIMME_INT m = primme->nLocal, ldu = primme->ldevecs >= m ? primme->ldevecs : m;
@@ -157,18 +159,15 @@ static int solve_host(void *evals, void *evecs, void *resNorms, primme_params *p
       if (hipk_sync(ctx)) { ret = PRIMME_UNEXPECTED_FAILURE; goto done; }
    }
    ret = solver(evals, devecs, resNorms, q);
-   /* everything the solver reports goes back into the caller's struct; what was replaced for the
-    * staging is restored */
-   {
-      primme_params saved = *primme;
-      *primme = *q;
-      primme->matrixMatvec = saved.matrixMatvec; primme->applyPreconditioner = saved.applyPreconditioner;
-      primme->convTestFun = saved.convTestFun; primme->monitorFun = saved.monitorFun;
-      primme->globalSumReal = saved.globalSumReal; primme->broadcastReal = saved.broadcastReal;
-      primme->ldevecs = saved.ldevecs; primme->ldOPs = saved.ldOPs; primme->queue = saved.queue;
-      primme->convtest = saved.convtest;
-      if (!saved.convTestFun) { primme->convTestFun = NULL; primme->convTestFun_type = saved.convTestFun_type; }
-   }
+   /* what the solver REPORTS goes back into the caller's struct, field by field: the struct itself stays the
+    * caller's (its callbacks may have changed fields of it during the solve, e.g. from a monitor) */
+   primme->stats = q->stats;
+   primme->initSize = q->initSize;
+   primme->aNorm = q->aNorm; primme->BNorm = q->BNorm; primme->invBNorm = q->invBNorm;
+   primme->dynamicMethodSwitch = q->dynamicMethodSwitch;
+   primme->correctionParams.maxInnerIterations = q->correctionParams.maxInnerIterations;   /* the dynamic method's choice */
+   for (int i = 0; i < 4; i++) primme->iseed[i] = q->iseed[i];
+   primme->ShiftsForPreconditioner = q->ShiftsForPreconditioner;
    {
       const int nout = primme->numOrthoConst + (primme->initSize > 0 ? primme->initSize : 0);
       const int nback = nout < ncols ? (ret == 0 || ret == PRIMME_MAIN_ITER_FAILURE ? ncols : nout) : ncols;

@@ -38,7 +38,8 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
       ctx->flag_host = (volatile unsigned long long *)fh;
       ctx->flag_dev = (unsigned long long *)fd;
       HIPK_CHECK(hipMalloc((void **)&ctx->fin_counter, 64));
-      HIPK_CHECK(hipMemset(ctx->fin_counter, 0, 64));
+      HIPK_CHECK(hipMemsetAsync(ctx->fin_counter, 0, 64, ctx->stream));   /* ordered before every kernel of this context */
+      HIPK_CHECK(hipStreamSynchronize(ctx->stream));
       ctx->arrive_counter = ctx->fin_counter + 8;
       ctx->seq_issued = 0;
       ctx->spin_wait = getenv("HIPK_NO_SPINWAIT") == NULL;
@@ -123,6 +124,8 @@ extern "C" int hipk_memset0(hipk_ctx *ctx, void *dst, size_t bytes) {
 }
 extern "C" int hipk_sync(hipk_ctx *ctx) {
    HIPK_CHECK(hipStreamSynchronize(ctx->stream));
+   ctx->seq_waited = ctx->seq_issued;
+   ctx->need_sync = 0;
    return 0;
 }
 /* Wait until the results of the LAST mirrored reduction enqueued on the context are in the pinned
@@ -153,14 +156,19 @@ void hipk_note_turnaround(hipk_ctx *ctx) {
    ctx->ht_t_ret = 0.0;
 }
 static int wait_results_impl(hipk_ctx *ctx) {
-   if (ctx->spin_wait && ctx->flag_host && ctx->seq_issued > 0) {
+   /* NOT a stream synchronisation: it returns when the last FLAGGED reduction has published its results.  Only
+    * valid when such a launch was enqueued since the previous wait and nothing un-flagged produced results after
+    * it; otherwise (stale sequence number, early-return / memset paths) drain the stream. */
+   if (ctx->spin_wait && ctx->flag_host && ctx->seq_issued > ctx->seq_waited && !ctx->need_sync) {
       const unsigned long long want = ctx->seq_issued;
       for (long spins = 0; spins < 200000000L; spins++) {
-         if (*ctx->flag_host >= want) return 0;
+         if (*ctx->flag_host >= want) { ctx->seq_waited = want; return 0; }
          __builtin_ia32_pause();
       }
    }
    HIPK_CHECK(hipStreamSynchronize(ctx->stream));
+   ctx->seq_waited = ctx->seq_issued;
+   ctx->need_sync = 0;
    return 0;
 }
 extern "C" int hipk_is_device_ptr(const void *p) {

@@ -34,6 +34,9 @@ struct hipk_ctx {
    unsigned int *fin_counter;                /* device: blocks of the running finalize launch that are done */
    unsigned int *arrive_counter;             /* device: arrival ticket of the in-kernel second stage (fin_counter + 16) */
    unsigned long long seq_issued;            /* sequence number of the last finalize launch with a mirror */
+   unsigned long long seq_waited;            /* the last sequence number hipk_wait_results returned on */
+   int need_sync;                            /* results were produced WITHOUT a flagged launch since the last one (early
+                                                returns, memset paths): the next wait must drain the stream */
    int spin_wait;                            /* 0: always hipStreamSynchronize (HIPK_NO_SPINWAIT) */
    /* HIPK_HOST_TIMING=1 (measurement knob): time the host spends waiting for results, and from the return of
     * a wait to the next fused-residual launch (the part of an outer iteration the device sits idle for) */
@@ -70,7 +73,8 @@ struct hipk_fin_flag { unsigned long long *flag; unsigned int *counter; unsigned
 /* next sequence number for a finalize launch whose output lies in the mirror (else an empty record) */
 static inline hipk_fin_flag hipk_next_flag(hipk_ctx *ctx, const double *out_dev) {
    hipk_fin_flag f = {NULL, NULL, 0};
-   if (ctx->flag_dev && hipk_mirror_of(ctx, out_dev)) { f.flag = ctx->flag_dev; f.counter = ctx->fin_counter; f.seq = ++ctx->seq_issued; }
+   if (ctx->flag_dev && hipk_mirror_of(ctx, out_dev)) { f.flag = ctx->flag_dev; f.counter = ctx->fin_counter; f.seq = ++ctx->seq_issued; ctx->need_sync = 0; }
+   else ctx->need_sync = 1;      /* a reduction whose results the flag does not cover */
    return f;
 }
 /* In-kernel second stage: the workgroup that arrives last adds the per-block partials itself (fixed
@@ -105,6 +109,10 @@ static inline hipk_fin_args hipk_make_fin(hipk_ctx *ctx, double *out_dev, int ki
    return fa;
 }
 void hipk_note_turnaround(hipk_ctx *ctx);
+/* the context a matrix was created under (its uploads and default launches use that stream) */
+hipk_ctx *hipk_csr_ctx(const hipk_csr *A);
+/* hipk_csr_matvec_scaled applies: CSR, the input entries are the matrix' own row slab */
+int hipk_csr_fusable(const hipk_csr *A);
 /* make sure ctx->partials can hold n doubles */
 int hipk_reserve_partials(hipk_ctx *ctx, size_t n);
 /* out[o] = sum_b partials[b*nout + o], deterministic order */

@@ -102,7 +102,7 @@ csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *
 #pragma unroll
          for (int u = 0; u < TILE_PER_LANE; u++) {
             const int q = threadIdx.x + u * HIPK_BLOCK;
-            const int qc = q < nz ? q : nz - 1;
+            const int qc = q < nz ? q : (nz > 0 ? nz - 1 : 0);   /* an all-empty tile reads the padded element */
             v[u] = (double)val[p0 + qc];
             cidx[u] = colind[p0 + qc];
          }
@@ -546,15 +546,30 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
          hipk_malloc(ctx, twin.size() * sizeof(int2), (void **)&A->twin) ||
          hipk_malloc(ctx, (size_t)nrows_local * es, &A->diag))
       return -2;
-   HIPK_CHECK(hipMemcpy(A->rowptr, rowptr_host, (size_t)(nrows_local + 1) * 4, hipMemcpyHostToDevice));
-   HIPK_CHECK(hipMemcpy(A->colind, colind_host, (size_t)nnz * 4, hipMemcpyHostToDevice));
-   HIPK_CHECK(hipMemcpy(A->values, values_host, (size_t)nnz * es, hipMemcpyHostToDevice));
-   HIPK_CHECK(hipMemcpy(A->tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
-   HIPK_CHECK(hipMemcpy(A->tileinfo, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice));
-   HIPK_CHECK(hipMemcpy(A->twin, twin.data(), twin.size() * sizeof(int2), hipMemcpyHostToDevice));
-   HIPK_CHECK(hipMemset((char *)A->colind + (size_t)nnz * 4, 0, 4));
-   HIPK_CHECK(hipMemset((char *)A->values + (size_t)nnz * es, 0, es));
-   HIPK_CHECK(hipMemcpy(A->diag, dg.data(), (size_t)nrows_local * es, hipMemcpyHostToDevice));
+   /* Every upload is ordered on the context's stream (the stream all kernels of this matrix run on), then
+    * drained once: nothing here goes through the NULL stream, which a hipStreamNonBlocking stream is not
+    * ordered against (and hipMemset on it does not even block the host). */
+   {
+      hipStream_t st = ctx->stream;
+      static int legacy = -1;       /* HIPK_LEGACY_UPLOAD=1: the round-2 NULL-stream uploads (repro knob, scripts/halo_repro.py) */
+      if (legacy < 0) legacy = getenv("HIPK_LEGACY_UPLOAD") != NULL;
+      if (legacy) st = NULL;
+#define UP(dst, src, bytes) do { if ((bytes) > 0) HIPK_CHECK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
+      UP(A->rowptr, rowptr_host, (size_t)(nrows_local + 1) * 4);
+      UP(A->colind, colind_host, (size_t)nnz * 4);
+      UP(A->values, values_host, (size_t)nnz * es);
+      UP(A->tiles, tiles.data(), tiles.size() * 4);
+      UP(A->tileinfo, tinfo.data(), tinfo.size() * sizeof(int4));
+      UP(A->twin, twin.data(), twin.size() * sizeof(int2));
+      UP(A->diag, dg.data(), (size_t)nrows_local * es);
+      /* the padded element behind the last nonzero (clamped loads of trailing empty tiles): value 0 and a column
+       * inside the owned slab, so that the gather stays in range with halos too */
+      const int32_t padcol = (int32_t)x0;
+      UP(A->colind + nnz, &padcol, (size_t)4);
+#undef UP
+      HIPK_CHECK(hipMemsetAsync((char *)A->values + (size_t)nnz * es, 0, es, st));
+      HIPK_CHECK(hipStreamSynchronize(st));      /* the host arrays (and the vectors above) may go away now */
+   }
    *out = A;
    return 0;
 }
@@ -707,7 +722,13 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout || !ctx) return -1;
    hipStream_t st = ctx->stream;
    if ((A->halo_lo > 0 && !A->xlo) || (A->halo_hi > 0 && !A->xhi)) return -1;
-   if (A->nrows == 0) { HIPK_CHECK(hipMemsetAsync(dot_dev, 0, sizeof(double), st)); return 0; }
+   if (A->nrows == 0) {      /* an empty slab: the result is 0; no flagged launch, so the next wait drains the stream */
+      HIPK_CHECK(hipMemsetAsync(dot_dev, 0, sizeof(double), st));
+      double *mh = hipk_mirror_of(ctx, dot_dev);
+      if (mh) { HIPK_CHECK(hipStreamSynchronize(st)); *mh = 0.0; }
+      ctx->need_sync = 1;
+      return 0;
+   }
    const int gx = ((A->ntiles + 7) / 8) * 8;
    if (hipk_reserve_partials(ctx, (size_t)gx)) return -2;
    const double es = A->dt == HIPK_F64 ? 8 : 4;
@@ -727,6 +748,8 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    return hipk_finalize_partials(ctx, ctx->partials, gx, 1, dot_dev);
 }
 extern "C" int hipk_csr_kind(const hipk_csr *A) { return A->kind; }
+hipk_ctx *hipk_csr_ctx(const hipk_csr *A) { return A->ctx; }
+int hipk_csr_fusable(const hipk_csr *A) { return A && A->kind == 0 && A->x0 == A->row0 && A->xlen == A->nrows; }      /* library-internal (hipk_internal.h) */
 extern "C" hipk_dtype hipk_csr_dtype(const hipk_csr *A) { return A->dt; }
 extern "C" int64_t hipk_csr_nrows(const hipk_csr *A) { return A->nrows; }
 

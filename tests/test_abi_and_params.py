@@ -111,6 +111,9 @@ def test_library_exports_every_declared_symbol(built):
     exported = {line.split()[-1] for line in syms.splitlines() if line.strip()}
     missing = sorted(d for d in declared if d not in exported)
     assert not missing, missing
+    # ... and nothing but the C ABI: the host solver's internals (pa_*) and the C++ helpers stay local (csrc/exports.map)
+    leaked = sorted(e for e in exported if e.startswith("pa_") or e.startswith("_Z"))
+    assert not leaked, leaked[:10]
     C.CDLL(F.PRODUCT_LIB)   # loads (HIP runtime present in the image even without a GPU)
 
 

@@ -191,3 +191,51 @@ def test_complex_svds_through_the_real_equivalent_form(built, m, n, k, target, m
         assert np.linalg.norm(Z @ r.V - r.U * r.svals) <= 1e-8 * s[0], be
         assert np.linalg.norm(Z.conj().T @ r.U - r.V * r.svals) <= 1e-8 * s[0], be
         assert np.linalg.norm(r.V.conj().T @ r.V - np.eye(k)) <= 1e-8 and np.linalg.norm(r.U.conj().T @ r.U - np.eye(k)) <= 1e-7, be
+
+
+@pytest.mark.parametrize("m,n,k,method", [(300, 200, 5, "normalequations"), (200, 300, 4, "hybrid")])
+def test_host_pointer_svds_entry_points(built, m, n, k, method):
+    """dprimme_svds() with the reference's HOST-pointer contract (csrc/svds_hostapi.c; BASELINE configs[4] is worded
+    with this entry point): host svecs, host callbacks that receive the CALLER's primme_svds_params.  The same
+    program, callbacks included, runs against the live reference's dprimme_svds: same counts, same singular values."""
+    A, (rp, ci, va) = _rect(m, n, seed=3)
+    s = np.linalg.svd(A, compute_uv=False)
+    libs = [("hostcheck", checkers.load_hostcheck())] + ([("reference", checkers.load_reference())] if HAVE_REF else [])
+    out = {}
+    for name, lib in libs:
+        ps = F.PrimmeSvdsParams()
+        lib.primme_svds_initialize(C.byref(ps))
+        seen = {"mv": 0, "user_struct": True}
+
+        def mv(x, ldx, y, ldy, bs, tr, pp, ierr, ps=ps, seen=seen):
+            seen["mv"] += bs[0]
+            seen["user_struct"] &= (C.addressof(pp[0]) == C.addressof(ps))
+            rin, rout = (m, n) if tr[0] else (n, m)
+            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(bs[0], ldx[0]))
+            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(bs[0], ldy[0]))
+            Y[:, :rout] = (A.T @ X[:, :rin].T).T if tr[0] else (A @ X[:, :rin].T).T
+            ierr[0] = 0
+        cmv = F.SVDS_BLOCK_OP(mv)
+        ps.m, ps.n, ps.numSvals, ps.eps, ps.printLevel, ps.outputFile = m, n, k, 1e-10, 0, None
+        ps.target = F.SVDS_TARGETS["largest"]
+        ps.matrixMatvec = C.cast(cmv, C.c_void_p)
+        lib.primme_svds_set_method(F.SVDS_METHODS[method], F.METHODS["GD_plusK"], F.METHODS["GD_plusK"], C.byref(ps))
+        svecs = np.zeros((m + n) * k); svals, rn = np.zeros(k), np.zeros(k)
+        f = lib.dprimme_svds
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(F.PrimmeSvdsParams)]; f.restype = C.c_int
+        ret = f(svals.ctypes.data, svecs.ctypes.data, rn.ctypes.data, C.byref(ps))
+        assert ret == 0 and ps.initSize == k and seen["user_struct"], (name, ret)
+        U = svecs[:m * k].reshape(k, m).T; V = svecs[m * k:].reshape(k, n).T
+        assert np.max(np.abs(svals - s[:k])) <= 1e-10 * s[0]
+        assert np.linalg.norm(A @ V - U * svals) <= 1e-8 * s[0]
+        assert np.linalg.norm(U.T @ U - np.eye(k)) <= 1e-8 and np.linalg.norm(V.T @ V - np.eye(k)) <= 1e-8
+        # stats.numMatvecs is the algorithm's count (the reference's accounting); the device path also applies the
+        # operator speculatively ahead of the host's decision (DESIGN.md section 4): a few of those are discarded
+        assert ps.stats.numMatvecs <= seen["mv"] <= ps.stats.numMatvecs * 1.05 + 2
+        if name == "reference":
+            assert seen["mv"] == ps.stats.numMatvecs
+        assert C.cast(ps.matrixMatvec, C.c_void_p).value == C.cast(cmv, C.c_void_p).value and not ps.queue   # caller's struct intact
+        out[name] = (svals.copy(), ps.stats.numOuterIterations, ps.stats.numMatvecs, ps.stats.numRestarts, seen["mv"])
+    if "reference" in out:
+        assert out["hostcheck"][1:4] == out["reference"][1:4], out
+        assert np.max(np.abs(out["hostcheck"][0] - out["reference"][0])) <= 1e-12 * s[0]
