@@ -208,12 +208,12 @@ def backend_object(backend):
 
 
 class Session(_api.Session):
-    def __init__(self, op, comm=None, dtype=np.float64, backend="hip"):
-        super().__init__(op, comm=comm, dtype=dtype, backend=backend_object(backend))
+    def __init__(self, op, comm=None, dtype=np.float64, backend="hip", complex_form="native"):
+        super().__init__(op, comm=comm, dtype=dtype, backend=backend_object(backend), complex_form=complex_form)
 
 
-def eigsh(op, backend="hip", comm=None, dtype=np.float64, **kw):
-    s = Session(op, comm=comm, dtype=dtype, backend=backend)
+def eigsh(op, backend="hip", comm=None, dtype=np.float64, complex_form="native", **kw):
+    s = Session(op, comm=comm, dtype=dtype, backend=backend, complex_form=complex_form)
     try:
         return s.solve(**kw)
     finally:

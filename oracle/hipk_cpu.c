@@ -33,6 +33,20 @@ static double now(void) {
    return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 static size_t esz(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : dt == HIPK_F32 ? 4 : dt == HIPK_C64 ? 16 : 8; }
+#define IS_Z(dt) ((dt) == HIPK_C64 || (dt) == HIPK_C32)
+/* the complex instantiation: oracle/hipk_cpu_complex.c */
+int hipk_z_panel_dots(hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg, const void *X, int64_t ldX, int nx, double *out, int ldout);
+int hipk_z_panel_project_to(hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg, const double *coef, int ldcoef, const void *X, int64_t ldX, void *Xout, int64_t ldXout, int nx, double *nrm2);
+int hipk_z_panel_project_mul(hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg, const double *coef, int ldcoef, const double *M, void *X, int64_t ldX, int nx);
+int hipk_z_ritz_update(hipk_dtype dt, int64_t m, const void *V, const void *W, int64_t ld, int k, const double *h, int ldh, const double *theta, const hipk_job *jobs, int njobs, double *nrm2);
+int hipk_z_scale_cols(hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx, const double *a);
+int hipk_z_axpy_cols(hipk_dtype dt, int64_t m, const double *a, const void *X, int64_t ldX, void *Y, int64_t ldY, int nx);
+int hipk_z_xpay_cols(hipk_dtype dt, int64_t m, const double *a, const void *X, int64_t ldX, void *Y, int64_t ldY, int nx);
+int hipk_z_col_norms2(hipk_dtype dt, int64_t m, const void *X, int64_t ldX, int nx, double *out);
+int hipk_z_residual_cols(hipk_dtype dt, int64_t m, const void *X, int64_t ldX, void *Wr, int64_t ldW, int nx, const double *theta, double *nrm2);
+int hipk_z_pair_dots(hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *Y, int64_t ldY, int nx, double *out);
+int hipk_z_csr_matvec(hipk_dtype dt, int64_t nrows, const int32_t *rp, const int32_t *ci, const void *val, int64_t x0, int64_t xlen, int64_t halo_lo, const void *xlo, int64_t ld_lo, const void *xhi, int64_t ld_hi, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols, const double *shift);
+int hipk_z_jacobi_apply(hipk_dtype dt, int64_t m, const void *diag, const double *shift, double min_den, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols);
 static double ld_(hipk_dtype dt, const void *p, int64_t i) {
    return dt == HIPK_F64 ? ((const double *)p)[i] : (double)((const float *)p)[i];
 }
@@ -72,7 +86,9 @@ int hipk_memset0(hipk_ctx *c, void *d, size_t b) { (void)c; memset(d, 0, b); ret
 int hipk_sync(hipk_ctx *c) { (void)c; return 0; }
 static double *g_mirror_dev, *g_mirror_host; static size_t g_mirror_n;
 int hipk_ctx_set_mirror(hipk_ctx *c, double *d, double *h, size_t n) { (void)c; g_mirror_dev = d; g_mirror_host = h; g_mirror_n = n; return 0; }
-static void mirror(const double *out, size_t cnt) {   /* keep the zero-copy contract on the host build */
+void hipk_cpu_mirror(const double *out, size_t cnt);
+static void mirror(const double *out, size_t cnt) { hipk_cpu_mirror(out, cnt); }
+void hipk_cpu_mirror(const double *out, size_t cnt) {   /* keep the zero-copy contract on the host build */
    if (g_mirror_dev && out >= g_mirror_dev && out < g_mirror_dev + g_mirror_n && g_mirror_host != g_mirror_dev)
       memmove(g_mirror_host + (out - g_mirror_dev), out, cnt * sizeof(double));
 }
@@ -86,6 +102,7 @@ int hipk_timer_stop(hipk_ctx *c, float *ms) { *ms = (float)((now() - c->t0) * 1e
 int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
       const void *X, int64_t ldX, int nx, double *out, int ldout) {
    (void)ctx; g_cnt[0]++;
+   if (IS_Z(dt)) return hipk_z_panel_dots(dt, m, segs, nseg, X, ldX, nx, out, ldout);
    const int tot = seg_total(segs, nseg);
    for (int c = 0; c < nx; c++) {
       const void *x = colp(dt, X, ldX, c);
@@ -104,6 +121,7 @@ int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *seg
 int hipk_panel_project_to(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
       const double *coef, int ldcoef, const void *X, int64_t ldX, void *Xout, int64_t ldXout, int nx, double *nrm2) {
    (void)ctx; g_cnt[1]++;
+   if (IS_Z(dt)) return hipk_z_panel_project_to(dt, m, segs, nseg, coef, ldcoef, X, ldX, Xout, ldXout, nx, nrm2);
    const int tot = seg_total(segs, nseg);
    for (int c = 0; c < nx; c++) {
       const void *x = colp(dt, X, ldX, c);
@@ -129,6 +147,7 @@ int hipk_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *
 int hipk_panel_project_mul(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
       const double *coef, int ldcoef, const double *M, void *X, int64_t ldX, int nx) {
    (void)ctx;
+   if (IS_Z(dt)) return hipk_z_panel_project_mul(dt, m, segs, nseg, coef, ldcoef, M, X, ldX, nx);
    if (nx <= 0) return 0;
    if (nx > 8) return 1;
    const int tot = seg_total(segs, nseg);
@@ -150,6 +169,7 @@ int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, con
       int64_t ld, int k, const double *h, int ldh, const double *theta, const hipk_job *jobs,
       int njobs, double *nrm2) {
    (void)ctx; g_cnt[2]++;
+   if (IS_Z(dt)) return hipk_z_ritz_update(dt, m, V, W, ld, k, h, ldh, theta, jobs, njobs, nrm2);
    if (k <= 0 || njobs <= 0) return 0;
    double *vr = malloc((size_t)k * 8), *wr = malloc((size_t)k * 8), *outv = malloc((size_t)njobs * 8);
    for (int q = 0; q < njobs; q++) if (jobs[q].kind == HIPK_JOB_RES && jobs[q].slot >= 0) nrm2[jobs[q].slot] = 0.0;
@@ -246,6 +266,7 @@ int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
 
 int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx, const double *a) {
    (void)ctx;
+   if (IS_Z(dt)) return hipk_z_scale_cols(dt, m, X, ldX, nx, a);
    for (int c = 0; c < nx; c++) { void *x = (void *)colp(dt, X, ldX, c); for (int64_t i = 0; i < m; i++) st_(dt, x, i, a[c] * ld_(dt, x, i)); }
    return 0;
 }
@@ -258,6 +279,7 @@ int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, 
 int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *a, const void *X, int64_t ldX,
       void *Y, int64_t ldY, int nx) {
    (void)ctx;
+   if (IS_Z(dt)) return hipk_z_axpy_cols(dt, m, a, X, ldX, Y, ldY, nx);
    for (int c = 0; c < nx; c++) {
       const void *x = colp(dt, X, ldX, c); void *y = (void *)colp(dt, Y, ldY, c);
       for (int64_t i = 0; i < m; i++) st_(dt, y, i, a[c] * ld_(dt, x, i) + ld_(dt, y, i));
@@ -290,6 +312,7 @@ int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int
 }
 int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, int nx, double *out) {
    (void)ctx;
+   if (IS_Z(dt)) return hipk_z_col_norms2(dt, m, X, ldX, nx, out);
    for (int c = 0; c < nx; c++) { const void *x = colp(dt, X, ldX, c); double s = 0; for (int64_t i = 0; i < m; i++) s += ld_(dt, x, i) * ld_(dt, x, i); out[c] = s; }
    mirror(out, nx);
    return 0;
@@ -297,6 +320,7 @@ int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int6
 int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, void *Wr, int64_t ldW,
       int nx, const double *theta, double *nrm2) {
    (void)ctx;
+   if (IS_Z(dt)) return hipk_z_residual_cols(dt, m, X, ldX, Wr, ldW, nx, theta, nrm2);
    for (int c = 0; c < nx; c++) {
       const void *x = colp(dt, X, ldX, c); void *w = (void *)colp(dt, Wr, ldW, c);
       double s = 0;
@@ -310,6 +334,7 @@ int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, i
 int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *Y, int64_t ldY,
       int nx, double *out) {
    (void)ctx;
+   if (IS_Z(dt)) return hipk_z_pair_dots(dt, m, X, ldX, Y, ldY, nx, out);
    for (int c = 0; c < nx; c++) {
       const void *x = colp(dt, X, ldX, c), *y = colp(dt, Y, ldY, c);
       double s = 0; for (int64_t i = 0; i < m; i++) s += ld_(dt, x, i) * ld_(dt, y, i);
@@ -321,6 +346,7 @@ int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64
 int hipk_xpay_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *a, const void *X, int64_t ldX,
       void *Y, int64_t ldY, int nx) {
    (void)ctx;
+   if (IS_Z(dt)) return hipk_z_xpay_cols(dt, m, a, X, ldX, Y, ldY, nx);
    for (int c = 0; c < nx; c++) {
       const void *x = colp(dt, X, ldX, c); void *y = (void *)colp(dt, Y, ldY, c);
       for (int64_t i = 0; i < m; i++) st_(dt, y, i, a[c] * ld_(dt, y, i) + ld_(dt, x, i));
@@ -375,7 +401,7 @@ static int csr_create_impl(hipk_dtype dt, int64_t nr, int64_t nc, int64_t row0, 
          int64_t g = ci[p];
          if (g < x0 && x0 - g > A->halo_lo) A->halo_lo = x0 - g;
          if (g >= x0 + xlen && g - (x0 + xlen) + 1 > A->halo_hi) A->halo_hi = g - (x0 + xlen) + 1;
-         if (g == row0 + i) st_(dt, A->diag, i, ld_(dt, val, p));
+         if (g == row0 + i) { if (IS_Z(dt)) memcpy((char *)A->diag + (size_t)i * esz(dt), (const char *)val + (size_t)p * esz(dt), esz(dt)); else st_(dt, A->diag, i, ld_(dt, val, p)); }
       }
    *out = A;
    return 0;
@@ -421,6 +447,7 @@ int64_t hipk_csr_nrows(const hipk_csr *A) { return A->nrows; }
 int hipk_csr_matvec(hipk_csr *A, void *stream, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols) {
    (void)stream;
    const hipk_dtype dt = A->dt;
+   if (IS_Z(dt)) return A->kind == 0 ? hipk_z_csr_matvec(dt, A->nrows, A->rowptr, A->colind, A->values, A->x0, A->xlen, A->halo_lo, A->xlo, A->ld_lo, A->xhi, A->ld_hi, x, ldx, y, ldy, ncols, NULL) : -44;
    for (int c = 0; c < ncols; c++) {
       const void *xc = colp(dt, x, ldx, c);
       const void *lo = A->xlo ? (const char *)A->xlo + (size_t)c * A->ld_lo * esz(dt) : NULL;
@@ -456,6 +483,7 @@ int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x, const doub
    (void)ctx; g_cnt[5]++;
    if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout) return -1;
    const hipk_dtype dt = A->dt;
+   if (IS_Z(dt)) return -44;
    const double a = norm2 ? 1.0 / sqrt(norm2[0]) : 1.0;
    double d = 0.0;
    for (int64_t i = 0; i < A->nrows; i++) {
@@ -511,6 +539,7 @@ int hipk_csr_matvec_shifted(hipk_csr *A, void *stream, const void *x, int64_t ld
       const double *shift) {
    if (ncols <= 0 || A->nrows == 0) return 0;
    if (A->kind != 0 || A->halo_lo != 0 || A->halo_hi != 0 || A->x0 != A->row0 || A->xlen != A->nrows || ncols > 64 || !shift) return 1;
+   if (IS_Z(A->dt)) return hipk_z_csr_matvec(A->dt, A->nrows, A->rowptr, A->colind, A->values, A->x0, A->xlen, 0, NULL, 0, NULL, 0, x, ldx, y, ldy, ncols, shift);
    int rc = hipk_csr_matvec(A, stream, x, ldx, y, ldy, ncols);
    for (int c = 0; c < ncols && !rc; c++)
       for (int64_t i = 0; i < A->nrows; i++)
@@ -545,6 +574,7 @@ int hipk_jacobi_apply(void *stream, hipk_dtype dt, int64_t m, const void *diag, 
       double min_den, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols) {
    (void)stream;
    if (!(min_den > 0.0)) min_den = 1e-300;
+   if (IS_Z(dt)) return hipk_z_jacobi_apply(dt, m, diag, shift, min_den, x, ldx, y, ldy, ncols);
    for (int c = 0; c < ncols; c++) {
       const void *xc = colp(dt, x, ldx, c); void *yc = (void *)colp(dt, y, ldy, c);
       for (int64_t i = 0; i < m; i++) {

@@ -85,7 +85,7 @@ def _resolve_backend(backend):
 
 
 class Session:
-    def __init__(self, op, comm=None, dtype=np.float64, backend="hip"):
+    def __init__(self, op, comm=None, dtype=np.float64, backend="hip", complex_form="native"):
         self.op, self.comm = op, comm
         self.be = _resolve_backend(backend)
         self.backend = self.be.name
@@ -110,7 +110,16 @@ class Session:
             rp, ci, va = op.csr
             rp = np.ascontiguousarray(rp, dtype=np.int32)
             ci = np.ascontiguousarray(ci, dtype=np.int32)
-            if self.cplx:
+            self.real_form = self.cplx and complex_form != "native"
+            if self.cplx and not self.real_form:
+                # a complex CSR matrix on the device: hip_zprimme / hip_cprimme run natively on complex panels
+                vz = np.ascontiguousarray(va, dtype=self.dtype)
+                cdt = F.HIPK_C64 if self.dtype == np.complex128 else F.HIPK_C32
+                rc = lib.hipk_csr_create(ctx, cdt, op.nrows, op.n, op.row0, rp.ctypes.data_as(C.c_void_p),
+                                         ci.ctypes.data_as(C.c_void_p), vz.ctypes.data_as(C.c_void_p), C.byref(A))
+            elif self.cplx:
+                # the real-equivalent 2n x 2n expansion (csrc/eigs_complex.c): what extractions / methods without
+                # complex objects fall back to
                 vz = np.ascontiguousarray(va, dtype=np.complex128)
                 rp2, ci2, va2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
                 rc = lib.primme_amd_csr_complex_to_real(op.nrows, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
@@ -135,7 +144,7 @@ class Session:
         if lib.primme_amd_operator_create(C.byref(oph), A, comm):
             raise RuntimeError("operator handle creation failed")
         self.handles.append(("op", oph))
-        if self.cplx: lib.primme_amd_operator_set_complex(oph, 1)
+        if self.cplx and self.real_form: lib.primme_amd_operator_set_complex(oph, 1)
         self.oph = oph
 
     def close(self):
@@ -274,14 +283,14 @@ class Session:
         return Result(ret, evals, None if evecs is None else evecs[nOC:nOC + numEvals].T.copy(), resNorms, p)
 
 
-def eigsh(op, backend="hip", comm=None, dtype=np.float64, **kw):
+def eigsh(op, backend="hip", comm=None, dtype=np.float64, complex_form="native", **kw):
     """One-shot: compute a few eigenpairs of the symmetric operator `op` (see Session.solve).
 
     v0: optional (nLocal x initSize) initial guesses -> initBasisMode defaults to
     primme_init_user so that no random numbers enter (parity runs).
     precond: None | "jacobi" (Davidson: per-vector shifts) | ("jacobi", shift) (fixed shift).
     """
-    s = Session(op, comm=comm, dtype=dtype, backend=backend)
+    s = Session(op, comm=comm, dtype=dtype, backend=backend, complex_form=complex_form)
     try:
         return s.solve(**kw)
     finally:

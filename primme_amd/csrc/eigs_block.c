@@ -22,13 +22,13 @@
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
 
 /* number of consecutive linearly independent columns judged from the Gram matrix G (upper) */
-static int rank_estimation(const double *G, int n0, int n1, int n, int ldG) {
+static int rank_estimation(const HS *G, int n0, int n1, int n, int ldG) {
    int i, j;
    for (i = n0; i < n1; i++) {
-      const double Gii = G[i + (size_t)i * ldG];
+      const double Gii = HS_RE(G[i + (size_t)i * ldG]);
       if (!isfinite(Gii) || Gii <= 0.0) break;
       for (j = 0; j < i; j++)
-         if (fabs(G[j + (size_t)i * ldG]) > .8 / n * sqrt(Gii * G[j + (size_t)j * ldG])) break;
+         if (HS_ABS(G[j + (size_t)i * ldG]) > .8 / n * sqrt(Gii * HS_RE(G[j + (size_t)j * ldG]))) break;
       if (j < i) break;
    }
    return i;
@@ -36,7 +36,7 @@ static int rank_estimation(const double *G, int n0, int n1, int n, int ldG) {
 
 /* Y = chol(C) (upper, Yortho = 0, D = 1) or, if C is not numerically SPD, the eigenvectors
  * with eigenvalues D in non-increasing order (Yortho = 1).  C upper, n x n, ld n. */
-static int decomposition(const double *Cm, int n, double *Y, double *D, int *Yortho) {
+static int decomposition(const HS *Cm, int n, HS *Y, double *D, int *Yortho) {
    for (int j = 0; j < n; j++)
       for (int i = 0; i < n; i++) Y[i + (size_t)j * n] = (i <= j) ? Cm[i + (size_t)j * n] : 0.0;
    if (pa_potrf_upper(n, Y, n) == 0) {
@@ -44,7 +44,7 @@ static int decomposition(const double *Cm, int n, double *Y, double *D, int *Yor
       for (int i = 0; i < n; i++) D[i] = 1.0;
       return 0;
    }
-   double *neg = (double *)malloc((size_t)n * n * sizeof(double));
+   HS *neg = (HS *)malloc((size_t)n * n * sizeof(HS));
    if (!neg) return PRIMME_MALLOC_FAILURE;
    for (int j = 0; j < n; j++)
       for (int i = 0; i < n; i++) neg[i + (size_t)j * n] = (i <= j) ? -Cm[i + (size_t)j * n] : 0.0;
@@ -57,22 +57,22 @@ static int decomposition(const double *Cm, int n, double *Y, double *D, int *Yor
 }
 
 /* fG(:, n0:n) <- Cholesky update given the new columns G(:, n0:n) */
-int pa_update_cholesky(const double *G, int ldG, double *fG, int ldfG, int n0, int n) {
+int pa_update_cholesky(const HS *G, int ldG, HS *fG, int ldfG, int n0, int n) {
    if (n <= n0) return 0;
    const int nc = n - n0;
-   double *A = (double *)malloc((size_t)n * nc * sizeof(double));
+   HS *A = (HS *)malloc((size_t)n * nc * sizeof(HS));
    if (!A) return PRIMME_MALLOC_FAILURE;
    for (int c = 0; c < nc; c++)
       for (int i = 0; i < n; i++) A[i + (size_t)c * n] = (i <= n0 + c) ? G[i + (size_t)(n0 + c) * ldG] : 0.0;
    pa_trsm_left_upper_trans(n0, nc, fG, ldfG, A, n);
    for (int c = 0; c < nc; c++)
       for (int r = 0; r <= c; r++) {
-         double t = 0.0;
-         for (int i = 0; i < n0; i++) t += A[i + (size_t)r * n] * A[i + (size_t)c * n];
+         HS t = 0.0;
+         for (int i = 0; i < n0; i++) t += HS_CONJ(A[i + (size_t)r * n]) * A[i + (size_t)c * n];
          A[n0 + r + (size_t)c * n] -= t;
       }
    /* Cholesky of the trailing block (upper part stored at rows n0.. of A) */
-   double *T = (double *)malloc((size_t)nc * nc * sizeof(double));
+   HS *T = (HS *)malloc((size_t)nc * nc * sizeof(HS));
    for (int c = 0; c < nc; c++)
       for (int r = 0; r < nc; r++) T[r + (size_t)c * nc] = (r <= c) ? A[n0 + r + (size_t)c * n] : 0.0;
    (void)pa_potrf_upper(nc, T, nc);   /* like the reference, a failure shows up later in rank estimation */
@@ -86,12 +86,12 @@ int pa_update_cholesky(const double *G, int ldG, double *fG, int ldfG, int n0, i
 }
 
 /* X(:, 0:nX) <- X * M (M nX x nX on the host), in place, one pass over X */
-static int right_multiply(pa_solver *s, char *X, int64_t ldX, int nX, const double *M) {
+static int right_multiply(pa_solver *s, char *X, int64_t ldX, int nX, const HS *M) {
    /* M travels tightly packed (leading dimension nX): the block can be wider than maxBasisSize
     * (numOrthoConst > maxBasisSize in init_basis), the coefficient buffers hold max(K, numOrthoConst)^2 */
    if ((size_t)nX * nX > s->coef_cap) return PRIMME_UNEXPECTED_FAILURE;
-   memcpy(s->h_coef, M, (size_t)nX * nX * sizeof(double));
-   CHK(hipk_h2d(s->ctx, s->d_coef, s->h_coef, (size_t)nX * nX * sizeof(double)));
+   memcpy(s->h_coef, M, (size_t)nX * nX * sizeof(HS));
+   CHK(hipk_h2d(s->ctx, s->d_coef, s->h_coef, (size_t)nX * nX * sizeof(HS)));
    s->coef_valid_k = -1;
    hipk_job jobs[HIPK_MAX_JOBS];
    /* wider than one launch's job table: column chunks read the whole row first, so they would see
@@ -105,9 +105,9 @@ static int right_multiply(pa_solver *s, char *X, int64_t ldX, int nX, const doub
 /* Orthonormalise Vp(:, b1..b2) against locked (numLocked columns), Vp(:, 0..b1) and among
  * themselves, maintaining s->VtBV / s->fVtBV (indexing: locked columns first, then Vp's). */
 int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
-      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int maxRank, int *b2_out) {
+      int64_t ldLocked, int numLocked, HS *RLocked, int ldRLocked, int maxRank, int *b2_out) {
    primme_params *p = s->p;
-   double *G = s->VtBV, *fG = s->fVtBV;
+   HS *G = s->VtBV, *fG = s->fVtBV;
    const int ldG = s->ldVtBV;
    b2++;                                  /* exclusive upper end */
    if (b2 <= b1) { *b2_out = b2; return 0; }
@@ -116,19 +116,20 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
    double t0 = pa_wtime();
    char *X = PCOL(s, Vp, ldV, b1);
 
-   double *A = G + (size_t)(b1 + numLocked) * ldG;      /* new columns of the Gram matrix */
-   double *r = NULL;
+   HS *A = G + (size_t)(b1 + numLocked) * ldG;      /* new columns of the Gram matrix */
+   HS *r = NULL;
    if (RLocked) {
       for (int c = 0; c < nX; c++) for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)c * ldRLocked] = 0.0;
-      r = (double *)calloc((size_t)nX * nX, sizeof(double));
+      r = (HS *)calloc((size_t)nX * nX, sizeof(HS));
       for (int i = 0; i < nX; i++) r[i + (size_t)i * nX] = 1.0;
    }
    double *D = (double *)malloc((size_t)nX * sizeof(double)), *N = (double *)malloc((size_t)nX * sizeof(double));
-   double *GdA = (double *)malloc((size_t)(nVL > 0 ? nVL : 1) * nX * sizeof(double));
-   double *Y = (double *)malloc((size_t)nX * nX * sizeof(double)), *Cm = (double *)malloc((size_t)nX * nX * sizeof(double));
-   double *M = (double *)malloc((size_t)nX * nX * sizeof(double));
+   HS *GdA = (HS *)malloc((size_t)(nVL > 0 ? nVL : 1) * nX * sizeof(HS));
+   HS *Y = (HS *)malloc((size_t)nX * nX * sizeof(HS)), *Cm = (HS *)malloc((size_t)nX * nX * sizeof(HS));
+   HS *M = (HS *)malloc((size_t)nX * nX * sizeof(HS));
    if (!D || !N || !GdA || !Y || !Cm || !M) return PRIMME_MALLOC_FAILURE;
    int rc = 0;
+   /* (red_cap counts scalars: the buffers hold twice as many doubles as that, enough for complex entries) */
    if ((size_t)nrowsA * nX > (size_t)s->red_cap || (size_t)nVL * nX > (size_t)s->red_cap || nrowsA > ldG) {
       free(r); free(D); free(N); free(GdA); free(Y); free(Cm); free(M);
       return PRIMME_UNEXPECTED_FAILURE;
@@ -154,17 +155,17 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
          const size_t ncoef = (size_t)nVL * nX, nM = (size_t)nX * nX;
          int fused = 0;
          if (nX <= 8 && ncoef + nM <= (size_t)s->red_cap) {
-            memcpy(s->h_red, GdA, ncoef * sizeof(double));
-            memcpy(s->h_red + ncoef, M, nM * sizeof(double));
-            CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, (ncoef + nM) * sizeof(double)));
-            int rcf = hipk_panel_project_mul(s->ctx, s->dt, s->m, segs, 2, s->d_red, nVL > 0 ? nVL : 1, s->d_red + ncoef, X, ldV, nX);
+            memcpy(s->h_red, GdA, ncoef * sizeof(HS));
+            memcpy((HS *)s->h_red + ncoef, M, nM * sizeof(HS));
+            CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, (ncoef + nM) * sizeof(HS)));
+            int rcf = hipk_panel_project_mul(s->ctx, s->dt, s->m, segs, 2, s->d_red, nVL > 0 ? nVL : 1, s->d_red + SD * ncoef, X, ldV, nX);
             if (rcf < 0) return rcf;
             fused = (rcf == 0);
          }
          if (!fused) {
             if (nVL > 0) {
-               memcpy(s->h_red, GdA, ncoef * sizeof(double));
-               CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, ncoef * sizeof(double)));
+               memcpy(s->h_red, GdA, ncoef * sizeof(HS));
+               CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, ncoef * sizeof(HS)));
                CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 2, s->d_red, nVL, X, ldV, nX, NULL));
             }
             CHK(right_multiply(s, X, ldV, nX, M));
@@ -172,22 +173,22 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
       }
       /* A = [Q V(0:b2)]' X */
       CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segsA, 2, X, ldV, nX, s->d_red, nrowsA));
-      CHK(pa_reduce(s, s->d_red, nrowsA * nX, 0, 0));
+      CHK(pa_reduce(s, s->d_red, SD * nrowsA * nX, 0, 0));
       for (int c = 0; c < nX; c++)
-         for (int i = 0; i < nrowsA; i++) A[i + (size_t)c * ldG] = s->h_red[i + (size_t)c * nrowsA];
+         for (int i = 0; i < nrowsA; i++) A[i + (size_t)c * ldG] = ((const HS *)s->h_red)[i + (size_t)c * nrowsA];
       p->stats.numOrthoInnerProds += (double)(numLocked + b1) * nX + (double)((nX + 1) / 2) * nX;
 
       if (rank_estimation(G, numLocked + b1, numLocked + b2, maxRank, ldG) == numLocked + b2) {
          if (its >= plus1) {
             int i;
-            for (i = b1; i < b2 && fabs(G[(numLocked + i) + (size_t)(numLocked + i) * ldG] - 1.0) < .8; i++) ;
+            for (i = b1; i < b2 && HS_ABS(G[(numLocked + i) + (size_t)(numLocked + i) * ldG] - 1.0) < .8; i++) ;
             if (i >= b2) break;
          } else plus1 = PA_MIN(its + 1, plus1);
       }
 
       /* overflowing norms: keep only the diagonal */
       for (int i = 0; i < nX; i++) {
-         if (A[i + (size_t)i * ldG] < DBL_MAX) continue;   /* index as in the reference (ortho.c:671) */
+         if (HS_RE(A[i + (size_t)i * ldG]) < DBL_MAX) continue;   /* index as in the reference (ortho.c:671) */
          for (int j = 0; j < numLocked + i; j++) G[j + (size_t)(numLocked + i) * ldG] = 0.0;
          A[i + (size_t)i * ldG] = DBL_MAX;
       }
@@ -200,12 +201,12 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
       pa_trsm_left_upper_trans(nVL, nX, fG, s->ldVtBV, GdA, nVL);
       for (int c = 0; c < nX; c++)
          for (int rr = 0; rr < nX; rr++) {
-            double t = 0.0;
-            for (int i = 0; i < nVL; i++) t += GdA[i + (size_t)rr * nVL] * GdA[i + (size_t)c * nVL];
+            HS t = 0.0;
+            for (int i = 0; i < nVL; i++) t += HS_CONJ(GdA[i + (size_t)rr * nVL]) * GdA[i + (size_t)c * nVL];
             Cm[rr + (size_t)c * nX] -= t;
          }
       pa_trsm_left_upper(nVL, nX, fG, s->ldVtBV, GdA, nVL);
-      for (int i = 0; i < nX; i++) N[i] = sqrt(PA_MAX(fabs(Cm[i + (size_t)i * nX]), eps_orth));
+      for (int i = 0; i < nX; i++) N[i] = sqrt(PA_MAX(HS_ABS(Cm[i + (size_t)i * nX]), eps_orth));
       for (int i = 0; i < nX; i++)
          for (int j = 0; j <= i; j++) Cm[j + (size_t)i * nX] /= N[i] * N[j];
       if ((rc = decomposition(Cm, nX, Y, D, &Yortho))) break;
@@ -215,15 +216,15 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
          /* RLocked += GdA(0:numLocked,:) * r;  r <- D .* (Y' or Y) * (N .* r) */
          for (int c = 0; c < nX; c++)
             for (int j = 0; j < numLocked; j++) {
-               double t = 0.0;
+               HS t = 0.0;
                for (int q = 0; q < nX; q++) t += GdA[j + (size_t)q * nVL] * r[q + (size_t)c * nX];
                RLocked[j + (size_t)c * ldRLocked] += t;
             }
          for (int c = 0; c < nX; c++) for (int j = 0; j < nX; j++) r[j + (size_t)c * nX] *= N[j];
          for (int c = 0; c < nX; c++)
             for (int i = 0; i < nX; i++) {
-               double t = 0.0;
-               if (Yortho) { for (int q = 0; q < nX; q++) t += Y[q + (size_t)i * nX] * r[q + (size_t)c * nX]; }
+               HS t = 0.0;
+               if (Yortho) { for (int q = 0; q < nX; q++) t += HS_CONJ(Y[q + (size_t)i * nX]) * r[q + (size_t)c * nX]; }
                else { for (int q = i; q < nX; q++) t += Y[i + (size_t)q * nX] * r[q + (size_t)c * nX]; }
                Cm[i + (size_t)c * nX] = t;
             }

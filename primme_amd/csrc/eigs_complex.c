@@ -28,9 +28,39 @@
 #include <string.h>
 #include "primme_amd.h"
 #include "primme_amd_kernels.h"
+#include "primme_amd_comm.h"
 #include "eigs_internal.h"
 
 int pa_eigs_solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double);
+/* the complex instantiation of the host solver (eigs_main_z.c and friends, eigs_scalar.h) */
+int pa_eigs_solve_z(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double);
+
+/* NATIVE path: complex panels, complex Hermitian projected problem, the reference's zprimme iteration for iteration.
+ * Covers Rayleigh-Ritz extraction with the Generalized-Davidson family (GD, GD+k, Olsen variants, LOBPCG-like
+ * presets; locking and soft locking; any block size), which includes the default method and BASELINE configs[3].
+ * Harmonic / refined extraction, the JDQMR inner solver and the dynamic method have no complex objects yet: those
+ * requests (and the library's operator when it was built on the real-equivalent CSR expansion) take the
+ * real-equivalent form below.  PRIMME_AMD_COMPLEX_REAL_FORM=1 forces the latter (A/B measurements). */
+static int native_complex_ok(const primme_params *primme) {
+   if (getenv("PRIMME_AMD_COMPLEX_REAL_FORM")) return 0;
+   primme_params t = *primme;
+   if (t.numProcs <= 1) { t.nLocal = t.n; t.procID = 0; }
+   primme_set_defaults(&t);
+   if (t.projectionParams.projection != primme_proj_RR) return 0;
+   if (t.correctionParams.maxInnerIterations != 0 || t.dynamicMethodSwitch > 0) return 0;
+   if (primme->matrixMatvec == primme_amd_matvec) {
+      /* the library's operator: native only over a complex CSR matrix */
+      if (!primme->matrix) return 0;
+      const hipk_dtype odt = hipk_csr_dtype(primme_amd_operator_matrix((primme_amd_operator *)primme->matrix));
+      if (odt != HIPK_C64 && odt != HIPK_C32) return 0;
+   }
+   if (primme->applyPreconditioner == primme_amd_jacobi_precond) {
+      if (!primme->preconditioner) return 0;
+      const hipk_dtype odt = hipk_csr_dtype(primme_amd_operator_matrix((primme_amd_operator *)primme->preconditioner));
+      if (odt != HIPK_C64 && odt != HIPK_C32) return 0;
+   }
+   return 1;
+}
 
 typedef struct {
    primme_params *user;   /* the caller's struct: what its callbacks expect to receive */
@@ -143,6 +173,9 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
    if (!resNorms_out) return -32;
    if (!primme->matrixMatvec) return -6;
    if (primme->n < 0 || primme->numEvals < 0 || primme->numEvals > primme->n) return primme->n < 0 ? -5 : -11;
+
+   if (native_complex_ok(primme))
+      return pa_eigs_solve_z(evals_out, evecs, resNorms_out, primme, dtr == HIPK_F64 ? HIPK_C64 : HIPK_C32, 0);
 
    cplx_side *sd = (cplx_side *)calloc(1, sizeof(cplx_side));
    if (!sd) return PRIMME_MALLOC_FAILURE;

@@ -18,6 +18,7 @@ int pa_ritz_update(pa_solver *s, int basisSize, const hipk_job *jobs, int njobs,
       int nslots, int64_t flop_cols);
 int pa_push_coefficients(pa_solver *s, int basisSize, int ldh);
 
+#if !PA_IS_COMPLEX
 /* default convTestFun (reference src/eigs/primme_c.c:555-570) */
 void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv,
       primme_params *p, int *ierr) {
@@ -27,6 +28,10 @@ void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv,
    *isConv = *rNorm < PA_MAX(p->eps, meps * 2) * pa_problem_norm(0, p);
    *ierr = 0;
 }
+
+#else
+void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv, primme_params *p, int *ierr);
+#endif
 
 static int call_conv_test(pa_solver *s, double eval, void *evec, double rnorm, int *isconv) {
    primme_params *p = s->p;
@@ -46,10 +51,10 @@ int pa_project_once(pa_solver *s, char *Q, int64_t ldQ, int nQ, char *X, int64_t
       char *x = PCOL(s, X, ldX, inX ? inX[c] : c);
       hipk_seg seg = {Q, ldQ, nQ};
       CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, x, ldX, 1, s->d_red, nQ));
-      CHK(pa_reduce(s, s->d_red, nQ, 1, (s->parallel && !s->dev_comm) ? 0 : 1));
-      CHK(hipk_panel_project(s->ctx, s->dt, s->m, &seg, 1, s->d_red, nQ, x, ldX, 1, s->d_red + nQ));
-      CHK(pa_reduce(s, s->d_red + nQ, 1, 0, 0));
-      if (norms) norms[c] = sqrt(s->h_red[nQ]);
+      CHK(pa_reduce(s, s->d_red, SD * nQ, 1, (s->parallel && !s->dev_comm) ? 0 : 1));
+      CHK(hipk_panel_project(s->ctx, s->dt, s->m, &seg, 1, s->d_red, nQ, x, ldX, 1, s->d_red + SD * nQ));
+      CHK(pa_reduce(s, s->d_red + SD * nQ, 1, 0, 0));
+      if (norms) norms[c] = sqrt(s->h_red[SD * nQ]);
       p->stats.numOrthoInnerProds += nQ + 1;
    }
    p->stats.timeOrtho += pa_wtime() - t0;
@@ -113,25 +118,25 @@ int pa_check_convergence(pa_solver *s, char *X, int64_t ldX, int givenX, char *R
 }
 
 /* p[i] = column of Vp (m x nV) closest in angle to column i of Wn (m x n), i in [n0,n) */
-void pa_map_vecs(const double *Vp, int mrows, int nV, int ldV, const double *Wn, int n0, int n,
+void pa_map_vecs(const HS *Vp, int mrows, int nV, int ldV, const HS *Wn, int n0, int n,
       int ldW, int *pm) {
    double *vn = (double *)malloc((size_t)(nV > 0 ? nV : 1) * sizeof(double));
-   double *ip = (double *)malloc((size_t)(nV > 0 ? nV : 1) * sizeof(double));
+   HS *ip = (HS *)malloc((size_t)(nV > 0 ? nV : 1) * sizeof(HS));
    for (int j = 0; j < nV; j++) {
       double t = 0;
-      for (int r = 0; r < mrows; r++) t += Vp[r + (size_t)j * ldV] * Vp[r + (size_t)j * ldV];
+      for (int r = 0; r < mrows; r++) t += HS_ABS2(Vp[r + (size_t)j * ldV]);
       vn[j] = sqrt(t);
    }
    for (int i = n0; i < n; i++) {
       for (int j = 0; j < nV; j++) {
-         double t = 0;
-         for (int r = 0; r < mrows; r++) t += Vp[r + (size_t)j * ldV] * Wn[r + (size_t)i * ldW];
+         HS t = 0;
+         for (int r = 0; r < mrows; r++) t += HS_CONJ(Vp[r + (size_t)j * ldV]) * Wn[r + (size_t)i * ldW];
          ip[j] = t;
       }
       int jmax = -1;
       double ipmax = -1;
       for (int j = 0; j < nV; j++) {
-         double ipij = fabs(ip[j]);
+         double ipij = HS_ABS(ip[j]);
          if (ipij > ipmax * vn[j]) {
             int k;
             for (k = 0; k < i && pm[k] != j; k++) ;
@@ -147,6 +152,11 @@ void pa_map_vecs(const double *Vp, int mrows, int nV, int ldV, const double *Wn,
    free(ip);
 }
 
+#if PA_IS_COMPLEX
+void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags, int *iblock,
+      int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
+      int *lockedFlags, double *lockedNorms, primme_event event);
+#else
 void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags, int *iblock,
       int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
       int *lockedFlags, double *lockedNorms, primme_event event) {
@@ -175,6 +185,7 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
          lockedEvals, numLocked, lockedFlags, lockedNorms, event);
 }
 
+/* (the fused block-size-1 paths below are real-arithmetic code: not in the complex objects) */
 /* the library's own operator can run the one-launch tail (scale + A t + t'At) on this solver's panels */
 int pa_svds_can_fuse(const primme_params *primme);
 int pa_svds_apply_scaled(primme_params *primme, hipk_ctx *ctx, const void *t, const double *norm2_dev, void *xout, void *y,
@@ -350,6 +361,8 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
    return 0;
 }
 
+#endif   /* !PA_IS_COMPLEX */
+
 /* Put the first unconverged Ritz pairs in the block, computing X, R and the
  * residual norms for them; flag converged pairs on the way. */
 int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arbitraryVecs, double smallestResNorm,
@@ -367,7 +380,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
    /* fused GD mode: the residual IS the correction, so it is produced directly in the V
     * slot of the new basis vector and the Ritz vector X is never materialised (the reference
     * writes X and R and then copies R over X, correction.c:378 with no preconditioner) */
-   const int fused = s->fuse_gd && computeXR;
+   const int fused = !PA_IS_COMPLEX && s->fuse_gd && computeXR;
    if (fused) { R = X; X = NULL; }
    /* overlaps (and the speculative tail) carried over a restart stay valid if the one candidate the restart
     * left is still the block when this call returns */
@@ -453,7 +466,9 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
 
       /* X = V h, R = W h - X theta, norms — one fused pass over V and W */
       const int nLk = p->numOrthoConst + numLocked;
+      (void)nLk;
       relaunched = 1;
+#if !PA_IS_COMPLEX
       if (fused && p->maxBlockSize == 1 && blockNormsSize == 1 && basisSize <= 32 && nLk <= 32) {
          /* block size 1, GD without preconditioner: the residual is the next basis vector, so
           * the same pass also delivers the first Gram-Schmidt pass' overlaps [V'r | Q'r | r'r] */
@@ -532,7 +547,9 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          p->stats.timeDense += pa_wtime() - t0;
          p->stats.flopsDense += (double)s->m * 2.0 * basisSize;
          }
-      } else {
+      } else
+#endif
+      {
          s->fov_valid = 0;
          if ((rc = pa_push_coefficients(s, basisSize, ldh))) goto out;
          int nj = 0;

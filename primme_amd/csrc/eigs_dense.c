@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#if !PA_IS_COMPLEX
 /* A: n x n, column-major, leading dim lda, symmetric, UPPER triangle referenced.
  * On exit evals[0..n) ascending and Z (ldz) the orthonormal eigenvectors. */
 int pa_sym_eig(int n, const double *A, int lda, double *evals, double *Z, int ldz) {
@@ -146,18 +147,146 @@ int pa_sym_eig(int n, const double *A, int lda, double *evals, double *Z, int ld
    return 0;
 }
 
+#else  /* PA_IS_COMPLEX */
+/* The Hermitian counterpart (the reference calls zheev / zheevx, blaslapack.c:1024-1145): unblocked Householder
+ * reduction to a REAL symmetric tridiagonal matrix (reflectors H = I - tau w w^H with w = (1; v), chosen so that the
+ * subdiagonal comes out real), the unitary factor formed explicitly, then the same implicit-shift QL sweeps as the
+ * real solver with the (real) rotations applied to its complex columns.  A: UPPER triangle referenced. */
+int pa_sym_eig(int n, const HS *A, int lda, double *evals, HS *Z, int ldz) {
+   if (n <= 0) return 0;
+   HS *a = (HS *)malloc((size_t)n * n * sizeof(HS));       /* full Hermitian copy, column-major */
+   HS *q = (HS *)malloc((size_t)n * n * sizeof(HS));
+   HS *tau = (HS *)malloc((size_t)n * sizeof(HS)), *w = (HS *)malloc((size_t)n * sizeof(HS));
+   double *e = (double *)malloc((size_t)n * sizeof(double)), *d = evals;
+   if (!a || !q || !tau || !w || !e) { free(a); free(q); free(tau); free(w); free(e); return PRIMME_MALLOC_FAILURE; }
+   for (int j = 0; j < n; j++)
+      for (int i = 0; i < n; i++) a[i + (size_t)j * n] = (i < j) ? A[i + (size_t)j * lda] : (i == j ? creal(A[i + (size_t)j * lda]) : conj(A[j + (size_t)i * lda]));
+
+   /* ---- reduction, column k annihilated below the subdiagonal ---- */
+   for (int k = 0; k < n - 1; k++) {
+      const int nn = n - k - 1;                 /* order of the trailing block, length of the reflector */
+      HS *x = a + (k + 1) + (size_t)k * n;      /* (alpha; x) = a[k+1:n, k] */
+      const HS alpha = x[0];
+      double xnorm2 = 0.0;
+      for (int i = 1; i < nn; i++) xnorm2 += creal(x[i]) * creal(x[i]) + cimag(x[i]) * cimag(x[i]);
+      if (xnorm2 == 0.0 && cimag(alpha) == 0.0) {
+         tau[k] = 0.0;
+         e[k] = creal(alpha);
+      } else {
+         double beta = sqrt(creal(alpha) * creal(alpha) + cimag(alpha) * cimag(alpha) + xnorm2);
+         if (creal(alpha) > 0.0) beta = -beta;
+         tau[k] = (beta - alpha) / beta;
+         const HS sc = 1.0 / (alpha - beta);
+         for (int i = 1; i < nn; i++) x[i] *= sc;
+         x[0] = 1.0;
+         e[k] = beta;
+         /* trailing block A22 <- H^H A22 H:  p = tau A22 v;  w = p - (tau/2)(p^H v) v;  A22 -= v w^H + w v^H */
+         HS *A22 = a + (k + 1) + (size_t)(k + 1) * n;
+         for (int i = 0; i < nn; i++) {
+            HS t = 0.0;
+            for (int j = 0; j < nn; j++) t += A22[i + (size_t)j * n] * x[j];
+            w[i] = tau[k] * t;
+         }
+         HS pv = 0.0;
+         for (int i = 0; i < nn; i++) pv += conj(w[i]) * x[i];
+         const HS al = -0.5 * tau[k] * pv;
+         for (int i = 0; i < nn; i++) w[i] += al * x[i];
+         for (int j = 0; j < nn; j++)
+            for (int i = 0; i < nn; i++) A22[i + (size_t)j * n] -= x[i] * conj(w[j]) + w[i] * conj(x[j]);
+         for (int i = 0; i < nn; i++) A22[i + (size_t)i * n] = creal(A22[i + (size_t)i * n]);
+      }
+      d[k] = creal(a[k + (size_t)k * n]);
+   }
+   d[n - 1] = creal(a[(n - 1) + (size_t)(n - 1) * n]);
+   e[n - 1] = 0.0;
+
+   /* ---- Q = H(0) H(1) ... H(n-2), accumulated from the last reflector ---- */
+   for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) q[i + (size_t)j * n] = (i == j) ? 1.0 : 0.0;
+   for (int k = n - 2; k >= 0; k--) {
+      if (tau[k] == 0.0) continue;
+      const int nn = n - k - 1;
+      const HS *v = a + (k + 1) + (size_t)k * n;
+      for (int j = k + 1; j < n; j++) {
+         HS *qc = q + (k + 1) + (size_t)j * n;
+         HS t = 0.0;
+         for (int i = 0; i < nn; i++) t += conj(v[i]) * qc[i];
+         t *= tau[k];
+         for (int i = 0; i < nn; i++) qc[i] -= t * v[i];
+      }
+   }
+
+   /* ---- implicit QL on (d, e); the rotations act on the columns of q ---- */
+   for (int l = 0; l < n; l++) {
+      int iter = 0, m;
+      do {
+         for (m = l; m < n - 1; m++) {
+            const double dd = fabs(d[m]) + fabs(d[m + 1]);
+            if (fabs(e[m]) <= DBL_EPSILON * dd) break;
+         }
+         if (m != l) {
+            if (iter++ == 200) { free(a); free(q); free(tau); free(w); free(e); return PRIMME_LAPACK_FAILURE; }
+            double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+            double r = hypot(g, 1.0);
+            g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+            double sn = 1.0, c = 1.0, p = 0.0;
+            int i;
+            for (i = m - 1; i >= l; i--) {
+               double f = sn * e[i];
+               const double b = c * e[i];
+               e[i + 1] = (r = hypot(f, g));
+               if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+               sn = f / r;
+               c = g / r;
+               g = d[i + 1] - p;
+               r = (d[i] - g) * sn + 2.0 * c * b;
+               d[i + 1] = g + (p = sn * r);
+               g = c * r - b;
+               HS *qi = q + (size_t)i * n, *qi1 = q + (size_t)(i + 1) * n;
+               for (int kk = 0; kk < n; kk++) {
+                  const HS fz = qi1[kk];
+                  qi1[kk] = sn * qi[kk] + c * fz;
+                  qi[kk] = c * qi[kk] - sn * fz;
+               }
+            }
+            if (r == 0.0 && i >= l) continue;
+            d[l] -= p;
+            e[l] = g;
+            e[m] = 0.0;
+         }
+      } while (m != l);
+   }
+
+   /* ---- ascending order and copy out ---- */
+   int *ord = (int *)malloc((size_t)n * sizeof(int));
+   if (!ord) { free(a); free(q); free(tau); free(w); free(e); return PRIMME_MALLOC_FAILURE; }
+   for (int i = 0; i < n; i++) ord[i] = i;
+   for (int i = 0; i < n - 1; i++) {
+      int kk = i;
+      for (int j = i + 1; j < n; j++) if (d[ord[j]] < d[ord[kk]]) kk = j;
+      int t = ord[i]; ord[i] = ord[kk]; ord[kk] = t;
+   }
+   for (int j = 0; j < n; j++) {
+      e[j] = d[ord[j]];
+      memcpy(Z + (size_t)j * ldz, q + (size_t)ord[j] * n, (size_t)n * sizeof(HS));
+   }
+   memcpy(d, e, (size_t)n * sizeof(double));
+   free(ord); free(a); free(q); free(tau); free(w); free(e);
+   return 0;
+}
+#endif
+
 /* Upper Cholesky A = U'U in place (upper triangle of A referenced/overwritten).
  * Returns 0, or j+1 if the leading minor of order j+1 is not positive definite. */
-int pa_potrf_upper(int n, double *A, int lda) {
+int pa_potrf_upper(int n, HS *A, int lda) {
    for (int j = 0; j < n; j++) {
-      double s = A[j + (size_t)j * lda];
-      for (int k = 0; k < j; k++) s -= A[k + (size_t)j * lda] * A[k + (size_t)j * lda];
+      double s = HS_RE(A[j + (size_t)j * lda]);
+      for (int k = 0; k < j; k++) s -= HS_ABS2(A[k + (size_t)j * lda]);
       if (!(s > 0.0) || !isfinite(s)) return j + 1;
       const double ujj = sqrt(s);
       A[j + (size_t)j * lda] = ujj;
       for (int c = j + 1; c < n; c++) {
-         double t = A[j + (size_t)c * lda];
-         for (int k = 0; k < j; k++) t -= A[k + (size_t)j * lda] * A[k + (size_t)c * lda];
+         HS t = A[j + (size_t)c * lda];
+         for (int k = 0; k < j; k++) t -= HS_CONJ(A[k + (size_t)j * lda]) * A[k + (size_t)c * lda];
          A[j + (size_t)c * lda] = t / ujj;
       }
    }
@@ -165,23 +294,23 @@ int pa_potrf_upper(int n, double *A, int lda) {
 }
 
 /* B <- U^-T B  (U upper n x n, B n x nb) */
-void pa_trsm_left_upper_trans(int n, int nb, const double *U, int ldu, double *B, int ldb) {
+void pa_trsm_left_upper_trans(int n, int nb, const HS *U, int ldu, HS *B, int ldb) {
    for (int c = 0; c < nb; c++) {
-      double *b = B + (size_t)c * ldb;
+      HS *b = B + (size_t)c * ldb;
       for (int i = 0; i < n; i++) {
-         double t = b[i];
-         for (int k = 0; k < i; k++) t -= U[k + (size_t)i * ldu] * b[k];
-         b[i] = t / U[i + (size_t)i * ldu];
+         HS t = b[i];
+         for (int k = 0; k < i; k++) t -= HS_CONJ(U[k + (size_t)i * ldu]) * b[k];
+         b[i] = t / HS_CONJ(U[i + (size_t)i * ldu]);
       }
    }
 }
 
 /* B <- U^-1 B */
-void pa_trsm_left_upper(int n, int nb, const double *U, int ldu, double *B, int ldb) {
+void pa_trsm_left_upper(int n, int nb, const HS *U, int ldu, HS *B, int ldb) {
    for (int c = 0; c < nb; c++) {
-      double *b = B + (size_t)c * ldb;
+      HS *b = B + (size_t)c * ldb;
       for (int i = n - 1; i >= 0; i--) {
-         double t = b[i];
+         HS t = b[i];
          for (int k = i + 1; k < n; k++) t -= U[i + (size_t)k * ldu] * b[k];
          b[i] = t / U[i + (size_t)i * ldu];
       }
@@ -189,30 +318,30 @@ void pa_trsm_left_upper(int n, int nb, const double *U, int ldu, double *B, int 
 }
 
 /* B <- B U^-1  (B mb x n) */
-void pa_trsm_right_upper(int mb, int n, const double *U, int ldu, double *B, int ldb) {
+void pa_trsm_right_upper(int mb, int n, const HS *U, int ldu, HS *B, int ldb) {
    for (int j = 0; j < n; j++) {
       for (int k = 0; k < j; k++) {
-         const double u = U[k + (size_t)j * ldu];
+         const HS u = U[k + (size_t)j * ldu];
          for (int i = 0; i < mb; i++) B[i + (size_t)j * ldb] -= B[i + (size_t)k * ldb] * u;
       }
-      const double inv = 1.0 / U[j + (size_t)j * ldu];
+      const HS inv = 1.0 / U[j + (size_t)j * ldu];
       for (int i = 0; i < mb; i++) B[i + (size_t)j * ldb] *= inv;
    }
 }
 
 /* Generalised symmetric-definite problem H x = lambda G x, upper triangles of
  * H and G referenced; G == NULL means identity.  Eigenvectors G-orthonormal. */
-int pa_sym_eig_gen(int n, const double *H, int ldh, const double *G, int ldg, double *evals,
-      double *Z, int ldz) {
+int pa_sym_eig_gen(int n, const HS *H, int ldh, const HS *G, int ldg, double *evals,
+      HS *Z, int ldz) {
    if (!G) return pa_sym_eig(n, H, ldh, evals, Z, ldz);
    if (n <= 0) return 0;
-   double *U = (double *)malloc((size_t)n * n * sizeof(double));
-   double *C = (double *)malloc((size_t)n * n * sizeof(double));
+   HS *U = (HS *)malloc((size_t)n * n * sizeof(HS));
+   HS *C = (HS *)malloc((size_t)n * n * sizeof(HS));
    if (!U || !C) { free(U); free(C); return PRIMME_MALLOC_FAILURE; }
    for (int j = 0; j < n; j++)
       for (int i = 0; i < n; i++) {
          U[i + (size_t)j * n] = (i <= j) ? G[i + (size_t)j * ldg] : 0.0;
-         C[i + (size_t)j * n] = (i <= j) ? H[i + (size_t)j * ldh] : H[j + (size_t)i * ldh];
+         C[i + (size_t)j * n] = (i <= j) ? H[i + (size_t)j * ldh] : HS_CONJ(H[j + (size_t)i * ldh]);
       }
    if (pa_potrf_upper(n, U, n)) { free(U); free(C); return PRIMME_LAPACK_FAILURE; }
    /* C <- U^-T C U^-1 */
@@ -221,8 +350,8 @@ int pa_sym_eig_gen(int n, const double *H, int ldh, const double *G, int ldg, do
    /* symmetrise the round-off */
    for (int j = 0; j < n; j++)
       for (int i = 0; i < j; i++) {
-         double s = 0.5 * (C[i + (size_t)j * n] + C[j + (size_t)i * n]);
-         C[i + (size_t)j * n] = C[j + (size_t)i * n] = s;
+         HS s = 0.5 * (C[i + (size_t)j * n] + HS_CONJ(C[j + (size_t)i * n]));
+         C[i + (size_t)j * n] = s; C[j + (size_t)i * n] = HS_CONJ(s);
       }
    int rc = pa_sym_eig(n, C, n, evals, Z, ldz);
    if (!rc) pa_trsm_left_upper(n, n, U, n, Z, ldz);
@@ -232,13 +361,15 @@ int pa_sym_eig_gen(int n, const double *H, int ldh, const double *G, int ldg, do
 }
 
 /* new column i = old column perm[i]  (reference src/linalg/auxiliary.c:716 semantics) */
-void pa_permute_cols(double *A, int mrows, int n, int lda, const int *perm) {
+void pa_permute_cols(HS *A, int mrows, int n, int lda, const int *perm) {
    if (n <= 0 || mrows <= 0) return;
-   double *tmp = (double *)malloc((size_t)mrows * n * sizeof(double));
-   for (int j = 0; j < n; j++) memcpy(tmp + (size_t)j * mrows, A + (size_t)perm[j] * lda, (size_t)mrows * sizeof(double));
-   for (int j = 0; j < n; j++) memcpy(A + (size_t)j * lda, tmp + (size_t)j * mrows, (size_t)mrows * sizeof(double));
+   HS *tmp = (HS *)malloc((size_t)mrows * n * sizeof(HS));
+   for (int j = 0; j < n; j++) memcpy(tmp + (size_t)j * mrows, A + (size_t)perm[j] * lda, (size_t)mrows * sizeof(HS));
+   for (int j = 0; j < n; j++) memcpy(A + (size_t)j * lda, tmp + (size_t)j * mrows, (size_t)mrows * sizeof(HS));
    free(tmp);
 }
+#if !PA_IS_COMPLEX      /* type-independent helpers exist once (the real object) */
+void pa_permute_reals(double *A, int mrows, int n, int lda, const int *perm) { pa_permute_cols(A, mrows, n, lda, perm); }
 void pa_permute_ints(int *a, int n, const int *perm) {
    if (n <= 0) return;
    int *tmp = (int *)malloc((size_t)n * sizeof(int));
@@ -246,30 +377,32 @@ void pa_permute_ints(int *a, int n, const int *perm) {
    memcpy(a, tmp, (size_t)n * sizeof(int));
    free(tmp);
 }
+#endif
 
 /* R = X' * Hsym * X with Hsym given by its upper triangle (order nh), X nh x nx.
  * (reference src/linalg/auxiliary.c:598-625 compute_submatrix) */
-void pa_submatrix(const double *X, int nx, int ldx, const double *H, int nh, int ldh, double *R,
+void pa_submatrix(const HS *X, int nx, int ldx, const HS *H, int nh, int ldh, HS *R,
       int ldr) {
    if (nx <= 0 || nh <= 0) return;
-   double *t = (double *)calloc((size_t)nh * nx, sizeof(double));
+   HS *t = (HS *)calloc((size_t)nh * nx, sizeof(HS));
    for (int c = 0; c < nx; c++)
       for (int j = 0; j < nh; j++) {
-         const double xj = X[j + (size_t)c * ldx];
+         const HS xj = X[j + (size_t)c * ldx];
          for (int i = 0; i < nh; i++) {
-            const double hij = (i <= j) ? H[i + (size_t)j * ldh] : H[j + (size_t)i * ldh];
+            const HS hij = (i <= j) ? H[i + (size_t)j * ldh] : HS_CONJ(H[j + (size_t)i * ldh]);
             t[i + (size_t)c * nh] += hij * xj;
          }
       }
    for (int c = 0; c < nx; c++)
       for (int r = 0; r < nx; r++) {
-         double s = 0.0;
-         for (int i = 0; i < nh; i++) s += X[i + (size_t)r * ldx] * t[i + (size_t)c * nh];
+         HS s = 0.0;
+         for (int i = 0; i < nh; i++) s += HS_CONJ(X[i + (size_t)r * ldx]) * t[i + (size_t)c * nh];
          R[r + (size_t)c * ldr] = s;
       }
    free(t);
 }
 
+#if !PA_IS_COMPLEX
 /* LAPACK xLARNV(idist = 2) stream, restated: 48-bit multiplicative congruential
  * generator x <- a*x mod 2^48, a = 33952834046453, uniform(-1,1) = 2*x/2^48 - 1.
  * iseed holds the state as four base-4096 digits (updated on exit).  Verified
@@ -344,3 +477,4 @@ int pa_svd(const double *A, int ldA, int n, double *U, int ldU, double *S, doubl
    free(W); free(perm); free(nrm); free(Vc);
    return 0;
 }
+#endif

@@ -5,22 +5,25 @@
 #include <stdint.h>
 #include "primme_amd.h"
 #include "primme_amd_kernels.h"
+#include "eigs_scalar.h"
 
 #define PA_MIN(a, b) ((a) < (b) ? (a) : (b))
 #define PA_MAX(a, b) ((a) > (b) ? (a) : (b))
 #define PA_EPS 2.220446049250313e-16 /* double */
 
-/* dense helpers (eigs_dense.c) */
-int  pa_sym_eig(int n, const double *A, int lda, double *evals, double *Z, int ldz);
-int  pa_sym_eig_gen(int n, const double *H, int ldh, const double *G, int ldg, double *evals,
-      double *Z, int ldz);
-int  pa_potrf_upper(int n, double *A, int lda);
-void pa_trsm_left_upper_trans(int n, int nb, const double *U, int ldu, double *B, int ldb);
-void pa_trsm_left_upper(int n, int nb, const double *U, int ldu, double *B, int ldb);
-void pa_trsm_right_upper(int mb, int n, const double *U, int ldu, double *B, int ldb);
-void pa_permute_cols(double *A, int mrows, int n, int lda, const int *perm);
+/* dense helpers (eigs_dense.c); HS = double, or double complex in the complex objects (Hermitian / unitary
+ * variants: ' reads as conjugate transpose) */
+int  pa_sym_eig(int n, const HS *A, int lda, double *evals, HS *Z, int ldz);
+int  pa_sym_eig_gen(int n, const HS *H, int ldh, const HS *G, int ldg, double *evals,
+      HS *Z, int ldz);
+int  pa_potrf_upper(int n, HS *A, int lda);
+void pa_trsm_left_upper_trans(int n, int nb, const HS *U, int ldu, HS *B, int ldb);
+void pa_trsm_left_upper(int n, int nb, const HS *U, int ldu, HS *B, int ldb);
+void pa_trsm_right_upper(int mb, int n, const HS *U, int ldu, HS *B, int ldb);
+void pa_permute_cols(HS *A, int mrows, int n, int lda, const int *perm);
+void pa_permute_reals(double *A, int mrows, int n, int lda, const int *perm);   /* Ritz values and other real rows */
 void pa_permute_ints(int *a, int n, const int *perm);
-void pa_submatrix(const double *X, int nx, int ldx, const double *H, int nh, int ldh, double *R,
+void pa_submatrix(const HS *X, int nx, int ldx, const HS *H, int nh, int ldh, HS *R,
       int ldr);
 void pa_larnv_uniform11(int64_t iseed[4], int64_t n, double *x);
 

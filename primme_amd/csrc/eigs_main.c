@@ -28,7 +28,7 @@ int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0
 int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc);
 int pa_random_col(pa_solver *s, char *col);
 int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
-      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int *b2_out);
+      int64_t ldLocked, int numLocked, HS *RLocked, int ldRLocked, int *b2_out);
 int pa_update_projection(pa_solver *s, int numCols, int blockSize);
 int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged);
 int pa_push_coefficients(pa_solver *s, int basisSize, int ldh);
@@ -39,7 +39,7 @@ void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv,
 int pa_check_convergence(pa_solver *s, char *X, int64_t ldX, int givenX, char *R, int64_t ldR,
       int givenR, int numLocked, int left, int right, int *flags, double *blockNorms,
       const double *hVals, int *reset, int practConvCheck);
-void pa_map_vecs(const double *Vp, int mrows, int nV, int ldV, const double *Wn, int n0, int n,
+void pa_map_vecs(const HS *Vp, int mrows, int nV, int ldV, const HS *Wn, int n0, int n,
       int ldW, int *pm);
 void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags, int *iblock,
       int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
@@ -57,10 +57,10 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
 /* ---- block orthogonalisation dispatcher (reference ortho.c:429-439, :522-530):
  *      implicit_I -> vector-by-vector CGS. ----------------------------------------- */
 int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
-      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int maxRank, int *b2_out);
+      int64_t ldLocked, int numLocked, HS *RLocked, int ldRLocked, int maxRank, int *b2_out);
 
 static int ortho_block(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
-      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int *b2_out) {
+      int64_t ldLocked, int numLocked, HS *RLocked, int ldRLocked, int *b2_out) {
    if (b2 < b1) { *b2_out = b2 + 1; return 0; }
    if (s->VtBV)   /* explicit_I: iterative CholQR/SVQB with the tracked Gram matrix */
       return pa_ortho_block_gram(s, Vp, ldV, b1, b2, locked, ldLocked, numLocked, RLocked, ldRLocked, s->maxRank, b2_out);
@@ -172,9 +172,10 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
    if (blockSize <= 0) return 0;
    double *shifts = (double *)malloc((size_t)blockSize * sizeof(double));
    double *olsen = (double *)malloc((size_t)blockSize * sizeof(double));
+   HS *colsen = (HS *)malloc((size_t)blockSize * sizeof(HS));      /* axpy factors in the panels' scalar type */
    double *sorted = s->hVals;
    int *ilev = iev, own = 0;
-   if (!shifts || !olsen) return PRIMME_MALLOC_FAILURE;
+   if (!shifts || !olsen || !colsen) return PRIMME_MALLOC_FAILURE;
    const int extremal = (p->target == primme_smallest || p->target == primme_largest);
    if (p->locking && extremal) {
       sorted = (double *)malloc((size_t)(numLocked + basisSize) * sizeof(double));
@@ -239,10 +240,13 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
 
    char *r = WCOL(s, basisSize), *x = VCOL(s, basisSize);
    int rc = 0;
+#if !PA_IS_COMPLEX
    if (p->correctionParams.maxInnerIterations != 0) {
       /* JDQMR: inner-outer iteration (reference correction.c:385-467) */
       rc = pa_correction_jdqmr(s, basisSize, blockSize, blockNorms, iev, shifts, numLocked, numConvergedStored, touch);
-   } else if (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX) {
+   } else
+#endif
+   if (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX) {
       /* exact Olsen: x <- K^-1 r - (x'K^-1 r / x'K^-1 x) K^-1 x  (reference correction.c:718-777);
        * K^-1 [x r] live in the scratch panel */
       if (2 * blockSize > s->nT) rc = PRIMME_UNEXPECTED_FAILURE;
@@ -250,20 +254,21 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
       if (!rc) rc = pa_precond(s, x, s->ld, Kx, s->ld, blockSize);
       if (!rc) rc = pa_precond(s, r, s->ld, Kr, s->ld, blockSize);
       if (!rc) rc = hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kx, s->ld, blockSize, s->d_red);
-      if (!rc) rc = hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kr, s->ld, blockSize, s->d_red + blockSize);
-      if (!rc) rc = pa_reduce(s, s->d_red, 2 * blockSize, 0, 0);
+      if (!rc) rc = hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kr, s->ld, blockSize, s->d_red + SD * blockSize);
+      if (!rc) rc = pa_reduce(s, s->d_red, SD * 2 * blockSize, 0, 0);
       if (!rc) {
+         const HS *hr = (const HS *)s->h_red;
          for (int b = 0; b < blockSize; b++)
-            olsen[b] = (fabs(s->h_red[b]) > 0.0) ? -s->h_red[blockSize + b] / s->h_red[b] : 0.0;
+            colsen[b] = (HS_ABS(hr[b]) > 0.0) ? -hr[blockSize + b] / hr[b] : 0.0;
          rc = hipk_copy_cols(s->ctx, s->dt, s->m, Kr, s->ld, x, s->ld, blockSize);
-         if (!rc) rc = hipk_axpy_cols(s->ctx, s->dt, s->m, olsen, Kx, s->ld, x, s->ld, blockSize);
+         if (!rc) rc = hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)colsen, Kx, s->ld, x, s->ld, blockSize);
       }
    } else {
       if (p->correctionParams.projectors.RightX &&
             ((p->correctionParams.precondition && p->applyPreconditioner) ||
                   (p->locking && p->orth == primme_orth_implicit_I))) {
-         for (int b = 0; b < blockSize; b++) olsen[b] = -olsen[b];
-         rc = hipk_axpy_cols(s->ctx, s->dt, s->m, olsen, x, s->ld, r, s->ld, blockSize);
+         for (int b = 0; b < blockSize; b++) colsen[b] = -olsen[b];
+         rc = hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)colsen, x, s->ld, r, s->ld, blockSize);
       }
       if (!rc && !s->fuse_gd) rc = pa_precond(s, r, s->ld, x, s->ld, blockSize);
    }
@@ -271,6 +276,7 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
    if (own) { free(sorted); free(ilev); }
    free(shifts);
    free(olsen);
+   free(colsen);
    return rc;
 }
 
@@ -509,11 +515,11 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
             /* orthogonalise the corrections; when GD runs with locking and no
              * preconditioner keep Q'r for the practical-convergence test below */
-            double *Rlocked = NULL;
+            HS *Rlocked = NULL;
             const int ldRlocked = p->numOrthoConst + numLocked;
             const int blockSize0 = blockSize;
             if (gdNoPrecondLocking) {
-               Rlocked = (double *)calloc((size_t)(ldRlocked > 0 ? ldRlocked : 1) * (blockSize > 0 ? blockSize : 1), sizeof(double));
+               Rlocked = (HS *)calloc((size_t)(ldRlocked > 0 ? ldRlocked : 1) * (blockSize > 0 ? blockSize : 1), sizeof(HS));
                if (!Rlocked) return PRIMME_MALLOC_FAILURE;
             }
             for (i = 0; i < maxNumRandoms; i++) {
@@ -541,14 +547,14 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                if (numLocked > 0) {
                   for (i = 0; i < blockSize0 && numConverged < p->numEvals; i++) {
                      double nR = 0.0, normXx = 0.0;
-                     for (int j = 0; j < ldRlocked; j++) nR += Rlocked[j + (size_t)i * ldRlocked] * Rlocked[j + (size_t)i * ldRlocked];
+                     for (int j = 0; j < ldRlocked; j++) nR += HS_ABS2(Rlocked[j + (size_t)i * ldRlocked]);
                      if (s->VtBV) {
                         /* |V_locked' x|^2 from the tracked Gram matrix (reference main_iter.c:747-758) */
                         for (int j = 0; j < numLocked; j++) {
-                           double t = 0.0;
+                           HS t = 0.0;
                            for (int q = 0; q < basisSize; q++)
                               t += s->VtBV[j + (size_t)(numLocked + q) * s->ldVtBV] * s->hVecs[q + (size_t)iev[i] * basisSize];
-                           normXx += t * t;
+                           normXx += HS_ABS2(t);
                         }
                      }
                      double newBlockNorm = sqrt(PA_MAX(s->blockNorms[i] * s->blockNorms[i] - nR * (1. + normXx), 0.0));
@@ -575,11 +581,14 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                   break;
             }
 
+#if !PA_IS_COMPLEX
             if (s->spec2_valid && s->spec2_k == basisSize && blockSize == 1) {
                /* W(:,k) = A v and V'W(:,k) were produced by the speculative tail (eigs_conv.c) */
                p->stats.numMatvecs += 1;
                for (i = 0; i <= basisSize; i++) s->H[i + (size_t)basisSize * s->K] = s->spec_hcol[i];
-            } else {
+            } else
+#endif
+            {
                CHK(pa_matvec(s, s->V, s->ld, s->W, s->ld, basisSize, blockSize));
                CHK(pa_update_projection(s, basisSize, blockSize));
             }
@@ -593,8 +602,8 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
             /* remember the coefficient vectors of this step (the +k directions) */
             for (int j = 0; j < basisSize; j++) {
-               memcpy(s->prevhVecs + (size_t)j * s->K, s->hVecs + (size_t)j * basisSize, (size_t)basisSize * sizeof(double));
-               memset(s->prevhVecs + (size_t)j * s->K + basisSize, 0, (size_t)(s->K - basisSize) * sizeof(double));
+               memcpy(s->prevhVecs + (size_t)j * s->K, s->hVecs + (size_t)j * basisSize, (size_t)basisSize * sizeof(HS));
+               memset(s->prevhVecs + (size_t)j * s->K + basisSize, 0, (size_t)(s->K - basisSize) * sizeof(HS));
             }
             nprevhVecs = basisSize;
             basisSize += blockSize;
@@ -721,7 +730,9 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
                numLocked == nlAtLastRestart) { if (++idleRestarts >= 5) stalled = wholeSpace = 1; }
          else idleRestarts = 0;
          mvAtLastRestart = p->stats.numMatvecs; bsAtLastRestart = basisSize; ncAtLastRestart = numConverged; nlAtLastRestart = numLocked;
+#if !PA_IS_COMPLEX
          if (s->wtr_enabled && s->fuse_gd && !s->Q) CHK(pa_refresh_wtq(s, basisSize, p->numOrthoConst + numLocked));
+#endif
          if (p->dynamicMethodSwitch == 1) {
             /* few eigenpairs: GD+k is judged after each restart, restart cost included */
             CHK(hipk_sync(s->ctx));
@@ -843,7 +854,15 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    if (rc) return rc;
 
    /* what this build of the path covers; anything else must fail loudly */
+#if PA_IS_COMPLEX
+   if (dt != HIPK_C64 && dt != HIPK_C32) return PRIMME_FUNCTION_UNAVAILABLE;
+   /* the complex objects carry Rayleigh-Ritz extraction and the Generalized-Davidson family; eigs_complex.c sends
+    * everything else to the real-equivalent form and never calls in here with it */
+   if (p->projectionParams.projection != primme_proj_RR || p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0)
+      return PRIMME_FUNCTION_UNAVAILABLE;
+#else
    if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
+#endif
    const int refined = (p->projectionParams.projection == primme_proj_refined);
    const int harmonic = (p->projectionParams.projection == primme_proj_harmonic) || refined;
    if (p->massMatrixMatvec ||
@@ -863,7 +882,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 
    pa_solver *s = (pa_solver *)calloc(1, sizeof(pa_solver));
    if (!s) return PRIMME_MALLOC_FAILURE;
-   s->p = p; s->dt = dt; s->es = (dt == HIPK_F64) ? 8 : 4; s->mach_eps = mach_eps;
+   s->p = p; s->dt = dt; s->es = (dt == HIPK_F64) ? 8 : (dt == HIPK_F32) ? 4 : (dt == HIPK_C64) ? 16 : 8; s->mach_eps = mach_eps;
    s->m = p->nLocal; s->ld = p->ldOPs; s->K = p->maxBasisSize;
    /* Columns of V, W and the scratch panels on 128-byte boundaries when nobody outside the library sees their leading
     * dimension (its own operator and preconditioner, ldOPs left at nLocal): a wave's 1 KB of a column is then 8 cache
@@ -888,7 +907,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->parallel = ((p->numProcs > 1 || getenv("PRIMME_AMD_FORCE_COMM")) && p->globalSumReal != NULL);
    s->dev_comm = (s->parallel && p->globalSumReal == primme_amd_global_sum);
    s->coef_valid_k = -1;
-   s->fuse_gd = (p->correctionParams.maxInnerIterations == 0 && p->dynamicMethodSwitch <= 0 && !p->correctionParams.precondition &&
+   s->fuse_gd = !PA_IS_COMPLEX && (p->correctionParams.maxInnerIterations == 0 && p->dynamicMethodSwitch <= 0 && !p->correctionParams.precondition &&
                  !p->correctionParams.projectors.RightX &&
                  (p->convTestFun == pa_conv_test_absolute || pa_svds_conv_test_is_vector_free(p)));
    s->maxRank = p->numOrthoConst + (p->locking ? p->numEvals : 0) + p->maxBasisSize;
@@ -923,11 +942,11 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
         hipk_malloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->d_red) ||
         (harmonic && hipk_malloc(s->ctx, colBytes * K, (void **)&s->Q)) ||
         (need_hat && hipk_malloc(s->ctx, (size_t)(s->ldevecs > 0 ? s->ldevecs : 1) * s->es * maxEvecs, (void **)&s->evecsHat)) ||
-        hipk_malloc(s->ctx, s->coef_cap * 8, (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
+        hipk_malloc(s->ctx, s->coef_cap * sizeof(HS), (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
         hipk_host_alloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->h_red) ||
-        hipk_host_alloc(s->ctx, s->coef_cap * 8, (void **)&s->h_coef) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta);
-   s->H = (double *)calloc((size_t)K * K, 8); s->hVecs = (double *)calloc((size_t)K * K, 8);
-   s->prevhVecs = (double *)calloc((size_t)K * K, 8); s->hVals = (double *)calloc((size_t)K, 8);
+        hipk_host_alloc(s->ctx, s->coef_cap * sizeof(HS), (void **)&s->h_coef) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta);
+   s->H = (HS *)calloc((size_t)K * K, sizeof(HS)); s->hVecs = (HS *)calloc((size_t)K * K, sizeof(HS));
+   s->prevhVecs = (HS *)calloc((size_t)K * K, sizeof(HS)); s->hVals = (double *)calloc((size_t)K, 8);
    s->prevRitzVals = (double *)calloc((size_t)K + nev, 8);
    s->blockNorms = (double *)calloc((size_t)K + b, 8); s->basisNorms = (double *)calloc((size_t)K, 8);
    s->spec_hcol = (double *)calloc((size_t)K + 2, 8);
@@ -939,12 +958,12 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->fused_restart = getenv("PRIMME_AMD_NO_FUSED_RESTART") == NULL;
    s->wtq_rows = -1;
    if (harmonic) {
-      s->R = (double *)calloc((size_t)K * K + 1, 8);
-      s->hU = (double *)calloc((size_t)K * K + 1, 8);
+      s->R = (HS *)calloc((size_t)K * K + 1, sizeof(HS));
+      s->hU = (HS *)calloc((size_t)K * K + 1, sizeof(HS));
       if (refined) {
          s->refined = 1;
-         s->hSVals = (double *)calloc((size_t)K + 1, 8); s->hVecsRot = (double *)calloc((size_t)K * K + 1, 8);
-      } else s->QtV = (double *)calloc((size_t)K * K + 1, 8);
+         s->hSVals = (double *)calloc((size_t)K + 1, 8); s->hVecsRot = (HS *)calloc((size_t)K * K + 1, sizeof(HS));
+      } else s->QtV = (HS *)calloc((size_t)K * K + 1, sizeof(HS));
       if (!s->R || !s->hU || (refined ? (!s->hSVals || !s->hVecsRot) : !s->QtV)) { free_solver(s); p->queue = user_queue; return PRIMME_MALLOC_FAILURE; }
    }
    s->flags = (int *)calloc((size_t)K, sizeof(int)); s->map = (int *)calloc((size_t)K, sizeof(int));
@@ -952,8 +971,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->lockedFlags = (int *)calloc((size_t)nev + 1, sizeof(int));
    if (p->orth == primme_orth_explicit_I) {
       s->ldVtBV = s->maxRank;
-      s->VtBV = (double *)calloc((size_t)s->maxRank * s->maxRank, 8);
-      s->fVtBV = (double *)calloc((size_t)s->maxRank * s->maxRank, 8);
+      s->VtBV = (HS *)calloc((size_t)s->maxRank * s->maxRank, sizeof(HS));
+      s->fVtBV = (HS *)calloc((size_t)s->maxRank * s->maxRank, sizeof(HS));
       if (!s->VtBV || !s->fVtBV) rc = 1;
    }
    if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap * 2);
@@ -996,6 +1015,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    return rc;
 }
 
+#if !PA_IS_COMPLEX
 int hip_dprimme(double *evals, double *evecs, double *resNorms, primme_params *primme) {
    return solve(evals, evecs, resNorms, primme, HIPK_F64, 0);
 }
@@ -1003,6 +1023,7 @@ int hip_sprimme(float *evals, float *evecs, float *resNorms, primme_params *prim
    return solve(evals, evecs, resNorms, primme, HIPK_F32, 0);
 }
 /* hip_zprimme / hip_cprimme: eigs_complex.c */
+#endif
 
 /* internal entry for the svds front end: eigenvalues and residual norms always in double */
 int pa_eigs_solve(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double) {

@@ -14,6 +14,7 @@
 #include <string.h>
 #include <time.h>
 
+#if !PA_IS_COMPLEX      /* type-independent pieces exist once (the real objects) */
 double pa_wtime(void) {
    struct timespec ts;
    clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -110,6 +111,13 @@ int pa_reduce_host(pa_solver *s, double *buf, int count) {
    return 0;
 }
 
+#endif   /* !PA_IS_COMPLEX */
+#if PA_IS_COMPLEX
+double pa_problem_norm(int overrideUser, const primme_params *p);
+int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
+int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0, int nc);
+int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc);
+#else
 /* ---- W(:,c0:c0+nc) = A * V(:,c0:c0+nc)  (reference auxiliary_eigs.c:183-230) ---- */
 int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0, int nc) {
    primme_params *p = s->p;
@@ -144,19 +152,22 @@ int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc)
    return 0;
 }
 
-/* random column (reference blaslapack.c:938-988 Num_larnv: host xLARNV then upload) */
+#endif
+/* random column (reference blaslapack.c:938-988 Num_larnv: host xLARNV then upload; complex entries take two
+ * consecutive numbers of the stream, (re, im), as zlarnv does) */
 int pa_random_col(pa_solver *s, char *col) {
    s->fov_valid = 0;
-   double *tmp = (double *)malloc((size_t)(s->m > 0 ? s->m : 1) * sizeof(double));
+   const int64_t nreal = s->m * SD;
+   double *tmp = (double *)malloc((size_t)(nreal > 0 ? nreal : 1) * sizeof(double));
    if (!tmp) return PRIMME_MALLOC_FAILURE;
-   pa_larnv_uniform11(s->p->iseed, s->m, tmp);
+   pa_larnv_uniform11(s->p->iseed, nreal, tmp);
    int rc;
-   if (s->dt == HIPK_F64) {
-      rc = hipk_h2d(s->ctx, col, tmp, (size_t)s->m * 8);
+   if (s->dt == HIPK_F64 || s->dt == HIPK_C64) {
+      rc = hipk_h2d(s->ctx, col, tmp, (size_t)nreal * 8);
    } else {
       float *f = (float *)tmp; /* in-place narrowing, front to back */
-      for (int64_t i = 0; i < s->m; i++) f[i] = (float)tmp[i];
-      rc = hipk_h2d(s->ctx, col, tmp, (size_t)s->m * 4);
+      for (int64_t i = 0; i < nreal; i++) f[i] = (float)tmp[i];
+      rc = hipk_h2d(s->ctx, col, tmp, (size_t)nreal * 4);
    }
    if (!rc) rc = hipk_sync(s->ctx);
    free(tmp);
@@ -178,7 +189,7 @@ int pa_random_col(pa_solver *s, char *col) {
  * and the host synchronises once to apply the test.
  */
 int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *locked,
-      int64_t ldLocked, int numLocked, double *RLocked, int ldRLocked, int *b2_out) {
+      int64_t ldLocked, int numLocked, HS *RLocked, int ldRLocked, int *b2_out) {
    primme_params *p = s->p;
    const int maxNumOrthos = 3, maxNumRandoms = 10;
    const double tol = sqrt(2.0) / 2.0;
@@ -213,19 +224,21 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
          hipk_seg segs[3] = {{Vp, ldV, i}, {locked, ldLocked, numLocked}, {v, ldV, first ? 1 : 0}};
          /* overlaps of the first pass may already be there: the fused residual kernel computed
           * [Vp' v | locked' v | v'v] while it produced v (eigs_conv.c) */
-         const int use_fov = first && randomizations == 0 && s->fov_valid && Vp == s->V && v == s->fov_col &&
+         const int use_fov = !PA_IS_COMPLEX && first && randomizations == 0 && s->fov_valid && Vp == s->V && v == s->fov_col &&
                              i == s->fov_k && numLocked == s->fov_L && (numLocked == 0 || locked == s->evecs);
          double *dbase = use_fov ? s->d_fov : s->d_red;
          double *hbase = use_fov ? s->h_fov : s->h_red;
-         const int s1_off = use_fov ? s->fov_s1_off : nov + 1;
+         /* layout of the buffer: nov (+1) scalars of overlaps, then the REAL squared norm of the update at
+          * double offset s1_off */
+         const int s1_off = use_fov ? s->fov_s1_off : SD * (nov + 1);
          double *d_ov = dbase, *d_s1 = dbase + s1_off;
          if (first) s->fov_valid = 0;
          if (!use_fov) {
             CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segs, 3, v, ldV, 1, d_ov, ndot));
             if (parallel && !s->dev_comm) {
-               CHK(pa_reduce(s, d_ov, ndot, 1, 0));
+               CHK(pa_reduce(s, d_ov, SD * ndot, 1, 0));
             } else if (parallel) {
-               CHK(pa_reduce(s, d_ov, ndot, 1, 1));
+               CHK(pa_reduce(s, d_ov, SD * ndot, 1, 1));
             }
          }
          p->stats.numOrthoInnerProds += ndot;
@@ -246,8 +259,8 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
          s->spec_fused = 0;
 
          if (updateR)
-            for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += hbase[i + j];
-         if (first) { s02 = hbase[nov]; s0 = sqrt(s02); }
+            for (int j = 0; j < numLocked; j++) RLocked[j + (size_t)(i - b1) * ldRLocked] += ((const HS *)hbase)[i + j];
+         if (first) { s02 = HS_RE(((const HS *)hbase)[nov]); s0 = sqrt(s02); }
          s12 = hbase[s1_off];
          s1 = sqrt(s12);
 
@@ -282,23 +295,23 @@ done:
  * Orthonormalises the single vector x (length n) against Q (n x nQ, ldQ) in the
  * G inner product (G upper-stored n x n, or NULL for identity).  *R receives the
  * norm left after projection (0 if the vector had to be randomised). */
-int pa_ortho_local_vec(double *x, int n, const double *Q, int ldQ, int nQ, const double *G,
+int pa_ortho_local_vec(HS *x, int n, const HS *Q, int ldQ, int nQ, const HS *G,
       int ldG, double *R, int64_t iseed[4]) {
    const int maxNumOrthos = 7, maxNumRandoms = 10;
    const double tol = sqrt(2.0) / 2.0;
-   double *ov = (double *)malloc((size_t)(nQ + 1) * sizeof(double));
-   double *Bx = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+   HS *ov = (HS *)malloc((size_t)(nQ + 1) * sizeof(HS));
+   HS *Bx = (HS *)malloc((size_t)(n > 0 ? n : 1) * sizeof(HS));
    if (!ov || !Bx) { free(ov); free(Bx); return PRIMME_MALLOC_FAILURE; }
    int nOrth = 0, randomizations = 0, updateR = 1, rc = -3;
    double s0 = 0, s02 = 0, s1 = 0, s12 = 0;
    *R = 0.0;
 #define APPLY_G(dst, src)                                                           \
    do {                                                                             \
-      if (!G) memcpy(dst, src, (size_t)n * sizeof(double));                         \
+      if (!G) memcpy(dst, src, (size_t)n * sizeof(HS));                             \
       else for (int i_ = 0; i_ < n; i_++) {                                         \
-         double t_ = 0;                                                             \
+         HS t_ = 0;                                                                 \
          for (int j_ = 0; j_ < n; j_++)                                             \
-            t_ += ((i_ <= j_) ? G[i_ + (size_t)j_ * ldG] : G[j_ + (size_t)i_ * ldG]) * (src)[j_]; \
+            t_ += ((i_ <= j_) ? G[i_ + (size_t)j_ * ldG] : HS_CONJ(G[j_ + (size_t)i_ * ldG])) * (src)[j_]; \
          (dst)[i_] = t_;                                                            \
       }                                                                             \
    } while (0)
@@ -306,23 +319,23 @@ int pa_ortho_local_vec(double *x, int n, const double *Q, int ldQ, int nQ, const
       if (nOrth >= maxNumOrthos) {
          if (updateR) { *R = 0.0; updateR = 0; }
          if (randomizations >= maxNumRandoms) break;
-         pa_larnv_uniform11(iseed, n, x);
+         pa_larnv_uniform11(iseed, (int64_t)n * SD, (double *)x);
          randomizations++;
          nOrth = 0;
       }
       nOrth++;
       APPLY_G(Bx, x);
-      if (nOrth == 1) { s02 = 0; for (int i = 0; i < n; i++) s02 += x[i] * Bx[i]; s0 = sqrt(s02); }
+      if (nOrth == 1) { s02 = 0; for (int i = 0; i < n; i++) s02 += HS_RE(HS_CONJ(x[i]) * Bx[i]); s0 = sqrt(s02); }
       for (int j = 0; j < nQ; j++) {
-         double t = 0;
-         for (int i = 0; i < n; i++) t += Q[i + (size_t)j * ldQ] * Bx[i];
+         HS t = 0;
+         for (int i = 0; i < n; i++) t += HS_CONJ(Q[i + (size_t)j * ldQ]) * Bx[i];
          ov[j] = t;
       }
       for (int j = 0; j < nQ; j++)
          for (int i = 0; i < n; i++) x[i] -= Q[i + (size_t)j * ldQ] * ov[j];
       APPLY_G(Bx, x);
       s12 = 0;
-      for (int i = 0; i < n; i++) s12 += x[i] * Bx[i];
+      for (int i = 0; i < n; i++) s12 += HS_RE(HS_CONJ(x[i]) * Bx[i]);
       s1 = sqrt(s12);
       if (!isfinite(s0) || !isfinite(s1) || s1 <= PA_EPS * s0) {
          nOrth = maxNumOrthos;
@@ -348,34 +361,41 @@ int pa_update_projection(pa_solver *s, int numCols, int blockSize) {
    const int mrows = numCols + blockSize;
    hipk_seg seg = {s->V, s->ld, mrows};
    CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, WCOL(s, numCols), s->ld, blockSize, s->d_red, mrows));
-   CHK(pa_reduce(s, s->d_red, mrows * blockSize, 0, 0));
+   CHK(pa_reduce(s, s->d_red, SD * mrows * blockSize, 0, 0));
    for (int c = 0; c < blockSize; c++)
       for (int i = 0; i < mrows; i++)
-         s->H[i + (size_t)(numCols + c) * s->K] = s->h_red[i + (size_t)c * mrows];
+         s->H[i + (size_t)(numCols + c) * s->K] = ((const HS *)s->h_red)[i + (size_t)c * mrows];
    return 0;
 }
 
 /* ---- Rayleigh-Ritz on the projected matrix (reference solve_projection.c:94-154,
  *      :188-331): eigenpairs of H (upper) ordered by primme->target, then the
  *      running estimates of the spectrum edges. --------------------------------- */
-int pa_solve_H_RR(pa_solver *s, const double *H, int ldH, const double *VtBV, int ldVtBV,
-      double *hVecs, int ldhVecs, double *hVals, int n, int numConverged) {
+int pa_solve_H_RR(pa_solver *s, const HS *H, int ldH, const HS *VtBV, int ldVtBV,
+      HS *hVecs, int ldhVecs, double *hVals, int n, int numConverged) {
    primme_params *p = s->p;
    if (n == 0) return 0;
    if (p->target == primme_largest) {
-      double *Hn = (double *)malloc((size_t)n * n * sizeof(double));
+      HS *Hn = (HS *)calloc((size_t)n * n, sizeof(HS));
       if (!Hn) return PRIMME_MALLOC_FAILURE;
       for (int j = 0; j < n; j++)
          for (int i = 0; i <= j; i++) Hn[i + (size_t)j * n] = -H[i + (size_t)j * ldH];
+#if PA_IS_COMPLEX
+      int rc = pa_sym_eig_gen(n, Hn, n, VtBV, ldVtBV, hVals, hVecs, ldhVecs);
+#else
       int rc = (s->device_rr && !VtBV && n <= 64) ? hipk_sym_eig(s->ctx, n, Hn, n, hVals, hVecs, ldhVecs)
                                                    : pa_sym_eig_gen(n, Hn, n, VtBV, ldVtBV, hVals, hVecs, ldhVecs);
+#endif
       free(Hn);
       if (rc) return rc;
       for (int i = 0; i < n; i++) hVals[i] = -hVals[i];
       return 0;
    }
+#if !PA_IS_COMPLEX
    if (s->device_rr && !VtBV && n <= 64) CHK(hipk_sym_eig(s->ctx, n, H, ldH, hVals, hVecs, ldhVecs));
-   else CHK(pa_sym_eig_gen(n, H, ldH, VtBV, ldVtBV, hVals, hVecs, ldhVecs));
+   else
+#endif
+   CHK(pa_sym_eig_gen(n, H, ldH, VtBV, ldVtBV, hVals, hVecs, ldhVecs));
    if (p->target == primme_smallest) return 0;
 
    /* interior targets: permutation by closeness to the first unlocked shift */
@@ -407,22 +427,25 @@ int pa_solve_H_RR(pa_solver *s, const double *H, int ldH, const double *VtBV, in
          else permu[idx++] = j++;
       }
    }
-   pa_permute_cols(hVals, 1, n, 1, permu);
+   pa_permute_reals(hVals, 1, n, 1, permu);
    pa_permute_cols(hVecs, n, n, ldhVecs, permu);
    free(permu);
    return 0;
 }
 
-int pa_solve_H_harm(pa_solver *s, int k, const double *G, int ldG);
+int pa_solve_H_harm(pa_solver *s, int k, const HS *G, int ldG);
 int pa_solve_H_ref(pa_solver *s, int k, double *hVals_out);
 
 int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged) {
    primme_params *p = s->p;
    const int off = p->numOrthoConst + numLocked;
-   const double *G = s->VtBV ? s->VtBV + (size_t)off * s->ldVtBV + off : NULL;
+   const HS *G = s->VtBV ? s->VtBV + (size_t)off * s->ldVtBV + off : NULL;
+#if !PA_IS_COMPLEX      /* harmonic / refined extraction: real objects only (eigs_scalar.h) */
    if (s->refined) CHK(pa_solve_H_ref(s, basisSize, s->hVals));
    else if (s->Q) CHK(pa_solve_H_harm(s, basisSize, G, s->ldVtBV));
-   else CHK(pa_solve_H_RR(s, s->H, s->K, G, s->ldVtBV, s->hVecs, basisSize, s->hVals, basisSize, numConverged));
+   else
+#endif
+   CHK(pa_solve_H_RR(s, s->H, s->K, G, s->ldVtBV, s->hVecs, basisSize, s->hVals, basisSize, numConverged));
    for (int i = 0; i < basisSize; i++) {
       p->stats.estimateMinEVal = PA_MIN(p->stats.estimateMinEVal, s->hVals[i]);
       p->stats.estimateMaxEVal = PA_MAX(p->stats.estimateMaxEVal, s->hVals[i]);
@@ -436,9 +459,9 @@ int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged) {
 int pa_push_coefficients(pa_solver *s, int basisSize, int ldh) {
    if (s->coef_valid_k == basisSize) return 0;
    for (int j = 0; j < basisSize; j++)
-      memcpy(s->h_coef + (size_t)j * s->K, s->hVecs + (size_t)j * ldh, (size_t)basisSize * sizeof(double));
+      memcpy((HS *)s->h_coef + (size_t)j * s->K, s->hVecs + (size_t)j * ldh, (size_t)basisSize * sizeof(HS));
    memcpy(s->h_theta, s->hVals, (size_t)basisSize * sizeof(double));
-   CHK(hipk_h2d(s->ctx, s->d_coef, s->h_coef, (size_t)s->K * basisSize * sizeof(double)));
+   CHK(hipk_h2d(s->ctx, s->d_coef, s->h_coef, (size_t)s->K * basisSize * sizeof(HS)));
    CHK(hipk_h2d(s->ctx, s->d_theta, s->h_theta, (size_t)basisSize * sizeof(double)));
    s->coef_valid_k = basisSize;
    return 0;

@@ -25,10 +25,10 @@ int pa_push_coefficients(pa_solver *s, int basisSize, int ldh);
 int pa_check_convergence(pa_solver *s, char *X, int64_t ldX, int givenX, char *R, int64_t ldR,
       int givenR, int numLocked, int left, int right, int *flags, double *blockNorms,
       const double *hVals, int *reset, int practConvCheck);
-int pa_ortho_local_vec(double *x, int n, const double *Q, int ldQ, int nQ, const double *G,
+int pa_ortho_local_vec(HS *x, int n, const HS *Q, int ldQ, int nQ, const HS *G,
       int ldG, double *R, int64_t iseed[4]);
-int pa_solve_H_RR(pa_solver *s, const double *H, int ldH, const double *VtBV, int ldVtBV,
-      double *hVecs, int ldhVecs, double *hVals, int n, int numConverged);
+int pa_solve_H_RR(pa_solver *s, const HS *H, int ldH, const HS *VtBV, int ldVtBV,
+      HS *hVecs, int ldhVecs, double *hVals, int n, int numConverged);
 void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags, int *iblock,
       int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
       int *lockedFlags, double *lockedNorms, primme_event event);
@@ -41,7 +41,7 @@ int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, in
       int indexOfPreviousVecs, int indexOfPreviousVecsBeforeRestart, const int *restartPerm, const int *hVecsPerm,
       int *numArbitraryVecs);
 int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged);
-int pa_update_cholesky(const double *G, int ldG, double *fG, int ldfG, int n0, int n);
+int pa_update_cholesky(const HS *G, int ldG, HS *fG, int ldfG, int n0, int n);
 
 /* explicit_I: after V <- V*h, W <- W*h recompute from the data the Gram block G = V'V and
  * H = V'W of the restarted basis (reference auxiliary_eigs_normal.c:296-309 does it inside the
@@ -50,11 +50,11 @@ int pa_update_cholesky(const double *G, int ldG, double *fG, int ldfG, int n0, i
 static int refresh_gram_after_restart(pa_solver *s, int evecsSize, int nVold, int rs, int ldh) {
    if (!s->VtBV || rs <= 0) return 0;
    const int ldG = s->ldVtBV;
-   double *work = (double *)malloc((size_t)(evecsSize > 0 ? evecsSize : 1) * rs * sizeof(double));
+   HS *work = (HS *)malloc((size_t)(evecsSize > 0 ? evecsSize : 1) * rs * sizeof(HS));
    if (!work) return PRIMME_MALLOC_FAILURE;
    for (int c = 0; c < rs; c++)
       for (int i = 0; i < evecsSize; i++) {
-         double t = 0.0;
+         HS t = 0.0;
          for (int q = 0; q < nVold; q++) t += s->VtBV[i + (size_t)(evecsSize + q) * ldG] * s->hVecs[q + (size_t)c * ldh];
          work[i + (size_t)c * evecsSize] = t;
       }
@@ -63,13 +63,13 @@ static int refresh_gram_after_restart(pa_solver *s, int evecsSize, int nVold, in
    free(work);
    hipk_seg seg = {s->V, s->ld, rs};
    CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, s->V, s->ld, rs, s->d_red, rs));
-   CHK(pa_reduce(s, s->d_red, rs * rs, 0, 0));
+   CHK(pa_reduce(s, s->d_red, SD * rs * rs, 0, 0));
    for (int c = 0; c < rs; c++)
-      for (int i = 0; i < rs; i++) s->VtBV[(evecsSize + i) + (size_t)(evecsSize + c) * ldG] = s->h_red[i + (size_t)c * rs];
+      for (int i = 0; i < rs; i++) s->VtBV[(evecsSize + i) + (size_t)(evecsSize + c) * ldG] = ((const HS *)s->h_red)[i + (size_t)c * rs];
    CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, s->W, s->ld, rs, s->d_red, rs));
-   CHK(pa_reduce(s, s->d_red, rs * rs, 0, 0));
+   CHK(pa_reduce(s, s->d_red, SD * rs * rs, 0, 0));
    for (int c = 0; c < rs; c++)
-      for (int i = 0; i < rs; i++) s->H[i + (size_t)c * s->K] = s->h_red[i + (size_t)c * rs];
+      for (int i = 0; i < rs; i++) s->H[i + (size_t)c * s->K] = ((const HS *)s->h_red)[i + (size_t)c * rs];
    return 0;
 }
 
@@ -111,17 +111,17 @@ static int insertion_sort(double newVal, double *evals, double newNorm, double *
 /* Orthogonalise up to *numPrevRetained previous coefficient vectors against the
  * first indexOfPreviousVecs (+ already retained) current ones and append them. */
 static int ortho_coefficient_vectors(pa_solver *s, int basisSize, int ldh, int indexOfPreviousVecs,
-      const double *G, int ldG, int nprevhVecs, const int *flags, int *numPrevRetained) {
+      const HS *G, int ldG, int nprevhVecs, const int *flags, int *numPrevRetained) {
    primme_params *p = s->p;
    int retained = 0;
    for (int i = 0; i < nprevhVecs && retained < *numPrevRetained &&
                    indexOfPreviousVecs + retained < basisSize; i++) {
       if (p->locking == 0 && flags[i] != UNCONV) continue;
       double R = 0.0;
-      double *x = s->prevhVecs + (size_t)i * s->K;
+      HS *x = s->prevhVecs + (size_t)i * s->K;
       pa_ortho_local_vec(x, basisSize, s->hVecs, ldh, indexOfPreviousVecs + retained, G, ldG, &R, p->iseed);
       if (fabs(R) < PA_EPS * sqrt(retained + 1.0)) continue;
-      memcpy(s->hVecs + (size_t)(indexOfPreviousVecs + retained) * ldh, x, (size_t)basisSize * sizeof(double));
+      memcpy(s->hVecs + (size_t)(indexOfPreviousVecs + retained) * ldh, x, (size_t)basisSize * sizeof(HS));
       retained++;
    }
    *numPrevRetained = retained;
@@ -135,11 +135,11 @@ static int restart_RR(pa_solver *s, int ldh, int newldh, int restartSize, int ba
       int numConverged, int numPrevRetained, int indexOfPreviousVecs, const int *hVecsPerm) {
    primme_params *p = s->p;
    const int K = s->K;
-   double *H = s->H;
+   HS *H = s->H;
    const double aNorm = PA_MAX(p->aNorm, p->stats.estimateLargestSVal);
 
    if (p->orth == primme_orth_implicit_I) {
-      double *blk = (double *)malloc((size_t)(numPrevRetained > 0 ? numPrevRetained * numPrevRetained : 1) * sizeof(double));
+      HS *blk = (HS *)malloc((size_t)(numPrevRetained > 0 ? numPrevRetained * numPrevRetained : 1) * sizeof(HS));
       if (!blk) return PRIMME_MALLOC_FAILURE;
       pa_submatrix(s->hVecs + (size_t)indexOfPreviousVecs * ldh, numPrevRetained, ldh, H, basisSize, K,
             blk, numPrevRetained);
@@ -154,7 +154,7 @@ static int restart_RR(pa_solver *s, int ldh, int newldh, int restartSize, int ba
    }
 
    const int nLocked = p->numOrthoConst + (p->locking ? numConverged : 0);
-   const double *G = s->VtBV ? s->VtBV + (size_t)nLocked * s->ldVtBV + nLocked : NULL;
+   const HS *G = s->VtBV ? s->VtBV + (size_t)nLocked * s->ldVtBV + nLocked : NULL;
    if (p->targetShifts &&
          (s->targetShiftIndex < 0 ||
                fabs(p->targetShifts[s->targetShiftIndex] -
@@ -178,10 +178,10 @@ static int restart_RR(pa_solver *s, int ldh, int newldh, int restartSize, int ba
       for (int i = 0; i < restartSize; i++) s->hVecs[i + (size_t)j * newldh] = 0.0;
       s->hVecs[hVecsPerm[j] + (size_t)j * newldh] = 1.0;
    }
-   pa_permute_cols(s->hVals, 1, restartSize, 1, hVecsPerm);
+   pa_permute_reals(s->hVals, 1, restartSize, 1, hVecsPerm);
 
    if (numPrevRetained > 0) {
-      const double *Gb = G ? G + (size_t)indexOfPreviousVecs * s->ldVtBV + indexOfPreviousVecs : NULL;
+      const HS *Gb = G ? G + (size_t)indexOfPreviousVecs * s->ldVtBV + indexOfPreviousVecs : NULL;
       CHK(pa_solve_H_RR(s, H + (size_t)indexOfPreviousVecs * K + indexOfPreviousVecs, K, Gb, s->ldVtBV,
             s->hVecs + (size_t)ordered * newldh + indexOfPreviousVecs, newldh, s->hVals + ordered,
             numPrevRetained, numConverged));
@@ -221,9 +221,10 @@ int pa_block_first_reorder(pa_solver *s, int basisSize, int *flags, const int *i
       if ((flags[i] != UNCONV && mm++ < numConverged - numLocked) || inIev) iwork[k++] = i;
       else iwork[numConverged - numLocked + blockSize + l++] = i;
    }
-   pa_permute_cols(s->hVals, 1, basisSize, 1, iwork);
+   pa_permute_reals(s->hVals, 1, basisSize, 1, iwork);
    pa_permute_cols(s->hVecs, basisSize, basisSize, basisSize, iwork);
    pa_permute_ints(flags, basisSize, iwork);
+#if !PA_IS_COMPLEX
    if (s->hVecsRot) {
       for (int c = s->numArbitraryVecs; c < basisSize; c++) {
          for (int r = 0; r < s->K; r++) s->hVecsRot[r + (size_t)c * s->K] = 0.0;
@@ -234,6 +235,7 @@ int pa_block_first_reorder(pa_solver *s, int basisSize, int *flags, const int *i
       for (i = 0; i < basisSize; i++) if (iwork[i] != i) last = i + 1;
       s->numArbitraryVecs = PA_MAX(s->numArbitraryVecs, last);
    }
+#endif
    s->coef_valid_k = -1;
    free(iwork);
    return 0;
@@ -242,6 +244,7 @@ int pa_block_first_reorder(pa_solver *s, int basisSize, int *flags, const int *i
 #define PA_PLANNED 7701     /* dry run of the restart: stopped where the pass would start */
 #define PA_PLAN_NONE 7702   /* dry run: this restart is not one the speculative pass covers */
 
+#if !PA_IS_COMPLEX      /* the fused / speculative restart is real-arithmetic code (block size 1, eigs_conv.c) */
 /* ---- fused restart ------------------------------------------------------
  * The convergence check at a full basis left the candidate's residual in T(:,2) and its overlaps with
  * the old basis in s->rst_ov (eigs_conv.c).  When the restart keeps that candidate as the next block and
@@ -288,6 +291,8 @@ static int stash_transform(pa_solver *s, int basisSize, int rs, int nLk) {
    return 0;
 }
 
+#endif
+
 static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, int ldh,
       int *restartPerm, int *flags, int *iev, int *ievSize, double *blockNorms, double *evals,
       double *resNorms, int *numConverged, int numPrevRetained, int *indexOfPreviousVecs,
@@ -322,8 +327,9 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
       if (k >= *numConverged || flags[i] == UNCONV) restartPerm[*numConverged + j++] = i;
       else restartPerm[k++] = i;
    }
-   pa_permute_cols(s->hVals, 1, basisSize, 1, restartPerm);
+   pa_permute_reals(s->hVals, 1, basisSize, 1, restartPerm);
    pa_permute_cols(s->hVecs, basisSize, basisSize, ldh, restartPerm);
+#if !PA_IS_COMPLEX
    if (s->plan_only) {        /* dry run (see restart_locking): the candidate is column numConverged */
       const int rs0 = *restartSize, K = s->K, nc0 = *numConverged;
       if (*ievSize != 1 || rs0 > 16 || rs0 + 1 > K || !s->h_coef2 || nc0 >= rs0) return PA_PLAN_NONE;
@@ -361,6 +367,8 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
             if (hVecsPerm[j] == *numConverged + i) iev[i] = j;
       return 0;
    }
+#endif
+   s->coef_valid_k = -1;
    CHK(pa_push_coefficients(s, basisSize, ldh));
 
    /* one pass: V, W <- V h, W h (in place); X, R for the next block; converged
@@ -374,17 +382,23 @@ static int restart_soft_locking(pa_solver *s, int *restartSize, int basisSize, i
       for (int c = 0; c < nb; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, nc + c, VCOL(s, rs + c), -1};
    for (int c = 0; c < nc; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, ECOL(s, p->numOrthoConst + c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
+#if PA_IS_COMPLEX
+   const int use_stash = 0;
+#else
    const int use_stash = (nb == 1 && s->fuse_gd && stash_matches(s, basisSize, ldh, nc, p->numOrthoConst));
+#endif
    if (!use_stash)
       for (int c = 0; c < nb; c++)
          jobs[nj++] = (hipk_job){HIPK_JOB_RES, nc + c, s->fuse_gd ? VCOL(s, rs + c) : WCOL(s, rs + c), c};
    int rc = pa_ritz_update(s, basisSize, jobs, nj, blockNorms, use_stash ? 0 : nb, (int64_t)2 * rs + 2 * nb + nc);
    free(jobs);
    if (rc) return rc;
+#if !PA_IS_COMPLEX
    if (use_stash) {
       blockNorms[0] = sqrt(s->rst_ov[basisSize + p->numOrthoConst]);
       CHK(stash_transform(s, basisSize, rs, p->numOrthoConst));
    }
+#endif
    CHK(refresh_gram_after_restart(s, p->numOrthoConst, basisSize, rs, ldh));
 
    for (i = 0; i < basisSize; i++) hVecsPerm[restartPerm[i]] = i;
@@ -422,8 +436,9 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
    }
    *restartSize = left + numPacked;
 
-   pa_permute_cols(s->hVals, 1, basisSize, 1, restartPerm);
+   pa_permute_reals(s->hVals, 1, basisSize, 1, restartPerm);
    pa_permute_cols(s->hVecs, basisSize, basisSize, ldh, restartPerm);
+#if !PA_IS_COMPLEX
    if (s->plan_only) {
       /* dry run: this is the coefficient block the pass would get.  One more column, a unit vector, makes the
        * pass copy W(:,k-1) next to the residual (its inner products with Q are needed, eigs_conv.c) */
@@ -447,6 +462,9 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
          if (memcmp(s->hVecs + (size_t)c * ldh, s->h_coef2 + (size_t)c * s->K, (size_t)basisSize * sizeof(double))) use_plan = 0;
    }
    s->pl_launched = 0;
+#else
+   const int use_plan = 0;
+#endif
    s->coef_valid_k = -1;
    if (!use_plan) CHK(pa_push_coefficients(s, basisSize, ldh));
 
@@ -463,6 +481,7 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
       for (int c = 0; c < sizeBlockNorms; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, X, s->ld, c), -1};
    for (int c = 0; c < numPacked; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, left + c, ECOL(s, *numLocked + nOC + c), -1};
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XW, c, WCOL(s, c), -1};
+#if !PA_IS_COMPLEX
    if (use_plan) {
       /* nothing to run: V2 / W2 hold V h, W h; the residual is in T(:,2); rst_c has its overlaps */
       char *t = s->V; s->V = s->V2; s->V2 = t;
@@ -476,6 +495,9 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
    const int use_stash = use_plan || (sizeBlockNorms == 1 && numPacked == 0 && s->fuse_gd &&
                           stash_matches(s, basisSize, ldh, 0, nOC + *numLocked));
    if (use_plan) goto pass_done;
+#else
+   const int use_stash = 0;
+#endif
    if (!use_stash)
       for (int c = 0; c < sizeBlockNorms; c++)
          jobs[nj++] = (hipk_job){HIPK_JOB_RES, c, s->fuse_gd ? PCOL(s, X, s->ld, c) : PCOL(s, R, s->ld, c), c};
@@ -484,16 +506,20 @@ static int restart_locking(pa_solver *s, int *restartSize, int basisSize, int ld
          (int64_t)2 * rs + 2 * sizeBlockNorms + 2 * numPacked);
    free(jobs);
    if (rc) { free(norms); return rc; }
+#if !PA_IS_COMPLEX
    if (use_stash) {
       norms[0] = sqrt(s->rst_ov[basisSize + nOC + *numLocked]);
       rc = stash_transform(s, basisSize, rs, nOC + *numLocked);
       if (rc) { free(norms); return rc; }
    }
+#endif
    for (int c = 0; c < sizeBlockNorms; c++) blockNorms[c] = norms[c];
    for (int c = 0; c < numPacked; c++)
       lockedResNorms[c] = PA_MAX(norms[sizeBlockNorms + c], p->stats.estimateResidualError);
    free(norms);
+#if !PA_IS_COMPLEX
 pass_done:
+#endif
 
    CHK(refresh_gram_after_restart(s, *numLocked + nOC, basisSize, rs, ldh));
 
@@ -579,14 +605,14 @@ pass_done:
 
    /* the same compaction on the host-side coefficient data */
    {
-      double *tmp = (double *)malloc((size_t)basisSize * (failed > 0 ? failed : 1) * sizeof(double));
+      HS *tmp = (HS *)malloc((size_t)basisSize * (failed > 0 ? failed : 1) * sizeof(HS));
       double *tv = (double *)malloc((size_t)(failed > 0 ? failed : 1) * sizeof(double));
       for (i = 0; i < failed; i++) {
-         memcpy(tmp + (size_t)i * basisSize, s->hVecs + (size_t)(left + ifailed[i]) * ldh, (size_t)basisSize * sizeof(double));
+         memcpy(tmp + (size_t)i * basisSize, s->hVecs + (size_t)(left + ifailed[i]) * ldh, (size_t)basisSize * sizeof(HS));
          tv[i] = s->hVals[left + ifailed[i]];
       }
       for (i = 0; i < failed; i++) {
-         memcpy(s->hVecs + (size_t)(left + i) * ldh, tmp + (size_t)i * basisSize, (size_t)basisSize * sizeof(double));
+         memcpy(s->hVecs + (size_t)(left + i) * ldh, tmp + (size_t)i * basisSize, (size_t)basisSize * sizeof(HS));
          s->hVals[left + i] = tv[i];
       }
       free(tmp);
@@ -598,7 +624,7 @@ pass_done:
        * failed ones (reference restart.c:1092-1117) */
       const int nLk = nOC + *numLocked, tot = left + numPacked, nG = nLk + tot, ldG = s->ldVtBV;
       int *iV = (int *)malloc((size_t)(tot > 0 ? tot : 1) * sizeof(int));
-      double *rw = (double *)malloc((size_t)nG * (tot > 0 ? tot : 1) * sizeof(double));
+      HS *rw = (HS *)malloc((size_t)nG * (tot > 0 ? tot : 1) * sizeof(HS));
       for (i = 0; i < numPacked - failed; i++) iV[i] = ifailed[failed + i] + left;
       for (i = 0; i < left; i++) iV[i + numPacked - failed] = i;
       for (i = 0; i < failed; i++) iV[i + left + numPacked - failed] = ifailed[i] + left;
@@ -610,13 +636,13 @@ pass_done:
       }
       free(iV); free(rw);
       /* H: failed rows/columns right after the restarted ones (reference :1119-1124) */
-      double *hc = (double *)malloc((size_t)(tot > 0 ? tot : 1) * (failed > 0 ? failed : 1) * sizeof(double));
+      HS *hc = (HS *)malloc((size_t)(tot > 0 ? tot : 1) * (failed > 0 ? failed : 1) * sizeof(HS));
       for (int c = 0; c < failed; c++)
          for (int r2 = 0; r2 < tot; r2++) hc[r2 + (size_t)c * tot] = s->H[r2 + (size_t)(left + ifailed[c]) * s->K];
       for (int c = 0; c < failed; c++)
          for (int r2 = 0; r2 < tot; r2++) s->H[r2 + (size_t)(left + c) * s->K] = hc[r2 + (size_t)c * tot];
       for (int c = 0; c < left + failed; c++) {
-         double tmpc[64];
+         HS tmpc[64];
          for (int r2 = 0; r2 < failed && r2 < 64; r2++) tmpc[r2] = s->H[(left + ifailed[r2]) + (size_t)c * s->K];
          for (int r2 = 0; r2 < failed && r2 < 64; r2++) s->H[(left + r2) + (size_t)c * s->K] = tmpc[r2];
       }
@@ -687,7 +713,7 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
    int indexOfPreviousVecs = p->locking ? restartSize + *numConverged - *numLocked : restartSize;
    const int indexOfPreviousVecsBeforeRestart = indexOfPreviousVecs;
    const int nLocked = p->numOrthoConst + *numLocked;
-   const double *G = s->VtBV ? s->VtBV + (size_t)nLocked * s->ldVtBV + nLocked : NULL;
+   const HS *G = s->VtBV ? s->VtBV + (size_t)nLocked * s->ldVtBV + nLocked : NULL;
    CHK(ortho_coefficient_vectors(s, basisSize, ldh, indexOfPreviousVecs, G, s->ldVtBV, nprevhVecs, flags,
          &numPrevRetained));
 
@@ -713,14 +739,15 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
    if (p->target != primme_smallest && p->target != primme_largest) {
       if (s->numPrevRitzVals > 0) {
          for (i = s->numPrevRitzVals; i < basisSize; i++) s->prevRitzVals[i] = s->prevRitzVals[s->numPrevRitzVals - 1];
-         pa_permute_cols(s->prevRitzVals, 1, basisSize, 1, restartPerm);
+         pa_permute_reals(s->prevRitzVals, 1, basisSize, 1, restartPerm);
       }
       for (i = 0; i < restartSize; i++)
          if (restartPerm[i] >= s->numPrevRitzVals) s->prevRitzVals[i] = s->hVals[i];
-      pa_permute_cols(s->prevRitzVals, 1, restartSize, 1, hVecsPerm);
+      pa_permute_reals(s->prevRitzVals, 1, restartSize, 1, hVecsPerm);
       s->numPrevRitzVals = restartSize;
    }
 
+#if !PA_IS_COMPLEX
    if (s->refined) {
       rc = pa_restart_refined(s, ldh, restartSize, basisSize, *numConverged, numPrevRetained, indexOfPreviousVecs,
             indexOfPreviousVecsBeforeRestart, restartPerm, hVecsPerm, &s->numArbitraryVecs);
@@ -735,6 +762,7 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       rc = pa_restart_harmonic(s, ldh, restartSize, basisSize, *numConverged);
       if (!rc) rc = pa_solve_H(s, restartSize, p->locking ? *numConverged : 0, *numConverged);
    } else
+#endif
    rc = restart_RR(s, ldh, restartSize, restartSize, basisSize, *numConverged, numPrevRetained,
          indexOfPreviousVecs, hVecsPerm);
    free(restartPerm);
@@ -767,8 +795,8 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       double acc = 0.0;
       for (int c = 0; c < nG; c++)
          for (int r2 = 0; r2 < c; r2++) {
-            const double g = s->VtBV[r2 + (size_t)c * ldG];
-            acc += 2 * g * g / fabs(s->VtBV[c + (size_t)c * ldG]) / fabs(s->VtBV[r2 + (size_t)r2 * ldG]);
+            const double g2 = HS_ABS2(s->VtBV[r2 + (size_t)c * ldG]);
+            acc += 2 * g2 / HS_ABS(s->VtBV[c + (size_t)c * ldG]) / HS_ABS(s->VtBV[r2 + (size_t)r2 * ldG]);
          }
       fn = sqrt(acc);
    }
@@ -780,6 +808,7 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       p->stats.estimateResidualError =
             2 * sqrt((double)*restartsSinceReset) * s->mach_eps * pa_problem_norm(1, p);
    }
+#if !PA_IS_COMPLEX
    if (s->rst_ready && restartSize == s->rst_rs && *ievSize == 1 && restartSize + 1 <= p->maxBasisSize && numGuesses <= 0) {
       /* first iteration after the restart: Gram-Schmidt update, operator and the new column of H from the
        * transformed overlaps; the residual is still in T(:,2), the normalised vector lands in V(:,restartSize) */
@@ -795,9 +824,12 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
        * residual job would have left it */
       CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 2), s->ld, VCOL(s, s->rst_rs), s->ld, 1));
    }
+#endif
    s->rst_ready = 0;
    return 0;
 }
+
+#if !PA_IS_COMPLEX
 
 /* Dry run of what the main loop and pa_restart do between the convergence check at a full basis and the restart
  * pass, under the assumption that the candidate iev_in[nblock-1] is NOT converged: on success (0) h_coef2 /
@@ -845,3 +877,4 @@ int pa_restart_plan(pa_solver *s, int basisSize, const int *flags_in, const int 
    free(sv); free(fl);
    return rc == PA_PLANNED ? 0 : 1;
 }
+#endif

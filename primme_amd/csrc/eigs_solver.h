@@ -37,9 +37,9 @@ typedef struct pa_solver {
    char *T;                /* scratch, m x nT */
    /* harmonic extraction: (A - tau I) V = Q R, with Q in HBM, R / Q'V / left vectors on the host */
    char *Q;
-   double *R, *QtV, *hU;
+   HS *R, *QtV, *hU;       /* (harmonic / refined extraction: real objects only) */
    int refined;            /* refined extraction: singular triplets of R instead of Q'V */
-   double *hSVals, *hVecsRot;
+   double *hSVals; HS *hVecsRot;
    int numArbitraryVecs;   /* leading columns of hVecs that are Rayleigh-Ritz vectors of a cluster */
    /* K^-1-weighted (skew) right projector of the correction equation: evecsHat = K^-1 evecs for
     * the stored converged / constraint vectors, M = evecs' evecsHat and its LU factors (host) */
@@ -60,9 +60,10 @@ typedef struct pa_solver {
    /* pinned host mirrors */
    double *h_red, *h_coef, *h_theta;
 
-   /* projected problem (host) */
-   double *H, *hVecs, *prevhVecs, *hVals, *prevRitzVals;
-   double *VtBV, *fVtBV;   /* explicit_I only */
+   /* projected problem (host); HS = double, or double complex in the complex objects (eigs_scalar.h) */
+   HS *H, *hVecs, *prevhVecs;
+   double *hVals, *prevRitzVals;
+   HS *VtBV, *fVtBV;       /* explicit_I only */
    int ldVtBV;
    double *blockNorms, *basisNorms;
    int *flags, *map, *iev, *perm, *lockedFlags;
