@@ -24,7 +24,7 @@ struct primme_amd_operator {
                                 callbacks are handed leading dimensions in complex elements */
 };
 
-static size_t op_elem(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : dt == HIPK_F32 ? 4 : 16; }
+static size_t op_elem(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : dt == HIPK_F32 ? 4 : dt == HIPK_C64 ? 16 : 8; }
 
 extern "C" int primme_amd_operator_create(primme_amd_operator **out, hipk_csr *A, primme_amd_comm *comm) {
    primme_amd_operator *op = (primme_amd_operator *)calloc(1, sizeof(*op));

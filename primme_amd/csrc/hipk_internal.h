@@ -131,6 +131,23 @@ static inline int hipk_grid_for_rows(const hipk_ctx *ctx, int64_t m, int rows_pe
    return (int)(need < cap ? need : cap);
 }
 
+/* ---- the complex instantiation (hipk_complex.hip); the entry points of the real files dispatch here ---- */
+#define HIPK_IS_Z(dt) ((dt) == HIPK_C64 || (dt) == HIPK_C32)
+static inline hipk_dtype hipk_real_of(hipk_dtype dt) { return dt == HIPK_C64 ? HIPK_F64 : dt == HIPK_C32 ? HIPK_F32 : dt; }
+int hipk_z_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg, const void *X, int64_t ldX, int nx,
+      double *out_dev, int ldout);
+int hipk_z_panel_project(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg, const double *coef, int ldcoef,
+      const double *M, const void *X, int64_t ldX, void *Xout, int64_t ldXout, int nx, double *nrm2_dev);
+int hipk_z_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W, int64_t ld, int k, const double *h, int ldh,
+      const double *theta, const hipk_job *jobs, int njobs, double *nrm2_dev);
+int hipk_z_axpy(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host, const void *X, int64_t ldX, void *Y, int64_t ldY, int nx, int xpay);
+int hipk_z_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *Y, int64_t ldY, int nx, double *out_dev);
+int hipk_z_csr_matvec(hipk_dtype dt, hipStream_t st, const int4 *tileinfo, int ntiles, const int32_t *rowptr, const int32_t *colind, const void *val,
+      const void *x, int64_t ldx, void *y, int64_t ldy, int ncols, int64_t x0, int64_t xlen, int64_t halo_lo, int64_t halo_hi, const void *xlo,
+      const void *xhi, int64_t ld_lo, int64_t ld_hi, const double *shift_host);
+int hipk_z_jacobi(hipStream_t st, int num_cu, hipk_dtype dt, int64_t m, const void *diag, const double *shift_host, double min_den, const void *x,
+      int64_t ldx, void *y, int64_t ldy, int ncols);
+
 #ifdef __HIPCC__
 /* ---- scalar traits: real types now; complex panels use the same kernels ------ */
 template <typename T> struct hipk_num;

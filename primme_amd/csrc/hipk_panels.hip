@@ -401,6 +401,7 @@ static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X,
 
 extern "C" int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs,
       int nseg, const void *X, int64_t ldX, int nx, double *out_dev, int ldout) {
+   if (HIPK_IS_Z(dt)) return hipk_z_panel_dots(ctx, dt, m, segs, nseg, X, ldX, nx, out_dev, ldout);
    SegArgs sa;
    if (pack_segs(segs, nseg, &sa)) return -1;
    if (sa.total == 0 || nx <= 0) return 0;
@@ -616,6 +617,7 @@ static int panel_project_mul_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, cons
 /* X <- (X - [segs] coef) M; returns 1 when the shape is not covered (caller uses the two-pass form) */
 extern "C" int hipk_panel_project_mul(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg,
       const double *coef_dev, int ldcoef, const double *M_dev, void *X, int64_t ldX, int nx) {
+   if (HIPK_IS_Z(dt)) return hipk_z_panel_project(ctx, dt, m, segs, nseg, coef_dev, ldcoef, M_dev, X, ldX, X, ldX, nx, NULL);
    SegArgs sa;
    if (pack_segs(segs, nseg, &sa)) return -1;
    if (nx <= 0) return 0;
@@ -670,6 +672,7 @@ static int panel_project_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
 extern "C" int hipk_panel_project_to(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs,
       int nseg, const double *coef_dev, int ldcoef, const void *X, int64_t ldX, void *Xout, int64_t ldXout,
       int nx, double *nrm2_dev) {
+   if (HIPK_IS_Z(dt)) return hipk_z_panel_project(ctx, dt, m, segs, nseg, coef_dev, ldcoef, NULL, X, ldX, Xout, ldXout, nx, nrm2_dev);
    SegArgs sa;
    if (pack_segs(segs, nseg, &sa)) return -1;
    if (nx <= 0) return 0;
@@ -986,6 +989,7 @@ static int ritz_update_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64
 extern "C" int hipk_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V,
       const void *W, int64_t ldVW, int k, const double *h_dev, int ldh,
       const double *theta_dev, const hipk_job *jobs, int njobs, double *nrm2_dev) {
+   if (HIPK_IS_Z(dt)) return hipk_z_ritz_update(ctx, dt, m, V, W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev);
    switch (dt) {
    case HIPK_F64: return ritz_update_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev);
    case HIPK_F32: return ritz_update_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, h_dev, ldh, theta_dev, jobs, njobs, nrm2_dev);
@@ -1771,6 +1775,8 @@ axpy_proj_dot_kernel(ColScal alpha, ColScal xr, const T *__restrict__ Wv, int64_
 
 extern "C" int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX,
       int nx, const double *alpha_host) {
+   /* real factors on complex columns: the real kernel on the panel seen as 2m reals */
+   if (HIPK_IS_Z(dt)) return hipk_scale_cols(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, nx, alpha_host);
    for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
       int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
       ColScal sc;
@@ -1787,6 +1793,7 @@ extern "C" int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X,
 extern "C" int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX,
       int nx, const double *norm2_dev) {
    if (nx <= 0) return 0;
+   if (HIPK_IS_Z(dt)) return hipk_scale_cols_rsqrt_dev(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, nx, norm2_dev);
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
    DISPATCH_RT(dt,
          hipLaunchKernelGGL(scale_rsqrt_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (T *)X, ldX, nx, norm2_dev, m),
@@ -1797,6 +1804,7 @@ extern "C" int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m
 
 extern "C" int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
       const void *X, int64_t ldX, void *Y, int64_t ldY, int nx) {
+   if (HIPK_IS_Z(dt)) return hipk_z_axpy(ctx, dt, m, alpha_host, X, ldX, Y, ldY, nx, 0);      /* (re, im) factors */
    for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
       int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
       ColScal sc;
@@ -1862,6 +1870,7 @@ extern "C" int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const voi
 
 extern "C" int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
       int64_t ldX, const int *perm_host, int n, void *Y, int64_t ldY) {
+   if (HIPK_IS_Z(dt)) return hipk_gather_cols(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, perm_host, n, Y, 2 * ldY);
    for (int c0 = 0; c0 < n; c0 += UTIL_MAXCOLS) {
       int nn = n - c0 < UTIL_MAXCOLS ? n - c0 : UTIL_MAXCOLS;
       ColPerm pm;
@@ -1878,6 +1887,7 @@ extern "C" int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
 extern "C" int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
       int64_t ldX, int nx, double *out_dev) {
    if (nx <= 0) return 0;
+   if (HIPK_IS_Z(dt)) return hipk_col_norms2(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, nx, out_dev);   /* |z|^2 = re^2 + im^2 */
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
    if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
    DISPATCH_RT(dt,
@@ -1889,6 +1899,7 @@ extern "C" int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const vo
 
 extern "C" int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
       int64_t ldX, void *Wr, int64_t ldW, int nx, const double *theta_host, double *nrm2_dev) {
+   if (HIPK_IS_Z(dt)) return hipk_residual_cols(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, Wr, 2 * ldW, nx, theta_host, nrm2_dev);   /* theta is real */
    const size_t es = (dt == HIPK_F64) ? 8 : 4;
    for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
       const int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
@@ -1911,6 +1922,7 @@ extern "C" int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const
 extern "C" int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX,
       const void *Y, int64_t ldY, int nx, double *out_dev) {
    if (nx <= 0) return 0;
+   if (HIPK_IS_Z(dt)) return hipk_z_pair_dots(ctx, dt, m, X, ldX, Y, ldY, nx, out_dev);
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
    if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
    DISPATCH_RT(dt,
@@ -1922,6 +1934,7 @@ extern "C" int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const voi
 
 extern "C" int hipk_xpay_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
       const void *X, int64_t ldX, void *Y, int64_t ldY, int nx) {
+   if (HIPK_IS_Z(dt)) return hipk_z_axpy(ctx, dt, m, alpha_host, X, ldX, Y, ldY, nx, 1);
    for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
       int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
       ColScal sc;

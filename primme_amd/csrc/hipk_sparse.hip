@@ -482,7 +482,7 @@ static size_t elem_size(hipk_dtype dt) {
 static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
       int64_t ncols_global, int64_t row0, int64_t x0, int64_t xlen, const int32_t *rowptr_host,
       const int32_t *colind_host, const void *values_host, hipk_csr **out) {
-   if (dt != HIPK_F64 && dt != HIPK_F32) return -44;
+   if (dt != HIPK_F64 && dt != HIPK_F32 && dt != HIPK_C64 && dt != HIPK_C32) return -44;
    if (nrows_local >= ((int64_t)1 << 31)) return -1;
    hipk_csr *A = (hipk_csr *)calloc(1, sizeof(hipk_csr));
    if (!A) return -2;
@@ -694,10 +694,32 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
    return 0;
 }
 
+/* complex matrices: the row-tile kernel of hipk_complex.hip (blocks of up to 64 columns per launch) */
+static int csr_matvec_z(hipk_csr *A, hipStream_t st, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols, const double *shift_host) {
+   if (A->kind != 0) return -44;
+   if ((A->halo_lo > 0 && !A->xlo) || (A->halo_hi > 0 && !A->xhi)) {
+      fprintf(stderr, "primme_amd: matvec needs halo data (rows outside the local slab) but none was set\n");
+      return -1;
+   }
+   const size_t es = A->dt == HIPK_C64 ? 16 : 8;
+   const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 2.0 * A->nrows * es * ncols);
+   int rc = 0;
+   for (int c0 = 0; c0 < ncols && !rc; c0 += 64) {
+      const int nc = ncols - c0 < 64 ? ncols - c0 : 64;
+      rc = hipk_z_csr_matvec(A->dt, st, A->tileinfo, A->ntiles, A->rowptr, A->colind, A->values, (const char *)x + (size_t)c0 * ldx * es, ldx,
+            (char *)y + (size_t)c0 * ldy * es, ldy, nc, A->x0, A->xlen, A->halo_lo, A->halo_hi,
+            A->xlo ? (const char *)A->xlo + (size_t)c0 * A->ld_lo * es : NULL, A->xhi ? (const char *)A->xhi + (size_t)c0 * A->ld_hi * es : NULL,
+            A->ld_lo, A->ld_hi, shift_host ? shift_host + c0 : NULL);
+   }
+   hipk_prof_end(pslot, st);
+   return rc;
+}
+
 extern "C" int hipk_csr_matvec(hipk_csr *A, void *hip_stream, const void *x, int64_t ldx, void *y,
       int64_t ldy, int ncols) {
    if (ncols <= 0 || A->nrows == 0) return 0;
    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : A->ctx->stream;
+   if (HIPK_IS_Z(A->dt)) return csr_matvec_z(A, st, x, ldx, y, ldy, ncols, NULL);
    if (A->dt == HIPK_F64) return csr_matvec_t<double>(A, st, (const double *)x, ldx, (double *)y, ldy, ncols);
    return csr_matvec_t<float>(A, st, (const float *)x, ldx, (float *)y, ldy, ncols);
 }
@@ -709,6 +731,7 @@ extern "C" int hipk_csr_matvec_shifted(hipk_csr *A, void *hip_stream, const void
    if (ncols <= 0 || A->nrows == 0) return 0;
    if (A->kind != 0 || A->halo_lo != 0 || A->halo_hi != 0 || A->x0 != A->row0 || A->xlen != A->nrows || ncols > 64 || !shift_host) return 1;
    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : A->ctx->stream;
+   if (HIPK_IS_Z(A->dt)) return csr_matvec_z(A, st, x, ldx, y, ldy, ncols, shift_host);
    if (A->dt == HIPK_F64) return csr_matvec_t<double>(A, st, (const double *)x, ldx, (double *)y, ldy, ncols, shift_host);
    return csr_matvec_t<float>(A, st, (const float *)x, ldx, (float *)y, ldy, ncols, shift_host);
 }
@@ -720,6 +743,7 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    /* ctx: the CALLER's context (stream, reduction scratch, pinned mirror of the results) — the matrix may
     * have been created under another one */
    if (A->kind != 0 || A->x0 != A->row0 || A->xlen != A->nrows || x == xout || !ctx) return -1;
+   if (HIPK_IS_Z(A->dt)) return -44;           /* the fused tail is real-arithmetic code (eigs_scalar.h) */
    hipStream_t st = ctx->stream;
    if ((A->halo_lo > 0 && !A->xlo) || (A->halo_hi > 0 && !A->xhi)) return -1;
    if (A->nrows == 0) {      /* an empty slab: the result is 0; no flagged launch, so the next wait drains the stream */
@@ -749,7 +773,7 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
 }
 extern "C" int hipk_csr_kind(const hipk_csr *A) { return A->kind; }
 hipk_ctx *hipk_csr_ctx(const hipk_csr *A) { return A->ctx; }
-int hipk_csr_fusable(const hipk_csr *A) { return A && A->kind == 0 && A->x0 == A->row0 && A->xlen == A->nrows; }      /* library-internal (hipk_internal.h) */
+int hipk_csr_fusable(const hipk_csr *A) { return A && A->kind == 0 && A->x0 == A->row0 && A->xlen == A->nrows && !HIPK_IS_Z(A->dt); }      /* library-internal (hipk_internal.h) */
 extern "C" hipk_dtype hipk_csr_dtype(const hipk_csr *A) { return A->dt; }
 extern "C" int64_t hipk_csr_nrows(const hipk_csr *A) { return A->nrows; }
 
@@ -758,6 +782,11 @@ extern "C" int hipk_jacobi_apply(void *hip_stream, hipk_dtype dt, int64_t m, con
    if (ncols <= 0) return 0;
    if (!(min_den > 0.0)) min_den = 1e-300;
    if (ncols > 64) return -1;
+   if (HIPK_IS_Z(dt)) {
+      int dev = 0, ncu = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      return hipk_z_jacobi((hipStream_t)hip_stream, ncu > 0 ? ncu : 256, dt, m, diag, shift_host, min_den, x, ldx, y, ldy, ncols);
+   }
    JacShift sh;
    for (int c = 0; c < ncols; c++) sh.s[c] = shift_host ? shift_host[c] : 0.0;
    static int num_cu = 0;                      /* launch geometry only: read the device once */

@@ -1,6 +1,6 @@
 """BASELINE configs[3] on one GPU: complex Hermitian band matrix n = 4 M (half-bandwidth 3),
-6 largest, block size 4, GD+k, basis 20 / restart 8, through hip_zprimme (real-equivalent form,
-csrc/eigs_complex.c).  Writes gpurun_out/config4_run.json."""
+6 largest, block size 4, GD+k, basis 20 / restart 8, through hip_zprimme: natively on complex panels (default) or,
+with FORM=real, on the real-equivalent form (csrc/eigs_complex.c).  Writes gpurun_out/config4_run_<form>.json."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,8 @@ from checkers import Operator, Session
 
 n = int(os.environ.get("N", 4_000_000))
 rp, ci, va = problems.hermitian_banded_csr(n)
-s = Session(Operator(n, csr=(rp, ci, va)), dtype=np.complex128, backend="hip")
+form = os.environ.get("FORM", "native")          # native complex panels (default) | real: the real-equivalent form
+s = Session(Operator(n, csr=(rp, ci, va)), dtype=np.complex128, backend="hip", complex_form=form)
 out = []
 for rep in range(2):
     t = time.time()
@@ -25,5 +26,5 @@ for rep in range(2):
     print(out[-1], flush=True)
 s.close()
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(dict(workload=f"configs[3] hermitian band n={n} hbw=3, 6 largest, b=4, GD+k, one GPU, real-equivalent form", runs=out),
-          open("gpurun_out/config4_run.json", "w"), indent=1)
+json.dump(dict(workload=f"configs[3] hermitian band n={n} hbw=3, 6 largest, b=4, GD+k, one GPU, {form} form", runs=out),
+          open(f"gpurun_out/config4_run_{form}.json", "w"), indent=1)

@@ -7,7 +7,7 @@ from primme_amd import _ffi as F
 
 import checkers
 
-NPDT = {F.HIPK_F64: np.float64, F.HIPK_F32: np.float32}
+NPDT = {F.HIPK_F64: np.float64, F.HIPK_F32: np.float32, F.HIPK_C64: np.complex128, F.HIPK_C32: np.complex64}
 
 
 class DevArray:
