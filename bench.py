@@ -177,9 +177,11 @@ def main():
         traffic, tsrc = None, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pj.get("workload") == name and dom == 2 and world == 1:
+            pj = pj.get(name, pj if pj.get("workload") == name else {})
+            if pj.get("workload") == name and dom == 2 and world == 1 and pj.get("ritz_class_hbm_bytes_per_launch"):
+                # a figure from a SEPARATE profiled process (PMC counters cannot be read from inside this one): labelled so
                 traffic = round(pj["ritz_class_hbm_bytes_per_launch"])
-                tsrc = pj.get("source", "profiles/pmc_traffic.json (separate --pmc passes, bytes per launch)")
+                tsrc = "NOT measured in this run: " + pj.get("source", "profiles/pmc_traffic.json (separate --pmc passes, bytes per launch)")
         except Exception:
             pass
         # the inner loop the north star names: CSR SpMV + orthogonalisation (+ the fused residual /

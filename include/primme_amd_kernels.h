@@ -17,6 +17,15 @@
  *     Num_set_matrix/Num_get_matrix, cublas_wrapper.c:335-395).
  *   - dtype: element type of the panels.  Reductions accumulate and are returned
  *     in double (real) / double complex (complex), laid out as doubles.
+ *   - complex panels (HIPK_C64 / HIPK_C32, csrc/hipk_complex.hip; the reference's SCALAR = complex instantiation,
+ *     src/include/template_types.h:91): elements are interleaved (re, im) pairs and leading dimensions count complex
+ *     elements.  Every "accumulator scalar" argument — inner products (the left operand is conjugated: col_j^H X,
+ *     x^H y), projection coefficients, Ritz coefficient vectors, the M of hipk_panel_project_mul, the factors of
+ *     hipk_axpy_cols / hipk_xpay_cols — is a (re, im) pair of doubles with leading dimensions in pairs; Ritz values,
+ *     shifts, squared norms and the factors of hipk_scale_cols stay real.  Entry points that exist only for the
+ *     fused real block-size-1 iteration (hipk_ritz_residual_overlaps, hipk_ritz_update_overlaps,
+ *     hipk_csr_matvec_scaled), the stencil operator and the QMR kernels return -44 for complex dtypes: a complex
+ *     JDQMR / harmonic solve runs on the real-equivalent form (csrc/eigs_complex.c).
  *   - return 0 on success, PRIMME-style negative code otherwise.
  */
 #ifndef PRIMME_AMD_KERNELS_H

@@ -102,7 +102,7 @@ class ReferenceBackend:
         keep.append(cb)
         p.matrixMatvec = C.cast(cb, C.c_void_p)
         if precond is not None:
-            dg = op.diagonal()
+            dg = np.real(op.diagonal())        # Hermitian: the diagonal is real (divide by a real number, as the device kernel does)
             jfixed = None if precond == "jacobi" else float(precond[1])
 
             def pc(x, ldx, y, ldy, bs, pp, ierr):

@@ -77,44 +77,49 @@ static int zgrid(const hipk_ctx *ctx, int64_t m, int per_cu) {
 }
 
 /* ============================ TN panel: out = [segs]^H X =============================================
- * Each lane keeps JT x NX complex accumulators: a row of NX right-hand columns is loaded once per tile of JT
- * basis columns (grid.y = tiles).  partials[o * nblocks + block] with o = 2 (j + c * tot) + {re, im}. */
-template <typename R, int NX, int JT>
+ * Column-split (like the real ritz_cgs_kernel): the four waves of a workgroup walk the SAME rows, wave w owns basis
+ * columns [j0 + w CPW, j0 + (w + 1) CPW) and keeps CPW x NX complex accumulators per lane.  Every basis column is read
+ * once; the NX right-hand columns are requested by all four waves but come out of HBM once per workgroup (the other
+ * three requests hit the CU's L1 / the XCD's L2).  blockIdx.y = group of 4 CPW basis columns.  No cross-wave
+ * reduction: a wave's lanes are summed with shuffles and lane 0 stores partials[o * nblocks + block],
+ * o = 2 (j + c * tot) + {re, im}. */
+template <typename R, int NX, int CPW>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 zdots_kernel(ZSegs sa, const cpx<R> *__restrict__ X, int64_t ldX, int nx, int c0, int64_t m, int tot,
       double *__restrict__ partials) {
-   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
-   const int j0 = blockIdx.y * JT;
-   const cpx<R> *col[JT];
+   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const int j0 = blockIdx.y * (4 * CPW) + wave * CPW;
+   const cpx<R> *col[CPW];
 #pragma unroll
-   for (int t = 0; t < JT; t++) col[t] = zseg_col<R>(sa, j0 + t < tot ? j0 + t : tot - 1);
+   for (int t = 0; t < CPW; t++) col[t] = zseg_col<R>(sa, j0 + t < tot ? j0 + t : tot - 1);
    const int nxv = min(NX, nx - c0);
-   zacc acc[JT][NX];
+   zacc acc[CPW][NX];
 #pragma unroll
-   for (int t = 0; t < JT; t++)
+   for (int t = 0; t < CPW; t++)
 #pragma unroll
       for (int c = 0; c < NX; c++) acc[t][c] = {0.0, 0.0};
-   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
-   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
-      zacc xv[NX];
+   const int64_t stride = (int64_t)gridDim.x * 64;
+   if (j0 < tot) {
+      for (int64_t i = (int64_t)blockIdx.x * 64 + lane; i < m; i += stride) {
+         zacc xv[NX];
 #pragma unroll
-      for (int c = 0; c < NX; c++) xv[c] = zload(X + (size_t)(c0 + (c < nxv ? c : 0)) * ldX + i);
-      zacc av[JT];
+         for (int c = 0; c < NX; c++) xv[c] = zload(X + (size_t)(c0 + (c < nxv ? c : 0)) * ldX + i);
+         zacc av[CPW];
 #pragma unroll
-      for (int t = 0; t < JT; t++) av[t] = zload(col[t] + i);
+         for (int t = 0; t < CPW; t++) av[t] = zload(col[t] + i);
 #pragma unroll
-      for (int t = 0; t < JT; t++)
+         for (int t = 0; t < CPW; t++)
 #pragma unroll
-         for (int c = 0; c < NX; c++) zfma_conj(acc[t][c], av[t], xv[c]);
+            for (int c = 0; c < NX; c++) zfma_conj(acc[t][c], av[t], xv[c]);
+      }
    }
    const unsigned nb = gridDim.x;
 #pragma unroll
-   for (int t = 0; t < JT; t++)
+   for (int t = 0; t < CPW; t++)
 #pragma unroll
       for (int c = 0; c < NX; c++) {
-         const double re = zblock_sum(acc[t][c].re, sm);
-         const double im = zblock_sum(acc[t][c].im, sm);
-         if (threadIdx.x == 0 && j0 + t < tot && c < nxv) {
+         const double re = hipk_wave_sum(acc[t][c].re), im = hipk_wave_sum(acc[t][c].im);
+         if (lane == 0 && j0 + t < tot && c < nxv) {
             const size_t o = 2 * ((size_t)(j0 + t) + (size_t)(c0 + c) * tot);
             partials[o * nb + blockIdx.x] = re;
             partials[(o + 1) * nb + blockIdx.x] = im;
@@ -125,18 +130,22 @@ zdots_kernel(ZSegs sa, const cpx<R> *__restrict__ X, int64_t ldX, int nx, int c0
 template <typename R>
 static int zpanel_dots_t(hipk_ctx *ctx, int64_t m, const ZSegs &sa, const void *X, int64_t ldX, int nx, double *out_dev, int ldout) {
    const int tot = sa.total;
-   const int gx = zgrid(ctx, m, 2);
+   int64_t need = (m + 63) / 64;
+   if (need < 1) need = 1;
+   const int gx = (int)(need < (int64_t)ctx->num_cu * 4 ? need : (int64_t)ctx->num_cu * 4);     /* a workgroup walks 64 rows per step */
    const size_t nout = 2 * (size_t)tot * nx;
    if (hipk_reserve_partials(ctx, nout * gx)) return -2;
    const int pslot = hipk_prof_begin(HIPK_PROF_DOTS, ctx->stream, (double)(tot + nx) * (double)m * 2.0 * sizeof(R));
    for (int c0 = 0; c0 < nx; c0 += 8) {
       const int nc = nx - c0;
-#define ZD(NXV, JTV) hipLaunchKernelGGL((zdots_kernel<R, NXV, JTV>), dim3(gx, (tot + JTV - 1) / JTV), dim3(HIPK_BLOCK), 0, ctx->stream, \
+      /* columns per wave: as many as the accumulators allow (CPW * NX <= 32 complex = 64 doubles), no more than needed */
+      const int want = (tot + 3) / 4;
+#define ZD(NXV, CPWV) hipLaunchKernelGGL((zdots_kernel<R, NXV, CPWV>), dim3(gx, (tot + 4 * CPWV - 1) / (4 * CPWV)), dim3(HIPK_BLOCK), 0, ctx->stream, \
             sa, (const cpx<R> *)X, ldX, nx, c0, m, tot, ctx->partials)
-      if (nc == 1) ZD(1, 8);
-      else if (nc == 2) ZD(2, 8);
-      else if (nc <= 4) ZD(4, 4);
-      else ZD(8, 2);
+      if (nc == 1) { if (want <= 2) ZD(1, 2); else if (want <= 4) ZD(1, 4); else if (want <= 8) ZD(1, 8); else ZD(1, 16); }
+      else if (nc == 2) { if (want <= 2) ZD(2, 2); else if (want <= 4) ZD(2, 4); else ZD(2, 8); }
+      else if (nc <= 4) { if (want <= 2) ZD(4, 2); else if (want <= 4) ZD(4, 4); else ZD(4, 8); }
+      else { if (want <= 2) ZD(8, 2); else ZD(8, 4); }
 #undef ZD
    }
    hipk_prof_end(pslot, ctx->stream);

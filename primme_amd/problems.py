@@ -167,6 +167,29 @@ def svds_synthetic_csr(m, n, row0=0, nrows=None):
     return rowptr.astype(np.int32), cols[keep].astype(np.int32), vals[keep]
 
 
+def hermitian_graded_csr(n, hbw=3):
+    """Closed-form complex Hermitian band matrix with a graded diagonal (well separated extremal eigenvalues: the
+    parity fixtures of the native complex path): d_j = 0.05 (j + 1) + sin(j), a_{j,j+q} = 0.3 exp(0.37 i q (1 + j mod 3)) / (q + 1)."""
+    j = np.arange(n, dtype=np.int64)
+    offs = np.arange(-hbw, hbw + 1)
+    cols = j[:, None] + offs[None, :]
+    ok = (cols >= 0) & (cols < n)
+    vals = np.zeros(cols.shape, dtype=np.complex128)
+    for t, o in enumerate(offs):
+        q = abs(int(o))
+        lo = np.minimum(j, j + o)                      # the entry belongs to the pair (lo, lo + q)
+        ph = np.exp(0.37j * q * (1 + lo % 3)) * 0.3 / (q + 1.0)
+        vals[:, t] = ph if o > 0 else (np.conj(ph) if o < 0 else 0.05 * (j + 1) + np.sin(j))
+    rp = np.zeros(n + 1, dtype=np.int64)
+    rp[1:] = np.cumsum(ok.sum(axis=1))
+    return rp.astype(np.int32), cols[ok].astype(np.int32), vals[ok]
+
+
+def complex_start_vector(n):
+    """start_vector with a closed-form phase per entry (complex parity runs)."""
+    return start_vector(n) * np.exp(0.1j * np.arange(n))
+
+
 def hermitian_banded_csr(n, row0=0, nrows=None, hbw=3):
     """BASELINE configs[3]: complex Hermitian band matrix, diagonal
     d_j = 2 + (j mod 97)/97, off-diagonals a_{j,j+q} = exp(0.37 i q)/(q+1), q = 1..hbw.

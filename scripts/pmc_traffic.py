@@ -2,7 +2,9 @@
 --kernel-trace only), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: the counters report KiB and
 FETCH_SIZE counts half of the bytes of a wide coalesced streaming read (x2).  Writes the per-kernel table and the
 launch-weighted figure of the dominant (ritz) class that bench.py reports as roofline.traffic.
-usage: python scripts/pmc_traffic.py <fetch.db> <write.db> <out.md> <out.json> [bench_line.json] [tag]"""
+usage: python scripts/pmc_traffic.py <fetch.db> <write.db> <out.md> <out.json> [bench_line.json] [tag] [workload]
+out.json is a dictionary keyed by workload (lap3d_2m = BASELINE configs[1], lap2d_10m = the north-star workload); an
+existing file is updated, not replaced."""
 import json, re, sqlite3, sys
 
 def load(path, ctr):
@@ -12,15 +14,17 @@ def load(path, ctr):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 tag = sys.argv[6] if len(sys.argv) > 6 else "r02"
+workload = sys.argv[7] if len(sys.argv) > 7 else "lap3d_2m"
 alg = None
 if len(sys.argv) > 5:
     try:
-        alg = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])["roofline"]["alg_bytes_per_launch"]
+        bl = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
+        alg = (bl["roofline"] if workload == "lap3d_2m" else bl["north_star"]["roofline"])["alg_bytes_per_launch"]
     except Exception:
         alg = None
-lines = [f"# {tag} — HBM traffic from PMC counters (BASELINE configs[1], one solve, separate --pmc passes)", "",
+lines = [f"# {tag} — HBM traffic from PMC counters ({'BASELINE configs[1]' if workload == 'lap3d_2m' else 'north-star workload lap2d_10m, first outer iterations'}, one solve, separate --pmc passes)", "",
          "Collected by `scripts/profile_round.sh` with `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `rocprofv3 --pmc WRITE_SIZE --kernel-trace`",
-         "on `python scripts/one_solve.py csr` (gpurun, 1xMI355X).  The counters report KiB.  Correction as `MI355X_MICROARCH.md` §HBM prescribes for gfx950:",
+         f"on `python scripts/one_solve.py csr {workload}` (gpurun, 1xMI355X).  The counters report KiB.  Correction as `MI355X_MICROARCH.md` §HBM prescribes for gfx950:",
          "FETCH_SIZE counts half of the bytes of a wide coalesced streaming read, so fetched bytes = FETCH_SIZE x 1024 x 2; WRITE_SIZE x 1024 is used as reported.", "",
          "| kernel | launches | avg us | FETCH_SIZE KiB (avg) | fetched MB (x2) | WRITE_SIZE KiB (avg) | written MB | HBM MB / launch |", "|---|---|---|---|---|---|---|---|"]
 tot_b = tot_n = 0.0
@@ -40,7 +44,14 @@ if per:
     lines.append(s + ".")
     lines.append("(The memory-side counters include what the 256 MiB Infinity Cache still holds from the previous kernel; a ratio near 1 means no re-reads.)")
 open(sys.argv[3], "w").write("\n".join(lines) + "\n")
-json.dump({"workload": "lap3d_2m", "ritz_class_hbm_bytes_per_launch": per, "launches": int(tot_n),
-           "source": f"profiles/{tag}_pmc_traffic.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per MI355X_MICROARCH.md, bytes per launch)"},
-          open(sys.argv[4], "w"), indent=1)
+try:
+    allw = json.load(open(sys.argv[4]))
+    if "workload" in allw:            # the round-2 single-workload layout
+        allw = {allw["workload"]: allw}
+except Exception:
+    allw = {}
+allw[workload] = {"workload": workload, "ritz_class_hbm_bytes_per_launch": per, "launches": int(tot_n),
+                  "source": f"profiles/{tag}_pmc_traffic{'' if workload == 'lap3d_2m' else '_' + workload}.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                            "passes on another process of the same workload, FETCH_SIZE x2 per MI355X_MICROARCH.md, bytes per launch); NOT measured in this run"}
+json.dump(allw, open(sys.argv[4], "w"), indent=1)
 print("\n".join(lines[-3:]))

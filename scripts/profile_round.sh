@@ -3,7 +3,7 @@
 #   full -m gpu suite, bench line, rocprofv3 kernel stats of the bench and of configs[2], PMC passes
 #   (MFMA counters on a block solve; FETCH_SIZE / WRITE_SIZE on the bench solve).
 # usage: bash scripts/profile_round.sh <tag>     (outputs: gpurun_out/<tag>_*)
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/${TAG}_gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/${TAG}_gpu_tests.log; tail -4 $O/${TAG}_gpu_tests.log
@@ -20,4 +20,12 @@ python scripts/pmc_summary.py $O/${TAG}_pmc_fetch/p_results.db $O/${TAG}_pmc_fet
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_pmc_write -o p -- python scripts/one_solve.py csr > /dev/null 2> $O/${TAG}_pmc_write.log
 python scripts/pmc_summary.py $O/${TAG}_pmc_write/p_results.db $O/${TAG}_pmc_write.md > /dev/null
 python scripts/pmc_traffic.py $O/${TAG}_pmc_fetch/p_results.db $O/${TAG}_pmc_write/p_results.db $O/${TAG}_pmc_traffic.md $O/${TAG}_pmc_traffic.json $O/${TAG}_bench.json ${TAG}
+# ---- north-star workload (10 M-row 5-pt Laplacian): kernel statistics of the first 3000 outer iterations and the two PMC passes
+rocprofv3 --kernel-trace -d $O/${TAG}_prof_ns -o ns -- python scripts/one_solve.py csr lap2d_10m 3000 > $O/${TAG}_ns_run.log 2> $O/${TAG}_prof_ns.log
+python scripts/rocpd_summary.py $O/${TAG}_prof_ns/ns_results.db $O/${TAG}_north_star_kernel_stats.md > /dev/null; head -12 $O/${TAG}_north_star_kernel_stats.md; tail -1 $O/${TAG}_north_star_kernel_stats.md
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pmc_fetch_ns -o p -- python scripts/one_solve.py csr lap2d_10m 400 > /dev/null 2> $O/${TAG}_pmc_fetch_ns.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_pmc_write_ns -o p -- python scripts/one_solve.py csr lap2d_10m 400 > /dev/null 2> $O/${TAG}_pmc_write_ns.log
+cp $O/${TAG}_pmc_traffic.json $O/${TAG}_pmc_traffic_all.json 2>/dev/null
+python scripts/pmc_traffic.py $O/${TAG}_pmc_fetch_ns/p_results.db $O/${TAG}_pmc_write_ns/p_results.db $O/${TAG}_pmc_traffic_lap2d_10m.md $O/${TAG}_pmc_traffic.json $O/${TAG}_bench.json ${TAG} lap2d_10m
+rm -rf $O/${TAG}_prof_ns $O/${TAG}_pmc_fetch_ns $O/${TAG}_pmc_write_ns
 rm -rf $O/${TAG}_prof_bench $O/${TAG}_prof_c3 $O/${TAG}_pmc_mfma $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write

@@ -1,0 +1,70 @@
+"""Generates tests/golden/reference_solves_complex.json from the REAL reference's zprimme / cprimme
+(oracle/_ref/libprimme_ref.so, built from /root/reference by oracle/Makefile).  Run in the build container only:
+    python tests/golden/make_complex_golden.py
+Fixtures are data: the matrices and start vectors are closed forms (primme_amd.problems.hermitian_graded_csr,
+complex_start_vector), the outputs are the reference's evals / resNorms / counts for the native complex path of
+hip_zprimme / hip_cprimme (Rayleigh-Ritz extraction, Generalized-Davidson family) to reproduce."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from primme_amd import problems  # noqa: E402
+from primme_amd import _ffi as F  # noqa: E402
+from checkers import eigsh, Operator  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    "z_gdk_lock": (600, dict(numEvals=6, method="GD_plusK", eps=1e-10)),
+    "z_gdk_soft": (600, dict(numEvals=3, method="GD_plusK", eps=1e-10, locking=0)),
+    "z_gdk_largest_blk4": (600, dict(numEvals=6, method="GD_plusK", eps=1e-9, target="largest", maxBlockSize=4, maxBasisSize=20, minRestartSize=8)),
+    "z_olsen_largest": (600, dict(numEvals=5, method="GD_Olsen_plusK", eps=1e-10, target="largest")),
+    "z_gd": (400, dict(numEvals=3, method="GD", eps=1e-9)),
+    "z_jacobi": (600, dict(numEvals=5, method="GD_plusK", eps=1e-10, precond="jacobi")),
+    "z_olsen_jacobi_blk2": (600, dict(numEvals=5, method="GD_Olsen_plusK", eps=1e-10, precond="jacobi", maxBlockSize=2)),
+    "z_lobpcg": (400, dict(numEvals=3, method="LOBPCG_OrthoBasis", eps=1e-7)),
+    "z_closest_abs": (400, dict(numEvals=3, method="GD_plusK", eps=1e-9, target="closest_abs", targetShifts=[5.0])),
+    "z_closest_geq": (400, dict(numEvals=3, method="GD_plusK", eps=1e-9, target="closest_geq", targetShifts=[5.0])),
+    "z_blk2_implicit": (600, dict(numEvals=5, method="GD_plusK", eps=1e-9, maxBlockSize=2, orth=F.primme_orth_implicit_I)),
+    "z_blk1_explicit": (600, dict(numEvals=4, method="GD_plusK", eps=1e-9, orth=F.primme_orth_explicit_I)),
+    "z_krylov_rng": (600, dict(numEvals=4, method="GD_plusK", eps=1e-9, v0=None, iseed=(1, 2, 3, 5))),
+    "c_gdk_blk2": (600, dict(numEvals=4, method="GD_plusK", eps=1e-4, maxBlockSize=2, dtype="complex64")),
+    "c_gdk_b1": (600, dict(numEvals=3, method="GD_plusK", eps=1e-4, dtype="complex64")),
+}
+
+
+def build_kwargs(kw, n):
+    kw = dict(kw)
+    dtype = np.dtype(kw.pop("dtype", "complex128"))
+    if "v0" not in kw:
+        kw["v0"] = problems.complex_start_vector(n)
+    nc = kw.pop("constraints", 0)
+    if nc:
+        # closed-form orthonormal constraint vectors: normalised complex exponentials
+        j = np.arange(n)
+        Q = np.stack([np.exp(2j * np.pi * (c + 1) * j / n) / np.sqrt(n) for c in range(nc)], axis=1)
+        kw["constraints"] = Q
+    return kw, dtype
+
+
+def main():
+    out = {}
+    for name, (n, kw0) in CASES.items():
+        rp, ci, va = problems.hermitian_graded_csr(n)
+        kw, dtype = build_kwargs(kw0, n)
+        r = eigsh(Operator(n, csr=(rp, ci, va)), backend="reference", dtype=dtype, **kw)
+        out[name] = dict(n=n, kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in kw0.items()}, ret=r.ret, initSize=r.initSize,
+                         evals=np.asarray(r.evals, dtype=np.float64).tolist(), resNorms=np.asarray(r.resNorms, dtype=np.float64).tolist(),
+                         aNorm=r.params["aNorm"],
+                         stats={k: r.stats[k] for k in ("numOuterIterations", "numMatvecs", "numRestarts", "numPreconds")})
+        print(name, r.ret, r.initSize, out[name]["stats"])
+    json.dump(out, open(os.path.join(HERE, "reference_solves_complex.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
