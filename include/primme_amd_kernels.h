@@ -79,6 +79,11 @@ int  hipk_publish_results(hipk_ctx *ctx, const double *dev, int count);
  * Num_*_ddh call, cublas_wrapper.c:479-499).  Pass NULLs to switch off. */
 int  hipk_ctx_set_mirror(hipk_ctx *ctx, double *dev_base, double *pinned_host_base, size_t count);
 int  hipk_is_device_ptr(const void *p);  /* Num_check_pointer, cublas_wrapper.c:162 */
+/* x(0:n) (DEVICE, n REAL numbers of the panel's precision: a complex element takes two) = the next n numbers of
+ * LAPACK's xLARNV(idist = 2) stream in (-1, 1), generated on the device by jumping ahead in the 48-bit congruential
+ * sequence; iseed (four base-4096 digits, host) is advanced as xLARNV advances it.  Replaces Num_larnv
+ * (cublas_wrapper.c:707-736: host generation + upload), same numbers bit for bit. */
+int  hipk_larnv_uniform11(hipk_ctx *ctx, hipk_dtype dt, int64_t iseed[4], int64_t n, void *x);
 /* events around a region on the ctx stream; ms returned by hipk_timer_stop (syncs) */
 int  hipk_timer_start(hipk_ctx *ctx);
 int  hipk_timer_stop(hipk_ctx *ctx, float *ms);

@@ -93,6 +93,17 @@ void hipk_cpu_mirror(const double *out, size_t cnt) {   /* keep the zero-copy co
       memmove(g_mirror_host + (out - g_mirror_dev), out, cnt * sizeof(double));
 }
 int hipk_is_device_ptr(const void *p) { return p != NULL; }
+void pa_larnv_uniform11(int64_t iseed[4], int64_t n, double *x);      /* the host routine checked against LAPACK (tests/test_dense_host.py) */
+int hipk_larnv_uniform11(hipk_ctx *ctx, hipk_dtype dt, int64_t iseed[4], int64_t n, void *x) {
+   (void)ctx;
+   if (n <= 0) return 0;
+   double *t = malloc((size_t)n * sizeof(double));
+   pa_larnv_uniform11(iseed, n, t);
+   if (dt == HIPK_F64 || dt == HIPK_C64) memcpy(x, t, (size_t)n * sizeof(double));
+   else for (int64_t i = 0; i < n; i++) ((float *)x)[i] = (float)t[i];
+   free(t);
+   return 0;
+}
 int hipk_wait_results(hipk_ctx *ctx) { (void)ctx; return 0; }
 int hipk_publish_results(hipk_ctx *ctx, const double *dev, int count) { (void)ctx; mirror(dev, (size_t)count); return 0; }
 int hipk_timer_start(hipk_ctx *c) { c->t0 = now(); return 0; }

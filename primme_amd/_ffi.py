@@ -185,6 +185,7 @@ def declare_kernels(lib):
         "hipk_malloc": [_vp, C.c_size_t, P(_vp)], "hipk_free": [_vp, _vp],
         "hipk_h2d": [_vp, _vp, _vp, C.c_size_t], "hipk_d2h": [_vp, _vp, _vp, C.c_size_t],
         "hipk_host_alloc": [_vp, C.c_size_t, P(_vp)], "hipk_host_free": [_vp, _vp],
+        "hipk_larnv_uniform11": [_vp, _i, P(C.c_int64), _i64, _vp],
         "hipk_timer_start": [_vp], "hipk_timer_stop": [_vp, P(C.c_float)],
         "hipk_panel_dots": [_vp, _i, _i64, P(HipkSeg), _i, _vp, _i64, _i, _vp, _i],
         "hipk_panel_project": [_vp, _i, _i64, P(HipkSeg), _i, _vp, _i, _vp, _i64, _i, _vp],

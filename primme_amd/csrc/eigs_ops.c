@@ -157,21 +157,11 @@ int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc)
  * consecutive numbers of the stream, (re, im), as zlarnv does) */
 int pa_random_col(pa_solver *s, char *col) {
    s->fov_valid = 0;
-   const int64_t nreal = s->m * SD;
-   double *tmp = (double *)malloc((size_t)(nreal > 0 ? nreal : 1) * sizeof(double));
-   if (!tmp) return PRIMME_MALLOC_FAILURE;
-   pa_larnv_uniform11(s->p->iseed, nreal, tmp);
-   int rc;
-   if (s->dt == HIPK_F64 || s->dt == HIPK_C64) {
-      rc = hipk_h2d(s->ctx, col, tmp, (size_t)nreal * 8);
-   } else {
-      float *f = (float *)tmp; /* in-place narrowing, front to back */
-      for (int64_t i = 0; i < nreal; i++) f[i] = (float)tmp[i];
-      rc = hipk_h2d(s->ctx, col, tmp, (size_t)nreal * 4);
-   }
-   if (!rc) rc = hipk_sync(s->ctx);
-   free(tmp);
-   return rc;
+   /* generated on the device (hipk_larnv_uniform11): the same stream, nothing crosses PCIe */
+   int64_t seed[4] = {s->p->iseed[0], s->p->iseed[1], s->p->iseed[2], s->p->iseed[3]};
+   CHK(hipk_larnv_uniform11(s->ctx, s->dt, seed, s->m * SD, col));
+   for (int i = 0; i < 4; i++) s->p->iseed[i] = seed[i];
+   return 0;
 }
 
 /* ---- classical Gram-Schmidt with reorthogonalisation ---------------------------

@@ -285,6 +285,46 @@ extern "C" int hipk_ctx_set_mirror(hipk_ctx *ctx, double *dev_base, double *pinn
    return 0;
 }
 
+/* ---- LAPACK's xLARNV(idist = 2) stream generated on the device ------------------------------------------
+ * The reference fills random vectors with Num_larnv (host xLARNV + upload, blaslapack.c:938-988 /
+ * cublas_wrapper.c:707-736).  The generator is the 48-bit multiplicative congruential x <- a x mod 2^48,
+ * a = 33952834046453; element i of the stream that starts at state s is (a^(i+1) s) mod 2^48, so every lane can
+ * jump to its own element with a table of a^(2^b): the SAME numbers, bit for bit, as the host routine
+ * (pa_larnv_uniform11, verified against LAPACK), without 8 bytes per element crossing PCIe.  n counts REAL numbers
+ * (a complex element takes two consecutive ones: re, im). */
+struct LarnvPow { unsigned long long p[48]; };
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+hipk_larnv_kernel(T *__restrict__ x, int64_t n, unsigned long long s0, LarnvPow pw) {
+   const unsigned long long MASK = (1ULL << 48) - 1;
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < n; i += stride) {
+      unsigned long long e = (unsigned long long)i + 1ULL, v = s0;
+      for (int b = 0; e; b++, e >>= 1) if (e & 1ULL) v = (v * pw.p[b]) & MASK;
+      x[i] = (T)(2.0 * ((double)v / 281474976710656.0) - 1.0);
+   }
+}
+extern "C" int hipk_larnv_uniform11(hipk_ctx *ctx, hipk_dtype dt, int64_t iseed[4], int64_t n, void *x) {
+   if (n <= 0) return 0;
+   const unsigned long long A = 33952834046453ULL, MASK = (1ULL << 48) - 1;
+   const unsigned long long s0 = ((((unsigned long long)iseed[0] * 4096 + (unsigned long long)iseed[1]) * 4096 +
+                                   (unsigned long long)iseed[2]) * 4096 + (unsigned long long)iseed[3]) & MASK;
+   LarnvPow pw;
+   pw.p[0] = A;
+   for (int b = 1; b < 48; b++) pw.p[b] = (pw.p[b - 1] * pw.p[b - 1]) & MASK;
+   const int gx = hipk_grid_for_rows(ctx, n, HIPK_BLOCK * 2, 8);
+   const bool dbl = (dt == HIPK_F64 || dt == HIPK_C64);
+   if (dbl) hipLaunchKernelGGL(hipk_larnv_kernel<double>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (double *)x, n, s0, pw);
+   else hipLaunchKernelGGL(hipk_larnv_kernel<float>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (float *)x, n, s0, pw);
+   HIPK_CHECK(hipGetLastError());
+   /* the state after n numbers: a^n s0 */
+   unsigned long long e = (unsigned long long)n, v = s0;
+   for (int b = 0; e; b++, e >>= 1) if (e & 1ULL) v = (v * pw.p[b]) & MASK;
+   iseed[0] = (int64_t)((v >> 36) & 4095); iseed[1] = (int64_t)((v >> 24) & 4095);
+   iseed[2] = (int64_t)((v >> 12) & 4095); iseed[3] = (int64_t)(v & 4095);
+   return 0;
+}
+
 /* ---- attainable-HBM probe (device copy, 16 B per lane) ------------------------ */
 __global__ void __launch_bounds__(HIPK_BLOCK)
 hipk_copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n16) {

@@ -679,3 +679,22 @@ def test_csr_row_slabs_with_halo(built, dt, dims, nslabs):
             assert np.max(np.abs(yf[0] - a * Yref[0, row0:row0 + nloc])) <= 50 * tol * scale
             assert abs(dot - a * a * float(X[0, row0:row0 + nloc] @ Yref[0, row0:row0 + nloc])) <= 500 * tol * scale * np.sqrt(nloc)
         assert np.max(np.abs(outs[0][0] - outs[1][0])) <= 50 * tol * scale
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+def test_larnv_stream_on_the_device(built, dt):
+    """hipk_larnv_uniform11: the xLARNV(2) stream generated on the device by jumping ahead in the 48-bit congruential
+    sequence — bit for bit the numbers of the host routine (itself checked against LAPACK in tests/test_dense_host.py),
+    the same seed afterwards, consecutive calls continue the stream."""
+    npdt = NPDT[dt]
+    for n in (1, 63, 4097, 300001):
+        outs = []
+        for side in (Dev(), Host()):
+            seed = (C.c_int64 * 4)(1, 2, 3, 5)
+            x = side.arr(np.zeros(n + 7, npdt))
+            assert side.lib.hipk_larnv_uniform11(side.ctx, dt, seed, n, side.ptr(x)) == 0
+            assert side.lib.hipk_larnv_uniform11(side.ctx, dt, seed, 7, side.ptr(x, n)) == 0
+            outs.append((side.get(x), list(seed)))
+            side.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+        assert np.all(np.abs(outs[0][0]) < 1.0) and outs[0][1] != [1, 2, 3, 5]
