@@ -10,21 +10,54 @@
 #include "primme_amd_io.h"
 #include <math.h>
 
-struct primme_amd_operator { hipk_csr *A; int jacobi_fixed; double jacobi_shift; int ldscale; };
+typedef void (*hostcheck_allreduce_fn)(double *buf, int count);
+struct primme_amd_comm { hostcheck_allreduce_fn cb; int rank, size; long calls; };
+/* comm / xfull: a row slab that references rows of other ranks (halo) gathers the whole vector through the stand-in
+ * communicator's all-reduce (every rank contributes its slab to a zero-padded copy) and hands the kernels the two
+ * halo windows inside it, like the all-gather mode of the real operator (amd_operator.hip) */
+struct primme_amd_operator { hipk_csr *A; int jacobi_fixed; double jacobi_shift; int ldscale; primme_amd_comm *comm; double *xfull; int64_t n, row0, nrows; };
 int primme_amd_operator_set_complex(primme_amd_operator *op, int on) { op->ldscale = on ? 2 : 1; return 0; }
 int primme_amd_operator_set_jacobi(primme_amd_operator *op, int fixed, double shift) { op->jacobi_fixed = fixed; op->jacobi_shift = shift; return 0; }
 int primme_amd_operator_create(primme_amd_operator **op, hipk_csr *A, primme_amd_comm *c) {
-   (void)c; *op = calloc(1, sizeof(**op)); (*op)->A = A; (*op)->ldscale = 1; return 0;
+   *op = calloc(1, sizeof(**op)); (*op)->A = A; (*op)->ldscale = 1;
+   if (c && c->size > 1 && (hipk_csr_halo_lo(A) > 0 || hipk_csr_halo_hi(A) > 0)) {
+      /* global size and my first row: sum / prefix of the slab sizes through the all-reduce */
+      double *cnt = calloc((size_t)c->size, sizeof(double));
+      cnt[c->rank] = (double)hipk_csr_nrows(A);
+      c->cb(cnt, c->size);
+      (*op)->comm = c; (*op)->nrows = hipk_csr_nrows(A);
+      for (int r = 0; r < c->size; r++) { if (r < c->rank) (*op)->row0 += (int64_t)cnt[r]; (*op)->n += (int64_t)cnt[r]; }
+      free(cnt);
+      (*op)->xfull = calloc((size_t)(*op)->n * 64, sizeof(double));
+   }
+   return 0;
 }
-int primme_amd_operator_destroy(primme_amd_operator *op) { free(op); return 0; }
+int primme_amd_operator_destroy(primme_amd_operator *op) { if (op) free(op->xfull); free(op); return 0; }
+/* x (nrows x nc, ld ldx, doubles) -> xfull (n x nc) on every rank; halo windows set on the matrix */
+static int gather_halo(primme_amd_operator *op, const void *x, int64_t ldx, int nc) {
+   if (!op->comm) return 0;
+   if (nc > 64 || hipk_csr_dtype(op->A) != HIPK_F64) return -44;
+   const int64_t n = op->n;
+   for (int c = 0; c < nc; c++) {
+      for (int64_t i = 0; i < n; i++) op->xfull[i + (size_t)c * n] = 0.0;
+      for (int64_t i = 0; i < op->nrows; i++) op->xfull[op->row0 + i + (size_t)c * n] = ((const double *)x)[i + (size_t)c * ldx];
+   }
+   op->comm->cb(op->xfull, (int)(n * nc));
+   const int64_t lo = hipk_csr_halo_lo(op->A);
+   return hipk_csr_set_halo_ld(op->A, op->xfull + (op->row0 - lo), n, op->xfull + op->row0 + op->nrows, n);
+}
 hipk_csr *primme_amd_operator_matrix(primme_amd_operator *op) { return op->A; }
 int primme_amd_operator_apply(primme_amd_operator *op, void *st, const void *x, int64_t ldx, void *y, int64_t ldy, int nc) {
+   int rc = gather_halo(op, x, ldx, nc);
+   if (rc) return rc;
    return hipk_csr_matvec(op->A, st, x, ldx, y, ldy, nc);
 }
 int primme_amd_operator_can_fuse(const primme_amd_operator *op) { return op && op->ldscale == 1 && hipk_csr_kind(op->A) == 0; }
 int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ctx *ctx, const void *x, const double *norm2, void *xout,
       void *y, double *dot) {
    if (!primme_amd_operator_can_fuse(op)) return -1;
+   int rc = gather_halo(op, x, hipk_csr_nrows(op->A), 1);        /* the un-normalised vector: the kernel scales the halo entries too */
+   if (rc) return rc;
    return hipk_csr_matvec_scaled(op->A, ctx, x, norm2, xout, y, dot);
 }
 int primme_amd_operator_apply_shifted(primme_amd_operator *op, void *st, const void *x, int64_t ldx, void *y, int64_t ldy,
@@ -53,8 +86,6 @@ void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ld
  * place to the "device" buffer, which is host memory here.  With it installed the solver runs the SAME code path as
  * on several GPUs -- reductions inside the stream of launches, |t|^2 and t'At in one all-reduce, the fused /
  * speculative restart with reduced overlaps -- in the world_size-2 CPU tests (tests/test_multirank_gloo.py). */
-typedef void (*hostcheck_allreduce_fn)(double *buf, int count);
-struct primme_amd_comm { hostcheck_allreduce_fn cb; int rank, size; long calls; };
 int primme_amd_hostcheck_comm_create(primme_amd_comm **out, hostcheck_allreduce_fn cb, int rank, int size) {
    primme_amd_comm *c = calloc(1, sizeof(*c));
    if (!c) return -2;

@@ -273,13 +273,12 @@ extern "C" int primme_amd_svds_operator_set_jacobi(primme_amd_svds_operator *op,
    free(sum);
    if (!op->jac_r && hipMalloc(&op->jac_r, es * (size_t)(m > 0 ? m : 1)) != hipSuccess) { free(packed); return -2; }
    if (!op->jac_c && hipMalloc(&op->jac_c, es * (size_t)(n > 0 ? n : 1)) != hipSuccess) { free(packed); return -2; }
-   /* on the stream the operator's kernels run on, then drained (never the NULL stream: see csr_create_impl) */
-   hipStream_t st = (hipStream_t)hipk_ctx_stream(hipk_csr_ctx(op->A));
-   hipError_t e1 = m > 0 ? hipMemcpyAsync(op->jac_r, packed, es * (size_t)m, hipMemcpyHostToDevice, st) : hipSuccess;
-   hipError_t e2 = n > 0 ? hipMemcpyAsync(op->jac_c, packed + es * (size_t)m, es * (size_t)n, hipMemcpyHostToDevice, st) : hipSuccess;
-   hipError_t e3 = hipStreamSynchronize(st);
+   /* through pinned staging on the stream the operator's kernels run on (hipk_upload: never the NULL stream) */
+   hipk_ctx *octx = hipk_csr_ctx(op->A);
+   const int e1 = m > 0 ? hipk_upload(octx, op->jac_r, packed, es * (size_t)m) : 0;
+   const int e2 = n > 0 ? hipk_upload(octx, op->jac_c, packed + es * (size_t)m, es * (size_t)n) : 0;
    free(packed);
-   return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -1;
+   return (e1 == 0 && e2 == 0) ? 0 : -1;
 }
 
 /* applyPreconditioner of primme_svds_params for the operator's Jacobi data: y = x / diag(A'A),

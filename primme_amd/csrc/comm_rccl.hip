@@ -26,6 +26,7 @@ struct primme_amd_comm {
    int rank, nranks;
    hipStream_t stream;     /* for the host-buffer callback path */
    double *dbuf;           /* staging for the host-buffer path */
+   double *hbuf;           /* its pinned host twin: the caller's (pageable) buffers never meet an asynchronous copy */
    size_t dbuf_cap;
 };
 
@@ -56,6 +57,7 @@ extern "C" int primme_amd_comm_create(primme_amd_comm **out, const void *id128, 
    HIPK_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
    c->dbuf_cap = 8192;
    HIPK_CHECK(hipMalloc((void **)&c->dbuf, c->dbuf_cap * sizeof(double)));
+   HIPK_CHECK(hipHostMalloc((void **)&c->hbuf, c->dbuf_cap * sizeof(double), hipHostMallocDefault));
    *out = c;
    return 0;
 }
@@ -65,6 +67,7 @@ extern "C" int primme_amd_comm_destroy(primme_amd_comm *c) {
    hipStreamSynchronize(c->stream);
    ncclCommDestroy(c->comm);
    (void)hipFree(c->dbuf);
+   if (c->hbuf) (void)hipHostFree(c->hbuf);
    (void)hipStreamDestroy(c->stream);
    free(c);
    return 0;
@@ -89,14 +92,19 @@ extern "C" void primme_amd_global_sum(void *sendBuf, void *recvBuf, int *count,
    if (n == 0) { *ierr = 0; return; }
    if (n > c->dbuf_cap) {
       (void)hipFree(c->dbuf);
+      if (c->hbuf) (void)hipHostFree(c->hbuf);
+      c->hbuf = NULL;
       c->dbuf_cap = 2 * n;
       if (hipMalloc((void **)&c->dbuf, c->dbuf_cap * sizeof(double)) != hipSuccess) return;
+      if (hipHostMalloc((void **)&c->hbuf, c->dbuf_cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return;
    }
    /* globalSumReal_type: this callback handles double (the solver always reduces doubles) */
-   if (hipMemcpyAsync(c->dbuf, sendBuf, n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
+   memcpy(c->hbuf, sendBuf, n * sizeof(double));
+   if (hipMemcpyAsync(c->dbuf, c->hbuf, n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
    if (ncclAllReduce(c->dbuf, c->dbuf, n, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
-   if (hipMemcpyAsync(recvBuf, c->dbuf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return;
+   if (hipMemcpyAsync(c->hbuf, c->dbuf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return;
    if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+   memcpy(recvBuf, c->hbuf, n * sizeof(double));
    *ierr = 0;
 }
 
@@ -174,10 +182,15 @@ extern "C" void primme_amd_svds_global_sum(void *sendBuf, void *recvBuf, int *co
 extern "C" int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n, int64_t *all) {
    int64_t *d = NULL;
    HIPK_CHECK(hipMalloc((void **)&d, (size_t)(c->nranks + 1) * n * sizeof(int64_t)));
-   HIPK_CHECK(hipMemcpyAsync(d + (size_t)c->nranks * n, mine, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+   int64_t *h = NULL;      /* pinned twin of the exchange buffer */
+   HIPK_CHECK(hipHostMalloc((void **)&h, (size_t)(c->nranks + 1) * n * sizeof(int64_t), hipHostMallocDefault));
+   memcpy(h + (size_t)c->nranks * n, mine, (size_t)n * sizeof(int64_t));
+   HIPK_CHECK(hipMemcpyAsync(d + (size_t)c->nranks * n, h + (size_t)c->nranks * n, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
    NCCL_CHECK(ncclAllGather(d + (size_t)c->nranks * n, d, (size_t)n * sizeof(int64_t), ncclChar, c->comm, c->stream));
-   HIPK_CHECK(hipMemcpyAsync(all, d, (size_t)c->nranks * n * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+   HIPK_CHECK(hipMemcpyAsync(h, d, (size_t)c->nranks * n * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
    HIPK_CHECK(hipStreamSynchronize(c->stream));
+   memcpy(all, h, (size_t)c->nranks * n * sizeof(int64_t));
+   (void)hipHostFree(h);
    (void)hipFree(d);
    return 0;
 }

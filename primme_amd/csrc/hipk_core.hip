@@ -94,24 +94,95 @@ extern "C" int hipk_free(hipk_ctx *ctx, void *dptr) {
    if (ctx && ctx->host_timing && dptr) { g_alloc_s += alloc_now() - t0; g_alloc_n++; }
    return 0;
 }
+/* The pinned buffers this library handed out: hipk_h2d / hipk_d2h copy asynchronously only to / from these; any
+ * other host pointer (the caller's numpy arrays, malloc'd or stack memory) is staged through a pinned buffer and the
+ * copy is complete on return, so the runtime is never asked to DMA asynchronously out of or into pageable memory. */
+#include <atomic>
+#define HIPK_PINNED_MAX 256
+static struct { const char *lo, *hi; } g_pinned[HIPK_PINNED_MAX];
+static std::atomic_flag g_pinned_lock = ATOMIC_FLAG_INIT;
+static void pinned_note(const void *p, size_t bytes, bool add) {
+   while (g_pinned_lock.test_and_set(std::memory_order_acquire)) { }
+   for (int i = 0; i < HIPK_PINNED_MAX; i++) {
+      if (add ? g_pinned[i].lo == NULL : g_pinned[i].lo == (const char *)p) {
+         g_pinned[i].lo = add ? (const char *)p : NULL;
+         g_pinned[i].hi = add ? (const char *)p + bytes : NULL;
+         break;
+      }
+   }
+   g_pinned_lock.clear(std::memory_order_release);
+}
+static bool pinned_has(const void *p, size_t bytes) {
+   bool found = false;
+   while (g_pinned_lock.test_and_set(std::memory_order_acquire)) { }
+   for (int i = 0; i < HIPK_PINNED_MAX && !found; i++)
+      found = g_pinned[i].lo && (const char *)p >= g_pinned[i].lo && (const char *)p + bytes <= g_pinned[i].hi;
+   g_pinned_lock.clear(std::memory_order_release);
+   return found;
+}
 extern "C" int hipk_host_alloc(hipk_ctx *ctx, size_t bytes, void **hptr) {
    (void)ctx;
    if (bytes == 0) bytes = 8;
    hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocDefault);
    if (e != hipSuccess) { *hptr = NULL; return -2; }
+   pinned_note(*hptr, bytes, true);
    return 0;
 }
 extern "C" int hipk_host_free(hipk_ctx *ctx, void *hptr) {
    (void)ctx;
-   if (hptr) HIPK_CHECK(hipHostFree(hptr));
+   if (hptr) { pinned_note(hptr, 0, false); HIPK_CHECK(hipHostFree(hptr)); }
    return 0;
 }
+/* Host array of ANY kind (pageable: numpy arrays, std::vector data, stack variables) -> device, finished on return.
+ * Goes through a pinned staging buffer in chunks, each chunk an asynchronous copy on the context's stream followed
+ * by a drain: the only transfers the device layer issues from memory it did not allocate itself.  (Round 2 used
+ * blocking hipMemcpy on the NULL stream, which the context's non-blocking stream is not ordered against; an
+ * asynchronous copy straight from pageable memory leaves it to the runtime to pin and unpin the caller's pages on the
+ * fly — with that variant the GPU suite aborted once inside hipStreamSynchronize and hung once at exit,
+ * profiles/r03_gpu_suite_run3_aborted.txt.) */
+int hipk_upload(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+   if (bytes == 0) return 0;
+   const size_t cap = bytes < ((size_t)32 << 20) ? bytes : ((size_t)32 << 20);
+   void *stage = NULL;
+   HIPK_CHECK(hipHostMalloc(&stage, cap, hipHostMallocDefault));
+   int rc = 0;
+   for (size_t off = 0; off < bytes && !rc; off += cap) {
+      const size_t n = bytes - off < cap ? bytes - off : cap;
+      memcpy(stage, (const char *)src + off, n);
+      if (hipMemcpyAsync((char *)dst + off, stage, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) rc = -1;
+   }
+   (void)hipHostFree(stage);
+   return rc;
+}
+
+/* device -> host array of any kind, complete on return (the counterpart of hipk_upload) */
+int hipk_download(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+   if (bytes == 0) return 0;
+   const size_t cap = bytes < ((size_t)32 << 20) ? bytes : ((size_t)32 << 20);
+   void *stage = NULL;
+   HIPK_CHECK(hipHostMalloc(&stage, cap, hipHostMallocDefault));
+   int rc = 0;
+   for (size_t off = 0; off < bytes && !rc; off += cap) {
+      const size_t n = bytes - off < cap ? bytes - off : cap;
+      if (hipMemcpyAsync(stage, (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) rc = -1;
+      else memcpy((char *)dst + off, stage, n);
+   }
+   (void)hipHostFree(stage);
+   return rc;
+}
+/* stream-ordered (asynchronous) for the library's pinned buffers, staged and complete on return for anything else */
 extern "C" int hipk_h2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
-   if (bytes) HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+   if (!bytes) return 0;
+   if (!pinned_has(src, bytes)) return hipk_upload(ctx, dst, src, bytes);
+   HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
    return 0;
 }
 extern "C" int hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
-   if (bytes) HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+   if (!bytes) return 0;
+   if (!pinned_has(dst, bytes)) return hipk_download(ctx, dst, src, bytes);
+   HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
    return 0;
 }
 extern "C" int hipk_d2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
@@ -528,16 +599,15 @@ extern "C" int hipk_sym_eig(hipk_ctx *ctx, int n, const double *A_host, int lda,
    double *tight = (double *)malloc(nn * sizeof(double));
    if (!tight) { (void)hipFree(buf); return -2; }
    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) tight[i + (size_t)j * n] = (i <= j) ? A_host[i + (size_t)j * lda] : 0.0;
-   hipError_t e = hipMemcpyAsync(dA, tight, nn * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+   hipError_t e = hipk_upload(ctx, dA, tight, nn * sizeof(double)) ? hipErrorUnknown : hipSuccess;
    if (e == hipSuccess) {
       hipLaunchKernelGGL(sym_eig_jacobi_kernel, dim3(1), dim3(HIPK_BLOCK), 2 * (size_t)np * np * sizeof(double), ctx->stream,
             dA, n, np, dE, dZ, dS);
       e = hipGetLastError();
    }
    double *ev = (double *)malloc(n * sizeof(double)), *Z = (double *)malloc(nn * sizeof(double));
-   if (e == hipSuccess) e = hipMemcpyAsync(ev, dE, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-   if (e == hipSuccess) e = hipMemcpyAsync(Z, dZ, nn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+   if (e == hipSuccess && hipk_download(ctx, ev, dE, n * sizeof(double))) e = hipErrorUnknown;
+   if (e == hipSuccess && hipk_download(ctx, Z, dZ, nn * sizeof(double))) e = hipErrorUnknown;
    (void)hipFree(buf);
    free(tight);
    if (e != hipSuccess) { free(ev); free(Z); fprintf(stderr, "primme_amd: hipk_sym_eig: %s\n", hipGetErrorString(e)); return -1; }

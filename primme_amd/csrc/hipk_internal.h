@@ -109,6 +109,9 @@ static inline hipk_fin_args hipk_make_fin(hipk_ctx *ctx, double *out_dev, int ki
    return fa;
 }
 void hipk_note_turnaround(hipk_ctx *ctx);
+/* pageable host array -> device through a pinned staging buffer on the context's stream; complete on return */
+int hipk_upload(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);
+int hipk_download(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* the context a matrix was created under (its uploads and default launches use that stream) */
 hipk_ctx *hipk_csr_ctx(const hipk_csr *A);
 /* hipk_csr_matvec_scaled applies: CSR, the input entries are the matrix' own row slab */

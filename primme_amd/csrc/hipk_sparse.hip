@@ -546,29 +546,24 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
          hipk_malloc(ctx, twin.size() * sizeof(int2), (void **)&A->twin) ||
          hipk_malloc(ctx, (size_t)nrows_local * es, &A->diag))
       return -2;
-   /* Every upload is ordered on the context's stream (the stream all kernels of this matrix run on), then
-    * drained once: nothing here goes through the NULL stream, which a hipStreamNonBlocking stream is not
-    * ordered against (and hipMemset on it does not even block the host). */
+   /* Every upload goes through pinned staging on the context's stream (hipk_upload) and is complete on return: nothing
+    * goes through the NULL stream, which a hipStreamNonBlocking stream is not ordered against, and the runtime is never
+    * asked to copy asynchronously out of the caller's pageable arrays. */
    {
-      hipStream_t st = ctx->stream;
-      static int legacy = -1;       /* HIPK_LEGACY_UPLOAD=1: the round-2 NULL-stream uploads (repro knob, scripts/halo_repro.py) */
-      if (legacy < 0) legacy = getenv("HIPK_LEGACY_UPLOAD") != NULL;
-      if (legacy) st = NULL;
-#define UP(dst, src, bytes) do { if ((bytes) > 0) HIPK_CHECK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
-      UP(A->rowptr, rowptr_host, (size_t)(nrows_local + 1) * 4);
-      UP(A->colind, colind_host, (size_t)nnz * 4);
-      UP(A->values, values_host, (size_t)nnz * es);
-      UP(A->tiles, tiles.data(), tiles.size() * 4);
-      UP(A->tileinfo, tinfo.data(), tinfo.size() * sizeof(int4));
-      UP(A->twin, twin.data(), twin.size() * sizeof(int2));
-      UP(A->diag, dg.data(), (size_t)nrows_local * es);
       /* the padded element behind the last nonzero (clamped loads of trailing empty tiles): value 0 and a column
        * inside the owned slab, so that the gather stays in range with halos too */
       const int32_t padcol = (int32_t)x0;
-      UP(A->colind + nnz, &padcol, (size_t)4);
-#undef UP
-      HIPK_CHECK(hipMemsetAsync((char *)A->values + (size_t)nnz * es, 0, es, st));
-      HIPK_CHECK(hipStreamSynchronize(st));      /* the host arrays (and the vectors above) may go away now */
+      const char zero[16] = {0};
+      if (hipk_upload(ctx, A->rowptr, rowptr_host, (size_t)(nrows_local + 1) * 4) ||
+            hipk_upload(ctx, A->colind, colind_host, (size_t)nnz * 4) ||
+            hipk_upload(ctx, A->values, values_host, (size_t)nnz * es) ||
+            hipk_upload(ctx, A->tiles, tiles.data(), tiles.size() * 4) ||
+            hipk_upload(ctx, A->tileinfo, tinfo.data(), tinfo.size() * sizeof(int4)) ||
+            hipk_upload(ctx, A->twin, twin.data(), twin.size() * sizeof(int2)) ||
+            hipk_upload(ctx, A->diag, dg.data(), (size_t)nrows_local * es) ||
+            hipk_upload(ctx, A->colind + nnz, &padcol, (size_t)4) ||
+            hipk_upload(ctx, (char *)A->values + (size_t)nnz * es, zero, es))
+         return -1;
    }
    *out = A;
    return 0;

@@ -52,6 +52,13 @@ def run(rank, world, port, case, out_path):
         rp, ci, va, n0 = problems.laplacian_csr(dims)
         rpt, cit, vat = problems.tile_block_diagonal(rp, ci, va, 1, scale_fn=lambda t: 1.0 + 0.37 * t, row0_tile=rank)
         n = n0 * world
+        if case == "devcomm_halo":
+            # ONE 2-D Laplacian split by rows: the slabs reference each other's boundary rows, so the operator exchanges
+            # halo data and the one-launch tail (scale + A t + t'At) runs with halo buffers, as on several GPUs
+            dims = (24, 22)
+            n = dims[0] * dims[1]
+            n0 = n // world
+            rpt, cit, vat, _ = problems.laplacian_csr(dims, row0=rank * n0, nrows=n0)
         lib = checkers.load_hostcheck()
         AR = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int)
 
@@ -67,10 +74,10 @@ def run(rank, world, port, case, out_path):
         op = Operator(n, csr=(rpt, cit, vat), row0=rank * n0, nrows=n0)
         v0 = problems.start_vector(n, row0=rank * n0, nrows=n0)
         s = Session(op, comm=comm, backend="hostcheck")
-        nev = 10 if case == "devcomm_lock" else 4
+        nev = 10 if case == "devcomm_lock" else (6 if case == "devcomm_halo" else 4)
         counts = (C.c_long * 8)()
         lib.hipk_cpu_counts(counts, 1)
-        r = s.solve(numEvals=nev, eps=1e-10, aNorm=8.0 * 1.37, v0=v0, numProcs=world, procID=rank)
+        r = s.solve(numEvals=nev, eps=1e-10, aNorm=8.0 * (1.0 if case == "devcomm_halo" else 1.37), v0=v0, numProcs=world, procID=rank)
         lib.hipk_cpu_counts(counts, 1)
         lib.primme_amd_hostcheck_comm_calls.restype = C.c_long
         lib.primme_amd_hostcheck_comm_calls.argtypes = [C.c_void_p]

@@ -55,6 +55,17 @@ def run(rank, world, port, case, out_path):
             v0 = np.random.default_rng(7).standard_normal((n, 4))[row0:row0 + nloc]
             r = s.solve(v0=v0, maxBlockSize=4, method="JDQMR", **kw)
         s.close()
+    elif case in ("config2_full", "lap2d_10m"):
+        # the bench workloads under the bench's own row partition (bench.py --gpus N): BASELINE configs[1] at full
+        # size, and the north-star 10 M-row 5-point Laplacian (2 pairs: the partition is what is under test)
+        dims, nev, aN = ((125, 126, 127), 10, 12.0) if case == "config2_full" else ((3162, 3163), 2, 8.0)
+        n = int(np.prod(dims))
+        row0, nloc = split(n, world, rank)
+        rp, ci, va, _ = problems.laplacian_csr(dims, row0=row0, nrows=nloc)
+        s = Session(Operator(n, csr=(rp, ci, va), row0=row0, nrows=nloc), comm=comm)
+        r = s.solve(numEvals=nev, eps=1e-8, aNorm=aN, method="GD_plusK", numProcs=world, procID=rank,
+                    v0=problems.start_vector(n, row0=row0, nrows=nloc))
+        s.close()
     elif case == "blockdiag":
         dims = (40, 41)
         rp, ci, va, n0 = problems.laplacian_csr(dims)

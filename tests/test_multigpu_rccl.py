@@ -66,6 +66,19 @@ def test_rccl_halo_stencil(built, tmp_path, case):
         assert abs(res[0]["its"] - one.stats["numOuterIterations"]) <= max(2, 0.03 * one.stats["numOuterIterations"])
 
 
+@pytest.mark.parametrize("case,dims,nev,aN", [("config2_full", (125, 126, 127), 10, 12.0), ("lap2d_10m", (3162, 3163), 2, 8.0)])
+def test_rccl_bench_workloads_under_the_bench_partition(built, tmp_path, case, dims, nev, aN):
+    """What `bench.py --gpus N` runs, checked instead of timed: BASELINE configs[1] at full size and the north-star
+    10 M-row Laplacian, rows split over every visible GPU, against the analytic spectrum; identical bits on all ranks
+    (asserted in _launch); the slabs of the returned vectors are together unit vectors."""
+    world, res = _launch(case, tmp_path)
+    ex = problems.laplacian_eigenvalues(dims, nev)
+    assert np.max(np.abs(np.sort(res[0]["evals"]) - ex)) <= 1e-8 * aN
+    assert np.all(np.array(res[0]["resNorms"]) <= 1e-8 * aN * (1 + 1e-6))
+    assert abs(sum(r["evecs_norm2"] for r in res) - nev) < 1e-6
+    assert res[0]["numGlobalSum"] >= res[0]["its"]          # every outer iteration reduced something across ranks
+
+
 def test_rccl_block_diagonal(built, tmp_path):
     world, res = _launch("blockdiag", tmp_path)
     dims = (40, 41)

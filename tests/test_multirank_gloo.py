@@ -125,3 +125,24 @@ def test_device_communicator_path_two_ranks(built, tmp_path, case, nev):
     assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]
     assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - nev) < 1e-8
     assert abs(res[0]["its"] - single.stats["numOuterIterations"]) <= max(3, 0.05 * single.stats["numOuterIterations"])
+
+
+def test_device_communicator_path_with_halo_two_ranks(built, tmp_path):
+    """The same path on ONE Laplacian split by rows (the bench's partition): the operator exchanges halo rows and the
+    fused tail (hipk_csr_matvec_scaled: scale + A t + t'At) runs with halo buffers — the combination whose one-GPU
+    kernel test failed once in the round-2 driver run.  Eigenvalues against the analytic spectrum and the one-rank
+    solve, identical bits on both ranks, the one-launch tail in (almost) every iteration."""
+    res = _launch("devcomm_halo", tmp_path)
+    dims = (24, 22)
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    single = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", numEvals=6, eps=1e-10, aNorm=8.0, v0=problems.start_vector(n))
+    ex = problems.laplacian_eigenvalues(dims, 6)
+    for r in res:
+        assert r["ret"] == 0
+        assert np.max(np.abs(np.sort(r["evals"]) - ex)) <= 1e-10 * 8
+        assert np.max(np.abs(np.array(r["evals"]) - single.evals)) <= 1e-10 * 8
+        assert np.all(np.array(r["resNorms"]) <= 1e-10 * 8 * 1.001)
+        assert r["fused_tail"] >= r["its"] - 20
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]
+    assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - 6) < 1e-8
+    assert abs(res[0]["its"] - single.stats["numOuterIterations"]) <= max(3, 0.05 * single.stats["numOuterIterations"])
