@@ -39,6 +39,20 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
       int blockSize, double *basisNorms, int numConverged, double *lockedEvals, int numLocked,
       int *lockedFlags, double *lockedNorms, primme_event event);
 
+/* The QMR recurrences are REAL for complex data too (the reference takes real parts: Num_dist_dots_real,
+ * inner_solve.c:283-420, and real axpy factors): on a complex panel those steps are the real kernels on the panel seen as
+ * 2m reals (Re(x^H y) = the real inner product of the two 2m-vectors).  Only the operator and the projectors work with
+ * complex coefficients.  RDT / RM / R2: dtype, row count and leading dimension of that real view. */
+#if PA_IS_COMPLEX
+#define RDT(s) ((s)->dt == HIPK_C64 ? HIPK_F64 : HIPK_F32)
+#define RM(s) (2 * (s)->m)
+#define R2(ld) (2 * (ld))
+#else
+#define RDT(s) ((s)->dt)
+#define RM(s) ((s)->m)
+#define R2(ld) (ld)
+#endif
+
 static int conv_test(pa_solver *s, double eval, double rnorm, int *isconv) {
    primme_params *p = s->p;
    if (p->convTestFun == pa_conv_test_absolute) {
@@ -55,7 +69,7 @@ static int project_panel(pa_solver *s, char *Q, int64_t ldQ, char *Qhat, int64_t
    double t0 = pa_wtime();
    hipk_seg sq = {Q, ldQ, numCols}, sh = {Qhat, ldQhat, numCols};
    CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, v, ldv, nb, s->d_red, numCols));
-   CHK(pa_reduce(s, s->d_red, numCols * nb, 1, 1));
+   CHK(pa_reduce(s, s->d_red, SD * numCols * nb, 1, 1));
    CHK(hipk_panel_project(s->ctx, s->dt, s->m, &sh, 1, s->d_red, numCols, v, ldv, nb, NULL));
    s->p->stats.numOrthoInnerProds += (double)numCols * nb;
    s->p->stats.timeOrtho += pa_wtime() - t0;
@@ -67,17 +81,18 @@ static int project_each(pa_solver *s, char *X, int64_t ldX, char *Xhat, int64_t 
    if (nb <= 0) return 0;
    double t0 = pa_wtime();
    CHK(hipk_pair_dots(s->ctx, s->dt, s->m, X, ldX, v, ldv, nb, s->d_red));
-   CHK(pa_reduce(s, s->d_red, nb, 0, 0));
-   double alpha[64];
-   for (int i = 0; i < nb; i++) alpha[i] = -s->h_red[i];
-   CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, alpha, Xhat, ldXhat, v, ldv, nb));
+   CHK(pa_reduce(s, s->d_red, SD * nb, 0, 0));
+   HS alpha[64];
+   for (int i = 0; i < nb; i++) alpha[i] = -((const HS *)s->h_red)[i];
+   CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)alpha, Xhat, ldXhat, v, ldv, nb));
    s->p->stats.numOrthoInnerProds += nb;
    s->p->stats.timeOrtho += pa_wtime() - t0;
    return 0;
 }
 
+/* out[c] = Re(X(:,c)^H Y(:,c)) */
 static int pair_dots_host(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nb, double *out) {
-   CHK(hipk_pair_dots(s->ctx, s->dt, s->m, X, ldX, Y, ldY, nb, s->d_red));
+   CHK(hipk_pair_dots(s->ctx, RDT(s), RM(s), X, R2(ldX), Y, R2(ldY), nb, s->d_red));
    CHK(pa_reduce(s, s->d_red, nb, 0, 0));
    for (int i = 0; i < nb; i++) out[i] = s->h_red[i];
    return 0;
@@ -119,23 +134,23 @@ typedef struct {
 
 /* ---- M = evecs' evecsHat: dense LU with partial pivoting on the host (the reference keeps a
  * Bunch-Kaufman factorisation, factorize.c:183-262; same solution up to rounding) ---- */
-static int lu_factor(const double *A, int ldA, int n, double *LU, int *piv) {
+static int lu_factor(const HS *A, int ldA, int n, HS *LU, int *piv) {
    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) LU[i + (size_t)j * n] = A[i + (size_t)j * ldA];
    for (int k = 0; k < n; k++) {
       int pi = k;
-      for (int i = k + 1; i < n; i++) if (fabs(LU[i + (size_t)k * n]) > fabs(LU[pi + (size_t)k * n])) pi = i;
+      for (int i = k + 1; i < n; i++) if (HS_ABS(LU[i + (size_t)k * n]) > HS_ABS(LU[pi + (size_t)k * n])) pi = i;
       piv[k] = pi;
       if (LU[pi + (size_t)k * n] == 0.0) return PRIMME_LAPACK_FAILURE;
-      if (pi != k) for (int j = 0; j < n; j++) { double t = LU[k + (size_t)j * n]; LU[k + (size_t)j * n] = LU[pi + (size_t)j * n]; LU[pi + (size_t)j * n] = t; }
+      if (pi != k) for (int j = 0; j < n; j++) { HS t = LU[k + (size_t)j * n]; LU[k + (size_t)j * n] = LU[pi + (size_t)j * n]; LU[pi + (size_t)j * n] = t; }
       for (int i = k + 1; i < n; i++) {
-         const double l = LU[i + (size_t)k * n] /= LU[k + (size_t)k * n];
+         const HS l = LU[i + (size_t)k * n] /= LU[k + (size_t)k * n];
          for (int j = k + 1; j < n; j++) LU[i + (size_t)j * n] -= l * LU[k + (size_t)j * n];
       }
    }
    return 0;
 }
-static void lu_solve(const double *LU, const int *piv, int n, double *b) {
-   for (int k = 0; k < n; k++) { const int pi = piv[k]; if (pi != k) { double t = b[k]; b[k] = b[pi]; b[pi] = t; } }
+static void lu_solve(const HS *LU, const int *piv, int n, HS *b) {
+   for (int k = 0; k < n; k++) { const int pi = piv[k]; if (pi != k) { HS t = b[k]; b[k] = b[pi]; b[pi] = t; } }
    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) b[i] -= LU[i + (size_t)j * n] * b[j];
    for (int i = n - 1; i >= 0; i--) { for (int j = i + 1; j < n; j++) b[i] -= LU[i + (size_t)j * n] * b[j]; b[i] /= LU[i + (size_t)i * n]; }
 }
@@ -152,11 +167,12 @@ static int extend_evecs_hat(pa_solver *s, int c0, int count) {
       const int nj = PA_MIN(8, count - j0);
       hipk_seg sq = {s->evecs, s->ldevecs, nM};
       CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, hat + (size_t)j0 * s->ldevecs * s->es, s->ldevecs, nj, s->d_red, nM));
-      CHK(pa_reduce(s, s->d_red, nM * nj, 0, 0));
+      CHK(pa_reduce(s, s->d_red, SD * nM * nj, 0, 0));
       for (int j = 0; j < nj; j++)
          for (int i = 0; i < nM; i++) {
-            s->Mq[i + (size_t)(c0 + j0 + j) * s->ldM] = s->h_red[i + (size_t)j * nM];
-            if (i < c0) s->Mq[(c0 + j0 + j) + (size_t)i * s->ldM] = s->h_red[i + (size_t)j * nM];   /* K symmetric */
+            const HS mij = ((const HS *)s->h_red)[i + (size_t)j * nM];
+            s->Mq[i + (size_t)(c0 + j0 + j) * s->ldM] = mij;
+            if (i < c0) s->Mq[(c0 + j0 + j) + (size_t)i * s->ldM] = HS_CONJ(mij);   /* K Hermitian */
          }
    }
    return lu_factor(s->Mq, s->ldM, nM, s->Mlu, s->Mpiv);
@@ -199,10 +215,10 @@ static int skew_project_Q(pa_solver *s, const jd_proj *P, char *v, int64_t ldv, 
    double t0 = pa_wtime();
    hipk_seg sq = {s->evecs, s->ldevecs, nQ}, sh = {P->RQ, P->ldRQ, nQ};
    CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, v, ldv, nb, s->d_red, nQ));
-   CHK(pa_reduce(s, s->d_red, nQ * nb, 0, 0));
-   if (nQ > 1) for (int c = 0; c < nb; c++) lu_solve(s->Mlu, s->Mpiv, nQ, s->h_red + (size_t)c * nQ);
-   else for (int c = 0; c < nb; c++) s->h_red[c] /= s->Mq[0];
-   CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, sizeof(double) * (size_t)nQ * nb));
+   CHK(pa_reduce(s, s->d_red, SD * nQ * nb, 0, 0));
+   if (nQ > 1) for (int c = 0; c < nb; c++) lu_solve(s->Mlu, s->Mpiv, nQ, (HS *)s->h_red + (size_t)c * nQ);
+   else for (int c = 0; c < nb; c++) ((HS *)s->h_red)[c] /= s->Mq[0];
+   CHK(hipk_h2d(s->ctx, s->d_red, s->h_red, sizeof(HS) * (size_t)nQ * nb));
    CHK(hipk_panel_project(s->ctx, s->dt, s->m, &sh, 1, s->d_red, nQ, v, ldv, nb, NULL));
    s->p->stats.numOrthoInnerProds += (double)nQ * nb;
    s->p->stats.timeOrtho += pa_wtime() - t0;
@@ -237,6 +253,24 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
    for (int i = 0; i < nb; i++) ms[i] = -shift[i];
    if (P->nLX > 0) {
       double t0 = pa_wtime();
+#if PA_IS_COMPLEX
+      /* the reference's operation order with complex projector coefficients: result -= shift v (real), (I - Q Q^H),
+       * c = x^H result (complex), result -= c x, vdot = Re(v^H result) */
+      (void)xr_out;
+      if (!shifted) CHK(hipk_axpy_cols(s->ctx, RDT(s), RM(s), ms, v, R2(ldv), result, R2(ldres), nb));
+      if (P->nLQ > 0) CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+      CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, result, ldres, nb, s->d_red));
+      CHK(pa_reduce(s, s->d_red, SD * nb, 0, 0));
+      {
+         HS mc[64];
+         for (int i = 0; i < nb; i++) mc[i] = -((const HS *)s->h_red)[i];
+         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)mc, P->LX, P->ldLX, result, ldres, nb));
+      }
+      CHK(pair_dots_host(s, v, ldv, result, ldres, nb, vdot));
+      s->p->stats.numOrthoInnerProds += nb;
+      s->p->stats.timeOrtho += pa_wtime() - t0;
+      return 0;
+#else
       if (xr_out) {
          if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
          if (P->nLQ > 0) CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
@@ -269,8 +303,9 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
       for (int i = 0; i < nb; i++) vdot[i] = s->h_red[i];
       s->p->stats.numOrthoInnerProds += nb;
       s->p->stats.timeOrtho += pa_wtime() - t0;
+#endif
    } else {
-      if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
+      if (!shifted) CHK(hipk_axpy_cols(s->ctx, RDT(s), RM(s), ms, v, R2(ldv), result, R2(ldres), nb));
       CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
       CHK(pair_dots_host(s, v, ldv, result, ldres, nb, vdot));
    }
@@ -287,10 +322,10 @@ static int apply_projected_preconditioner(pa_solver *s, char *v, int64_t ldv, co
          /* result_i -= K^-1 x_i (x_i' result_i) / (x_i' K^-1 x_i)  (reference inner_solve.c:737-741) */
          double t0 = pa_wtime();
          CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->x, s->ld, result, ldres, nb, s->d_red));
-         CHK(pa_reduce(s, s->d_red, nb, 0, 0));
-         double alpha[64];
-         for (int i = 0; i < nb; i++) alpha[i] = -s->h_red[i] / P->xKx[i];
-         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, alpha, P->RX, P->ldRX, result, ldres, nb));
+         CHK(pa_reduce(s, s->d_red, SD * nb, 0, 0));
+         HS alpha[64];
+         for (int i = 0; i < nb; i++) alpha[i] = -((const HS *)s->h_red)[i] / P->xKx[i];
+         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)alpha, P->RX, P->ldRX, result, ldres, nb));
          s->p->stats.numOrthoInnerProds += nb;
          s->p->stats.timeOrtho += pa_wtime() - t0;
       } else {
@@ -319,7 +354,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    const void *jac_diag = NULL;
    int jac_fixed = 0;
    double jac_shift = 0.0, rho_new[64];
-   const int fuse_pk = (b0 > 1 && !plain_K && p->correctionParams.precondition && p->applyPreconditioner == primme_amd_jacobi_precond &&
+   const int fuse_pk = (!PA_IS_COMPLEX && b0 > 1 && !plain_K && p->correctionParams.precondition && p->applyPreconditioner == primme_amd_jacobi_precond &&
                         p->preconditioner && P->nRQ == 0 && P->nRX == 0 && !P->skewQ &&
                         primme_amd_operator_jacobi_data((primme_amd_operator *)p->preconditioner, &jac_diag, &jac_fixed, &jac_shift) == 0);
    int pm[64], p0[64];
@@ -363,7 +398,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    for (int64_t numIts = 0; numIts < maxIterations && blockSize > 0; numIts++) {
       /* blocks: the x-projection of w is folded into the update of g below (one pass and one
        * synchronisation fewer per step); block size 1 keeps the reference's operation order */
-      const int fold_x = (b0 > 1 && P->nLX > 0);
+      const int fold_x = (!PA_IS_COMPLEX && b0 > 1 && P->nLX > 0);
       double xr[64];
       CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld, tmp, fold_x ? xr : NULL));
       for (i = 0; i < blockSize; i++) sigma_prev[pm[i]] = tmp[i];
@@ -391,15 +426,15 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          for (i = 0; i < blockSize; i++) al[i] = -malpha[i];
          CHK(hipk_axpy_proj_dot(s->ctx, s->dt, s->m, blockSize, al, xr, w, ld, P->LX, P->ldLX, g, ld, s->d_red));
       } else
-      CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, blockSize, malpha, w, ld, g, ld, NULL, 0, s->d_red));
+      CHK(hipk_axpy_dot(s->ctx, RDT(s), RM(s), blockSize, malpha, w, R2(ld), g, R2(ld), NULL, 0, s->d_red));
       CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
       for (i = 0; i < blockSize; i++) gg[i] = s->h_red[i];
 
 #define SHRINK()                                                                                   \
       do {                                                                                         \
          pa_permute_ints(pm, blockSize, p0);                                                       \
-         pa_permute_cols(shift, 1, blockSize, 1, p0);                                              \
-         pa_permute_cols(gg, 1, blockSize, 1, p0);                                                 \
+         pa_permute_reals(shift, 1, blockSize, 1, p0);                                             \
+         pa_permute_reals(gg, 1, blockSize, 1, p0);                                                \
          CHK(permute_panel(s, g, ld, blockSize, p0));                                              \
          CHK(permute_panel(s, d, ld, blockSize, p0));                                              \
          CHK(permute_panel(s, delta, ld, blockSize, p0));                                          \
@@ -407,7 +442,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          CHK(permute_panel(s, x, ld, blockSize, p0));    /* LX / RX alias x */                     \
          if (P->skewX && P->nRX) {                                                                 \
             CHK(permute_panel(s, P->RX, P->ldRX, blockSize, p0));                                  \
-            pa_permute_cols(P->xKx, 1, blockSize, 1, p0);                                          \
+            pa_permute_reals(P->xKx, 1, blockSize, 1, p0);                                         \
          }                                                                                         \
          CHK(permute_panel(s, sol, ld, blockSize, p0));                                            \
          blockSize -= conv;                                                                        \
@@ -441,7 +476,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          p->stats.timePrecond += pa_wtime() - t0;
          have_w = 1;
       } else {
-         CHK(hipk_qmr_update(s->ctx, s->dt, s->m, blockSize, gam_c, eta_c, d, ld, delta, ld, sol, ld, s->d_red));
+         CHK(hipk_qmr_update(s->ctx, RDT(s), RM(s), blockSize, gam_c, eta_c, d, R2(ld), delta, R2(ld), sol, R2(ld), s->d_red));
          if (adaptive) {
             CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
             for (i = 0; i < blockSize; i++) dot_sol[i] = s->h_red[i];
@@ -494,7 +529,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
       }
       if (have_w && conv > 0) {
          CHK(permute_panel(s, w, ld, blockSize, p0));
-         pa_permute_cols(rho_new, 1, blockSize, 1, p0);
+         pa_permute_reals(rho_new, 1, blockSize, 1, p0);
       }
       SHRINK();
       if (blockSize <= 0) break;
@@ -515,9 +550,9 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
             rho_prev[q] = rho[q]; tau_prev[q] = tau[q]; Theta_prev[q] = Theta[q];
          }
          if (plain_K) {
-            CHK(hipk_xpay_cols(s->ctx, s->dt, s->m, beta, g, ld, d, ld, blockSize));      /* d = g + beta d */
+            CHK(hipk_xpay_cols(s->ctx, RDT(s), RM(s), beta, g, R2(ld), d, R2(ld), blockSize));      /* d = g + beta d */
          } else {
-            CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, beta, d, ld, w, ld, blockSize));      /* w += beta d */
+            CHK(hipk_axpy_cols(s->ctx, RDT(s), RM(s), beta, d, R2(ld), w, R2(ld), blockSize));      /* w += beta d */
             char *t = d; d = w; w = t;
          }
       }

@@ -240,13 +240,10 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
 
    char *r = WCOL(s, basisSize), *x = VCOL(s, basisSize);
    int rc = 0;
-#if !PA_IS_COMPLEX
    if (p->correctionParams.maxInnerIterations != 0) {
       /* JDQMR: inner-outer iteration (reference correction.c:385-467) */
       rc = pa_correction_jdqmr(s, basisSize, blockSize, blockNorms, iev, shifts, numLocked, numConvergedStored, touch);
-   } else
-#endif
-   if (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX) {
+   } else if (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX) {
       /* exact Olsen: x <- K^-1 r - (x'K^-1 r / x'K^-1 x) K^-1 x  (reference correction.c:718-777);
        * K^-1 [x r] live in the scratch panel */
       if (2 * blockSize > s->nT) rc = PRIMME_UNEXPECTED_FAILURE;
@@ -856,9 +853,9 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    /* what this build of the path covers; anything else must fail loudly */
 #if PA_IS_COMPLEX
    if (dt != HIPK_C64 && dt != HIPK_C32) return PRIMME_FUNCTION_UNAVAILABLE;
-   /* the complex objects carry Rayleigh-Ritz extraction and the Generalized-Davidson family; eigs_complex.c sends
-    * everything else to the real-equivalent form and never calls in here with it */
-   if (p->projectionParams.projection != primme_proj_RR || p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0)
+   /* the complex objects carry Rayleigh-Ritz extraction with the Generalized-Davidson family and the JDQMR inner solver;
+    * eigs_complex.c sends everything else to the real-equivalent form and never calls in here with it */
+   if (p->projectionParams.projection != primme_proj_RR || p->dynamicMethodSwitch > 0)
       return PRIMME_FUNCTION_UNAVAILABLE;
 #else
    if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
@@ -931,8 +928,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
                         p->correctionParams.projectors.RightQ && p->correctionParams.projectors.SkewQ;
    if (need_hat) {
       s->ldM = maxEvecs;
-      s->Mq = (double *)calloc((size_t)maxEvecs * maxEvecs + 1, 8);
-      s->Mlu = (double *)calloc((size_t)maxEvecs * maxEvecs + 1, 8);
+      s->Mq = (HS *)calloc((size_t)maxEvecs * maxEvecs + 1, sizeof(HS));
+      s->Mlu = (HS *)calloc((size_t)maxEvecs * maxEvecs + 1, sizeof(HS));
       s->Mpiv = (int *)calloc((size_t)maxEvecs + 1, sizeof(int));
       if (!s->Mq || !s->Mlu || !s->Mpiv) { free_solver(s); p->queue = user_queue; return PRIMME_MALLOC_FAILURE; }
    }

@@ -1,12 +1,12 @@
 /* eigs_scalar.h — the scalar type of the projected problem (the reference's HSCALAR, src/include/template.h).
  *
  * The host solver sources that touch coefficient-space data (eigs_main.c, eigs_ops.c, eigs_conv.c,
- * eigs_restart.c, eigs_block.c, eigs_dense.c) are compiled twice, like the reference's templated sources: once
+ * eigs_restart.c, eigs_block.c, eigs_dense.c, eigs_jd.c) are compiled twice, like the reference's templated sources: once
  * as they are (HS = double: hip_dprimme / hip_sprimme) and once with PA_COMPLEX defined (HS = double complex:
  * the native path of hip_zprimme / hip_cprimme) through the one-line wrappers eigs_*_z.c.  In the complex
  * objects every external function of those files carries the suffix _z (the list below is checked by the
  * linker: a missing entry is a duplicate symbol).  Files that are NOT on the native complex path (harmonic /
- * refined extraction, the JDQMR inner solver, the dynamic method) exist once; a Hermitian problem that asks
+ * refined extraction, the dynamic method) exist once; a Hermitian problem that asks
  * for them runs on the real-equivalent form (eigs_complex.c).
  *
  * Device-layer conventions for complex panels (include/primme_amd_kernels.h): inner products, projection
@@ -51,6 +51,9 @@ typedef double _Complex HS;
 #define pa_block_first_reorder pa_block_first_reorder_z
 #define pa_restart pa_restart_z
 #define pa_eigs_solve pa_eigs_solve_z
+#define pa_evecs_hat_init pa_evecs_hat_init_z
+#define pa_evecs_hat_update pa_evecs_hat_update_z
+#define pa_correction_jdqmr pa_correction_jdqmr_z
 #else
 typedef double HS;
 #define SD 1

@@ -44,7 +44,7 @@ typedef struct pa_solver {
    /* K^-1-weighted (skew) right projector of the correction equation: evecsHat = K^-1 evecs for
     * the stored converged / constraint vectors, M = evecs' evecsHat and its LU factors (host) */
    char *evecsHat;
-   double *Mq, *Mlu;
+   HS *Mq, *Mlu;
    int *Mpiv, ldM;
    char *Jw;               /* JDQMR work panels g, d, delta, w, sol: m x 5b (only with inner iterations) */
    int nT;

@@ -20,6 +20,12 @@ python scripts/pmc_summary.py $O/${TAG}_pmc_fetch/p_results.db $O/${TAG}_pmc_fet
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_pmc_write -o p -- python scripts/one_solve.py csr > /dev/null 2> $O/${TAG}_pmc_write.log
 python scripts/pmc_summary.py $O/${TAG}_pmc_write/p_results.db $O/${TAG}_pmc_write.md > /dev/null
 python scripts/pmc_traffic.py $O/${TAG}_pmc_fetch/p_results.db $O/${TAG}_pmc_write/p_results.db $O/${TAG}_pmc_traffic.md $O/${TAG}_pmc_traffic.json $O/${TAG}_bench.json ${TAG}
+# ---- configs[4] SpMV pair: how many bytes the two products really move (each 8-byte gather of this matrix pulls its own
+#      cache line: the kernels are bound by lines, not by the algorithmic bytes)
+python scripts/config5_spmv_perf.py > $O/${TAG}_config5_spmv_pair.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pmc_c5 -o p -- python scripts/config5_spmv_perf.py > /dev/null 2> $O/${TAG}_pmc_c5.log
+python scripts/pmc_summary.py $O/${TAG}_pmc_c5/p_results.db $O/${TAG}_pmc_config5_spmv_fetch.md > /dev/null; cat $O/${TAG}_pmc_config5_spmv_fetch.md | head -6
+rm -rf $O/${TAG}_pmc_c5
 # ---- north-star workload (10 M-row 5-pt Laplacian): kernel statistics of the first 3000 outer iterations and the two PMC passes
 rocprofv3 --kernel-trace -d $O/${TAG}_prof_ns -o ns -- python scripts/one_solve.py csr lap2d_10m 3000 > $O/${TAG}_ns_run.log 2> $O/${TAG}_prof_ns.log
 python scripts/rocpd_summary.py $O/${TAG}_prof_ns/ns_results.db $O/${TAG}_north_star_kernel_stats.md > /dev/null; head -12 $O/${TAG}_north_star_kernel_stats.md; tail -1 $O/${TAG}_north_star_kernel_stats.md

@@ -3,7 +3,7 @@
     python tests/golden/make_complex_golden.py
 Fixtures are data: the matrices and start vectors are closed forms (primme_amd.problems.hermitian_graded_csr,
 complex_start_vector), the outputs are the reference's evals / resNorms / counts for the native complex path of
-hip_zprimme / hip_cprimme (Rayleigh-Ritz extraction, Generalized-Davidson family) to reproduce."""
+hip_zprimme / hip_cprimme (Rayleigh-Ritz extraction, Generalized-Davidson family and JDQMR) to reproduce."""
 import json
 import os
 import sys
@@ -33,6 +33,11 @@ CASES = {
     "z_blk2_implicit": (600, dict(numEvals=5, method="GD_plusK", eps=1e-9, maxBlockSize=2, orth=F.primme_orth_implicit_I)),
     "z_blk1_explicit": (600, dict(numEvals=4, method="GD_plusK", eps=1e-9, orth=F.primme_orth_explicit_I)),
     "z_krylov_rng": (600, dict(numEvals=4, method="GD_plusK", eps=1e-9, v0=None, iseed=(1, 2, 3, 5))),
+    # JDQMR inner-outer iteration on complex data (real QMR recurrences, complex projectors)
+    "z_jdqmr": (600, dict(numEvals=4, method="JDQMR", eps=1e-10)),
+    "z_jdqmr_etol": (600, dict(numEvals=4, method="JDQMR_ETol", eps=1e-10)),
+    "z_jdqmr_largest_soft": (600, dict(numEvals=3, method="JDQMR", eps=1e-9, target="largest", locking=0)),
+    "z_jdqmr_etol_jacobi": (600, dict(numEvals=4, method="JDQMR_ETol", eps=1e-10, precond="jacobi")),
     "c_gdk_blk2": (600, dict(numEvals=4, method="GD_plusK", eps=1e-4, maxBlockSize=2, dtype="complex64")),
     "c_gdk_b1": (600, dict(numEvals=3, method="GD_plusK", eps=1e-4, dtype="complex64")),
 }
