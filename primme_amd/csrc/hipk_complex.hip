@@ -329,10 +329,97 @@ zritz_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *__
    }
 }
 
+/* The same with TWO lanes per row for more than 16 outputs: lanes 2r and 2r + 1 read the same elements of V and W (one
+ * 16-byte request, merged by the coalescer) and each keeps half of the accumulators — NJH = 16 complex instead of 32,
+ * so the kernel runs at 3-4 waves per SIMD where the one-lane form holds 256 VGPRs (one wave per SIMD, 3.1 TB/s on the
+ * restart pass of configs[3]).  Slot tables live in LDS (a lane's half is not uniform across the wave). */
+struct ZJobs2 { void *dst[2][16]; int col[2][16]; signed char isw[2][16]; short slot[2][16]; };
+template <typename R, int NRH>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+zritz2_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *__restrict__ h, int ldh,
+      const double *__restrict__ theta, ZJobs2 jb, int64_t m, double *__restrict__ partials) {
+   constexpr int NJH = 16, NPH = NJH - NRH;
+   __shared__ zacc sh[ZRITZ_JT * 2 * NJH];        /* sh[(jj * 2 + half) * NJH + q] */
+   __shared__ double sth[2][NRH];
+   __shared__ void *sdst[2][NJH];
+   __shared__ int sisw[2][NJH];
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
+   for (int t = threadIdx.x; t < 2 * NJH; t += HIPK_BLOCK) {
+      const int hf = t / NJH, q = t % NJH;
+      sdst[hf][q] = jb.dst[hf][q]; sisw[hf][q] = jb.isw[hf][q];
+      if (q >= NPH) sth[hf][q - NPH] = jb.col[hf][q] >= 0 ? theta[jb.col[hf][q]] : 0.0;
+   }
+   const int half = threadIdx.x & 1;
+   const int64_t stride = (int64_t)gridDim.x * (HIPK_BLOCK / 2);
+   const int64_t mpad = (m + stride - 1) / stride * stride;
+   double n2[NRH];
+#pragma unroll
+   for (int q = 0; q < NRH; q++) n2[q] = 0.0;
+   const bool once = k <= ZRITZ_JT;
+   if (once) {
+      for (int t = threadIdx.x; t < k * 2 * NJH; t += HIPK_BLOCK) {
+         const int jj = t / (2 * NJH), r = t % (2 * NJH), hf = r / NJH, q = r % NJH;
+         sh[t] = (jb.col[hf][q] >= 0) ? h[jj + (size_t)jb.col[hf][q] * ldh] : zacc{0.0, 0.0};
+      }
+   }
+   __syncthreads();
+   for (int64_t i = (int64_t)blockIdx.x * (HIPK_BLOCK / 2) + (threadIdx.x >> 1); i < mpad; i += stride) {
+      const bool live = i < m;
+      const int64_t ic = live ? i : m - 1;
+      zacc acc[NJH];
+#pragma unroll
+      for (int q = 0; q < NJH; q++) acc[q] = {0.0, 0.0};
+      for (int j0 = 0; j0 < k; j0 += ZRITZ_JT) {
+         const int jn = min(ZRITZ_JT, k - j0);
+         if (!once) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < jn * 2 * NJH; t += HIPK_BLOCK) {
+               const int jj = t / (2 * NJH), r = t % (2 * NJH), hf = r / NJH, q = r % NJH;
+               sh[t] = (jb.col[hf][q] >= 0) ? h[(j0 + jj) + (size_t)jb.col[hf][q] * ldh] : zacc{0.0, 0.0};
+            }
+            __syncthreads();
+         }
+#pragma unroll 1
+         for (int jj = 0; jj < jn; jj++) {
+            const zacc v = zload(V + (size_t)(j0 + jj) * ld + ic);
+            const zacc w = W ? zload(W + (size_t)(j0 + jj) * ld + ic) : zacc{0.0, 0.0};
+            const zacc *hrow = sh + (size_t)(jj * 2 + half) * NJH;
+#pragma unroll
+            for (int q = 0; q < NPH; q++) zfma(acc[q], sisw[half][q] ? w : v, hrow[q]);
+#pragma unroll
+            for (int q = 0; q < NRH; q++) {
+               const double th = sth[half][q];
+               const zacc sres = {fma(-th, v.re, w.re), fma(-th, v.im, w.im)};
+               zfma(acc[NPH + q], sres, hrow[NPH + q]);
+            }
+         }
+      }
+      if (live) {
+#pragma unroll
+         for (int q = 0; q < NJH; q++) {
+            cpx<R> st; st.re = (R)acc[q].re; st.im = (R)acc[q].im;
+            cpx<R> *dq = (cpx<R> *)sdst[half][q];
+            if (dq) dq[i] = st;
+            if (q >= NPH) n2[q - NPH] = fma((double)st.re, (double)st.re, fma((double)st.im, (double)st.im, n2[q - NPH]));
+         }
+      }
+   }
+   if (partials) {
+      const unsigned nb = gridDim.x;
+      for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+         for (int q = 0; q < NRH; q++) {
+            const int slot = jb.slot[hf][NPH + q];
+            const double v = zblock_sum(half == hf ? n2[q] : 0.0, sm);
+            if (threadIdx.x == 0 && slot >= 0) partials[(size_t)slot * nb + blockIdx.x] = v;
+         }
+   }
+}
+
 /* one launch: np plain jobs + nr residual jobs, np + nr <= 32 */
 template <typename R>
 static int zritz_launch(hipk_ctx *ctx, int64_t m, const void *V, const void *W, int64_t ld, int k, const double *h, int ldh,
-      const double *theta, const hipk_job *jobs, int nj, int gx, bool norms) {
+      const double *theta, const hipk_job *jobs, int nj, int gx, bool norms, bool allow_split) {
    int np = 0, nr = 0;
    for (int q = 0; q < nj; q++) { if (jobs[q].kind == HIPK_JOB_RES) nr++; else np++; }
    int NJ, NR;
@@ -342,6 +429,35 @@ static int zritz_launch(hipk_ctx *ctx, int64_t m, const void *V, const void *W, 
    else if (np == 0 && nr <= 16) { NJ = 16; NR = 16; }
    else if (nr <= 16 && np <= 16) { NJ = 32; NR = 16; }
    else return 1;                                 /* does not fit one pass */
+   static int nosplit = -1;                       /* HIPK_Z_NO_SPLIT=1: the one-lane-per-row form for every size (A/B knob) */
+   if (nosplit < 0) nosplit = getenv("HIPK_Z_NO_SPLIT") != NULL;
+   if (NJ == 32 && !nosplit && allow_split) {
+      /* two lanes per row: half 0 takes the first ceil(np/2) plain and ceil(nr/2) residual jobs, half 1 the rest */
+      const int NRH = (NR == 4) ? 2 : 8, NPH = 16 - NRH;
+      ZJobs2 j2;
+      for (int hf = 0; hf < 2; hf++) for (int q = 0; q < 16; q++) { j2.dst[hf][q] = NULL; j2.col[hf][q] = -1; j2.isw[hf][q] = 0; j2.slot[hf][q] = -1; }
+      int ip[2] = {0, 0}, ir[2] = {NPH, NPH};
+      const int np0 = (np + 1) / 2, nr0 = (nr + 1) / 2;
+      int seenp = 0, seenr = 0;
+      bool fits = np0 <= NPH && nr0 <= NRH;
+      for (int q = 0; q < nj && fits; q++) {
+         const bool res = jobs[q].kind == HIPK_JOB_RES;
+         const int hf = res ? (seenr++ < nr0 ? 0 : 1) : (seenp++ < np0 ? 0 : 1);
+         const int at = res ? ir[hf]++ : ip[hf]++;
+         j2.dst[hf][at] = jobs[q].dst; j2.col[hf][at] = jobs[q].col; j2.isw[hf][at] = (jobs[q].kind == HIPK_JOB_XW); j2.slot[hf][at] = (short)jobs[q].slot;
+      }
+      if (fits) {
+         int64_t need = (m + 127) / 128;
+         const int gx2 = (int)(need < 1 ? 1 : (need < (int64_t)ctx->num_cu * 8 ? need : (int64_t)ctx->num_cu * 8));
+         /* the partial sums of the norms are indexed by THIS grid: the caller's second stage is told through gx_out */
+#define ZR2(NRHV) hipLaunchKernelGGL((zritz2_kernel<R, NRHV>), dim3(gx2), dim3(HIPK_BLOCK), 0, ctx->stream, (const cpx<R> *)V, (const cpx<R> *)W, ld, k, \
+            (const zacc *)h, ldh, theta, j2, m, norms ? ctx->partials : (double *)NULL)
+         if (NRH == 2) ZR2(2); else ZR2(8);
+#undef ZR2
+         HIPK_CHECK(hipGetLastError());
+         return -(1000 + gx2);                     /* launched with its own grid: the caller finalises over gx2 blocks */
+      }
+   }
    ZJobs jb;
    for (int q = 0; q < ZRITZ_JOBS; q++) { jb.dst[q] = NULL; jb.col[q] = -1; jb.isw[q] = 0; jb.slot[q] = -1; }
    int ip = 0, ir = NJ - NR;
@@ -369,9 +485,11 @@ static int zritz_t(hipk_ctx *ctx, int64_t m, const void *V, const void *W, int64
    }
    if (nslots > 0 && !nrm2_dev) return -1;
    const int gx = zgrid(ctx, m, 4);
-   if (nslots > 0 && hipk_reserve_partials(ctx, (size_t)nslots * gx)) return -2;
+   if (nslots > 0 && hipk_reserve_partials(ctx, (size_t)nslots * (size_t)ctx->num_cu * 8)) return -2;   /* (the two-lane form runs up to 8 workgroups per CU) */
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)(2 * k + nout) * (double)m * 2.0 * sizeof(R));
-   int rc = zritz_launch<R>(ctx, m, V, W, ld, k, h, ldh, theta, jobs, njobs, gx, nslots > 0);
+   int gfin = gx;                                  /* blocks the partial norms were written by */
+   int rc = zritz_launch<R>(ctx, m, V, W, ld, k, h, ldh, theta, jobs, njobs, gx, nslots > 0, true);
+   if (rc <= -1000) { gfin = -rc - 1000; rc = 0; }
    if (rc == 1) {
       /* more outputs than one pass holds: every chunk reads the OLD panels, so the chunks write a temporary and the
        * columns move to their (possibly aliasing) destinations afterwards; slots never written are zeroed first */
@@ -388,7 +506,7 @@ static int zritz_t(hipk_ctx *ctx, int64_t m, const void *V, const void *W, int64
       for (int q = 0; q <= njobs && !rc; q++) {
          const bool res = q < njobs && work[q].kind == HIPK_JOB_RES;
          if (q == njobs || (res ? cr == 16 : cp == 16)) {
-            if (!chunk.empty()) rc = zritz_launch<R>(ctx, m, V, W, ld, k, h, ldh, theta, chunk.data(), (int)chunk.size(), gx, nslots > 0);
+            if (!chunk.empty()) rc = zritz_launch<R>(ctx, m, V, W, ld, k, h, ldh, theta, chunk.data(), (int)chunk.size(), gx, nslots > 0, false);
             chunk.clear(); cp = cr = 0;
          }
          if (q < njobs) { chunk.push_back(work[q]); if (res) cr++; else cp++; }
@@ -400,7 +518,7 @@ static int zritz_t(hipk_ctx *ctx, int64_t m, const void *V, const void *W, int64
    }
    hipk_prof_end(pslot, ctx->stream);
    if (rc) return rc;
-   if (nslots > 0) return hipk_finalize_partials_t(ctx, ctx->partials, gx, nslots, nrm2_dev);
+   if (nslots > 0) return hipk_finalize_partials_t(ctx, ctx->partials, gfin, nslots, nrm2_dev);
    return 0;
 }
 
