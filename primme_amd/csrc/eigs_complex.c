@@ -36,10 +36,11 @@ int pa_eigs_solve(void *evals_out, void *evecs, void *resNorms_out, primme_param
 int pa_eigs_solve_z(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double);
 
 /* NATIVE path: complex panels, complex Hermitian projected problem, the reference's zprimme iteration for iteration.
- * Covers Rayleigh-Ritz extraction with the Generalized-Davidson family (GD, GD+k, Olsen variants, LOBPCG-like
- * presets; locking and soft locking; any block size), which includes the default method and BASELINE configs[3], and
- * the JDQMR inner-outer iteration (real QMR recurrences on the 2m-real view of the panels, complex projectors).
- * Harmonic / refined extraction and the dynamic method have no complex objects yet: those
+ * Covers the Generalized-Davidson family (GD, GD+k, Olsen variants, LOBPCG-like presets; locking and soft locking;
+ * any block size), which includes the default method and BASELINE configs[3], the JDQMR inner-outer iteration
+ * (real QMR recurrences on the 2m-real view of the panels, complex projectors), and the three extractions
+ * (Rayleigh-Ritz; harmonic and refined for interior targets, eigs_harm.c).
+ * The dynamic method switch has no complex objects yet: those
  * requests (and the library's operator when it was built on the real-equivalent CSR expansion) take the
  * real-equivalent form below.  PRIMME_AMD_COMPLEX_REAL_FORM=1 forces the latter (A/B measurements). */
 static int native_complex_ok(const primme_params *primme) {
@@ -47,7 +48,6 @@ static int native_complex_ok(const primme_params *primme) {
    primme_params t = *primme;
    if (t.numProcs <= 1) { t.nLocal = t.n; t.procID = 0; }
    primme_set_defaults(&t);
-   if (t.projectionParams.projection != primme_proj_RR) return 0;
    if (t.dynamicMethodSwitch > 0) return 0;
    if (primme->matrixMatvec == primme_amd_matvec) {
       /* the library's operator: native only over a complex CSR matrix */

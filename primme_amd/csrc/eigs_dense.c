@@ -422,13 +422,17 @@ void pa_larnv_uniform11(int64_t iseed[4], int64_t n, double *x) {
    iseed[3] = (int64_t)(s & 4095);
 }
 
+#endif   /* !PA_IS_COMPLEX */
+
 /* ---- singular value decomposition A = U diag(S) V' of a small square matrix ------------------
  * One-sided Jacobi (Hestenes): columns of W = A V are rotated until mutually orthogonal; S are
  * their norms, sorted descending like xGESVD (which the reference calls, blaslapack.c Num_gesvd).
- * High relative accuracy also for the small singular values the refined extraction looks at. */
-int pa_svd(const double *A, int ldA, int n, double *U, int ldU, double *S, double *V, int ldV) {
+ * High relative accuracy also for the small singular values the refined extraction looks at.
+ * Complex: the pair (p, q) is first brought to a real inner product by the phase of w_p^H w_q, then
+ * rotated as in the real case; V' means V^H. */
+int pa_svd(const HS *A, int ldA, int n, HS *U, int ldU, double *S, HS *V, int ldV) {
    if (n <= 0) return 0;
-   double *W = (double *)malloc(sizeof(double) * (size_t)n * n);
+   HS *W = (HS *)malloc(sizeof(HS) * (size_t)n * n);
    if (!W) return PRIMME_MALLOC_FAILURE;
    for (int j = 0; j < n; j++)
       for (int i = 0; i < n; i++) { W[i + (size_t)j * n] = A[i + (size_t)j * ldA]; V[i + (size_t)j * ldV] = (i == j) ? 1.0 : 0.0; }
@@ -436,18 +440,27 @@ int pa_svd(const double *A, int ldA, int n, double *U, int ldU, double *S, doubl
       int rotated = 0;
       for (int p = 0; p < n - 1; p++)
          for (int q = p + 1; q < n; q++) {
-            double a = 0.0, b = 0.0, g = 0.0;
-            const double *wp = W + (size_t)p * n, *wq = W + (size_t)q * n;
-            for (int i = 0; i < n; i++) { a += wp[i] * wp[i]; b += wq[i] * wq[i]; g += wp[i] * wq[i]; }
-            if (fabs(g) <= PA_EPS * sqrt(a * b) || g == 0.0) continue;
+            double a = 0.0, b = 0.0;
+            HS gz = 0.0;
+            const HS *wp = W + (size_t)p * n, *wq = W + (size_t)q * n;
+            for (int i = 0; i < n; i++) { a += HS_ABS2(wp[i]); b += HS_ABS2(wq[i]); gz += HS_CONJ(wp[i]) * wq[i]; }
+            const double g = HS_ABS(gz);
+            if (g <= PA_EPS * sqrt(a * b) || g == 0.0) continue;
             rotated = 1;
-            const double zeta = (b - a) / (2.0 * g);
+#if PA_IS_COMPLEX
+            const HS ph = HS_CONJ(gz) / g;          /* w_q ph has a real, positive inner product with w_p */
+            const double gs = g;
+#else
+            const HS ph = 1.0;
+            const double gs = gz;
+#endif
+            const double zeta = (b - a) / (2.0 * gs);
             const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
             const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-            double *xp = W + (size_t)p * n, *xq = W + (size_t)q * n;
-            for (int i = 0; i < n; i++) { const double u = xp[i], v = xq[i]; xp[i] = c * u - sn * v; xq[i] = sn * u + c * v; }
-            double *vp = V + (size_t)p * ldV, *vq = V + (size_t)q * ldV;
-            for (int i = 0; i < n; i++) { const double u = vp[i], v = vq[i]; vp[i] = c * u - sn * v; vq[i] = sn * u + c * v; }
+            HS *xp = W + (size_t)p * n, *xq = W + (size_t)q * n;
+            for (int i = 0; i < n; i++) { const HS u = xp[i], v = xq[i] * ph; xp[i] = c * u - sn * v; xq[i] = sn * u + c * v; }
+            HS *vp = V + (size_t)p * ldV, *vq = V + (size_t)q * ldV;
+            for (int i = 0; i < n; i++) { const HS u = vp[i], v = vq[i] * ph; vp[i] = c * u - sn * v; vq[i] = sn * u + c * v; }
          }
       if (!rotated) break;
    }
@@ -456,7 +469,7 @@ int pa_svd(const double *A, int ldA, int n, double *U, int ldU, double *S, doubl
    if (!perm || !nrm) { free(W); free(perm); free(nrm); return PRIMME_MALLOC_FAILURE; }
    for (int j = 0; j < n; j++) {
       double t = 0.0;
-      for (int i = 0; i < n; i++) t += W[i + (size_t)j * n] * W[i + (size_t)j * n];
+      for (int i = 0; i < n; i++) t += HS_ABS2(W[i + (size_t)j * n]);
       nrm[j] = sqrt(t); perm[j] = j;
    }
    for (int i = 1; i < n; i++) {             /* insertion sort, descending */
@@ -465,16 +478,34 @@ int pa_svd(const double *A, int ldA, int n, double *U, int ldU, double *S, doubl
       while (j >= 0 && nrm[perm[j]] < nrm[pi]) { perm[j + 1] = perm[j]; j--; }
       perm[j + 1] = pi;
    }
-   double *Vc = (double *)malloc(sizeof(double) * (size_t)n * n);
+   HS *Vc = (HS *)malloc(sizeof(HS) * (size_t)n * n);
    if (!Vc) { free(W); free(perm); free(nrm); return PRIMME_MALLOC_FAILURE; }
-   for (int j = 0; j < n; j++) memcpy(Vc + (size_t)j * n, V + (size_t)perm[j] * ldV, sizeof(double) * (size_t)n);
+   for (int j = 0; j < n; j++) memcpy(Vc + (size_t)j * n, V + (size_t)perm[j] * ldV, sizeof(HS) * (size_t)n);
    for (int j = 0; j < n; j++) {
       const int pj = perm[j];
       S[j] = nrm[pj];
-      memcpy(V + (size_t)j * ldV, Vc + (size_t)j * n, sizeof(double) * (size_t)n);
+      memcpy(V + (size_t)j * ldV, Vc + (size_t)j * n, sizeof(HS) * (size_t)n);
       for (int i = 0; i < n; i++) U[i + (size_t)j * ldU] = (nrm[pj] > 0.0) ? W[i + (size_t)pj * n] / nrm[pj] : (i == j ? 1.0 : 0.0);
+   }
+   /* V is a product of thousands of plane rotations: its columns are orthonormal to about 1e-14 only, and the
+    * restarted basis V h inherits that with every restart (xGESVD's Householder vectors keep 1e-16).  Two
+    * Gram-Schmidt passes bring it back, from the smallest singular value (left as it is, but normalised) upwards;
+    * U and S keep describing A V to a backward error of that size. */
+   for (int j = n - 1; j >= 0; j--) {
+      HS *vj = V + (size_t)j * ldV;
+      for (int pass = 0; pass < 2; pass++)
+         for (int k = n - 1; k > j; k--) {
+            const HS *vk = V + (size_t)k * ldV;
+            HS t = 0.0;
+            for (int i = 0; i < n; i++) t += HS_CONJ(vk[i]) * vj[i];
+            for (int i = 0; i < n; i++) vj[i] -= t * vk[i];
+         }
+      double t = 0.0;
+      for (int i = 0; i < n; i++) t += HS_ABS2(vj[i]);
+      t = sqrt(t);
+      if (t > 0.0) for (int i = 0; i < n; i++) vj[i] /= t;
    }
    free(W); free(perm); free(nrm); free(Vc);
    return 0;
 }
-#endif
+

@@ -12,6 +12,10 @@
  * Gram-Schmidt with Daniel's test as for V, with the coefficients recorded in R.
  * Covered: orth = implicit_I (block size 1, double — the default for these targets), for both the
  * harmonic and the refined extraction (second half of this file).
+ *
+ * Compiled twice (eigs_scalar.h): HS = double, and HS = double complex through eigs_harm_z.c.  In the complex
+ * objects R, Q'V, hU and hVecsRot are complex, inner products come back as (re, im) pairs (Q^H x), the singular
+ * values and Ritz values stay real.
  */
 #include "eigs_solver.h"
 #include <math.h>
@@ -19,9 +23,9 @@
 #include <string.h>
 
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
-int pa_solve_H_RR(pa_solver *s, const double *H, int ldH, const double *VtBV, int ldVtBV,
-      double *hVecs, int ldhVecs, double *hVals, int n, int numConverged);
-int pa_ortho_local_vec(double *x, int n, const double *Q, int ldQ, int nQ, const double *G,
+int pa_solve_H_RR(pa_solver *s, const HS *H, int ldH, const HS *VtBV, int ldVtBV,
+      HS *hVecs, int ldhVecs, double *hVals, int n, int numConverged);
+int pa_ortho_local_vec(HS *x, int n, const HS *Q, int ldQ, int nQ, const HS *G,
       int ldG, double *R, int64_t iseed[4]);
 
 /* CGS + Daniel reorthogonalisation of Q(:, b1..b2) against Q(:, 0..i-1), coefficients into R
@@ -41,13 +45,15 @@ static int ortho_Q(pa_solver *s, int b1, int b2, int *nQ_out) {
          const int first = (pass == 0), nov = i, ndot = nov + (first ? 1 : 0);
          hipk_seg segs[3] = {{s->Q, s->ld, i}, {NULL, 0, 0}, {q, s->ld, first ? 1 : 0}};
          CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segs, 3, q, s->ld, 1, s->d_red, ndot));
-         CHK(pa_reduce(s, s->d_red, ndot, 1, 1));
-         CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 1, s->d_red, nov > 0 ? nov : 1, q, s->ld, 1, s->d_red + nov + 1));
-         CHK(pa_reduce(s, s->d_red + nov + 1, 1, 0, 0));
+         /* buffer: nov (+1) scalars of overlaps, then the REAL squared norm of the update (as in pa_ortho_cgs) */
+         const int s1_off = SD * (nov + 1);
+         CHK(pa_reduce(s, s->d_red, SD * ndot, 1, 1));
+         CHK(hipk_panel_project(s->ctx, s->dt, s->m, segs, 1, s->d_red, nov > 0 ? nov : 1, q, s->ld, 1, s->d_red + s1_off));
+         CHK(pa_reduce(s, s->d_red + s1_off, 1, 0, 0));
          p->stats.numOrthoInnerProds += ndot + nov + 1;
-         for (int j = 0; j < i; j++) s->R[j + (size_t)i * K] += s->h_red[j];
-         if (first) s0 = sqrt(s->h_red[nov]);
-         s1 = sqrt(s->h_red[nov + 1]);
+         for (int j = 0; j < i; j++) s->R[j + (size_t)i * K] += ((const HS *)s->h_red)[j];
+         if (first) s0 = sqrt(HS_RE(((const HS *)s->h_red)[nov]));
+         s1 = sqrt(s->h_red[s1_off]);
          if (!isfinite(s0) || !isfinite(s1) || s1 <= s->mach_eps * s0) break;   /* rank deficient */
          if (s1 > tol * s0) { ok = 1; break; }
          s0 = s1;
@@ -65,12 +71,12 @@ static int ortho_Q(pa_solver *s, int b1, int b2, int *nQ_out) {
 /* Q(:, col0:col0+bs) = W - tau V for the new columns, then orthonormalised against Q(:, 0:*nQ) */
 int pa_update_Q(pa_solver *s, double tau, int col0, int bs, int *nQ) {
    if (bs <= 0 || !s->Q) return 0;
-   double mt[64];
+   HS mt[64];
    for (int c0 = 0; c0 < bs; c0 += 64) {
       const int n = PA_MIN(64, bs - c0);
       for (int c = 0; c < n; c++) mt[c] = -tau;
       CHK(hipk_copy_cols(s->ctx, s->dt, s->m, WCOL(s, col0 + c0), s->ld, PCOL(s, s->Q, s->ld, col0 + c0), s->ld, n));
-      CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, mt, VCOL(s, col0 + c0), s->ld, PCOL(s, s->Q, s->ld, col0 + c0), s->ld, n));
+      CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)mt, VCOL(s, col0 + c0), s->ld, PCOL(s, s->Q, s->ld, col0 + c0), s->ld, n));
    }
    CHK(ortho_Q(s, *nQ, *nQ + bs - 1, nQ));
    for (int j = 0; j < col0; j++)                 /* R stays upper triangular */
@@ -86,35 +92,35 @@ int pa_update_QtV(pa_solver *s, int col0, int bs) {
       const int n = PA_MIN(8, bs - c0);
       hipk_seg sq = {s->Q, s->ld, n1};
       CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, VCOL(s, col0 + c0), s->ld, n, s->d_red, n1));
-      CHK(pa_reduce(s, s->d_red, n1 * n, 0, 0));
+      CHK(pa_reduce(s, s->d_red, SD * n1 * n, 0, 0));
       for (int c = 0; c < n; c++)
-         for (int i = 0; i < n1; i++) s->QtV[i + (size_t)(col0 + c0 + c) * K] = s->h_red[i + (size_t)c * n1];
+         for (int i = 0; i < n1; i++) s->QtV[i + (size_t)(col0 + c0 + c) * K] = ((const HS *)s->h_red)[i + (size_t)c * n1];
    }
    for (int c0 = 0; c0 < col0; c0 += 8) {          /* new rows: Q(:,new)' V(:,0:col0) */
       const int n = PA_MIN(8, col0 - c0);
       hipk_seg sq = {PCOL(s, s->Q, s->ld, col0), s->ld, bs};
       CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, VCOL(s, c0), s->ld, n, s->d_red, bs));
-      CHK(pa_reduce(s, s->d_red, bs * n, 0, 0));
+      CHK(pa_reduce(s, s->d_red, SD * bs * n, 0, 0));
       for (int c = 0; c < n; c++)
-         for (int i = 0; i < bs; i++) s->QtV[(col0 + i) + (size_t)(c0 + c) * K] = s->h_red[i + (size_t)c * bs];
+         for (int i = 0; i < bs; i++) s->QtV[(col0 + i) + (size_t)(c0 + c) * K] = ((const HS *)s->h_red)[i + (size_t)c * bs];
    }
    return 0;
 }
 
 /* harmonic Ritz pairs of the current basis: hVecs (k x k, ld k), hVals (Rayleigh quotients) */
-int pa_solve_H_harm(pa_solver *s, int k, const double *G, int ldG) {
+int pa_solve_H_harm(pa_solver *s, int k, const HS *G, int ldG) {
    primme_params *p = s->p;
    if (k == 0) return 0;
    const int K = s->K;
-   double *X = (double *)malloc(sizeof(double) * (size_t)k * k * 2);
+   HS *X = (HS *)malloc(sizeof(HS) * (size_t)k * k * 2);
    if (!X) return PRIMME_MALLOC_FAILURE;
-   double *HY = X + (size_t)k * k;
-   /* X = R^-T (Q'V)^T: forward substitution with R^T (R upper triangular) */
+   HS *HY = X + (size_t)k * k;
+   /* X = R^-H (Q'V)^H: forward substitution with R^H (R upper triangular) */
    for (int c = 0; c < k; c++) {
       for (int i = 0; i < k; i++) {
-         double t = s->QtV[c + (size_t)i * K];                 /* ((Q'V)^T)(i, c) */
-         for (int j = 0; j < i; j++) t -= s->R[j + (size_t)i * K] * X[j + (size_t)c * k];
-         X[i + (size_t)c * k] = t / s->R[i + (size_t)i * K];
+         HS t = HS_CONJ(s->QtV[c + (size_t)i * K]);            /* ((Q'V)^H)(i, c) */
+         for (int j = 0; j < i; j++) t -= HS_CONJ(s->R[j + (size_t)i * K]) * X[j + (size_t)c * k];
+         X[i + (size_t)c * k] = t / HS_CONJ(s->R[i + (size_t)i * K]);
       }
    }
    /* eigenpairs of X ordered for the inverse problem around shift 0 */
@@ -127,12 +133,12 @@ int pa_solve_H_harm(pa_solver *s, int k, const double *G, int ldG) {
    p->targetShifts = oldShifts;
    p->target = oldTarget;
    if (rc) { free(X); return rc; }
-   for (int c = 0; c < k; c++) memcpy(s->hU + (size_t)c * k, s->hVecs + (size_t)c * k, sizeof(double) * (size_t)k);
+   for (int c = 0; c < k; c++) memcpy(s->hU + (size_t)c * k, s->hVecs + (size_t)c * k, sizeof(HS) * (size_t)k);
    /* hVecs = R^-1 hU, then orthonormal columns */
    for (int c = 0; c < k; c++) {
-      double *y = s->hVecs + (size_t)c * k;
+      HS *y = s->hVecs + (size_t)c * k;
       for (int i = k - 1; i >= 0; i--) {
-         double t = y[i];
+         HS t = y[i];
          for (int j = i + 1; j < k; j++) t -= s->R[i + (size_t)j * K] * y[j];
          y[i] = t / s->R[i + (size_t)i * K];
       }
@@ -142,16 +148,16 @@ int pa_solve_H_harm(pa_solver *s, int k, const double *G, int ldG) {
       rc = pa_ortho_local_vec(s->hVecs + (size_t)c * k, k, s->hVecs, k, c, G, ldG, &r, p->iseed);
       if (rc) { free(X); return rc; }
    }
-   /* hVals_i = y_i' H y_i (H upper-stored symmetric) */
+   /* hVals_i = y_i' H y_i (H upper-stored Hermitian) */
    for (int c = 0; c < k; c++) {
-      const double *y = s->hVecs + (size_t)c * k;
+      const HS *y = s->hVecs + (size_t)c * k;
       for (int i = 0; i < k; i++) {
-         double t = 0.0;
-         for (int j = 0; j < k; j++) t += (j >= i ? s->H[i + (size_t)j * K] : s->H[j + (size_t)i * K]) * y[j];
+         HS t = 0.0;
+         for (int j = 0; j < k; j++) t += (j >= i ? s->H[i + (size_t)j * K] : HS_CONJ(s->H[j + (size_t)i * K])) * y[j];
          HY[i + (size_t)c * k] = t;
       }
       double v = 0.0;
-      for (int i = 0; i < k; i++) v += y[i] * HY[i + (size_t)c * k];
+      for (int i = 0; i < k; i++) v += HS_RE(HS_CONJ(y[i]) * HY[i + (size_t)c * k]);
       s->hVals[c] = v;
    }
    free(X);
@@ -163,7 +169,7 @@ int pa_restart_harmonic(pa_solver *s, int ldh, int restartSize, int basisSize, i
    primme_params *p = s->p;
    const int K = s->K;
    if (p->orth == primme_orth_implicit_I) {
-      double *blk = (double *)malloc(sizeof(double) * (size_t)(restartSize > 0 ? restartSize * restartSize : 1));
+      HS *blk = (HS *)malloc(sizeof(HS) * (size_t)(restartSize > 0 ? restartSize * restartSize : 1));
       if (!blk) return PRIMME_MALLOC_FAILURE;
       pa_submatrix(s->hVecs, restartSize, ldh, s->H, basisSize, K, blk, restartSize);
       for (int j = 0; j < restartSize; j++)
@@ -185,7 +191,7 @@ int pa_restart_harmonic(pa_solver *s, int ldh, int restartSize, int basisSize, i
  *                                                          singular values ("arbitrary vectors")
  *   pa_restart_refined   <- restart.c:1837-2160          Q, R after V <- V h without re-factorising
  * The QR factorisation (A - tau I) V = Q R is the one of the harmonic path (pa_update_Q). */
-int pa_svd(const double *A, int ldA, int n, double *U, int ldU, double *S, double *V, int ldV);
+int pa_svd(const HS *A, int ldA, int n, HS *U, int ldU, double *S, HS *V, int ldV);
 
 int pa_solve_H_ref(pa_solver *s, int k, double *hVals_out) {
    primme_params *p = s->p;
@@ -196,20 +202,20 @@ int pa_solve_H_ref(pa_solver *s, int k, double *hVals_out) {
       /* ascending singular values: the pairs closest to the shift first */
       for (int i = 0; i < k / 2; i++) {
          const int j = k - 1 - i;
-         double t = s->hSVals[i]; s->hSVals[i] = s->hSVals[j]; s->hSVals[j] = t;
+         double ts = s->hSVals[i]; s->hSVals[i] = s->hSVals[j]; s->hSVals[j] = ts;
          for (int r = 0; r < k; r++) {
-            t = s->hVecs[r + (size_t)i * k]; s->hVecs[r + (size_t)i * k] = s->hVecs[r + (size_t)j * k]; s->hVecs[r + (size_t)j * k] = t;
+            HS t = s->hVecs[r + (size_t)i * k]; s->hVecs[r + (size_t)i * k] = s->hVecs[r + (size_t)j * k]; s->hVecs[r + (size_t)j * k] = t;
             t = s->hU[r + (size_t)i * k]; s->hU[r + (size_t)i * k] = s->hU[r + (size_t)j * k]; s->hU[r + (size_t)j * k] = t;
          }
       }
    }
    for (int c = 0; c < k; c++) {
-      const double *y = s->hVecs + (size_t)c * k;
+      const HS *y = s->hVecs + (size_t)c * k;
       double v = 0.0;
       for (int i = 0; i < k; i++) {
-         double t = 0.0;
-         for (int j = 0; j < k; j++) t += (j >= i ? s->H[i + (size_t)j * K] : s->H[j + (size_t)i * K]) * y[j];
-         v += y[i] * t;
+         HS t = 0.0;
+         for (int j = 0; j < k; j++) t += (j >= i ? s->H[i + (size_t)j * K] : HS_CONJ(s->H[j + (size_t)i * K])) * y[j];
+         v += HS_RE(HS_CONJ(y[i]) * t);
       }
       hVals_out[c] = v;
    }
@@ -233,7 +239,7 @@ int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arb
       double ip = 0.0;
       for (i = j + 1; i < basisSize; i++) {
          const double minDiff = sqrt(2.0) * s->hSVals[basisSize - 1] * PA_EPS / (aNorm * eps / fabs(s->hVals[i] - s->hVals[i - 1]));
-         const double ip0 = fabs(s->hVecs[(size_t)(i - 1) * ldh + basisSize - 1]);
+         const double ip0 = HS_ABS(s->hVecs[(size_t)(i - 1) * ldh + basisSize - 1]);
          ip += ip0 * ip0;
          const double ip1 = (ip != 0.0) ? ip : HUGE_VAL;
          someCandidate = 1;
@@ -244,8 +250,8 @@ int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arb
       i = PA_MIN(i, basisSize);
       if (i - j > 1 && (someCandidate || RRForAll)) {
          const int an = i - j;
-         double *aH = (double *)malloc(sizeof(double) * (size_t)basisSize * an);
-         double *ah = (double *)calloc((size_t)an * an, sizeof(double));
+         HS *aH = (HS *)malloc(sizeof(HS) * (size_t)basisSize * an);
+         HS *ah = (HS *)calloc((size_t)an * an, sizeof(HS));
          double *av = (double *)malloc(sizeof(double) * (size_t)an);
          if (!aH || !ah || !av) { free(aH); free(ah); free(av); return PRIMME_MALLOC_FAILURE; }
          for (int c = *arbitraryVecs; c < i; c++) {           /* hVecsRot(:, arbitraryVecs:i-1) = I */
@@ -253,7 +259,8 @@ int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arb
             s->hVecsRot[c + (size_t)c * K] = 1.0;
          }
          pa_submatrix(s->hVecs + (size_t)j * ldh, an, ldh, s->H, basisSize, K, aH, an);
-         int rc = pa_solve_H_RR(s, aH, an, NULL, 0, ah, an, av, an, 0);
+         /* ordered for the shift of the current factorisation (the reference passes targetShiftIndex here) */
+         int rc = pa_solve_H_RR(s, aH, an, NULL, 0, ah, an, av, an, PA_MAX(s->targetShiftIndex, 0));
          if (rc) { free(aH); free(ah); free(av); return rc; }
          for (int c = 0; c < an; c++) {
             s->hVals[j + c] = av[c];
@@ -261,11 +268,11 @@ int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arb
          }
          for (int c = 0; c < an; c++)                          /* hVecs(:, j:i-1) *= ahVecs */
             for (int r = 0; r < basisSize; r++) {
-               double t = 0.0;
+               HS t = 0.0;
                for (int q = 0; q < an; q++) t += s->hVecs[r + (size_t)(j + q) * ldh] * ah[q + (size_t)c * an];
                aH[r + (size_t)c * basisSize] = t;
             }
-         for (int c = 0; c < an; c++) memcpy(s->hVecs + (size_t)(j + c) * ldh, aH + (size_t)c * basisSize, sizeof(double) * (size_t)basisSize);
+         for (int c = 0; c < an; c++) memcpy(s->hVecs + (size_t)(j + c) * ldh, aH + (size_t)c * basisSize, sizeof(HS) * (size_t)basisSize);
          free(aH); free(ah); free(av);
          s->coef_valid_k = -1;      /* the copy of hVecs in HBM is stale now */
          *arbitraryVecs = i;
@@ -276,22 +283,22 @@ int pa_prepare_vecs(pa_solver *s, int basisSize, int i0, int blockSize, int *arb
 
 /* orthonormalise columns b1..b2 of X (rows n, ld ldx) against the previous ones, coefficients into
  * R (K-strided): the host Bortho_local with R of the reference, column by column */
-static int ortho_local_cols_R(pa_solver *s, double *X, int n, int ldx, int b1, int b2, double *R, int ldR) {
+static int ortho_local_cols_R(pa_solver *s, HS *X, int n, int ldx, int b1, int b2, HS *R, int ldR) {
    for (int c = b1; c <= b2; c++) {
-      double *x = X + (size_t)c * ldx;
+      HS *x = X + (size_t)c * ldx;
       /* coefficients: two classical passes recorded in R */
       for (int r = 0; r <= c; r++) R[r + (size_t)c * ldR] = 0.0;
       for (int pass = 0; pass < 3; pass++) {
          for (int q = 0; q < c; q++) {
-            const double *y = X + (size_t)q * ldx;
-            double t = 0.0;
-            for (int i = 0; i < n; i++) t += y[i] * x[i];
+            const HS *y = X + (size_t)q * ldx;
+            HS t = 0.0;
+            for (int i = 0; i < n; i++) t += HS_CONJ(y[i]) * x[i];
             for (int i = 0; i < n; i++) x[i] -= t * y[i];
             R[q + (size_t)c * ldR] += t;
          }
       }
       double nr = 0.0;
-      for (int i = 0; i < n; i++) nr += x[i] * x[i];
+      for (int i = 0; i < n; i++) nr += HS_ABS2(x[i]);
       nr = sqrt(nr);
       R[c + (size_t)c * ldR] = nr;
       if (nr > 0.0) for (int i = 0; i < n; i++) x[i] /= nr;
@@ -312,7 +319,7 @@ int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, in
    const int K = s->K;
    const double aNorm = PA_MAX(p->aNorm, p->stats.estimateLargestSVal);
    if (p->orth == primme_orth_implicit_I) {
-      double *blk = (double *)malloc(sizeof(double) * (size_t)(restartSize > 0 ? restartSize * restartSize : 1));
+      HS *blk = (HS *)malloc(sizeof(HS) * (size_t)(restartSize > 0 ? restartSize * restartSize : 1));
       if (!blk) return PRIMME_MALLOC_FAILURE;
       pa_submatrix(s->hVecs, restartSize, ldh, s->H, basisSize, K, blk, restartSize);
       for (int j = 0; j < restartSize; j++)
@@ -339,16 +346,16 @@ int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, in
    for (int i = 0; i < restartSize - numPrevRetained; i++) if (rp0[i] < *numArbitraryVecs) newArb++;
 
    /* R * prevhVecs */
-   double *RPrev = (double *)calloc((size_t)(numPrevRetained > 0 ? numPrevRetained : 1) * basisSize, sizeof(double));
+   HS *RPrev = (HS *)calloc((size_t)(numPrevRetained > 0 ? numPrevRetained : 1) * basisSize, sizeof(HS));
    const int nRegular = restartSize - numPrevRetained;
    int mRot = *numArbitraryVecs;
    for (int i = 0; i < nRegular; i++) mRot = PA_MAX(mRot, rp0[i] + 1);
-   double *Rot0 = (double *)calloc((size_t)(mRot > 0 ? mRot : 1) * (nRegular > 0 ? nRegular : 1), sizeof(double));
-   double *work = (double *)malloc(sizeof(double) * (size_t)basisSize * (restartSize > 0 ? restartSize : 1));
+   HS *Rot0 = (HS *)calloc((size_t)(mRot > 0 ? mRot : 1) * (nRegular > 0 ? nRegular : 1), sizeof(HS));
+   HS *work = (HS *)malloc(sizeof(HS) * (size_t)basisSize * (restartSize > 0 ? restartSize : 1));
    if (!RPrev || !Rot0 || !work) { free(rp0); free(RPrev); free(Rot0); free(work); return PRIMME_MALLOC_FAILURE; }
    for (int c = 0; c < numPrevRetained; c++)
       for (int r = 0; r < basisSize; r++) {
-         double t = 0.0;
+         HS t = 0.0;
          for (int q = 0; q < basisSize; q++) t += s->R[r + (size_t)q * K] * s->hVecs[q + (size_t)(indexOfPreviousVecs + c) * ldh];
          RPrev[r + (size_t)c * basisSize] = t;
       }
@@ -362,12 +369,12 @@ int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, in
    if (!rc) {
       for (int c = 0; c < nRegular; c++)
          for (int r = 0; r < basisSize; r++) {
-            double t = 0.0;
+            HS t = 0.0;
             for (int q = 0; q < mRot; q++) t += s->hU[r + (size_t)q * basisSize] * Rot0[q + (size_t)c * mRot];
             work[r + (size_t)c * basisSize] = t;
          }
-      for (int c = 0; c < numPrevRetained; c++) memcpy(work + (size_t)(nRegular + c) * basisSize, RPrev + (size_t)c * basisSize, sizeof(double) * (size_t)basisSize);
-      memcpy(s->hU, work, sizeof(double) * (size_t)basisSize * restartSize);
+      for (int c = 0; c < numPrevRetained; c++) memcpy(work + (size_t)(nRegular + c) * basisSize, RPrev + (size_t)c * basisSize, sizeof(HS) * (size_t)basisSize);
+      memcpy(s->hU, work, sizeof(HS) * (size_t)basisSize * restartSize);
       rc = ortho_local_cols_R(s, s->hU, basisSize, basisSize, nRegular, nRegular + numPrevRetained - 1, s->R, K);
    }
    if (!rc) {
@@ -379,8 +386,8 @@ int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, in
       if (*numArbitraryVecs <= indexOfPreviousVecsBeforeRestart)
          for (int c = nRegular; c < restartSize; c++) for (int r = 0; r < nRegular; r++) s->R[r + (size_t)c * K] = 0.0;
       /* Q <- Q hU on the device */
-      for (int c = 0; c < restartSize; c++) memcpy(s->h_coef + (size_t)c * K, s->hU + (size_t)c * basisSize, sizeof(double) * (size_t)basisSize);
-      rc = hipk_h2d(s->ctx, s->d_coef, s->h_coef, sizeof(double) * (size_t)K * restartSize);
+      for (int c = 0; c < restartSize; c++) memcpy((HS *)s->h_coef + (size_t)c * K, s->hU + (size_t)c * basisSize, sizeof(HS) * (size_t)basisSize);
+      rc = hipk_h2d(s->ctx, s->d_coef, s->h_coef, sizeof(HS) * (size_t)K * restartSize);
       s->coef_valid_k = -1;
       hipk_job *jobs = (hipk_job *)malloc(sizeof(hipk_job) * (size_t)(restartSize > 0 ? restartSize : 1));
       if (!jobs) rc = PRIMME_MALLOC_FAILURE;
@@ -401,7 +408,7 @@ int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, in
    rc = pa_solve_H_ref(s, restartSize, dummy);
    free(dummy);
    if (rc) { free(rp0); return rc; }
-   pa_permute_cols(s->hVals, 1, restartSize, 1, hVecsPerm);
+   pa_permute_reals(s->hVals, 1, restartSize, 1, hVecsPerm);
    int *inv = (int *)malloc(sizeof(int) * (size_t)(restartSize > 0 ? restartSize : 1));
    if (!inv) { free(rp0); return PRIMME_MALLOC_FAILURE; }
    for (int i = 0; i < restartSize; i++) inv[hVecsPerm[i]] = i;
@@ -416,7 +423,7 @@ int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, in
    /* hVecsRot <- hVecs' for the arbitrary vectors, whose coefficient vectors become unit vectors */
    for (int j = 0; j < K; j++) for (int i = 0; i < K; i++) s->hVecsRot[i + (size_t)j * K] = 0.0;
    for (int j = 0; j < *numArbitraryVecs; j++)
-      for (int i = 0; i < restartSize; i++) s->hVecsRot[i + (size_t)j * K] = s->hVecs[j + (size_t)i * restartSize];
+      for (int i = 0; i < restartSize; i++) s->hVecsRot[i + (size_t)j * K] = HS_CONJ(s->hVecs[j + (size_t)i * restartSize]);
    for (int j = 0; j < *numArbitraryVecs; j++) {
       for (int i = 0; i < restartSize; i++) s->hVecs[i + (size_t)j * restartSize] = 0.0;
       s->hVecs[hVecsPerm[j] + (size_t)j * restartSize] = 1.0;

@@ -430,12 +430,9 @@ int pa_solve_H(pa_solver *s, int basisSize, int numLocked, int numConverged) {
    primme_params *p = s->p;
    const int off = p->numOrthoConst + numLocked;
    const HS *G = s->VtBV ? s->VtBV + (size_t)off * s->ldVtBV + off : NULL;
-#if !PA_IS_COMPLEX      /* harmonic / refined extraction: real objects only (eigs_scalar.h) */
    if (s->refined) CHK(pa_solve_H_ref(s, basisSize, s->hVals));
    else if (s->Q) CHK(pa_solve_H_harm(s, basisSize, G, s->ldVtBV));
-   else
-#endif
-   CHK(pa_solve_H_RR(s, s->H, s->K, G, s->ldVtBV, s->hVecs, basisSize, s->hVals, basisSize, numConverged));
+   else CHK(pa_solve_H_RR(s, s->H, s->K, G, s->ldVtBV, s->hVecs, basisSize, s->hVals, basisSize, numConverged));
    for (int i = 0; i < basisSize; i++) {
       p->stats.estimateMinEVal = PA_MIN(p->stats.estimateMinEVal, s->hVals[i]);
       p->stats.estimateMaxEVal = PA_MAX(p->stats.estimateMaxEVal, s->hVals[i]);

@@ -224,7 +224,6 @@ int pa_block_first_reorder(pa_solver *s, int basisSize, int *flags, const int *i
    pa_permute_reals(s->hVals, 1, basisSize, 1, iwork);
    pa_permute_cols(s->hVecs, basisSize, basisSize, basisSize, iwork);
    pa_permute_ints(flags, basisSize, iwork);
-#if !PA_IS_COMPLEX
    if (s->hVecsRot) {
       for (int c = s->numArbitraryVecs; c < basisSize; c++) {
          for (int r = 0; r < s->K; r++) s->hVecsRot[r + (size_t)c * s->K] = 0.0;
@@ -235,7 +234,6 @@ int pa_block_first_reorder(pa_solver *s, int basisSize, int *flags, const int *i
       for (i = 0; i < basisSize; i++) if (iwork[i] != i) last = i + 1;
       s->numArbitraryVecs = PA_MAX(s->numArbitraryVecs, last);
    }
-#endif
    s->coef_valid_k = -1;
    free(iwork);
    return 0;
@@ -747,7 +745,6 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       s->numPrevRitzVals = restartSize;
    }
 
-#if !PA_IS_COMPLEX
    if (s->refined) {
       rc = pa_restart_refined(s, ldh, restartSize, basisSize, *numConverged, numPrevRetained, indexOfPreviousVecs,
             indexOfPreviousVecsBeforeRestart, restartPerm, hVecsPerm, &s->numArbitraryVecs);
@@ -762,9 +759,8 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       rc = pa_restart_harmonic(s, ldh, restartSize, basisSize, *numConverged);
       if (!rc) rc = pa_solve_H(s, restartSize, p->locking ? *numConverged : 0, *numConverged);
    } else
-#endif
-   rc = restart_RR(s, ldh, restartSize, restartSize, basisSize, *numConverged, numPrevRetained,
-         indexOfPreviousVecs, hVecsPerm);
+      rc = restart_RR(s, ldh, restartSize, restartSize, basisSize, *numConverged, numPrevRetained,
+            indexOfPreviousVecs, hVecsPerm);
    free(restartPerm);
    if (rc) { free(hVecsPerm); return rc; }
    s->coef_valid_k = -1;

@@ -1,13 +1,13 @@
 /* eigs_scalar.h — the scalar type of the projected problem (the reference's HSCALAR, src/include/template.h).
  *
  * The host solver sources that touch coefficient-space data (eigs_main.c, eigs_ops.c, eigs_conv.c,
- * eigs_restart.c, eigs_block.c, eigs_dense.c, eigs_jd.c) are compiled twice, like the reference's templated sources: once
+ * eigs_restart.c, eigs_block.c, eigs_dense.c, eigs_jd.c, eigs_harm.c) are compiled twice, like the reference's templated sources: once
  * as they are (HS = double: hip_dprimme / hip_sprimme) and once with PA_COMPLEX defined (HS = double complex:
  * the native path of hip_zprimme / hip_cprimme) through the one-line wrappers eigs_*_z.c.  In the complex
  * objects every external function of those files carries the suffix _z (the list below is checked by the
- * linker: a missing entry is a duplicate symbol).  Files that are NOT on the native complex path (harmonic /
- * refined extraction, the dynamic method) exist once; a Hermitian problem that asks
- * for them runs on the real-equivalent form (eigs_complex.c).
+ * linker: a missing entry is a duplicate symbol).  What is NOT on the native complex path (the dynamic method
+ * switch, eigs_dyn.c) exists once; a Hermitian problem that asks for it runs on the real-equivalent form
+ * (eigs_complex.c).
  *
  * Device-layer conventions for complex panels (include/primme_amd_kernels.h): inner products, projection
  * coefficients, Ritz coefficient vectors and axpy factors are (re, im) pairs; Ritz values, shifts, squared
@@ -54,6 +54,14 @@ typedef double _Complex HS;
 #define pa_evecs_hat_init pa_evecs_hat_init_z
 #define pa_evecs_hat_update pa_evecs_hat_update_z
 #define pa_correction_jdqmr pa_correction_jdqmr_z
+#define pa_svd pa_svd_z
+#define pa_update_Q pa_update_Q_z
+#define pa_update_QtV pa_update_QtV_z
+#define pa_solve_H_harm pa_solve_H_harm_z
+#define pa_solve_H_ref pa_solve_H_ref_z
+#define pa_prepare_vecs pa_prepare_vecs_z
+#define pa_restart_harmonic pa_restart_harmonic_z
+#define pa_restart_refined pa_restart_refined_z
 #else
 typedef double HS;
 #define SD 1

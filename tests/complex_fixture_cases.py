@@ -40,8 +40,15 @@ def check(name, backend):
     # (also the Davidson preconditioner on this graded diagonal: 1 / (d_j - theta) amplifies the last bits of theta, the two
     # histories separate by 1e-9 after ~30 iterations and end within 3 % of each other)
     interior = "closest" in fx["kwargs"].get("target", "") or "precond" in fx["kwargs"]
+    refined = fx["kwargs"].get("projection") == "refined"
     for k in COUNT_KEYS:
         loose = 0.12 if ("precond" in fx["kwargs"] and "JDQMR" in fx["kwargs"].get("method", "")) else 0.03   # (inner iterations amplify it further)
+        if refined:
+            # the refined extraction on this unpreconditioned interior problem stagnates at a residual of 0.2 for a
+            # hundred iterations before it locks on; the histories of two implementations separate at 1e-9 after 90
+            # iterations (SVD of R by different algorithms) and the totals then differ like two different start vectors
+            # would: +-30 % observed, for the real path against dprimme as well
+            loose = 0.4
         if interior:
             # interior Ritz values move with the rounding of every inner product (a long run near the rounding floor of
             # the coefficient vectors): as for the real path the counts agree to within 3 %

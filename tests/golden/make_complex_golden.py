@@ -3,7 +3,8 @@
     python tests/golden/make_complex_golden.py
 Fixtures are data: the matrices and start vectors are closed forms (primme_amd.problems.hermitian_graded_csr,
 complex_start_vector), the outputs are the reference's evals / resNorms / counts for the native complex path of
-hip_zprimme / hip_cprimme (Rayleigh-Ritz extraction, Generalized-Davidson family and JDQMR) to reproduce."""
+hip_zprimme / hip_cprimme (Rayleigh-Ritz, harmonic and refined extraction, Generalized-Davidson family and JDQMR) to
+reproduce."""
 import json
 import os
 import sys
@@ -38,6 +39,15 @@ CASES = {
     "z_jdqmr_etol": (600, dict(numEvals=4, method="JDQMR_ETol", eps=1e-10)),
     "z_jdqmr_largest_soft": (600, dict(numEvals=3, method="JDQMR", eps=1e-9, target="largest", locking=0)),
     "z_jdqmr_etol_jacobi": (600, dict(numEvals=4, method="JDQMR_ETol", eps=1e-10, precond="jacobi")),
+    # harmonic / refined extraction for interior targets (eigs_harm.c compiled for complex scalars)
+    "z_harm_abs": (400, dict(numEvals=3, method="GD_plusK", eps=1e-9, target="closest_abs", targetShifts=[5.0], projection="harmonic")),
+    "z_harm_geq": (400, dict(numEvals=3, method="GD_plusK", eps=1e-9, target="closest_geq", targetShifts=[5.0], projection="harmonic")),
+    "z_harm_leq": (400, dict(numEvals=3, method="GD_plusK", eps=1e-9, target="closest_leq", targetShifts=[5.0], projection="harmonic")),
+    "z_harm_jacobi": (400, dict(numEvals=3, method="GD_plusK", eps=1e-9, target="closest_abs", targetShifts=[5.0], projection="harmonic", precond="jacobi")),
+    "z_ref_abs": (400, dict(numEvals=3, method="GD_plusK", eps=1e-9, target="closest_abs", targetShifts=[5.0], projection="refined")),
+    "z_ref_geq": (400, dict(numEvals=3, method="GD_plusK", eps=1e-9, target="closest_geq", targetShifts=[5.0], projection="refined")),
+    "z_ref_jdqmr": (400, dict(numEvals=3, method="JDQMR", eps=1e-9, target="closest_abs", targetShifts=[5.0], projection="refined")),
+    "z_ref_2shifts": (400, dict(numEvals=4, method="GD_plusK", eps=1e-9, target="closest_abs", targetShifts=[5.0, 9.0], projection="refined")),
     "c_gdk_blk2": (600, dict(numEvals=4, method="GD_plusK", eps=1e-4, maxBlockSize=2, dtype="complex64")),
     "c_gdk_b1": (600, dict(numEvals=3, method="GD_plusK", eps=1e-4, dtype="complex64")),
 }
