@@ -329,53 +329,60 @@ zritz_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *__
    }
 }
 
-/* The same with TWO lanes per row for more than 16 outputs: lanes 2r and 2r + 1 read the same elements of V and W (one
- * 16-byte request, merged by the coalescer) and each keeps half of the accumulators — NJH = 16 complex instead of 32,
- * so the kernel runs at 3-4 waves per SIMD where the one-lane form holds 256 VGPRs (one wave per SIMD, 3.1 TB/s on the
- * restart pass of configs[3]).  Slot tables live in LDS (a lane's half is not uniform across the wave). */
-struct ZJobs2 { void *dst[2][16]; int col[2][16]; signed char isw[2][16]; short slot[2][16]; };
-template <typename R, int NRH>
+/* The same with L = 2 or 4 lanes per row for more than 16 outputs: the L lanes of a row read the same elements of V and W
+ * (one 16-byte request, merged by the coalescer) and each keeps NS = NVH + NWH + NRH <= 24 of the accumulators — up to 64
+ * outputs in ONE pass over V and W, where the one-lane form holds 256 VGPRs at 32 outputs (one wave per SIMD, 3.1 TB/s
+ * on the restart pass of configs[3]) and more than 32 used to take two passes through a temporary.  The lanes of a row
+ * sit in the same wave, so every load of a row precedes every store to it (destinations may alias V and W).
+ * A part's slots are [V-products: NVH | W-products: NWH | residuals: NRH], fixed at compile time: selecting v or w per
+ * slot at run time costs four v_cndmask per complex FMA, as many VALU cycles as the FMA itself (SIMDs are 16 lanes wide,
+ * every wave64 instruction takes four cycles), and this kernel is VALU / LDS bound, not HBM bound. */
+#define ZRITZ2_SLOTS 24
+template <int L> struct ZJobsL { void *dst[L][ZRITZ2_SLOTS]; int col[L][ZRITZ2_SLOTS]; short slot[L][ZRITZ2_SLOTS]; };
+template <typename R, int L, int NVH, int NWH, int NRH>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 zritz2_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *__restrict__ h, int ldh,
-      const double *__restrict__ theta, ZJobs2 jb, int64_t m, double *__restrict__ partials) {
-   constexpr int NJH = 16, NPH = NJH - NRH;
-   __shared__ zacc sh[ZRITZ_JT * 2 * NJH];        /* sh[(jj * 2 + half) * NJH + q] */
-   __shared__ double sth[2][NRH];
-   __shared__ void *sdst[2][NJH];
-   __shared__ int sisw[2][NJH];
+      const double *__restrict__ theta, ZJobsL<L> jb, int64_t m, double *__restrict__ partials) {
+   constexpr int NS = NVH + NWH + NRH, NPH = NVH + NWH, JT = 128 / L, ROWS = HIPK_BLOCK / L;
+   /* the L parts of a wave read L different rows of sh in one ds_read_b128: a row stride of 16 complex (256 bytes = all
+    * 64 banks) would put them on the same banks (the L = 4 form ran LDS-bound at 2.0 TB/s); NJS = NS + 1 staggers them */
+   constexpr int NJS = NS + 1;
+   __shared__ zacc sh[JT * L * NJS];              /* sh[(jj * L + part) * NJS + q] */
+   __shared__ double sth[L][NRH];
+   __shared__ void *sdst[L][NS];
    __shared__ double sm[HIPK_BLOCK / HIPK_WAVE];
-   for (int t = threadIdx.x; t < 2 * NJH; t += HIPK_BLOCK) {
-      const int hf = t / NJH, q = t % NJH;
-      sdst[hf][q] = jb.dst[hf][q]; sisw[hf][q] = jb.isw[hf][q];
+   for (int t = threadIdx.x; t < L * NS; t += HIPK_BLOCK) {
+      const int hf = t / NS, q = t % NS;
+      sdst[hf][q] = jb.dst[hf][q];
       if (q >= NPH) sth[hf][q - NPH] = jb.col[hf][q] >= 0 ? theta[jb.col[hf][q]] : 0.0;
    }
-   const int half = threadIdx.x & 1;
-   const int64_t stride = (int64_t)gridDim.x * (HIPK_BLOCK / 2);
+   const int part = threadIdx.x & (L - 1);
+   const int64_t stride = (int64_t)gridDim.x * ROWS;
    const int64_t mpad = (m + stride - 1) / stride * stride;
    double n2[NRH];
 #pragma unroll
    for (int q = 0; q < NRH; q++) n2[q] = 0.0;
-   const bool once = k <= ZRITZ_JT;
+   const bool once = k <= JT;
    if (once) {
-      for (int t = threadIdx.x; t < k * 2 * NJH; t += HIPK_BLOCK) {
-         const int jj = t / (2 * NJH), r = t % (2 * NJH), hf = r / NJH, q = r % NJH;
-         sh[t] = (jb.col[hf][q] >= 0) ? h[jj + (size_t)jb.col[hf][q] * ldh] : zacc{0.0, 0.0};
+      for (int t = threadIdx.x; t < k * L * NS; t += HIPK_BLOCK) {
+         const int jj = t / (L * NS), r = t % (L * NS), hf = r / NS, q = r % NS;
+         sh[(jj * L + hf) * NJS + q] = (jb.col[hf][q] >= 0) ? h[jj + (size_t)jb.col[hf][q] * ldh] : zacc{0.0, 0.0};
       }
    }
    __syncthreads();
-   for (int64_t i = (int64_t)blockIdx.x * (HIPK_BLOCK / 2) + (threadIdx.x >> 1); i < mpad; i += stride) {
+   for (int64_t i = (int64_t)blockIdx.x * ROWS + (threadIdx.x / L); i < mpad; i += stride) {
       const bool live = i < m;
       const int64_t ic = live ? i : m - 1;
-      zacc acc[NJH];
+      zacc acc[NS];
 #pragma unroll
-      for (int q = 0; q < NJH; q++) acc[q] = {0.0, 0.0};
-      for (int j0 = 0; j0 < k; j0 += ZRITZ_JT) {
-         const int jn = min(ZRITZ_JT, k - j0);
+      for (int q = 0; q < NS; q++) acc[q] = {0.0, 0.0};
+      for (int j0 = 0; j0 < k; j0 += JT) {
+         const int jn = min(JT, k - j0);
          if (!once) {
             __syncthreads();
-            for (int t = threadIdx.x; t < jn * 2 * NJH; t += HIPK_BLOCK) {
-               const int jj = t / (2 * NJH), r = t % (2 * NJH), hf = r / NJH, q = r % NJH;
-               sh[t] = (jb.col[hf][q] >= 0) ? h[(j0 + jj) + (size_t)jb.col[hf][q] * ldh] : zacc{0.0, 0.0};
+            for (int t = threadIdx.x; t < jn * L * NS; t += HIPK_BLOCK) {
+               const int jj = t / (L * NS), r = t % (L * NS), hf = r / NS, q = r % NS;
+               sh[(jj * L + hf) * NJS + q] = (jb.col[hf][q] >= 0) ? h[(j0 + jj) + (size_t)jb.col[hf][q] * ldh] : zacc{0.0, 0.0};
             }
             __syncthreads();
          }
@@ -383,12 +390,14 @@ zritz2_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *_
          for (int jj = 0; jj < jn; jj++) {
             const zacc v = zload(V + (size_t)(j0 + jj) * ld + ic);
             const zacc w = W ? zload(W + (size_t)(j0 + jj) * ld + ic) : zacc{0.0, 0.0};
-            const zacc *hrow = sh + (size_t)(jj * 2 + half) * NJH;
+            const zacc *hrow = sh + (size_t)(jj * L + part) * NJS;
 #pragma unroll
-            for (int q = 0; q < NPH; q++) zfma(acc[q], sisw[half][q] ? w : v, hrow[q]);
+            for (int q = 0; q < NVH; q++) zfma(acc[q], v, hrow[q]);
+#pragma unroll
+            for (int q = 0; q < NWH; q++) zfma(acc[NVH + q], w, hrow[NVH + q]);
 #pragma unroll
             for (int q = 0; q < NRH; q++) {
-               const double th = sth[half][q];
+               const double th = sth[part][q];
                const zacc sres = {fma(-th, v.re, w.re), fma(-th, v.im, w.im)};
                zfma(acc[NPH + q], sres, hrow[NPH + q]);
             }
@@ -396,9 +405,9 @@ zritz2_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *_
       }
       if (live) {
 #pragma unroll
-         for (int q = 0; q < NJH; q++) {
+         for (int q = 0; q < NS; q++) {
             cpx<R> st; st.re = (R)acc[q].re; st.im = (R)acc[q].im;
-            cpx<R> *dq = (cpx<R> *)sdst[half][q];
+            cpx<R> *dq = (cpx<R> *)sdst[part][q];
             if (dq) dq[i] = st;
             if (q >= NPH) n2[q - NPH] = fma((double)st.re, (double)st.re, fma((double)st.im, (double)st.im, n2[q - NPH]));
          }
@@ -406,22 +415,66 @@ zritz2_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *_
    }
    if (partials) {
       const unsigned nb = gridDim.x;
-      for (int hf = 0; hf < 2; hf++)
+      for (int hf = 0; hf < L; hf++)
 #pragma unroll
          for (int q = 0; q < NRH; q++) {
             const int slot = jb.slot[hf][NPH + q];
-            const double v = zblock_sum(half == hf ? n2[q] : 0.0, sm);
+            const double v = zblock_sum(part == hf ? n2[q] : 0.0, sm);
             if (threadIdx.x == 0 && slot >= 0) partials[(size_t)slot * nb + blockIdx.x] = v;
          }
    }
 }
 
-/* one launch: np plain jobs + nr residual jobs, np + nr <= 32 */
+/* fill the slot tables of the L-lane form: part p takes the p-th share of the V-products, of the W-products and of the
+ * residual jobs; false when a share does not fit its slots */
+template <int L>
+static bool zjobs_split(const hipk_job *jobs, int nj, int NVH, int NWH, int NRH, ZJobsL<L> &jl) {
+   for (int hf = 0; hf < L; hf++) for (int q = 0; q < ZRITZ2_SLOTS; q++) { jl.dst[hf][q] = NULL; jl.col[hf][q] = -1; jl.slot[hf][q] = -1; }
+   int n[3] = {0, 0, 0};
+   for (int q = 0; q < nj; q++) n[jobs[q].kind == HIPK_JOB_RES ? 2 : jobs[q].kind == HIPK_JOB_XW ? 1 : 0]++;
+   const int cap[3] = {NVH, NWH, NRH}, base[3] = {0, NVH, NVH + NWH};
+   int share[3], seen[3] = {0, 0, 0}, at[3][L];
+   for (int c = 0; c < 3; c++) {
+      share[c] = (n[c] + L - 1) / L;
+      if (share[c] > cap[c]) return false;
+      for (int hf = 0; hf < L; hf++) at[c][hf] = base[c];
+   }
+   for (int q = 0; q < nj; q++) {
+      const int c = jobs[q].kind == HIPK_JOB_RES ? 2 : jobs[q].kind == HIPK_JOB_XW ? 1 : 0;
+      const int hf = seen[c]++ / share[c];
+      const int a = at[c][hf]++;
+      jl.dst[hf][a] = jobs[q].dst; jl.col[hf][a] = jobs[q].col; jl.slot[hf][a] = (short)jobs[q].slot;
+   }
+   return true;
+}
+
+/* one launch: np plain jobs + nr residual jobs; up to 16 + 16 in the one-lane form, up to 60 + 4 / 48 + 16 with four lanes
+ * per row.  Returns 1 when the jobs do not fit one pass, -(1000 + grid) when the multi-lane form ran (its own grid). */
 template <typename R>
 static int zritz_launch(hipk_ctx *ctx, int64_t m, const void *V, const void *W, int64_t ld, int k, const double *h, int ldh,
       const double *theta, const hipk_job *jobs, int nj, int gx, bool norms, bool allow_split) {
    int np = 0, nr = 0;
    for (int q = 0; q < nj; q++) { if (jobs[q].kind == HIPK_JOB_RES) nr++; else np++; }
+   static int nosplit = -1;                       /* HIPK_Z_NO_SPLIT=1: the one-lane-per-row form only (A/B knob) */
+   if (nosplit < 0) nosplit = getenv("HIPK_Z_NO_SPLIT") != NULL;
+   if ((np > 12 || nr > 4) && !(np == 0 && nr <= 16) && nr <= 16 && !nosplit && allow_split) {
+      /* more than 16 outputs: the cheapest multi-lane form the jobs fit (cost ~ lanes x slots) */
+      int64_t need2 = (m + HIPK_BLOCK / 2 - 1) / (HIPK_BLOCK / 2), need4 = (m + HIPK_BLOCK / 4 - 1) / (HIPK_BLOCK / 4);
+      const int64_t gmax = (int64_t)ctx->num_cu * 8;
+      const int g2 = (int)(need2 < 1 ? 1 : need2 < gmax ? need2 : gmax), g4 = (int)(need4 < 1 ? 1 : need4 < gmax ? need4 : gmax);
+      int launched = 0;
+      /* the partial sums of the norms are indexed by THIS grid: the caller's second stage is told through the return value */
+#define ZR2(LV, A, B, C, G) do { ZJobsL<LV> jl; if (!launched && zjobs_split<LV>(jobs, nj, A, B, C, jl)) { \
+            hipLaunchKernelGGL((zritz2_kernel<R, LV, A, B, C>), dim3(G), dim3(HIPK_BLOCK), 0, ctx->stream, (const cpx<R> *)V, (const cpx<R> *)W, ld, k, \
+                  (const zacc *)h, ldh, theta, jl, m, norms ? ctx->partials : (double *)NULL); launched = G; } } while (0)
+      if (nr <= 4) { ZR2(2, 7, 7, 2, g2); ZR2(2, 9, 7, 2, g2); ZR2(2, 12, 10, 2, g2); ZR2(4, 6, 5, 1, g4); ZR2(4, 8, 7, 1, g4); }
+      ZR2(2, 4, 4, 8, g2); ZR2(4, 8, 4, 4, g4);
+#undef ZR2
+      if (launched) {
+         HIPK_CHECK(hipGetLastError());
+         return -(1000 + launched);                /* launched with its own grid: the caller finalises over that many blocks */
+      }
+   }
    int NJ, NR;
    if (nr <= 4 && np <= 4) { NJ = 8; NR = 4; }
    else if (nr <= 4 && np <= 12) { NJ = 16; NR = 4; }
@@ -429,35 +482,6 @@ static int zritz_launch(hipk_ctx *ctx, int64_t m, const void *V, const void *W, 
    else if (np == 0 && nr <= 16) { NJ = 16; NR = 16; }
    else if (nr <= 16 && np <= 16) { NJ = 32; NR = 16; }
    else return 1;                                 /* does not fit one pass */
-   static int nosplit = -1;                       /* HIPK_Z_NO_SPLIT=1: the one-lane-per-row form for every size (A/B knob) */
-   if (nosplit < 0) nosplit = getenv("HIPK_Z_NO_SPLIT") != NULL;
-   if (NJ == 32 && !nosplit && allow_split) {
-      /* two lanes per row: half 0 takes the first ceil(np/2) plain and ceil(nr/2) residual jobs, half 1 the rest */
-      const int NRH = (NR == 4) ? 2 : 8, NPH = 16 - NRH;
-      ZJobs2 j2;
-      for (int hf = 0; hf < 2; hf++) for (int q = 0; q < 16; q++) { j2.dst[hf][q] = NULL; j2.col[hf][q] = -1; j2.isw[hf][q] = 0; j2.slot[hf][q] = -1; }
-      int ip[2] = {0, 0}, ir[2] = {NPH, NPH};
-      const int np0 = (np + 1) / 2, nr0 = (nr + 1) / 2;
-      int seenp = 0, seenr = 0;
-      bool fits = np0 <= NPH && nr0 <= NRH;
-      for (int q = 0; q < nj && fits; q++) {
-         const bool res = jobs[q].kind == HIPK_JOB_RES;
-         const int hf = res ? (seenr++ < nr0 ? 0 : 1) : (seenp++ < np0 ? 0 : 1);
-         const int at = res ? ir[hf]++ : ip[hf]++;
-         j2.dst[hf][at] = jobs[q].dst; j2.col[hf][at] = jobs[q].col; j2.isw[hf][at] = (jobs[q].kind == HIPK_JOB_XW); j2.slot[hf][at] = (short)jobs[q].slot;
-      }
-      if (fits) {
-         int64_t need = (m + 127) / 128;
-         const int gx2 = (int)(need < 1 ? 1 : (need < (int64_t)ctx->num_cu * 8 ? need : (int64_t)ctx->num_cu * 8));
-         /* the partial sums of the norms are indexed by THIS grid: the caller's second stage is told through gx_out */
-#define ZR2(NRHV) hipLaunchKernelGGL((zritz2_kernel<R, NRHV>), dim3(gx2), dim3(HIPK_BLOCK), 0, ctx->stream, (const cpx<R> *)V, (const cpx<R> *)W, ld, k, \
-            (const zacc *)h, ldh, theta, j2, m, norms ? ctx->partials : (double *)NULL)
-         if (NRH == 2) ZR2(2); else ZR2(8);
-#undef ZR2
-         HIPK_CHECK(hipGetLastError());
-         return -(1000 + gx2);                     /* launched with its own grid: the caller finalises over gx2 blocks */
-      }
-   }
    ZJobs jb;
    for (int q = 0; q < ZRITZ_JOBS; q++) { jb.dst[q] = NULL; jb.col[q] = -1; jb.isw[q] = 0; jb.slot[q] = -1; }
    int ip = 0, ir = NJ - NR;

@@ -99,24 +99,30 @@ extern "C" int hipk_free(hipk_ctx *ctx, void *dptr) {
  * copy is complete on return, so the runtime is never asked to DMA asynchronously out of or into pageable memory. */
 #include <atomic>
 #define HIPK_PINNED_MAX 256
-static struct { const char *lo, *hi; } g_pinned[HIPK_PINNED_MAX];
+static struct { const char *lo, *hi, *dev; } g_pinned[HIPK_PINNED_MAX];      /* dev: the device address of lo (mapped memory) */
 static std::atomic_flag g_pinned_lock = ATOMIC_FLAG_INIT;
 static void pinned_note(const void *p, size_t bytes, bool add) {
+   void *dp = NULL;
+   if (add && hipHostGetDevicePointer(&dp, (void *)p, 0) != hipSuccess) { dp = NULL; (void)hipGetLastError(); }
    while (g_pinned_lock.test_and_set(std::memory_order_acquire)) { }
    for (int i = 0; i < HIPK_PINNED_MAX; i++) {
       if (add ? g_pinned[i].lo == NULL : g_pinned[i].lo == (const char *)p) {
          g_pinned[i].lo = add ? (const char *)p : NULL;
          g_pinned[i].hi = add ? (const char *)p + bytes : NULL;
+         g_pinned[i].dev = add ? (const char *)dp : NULL;
          break;
       }
    }
    g_pinned_lock.clear(std::memory_order_release);
 }
-static bool pinned_has(const void *p, size_t bytes) {
+/* is [p, p + bytes) inside one of the library's pinned buffers?  *dev (optional) gets the address a kernel reaches it by */
+static bool pinned_has(const void *p, size_t bytes, const char **dev = NULL) {
    bool found = false;
    while (g_pinned_lock.test_and_set(std::memory_order_acquire)) { }
-   for (int i = 0; i < HIPK_PINNED_MAX && !found; i++)
+   for (int i = 0; i < HIPK_PINNED_MAX && !found; i++) {
       found = g_pinned[i].lo && (const char *)p >= g_pinned[i].lo && (const char *)p + bytes <= g_pinned[i].hi;
+      if (found && dev) *dev = g_pinned[i].dev ? g_pinned[i].dev + ((const char *)p - g_pinned[i].lo) : NULL;
+   }
    g_pinned_lock.clear(std::memory_order_release);
    return found;
 }
@@ -172,16 +178,39 @@ int hipk_download(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
    (void)hipHostFree(stage);
    return rc;
 }
+/* Small transfers between the library's pinned (mapped) buffers and HBM go through a copy KERNEL on the context's
+ * stream instead of hipMemcpyAsync: the coefficient blocks and Ritz values a solver step uploads are a few KB, and a
+ * runtime copy of that size costs 40-240 us of idle device before it starts (profiles/r03_config4_native_gaps.md:
+ * 800 copies, 106 ms idle in two solves of configs[3]) where a kernel launch costs 5-8 us.  The kernel reads / writes
+ * the host buffer through its device address; ordering and lifetime rules are those of the asynchronous copy it
+ * replaces.  HIPK_NO_COPY_KERNEL=1 restores the runtime copies (A/B knob). */
+#define HIPK_COPY_KERNEL_MAX ((size_t)1 << 20)
+__global__ void __launch_bounds__(HIPK_BLOCK) hipk_small_copy_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t nwords) {
+   for (size_t i = (size_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < nwords; i += (size_t)gridDim.x * HIPK_BLOCK) dst[i] = src[i];
+}
+static bool small_copy(hipk_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) {
+   static int off = -1;
+   if (off < 0) off = getenv("HIPK_NO_COPY_KERNEL") != NULL;
+   if (off || bytes > HIPK_COPY_KERNEL_MAX || (bytes & 3) || ((uintptr_t)dst_dev & 3) || ((uintptr_t)src_dev & 3) || !dst_dev || !src_dev) return false;
+   const size_t nw = bytes / 4;
+   const int gx = (int)((nw + HIPK_BLOCK - 1) / HIPK_BLOCK < 64 ? (nw + HIPK_BLOCK - 1) / HIPK_BLOCK : 64);
+   hipLaunchKernelGGL(hipk_small_copy_kernel, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (uint32_t *)dst_dev, (const uint32_t *)src_dev, nw);
+   return hipGetLastError() == hipSuccess;
+}
 /* stream-ordered (asynchronous) for the library's pinned buffers, staged and complete on return for anything else */
 extern "C" int hipk_h2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
    if (!bytes) return 0;
-   if (!pinned_has(src, bytes)) return hipk_upload(ctx, dst, src, bytes);
+   const char *sdev = NULL;
+   if (!pinned_has(src, bytes, &sdev)) return hipk_upload(ctx, dst, src, bytes);
+   if (small_copy(ctx, dst, sdev, bytes)) return 0;
    HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
    return 0;
 }
 extern "C" int hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
    if (!bytes) return 0;
-   if (!pinned_has(dst, bytes)) return hipk_download(ctx, dst, src, bytes);
+   const char *ddev = NULL;
+   if (!pinned_has(dst, bytes, &ddev)) return hipk_download(ctx, dst, src, bytes);
+   if (small_copy(ctx, (void *)ddev, src, bytes)) return 0;
    HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
    return 0;
 }

@@ -43,6 +43,8 @@ def check(name, backend):
     refined = fx["kwargs"].get("projection") == "refined"
     for k in COUNT_KEYS:
         loose = 0.12 if ("precond" in fx["kwargs"] and "JDQMR" in fx["kwargs"].get("method", "")) else 0.03   # (inner iterations amplify it further)
+        if fx["kwargs"].get("projection") == "harmonic" and "precond" not in fx["kwargs"]:
+            loose = 0.10     # 1500 unpreconditioned interior iterations: 2 % on the CPU checker, 8 % on the GPU (different summation order)
         if refined:
             # the refined extraction on this unpreconditioned interior problem stagnates at a residual of 0.2 for a
             # hundred iterations before it locks on; the histories of two implementations separate at 1e-9 after 90

@@ -107,12 +107,17 @@ def test_complex_panel_project_mul(built, dt, m, k, L, nx):
 
 @pytest.mark.parametrize("dt", ZDT)
 @pytest.mark.parametrize("m,k,shape", [(999, 3, None), (50003, 15, None), (200001, 24, None), (40000, 41, None), (30011, 140, None),
-                                       (70001, 20, (10, 4, 0)), (70002, 20, (5, 3, 3)), (1000001, 20, (8, 4, 0))])
+                                       (70001, 20, (10, 4, 0)), (70002, 20, (5, 3, 3)), (1000001, 20, (8, 4, 0)),
+                                       (70003, 20, (14, 4, 0)), (70004, 30, (20, 4, 2)), (1000002, 20, (14, 4, 0)),
+                                       (70005, 40, (24, 4, 0)), (70006, 12, (3, 2, 3)), (70007, 26, (18, 4, 0)), (70008, 40, (22, 4, 0))])
 def test_complex_ritz_update_inplace_restart(built, dt, m, k, shape):
     """The restart shape with complex coefficient vectors: V, W <- V h, W h in place, the next block's X and R, copies
-    of locked vectors and residual norms; more than 32 outputs take the chunked path.  shape = (restart size, block,
-    locked): 24 + 4 and 16 + 6 outputs run through the two-lanes-per-row kernel (the configs[3] restart, also at its
-    full-size kernel grid: 1 M rows against numpy)."""
+    of locked vectors and residual norms.  shape = (restart size, block, locked) -> (V-products, W-products, residuals):
+    (10,4,0) -> (14,10,4) and (8,4,0) run the two-lane kernel <7,7,2>, (3,2,3) -> (8,3,5) the two-lane <4,4,8>,
+    (5,3,3) -> (11,5,6) the four-lane <8,4,4>, (14,4,0) -> (18,14,4) the two-lane <9,7,2> (the configs[3] restart, also
+    at its full-size kernel grid: 1 M rows against numpy), (18,4,0) -> (22,18,4) the two-lane <12,10,2>, (22,4,0) -> (26,22,4) with k = 40 the four-lane <8,7,1>, (24,4,0) -> (28,24,4) likewise, both with the
+    coefficient block staged in two tiles; (20,4,2) -> (26,20,6) and the larger default shapes fit none of them and take
+    the chunked path."""
     rng = np.random.default_rng(m + k)
     ld, K = m + 1, k + 6
     V, W = _z(rng, (K, ld), dt), _z(rng, (K, ld), dt)
