@@ -38,17 +38,12 @@ int pa_eigs_solve_z(void *evals_out, void *evecs, void *resNorms_out, primme_par
 /* NATIVE path: complex panels, complex Hermitian projected problem, the reference's zprimme iteration for iteration.
  * Covers the Generalized-Davidson family (GD, GD+k, Olsen variants, LOBPCG-like presets; locking and soft locking;
  * any block size), which includes the default method and BASELINE configs[3], the JDQMR inner-outer iteration
- * (real QMR recurrences on the 2m-real view of the panels, complex projectors), and the three extractions
- * (Rayleigh-Ritz; harmonic and refined for interior targets, eigs_harm.c).
- * The dynamic method switch has no complex objects yet: those
- * requests (and the library's operator when it was built on the real-equivalent CSR expansion) take the
+ * (real QMR recurrences on the 2m-real view of the panels, complex projectors), the dynamic switch between the two,
+ * and the three extractions (Rayleigh-Ritz; harmonic and refined for interior targets, eigs_harm.c).
+ * Only the library's operator when it was built on the real-equivalent CSR expansion takes the
  * real-equivalent form below.  PRIMME_AMD_COMPLEX_REAL_FORM=1 forces the latter (A/B measurements). */
 static int native_complex_ok(const primme_params *primme) {
    if (getenv("PRIMME_AMD_COMPLEX_REAL_FORM")) return 0;
-   primme_params t = *primme;
-   if (t.numProcs <= 1) { t.nLocal = t.n; t.procID = 0; }
-   primme_set_defaults(&t);
-   if (t.dynamicMethodSwitch > 0) return 0;
    if (primme->matrixMatvec == primme_amd_matvec) {
       /* the library's operator: native only over a complex CSR matrix */
       if (!primme->matrix) return 0;

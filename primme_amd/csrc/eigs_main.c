@@ -853,9 +853,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    /* what this build of the path covers; anything else must fail loudly */
 #if PA_IS_COMPLEX
    if (dt != HIPK_C64 && dt != HIPK_C32) return PRIMME_FUNCTION_UNAVAILABLE;
-   /* the complex objects carry the three extractions with the Generalized-Davidson family and the JDQMR inner solver;
-    * eigs_complex.c sends the dynamic method switch to the real-equivalent form and never calls in here with it */
-   if (p->dynamicMethodSwitch > 0) return PRIMME_FUNCTION_UNAVAILABLE;
+   /* the complex objects carry the three extractions with the Generalized-Davidson family, the JDQMR inner solver and the
+    * dynamic switch between the two (eigs_dynamic.c holds timings and ratios only, nothing scalar-typed) */
 #else
    if (dt != HIPK_F64 && dt != HIPK_F32) return PRIMME_FUNCTION_UNAVAILABLE;
 #endif

@@ -5,9 +5,8 @@
  * as they are (HS = double: hip_dprimme / hip_sprimme) and once with PA_COMPLEX defined (HS = double complex:
  * the native path of hip_zprimme / hip_cprimme) through the one-line wrappers eigs_*_z.c.  In the complex
  * objects every external function of those files carries the suffix _z (the list below is checked by the
- * linker: a missing entry is a duplicate symbol).  What is NOT on the native complex path (the dynamic method
- * switch, eigs_dyn.c) exists once; a Hermitian problem that asks for it runs on the real-equivalent form
- * (eigs_complex.c).
+ * linker: a missing entry is a duplicate symbol).  eigs_dynamic.c (timings and cost ratios of the dynamic method
+ * switch, nothing scalar-typed) and the parameter / callback plumbing exist once and serve both.
  *
  * Device-layer conventions for complex panels (include/primme_amd_kernels.h): inner products, projection
  * coefficients, Ritz coefficient vectors and axpy factors are (re, im) pairs; Ritz values, shifts, squared

@@ -115,3 +115,16 @@ def test_hip_native_complex_halves_the_real_form(built):
     assert nat.ret == 0 and rea.ret == 0
     assert np.max(np.abs(nat.evals - rea.evals)) <= 1e-9 * nat.params["aNorm"]
     assert rea.stats["numMatvecs"] >= 1.6 * nat.stats["numMatvecs"]
+
+
+def test_hip_native_complex_dynamic_method(built):
+    """method = DYNAMIC through hip_zprimme on complex panels: the pairs of the dense solve, true residuals."""
+    n = 3000
+    A, csr = hermitian_band(n, seed=7)
+    w = np.linalg.eigvalsh(A)
+    r = eigsh(Operator(n, csr=csr), backend="hip", dtype=np.complex128, numEvals=6, eps=1e-10, method="DYNAMIC", iseed=(1, 2, 3, 5))
+    assert r.ret == 0 and r.initSize == 6 and r.params["dynamicMethodSwitch"] in (-1, -2, -3)
+    aN = r.params["aNorm"]
+    assert np.max(np.abs(r.evals - w[:6])) <= 1e-9 * aN
+    AX = A @ r.evecs
+    assert np.all(np.linalg.norm(AX - r.evecs * r.evals, axis=0) <= 1.5e-10 * aN)

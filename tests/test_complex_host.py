@@ -200,3 +200,24 @@ def test_native_complex_follows_live_reference_and_halves_the_real_form(built, k
     assert np.max(np.abs(nat.evals - ref.evals)) <= 1e-10 * nat.params["aNorm"]
     assert np.max(np.abs(nat.evals - rea.evals)) <= 1e-9 * nat.params["aNorm"]
     assert rea.stats["numMatvecs"] >= 1.6 * nat.stats["numMatvecs"]
+
+
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("kw", [dict(numEvals=6, eps=1e-10), dict(numEvals=3, eps=1e-9, target="largest", locking=0),
+                                dict(numEvals=8, eps=1e-9, precond="jacobi", maxBlockSize=2)])
+def test_native_complex_dynamic_method(built, kw):
+    """method = DYNAMIC on complex panels (round 3: eigs_dynamic.c holds timings and ratios only and serves both
+    instantiations).  The switch between GD+k and JDQMR follows measured times, so the counts are not reproducible; the
+    pairs are zprimme's, true residuals within the tolerance, and the method it ends on is one of the two."""
+    n = 600
+    rp, ci, va = problems.hermitian_graded_csr(n)
+    v0 = problems.complex_start_vector(n)
+    got = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", dtype=np.complex128, v0=v0, method="DYNAMIC", **kw)
+    ref = eigsh(Operator(n, csr=(rp, ci, va)), backend="reference", dtype=np.complex128, v0=v0, method="DYNAMIC", **kw)
+    assert got.ret == 0 and ref.ret == 0 and got.initSize == ref.initSize == kw["numEvals"]
+    aN = got.params["aNorm"]
+    assert np.max(np.abs(np.sort(got.evals) - np.sort(ref.evals))) <= 1e-9 * aN
+    AX = problems.csr_matvec_numpy(rp, ci, va, got.evecs)
+    assert np.all(np.linalg.norm(AX - got.evecs * got.evals, axis=0) <= 1.5 * kw["eps"] * aN)
+    assert got.params["dynamicMethodSwitch"] in (-1, -2, -3)
+    assert got.stats["numMatvecs"] <= 2.5 * ref.stats["numMatvecs"]
