@@ -230,6 +230,17 @@ int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int
 int hipk_axpy_proj_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha_host, const double *xr_host,
       const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, double *out_dev);
 
+/* the same with the next inner product of the Jacobi-preconditioned QMR taken on the updated g:
+ * out_dev[c] = |g_c|^2, out_dev[nx + c] = g_c' (g_c ./ (diag - shift[c])) — rho of the next step one pass early */
+int hipk_axpy_proj_dot_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha_host, const double *xr_host,
+      const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, const void *diag, const double *shift_host,
+      double min_denominator, double *out_dev);
+/* delta = gamma delta + eta d; sol += delta; dotsol_dev[c] = |sol(:,c)|^2; d = g ./ (diag - shift[c]) + beta d in place:
+ * the QMR step of hipk_qmr_update_jacobi and the direction update that followed it (w += beta d, d <-> w) in one pass */
+int hipk_qmr_update_dir(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gamma_host, const double *eta_host,
+      const double *beta_host, void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G,
+      int64_t ldG, const void *diag, const double *shift_host, double min_denominator, double *dotsol_dev);
+
 /* ---- sparse operator: the user matvec ------------------------------------------
  * Replaces the hipsparseSpMM-based callback of examples/ex_eigs_dhipblas.c:239-264
  * and the SPARSKIT amux of tests/COMMON/mat.c:64-90.

@@ -581,6 +581,57 @@ int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, cons
    return 0;
 }
 
+int hipk_axpy_proj_dot_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha, const double *xr, const void *W,
+      int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, const void *diag, const double *shift, double min_den, double *out) {
+   (void)ctx;
+   if (!(min_den > 0.0)) min_den = 1e-300;
+   for (int c = 0; c < nx; c++) {
+      const void *w = colp(dt, W, ldW, c), *x = colp(dt, X, ldX, c);
+      void *g = (void *)colp(dt, G, ldG, c);
+      double s1 = 0, s2 = 0;
+      for (int64_t i = 0; i < m; i++) {
+         double wp = ld_(dt, w, i) - xr[c] * ld_(dt, x, i);
+         if (dt == HIPK_F32) wp = (double)(float)wp;
+         st_(dt, g, i, ld_(dt, g, i) - alpha[c] * wp);
+         const double gi = ld_(dt, g, i);
+         s1 += gi * gi;
+         double den = ld_(dt, diag, i) - (shift ? shift[c] : 0.0);
+         if (!(fabs(den) > min_den)) den = copysign(min_den, den);
+         double wi = gi / den;
+         if (dt == HIPK_F32) wi = (double)(float)wi;
+         s2 += gi * wi;
+      }
+      out[c] = s1; out[nx + c] = s2;
+   }
+   mirror(out, (size_t)2 * nx);
+   return 0;
+}
+int hipk_qmr_update_dir(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gam, const double *eta, const double *beta,
+      void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G, int64_t ldG,
+      const void *diag, const double *shift, double min_den, double *out) {
+   (void)ctx;
+   if (!(min_den > 0.0)) min_den = 1e-300;
+   for (int c = 0; c < nx; c++) {
+      const void *g = colp(dt, G, ldG, c);
+      void *d = (void *)colp(dt, D, ldD, c), *de = (void *)colp(dt, Delta, ldDelta, c), *so = (void *)colp(dt, Sol, ldSol, c);
+      double s1 = 0.0;
+      for (int64_t i = 0; i < m; i++) {
+         const double di = ld_(dt, d, i);
+         st_(dt, de, i, ld_(dt, de, i) * gam[c] + di * eta[c]);
+         st_(dt, so, i, ld_(dt, de, i) + ld_(dt, so, i));
+         s1 += ld_(dt, so, i) * ld_(dt, so, i);
+         double den = ld_(dt, diag, i) - (shift ? shift[c] : 0.0);
+         if (!(fabs(den) > min_den)) den = copysign(min_den, den);
+         double wi = ld_(dt, g, i) / den;
+         if (dt == HIPK_F32) wi = (double)(float)wi;
+         st_(dt, d, i, wi + beta[c] * di);
+      }
+      out[c] = s1;
+   }
+   mirror(out, (size_t)nx);
+   return 0;
+}
+
 int hipk_jacobi_apply(void *stream, hipk_dtype dt, int64_t m, const void *diag, const double *shift,
       double min_den, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols) {
    (void)stream;

@@ -357,6 +357,14 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    const int fuse_pk = (!PA_IS_COMPLEX && b0 > 1 && !plain_K && p->correctionParams.precondition && p->applyPreconditioner == primme_amd_jacobi_precond &&
                         p->preconditioner && P->nRQ == 0 && P->nRX == 0 && !P->skewQ &&
                         primme_amd_operator_jacobi_data((primme_amd_operator *)p->preconditioner, &jac_diag, &jac_fixed, &jac_shift) == 0);
+   /* ... and with the x-projection folded into the update of g (fold_x) the inner product rho = g'K^-1 g of the NEXT step
+    * rides on that update (hipk_axpy_proj_dot_jacobi): beta is known one synchronisation earlier, and the QMR update
+    * writes the new direction d = K^-1 g + beta d in place (hipk_qmr_update_dir) — w = K^-1 g is never stored and the
+    * separate pass w += beta d disappears (7 array passes per column instead of 11 after the update of g).
+    * PRIMME_AMD_NO_EARLY_RHO=1 keeps the round-2 sequence (A/B knob). */
+   static int no_early = -1;
+   if (no_early < 0) no_early = getenv("PRIMME_AMD_NO_EARLY_RHO") != NULL;
+   const int early_rho = fuse_pk && P->nLX > 0 && !no_early;
    int pm[64], p0[64];
    const int adaptive = (p->correctionParams.convTest == primme_adaptive ||
                          p->correctionParams.convTest == primme_adaptive_ETolerance);
@@ -421,6 +429,18 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          malpha[i] = -alpha_prev[q];
       }
       /* g -= alpha w (0 for dropped columns) and g'g in the same pass */
+      const int early = early_rho && fold_x && numIts + 1 < maxIterations;
+      if (early) {
+         double al[64], jsh[64];
+         for (i = 0; i < blockSize; i++) {
+            al[i] = -malpha[i];
+            jsh[i] = jac_fixed ? jac_shift : (p->ShiftsForPreconditioner ? p->ShiftsForPreconditioner[i] : 0.0);
+         }
+         CHK(hipk_axpy_proj_dot_jacobi(s->ctx, s->dt, s->m, blockSize, al, xr, w, ld, P->LX, P->ldLX, g, ld, jac_diag, jsh,
+               1e-14 * (p->aNorm >= 0.0 ? p->aNorm : 1.0), s->d_red));
+         CHK(pa_reduce(s, s->d_red, 2 * blockSize, 0, 0));
+         for (i = 0; i < blockSize; i++) { gg[i] = s->h_red[i]; rho_new[i] = s->h_red[blockSize + i]; }
+      } else {
       if (fold_x) {
          double al[64];
          for (i = 0; i < blockSize; i++) al[i] = -malpha[i];
@@ -429,6 +449,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
       CHK(hipk_axpy_dot(s->ctx, RDT(s), RM(s), blockSize, malpha, w, R2(ld), g, R2(ld), NULL, 0, s->d_red));
       CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
       for (i = 0; i < blockSize; i++) gg[i] = s->h_red[i];
+      }
 
 #define SHRINK()                                                                                   \
       do {                                                                                         \
@@ -449,6 +470,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          if (P->nLX) P->nLX -= conv;                                                               \
          if (P->nRX) P->nRX -= conv;                                                               \
       } while (0)
+      if (early && conv > 0) pa_permute_reals(rho_new, 1, blockSize, 1, p0);
       SHRINK();
       if (blockSize <= 0) break;
 
@@ -463,8 +485,23 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          gam_c[i] = gamma[q]; eta_c[i] = eta[q];
       }
       /* delta = gamma delta + eta d; sol += delta; |sol|^2 */
-      int have_w = 0;
-      if (fuse_pk && numIts + 1 < maxIterations) {
+      int have_w = 0, have_d = 0;
+      if (early) {
+         /* rho of the next step is known: the update writes the next direction straight into d */
+         double jsh[64], beta_c[64];
+         for (i = 0; i < blockSize; i++) {
+            jsh[i] = jac_fixed ? jac_shift : (p->ShiftsForPreconditioner ? p->ShiftsForPreconditioner[i] : 0.0);
+            beta_c[i] = rho_new[i] / rho_prev[pm[i]];
+         }
+         double t0 = pa_wtime();
+         CHK(hipk_qmr_update_dir(s->ctx, s->dt, s->m, blockSize, gam_c, eta_c, beta_c, d, ld, delta, ld, sol, ld, g, ld, jac_diag, jsh,
+               1e-14 * (p->aNorm >= 0.0 ? p->aNorm : 1.0), s->d_red));
+         CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
+         for (i = 0; i < blockSize; i++) dot_sol[i] = s->h_red[i];
+         p->stats.numPreconds += blockSize;
+         p->stats.timePrecond += pa_wtime() - t0;
+         have_d = 1;
+      } else if (fuse_pk && numIts + 1 < maxIterations) {
          double jsh[64];
          for (i = 0; i < blockSize; i++) jsh[i] = jac_fixed ? jac_shift : (p->ShiftsForPreconditioner ? p->ShiftsForPreconditioner[i] : 0.0);
          double t0 = pa_wtime();
@@ -531,10 +568,18 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          CHK(permute_panel(s, w, ld, blockSize, p0));
          pa_permute_reals(rho_new, 1, blockSize, 1, p0);
       }
+      if (have_d && conv > 0) pa_permute_reals(rho_new, 1, blockSize, 1, p0);
       SHRINK();
       if (blockSize <= 0) break;
 
-      if (numIts + 1 < maxIterations) {
+      if (have_d) {
+         /* d already holds K^-1 g + beta d */
+         for (i = 0; i < blockSize; i++) {
+            const int q = pm[i];
+            rho[q] = rho_new[i];
+            rho_prev[q] = rho[q]; tau_prev[q] = tau[q]; Theta_prev[q] = Theta[q];
+         }
+      } else if (numIts + 1 < maxIterations) {
          if (!plain_K) {
             if (have_w) { for (i = 0; i < blockSize; i++) tmp[i] = rho_new[i]; }
             else {

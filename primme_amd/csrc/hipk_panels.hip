@@ -1766,6 +1766,98 @@ axpy_proj_dot_kernel(ColScal alpha, ColScal xr, const T *__restrict__ Wv, int64_
    }
 }
 
+/* The same with the NEXT inner product of the preconditioned QMR already taken: out[nx + c] = g_c' K^-1 g_c for the
+ * updated g and the Jacobi preconditioner K = diag - shift[c].  With rho known at this synchronisation the step's
+ * beta = rho / rho_prev is known before the QMR update runs, and that pass can write the new direction
+ * d = K^-1 g + beta d in place (qmr_update_dir_kernel) instead of storing w = K^-1 g and adding beta d in a further pass.
+ * Rows outside, (up to 8) columns inside: the diagonal is read once per row. */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+axpy_proj_dot_jacobi_kernel(ColScal alpha, ColScal xr, ColScal shf, double min_den, const T *__restrict__ Wv, int64_t ldW,
+      const T *__restrict__ X, int64_t ldX, T *__restrict__ G, int64_t ldG, const T *__restrict__ diag, int nx, int c0, int64_t m,
+      double *__restrict__ partials) {
+   constexpr int NXC = 8;
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][2 * NXC];
+   const int nc = min(NXC, nx - c0);
+   double s1[NXC], s2[NXC];
+#pragma unroll
+   for (int c = 0; c < NXC; c++) { s1[c] = 0.0; s2[c] = 0.0; }
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      const double dg = (double)diag[i];
+#pragma unroll
+      for (int c = 0; c < NXC; c++)
+         if (c < nc) {
+            const size_t cc = (size_t)(c0 + c);
+            const T wp = (T)fma(-xr.a[c0 + c], (double)X[i + cc * ldX], (double)Wv[i + cc * ldW]);   /* rounded like the stored projected w */
+            const T ng = (T)fma(-alpha.a[c0 + c], (double)wp, (double)G[i + cc * ldG]);
+            G[i + cc * ldG] = ng;
+            s1[c] = fma((double)ng, (double)ng, s1[c]);
+            double den = dg - shf.a[c0 + c];
+            if (!(fabs(den) > min_den)) den = copysign(min_den, den);
+            const T wi = (T)((double)ng / den);                      /* rounded like the stored K^-1 g */
+            s2[c] = fma((double)ng, (double)wi, s2[c]);
+         }
+   }
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+   for (int c = 0; c < NXC; c++) {
+      const double a = hipk_wave_sum(s1[c]), b = hipk_wave_sum(s2[c]);
+      if (lane == 0) { sm[wv][c] = a; sm[wv][NXC + c] = b; }
+   }
+   __syncthreads();
+   if (threadIdx.x < 2 * NXC) {
+      const int which = threadIdx.x / NXC, c = threadIdx.x % NXC;
+      if (c < nc)
+         partials[(size_t)blockIdx.x * 2 * nx + which * nx + c0 + c] =
+               (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+   }
+}
+
+/* delta = gamma delta + eta d;  sol += delta;  out[c] = |sol(:,c)|^2;  d = g ./ (diag - shift[c]) + beta d (in place):
+ * the QMR step and the next search direction in one pass over d, delta, sol, g (seven array passes per column; the
+ * sequence qmr_update_jacobi + axpy it replaces makes eleven) */
+template <typename T>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+qmr_update_dir_kernel(ColScal gam, ColScal eta, ColScal bet, ColScal shf, double min_den, T *__restrict__ D, int64_t ldD,
+      T *__restrict__ Delta, int64_t ldDelta, T *__restrict__ Sol, int64_t ldSol, const T *__restrict__ G, int64_t ldG,
+      const T *__restrict__ diag, int nx, int c0, int64_t m, double *__restrict__ partials) {
+   constexpr int NXC = 8;
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NXC];
+   const int nc = min(NXC, nx - c0);
+   double s1[NXC];
+#pragma unroll
+   for (int c = 0; c < NXC; c++) s1[c] = 0.0;
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      const double dg = (double)diag[i];
+#pragma unroll
+      for (int c = 0; c < NXC; c++)
+         if (c < nc) {
+            const size_t cc = (size_t)(c0 + c);
+            const double di = (double)D[i + cc * ldD];
+            const T nd = (T)fma((double)Delta[i + cc * ldDelta], gam.a[c0 + c], di * eta.a[c0 + c]);
+            Delta[i + cc * ldDelta] = nd;
+            const T ns = (T)((double)nd + (double)Sol[i + cc * ldSol]);
+            Sol[i + cc * ldSol] = ns;
+            s1[c] = fma((double)ns, (double)ns, s1[c]);
+            double den = dg - shf.a[c0 + c];
+            if (!(fabs(den) > min_den)) den = copysign(min_den, den);
+            const T wi = (T)((double)G[i + cc * ldG] / den);
+            D[i + cc * ldD] = (T)fma(bet.a[c0 + c], di, (double)wi);    /* w += beta d, as the axpy pass rounds it */
+         }
+   }
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+   for (int c = 0; c < NXC; c++) {
+      const double a = hipk_wave_sum(s1[c]);
+      if (lane == 0) sm[wv][c] = a;
+   }
+   __syncthreads();
+   if (threadIdx.x < NXC && (int)threadIdx.x < nc)
+      partials[(size_t)blockIdx.x * nx + c0 + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
 #define DISPATCH_RT(dt, CALL_D, CALL_F)         \
    switch (dt) {                                \
    case HIPK_F64: { typedef double T; CALL_D; } break; \
@@ -1997,6 +2089,44 @@ extern "C" int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, i
       HIPK_CHECK(hipGetLastError());
    }
    return hipk_finalize_partials(ctx, ctx->partials, gx, 2 * nx, out_dev);
+}
+
+extern "C" int hipk_axpy_proj_dot_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha_host, const double *xr_host,
+      const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, const void *diag, const double *shift_host,
+      double min_den, double *out_dev) {
+   if (nx <= 0) return 0;
+   if (nx > UTIL_MAXCOLS) return -1;
+   if (!(min_den > 0.0)) min_den = 1e-300;
+   ColScal a, r, sh;
+   for (int c = 0; c < nx; c++) { a.a[c] = alpha_host[c]; r.a[c] = xr_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * 2 * nx)) return -2;
+   for (int c0 = 0; c0 < nx; c0 += 8) {
+      DISPATCH_RT(dt,
+            hipLaunchKernelGGL(axpy_proj_dot_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, a, r, sh, min_den, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials),
+            hipLaunchKernelGGL(axpy_proj_dot_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, a, r, sh, min_den, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials));
+      HIPK_CHECK(hipGetLastError());
+   }
+   return hipk_finalize_partials(ctx, ctx->partials, gx, 2 * nx, out_dev);
+}
+
+extern "C" int hipk_qmr_update_dir(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gamma_host, const double *eta_host,
+      const double *beta_host, void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G, int64_t ldG,
+      const void *diag, const double *shift_host, double min_den, double *dotsol_dev) {
+   if (nx <= 0) return 0;
+   if (nx > UTIL_MAXCOLS) return -1;
+   if (!(min_den > 0.0)) min_den = 1e-300;
+   ColScal g, e, b, sh;
+   for (int c = 0; c < nx; c++) { g.a[c] = gamma_host[c]; e.a[c] = eta_host[c]; b.a[c] = beta_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   for (int c0 = 0; c0 < nx; c0 += 8) {
+      DISPATCH_RT(dt,
+            hipLaunchKernelGGL(qmr_update_dir_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, b, sh, min_den, (T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials),
+            hipLaunchKernelGGL(qmr_update_dir_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, b, sh, min_den, (T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials));
+      HIPK_CHECK(hipGetLastError());
+   }
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, dotsol_dev);
 }
 
 extern "C" int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *V, int64_t ldV,

@@ -481,6 +481,53 @@ def test_qmr_update_with_jacobi(built, dt):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("nx", [3, 8, 11])
+def test_qmr_early_rho_pair(built, dt, nx):
+    """The two passes of a block QMR step with the next rho taken early: g -= alpha (w - xr x), |g|^2 and g'K^-1 g in
+    one pass; delta / sol update and the new direction d = K^-1 g + beta d in place in the next.  Against the oracle and
+    against the sequence they replace (axpy_proj_dot, qmr_update_jacobi, w += beta d): same arithmetic per element."""
+    rng = np.random.default_rng(77 + nx)
+    npdt = NPDT[dt]
+    m, ld = 70003, 70004
+    X, W, G, D, De, So = (rng.standard_normal((nx, ld)).astype(npdt) for _ in range(6))
+    diag = (2.0 + rng.random(m)).astype(npdt); diag[5] = 1.0
+    alpha, xr, gam, eta, beta = (rng.standard_normal(nx) for _ in range(5))
+    sh = np.resize(np.array([1.0, 0.3, -2.0, 0.0, 1.5]), nx)
+    a = lambda v: (C.c_double * nx)(*v)
+    res = []
+    for side in (Dev(), Host()):
+        x, w, g, d, de, so, dg = (side.arr(t) for t in (X, W, G, D, De, So, diag))
+        o2, o1 = side.arr(np.zeros(2 * nx)), side.arr(np.zeros(nx))
+        assert side.lib.hipk_axpy_proj_dot_jacobi(side.ctx, dt, m, nx, a(alpha), a(xr), side.ptr(w), ld, side.ptr(x), ld, side.ptr(g), ld,
+                                                  side.ptr(dg), a(sh), C.c_double(1e-10), side.ptr(o2)) == 0
+        assert side.lib.hipk_qmr_update_dir(side.ctx, dt, m, nx, a(gam), a(eta), a(beta), side.ptr(d), ld, side.ptr(de), ld, side.ptr(so), ld,
+                                            side.ptr(g), ld, side.ptr(dg), a(sh), C.c_double(1e-10), side.ptr(o1)) == 0
+        new = [side.get(t).copy() for t in (g, d, de, so, o2, o1)]
+        # the replaced sequence on fresh copies
+        g2, d2, de2, so2 = (side.arr(t) for t in (G, D, De, So))
+        w2 = side.arr(np.zeros((nx, ld), dtype=npdt)); p1, p2 = side.arr(np.zeros(nx)), side.arr(np.zeros(2 * nx))
+        assert side.lib.hipk_axpy_proj_dot(side.ctx, dt, m, nx, a(alpha), a(xr), side.ptr(w), ld, side.ptr(x), ld, side.ptr(g2), ld, side.ptr(p1)) == 0
+        assert side.lib.hipk_qmr_update_jacobi(side.ctx, dt, m, nx, a(gam), a(eta), side.ptr(d2), ld, side.ptr(de2), ld, side.ptr(so2), ld,
+                                               side.ptr(g2), ld, side.ptr(dg), a(sh), C.c_double(1e-10), side.ptr(w2), ld, side.ptr(p2)) == 0
+        assert side.lib.hipk_axpy_cols(side.ctx, dt, m, a(beta), side.ptr(d2), ld, side.ptr(w2), ld, nx) == 0
+        old = [side.get(t).copy() for t in (g2, w2, de2, so2)] + [np.concatenate([side.get(p1), side.get(p2)[nx:]]), side.get(p2)[:nx].copy()]
+        res.append((new, old))
+        side.close()
+    tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+    for new, old in res:                                  # new sequence == old sequence, element for element
+        for t in range(4):
+            assert np.array_equal(new[t][:, :m], old[t][:, :m]), t
+        for t in (4, 5):
+            assert np.max(np.abs(new[t] - old[t]) / (1 + np.abs(old[t]))) <= tol * np.sqrt(m)
+    for t in range(4):                                    # device == oracle
+        assert np.max(np.abs(res[0][0][t][:, :m] - res[1][0][t][:, :m]) / (1 + np.abs(res[1][0][t][:, :m]))) <= tol * 10
+    for t in (4, 5):
+        assert np.max(np.abs(res[0][0][t] - res[1][0][t]) / (1 + np.abs(res[1][0][t]))) <= tol * np.sqrt(m)
+    for t in range(4):                                    # padding untouched
+        assert np.array_equal(res[0][0][t][:, m:], (G, D, De, So)[t][:, m:])
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
 def test_csr_matvec_scaled_fused_tail(built, dt):
     """y = A (a x), xout = a x, dot = xout' y with a = 1/sqrt(norm2) read from device memory: one launch for the
     normalisation, the operator and t'At of the one-synchronisation iteration; against the oracle and against
