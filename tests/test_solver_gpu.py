@@ -34,7 +34,13 @@ LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_le
          "lap1d_ex_dseq_dynamic": 1e9, "lap3d_dynamic": 1e9, "lap2d_dynamic_few_soft": 1e9,   # timing-driven paths
          "ref_closest_abs": 0.35, "ref_closest_geq": 0.35, "ref_closest_leq_jdqmr": 0.35, "ref_soft": 0.35, "ref_two_shifts": 0.35,
          "harm_closest_abs": 0.35, "harm_closest_geq": 0.35, "harm_closest_leq_jdqmr": 0.35, "harm_two_shifts": 0.35,
-         "jdqmr_blk4": 0.5, "jdqmr_etol_blk8_jacobi": 0.5, "jdqmr_closest_abs": 0.5}
+         "jdqmr_blk4": 0.3, "jdqmr_etol_blk8_jacobi": 0.3, "jdqmr_closest_abs": 0.3}
+# Block JDQMR is a different (equally valid) block iteration from the reference's, which indexes some QMR recurrences by
+# block position and others by original column; unpreconditioned interior runs are chaotic at any
+# block size.  profiles/r03_jdqmr_block_count_sweep.txt (48 random configurations against the live reference): operator
+# applications within 0.79-1.18 of dprimme's (median 1.01), outer iterations 0.58-1.10 (fewer, longer inner solves at
+# b = 4, 8), block size 1 exact.  The work measure (matvecs) gets the tight bound, the outer count the loose one.
+LOOSE_MATVECS = {"jdqmr_blk4": 0.15, "jdqmr_etol_blk8_jacobi": 0.15, "jdqmr_closest_abs": 0.15}
 
 
 def _case(name):
@@ -77,6 +83,8 @@ def test_hip_against_reference_fixture(built, name):
     # exactly for most cases; allow 2 % (5 % for the interior targets, where the reference
     # itself varies from run to run)
     assert abs(its - itsg) <= max(2, LOOSE.get(name, 0.02) * itsg), (its, itsg)
+    if name in LOOSE_MATVECS:
+        assert abs(r.stats["numMatvecs"] - g["stats"]["numMatvecs"]) <= LOOSE_MATVECS[name] * g["stats"]["numMatvecs"]
     if name not in LOOSE and its == itsg and r.stats["numMatvecs"] == g["stats"]["numMatvecs"]:
         # same convergence history as the reference: its residual norms are reproduced too (north
         # star: eigenvalues AND residual norms within 1e-10 |A| in double, 1e-4 |A| in float)

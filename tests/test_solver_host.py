@@ -31,9 +31,15 @@ LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_le
          # block JDQMR: the reference's inner solver mixes position- and column-indexed scalars once a
          # block column has converged (see eigs_jd.c header); results agree, the paths do not
          "lap1d_ex_dseq_dynamic": 1e9, "lap3d_dynamic": 1e9, "lap2d_dynamic_few_soft": 1e9,   # timing-driven paths
-         "ref_closest_abs": 0.1, "ref_closest_geq": 0.1, "ref_closest_leq_jdqmr": 0.3, "ref_soft": 0.1, "ref_two_shifts": 0.3,
-         "harm_closest_abs": 0.1, "harm_closest_geq": 0.1, "harm_closest_leq_jdqmr": 0.3, "harm_two_shifts": 0.1,
-         "jdqmr_blk4": 0.5, "jdqmr_etol_blk8_jacobi": 0.5, "jdqmr_closest_abs": 0.5}
+         "ref_closest_abs": 0.1, "ref_closest_geq": 0.1, "ref_closest_leq_jdqmr": 0.15, "ref_soft": 0.1, "ref_two_shifts": 0.15,
+         "harm_closest_abs": 0.1, "harm_closest_geq": 0.1, "harm_closest_leq_jdqmr": 0.15, "harm_two_shifts": 0.1,
+         "jdqmr_blk4": 0.3, "jdqmr_etol_blk8_jacobi": 0.3, "jdqmr_closest_abs": 0.3}
+# Block JDQMR is a different (equally valid) block iteration from the reference's, which indexes some QMR recurrences by
+# block position and others by original column; unpreconditioned interior runs are chaotic at any
+# block size.  profiles/r03_jdqmr_block_count_sweep.txt (48 random configurations against the live reference): operator
+# applications within 0.79-1.18 of dprimme's (median 1.01), outer iterations 0.58-1.10 (fewer, longer inner solves at
+# b = 4, 8), block size 1 exact.  The work measure (matvecs) gets the tight bound, the outer count the loose one.
+LOOSE_MATVECS = {"jdqmr_blk4": 0.15, "jdqmr_etol_blk8_jacobi": 0.15, "jdqmr_closest_abs": 0.15}
 
 
 def _run(name, backend):
@@ -74,6 +80,8 @@ def test_against_reference_fixture(built, name, projection_column, monkeypatch):
     its, itsg = r.stats["numOuterIterations"], g["stats"]["numOuterIterations"]
     tol = LOOSE.get(name, 0.0)
     assert abs(its - itsg) <= tol * itsg, (its, itsg)
+    if name in LOOSE_MATVECS:
+        assert abs(r.stats["numMatvecs"] - g["stats"]["numMatvecs"]) <= LOOSE_MATVECS[name] * g["stats"]["numMatvecs"]
     if tol == 0.0:
         assert r.stats["numMatvecs"] == g["stats"]["numMatvecs"]
         assert r.stats["numRestarts"] == g["stats"]["numRestarts"]
