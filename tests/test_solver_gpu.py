@@ -32,8 +32,8 @@ def _make_v0(spec, n):
 
 LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_leq": 0.05,
          "lap1d_ex_dseq_dynamic": 1e9, "lap3d_dynamic": 1e9, "lap2d_dynamic_few_soft": 1e9,   # timing-driven paths
-         "ref_closest_abs": 0.35, "ref_closest_geq": 0.35, "ref_closest_leq_jdqmr": 0.35, "ref_soft": 0.35, "ref_two_shifts": 0.35,
-         "harm_closest_abs": 0.35, "harm_closest_geq": 0.35, "harm_closest_leq_jdqmr": 0.35, "harm_two_shifts": 0.35,
+         "ref_closest_abs": 0.25, "ref_closest_geq": 0.25, "ref_closest_leq_jdqmr": 0.25, "ref_soft": 0.25, "ref_two_shifts": 0.25,
+         "harm_closest_abs": 0.25, "harm_closest_geq": 0.25, "harm_closest_leq_jdqmr": 0.25, "harm_two_shifts": 0.25,
          "jdqmr_blk4": 0.3, "jdqmr_etol_blk8_jacobi": 0.3, "jdqmr_closest_abs": 0.3}
 # Block JDQMR is a different (equally valid) block iteration from the reference's, which indexes some QMR recurrences by
 # block position and others by original column; unpreconditioned interior runs are chaotic at any
