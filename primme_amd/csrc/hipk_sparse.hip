@@ -33,7 +33,12 @@ struct hipk_csr {
    int32_t *tiles;             /* device: ntiles+1 row offsets */
    int4 *tileinfo;             /* device: {first row, end row, first nonzero, end nonzero} per tile */
    int2 *twin;                 /* device: {first column, window width} per tile; width 0 = not windowable */
+   uint16_t *col16;            /* device, or NULL: column - (row0 + first row of the tile - c16back) for every nonzero, when that
+                                  fits 16 bits for the whole matrix (banded / stencil / block-diagonal patterns): 2 bytes per
+                                  nonzero out of HBM instead of 4 in the tile kernels, the base follows from the tile record */
+   int64_t c16back;            /* how far below its first row a tile's columns reach, at most */
    int windowed;               /* most tiles have a narrow column window inside the owned slab */
+   int cw_max;                 /* widest window among the windowable tiles */
    int ntiles;
    void *diag;                 /* device, nrows elements */
    int64_t halo_lo, halo_hi;   /* extent of off-rank columns below / above */
@@ -74,10 +79,11 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
  * x), and the tile's part of xout' y goes to partials[blockIdx.x].  Replaces the separate
  * normalisation pass and the two-vector inner product t'At of the one-synchronisation GD
  * iteration (eigs_conv.c); same arithmetic per element as scale_rsqrt_kernel + this kernel. */
-template <typename T, bool FUSED>
+template <typename T, bool FUSED, bool C16>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *__restrict__ rowptr,
-      const int32_t *__restrict__ colind, const T *__restrict__ val, const T *__restrict__ x,
+      const int32_t *__restrict__ colind, const uint16_t *__restrict__ col16, int64_t c16off,
+      const T *__restrict__ val, const T *__restrict__ x,
       int64_t ldx, T *__restrict__ y, int64_t ldy, int ncols, int64_t row0, int64_t nrows,
       int64_t halo_lo, int64_t halo_hi, const T *__restrict__ xlo, const T *__restrict__ xhi,
       int64_t ld_lo, int64_t ld_hi, const double *__restrict__ norm2, T *__restrict__ xout,
@@ -104,7 +110,15 @@ csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *
             const int q = threadIdx.x + u * HIPK_BLOCK;
             const int qc = q < nz ? q : (nz > 0 ? nz - 1 : 0);   /* an all-empty tile reads the padded element */
             v[u] = (double)val[p0 + qc];
-            cidx[u] = colind[p0 + qc];
+            /* C16 (a template parameter: exactly one index stream is loaded): global column = row0 + r0 - c16back + entry;
+             * an empty tile reads a neighbour's entry against its own base, so its (unused) gather goes to a valid row */
+            if (C16) cidx[u] = (int32_t)col16[p0 + qc];          /* raw: any arithmetic here would make the batch wait load by load */
+            else cidx[u] = colind[p0 + qc];
+         }
+         if (C16) {
+            const int32_t cbase = (int32_t)(c16off + r0);
+#pragma unroll
+            for (int u = 0; u < TILE_PER_LANE; u++) cidx[u] = nz > 0 ? cbase + cidx[u] : (int32_t)row0;
          }
          for (int c = 0; c < ncols; c++) {
             const T *xc = x + (size_t)c * ldx;
@@ -289,58 +303,62 @@ csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32
  * shift != NULL: y = A x - shift[c] x(:,c), the first update of the projected operator in the
  * JDQMR inner iteration (reference inner_solve.c:853-858) fused into the operator. */
 #define XS_MAX 3072
-struct SpmmShift { double s[64]; int on; };
-template <typename T, int NC>
+struct SpmmShift { double s[64]; int on; int nosplit; };
+template <typename T, int NC, int XS, bool C16>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restrict__ twin, int ntiles,
-      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, const T *__restrict__ val,
+      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, const uint16_t *__restrict__ col16, int64_t c16off,
+      const T *__restrict__ val,
       const T *__restrict__ x, int64_t ldx, T *__restrict__ y, int64_t ldy, int ncols, int64_t row0,
       SpmmShift sh) {
    __shared__ T sval[TILE_NNZ];
    __shared__ int32_t scol[TILE_NNZ];
    __shared__ int rp[TILE_ROWS + 1];
-   __shared__ double xs[XS_MAX];                 /* xs[w * ncols + c] = x(cmin + w, c) */
+   __shared__ double xs[XS];                 /* xs[w * ncols + c] = x(cmin + w, c) */
    const int tile = xcd_tile(blockIdx.x, ntiles);
    if (tile >= ntiles) return;
    const int4 ti = tileinfo[tile];
    const int2 tw = twin[tile];
    const int r0 = ti.x, r1 = ti.y, p0 = ti.z, nz = ti.w - ti.z, nr = r1 - r0;
    const int cmin = tw.x, cw = tw.y;
-   const bool win = cw > 0 && cw * ncols <= XS_MAX && nz <= TILE_NNZ;
+   const bool win = cw > 0 && cw * ncols <= XS && nz <= TILE_NNZ;
    if (nz <= TILE_NNZ) {
       {  /* every load of the tile — (value, column) pairs, row pointers, the x window — is issued before
           * the first LDS store: indices clamped, not predicated, so nothing branches around a load */
          T tv[TILE_PER_LANE];
          int32_t tc[TILE_PER_LANE];
-         T xw[XS_MAX / HIPK_BLOCK];
+         T xw[XS / HIPK_BLOCK];
 #pragma unroll
          for (int u = 0; u < TILE_PER_LANE; u++) {
             const int q = threadIdx.x + u * HIPK_BLOCK;
             const int qc = q < nz ? q : (nz > 0 ? nz - 1 : 0);
-            tv[u] = val[p0 + qc]; tc[u] = colind[p0 + qc];
+            tv[u] = val[p0 + qc];
+            if (C16) tc[u] = (int32_t)col16[p0 + qc];            /* raw: the base is added when the entry goes to LDS */
+            else tc[u] = colind[p0 + qc];
          }
          const int rr = threadIdx.x <= nr ? threadIdx.x : nr;
          const int rpv = rowptr[r0 + rr] - p0;
          const int nxw = win ? cw * ncols : 0;
          if (win) {
 #pragma unroll
-            for (int u = 0; u < XS_MAX / HIPK_BLOCK; u++) {
+            for (int u = 0; u < XS / HIPK_BLOCK; u++) {
                const int idx = threadIdx.x + u * HIPK_BLOCK;
                const int ic = idx < nxw ? idx : nxw - 1;
                const int c = ic / cw, w = ic - c * cw;          /* coalesced along the window for each column */
                xw[u] = x[(int64_t)cmin - row0 + w + (size_t)c * ldx];
             }
          }
+         const int32_t cadj = (C16 ? (int32_t)(c16off + r0) : 0) - (win ? cmin : 0);   /* stored column: global, or window-relative */
 #pragma unroll
          for (int u = 0; u < TILE_PER_LANE; u++) {
             const int q = threadIdx.x + u * HIPK_BLOCK;
-            if (q < nz) { sval[q] = tv[u]; scol[q] = tc[u] - (win ? cmin : 0); }
+            if (q < nz) { sval[q] = tv[u]; scol[q] = tc[u] + cadj; }
          }
          if (threadIdx.x <= nr) rp[threadIdx.x] = rpv;
          if (threadIdx.x == 0 && nr == TILE_ROWS) rp[TILE_ROWS] = rowptr[r0 + TILE_ROWS] - p0;
          if (win) {
 #pragma unroll
-            for (int u = 0; u < XS_MAX / HIPK_BLOCK; u++) {
+            for (int u = 0; u < XS / HIPK_BLOCK; u++) {
                const int idx = threadIdx.x + u * HIPK_BLOCK;
                if (idx < nxw) { const int c = idx / cw, w = idx - c * cw; xs[w * ncols + c] = (double)xw[u]; }   /* LDS rows are ncols apart */
             }
@@ -348,12 +366,18 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
       }
       __syncthreads();
       const int ngroups = (ncols + NC - 1) / NC;
-      for (int idx = threadIdx.x; idx < nr * ngroups; idx += HIPK_BLOCK) {
+      /* A tile of 2048 nonzeros has ~120 rows of 17: with one lane per (row, column group) half of the workgroup idles
+       * through the row walk, a chain of dependent LDS reads.  When the work fits twice, two adjacent lanes share a row:
+       * each walks half of its nonzeros and the halves meet in a shuffle (fixed order: low half + high half). */
+      const int split = (2 * nr * ngroups <= HIPK_BLOCK && !sh.nosplit) ? 2 : 1;
+      for (int idx0 = threadIdx.x; idx0 < nr * ngroups * split; idx0 += HIPK_BLOCK) {
+         const int idx = idx0 / split, half = idx0 - idx * split;
          const int g = idx / nr, r = idx - g * nr, c0 = g * NC;
          double acc[NC];
 #pragma unroll
          for (int c = 0; c < NC; c++) acc[c] = 0.0;
-         const int qa = rp[r], qb = rp[r + 1];
+         int qa = rp[r], qb = rp[r + 1];
+         if (split == 2) { const int qm = qa + (qb - qa + 1) / 2; if (half) qa = qm; else qb = qm; }
          if (win) {
             int cofs[NC];
 #pragma unroll
@@ -383,6 +407,12 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
 #pragma unroll
                   for (int c = 0; c < NC; c++) acc[c] = fma(v[u], (double)xg[c][gc[u]], acc[c]);
             }
+         }
+         if (split == 2) {
+            /* (2 nr ngroups <= 256: one trip, both lanes of a pair are in it) */
+#pragma unroll
+            for (int c = 0; c < NC; c++) { const double o = __shfl_xor(acc[c], 1); acc[c] = half ? o + acc[c] : acc[c] + o; }
+            if (half) continue;
          }
 #pragma unroll
          for (int c = 0; c < NC; c++)
@@ -523,6 +553,7 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
    std::vector<int4> tinfo((size_t)A->ntiles + 1);
    std::vector<int2> twin((size_t)A->ntiles + 1);
    int64_t narrow = 0;
+   A->cw_max = 0;
    for (int t = 0; t < A->ntiles; t++) {
       tinfo[t] = make_int4(tiles[t], tiles[t + 1], rowptr_host[tiles[t]], rowptr_host[tiles[t + 1]]);
       int64_t cmin = INT64_MAX, cmax = -1;
@@ -534,9 +565,38 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
       /* the shifted product also reads x at the tile's own rows: they are local by construction */
       const bool inside = cmax >= cmin && cmin >= x0 && cmax < x0 + xlen && cmax - cmin + 1 <= XS_MAX;
       twin[t] = inside ? make_int2((int)cmin, (int)(cmax - cmin + 1)) : make_int2(0, 0);
+      if (inside && (int)(cmax - cmin + 1) > A->cw_max) A->cw_max = (int)(cmax - cmin + 1);
       if (inside && (cmax - cmin + 1) * 8 <= XS_MAX) narrow++;
    }
    A->windowed = (lo == 0 && hi == 0 && A->ntiles > 0 && narrow * 10 >= (int64_t)A->ntiles * 9);
+   /* A second, 2-byte index stream when the pattern allows it: entry = column - (row0 + first row of the tile - c16back),
+    * c16back = the farthest any tile reaches below its first row.  10 instead of 12 bytes per nonzero out of HBM for a
+    * double matrix; the tile kernels rebuild the column from the tile record they load anyway. */
+   std::vector<uint16_t> c16;
+   A->c16back = 0;
+   if ((dt == HIPK_F64 || dt == HIPK_F32) && A->ntiles > 0) {
+      int64_t back = 0, reach = 0;
+      std::vector<int64_t> tmin((size_t)A->ntiles), tmax((size_t)A->ntiles);
+      for (int t = 0; t < A->ntiles; t++) {
+         int64_t cmin = INT64_MAX, cmax = -1;
+         for (int32_t p = rowptr_host[tiles[t]]; p < rowptr_host[tiles[t + 1]]; p++) {
+            const int64_t g = colind_host[p];
+            if (g < cmin) cmin = g;
+            if (g > cmax) cmax = g;
+         }
+         tmin[t] = cmin; tmax[t] = cmax;
+         if (cmax >= cmin && row0 + tiles[t] - cmin > back) back = row0 + tiles[t] - cmin;
+      }
+      for (int t = 0; t < A->ntiles; t++)
+         if (tmax[t] >= tmin[t] && tmax[t] - (row0 + tiles[t] - back) > reach) reach = tmax[t] - (row0 + tiles[t] - back);
+      if (reach <= 65535 && row0 - back > (int64_t)INT32_MIN / 2 && ncols_global < (int64_t)INT32_MAX) {
+         A->c16back = back;
+         c16.assign((size_t)nnz + 1, 0);
+         for (int t = 0; t < A->ntiles; t++)
+            for (int32_t p = rowptr_host[tiles[t]]; p < rowptr_host[tiles[t + 1]]; p++)
+               c16[p] = (uint16_t)(colind_host[p] - (row0 + tiles[t] - back));
+      }
+   }
 
    if (hipk_malloc(ctx, (size_t)(nrows_local + 1) * 4, (void **)&A->rowptr) ||
          hipk_malloc(ctx, (size_t)(nnz + 1) * 4, (void **)&A->colind) ||       /* +1: clamped loads of an empty tile */
@@ -544,7 +604,8 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
          hipk_malloc(ctx, tiles.size() * 4, (void **)&A->tiles) ||
          hipk_malloc(ctx, tinfo.size() * sizeof(int4), (void **)&A->tileinfo) ||
          hipk_malloc(ctx, twin.size() * sizeof(int2), (void **)&A->twin) ||
-         hipk_malloc(ctx, (size_t)nrows_local * es, &A->diag))
+         hipk_malloc(ctx, (size_t)nrows_local * es, &A->diag) ||
+         (!c16.empty() && hipk_malloc(ctx, c16.size() * sizeof(uint16_t), (void **)&A->col16)))
       return -2;
    /* Every upload goes through pinned staging on the context's stream (hipk_upload) and is complete on return: nothing
     * goes through the NULL stream, which a hipStreamNonBlocking stream is not ordered against, and the runtime is never
@@ -561,6 +622,7 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
             hipk_upload(ctx, A->tileinfo, tinfo.data(), tinfo.size() * sizeof(int4)) ||
             hipk_upload(ctx, A->twin, twin.data(), twin.size() * sizeof(int2)) ||
             hipk_upload(ctx, A->diag, dg.data(), (size_t)nrows_local * es) ||
+            (A->col16 && hipk_upload(ctx, A->col16, c16.data(), c16.size() * sizeof(uint16_t))) ||
             hipk_upload(ctx, A->colind + nnz, &padcol, (size_t)4) ||
             hipk_upload(ctx, (char *)A->values + (size_t)nnz * es, zero, es))
          return -1;
@@ -619,6 +681,7 @@ extern "C" int hipk_csr_destroy(hipk_csr *A) {
    if (A->tiles) (void)hipFree(A->tiles);
    if (A->tileinfo) (void)hipFree(A->tileinfo);
    if (A->twin) (void)hipFree(A->twin);
+   if (A->col16) (void)hipFree(A->col16);
    if (A->diag) (void)hipFree(A->diag);
    free(A);
    return 0;
@@ -635,6 +698,13 @@ extern "C" int hipk_csr_set_halo(hipk_csr *A, const void *lo, const void *hi) {
 extern "C" int hipk_csr_set_halo_ld(hipk_csr *A, const void *lo, int64_t ld_lo, const void *hi, int64_t ld_hi) {
    A->xlo = lo; A->xhi = hi; A->ld_lo = ld_lo; A->ld_hi = ld_hi;
    return 0;
+}
+
+/* the 2-byte index stream of a matrix, if it has one (HIPK_SPMM_NO_COL16=1: never, the A/B knob) */
+static const uint16_t *csr16(const hipk_csr *A) {
+   static int no16 = -1;
+   if (no16 < 0) no16 = getenv("HIPK_SPMM_NO_COL16") != NULL;
+   return no16 ? (const uint16_t *)NULL : A->col16;
 }
 
 template <typename T>
@@ -667,18 +737,30 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
       if (use_win) {
          SpmmShift sh;
          sh.on = shift_host != NULL;
+         static int nosplit = -1;                   /* HIPK_SPMM_NO_SPLIT=1: one lane per row always (A/B knob) */
+         if (nosplit < 0) nosplit = getenv("HIPK_SPMM_NO_SPLIT") != NULL;
+         sh.nosplit = nosplit;
          for (int c = 0; c < 64; c++) sh.s[c] = (shift_host && c < ncols) ? shift_host[c] : 0.0;
-         if (ncols <= 2)
-            hipLaunchKernelGGL((csr_window_block_kernel<T, 2>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->tileinfo, A->twin,
-                  A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, ncols, A->x0, sh);
-         else
-            hipLaunchKernelGGL((csr_window_block_kernel<T, 4>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->tileinfo, A->twin,
-                  A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy, ncols, A->x0, sh);
-      } else if (ncols == 1 && force == 0)
-         hipLaunchKernelGGL((csr_stream_kernel<T, false>), dim3(gx), dim3(HIPK_BLOCK), 0, stream,
-               A->tileinfo, A->ntiles, A->rowptr, A->colind, (const T *)A->values, x, ldx, y, ldy,
-               ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo,
-               (const T *)A->xhi, A->ld_lo, A->ld_hi, (const double *)NULL, (T *)NULL, (double *)NULL, hipk_fin_args());
+         /* the window buffer in two sizes: 1536 values when every window of this matrix fits (38 KB of LDS per
+          * workgroup, 4 per CU) and XS_MAX = 3072 otherwise (50 KB, 3 per CU) */
+         static int bigxs = -1;                     /* HIPK_SPMM_BIG_WINDOW=1: always the large buffer (A/B knob) */
+         if (bigxs < 0) bigxs = getenv("HIPK_SPMM_BIG_WINDOW") != NULL;
+         const bool small = !bigxs && (int64_t)A->cw_max * ncols <= 1536;
+#define LAUNCH_WIN(NCV, XSV, C16V) hipLaunchKernelGGL((csr_window_block_kernel<T, NCV, XSV, C16V>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->tileinfo, A->twin, \
+                  A->ntiles, A->rowptr, A->colind, csr16(A), A->row0 - A->c16back, (const T *)A->values, x, ldx, y, ldy, ncols, A->x0, sh)
+#define LAUNCH_WIN2(NCV, XSV) do { if (csr16(A)) LAUNCH_WIN(NCV, XSV, true); else LAUNCH_WIN(NCV, XSV, false); } while (0)
+         if (ncols <= 2) { if (small) LAUNCH_WIN2(2, 1536); else LAUNCH_WIN2(2, XS_MAX); }
+         else { if (small) LAUNCH_WIN2(4, 1536); else LAUNCH_WIN2(4, XS_MAX); }
+#undef LAUNCH_WIN2
+#undef LAUNCH_WIN
+      } else if (ncols == 1 && force == 0) {
+#define LAUNCH_STREAM(C16V) hipLaunchKernelGGL((csr_stream_kernel<T, false, C16V>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, \
+               A->tileinfo, A->ntiles, A->rowptr, A->colind, csr16(A), A->row0 - A->c16back, (const T *)A->values, x, ldx, y, ldy, \
+               ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo, \
+               (const T *)A->xhi, A->ld_lo, A->ld_hi, (const double *)NULL, (T *)NULL, (double *)NULL, hipk_fin_args())
+         if (csr16(A)) LAUNCH_STREAM(true); else LAUNCH_STREAM(false);
+#undef LAUNCH_STREAM
+      }
       else if (force == 1) LAUNCH_ROWS(1);
       else if (force == 2 || (force == 0 && ncols <= 2)) LAUNCH_ROWS(2);
       else LAUNCH_ROWS(4);
@@ -753,14 +835,12 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    const double es = A->dt == HIPK_F64 ? 8 : 4;
    const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV);
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
-   if (A->dt == HIPK_F64)
-      hipLaunchKernelGGL((csr_stream_kernel<double, true>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr,
-            A->colind, (const double *)A->values, (const double *)x, A->nrows, (double *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo,
-            A->halo_hi, (const double *)A->xlo, (const double *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (double *)xout, ctx->partials, fa);
-   else
-      hipLaunchKernelGGL((csr_stream_kernel<float, true>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr,
-            A->colind, (const float *)A->values, (const float *)x, A->nrows, (float *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo,
-            A->halo_hi, (const float *)A->xlo, (const float *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (float *)xout, ctx->partials, fa);
+#define LAUNCH_FUSED(TT, C16V) hipLaunchKernelGGL((csr_stream_kernel<TT, true, C16V>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr, \
+            A->colind, csr16(A), A->row0 - A->c16back, (const TT *)A->values, (const TT *)x, A->nrows, (TT *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo, \
+            A->halo_hi, (const TT *)A->xlo, (const TT *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (TT *)xout, ctx->partials, fa)
+   if (A->dt == HIPK_F64) { if (csr16(A)) LAUNCH_FUSED(double, true); else LAUNCH_FUSED(double, false); }
+   else { if (csr16(A)) LAUNCH_FUSED(float, true); else LAUNCH_FUSED(float, false); }
+#undef LAUNCH_FUSED
    hipk_prof_end(pslot, st);
    HIPK_CHECK(hipGetLastError());
    if (fa.enabled) return 0;
