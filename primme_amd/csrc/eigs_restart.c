@@ -850,6 +850,9 @@ int pa_restart_plan(pa_solver *s, int basisSize, const int *flags_in, const int 
    PRIMME_INT seed[4];
    memcpy(seed, p->iseed, sizeof(seed));
    const int cvk = s->coef_valid_k, nav = s->numArbitraryVecs;
+   /* state the dry run must not touch (advisor, round 2): checked afterwards, a plan that moved any of it is dropped */
+   const int g_tsi = s->targetShiftIndex, g_npr = s->numPrevRitzVals, g_init = p->initSize;
+   const double g_e0 = evals ? evals[0] : 0.0, g_r0 = resNorms ? resNorms[0] : 0.0;
 
    int numConverged = numLocked;
    for (int i = 0; i < basisSize; i++)
@@ -871,6 +874,14 @@ int pa_restart_plan(pa_solver *s, int basisSize, const int *flags_in, const int 
    memcpy(p->iseed, seed, sizeof(seed));
    s->coef_valid_k = cvk; s->numArbitraryVecs = nav;
    free(sv); free(fl);
+   if (s->targetShiftIndex != g_tsi || s->numPrevRitzVals != g_npr || p->initSize != g_init ||
+         (evals && evals[0] != g_e0) || (resNorms && resNorms[0] != g_r0)) {
+      s->targetShiftIndex = g_tsi; s->numPrevRitzVals = g_npr; p->initSize = g_init;
+      if (evals) evals[0] = g_e0;
+      if (resNorms) resNorms[0] = g_r0;
+      if (getenv("PRIMME_AMD_TRACE_ERRORS")) fprintf(stderr, "primme_amd: restart dry run touched solver state outside its saved set; plan dropped\n");
+      return 1;
+   }
    return rc == PA_PLANNED ? 0 : 1;
 }
 #endif
