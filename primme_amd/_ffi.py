@@ -152,7 +152,8 @@ class HipkJob(C.Structure):
     _fields_ = [("kind", C.c_int), ("col", C.c_int), ("dst", C.c_void_p), ("slot", C.c_int)]
 
 
-PRODUCT_LIB = os.path.join(_HERE, "libprimme_amd.so")
+# PRIMME_AMD_LIB: another build of the product library (measurement only: the build-time variants of scripts/build_variant.sh)
+PRODUCT_LIB = os.environ.get("PRIMME_AMD_LIB") or os.path.join(_HERE, "libprimme_amd.so")
 
 _vp, _i, _i64, _dp = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double)
 

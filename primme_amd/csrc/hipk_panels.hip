@@ -40,6 +40,39 @@ template <> struct __attribute__((aligned(16))) lanevec<double, 2> { double e[2]
 template <> struct __attribute__((aligned(16))) lanevec<float, 4> { float e[4]; };
 template <> struct __attribute__((aligned(8))) lanevec<float, 2> { float e[2]; };
 template <typename T> struct vecwidth { enum { value = 16 / sizeof(T) }; };
+/* Streamed panels are loaded (and the restart pass' outputs stored) with the NON-TEMPORAL hint: V and W are read once per
+ * kernel and are far larger than the 256 MiB Infinity Cache, so letting them allocate there only evicts what does get
+ * re-read every iteration — the CSR matrix and the vectors of the SpMV (215 MB at n = 2 M).  Measured on one box, back to
+ * back (profiles/r03_nontemporal_ab.log): configs[1] 13.72 -> 14.82 eigenpairs/s (SpMV 146 -> 124 ms per solve: it now
+ * hits the cache; fused residual / restart class 4.96 -> 5.44 TB/s), north-star workload 2.466 -> 2.321 s per 3000
+ * iterations.  HIPK_NT_LOADS is a build-time mask for A/B builds (scripts/build_variant.sh): 1 = W in the fused
+ * residual kernel, 2 = V, Q there and the panels of the Gram-Schmidt update, 4 = loads of the restart kernels,
+ * 8 = stores of the restart pass, 16 = panels of the TN kernel (no gain: left off).  Default 15. */
+#ifndef HIPK_NT_LOADS
+#define HIPK_NT_LOADS 15
+#endif
+template <typename T, int NTBIT>
+__device__ __forceinline__ T ldstream1(const T *p) {
+   if ((HIPK_NT_LOADS & NTBIT) != 0) return __builtin_nontemporal_load(p);
+   return *p;
+}
+template <typename T, int NTBIT>
+__device__ __forceinline__ void ststream1(T *p, T v) {
+   if ((HIPK_NT_LOADS & NTBIT) != 0) __builtin_nontemporal_store(v, p);
+   else *p = v;
+}
+template <typename T, int VW, int NTBIT>
+__device__ __forceinline__ lanevec<T, VW> ldstream(const T *col, int64_t idx) {
+   if ((HIPK_NT_LOADS & NTBIT) != 0) {
+      typedef T nvec __attribute__((ext_vector_type(VW)));
+      const nvec t = __builtin_nontemporal_load((const nvec *)col + idx);
+      lanevec<T, VW> r;
+#pragma unroll
+      for (int i = 0; i < VW; i++) r.e[i] = t[i];
+      return r;
+   }
+   return ((const lanevec<T, VW> *)col)[idx];
+}
 
 static inline bool aligned16(const void *p, int64_t ld, size_t es) {
    return (((uintptr_t)p) & 15) == 0 && ((ld * (int64_t)es) & 15) == 0;
@@ -107,7 +140,7 @@ dots_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int64_t 
          if (c < nxv) xv[c] = ((const LV *)(xp + (size_t)c * ldX))[g];
 #pragma unroll
       for (int jj = 0; jj < NC; jj++)
-         if (jj < ncv) a[jj] = ((const LV *)cp[jj])[g];
+         if (jj < ncv) a[jj] = ldstream<T, VW, 16>(cp[jj], g);
 #pragma unroll
       for (int jj = 0; jj < NC; jj++)
          if (jj < ncv) {
@@ -183,7 +216,7 @@ dots_wide_kernel(SegArgs segs, const T *__restrict__ X, int64_t ldX, int nx, int
             if (c < nxv) xv[c] = ((const LV *)(xp + (size_t)c * ldX))[g];
 #pragma unroll
          for (int jj = 0; jj < NC; jj++)
-            if (jj < ncv) a[jj] = ((const LV *)cp[jj])[g];
+            if (jj < ncv) a[jj] = ldstream<T, VW, 16>(cp[jj], g);
 #pragma unroll
          for (int jj = 0; jj < NC; jj++)
             if (jj < ncv) {
@@ -457,7 +490,7 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *X,
       for (; j + 8 <= total; j += 8) {
          LV a[8];
 #pragma unroll
-         for (int u = 0; u < 8; u++) a[u] = ((const LV *)sptr[j + u])[g];
+         for (int u = 0; u < 8; u++) a[u] = ldstream<T, VW, 2>(sptr[j + u], g);
 #pragma unroll
          for (int u = 0; u < 8; u++)
 #pragma unroll
@@ -750,10 +783,10 @@ ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
       double roww[PRE ? NK : 1];
       double xres[NR];
 #pragma unroll
-      for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)V[i + (size_t)j * ld] : 0.0;
+      for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)ldstream1<T, 4>(V + i + (size_t)j * ld) : 0.0;
       if (PRE && needW) {
 #pragma unroll
-         for (int j = 0; j < NK; j++) roww[PRE ? j : 0] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+         for (int j = 0; j < NK; j++) roww[PRE ? j : 0] = (j < k) ? (double)ldstream1<T, 4>(W + i + (size_t)j * ld) : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < NR; r++) {
@@ -776,7 +809,7 @@ ritz_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
       if (needW) {
          if (!PRE) {
 #pragma unroll
-            for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+            for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)ldstream1<T, 4>(W + i + (size_t)j * ld) : 0.0;
          }
          for (int o = 0; o < ja.nxw; o++) {
             const double *hc = hs + (int)ja.xw_col[o] * NK;
@@ -1032,9 +1065,9 @@ ritz_ov_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int
    for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
       double row[NK], roww[NK], qv[QN];
 #pragma unroll
-      for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)V[i + (size_t)j * ld] : 0.0;
+      for (int j = 0; j < NK; j++) row[j] = (j < k) ? (double)ldstream1<T, 4>(V + i + (size_t)j * ld) : 0.0;
 #pragma unroll
-      for (int j = 0; j < NK; j++) roww[j] = (j < k) ? (double)W[i + (size_t)j * ld] : 0.0;
+      for (int j = 0; j < NK; j++) roww[j] = (j < k) ? (double)ldstream1<T, 4>(W + i + (size_t)j * ld) : 0.0;
       double wl = 0.0;
       if (QM > 0) {
 #pragma unroll
@@ -1061,8 +1094,8 @@ ritz_ov_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int
 #pragma unroll
             for (int j = 0; j < NK; j++) sw = fma(roww[j], hw[j], sw);
             const T tv = (T)sv, tw = (T)sw;
-            ((T *)ja.xv_dst[o])[i] = tv;
-            ((T *)ja.xw_dst[o])[i] = tw;
+            ststream1<T, 8>((T *)ja.xv_dst[o] + i, tv);
+            ststream1<T, 8>((T *)ja.xw_dst[o] + i, tw);
             ov[o] = fma((double)tv, r, ov[o]);
             ow[o] = fma((double)tw, r, ow[o]);
          }
@@ -1071,14 +1104,14 @@ ritz_ov_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int
          double sv = 0.0;
 #pragma unroll
          for (int j = 0; j < NK; j++) sv = fma(row[j], hc[j], sv);
-         ((T *)ja.xv_dst[o])[i] = (T)sv;
+         ststream1<T, 8>((T *)ja.xv_dst[o] + i, (T)sv);
       }
       for (int o = nb; o < ja.nxw; o++) {
          const double *hc = hs + (int)ja.xw_col[o] * NK;
          double sw = 0.0;
 #pragma unroll
          for (int j = 0; j < NK; j++) sw = fma(roww[j], hc[j], sw);
-         ((T *)ja.xw_dst[o])[i] = (T)sw;
+         ststream1<T, 8>((T *)ja.xw_dst[o] + i, (T)sw);
       }
       if (rdst) rdst[i] = res;
       if (QM > 0) {
@@ -1246,12 +1279,12 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
       LV v[CPW], w[CPW], q[QN], wl;
 #pragma unroll
       for (int jj = 0; jj < CPW; jj++)
-         if (j0 + jj < k) { v[jj] = ((const LV *)vp[jj])[e]; w[jj] = ((const LV *)wp[jj])[e]; }
+         if (j0 + jj < k) { v[jj] = ldstream<T, VW, 2>(vp[jj], e); w[jj] = ldstream<T, VW, 1>(wp[jj], e); }
       if (QPW > 0) {
 #pragma unroll
          for (int qq = 0; qq < QN; qq++)
-            if (q0 + qq < L) q[qq] = ((const LV *)qp[qq])[e];
-         if (WT && q0 < L) wl = ((const LV *)wlast)[e];
+            if (q0 + qq < L) q[qq] = ldstream<T, VW, 2>(qp[qq], e);
+         if (WT && q0 < L) wl = ldstream<T, VW, 1>(wlast, e);
       }
       double px[VW], py[VW];
 #pragma unroll

@@ -79,7 +79,9 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
  * x), and the tile's part of xout' y goes to partials[blockIdx.x].  Replaces the separate
  * normalisation pass and the two-vector inner product t'At of the one-synchronisation GD
  * iteration (eigs_conv.c); same arithmetic per element as scale_rsqrt_kernel + this kernel. */
-template <typename T, bool FUSED, bool C16>
+/* NTM: the (value, index) stream with the non-temporal hint — for matrices too large to stay in the 256 MiB Infinity
+ * Cache between two products (the launcher decides by the size of the stream); smaller ones are left to be cached. */
+template <typename T, bool FUSED, bool C16, bool NTM>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *__restrict__ rowptr,
       const int32_t *__restrict__ colind, const uint16_t *__restrict__ col16, int64_t c16off,
@@ -109,11 +111,11 @@ csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *
          for (int u = 0; u < TILE_PER_LANE; u++) {
             const int q = threadIdx.x + u * HIPK_BLOCK;
             const int qc = q < nz ? q : (nz > 0 ? nz - 1 : 0);   /* an all-empty tile reads the padded element */
-            v[u] = (double)val[p0 + qc];
+            v[u] = (double)(NTM ? __builtin_nontemporal_load(val + p0 + qc) : val[p0 + qc]);
             /* C16 (a template parameter: exactly one index stream is loaded): global column = row0 + r0 - c16back + entry;
              * an empty tile reads a neighbour's entry against its own base, so its (unused) gather goes to a valid row */
-            if (C16) cidx[u] = (int32_t)col16[p0 + qc];          /* raw: any arithmetic here would make the batch wait load by load */
-            else cidx[u] = colind[p0 + qc];
+            if (C16) cidx[u] = (int32_t)(NTM ? __builtin_nontemporal_load(col16 + p0 + qc) : col16[p0 + qc]);   /* raw: any arithmetic here would make the batch wait load by load */
+            else cidx[u] = NTM ? __builtin_nontemporal_load(colind + p0 + qc) : colind[p0 + qc];
          }
          if (C16) {
             const int32_t cbase = (int32_t)(c16off + r0);
@@ -707,6 +709,16 @@ static const uint16_t *csr16(const hipk_csr *A) {
    return no16 ? (const uint16_t *)NULL : A->col16;
 }
 
+/* stream the matrix past the Infinity Cache?  Yes when its (value, index) stream alone is more than about three quarters
+ * of the 256 MiB (it cannot stay until the next product anyway); HIPK_SPMV_NT=0 / 1 forces it (A/B knob) */
+static bool csr_stream_nt(const hipk_csr *A) {
+   static int force = -2;
+   if (force == -2) { const char *e = getenv("HIPK_SPMV_NT"); force = e ? atoi(e) : -1; }
+   if (force >= 0) return force != 0;
+   const double es = (A->dt == HIPK_F64) ? 8 : 4;
+   return (double)A->nnz * (es + (A->col16 ? 2 : 4)) > 192.0 * 1024 * 1024;
+}
+
 template <typename T>
 static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx, T *y, int64_t ldy, int ncols,
       const double *shift_host = NULL) {
@@ -754,11 +766,12 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
 #undef LAUNCH_WIN2
 #undef LAUNCH_WIN
       } else if (ncols == 1 && force == 0) {
-#define LAUNCH_STREAM(C16V) hipLaunchKernelGGL((csr_stream_kernel<T, false, C16V>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, \
+#define LAUNCH_STREAM(C16V, NTV) hipLaunchKernelGGL((csr_stream_kernel<T, false, C16V, NTV>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, \
                A->tileinfo, A->ntiles, A->rowptr, A->colind, csr16(A), A->row0 - A->c16back, (const T *)A->values, x, ldx, y, ldy, \
                ncols, A->x0, A->xlen, A->halo_lo, A->halo_hi, (const T *)A->xlo, \
                (const T *)A->xhi, A->ld_lo, A->ld_hi, (const double *)NULL, (T *)NULL, (double *)NULL, hipk_fin_args())
-         if (csr16(A)) LAUNCH_STREAM(true); else LAUNCH_STREAM(false);
+         if (csr_stream_nt(A)) { if (csr16(A)) LAUNCH_STREAM(true, true); else LAUNCH_STREAM(false, true); }
+         else { if (csr16(A)) LAUNCH_STREAM(true, false); else LAUNCH_STREAM(false, false); }
 #undef LAUNCH_STREAM
       }
       else if (force == 1) LAUNCH_ROWS(1);
@@ -835,11 +848,16 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    const double es = A->dt == HIPK_F64 ? 8 : 4;
    const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV);
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
-#define LAUNCH_FUSED(TT, C16V) hipLaunchKernelGGL((csr_stream_kernel<TT, true, C16V>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr, \
+#define LAUNCH_FUSED(TT, C16V, NTV) hipLaunchKernelGGL((csr_stream_kernel<TT, true, C16V, NTV>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr, \
             A->colind, csr16(A), A->row0 - A->c16back, (const TT *)A->values, (const TT *)x, A->nrows, (TT *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo, \
             A->halo_hi, (const TT *)A->xlo, (const TT *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (TT *)xout, ctx->partials, fa)
-   if (A->dt == HIPK_F64) { if (csr16(A)) LAUNCH_FUSED(double, true); else LAUNCH_FUSED(double, false); }
-   else { if (csr16(A)) LAUNCH_FUSED(float, true); else LAUNCH_FUSED(float, false); }
+   if (csr_stream_nt(A)) {
+      if (A->dt == HIPK_F64) { if (csr16(A)) LAUNCH_FUSED(double, true, true); else LAUNCH_FUSED(double, false, true); }
+      else { if (csr16(A)) LAUNCH_FUSED(float, true, true); else LAUNCH_FUSED(float, false, true); }
+   } else {
+      if (A->dt == HIPK_F64) { if (csr16(A)) LAUNCH_FUSED(double, true, false); else LAUNCH_FUSED(double, false, false); }
+      else { if (csr16(A)) LAUNCH_FUSED(float, true, false); else LAUNCH_FUSED(float, false, false); }
+   }
 #undef LAUNCH_FUSED
    hipk_prof_end(pslot, st);
    HIPK_CHECK(hipGetLastError());
