@@ -21,6 +21,19 @@
 template <typename R> struct __attribute__((aligned(2 * sizeof(R)))) cpx { R re, im; };
 struct zacc { double re, im; };
 template <typename R> __device__ __forceinline__ zacc zload(const cpx<R> *p) { const cpx<R> v = *p; return {(double)v.re, (double)v.im}; }
+/* a streamed panel element: with the non-temporal hint (as in hipk_panels.hip: the panels never stay in the Infinity
+ * Cache, the hint keeps them from evicting what does).  HIPK_Z_NT=0 at build time = plain loads (A/B builds). */
+#ifndef HIPK_Z_NT
+#define HIPK_Z_NT 1
+#endif
+template <typename R> __device__ __forceinline__ zacc zload_s(const cpx<R> *p) {
+   if (HIPK_Z_NT) {
+      typedef R nvec __attribute__((ext_vector_type(2)));
+      const nvec t = __builtin_nontemporal_load((const nvec *)p);
+      return {(double)t[0], (double)t[1]};
+   }
+   return zload(p);
+}
 template <typename R> __device__ __forceinline__ void zstore(cpx<R> *p, zacc v) { cpx<R> o; o.re = (R)v.re; o.im = (R)v.im; *p = o; }
 /* a += conj(x) * y */
 __device__ __forceinline__ void zfma_conj(zacc &a, const zacc &x, const zacc &y) {
@@ -106,7 +119,7 @@ zdots_kernel(ZSegs sa, const cpx<R> *__restrict__ X, int64_t ldX, int nx, int c0
          for (int c = 0; c < NX; c++) xv[c] = zload(X + (size_t)(c0 + (c < nxv ? c : 0)) * ldX + i);
          zacc av[CPW];
 #pragma unroll
-         for (int t = 0; t < CPW; t++) av[t] = zload(col[t] + i);
+         for (int t = 0; t < CPW; t++) av[t] = zload_s(col[t] + i);
 #pragma unroll
          for (int t = 0; t < CPW; t++)
 #pragma unroll
@@ -190,7 +203,7 @@ zproject_kernel(ZSegs sa, const zacc *__restrict__ coef, int ldcoef, const zacc 
 #pragma unroll
       for (int c = 0; c < NX; c++) xv[c] = (c < nxv) ? zload(X + (size_t)(c0 + c) * ldX + i) : zacc{0.0, 0.0};
       for (int j = 0; j < tot; j++) {
-         const zacc a = zload(sptr[j] + i);
+         const zacc a = zload_s(sptr[j] + i);
 #pragma unroll
          for (int c = 0; c < NX; c++) zfms(xv[c], a, scoef[j * NX + c]);
       }
@@ -298,8 +311,8 @@ zritz_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *__
          }
 #pragma unroll 2
          for (int jj = 0; jj < jn; jj++) {
-            const zacc v = zload(V + (size_t)(j0 + jj) * ld + ic);
-            const zacc w = W ? zload(W + (size_t)(j0 + jj) * ld + ic) : zacc{0.0, 0.0};
+            const zacc v = zload_s(V + (size_t)(j0 + jj) * ld + ic);
+            const zacc w = W ? zload_s(W + (size_t)(j0 + jj) * ld + ic) : zacc{0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < NP; q++) zfma(acc[q], jb.isw[q] ? w : v, sh[jj * NJ + q]);
 #pragma unroll
@@ -388,8 +401,8 @@ zritz2_kernel(const cpx<R> *V, const cpx<R> *W, int64_t ld, int k, const zacc *_
          }
 #pragma unroll 1
          for (int jj = 0; jj < jn; jj++) {
-            const zacc v = zload(V + (size_t)(j0 + jj) * ld + ic);
-            const zacc w = W ? zload(W + (size_t)(j0 + jj) * ld + ic) : zacc{0.0, 0.0};
+            const zacc v = zload_s(V + (size_t)(j0 + jj) * ld + ic);
+            const zacc w = W ? zload_s(W + (size_t)(j0 + jj) * ld + ic) : zacc{0.0, 0.0};
             const zacc *hrow = sh + (size_t)(jj * L + part) * NJS;
 #pragma unroll
             for (int q = 0; q < NVH; q++) zfma(acc[q], v, hrow[q]);
