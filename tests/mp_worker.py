@@ -132,18 +132,51 @@ def run(rank, world, port, case, out_path):
         r = s.solve(numEvals=5, eps=1e-10, aNorm=8.0, v0=v0, numProcs=world, procID=rank, global_sum=global_sum,
                     user_matvec=cb)
         s.close()
-    elif case == "hermitian":
+    elif case == "zdevcomm":
+        # BASELINE configs[3] in small on the path the GPUs take: complex panels, the library's own complex CSR operator and
+        # communicator (all-reduce of the (re, im) partial sums inside the stream of launches), block size 4
+        nloc = 150
+        n = nloc * world
+        rp, ci, va = problems.hermitian_banded_csr(nloc)
+        va = va * (1.0 + 0.21 * rank)
+        lib = checkers.load_hostcheck()
+        AR = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int)
+
+        def allreduce(buf, count):
+            a = np.ctypeslib.as_array(buf, shape=(count,))
+            t = torch.from_numpy(a.copy())
+            dist.all_reduce(t)
+            a[:] = t.numpy()
+        arcb = AR(allreduce)
+        comm = C.c_void_p()
+        lib.primme_amd_hostcheck_comm_create.argtypes = [C.POINTER(C.c_void_p), AR, C.c_int, C.c_int]
+        assert lib.primme_amd_hostcheck_comm_create(C.byref(comm), arcb, rank, world) == 0
+        op = Operator(n, csr=(rp, (ci + rank * nloc).astype(np.int32), va), row0=rank * nloc, nrows=nloc)
+        s = Session(op, comm=comm, backend="hostcheck", dtype=np.complex128)
+        r = s.solve(numEvals=6, target="largest", eps=1e-9, maxBlockSize=4, maxBasisSize=20, minRestartSize=8, numProcs=world, procID=rank,
+                    iseed=(2, 3, 5, 7))
+        lib.primme_amd_hostcheck_comm_calls.restype = C.c_long
+        lib.primme_amd_hostcheck_comm_calls.argtypes = [C.c_void_p]
+        zextra = dict(allreduces=int(lib.primme_amd_hostcheck_comm_calls(comm)))
+        s.close()
+        r.evecs = np.concatenate([r.evecs.real, r.evecs.imag])
+    elif case.startswith("hermitian"):
         # complex Hermitian band matrix (BASELINE configs[3] in small) cut into independent diagonal
-        # blocks, one per rank: hip_zprimme's real-equivalent solve and its final complex
-        # Gram-Schmidt sweep both reduce through the user's globalSumReal
+        # blocks, one per rank: hip_zprimme's native complex solve (complex panels: every inner product is a
+        # (re, im) pair in the reduction buffers) reduces through the user's globalSumReal.  Variants: the block
+        # iteration of configs[3], JDQMR, harmonic and refined extraction for an interior target
         nloc = 150
         n = nloc * world
         rp, ci, va = problems.hermitian_banded_csr(nloc)
         va = va * (1.0 + 0.21 * rank)
         op = Operator(n, csr=(rp, (ci + rank * nloc).astype(np.int32), va), row0=rank * nloc, nrows=nloc)
         s = Session(op, backend="hostcheck", dtype=np.complex128)
-        r = s.solve(numEvals=4, target="largest", eps=1e-10, numProcs=world, procID=rank, global_sum=global_sum,
-                    iseed=(5 + rank, 1, 2, 3))
+        extra = {"hermitian": {}, "hermitian_blk4": dict(maxBlockSize=4, maxBasisSize=20, minRestartSize=8),
+                 "hermitian_jdqmr": dict(method="JDQMR"),
+                 "hermitian_harmonic": dict(target="closest_abs", targetShifts=[2.5], projection="harmonic", eps=1e-8),
+                 "hermitian_refined": dict(target="closest_abs", targetShifts=[2.5], projection="refined", eps=1e-8)}[case]
+        kw = dict(dict(numEvals=4, target="largest", eps=1e-10), **extra)
+        r = s.solve(numProcs=world, procID=rank, global_sum=global_sum, iseed=(5 + rank, 1, 2, 3), **kw)
         s.close()
         r.evecs = np.concatenate([r.evecs.real, r.evecs.imag])
     elif case == "svds":
@@ -210,6 +243,8 @@ def run(rank, world, port, case, out_path):
                matvecs=r.stats["numMatvecs"])
     if case.startswith("devcomm"):
         res.update(extra)
+    if case == "zdevcomm":
+        res.update(zextra)
     json.dump(res, open(f"{out_path}.{rank}", "w"))
     dist.barrier()
     dist.destroy_process_group()
