@@ -19,12 +19,29 @@ extern "C" {
 
 typedef struct primme_amd_comm primme_amd_comm;
 
-/* rank 0 creates the 128-byte id; the launcher distributes it to all ranks */
+/* rank 0 creates the 128-byte id; the launcher distributes it to all ranks.
+ * Transports (environment variable PRIMME_AMD_COMM, read by the rank that creates the id):
+ *   rccl : every collective on RCCL (the id is an ncclUniqueId; the only form that spans nodes);
+ *   ipc  : every collective on the peer-to-peer mailboxes of csrc/comm_ipc.hip — device memory exported with
+ *          hipIpcGetMemHandle and written by the peers directly (xGMI, or the same device when ranks share one);
+ *          the id names a POSIX shared-memory segment (one node); at most 16 ranks;
+ *   auto (default) : the <= 32 KB reductions (reference call sites src/eigs/ortho.c:249, :290,
+ *          update_projection.c:136) and the neighbour halos on the mailboxes — one launch per reduction, the
+ *          local second stage included — and the bulk all-gather / reduce-scatter on RCCL; "ipc" when ranks
+ *          share a device.
+ * Sums are formed in rank order on every rank: all ranks hold identical bits. */
 int primme_amd_comm_unique_id(void *id128);
 int primme_amd_comm_create(primme_amd_comm **comm, const void *id128, int rank, int nranks);
 int primme_amd_comm_destroy(primme_amd_comm *comm);
 int primme_amd_comm_rank(const primme_amd_comm *comm);
 int primme_amd_comm_size(const primme_amd_comm *comm);
+const char *primme_amd_comm_transport(const primme_amd_comm *comm);     /* "rccl", "ipc" or "hybrid" */
+/* non-zero after a device-side wait of the peer-to-peer transport ran into its time limit
+ * (PRIMME_AMD_IPC_DEVICE_TIMEOUT_S, default 60): a rank died or left the collective call sequence */
+int primme_amd_comm_error(const primme_amd_comm *comm);
+/* dbuf[0:count) <- sum over the ranks (doubles, in place, stream-ordered): what primme_amd_global_sum does for
+ * host buffers and what the solver does with its device-resident partial sums */
+int primme_amd_comm_allreduce(primme_amd_comm *comm, void *hip_stream, double *dbuf, int count);
 int primme_amd_comm_halo(primme_amd_comm *c, void *hip_stream, const void *x, int64_t ldx,
       int64_t nrows, int ncols, size_t elem, int64_t send_lo_cnt, int64_t send_hi_cnt, void *lo,
       int64_t recv_lo_cnt, void *hi, int64_t recv_hi_cnt);

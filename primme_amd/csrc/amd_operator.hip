@@ -6,6 +6,7 @@
 #include "hipk_internal.h"
 #include "primme_amd.h"
 #include "primme_amd_comm.h"
+#include "comm_internal.h"
 
 struct primme_amd_operator {
    hipk_csr *A;
@@ -13,6 +14,7 @@ struct primme_amd_operator {
    int mode;                 /* 0 local, 1 neighbour halo, 2 all-gather */
    int64_t lo, hi;           /* rows needed from below / above */
    int64_t send_lo, send_hi; /* rows the neighbours need from me */
+   int64_t max_side;         /* the largest halo of any rank (sizes the peer-to-peer landing zones) */
    void *buf_lo, *buf_hi;    /* device halo buffers (grown on demand) */
    size_t cap_lo, cap_hi;
    void *xfull;              /* all-gather buffer */
@@ -45,6 +47,8 @@ extern "C" int primme_amd_operator_create(primme_amd_operator **out, hipk_csr *A
       int neighbour_ok = 1, any = 0, equal = 1;
       for (int q = 0; q < P; q++) {
          if (all[3 * q] > 0 || all[3 * q + 1] > 0) any = 1;
+         if (all[3 * q] > op->max_side) op->max_side = all[3 * q];
+         if (all[3 * q + 1] > op->max_side) op->max_side = all[3 * q + 1];
          if (q > 0 && all[3 * q] > all[3 * (q - 1) + 2]) neighbour_ok = 0;     /* needs more than rank q-1 owns */
          if (q < P - 1 && all[3 * q + 1] > all[3 * (q + 1) + 2]) neighbour_ok = 0;
          if (all[3 * q + 2] != all[2]) equal = 0;
@@ -96,10 +100,11 @@ extern "C" int primme_amd_operator_apply(primme_amd_operator *op, void *hip_stre
    if (op->mode == 1) {
       if (grow(&op->buf_lo, &op->cap_lo, (size_t)(op->lo > 0 ? op->lo : 1) * ncols * es)) return -2;
       if (grow(&op->buf_hi, &op->cap_hi, (size_t)(op->hi > 0 ? op->hi : 1) * ncols * es)) return -2;
-      int rc = primme_amd_comm_halo(op->comm, hip_stream, x, ldx, op->nrows, ncols, es, op->send_lo,
-            op->send_hi, op->buf_lo, op->lo, op->buf_hi, op->hi);
+      void *zl = NULL, *zh = NULL;
+      int rc = pa_comm_halo_auto(op->comm, hip_stream, x, ldx, op->nrows, ncols, es, op->send_lo,
+            op->send_hi, op->buf_lo, op->lo, op->buf_hi, op->hi, op->max_side, &zl, &zh);
       if (rc) return rc;
-      hipk_csr_set_halo(op->A, op->buf_lo, op->buf_hi);
+      hipk_csr_set_halo(op->A, zl, zh);
       return hipk_csr_matvec(op->A, hip_stream, x, ldx, y, ldy, ncols);
    } else if (op->mode == 2) {
       /* unstructured columns: gather the whole block [n x ncols] in ONE grouped exchange (a column per
@@ -134,10 +139,11 @@ extern "C" int primme_amd_operator_apply_scaled(primme_amd_operator *op, hipk_ct
    if (op->mode == 1) {
       if (grow(&op->buf_lo, &op->cap_lo, (size_t)(op->lo > 0 ? op->lo : 1) * es)) return -2;
       if (grow(&op->buf_hi, &op->cap_hi, (size_t)(op->hi > 0 ? op->hi : 1) * es)) return -2;
-      int rc = primme_amd_comm_halo(op->comm, hip_stream, x, op->nrows, op->nrows, 1, es, op->send_lo,
-            op->send_hi, op->buf_lo, op->lo, op->buf_hi, op->hi);
+      void *zl = NULL, *zh = NULL;
+      int rc = pa_comm_halo_auto(op->comm, hip_stream, x, op->nrows, op->nrows, 1, es, op->send_lo,
+            op->send_hi, op->buf_lo, op->lo, op->buf_hi, op->hi, op->max_side, &zl, &zh);
       if (rc) return rc;
-      hipk_csr_set_halo(op->A, op->buf_lo, op->buf_hi);
+      hipk_csr_set_halo(op->A, zl, zh);
    } else if (op->mode == 2) {
       if (grow(&op->xfull, &op->cap_full, (size_t)op->n * es)) return -2;
       int rc = primme_amd_comm_allgather(op->comm, hip_stream, x, op->xfull, (size_t)op->nrows * es);

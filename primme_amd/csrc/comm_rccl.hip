@@ -16,19 +16,8 @@
  * All broadcasts of the reference disappear: every rank solves the identical
  * small projected problem deterministically.
  */
-#include "hipk_internal.h"
+#include "comm_internal.h"
 #include "primme_amd.h"
-#include "primme_amd_comm.h"
-#include <rccl/rccl.h>
-
-struct primme_amd_comm {
-   ncclComm_t comm;
-   int rank, nranks;
-   hipStream_t stream;     /* for the host-buffer callback path */
-   double *dbuf;           /* staging for the host-buffer path */
-   double *hbuf;           /* its pinned host twin: the caller's (pageable) buffers never meet an asynchronous copy */
-   size_t dbuf_cap;
-};
 
 #define NCCL_CHECK(call)                                                              \
    do {                                                                               \
@@ -39,25 +28,67 @@ struct primme_amd_comm {
       }                                                                               \
    } while (0)
 
+/* PRIMME_AMD_COMM selects the transport when the id is created (rank 0) — the id tells the other ranks:
+ *   rccl          : everything on RCCL (an ncclUniqueId; the only form that spans nodes)
+ *   ipc           : everything on the peer-to-peer mailboxes (comm_ipc.hip); ranks may share one device
+ *   unset / auto  : mailboxes for the <= 32 KB reductions and the neighbour halos, RCCL for the bulk all-gather /
+ *                   reduce-scatter (ranks on distinct devices); everything on the mailboxes when ranks share a
+ *                   device; RCCL alone when the mailboxes cannot be brought up */
+static int comm_mode(void) {
+   const char *e = getenv("PRIMME_AMD_COMM");
+   if (!e || !*e || !strcmp(e, "auto") || !strcmp(e, "hybrid")) return PA_COMM_HYBRID;
+   if (!strcmp(e, "ipc")) return PA_COMM_IPC;
+   if (!strcmp(e, "rccl")) return PA_COMM_RCCL;
+   fprintf(stderr, "primme_amd: PRIMME_AMD_COMM=%s is not one of rccl | ipc | auto; using auto\n", e);
+   return PA_COMM_HYBRID;
+}
+
 extern "C" int primme_amd_comm_unique_id(void *id128) {
+   if (comm_mode() != PA_COMM_RCCL) return pa_ipc_unique_id(id128);
    ncclUniqueId id;
    NCCL_CHECK(ncclGetUniqueId(&id));
    memcpy(id128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
    return 0;
 }
 
-extern "C" int primme_amd_comm_create(primme_amd_comm **out, const void *id128, int rank, int nranks) {
-   primme_amd_comm *c = (primme_amd_comm *)calloc(1, sizeof(primme_amd_comm));
-   if (!c) return -2;
-   ncclUniqueId id;
-   memset(&id, 0, sizeof(id));
-   memcpy(&id, id128, sizeof(id) < 128 ? sizeof(id) : 128);
-   c->rank = rank; c->nranks = nranks;
-   NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
+static int comm_staging(primme_amd_comm *c) {
    HIPK_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
    c->dbuf_cap = 8192;
    HIPK_CHECK(hipMalloc((void **)&c->dbuf, c->dbuf_cap * sizeof(double)));
-   HIPK_CHECK(hipHostMalloc((void **)&c->hbuf, c->dbuf_cap * sizeof(double), hipHostMallocDefault));
+   HIPK_CHECK(hipHostMalloc((void **)&c->hbuf, c->dbuf_cap * sizeof(double), hipHostMallocMapped));
+   return 0;
+}
+
+extern "C" int primme_amd_comm_create(primme_amd_comm **out, const void *id128, int rank, int nranks) {
+   primme_amd_comm *c = (primme_amd_comm *)calloc(1, sizeof(primme_amd_comm));
+   if (!c) return -2;
+   c->rank = rank; c->nranks = nranks;
+   ncclUniqueId id;
+   memset(&id, 0, sizeof(id));
+   if (pa_ipc_is_ipc_id(id128)) {
+      /* the mode of the rank that made the id decides (a stray PRIMME_AMD_COMM on one rank must not split the job) */
+      int mode = comm_mode(), modes[HIPK_XR_MAXRANKS];
+      if (pa_ipc_attach(&c->ipc, id128, rank, nranks)) { free(c); return -43; }
+      if (pa_ipc_host_allgather(c->ipc, &mode, sizeof(int), modes)) { pa_ipc_detach(c->ipc); free(c); return -43; }
+      mode = modes[0] == PA_COMM_RCCL ? PA_COMM_HYBRID : modes[0];
+      c->kind = (mode == PA_COMM_HYBRID && pa_ipc_distinct_devices(c->ipc) && nranks > 1) ? PA_COMM_HYBRID : PA_COMM_IPC;
+      if (c->kind == PA_COMM_HYBRID) {
+         /* RCCL next to the mailboxes: its id travels through the rendez-vous segment */
+         char all[HIPK_XR_MAXRANKS][128];
+         if (rank == 0 && ncclGetUniqueId(&id) != ncclSuccess) memset(&id, 0, sizeof(id));
+         if (pa_ipc_host_allgather(c->ipc, &id, 128, all)) { pa_ipc_detach(c->ipc); free(c); return -43; }
+         memcpy(&id, all[0], 128);
+         NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
+      }
+   } else {
+      c->kind = PA_COMM_RCCL;
+      memcpy(&id, id128, sizeof(id) < 128 ? sizeof(id) : 128);
+      NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
+   }
+   if (comm_staging(c)) return -1;
+   if (getenv("PRIMME_AMD_COMM_VERBOSE") && rank == 0)
+      fprintf(stderr, "primme_amd: communicator of %d ranks: %s\n", nranks,
+            c->kind == PA_COMM_RCCL ? "rccl" : c->kind == PA_COMM_IPC ? "ipc (peer-to-peer mailboxes)" : "mailboxes + rccl");
    *out = c;
    return 0;
 }
@@ -65,7 +96,8 @@ extern "C" int primme_amd_comm_create(primme_amd_comm **out, const void *id128, 
 extern "C" int primme_amd_comm_destroy(primme_amd_comm *c) {
    if (!c) return 0;
    hipStreamSynchronize(c->stream);
-   ncclCommDestroy(c->comm);
+   if (c->kind != PA_COMM_IPC) ncclCommDestroy(c->comm);
+   if (c->ipc) pa_ipc_detach(c->ipc);
    (void)hipFree(c->dbuf);
    if (c->hbuf) (void)hipHostFree(c->hbuf);
    (void)hipStreamDestroy(c->stream);
@@ -75,13 +107,47 @@ extern "C" int primme_amd_comm_destroy(primme_amd_comm *c) {
 
 extern "C" int primme_amd_comm_rank(const primme_amd_comm *c) { return c->rank; }
 extern "C" int primme_amd_comm_size(const primme_amd_comm *c) { return c->nranks; }
+/* "rccl", "ipc" or "hybrid" */
+extern "C" const char *primme_amd_comm_transport(const primme_amd_comm *c) {
+   return !c ? "none" : c->kind == PA_COMM_RCCL ? "rccl" : c->kind == PA_COMM_IPC ? "ipc" : "hybrid";
+}
+/* non-zero after a device-side wait of the peer-to-peer transport ran into its time limit */
+extern "C" int primme_amd_comm_error(const primme_amd_comm *c) { return c && c->ipc ? pa_ipc_error(c->ipc) : 0; }
 
 extern "C" int pa_comm_allreduce_device(void *commInfo, double *dbuf, int count, void *hip_stream) {
    primme_amd_comm *c = (primme_amd_comm *)commInfo;
    if (!c) return -43;
+   if (c->ipc) {
+      hipk_fin_flag nof = {NULL, NULL, 0};
+      return pa_ipc_allreduce(c->ipc, (hipStream_t)hip_stream, dbuf, count, NULL, nof);
+   }
    NCCL_CHECK(ncclAllReduce(dbuf, dbuf, (size_t)count, ncclDouble, ncclSum, c->comm, (hipStream_t)hip_stream));
    return 0;
 }
+/* public form: dbuf[0:count) <- sum over the ranks, in place, on `hip_stream` (doubles) */
+extern "C" int primme_amd_comm_allreduce(primme_amd_comm *c, void *hip_stream, double *dbuf, int count) {
+   return pa_comm_allreduce_device(c, dbuf, count, hip_stream);
+}
+/* reduction + copy into the context's pinned mirror + completion flag in ONE launch (peer-to-peer transport);
+ * returns 1 when the transport cannot (RCCL: the caller publishes with a launch of its own) */
+extern "C" int pa_comm_allreduce_publish(void *commInfo, hipk_ctx *ctx, double *dbuf, int count) {
+   primme_amd_comm *c = (primme_amd_comm *)commInfo;
+   if (!c) return -43;
+   if (!c->ipc || count <= 0) return 1;
+   double *mh = hipk_mirror_of(ctx, dbuf);
+   if (!mh || !ctx->flag_dev || !ctx->spin_wait || !hipk_mirror_of(ctx, dbuf + count - 1)) return 1;
+   return pa_ipc_allreduce(c->ipc, ctx->stream, dbuf, count, mh, hipk_next_flag(ctx, dbuf)) ? -43 : 0;
+}
+/* the context's second-stage launches may reduce across the ranks themselves (hipk_xreduce_arm) */
+extern "C" int pa_comm_attach_ctx(void *commInfo, hipk_ctx *ctx) {
+   primme_amd_comm *c = (primme_amd_comm *)commInfo;
+   static int off = -1;              /* PRIMME_AMD_NO_XREDUCE=1: keep reduction launches separate (A/B knob) */
+   if (off < 0) off = getenv("PRIMME_AMD_NO_XREDUCE") != NULL;
+   ctx->xr = (c && c->ipc && !off) ? pa_ipc_xreduce(c->ipc) : NULL;
+   ctx->xr_armed = 0; ctx->xr_lo = NULL; ctx->xr_count = 0;
+   return ctx->xr ? 0 : 1;
+}
+extern "C" int pa_comm_failed(void *commInfo) { return primme_amd_comm_error((const primme_amd_comm *)commInfo); }
 
 extern "C" void primme_amd_global_sum(void *sendBuf, void *recvBuf, int *count,
       struct primme_params *primme, int *ierr) {
@@ -96,16 +162,33 @@ extern "C" void primme_amd_global_sum(void *sendBuf, void *recvBuf, int *count,
       c->hbuf = NULL;
       c->dbuf_cap = 2 * n;
       if (hipMalloc((void **)&c->dbuf, c->dbuf_cap * sizeof(double)) != hipSuccess) return;
-      if (hipHostMalloc((void **)&c->hbuf, c->dbuf_cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return;
+      if (hipHostMalloc((void **)&c->hbuf, c->dbuf_cap * sizeof(double), hipHostMallocMapped) != hipSuccess) return;
    }
    /* globalSumReal_type: this callback handles double (the solver always reduces doubles) */
    memcpy(c->hbuf, sendBuf, n * sizeof(double));
    if (hipMemcpyAsync(c->dbuf, c->hbuf, n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
-   if (ncclAllReduce(c->dbuf, c->dbuf, n, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
+   if (c->ipc) {
+      hipk_fin_flag nof = {NULL, NULL, 0};
+      if (pa_ipc_allreduce(c->ipc, c->stream, c->dbuf, (int)n, NULL, nof)) return;
+   } else if (ncclAllReduce(c->dbuf, c->dbuf, n, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
    if (hipMemcpyAsync(c->hbuf, c->dbuf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return;
    if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+   if (c->ipc && pa_ipc_error(c->ipc)) return;
    memcpy(recvBuf, c->hbuf, n * sizeof(double));
    *ierr = 0;
+}
+
+/* the neighbour exchange with the landing buffers chosen by the transport: RCCL receives into the caller's
+ * buffers (lo_buf / hi_buf), the mailboxes have the rows land in their own zones; *lo_out / *hi_out say where.
+ * max_side_rows: the largest halo count of ANY rank (the mailboxes size their zones with it, collectively). */
+extern "C" int pa_comm_halo_auto(primme_amd_comm *c, void *hip_stream, const void *x, int64_t ldx, int64_t nrows, int ncols,
+      size_t elem, int64_t send_lo_cnt, int64_t send_hi_cnt, void *lo_buf, int64_t recv_lo_cnt, void *hi_buf,
+      int64_t recv_hi_cnt, int64_t max_side_rows, void **lo_out, void **hi_out) {
+   if (c->ipc)
+      return pa_ipc_halo(c->ipc, (hipStream_t)hip_stream, x, ldx, nrows, ncols, elem, send_lo_cnt, send_hi_cnt, recv_lo_cnt,
+            recv_hi_cnt, (size_t)max_side_rows * ncols * elem, lo_out, hi_out);
+   *lo_out = lo_buf; *hi_out = hi_buf;
+   return primme_amd_comm_halo(c, hip_stream, x, ldx, nrows, ncols, elem, send_lo_cnt, send_hi_cnt, lo_buf, recv_lo_cnt, hi_buf, recv_hi_cnt);
 }
 
 /* Exchange with the two neighbouring ranks: send my first `send_lo_cnt` elements of
@@ -116,6 +199,23 @@ extern "C" int primme_amd_comm_halo(primme_amd_comm *c, void *hip_stream, const 
       int64_t nrows, int ncols, size_t elem, int64_t send_lo_cnt, int64_t send_hi_cnt, void *lo,
       int64_t recv_lo_cnt, void *hi, int64_t recv_hi_cnt) {
    hipStream_t st = (hipStream_t)hip_stream;
+   if (c->ipc) {
+      /* caller-owned landing buffers: agree on the zone size (a host rendez-vous: this entry point synchronises;
+       * the operator uses pa_comm_halo_auto, which does not), exchange, copy out */
+      int64_t mine = send_lo_cnt, all[HIPK_XR_MAXRANKS], mx = 0;
+      if (send_hi_cnt > mine) mine = send_hi_cnt;
+      if (recv_lo_cnt > mine) mine = recv_lo_cnt;
+      if (recv_hi_cnt > mine) mine = recv_hi_cnt;
+      if (pa_ipc_host_allgather(c->ipc, &mine, sizeof(mine), all)) return -43;
+      for (int p = 0; p < c->nranks; p++) if (all[p] > mx) mx = all[p];
+      void *zl = NULL, *zh = NULL;
+      int rc = pa_ipc_halo(c->ipc, st, x, ldx, nrows, ncols, elem, send_lo_cnt, send_hi_cnt, recv_lo_cnt, recv_hi_cnt,
+            (size_t)mx * ncols * elem, &zl, &zh);
+      if (rc) return rc;
+      if (c->rank > 0 && recv_lo_cnt > 0) HIPK_CHECK(hipMemcpyAsync(lo, zl, (size_t)recv_lo_cnt * ncols * elem, hipMemcpyDeviceToDevice, st));
+      if (c->rank < c->nranks - 1 && recv_hi_cnt > 0) HIPK_CHECK(hipMemcpyAsync(hi, zh, (size_t)recv_hi_cnt * ncols * elem, hipMemcpyDeviceToDevice, st));
+      return 0;
+   }
    NCCL_CHECK(ncclGroupStart());
    for (int col = 0; col < ncols; col++) {
       const char *xc = (const char *)x + (size_t)col * ldx * elem;
@@ -135,12 +235,14 @@ extern "C" int primme_amd_comm_halo(primme_amd_comm *c, void *hip_stream, const 
 /* all-gather of equal-sized slabs (used for unstructured column patterns) */
 extern "C" int primme_amd_comm_allgather(primme_amd_comm *c, void *hip_stream, const void *send,
       void *recv, size_t bytes_per_rank) {
+   if (c->kind == PA_COMM_IPC) return pa_ipc_allgather_cols(c->ipc, (hipStream_t)hip_stream, send, 0, recv, 0, bytes_per_rank, bytes_per_rank % 8 ? 4 : 8, 1);
    NCCL_CHECK(ncclAllGather(send, recv, bytes_per_rank, ncclChar, c->comm, (hipStream_t)hip_stream));
    return 0;
 }
 
 extern "C" int primme_amd_comm_reduce_scatter(primme_amd_comm *c, void *hip_stream, const void *send,
       void *recv, size_t count_per_rank, int is_double) {
+   if (c->kind == PA_COMM_IPC) return pa_ipc_reduce_scatter_cols(c->ipc, (hipStream_t)hip_stream, send, 0, recv, 0, count_per_rank, is_double, 1);
    NCCL_CHECK(ncclReduceScatter(send, recv, count_per_rank, is_double ? ncclDouble : ncclFloat, ncclSum, c->comm,
          (hipStream_t)hip_stream));
    return 0;
@@ -150,6 +252,7 @@ extern "C" int primme_amd_comm_reduce_scatter(primme_amd_comm *c, void *hip_stre
  * The calls are issued inside one RCCL group, i.e. one launch for the whole block. */
 extern "C" int primme_amd_comm_allgather_cols(primme_amd_comm *c, void *hip_stream, const void *send, int64_t ld_send,
       void *recv, int64_t ld_recv, size_t bytes_per_rank, size_t elem, int ncols) {
+   if (c->kind == PA_COMM_IPC) return pa_ipc_allgather_cols(c->ipc, (hipStream_t)hip_stream, send, ld_send, recv, ld_recv, bytes_per_rank, elem, ncols);
    NCCL_CHECK(ncclGroupStart());
    for (int col = 0; col < ncols; col++)
       NCCL_CHECK(ncclAllGather((const char *)send + (size_t)col * ld_send * elem, (char *)recv + (size_t)col * ld_recv * elem,
@@ -160,6 +263,7 @@ extern "C" int primme_amd_comm_allgather_cols(primme_amd_comm *c, void *hip_stre
 extern "C" int primme_amd_comm_reduce_scatter_cols(primme_amd_comm *c, void *hip_stream, const void *send, int64_t ld_send,
       void *recv, int64_t ld_recv, size_t count_per_rank, int is_double, int ncols) {
    const size_t elem = is_double ? 8 : 4;
+   if (c->kind == PA_COMM_IPC) return pa_ipc_reduce_scatter_cols(c->ipc, (hipStream_t)hip_stream, send, ld_send, recv, ld_recv, count_per_rank, is_double, ncols);
    NCCL_CHECK(ncclGroupStart());
    for (int col = 0; col < ncols; col++)
       NCCL_CHECK(ncclReduceScatter((const char *)send + (size_t)col * ld_send * elem, (char *)recv + (size_t)col * ld_recv * elem,
@@ -180,6 +284,18 @@ extern "C" void primme_amd_svds_global_sum(void *sendBuf, void *recvBuf, int *co
 
 /* small integer exchange at set-up time (neighbour halo sizes) */
 extern "C" int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n, int64_t *all) {
+   if (c->ipc) {
+      /* through the rendez-vous segment, PA_IPC_PAYLOAD bytes per rank and round */
+      const int per = PA_IPC_PAYLOAD / (int)sizeof(int64_t);
+      int64_t tmp[HIPK_XR_MAXRANKS * (PA_IPC_PAYLOAD / sizeof(int64_t))];
+      for (int i0 = 0; i0 < n; i0 += per) {
+         const int k = n - i0 < per ? n - i0 : per;
+         if (pa_ipc_host_allgather(c->ipc, mine + i0, (size_t)k * sizeof(int64_t), tmp)) return -43;
+         for (int p = 0; p < c->nranks; p++)
+            for (int i = 0; i < k; i++) all[(size_t)p * n + i0 + i] = tmp[(size_t)p * k + i];
+      }
+      return 0;
+   }
    int64_t *d = NULL;
    HIPK_CHECK(hipMalloc((void **)&d, (size_t)(c->nranks + 1) * n * sizeof(int64_t)));
    int64_t *h = NULL;      /* pinned twin of the exchange buffer */

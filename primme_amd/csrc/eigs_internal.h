@@ -50,6 +50,17 @@ int pa_check_input(const void *evals, const void *evecs, const void *resNorms,
 /* communicator (comm_rccl.c): device all-reduce used when primme->globalSumReal ==
  * primme_amd_global_sum */
 int pa_comm_allreduce_device(void *commInfo, double *dbuf, int count, void *hip_stream);
+/* peer-to-peer transport (comm_ipc.hip): reduction + pinned mirror + completion flag in one launch; 1 = not on this transport */
+int pa_comm_allreduce_publish(void *commInfo, hipk_ctx *ctx, double *dbuf, int count);
+/* let the context's second-stage launches reduce across the ranks themselves (no-op on RCCL); 0 = attached */
+int pa_comm_attach_ctx(void *commInfo, hipk_ctx *ctx);
+/* arm the NEXT second-stage launch on the context as a cross-rank one (only with an attached communicator) */
+void hipk_xreduce_arm(hipk_ctx *ctx);
+/* 1 when [buf, buf+count) was produced by an armed launch since the last call: the sums are already global and
+ * published (the record is consumed) */
+int hipk_xreduce_covered(hipk_ctx *ctx, const double *buf, int count);
+/* non-zero after a device-side wait of the transport ran into its time limit (a rank left the collective sequence) */
+int pa_comm_failed(void *commInfo);
 
 /* the matvec handle understands the communicator for halo exchange */
 #endif

@@ -907,6 +907,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
                  (p->convTestFun == pa_conv_test_absolute || pa_svds_conv_test_is_vector_free(p)));
    s->maxRank = p->numOrthoConst + (p->locking ? p->numEvals : 0) + p->maxBasisSize;
    if (hipk_ctx_create(&s->ctx, p->queue)) { free(s); return PRIMME_UNEXPECTED_FAILURE; }
+   /* peer-to-peer transport: the second stage of a reduction may exchange with the other ranks itself */
+   if (s->dev_comm) (void)pa_comm_attach_ctx(p->commInfo, s->ctx);
    /* callbacks find the solver's stream in primme->queue (reference: the queue/handle
     * field carries the device queue, examples/ex_eigs_dhipblas.c:177-179) */
    void *user_queue = p->queue;

@@ -42,12 +42,23 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
    const int parallel = s->parallel;
    double t0 = parallel ? pa_wtime() : 0.0;
    if (parallel && s->dev_comm) {
+      if (hipk_xreduce_covered(s->ctx, d_buf, count)) {
+         /* the producing launch's second stage exchanged its sums with the other ranks itself (peer-to-peer
+          * transport, hipk_xreduce_arm): d_buf and the pinned mirror already hold the global sums */
+         if (!defer_sync) CHK(hipk_wait_results(s->ctx));
+      } else {
+      /* peer-to-peer transport: reduction, mirror and completion flag are one launch */
+      int rcp = pa_comm_allreduce_publish(p->commInfo, s->ctx, d_buf, count);
+      if (rcp < 0) return PRIMME_PARALLEL_FAILURE;
+      if (rcp == 0) {
+         if (!defer_sync) CHK(hipk_wait_results(s->ctx));
+      } else {
       CHK(pa_comm_allreduce_device(p->commInfo, d_buf, count, hipk_ctx_stream(s->ctx)));
       /* the global sums reach the pinned mirror through a one-block launch that also publishes the completion flag
        * (the wait is then a spin on pinned memory, as on one rank); fallback: copy + stream synchronisation */
       static int no_publish = -1;      /* PRIMME_AMD_NO_PUBLISH=1: measurement knob, read once */
       if (no_publish < 0) no_publish = getenv("PRIMME_AMD_NO_PUBLISH") != NULL;
-      const int rcp = no_publish ? 1 : hipk_publish_results(s->ctx, d_buf, count);
+      rcp = no_publish ? 1 : hipk_publish_results(s->ctx, d_buf, count);
       if (rcp < 0) return PRIMME_UNEXPECTED_FAILURE;
       if (rcp == 0) {
          if (!defer_sync) CHK(hipk_wait_results(s->ctx));
@@ -55,6 +66,9 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
          CHK(hipk_d2h(s->ctx, s->h_red + (d_buf - s->d_red), d_buf, (size_t)count * sizeof(double)));
          if (!defer_sync) CHK(hipk_sync(s->ctx));
       }
+      }
+      }
+      if (!defer_sync && pa_comm_failed(p->commInfo)) return PRIMME_PARALLEL_FAILURE;
    } else {
       /* the reduction kernels already stored the local sums in h_red (zero-copy mirror) */
       if (parallel) {

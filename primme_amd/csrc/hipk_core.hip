@@ -296,10 +296,10 @@ extern "C" int hipk_timer_stop(hipk_ctx *ctx, float *ms) {
 /* STRIDE_O = true: partial-major (partials[b * nout + o]); false: o-major (partials[o * nblocks + b]).
  * Every lane issues four loads before the first add (the launch is pure latency: a few KB out of L2),
  * and the block grows with the number of partials so that no lane makes more than a few rounds. */
-template <bool PARTIAL_MAJOR>
+template <bool PARTIAL_MAJOR, bool XR>
 __global__ void __launch_bounds__(FIN_MAXBLOCK)
 hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout, int pstride,
-      double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
+      double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin, hipk_xr_dev xr) {
    __shared__ double sm[FIN_MAXBLOCK / HIPK_WAVE];
    const int o = blockIdx.x;
    const int nt = blockDim.x;
@@ -323,6 +323,23 @@ hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
    double s = hipk_wave_sum((s0 + s1) + (s2 + s3));
    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
    __syncthreads();
+   if (XR) {
+      /* row-partitioned run on the peer-to-peer transport: this rank's sum goes to every rank's mailbox and the
+       * global sum (rank order, identical bits everywhere) is what gets stored: second stage + all-reduce +
+       * publication in this one launch (comm_ipc.hip) */
+      if (threadIdx.x < 64) {
+         double v = 0.0;
+         const int nw = nt >> 6;
+         for (int w = 0; w < nw; w++) v += sm[w];
+         v = hipk_xr_exchange(xr, (unsigned)o, v, threadIdx.x < 16);
+         if (threadIdx.x == 0) {
+            out[o] = v;
+            if (out_host) out_host[o] = v;
+            hipk_publish_flag(fin, gridDim.x);
+         }
+      }
+      return;
+   }
    if (threadIdx.x == 0) {
       double v = 0.0;
       const int nw = nt >> 6;
@@ -335,12 +352,23 @@ hipk_finalize_kernel(const double *__restrict__ partials, int nblocks, int nout,
 static inline int fin_block_for(int nblocks) {
    return nblocks <= 1024 ? HIPK_BLOCK : (nblocks <= 2048 ? 512 : FIN_MAXBLOCK);
 }
-int hipk_finalize_partials_t(hipk_ctx *ctx, const double *partials, int nblocks, int nout, double *out_dev) {
+template <bool PM>
+static int launch_finalize(hipk_ctx *ctx, const double *partials, int nblocks, int pstride, int nout, double *out_dev) {
    if (nout <= 0) return 0;
-   hipLaunchKernelGGL(hipk_finalize_kernel<false>, dim3(nout), dim3(fin_block_for(nblocks)), 0, ctx->stream,
-         partials, nblocks, nout, nout, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
+   const hipk_xr_dev xr = hipk_xr_take(ctx, out_dev, nout);
+   double *mh = hipk_mirror_of(ctx, out_dev);
+   const hipk_fin_flag ff = hipk_next_flag(ctx, out_dev);
+   if (xr.tab)
+      hipLaunchKernelGGL((hipk_finalize_kernel<PM, true>), dim3(nout), dim3(fin_block_for(nblocks)), 0, ctx->stream,
+            partials, nblocks, nout, pstride, out_dev, mh, ff, xr);
+   else
+      hipLaunchKernelGGL((hipk_finalize_kernel<PM, false>), dim3(nout), dim3(fin_block_for(nblocks)), 0, ctx->stream,
+            partials, nblocks, nout, pstride, out_dev, mh, ff, xr);
    HIPK_CHECK(hipGetLastError());
    return 0;
+}
+int hipk_finalize_partials_t(hipk_ctx *ctx, const double *partials, int nblocks, int nout, double *out_dev) {
+   return launch_finalize<false>(ctx, partials, nblocks, nout, nout, out_dev);
 }
 
 int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, int nout,
@@ -350,11 +378,16 @@ int hipk_finalize_partials(hipk_ctx *ctx, const double *partials, int nblocks, i
 /* nout results out of rows of `pstride` partials (partials[b * pstride + o], o < nout) */
 int hipk_finalize_partials_strided(hipk_ctx *ctx, const double *partials, int nblocks, int pstride, int nout,
       double *out_dev) {
-   if (nout <= 0) return 0;
-   hipLaunchKernelGGL(hipk_finalize_kernel<true>, dim3(nout), dim3(fin_block_for(nblocks)), 0, ctx->stream,
-         partials, nblocks, nout, pstride, out_dev, hipk_mirror_of(ctx, out_dev), hipk_next_flag(ctx, out_dev));
-   HIPK_CHECK(hipGetLastError());
-   return 0;
+   return launch_finalize<true>(ctx, partials, nblocks, pstride, nout, out_dev);
+}
+
+/* ---- cross-rank second stage (see hipk_internal.h: hipk_ctx.xr) ---- */
+extern "C" void hipk_xreduce_arm(hipk_ctx *ctx) { if (ctx->xr) ctx->xr_armed = 1; }
+extern "C" int hipk_xreduce_covered(hipk_ctx *ctx, const double *buf, int count) {
+   const int yes = ctx->xr_lo && buf >= ctx->xr_lo && buf + count <= ctx->xr_lo + ctx->xr_count;
+   ctx->xr_lo = NULL; ctx->xr_count = 0;
+   ctx->xr_armed = 0;      /* an arm nobody took (a producer without a second stage) must not leak into a later launch */
+   return yes;
 }
 
 /* results produced by something else than our reductions (an all-reduce): into the mirror, then the flag */

@@ -43,7 +43,55 @@ struct hipk_ctx {
    int host_timing;
    double ht_wait_s, ht_turn_s, ht_t_ret;
    long ht_waits, ht_turns;
+   /* cross-rank second stage (row-partitioned runs on the peer-to-peer transport, comm_ipc.hip): when armed, the
+    * NEXT finalize launch also exchanges its results with every rank through the mailboxes and stores the global
+    * sums — local second stage + all-reduce + publication in one launch.  xr_lo/xr_count remember which results
+    * are already global so that the solver's reduce step does not reduce them again. */
+   struct hipk_xreduce *xr;
+   int xr_armed;
+   const double *xr_lo;
+   int xr_count;
 };
+
+/* what a kernel needs to take part in a mailbox reduction; filled by pa_ipc_xreduce_args */
+#define HIPK_XR_MAXRANKS 16
+struct hipk_xreduce {
+   unsigned long long **tab;     /* device array [nranks]: every rank's granule area, mapped into this process */
+   int nranks, rank;
+   unsigned int slot_doubles;    /* capacity of one (generation, source rank) slot */
+   unsigned int *seq;            /* HOST counter of the communicator: one tag per reduction, same sequence on every rank */
+   int *err_dev;                 /* pinned error word (device address): set when a wait ran into the time limit */
+   long long timeout_ticks;      /* of the 100 MHz wall clock */
+};
+/* by-value kernel argument */
+struct hipk_xr_dev {
+   unsigned long long **tab;
+   int nranks, rank;
+   unsigned int seq, slot_doubles;
+   int *err;
+   long long timeout_ticks;
+};
+static inline unsigned int hipk_xr_next_seq(hipk_xreduce *xr) {
+   unsigned int q = ++*xr->seq;
+   if (q == 0) q = ++*xr->seq;      /* 0 is the tag of an empty mailbox */
+   return q;
+}
+static inline hipk_xr_dev hipk_xr_make(hipk_xreduce *xr) {
+   hipk_xr_dev d;
+   d.tab = xr->tab; d.nranks = xr->nranks; d.rank = xr->rank; d.seq = hipk_xr_next_seq(xr);
+   d.slot_doubles = xr->slot_doubles; d.err = xr->err_dev; d.timeout_ticks = xr->timeout_ticks;
+   return d;
+}
+static inline hipk_xr_dev hipk_xr_none(void) {
+   hipk_xr_dev d; memset(&d, 0, sizeof(d)); return d;
+}
+/* the finalize launchers: take the arm (one-shot) and note the range that is global afterwards */
+static inline hipk_xr_dev hipk_xr_take(hipk_ctx *ctx, const double *out_dev, int nout) {
+   if (!ctx->xr_armed || !ctx->xr || nout > (int)ctx->xr->slot_doubles) { ctx->xr_armed = 0; return hipk_xr_none(); }
+   ctx->xr_armed = 0;
+   ctx->xr_lo = out_dev; ctx->xr_count = nout;
+   return hipk_xr_make(ctx->xr);
+}
 
 static inline double *hipk_mirror_of(const hipk_ctx *ctx, const double *out_dev) {
    if (ctx->mirror_dev && out_dev >= ctx->mirror_dev && out_dev < ctx->mirror_dev + ctx->mirror_count)
@@ -156,6 +204,41 @@ int hipk_z_jacobi(hipStream_t st, int num_cu, hipk_dtype dt, int64_t m, const vo
 template <typename T> struct hipk_num;
 template <> struct hipk_num<double> { typedef double acc_t; enum { acc_doubles = 1 }; };
 template <> struct hipk_num<float>  { typedef double acc_t; enum { acc_doubles = 1 }; };
+
+/* Mailbox exchange of one value per group of 16 lanes (four values per wave; v and idx identical within a group,
+ * `active` false: the group only takes part in the shuffles): lane p of the group writes this rank's value into
+ * rank p's mailbox as two 8-byte {tag, half} granules (write-through, system scope: the mailboxes are peer-mapped
+ * memory of other processes / other GPUs over xGMI) and polls the granules rank p wrote here; the values are then
+ * added in rank order — the same order on every rank, so every rank holds identical bits.  No fence, no separate
+ * flag: a granule is valid when its tag is the reduction's sequence number (MI355X_MICROARCH.md, hand-off rows).
+ * Generation = seq & 1: a slot is rewritten two reductions later, which its writer can only reach after this rank
+ * contributed to the reduction in between, i.e. after it finished this one.  All 64 lanes must call. */
+__device__ __forceinline__ double hipk_xr_exchange(const hipk_xr_dev &x, unsigned idx, double v, bool active) {
+   const int lane = threadIdx.x & 63, sub = lane & 15;
+   const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+   const unsigned long long tag = (unsigned long long)x.seq << 32;
+   const size_t gen = (size_t)(x.seq & 1u) * x.nranks;
+   double mine = 0.0;
+   if (active && sub < x.nranks) {
+      unsigned long long *dst = x.tab[sub] + ((gen + x.rank) * x.slot_doubles + idx) * 2;
+      __hip_atomic_store(dst, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(dst + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long *src = x.tab[x.rank] + ((gen + sub) * x.slot_doubles + idx) * 2;
+      const long long t0 = wall_clock64();
+      unsigned long long g0, g1;
+      for (;;) {
+         g0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+         g1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+         if ((g0 >> 32) == x.seq && (g1 >> 32) == x.seq) break;
+         if (wall_clock64() - t0 > x.timeout_ticks) { *(volatile int *)x.err = 1; g0 = g1 = 0; break; }
+         __builtin_amdgcn_s_sleep(2);
+      }
+      mine = __longlong_as_double((long long)((g1 << 32) | (g0 & 0xffffffffull)));
+   }
+   double acc = 0.0;
+   for (int p = 0; p < x.nranks; p++) acc += __shfl(mine, (lane & 48) + p, 64);
+   return acc;
+}
 
 /* called by thread 0 of every block of a finalize launch after its mirrored store: the block that
  * finishes last publishes the sequence number (system-scope fence first: the pinned results must be

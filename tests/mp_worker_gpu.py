@@ -20,6 +20,94 @@ def split(n, world, rank):
     return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
 
 
+def comm_ops(lib, comm, rank, world, res):
+    """Every collective of include/primme_amd_comm.h with known data (whatever transport the communicator has)."""
+    import time
+    import torch
+    lib.primme_amd_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.primme_amd_comm_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_size_t, C.c_int64,
+                                         C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    lib.primme_amd_comm_allgather_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_size_t, C.c_size_t, C.c_int]
+    lib.primme_amd_comm_reduce_scatter_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_size_t, C.c_int, C.c_int]
+    lib.primme_amd_comm_allgather_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.primme_amd_comm_error.argtypes = [C.c_void_p]
+    ok = True
+    gen = lambda r, n, salt: np.random.default_rng(1000 * salt + r).standard_normal(n)
+    # all-reduce: sizes around the granule slot (4096) and the 16-element blocks; rank-ordered sum, bit for bit
+    digests = []
+    for salt, cnt in enumerate([1, 2, 15, 16, 17, 300, 4096, 4097, 10000]):
+        x = torch.from_numpy(gen(rank, cnt, salt)).cuda()
+        assert lib.primme_amd_comm_allreduce(comm, None, x.data_ptr(), cnt) == 0
+        torch.cuda.synchronize()
+        want = np.zeros(cnt)
+        for r in range(world):
+            want = want + gen(r, cnt, salt)
+        got = x.cpu().numpy()
+        exact = np.array_equal(got, want)
+        ok &= bool(exact or np.allclose(got, want, rtol=0, atol=1e-12))
+        res.setdefault("allreduce_exact", []).append(bool(exact))
+        digests.append(got.tobytes().hex()[:64] + str(float(got.sum())))
+    res["digest"] = digests
+    # neighbour halo, several columns, uneven counts, twice in a row (generations)
+    nrows, ncols, ld = 1000 + 13 * rank, 3, 1100
+    for it in range(3):
+        xh = np.zeros((ncols, ld)); xh[:, :nrows] = (rank + 1) * 1000 + np.arange(nrows)[None, :] + 0.5 * np.arange(ncols)[:, None] + 0.25 * it
+        x = torch.from_numpy(xh).cuda()
+        lo_n, hi_n = 7, 5     # every rank needs 7 rows from below and 5 from above -> sends 5 down... (send_lo = what r-1 needs from above = 5)
+        lo = torch.zeros(ncols * lo_n, dtype=torch.float64, device="cuda"); hi = torch.zeros(ncols * hi_n, dtype=torch.float64, device="cuda")
+        assert lib.primme_amd_comm_halo(comm, None, x.data_ptr(), ld, nrows, ncols, 8, hi_n, lo_n, lo.data_ptr(), lo_n, hi.data_ptr(), hi_n) == 0
+        torch.cuda.synchronize()
+        if rank > 0:
+            nr = 1000 + 13 * (rank - 1)
+            want = (rank) * 1000 + np.arange(nr - lo_n, nr)[None, :] + 0.5 * np.arange(ncols)[:, None] + 0.25 * it
+            ok &= bool(np.array_equal(lo.cpu().numpy().reshape(ncols, lo_n), want))
+        if rank < world - 1:
+            want = (rank + 2) * 1000 + np.arange(hi_n)[None, :] + 0.5 * np.arange(ncols)[:, None] + 0.25 * it
+            ok &= bool(np.array_equal(hi.cpu().numpy().reshape(ncols, hi_n), want))
+    # all-gather / reduce-scatter of column blocks (double and float), repeated (window generations)
+    for it in range(3):
+        per, nc = 257 + it, 2
+        send = torch.from_numpy(np.stack([gen(rank, per, 50 + c + 10 * it) for c in range(nc)])).cuda()
+        recv = torch.zeros((nc, per * world + 3), dtype=torch.float64, device="cuda")
+        assert lib.primme_amd_comm_allgather_cols(comm, None, send.data_ptr(), per, recv.data_ptr(), per * world + 3, per * 8, 8, nc) == 0
+        torch.cuda.synchronize()
+        want = np.stack([np.concatenate([gen(r, per, 50 + c + 10 * it) for r in range(world)]) for c in range(nc)])
+        ok &= bool(np.array_equal(recv.cpu().numpy()[:, :per * world], want))
+        for dt, isd in ((torch.float64, 1), (torch.float32, 0)):
+            full = torch.from_numpy(np.stack([gen(rank, per * world, 70 + c + 10 * it) for c in range(nc)])).to(dt).cuda()
+            out = torch.zeros((nc, per), dtype=dt, device="cuda")
+            assert lib.primme_amd_comm_reduce_scatter_cols(comm, None, full.data_ptr(), per * world, out.data_ptr(), per, per, isd, nc) == 0
+            torch.cuda.synchronize()
+            npdt = np.float64 if isd else np.float32
+            want = np.zeros((nc, per), dtype=npdt)
+            for r in range(world):
+                want = want + np.stack([gen(r, per * world, 70 + c + 10 * it) for c in range(nc)]).astype(npdt)[:, rank * per:(rank + 1) * per]
+            ok &= bool(np.allclose(out.cpu().numpy(), want, rtol=0, atol=1e-12 if isd else 1e-5))
+    mine = (C.c_int64 * 40)(*[100 * rank + i for i in range(40)]); allv = (C.c_int64 * (40 * world))()
+    assert lib.primme_amd_comm_allgather_i64(comm, mine, 40, allv) == 0
+    ok &= list(allv) == [100 * r + i for r in range(world) for i in range(40)]
+    # latency of one small reduction: 200 back-to-back 8-double all-reduces, host clock around launch..sync
+    x = torch.ones(8, dtype=torch.float64, device="cuda")
+    for _ in range(20):
+        lib.primme_amd_comm_allreduce(comm, None, x.data_ptr(), 8)
+    x.fill_(1.0); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        lib.primme_amd_comm_allreduce(comm, None, x.data_ptr(), 8)
+        torch.cuda.synchronize()
+    res["allreduce8_sync_us"] = 1e6 * (time.perf_counter() - t0) / 200
+    x.fill_(1.0 / 1024); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        lib.primme_amd_comm_allreduce(comm, None, x.data_ptr(), 8)
+    torch.cuda.synchronize()
+    res["allreduce8_chain_us"] = 1e6 * (time.perf_counter() - t0) / 5
+    ok &= bool(np.all(x.cpu().numpy() == (1.0 / 1024) * float(world) ** 5))
+    ok &= lib.primme_amd_comm_error(comm) == 0
+    res.update(ret=0 if ok else 1, evals=[], resNorms=[], its=0, numGlobalSum=1, evecs_norm2=0.0, aNorm=0.0)
+    return None
+
+
 def run(rank, world, port, case, out_path):
     import torch
     import torch.distributed as dist
@@ -40,8 +128,32 @@ def run(rank, world, port, case, out_path):
     comm = C.c_void_p()
     assert lib.primme_amd_comm_create(C.byref(comm), bytes(uid.numpy().tobytes()), rank, world) == 0
 
-    res = dict(rank=rank, case=case)
-    if case in ("halo", "halo_block"):
+    lib.primme_amd_comm_transport.restype = C.c_char_p
+    lib.primme_amd_comm_transport.argtypes = [C.c_void_p]
+    res = dict(rank=rank, case=case, transport=lib.primme_amd_comm_transport(comm).decode())
+    if case == "comm_ops":
+        r = comm_ops(lib, comm, rank, world, res)
+    elif case == "lap3d_small":
+        # BASELINE configs[1] in small: 3-D 7-point Laplacian, 10 smallest, GD+k, block size 1
+        dims = (40, 41, 42)
+        n = int(np.prod(dims))
+        row0, nloc = split(n, world, rank)
+        rp, ci, va, _ = problems.laplacian_csr(dims, row0=row0, nrows=nloc)
+        s = Session(Operator(n, csr=(rp, ci, va), row0=row0, nrows=nloc), comm=comm)
+        r = s.solve(numEvals=10, eps=1e-8, aNorm=12.0, method="GD_plusK", numProcs=world, procID=rank,
+                    v0=problems.start_vector(n, row0=row0, nrows=nloc))
+        s.close()
+    elif case == "hermitian_b4":
+        # BASELINE configs[3] in small: complex Hermitian banded, block size 4, 6 largest, GD+k, rows split
+        nloc = 4000
+        n = nloc * world
+        rp, ci, va = problems.hermitian_banded_csr(n, row0=rank * nloc, nrows=nloc)
+        s = Session(Operator(n, csr=(rp, ci, va), row0=rank * nloc, nrows=nloc), comm=comm, dtype=np.complex128)
+        r = s.solve(numEvals=6, target="largest", eps=1e-10, numProcs=world, procID=rank, iseed=(5, 1, 2, 3), maxBlockSize=4,
+                    method="GD_plusK")
+        s.close()
+        r.evecs = np.concatenate([r.evecs.real, r.evecs.imag])
+    elif case in ("halo", "halo_block"):
         # one 3-D Laplacian split by rows: neighbour halo exchange inside the ready-made operator
         dims = (24, 25, 26)
         n = int(np.prod(dims))
