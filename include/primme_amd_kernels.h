@@ -304,8 +304,13 @@ int hipk_sym_eig(hipk_ctx *ctx, int n, const double *A_host, int lda, double *ev
       double *Z_host, int ldz);
 
 /* ---- measurement helpers ------------------------------------------------------- */
+/* index bytes per nonzero the single-vector CSR kernel streams (2 with the 16-bit index stream built at
+ * hipk_csr_create for banded / stencil / block-diagonal patterns, else 4): for byte accounting */
+int hipk_csr_index_bytes(const hipk_csr *A);
 /* device copy bandwidth probe: copies `bytes` src->dst `reps` times, returns GB/s (read+write) */
 int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);
+/* read-only probe with the access pattern of the panel kernels (16 columns walked together, 16-byte loads): GB/s read */
+int hipk_read_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);
 /* live per-kernel-class timing with HIP events on the launching stream (process-wide,
  * off by default).  cls: 0 = TN inner products, 1 = NN project, 2 = fused Ritz update,
  * 3 = sparse matvec.  alg_bytes = algorithmic HBM bytes of the timed launches. */

@@ -491,6 +491,42 @@ extern "C" int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, doubl
    return 0;
 }
 
+/* read-only stream probe with the access pattern of the panel kernels: NC columns walked together, 16-byte
+ * non-temporal loads, one partial sum per block (what "attainable read bandwidth" means for ritz_cgs_kernel) */
+typedef double probe_v2 __attribute__((ext_vector_type(2)));
+template <int NC>
+__global__ void __launch_bounds__(HIPK_BLOCK) hipk_read_probe_kernel(const probe_v2 *__restrict__ a, size_t rows2, double *__restrict__ part) {
+   double acc = 0.0;
+   for (size_t i = (size_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < rows2; i += (size_t)gridDim.x * HIPK_BLOCK) {
+      probe_v2 v[NC];
+#pragma unroll
+      for (int c = 0; c < NC; c++) v[c] = __builtin_nontemporal_load(a + (size_t)c * rows2 + i);
+#pragma unroll
+      for (int c = 0; c < NC; c++) acc += v[c].x + v[c].y;
+   }
+   acc = hipk_wave_sum(acc);
+   if ((threadIdx.x & 63) == 0) part[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
+}
+extern "C" int hipk_read_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps) {
+   const int NC = 16;
+   void *a = NULL;
+   const size_t rows2 = bytes / (16 * NC);
+   if (rows2 == 0) return -1;
+   const int grid = ctx->num_cu * 4;
+   if (hipk_malloc(ctx, rows2 * 16 * NC, &a) || hipk_reserve_partials(ctx, (size_t)grid * 4)) return -2;
+   HIPK_CHECK(hipMemsetAsync(a, 0, rows2 * 16 * NC, ctx->stream));
+   for (int w = 0; w < 2; w++)
+      hipLaunchKernelGGL(hipk_read_probe_kernel<16>, dim3(grid), dim3(HIPK_BLOCK), 0, ctx->stream, (const probe_v2 *)a, rows2, ctx->partials);
+   float ms = 0;
+   hipk_timer_start(ctx);
+   for (int r = 0; r < reps; r++)
+      hipLaunchKernelGGL(hipk_read_probe_kernel<16>, dim3(grid), dim3(HIPK_BLOCK), 0, ctx->stream, (const probe_v2 *)a, rows2, ctx->partials);
+   if (hipk_timer_stop(ctx, &ms)) return -1;
+   *gbps = (double)(rows2 * 16 * NC) * reps / (ms * 1e-3) / 1e9;
+   hipk_free(ctx, a);
+   return 0;
+}
+
 /* ---- live kernel-class profiler ---------------------------------------------- */
 #define PROF_RING 4096
 static struct {

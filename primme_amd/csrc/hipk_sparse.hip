@@ -709,6 +709,9 @@ static const uint16_t *csr16(const hipk_csr *A) {
    return no16 ? (const uint16_t *)NULL : A->col16;
 }
 
+/* bytes per nonzero the tile kernels really stream for the index: 2 with the 16-bit index stream, else 4 */
+extern "C" int hipk_csr_index_bytes(const hipk_csr *A) { return (A && A->kind == 0 && csr16(A)) ? 2 : 4; }
+
 /* stream the matrix past the Infinity Cache?  Yes when its (value, index) stream alone is more than about three quarters
  * of the 256 MiB (it cannot stay until the next product anyway); HIPK_SPMV_NT=0 / 1 forces it (A/B knob) */
 static bool csr_stream_nt(const hipk_csr *A) {
