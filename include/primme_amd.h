@@ -196,8 +196,12 @@ int  primme_params_destroy(primme_params *primme);
  * PRIMME_UNEXPECTED_FAILURE.
  * hip_zprimme / hip_cprimme (Hermitian problems; evecs and the callbacks' vectors are DEVICE
  * arrays of (re, im) pairs, leading dimensions in complex elements exactly as for
- * cublas_zprimme) run on the real-equivalent form of the problem (csrc/eigs_complex.c): same
- * eigenpairs and residual norms as zprimme, about twice its operator applications. */
+ * cublas_zprimme) run natively on complex panels (csrc/hipk_complex.hip, the host solver compiled
+ * for double complex, csrc/eigs_*_z.c): the GD family, JDQMR and the dynamic switch, with
+ * Rayleigh-Ritz, harmonic or refined extraction — zprimme's eigenpairs, residual norms and, on the
+ * committed extremal fixtures, its outer-iteration / matvec / restart counts.  PRIMME_AMD_COMPLEX_REAL_FORM=1
+ * (csrc/eigs_complex.c) selects the real-equivalent 2n form instead: same eigenpairs, about
+ * twice the operator applications; kept as a cross-check. */
 int hip_dprimme(double *evals, double *evecs, double *resNorms, primme_params *primme);
 int hip_zprimme(double *evals, void *evecs, double *resNorms, primme_params *primme);
 int hip_sprimme(float *evals, float *evecs, float *resNorms, primme_params *primme);

@@ -24,8 +24,10 @@
  *     hipk_axpy_cols / hipk_xpay_cols — is a (re, im) pair of doubles with leading dimensions in pairs; Ritz values,
  *     shifts, squared norms and the factors of hipk_scale_cols stay real.  Entry points that exist only for the
  *     fused real block-size-1 iteration (hipk_ritz_residual_overlaps, hipk_ritz_update_overlaps,
- *     hipk_csr_matvec_scaled), the stencil operator and the QMR kernels return -44 for complex dtypes: a complex
- *     JDQMR / harmonic solve runs on the real-equivalent form (csrc/eigs_complex.c).
+ *     hipk_csr_matvec_scaled, the early-rho step of the QMR iteration) and the stencil operator return -44 for
+ *     complex dtypes.  The QMR recurrences of a complex JDQMR solve run through the REAL kernels on the 2m-real
+ *     view of the m complex rows (their coefficients are real; csrc/eigs_jd.c), the harmonic and refined
+ *     extractions natively on complex panels (csrc/eigs_harm.c).
  *   - return 0 on success, PRIMME-style negative code otherwise.
  */
 #ifndef PRIMME_AMD_KERNELS_H

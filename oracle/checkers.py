@@ -103,7 +103,13 @@ class ReferenceBackend:
         p.matrixMatvec = C.cast(cb, C.c_void_p)
         if precond is not None:
             dg = np.real(op.diagonal())        # Hermitian: the diagonal is real (divide by a real number, as the device kernel does)
-            jfixed = None if precond == "jacobi" else float(precond[1])
+            zrot = None
+            if precond != "jacobi" and precond[0] == "zjacobi":
+                # NON-Hermitian diagonal preconditioner K = diag(A) (1 + i gamma w_j): makes x'K^-1 x complex
+                # (the reference keeps it as an HSCALAR, src/eigs/correction.c:969-977); examples/ex_eigs_zhip_precond.hip
+                from primme_amd.problems import zjacobi_rotation
+                zrot = zjacobi_rotation(len(dg), float(precond[1]))
+            jfixed = None if precond == "jacobi" else 0.0 if zrot is not None else float(precond[1])   # zjacobi: K = diag(A) (1 + i gamma w)
 
             def pc(x, ldx, y, ldy, bs, pp, ierr):
                 nb, lx, ly = bs[0], ldx[0], ldy[0]
@@ -119,7 +125,7 @@ class ReferenceBackend:
                     d = dg - (jfixed if jfixed is not None else (sh[c] if sh else 0.0))
                     small = ~(np.abs(d) > mind)
                     d[small] = np.copysign(mind, d[small])
-                    Y[c, :nLocal] = X[c, :nLocal] / d
+                    Y[c, :nLocal] = X[c, :nLocal] / (d if zrot is None else d * zrot)
                 ierr[0] = 0
             pcb = F.BLOCK_OP(pc)
             keep.append(pcb)

@@ -504,6 +504,9 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          const int wtr = speculate2 && s->wtr_enabled && !s->Q && basisSize <= HIPK_WTR_MAX_K && nLk <= HIPK_WTR_MAX_K &&
                          (nLk == 0 || (s->wtq_L == nLk && s->wtq_rows >= basisSize - 1));   /* (RR extraction only) */
          const int nfov = nov + 1 + (wtr ? basisSize + nLk : 0);      /* [V'r | Q'r | r'r | W'r | W(:,k-1)'Q] */
+         /* row-partitioned, peer-to-peer transport: the second stage of this pass exchanges the overlaps with the
+          * other ranks itself (ortho.c:249's all-reduce inside the launch that forms the local sums) */
+         if (s->parallel && s->dev_comm) hipk_xreduce_arm(s->ctx);
          if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
                     s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, wtr, s->d_fov))) goto out;
          if (speculate) {

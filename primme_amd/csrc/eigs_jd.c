@@ -129,7 +129,7 @@ typedef struct {
    char *RQ, *RX; int64_t ldRQ, ldRX; int nRQ, nRX;   /* right projectors: I - RQ M^-1 Q', I - RX_i x_i'/xKx_i */
    int skewQ, skewX;       /* RQ = K^-1 Q with M = Q'K^-1 Q factorised; RX = K^-1 x with xKx = x'K^-1 x */
    char *x;                /* the Ritz vectors (dotted against in the X projector) */
-   double xKx[64];
+   HS xKx[64];             /* x_i' K^-1 x_i: complex for a non-Hermitian preconditioner (reference: HSCALAR xKinvBx) */
 } jd_proj;
 
 /* ---- M = evecs' evecsHat: dense LU with partial pivoting on the host (the reference keeps a
@@ -463,7 +463,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          CHK(permute_panel(s, x, ld, blockSize, p0));    /* LX / RX alias x */                     \
          if (P->skewX && P->nRX) {                                                                 \
             CHK(permute_panel(s, P->RX, P->ldRX, blockSize, p0));                                  \
-            pa_permute_reals(P->xKx, 1, blockSize, 1, p0);                                         \
+            pa_permute_cols(P->xKx, 1, blockSize, 1, p0);                                          \
          }                                                                                         \
          CHK(permute_panel(s, sol, ld, blockSize, p0));                                            \
          blockSize -= conv;                                                                        \
@@ -640,7 +640,9 @@ int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double
          /* K^-1 x and x'K^-1 x (reference correction.c:969-977) */
          char *Kx = PCOL(s, s->Jw, s->ld, 5 * p->maxBlockSize);
          CHK(pa_precond(s, x, s->ld, Kx, s->ld, blockSize));
-         CHK(pair_dots_host(s, x, s->ld, Kx, s->ld, blockSize, P.xKx));
+         CHK(hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kx, s->ld, blockSize, s->d_red));
+         CHK(pa_reduce(s, s->d_red, SD * blockSize, 0, 0));
+         for (int i = 0; i < blockSize; i++) P.xKx[i] = ((const HS *)s->h_red)[i];
          P.RX = Kx; P.ldRX = s->ld; P.skewX = 1;
       } else {
          P.RX = x; P.ldRX = s->ld;

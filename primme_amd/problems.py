@@ -206,3 +206,34 @@ def hermitian_banded_csr(n, row0=0, nrows=None, hbw=3):
     rp = np.zeros(nrows + 1, dtype=np.int64)
     rp[1:] = np.cumsum(ok.sum(axis=1))
     return rp.astype(np.int32), cols[ok].astype(np.int32), vals[ok]
+
+
+def hermitian_tridiag_graded(n):
+    """examples/ex_eigs_zhip_precond.hip: A = tridiag(conj(a), d_j, a), d_j = 1 + j, a = -0.5 exp(0.7 i)
+    (unitarily similar to the real tridiag(|a|, d_j, |a|)).  Returns (rowptr, colind, values complex128, d, a)."""
+    j = np.arange(n, dtype=np.int64)
+    d = 1.0 + j
+    a = -0.5 * np.cos(0.7) - 0.5j * np.sin(0.7)
+    rows, cols, vals = [], [], []
+    cnt = np.full(n, 3, dtype=np.int64); cnt[0] -= 1; cnt[-1] -= 1
+    rp = np.zeros(n + 1, dtype=np.int64); rp[1:] = np.cumsum(cnt)
+    ci = np.empty(rp[-1], dtype=np.int64); va = np.empty(rp[-1], dtype=np.complex128)
+    pos = rp[:-1].copy()
+    lo = j > 0
+    ci[pos[lo]] = j[lo] - 1; va[pos[lo]] = np.conj(a); pos[lo] += 1
+    ci[pos] = j; va[pos] = d; pos += 1
+    hi = j < n - 1
+    ci[pos[hi]] = j[hi] + 1; va[pos[hi]] = a
+    return rp.astype(np.int32), ci.astype(np.int32), va, d, a
+
+
+def rational_complex_start_vector(n):
+    """start vector made of exactly representable quotients (the C example forms the same bits)"""
+    j = np.arange(n, dtype=np.int64)
+    return (((j * 7 + 3) % 11 - 5) / 5.0 + 1j * (((j * 5 + 1) % 13 - 6) / 6.0)).reshape(n, 1)
+
+
+def zjacobi_rotation(n, gamma):
+    """1 + i gamma w_j, w_j = ((j mod 7) - 3)/3: the non-Hermitian factor of the example's diagonal preconditioner"""
+    j = np.arange(n, dtype=np.int64)
+    return 1.0 + 1j * gamma * ((j % 7 - 3) / 3.0)

@@ -31,7 +31,6 @@ def _make_v0(spec, n):
     return np.random.default_rng(spec["rng"]).standard_normal((n, 9))[:, :spec["cols"]]
 
 LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_leq": 0.05,
-         "lap1d_ex_dseq_dynamic": 1e9, "lap3d_dynamic": 1e9, "lap2d_dynamic_few_soft": 1e9,   # timing-driven paths
          "ref_closest_abs": 0.25, "ref_closest_geq": 0.25, "ref_closest_leq_jdqmr": 0.25, "ref_soft": 0.25, "ref_two_shifts": 0.25,
          "harm_closest_abs": 0.25, "harm_closest_geq": 0.25, "harm_closest_leq_jdqmr": 0.25, "harm_two_shifts": 0.25,
          "jdqmr_blk4": 0.3, "jdqmr_etol_blk8_jacobi": 0.3, "jdqmr_closest_abs": 0.3}
@@ -41,6 +40,12 @@ LOOSE = {"lap2d_closest_abs": 0.05, "lap2d_closest_geq": 0.05, "lap2d_closest_le
 # applications within 0.79-1.18 of dprimme's (median 1.01), outer iterations 0.58-1.10 (fewer, longer inner solves at
 # b = 4, 8), block size 1 exact.  The work measure (matvecs) gets the tight bound, the outer count the loose one.
 LOOSE_MATVECS = {"jdqmr_blk4": 0.15, "jdqmr_etol_blk8_jacobi": 0.15, "jdqmr_closest_abs": 0.15}
+# PRIMME_DYNAMIC switches between GD+k and JDQMR on WALL-CLOCK ratios (reference src/eigs/main_iter.c:2196-2407; SURVEY
+# section 2 #4 marks it out of scope): neither its history nor the reference's is reproducible, so no count is compared.
+# What must hold: it converges to the reference's pairs, it ends in one of the states a finished dynamic run can be in
+# (dynamicMethodSwitch -1 = closing with JDQMR, -2 = GD+k, -3 = GD+k for few pairs), and the work stays within the band the
+# two methods span (the fixtures' own counts are one draw from it).
+DYNAMIC = {"lap1d_ex_dseq_dynamic", "lap3d_dynamic", "lap2d_dynamic_few_soft"}
 
 
 def _case(name):
@@ -79,6 +84,10 @@ def test_hip_against_reference_fixture(built, name):
     if thr > 0:
         assert np.all(r.resNorms <= thr * (1 + 1e-6))
     its, itsg = r.stats["numOuterIterations"], g["stats"]["numOuterIterations"]
+    if name in DYNAMIC:
+        assert r.params["dynamicMethodSwitch"] in (-1, -2, -3), r.params["dynamicMethodSwitch"]
+        assert g["stats"]["numMatvecs"] / 4 <= r.stats["numMatvecs"] <= 4 * g["stats"]["numMatvecs"]
+        return
     # the device reductions add in a different order than the CPU BLAS: counts agree closely,
     # exactly for most cases; allow 2 % (5 % for the interior targets, where the reference
     # itself varies from run to run)
