@@ -96,9 +96,9 @@ int main(int argc, char **argv) {
    if (hipMalloc((void **)&evecs_dev, sizeof(double2) * n * nev) != hipSuccess) { fprintf(stderr, "no HIP device\n"); return 2; }
    /* start vector: exactly representable quotients, the same bits as primme_amd.problems.rational_complex_start_vector */
    for (int64_t j = 0; j < n; j++) evecs[j] = make_double2((double)((j * 7 + 3) % 11 - 5) / 5.0, (double)((j * 5 + 1) % 13 - 6) / 6.0);
-   hipMemcpy(evecs_dev, evecs, sizeof(double2) * n, hipMemcpyHostToDevice);
+   (void)hipMemcpy(evecs_dev, evecs, sizeof(double2) * n, hipMemcpyHostToDevice);
    const int ret = hip_zprimme(evals, evecs_dev, rnorms, &primme);
-   hipMemcpy(evecs, evecs_dev, sizeof(double2) * n * nev, hipMemcpyDeviceToHost);
+   (void)hipMemcpy(evecs, evecs_dev, sizeof(double2) * n * nev, hipMemcpyDeviceToHost);
 
    int bad = (ret != 0 || primme.initSize != nev);
    double worst = 0.0;
@@ -122,7 +122,7 @@ int main(int argc, char **argv) {
          (long long)primme.stats.numOuterIterations, (long long)primme.stats.numMatvecs, (long long)primme.stats.numRestarts,
          (long long)primme.stats.numPreconds, worst);
    free(evecs);
-   hipFree(evecs_dev);
+   (void)hipFree(evecs_dev);
    primme_free(&primme);
    return bad;
 }

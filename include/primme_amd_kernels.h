@@ -309,6 +309,12 @@ int hipk_sym_eig(hipk_ctx *ctx, int n, const double *A_host, int lda, double *ev
 /* index bytes per nonzero the single-vector CSR kernel streams (2 with the 16-bit index stream built at
  * hipk_csr_create for banded / stencil / block-diagonal patterns, else 4): for byte accounting */
 int hipk_csr_index_bytes(const hipk_csr *A);
+/* Matrices created with hipk_csr_create_rect whose column pattern is scattered over an input vector larger than an
+ * XCD's L2 also get a PANEL-BLOCKED form (csrc/hipk_sparse_pb.hip: columns cut into panels whose slice of x fits the
+ * L2, one wave per row tile walking the panels with its row sums in registers; HIPK_PB=0 / 1 never / always,
+ * HIPK_PB_KB bytes of x per panel).  Number of panels (0: plain CSR kernels) and the bytes one product streams. */
+int hipk_csr_panels(const hipk_csr *A);
+double hipk_csr_streamed_bytes(const hipk_csr *A);
 /* device copy bandwidth probe: copies `bytes` src->dst `reps` times, returns GB/s (read+write) */
 int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);
 /* read-only probe with the access pattern of the panel kernels (16 columns walked together, 16-byte loads): GB/s read */

@@ -112,6 +112,14 @@ int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) {
    return 0;
 }
 
+/* the peer-to-peer transport and its fused second stage exist on the device only: the checker always takes the
+ * separate all-reduce above */
+int pa_comm_allreduce_publish(void *ci, struct hipk_ctx *ctx, double *d, int n) { (void)ci; (void)ctx; (void)d; (void)n; return 1; }
+int pa_comm_attach_ctx(void *ci, struct hipk_ctx *ctx) { (void)ci; (void)ctx; return 1; }
+void hipk_xreduce_arm(struct hipk_ctx *ctx) { (void)ctx; }
+int hipk_xreduce_covered(struct hipk_ctx *ctx, const double *buf, int count) { (void)ctx; (void)buf; (void)count; return 0; }
+int pa_comm_failed(void *ci) { (void)ci; return 0; }
+
 /* singular value operator on host memory */
 struct primme_amd_svds_operator { hipk_csr *A, *At; void *jac_r, *jac_c; int cplx; };
 int primme_amd_svds_operator_create(primme_amd_svds_operator **out, struct hipk_ctx *ctx, int dt, int64_t m, int64_t n,

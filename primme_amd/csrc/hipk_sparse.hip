@@ -45,7 +45,14 @@ struct hipk_csr {
    const void *xlo, *xhi;      /* device halo buffers for the current matvec */
    int64_t ld_lo, ld_hi;       /* their column strides (default: halo_lo / halo_hi, packed) */
    int sx, sy, sz;             /* stencil grid */
+   struct hipk_pb *pb;         /* panel-blocked form (hipk_sparse_pb.hip) for scattered column patterns, or NULL */
 };
+struct hipk_pb;
+extern "C" int hipk_pb_build(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int64_t n, const int32_t *rp, const int32_t *ci, const void *val, hipk_pb **out);
+extern "C" int hipk_pb_matvec(const hipk_pb *B, void *hip_stream, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols);
+extern "C" void hipk_pb_destroy(hipk_pb *B);
+extern "C" double hipk_pb_bytes(const hipk_pb *B);
+extern "C" int hipk_pb_panels(const hipk_pb *B);
 
 /* x element for global column g: owned slab, or the lo / hi halo buffers.  The address is
  * selected, the load itself is unconditional (a branch per gather would serialise the gathers). */
@@ -629,6 +636,12 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
             hipk_upload(ctx, (char *)A->values + (size_t)nnz * es, zero, es))
          return -1;
    }
+   /* scattered column pattern over an input vector that is all local (the rectangular operators of the singular value
+    * problem): the panel-blocked form serves the one-column products */
+   if (lo == 0 && hi == 0 && x0 == 0 && xlen == ncols_global && (dt == HIPK_F64 || dt == HIPK_F32)) {
+      const int rcp = hipk_pb_build(ctx, dt, nrows_local, ncols_global, rowptr_host, colind_host, values_host, &A->pb);
+      if (rcp < 0) return rcp;
+   }
    *out = A;
    return 0;
 }
@@ -685,6 +698,7 @@ extern "C" int hipk_csr_destroy(hipk_csr *A) {
    if (A->twin) (void)hipFree(A->twin);
    if (A->col16) (void)hipFree(A->col16);
    if (A->diag) (void)hipFree(A->diag);
+   if (A->pb) hipk_pb_destroy(A->pb);
    free(A);
    return 0;
 }
@@ -712,6 +726,10 @@ static const uint16_t *csr16(const hipk_csr *A) {
 /* bytes per nonzero the tile kernels really stream for the index: 2 with the 16-bit index stream, else 4 */
 extern "C" int hipk_csr_index_bytes(const hipk_csr *A) { return (A && A->kind == 0 && csr16(A)) ? 2 : 4; }
 
+/* number of column panels of the panel-blocked form (0: plain CSR kernels serve this matrix) */
+extern "C" int hipk_csr_panels(const hipk_csr *A) { return A && A->pb ? hipk_pb_panels(A->pb) : 0; }
+extern "C" double hipk_csr_streamed_bytes(const hipk_csr *A) { return A && A->pb ? hipk_pb_bytes(A->pb) : 0.0; }
+
 /* stream the matrix past the Infinity Cache?  Yes when its (value, index) stream alone is more than about three quarters
  * of the 256 MiB (it cannot stay until the next product anyway); HIPK_SPMV_NT=0 / 1 forces it (A/B knob) */
 static bool csr_stream_nt(const hipk_csr *A) {
@@ -734,6 +752,13 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
    const double alg = (A->kind == 1) ? 2.0 * A->nrows * es * ncols
                                      : (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 2.0 * A->nrows * es * ncols;
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, stream, alg);
+   static int pb_maxcols = -1;       /* HIPK_PB_MAXCOLS: widest block served column by column through the panel-blocked form */
+   if (pb_maxcols < 0) { const char *e = getenv("HIPK_PB_MAXCOLS"); pb_maxcols = e ? atoi(e) : 2; }
+   if (A->pb && !shift_host && ncols <= pb_maxcols) {
+      const int rc = hipk_pb_matvec(A->pb, stream, x, ldx, y, ldy, ncols);
+      hipk_prof_end(pslot, stream);
+      return rc;
+   }
    if (A->kind == 1) {
       int gx = hipk_grid_for_rows(ctx, A->nrows, HIPK_BLOCK, 8);
       hipLaunchKernelGGL(stencil_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->sx,

@@ -392,6 +392,44 @@ def test_csr_matvec(built, dt, ncols):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+def test_csr_panel_blocked_scattered_pattern(built, dt):
+    """BASELINE configs[4]'s pattern in small (5 entries per row at (i p_q + q) mod n) and its transpose: the input
+    vector is larger than an XCD's L2 and consecutive rows share no cache line, so hipk_csr_create_rect also builds the
+    panel-blocked form (csrc/hipk_sparse_pb.hip) and one- and two-column products go through it; wider blocks through
+    the plain CSR kernels.  Against the plain-C restatement and numpy; twice, bit for bit the same."""
+    from primme_amd.svds_api import transpose_csr
+    npdt = NPDT[dt]
+    m, n = (800_000, 900_000) if dt == F.HIPK_F64 else (1_700_000, 1_600_000)    # both vectors above the 6 MB threshold
+    rp, ci, va = problems.svds_synthetic_csr(m, n)
+    rpT, ciT, vaT = transpose_csr(m, n, rp, ci, va)
+    for name, (mm, nn, r_, c_, v_) in {"A": (m, n, rp, ci, va), "At": (n, m, rpT, ciT, vaT)}.items():
+        rng = np.random.default_rng(mm % 1000)
+        for ncols in (1, 2, 3):
+            X = rng.standard_normal((ncols, nn)).astype(npdt)
+            res = []
+            for side in (Dev(), Host()):
+                A = C.c_void_p()
+                vv = np.ascontiguousarray(v_, dtype=npdt)
+                assert side.lib.hipk_csr_create_rect(side.ctx, dt, mm, nn, r_.ctypes.data_as(C.c_void_p), c_.ctypes.data_as(C.c_void_p),
+                                                     vv.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+                if side.name == "hip":
+                    side.lib.hipk_csr_panels.argtypes = [C.c_void_p]
+                    assert side.lib.hipk_csr_panels(A) >= 2, name          # the panel-blocked form was built
+                x = side.arr(X); y = side.arr(np.zeros((ncols, mm), dtype=npdt))
+                assert side.lib.hipk_csr_matvec(A, None, side.ptr(x), nn, side.ptr(y), mm, ncols) == 0
+                first = side.get(y).copy()
+                assert side.lib.hipk_csr_matvec(A, None, side.ptr(x), nn, side.ptr(y), mm, ncols) == 0
+                assert np.array_equal(first, side.get(y)), name            # reproducible bits
+                res.append(first)
+                side.lib.hipk_csr_destroy(A)
+                side.close()
+            ref = problems.csr_matvec_numpy(r_, c_, np.asarray(v_).astype(npdt).astype(np.float64), X.T.astype(np.float64)).T
+            tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+            assert np.max(np.abs(res[0] - res[1])) <= tol * (1 + np.abs(res[1]).max()), (name, ncols)
+            assert np.max(np.abs(res[0] - ref)) <= tol * (1 + np.abs(ref).max()), (name, ncols)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
 @pytest.mark.parametrize("ncols", [2, 8])
 def test_csr_matvec_shifted(built, dt, ncols):
     """y = A x - shift[c] x(:,c) in one launch (the first update of the projected operator of the JDQMR inner
