@@ -159,7 +159,7 @@ class Session:
               maxMatvecs=0, maxOuterIterations=0, targetShifts=None, precond=None, printLevel=0,
               initBasisMode=None, global_sum=None, numProcs=1, procID=0, orth=None, iseed=None,
               profile=False, return_evecs=True, monitor=None, user_matvec=None, projection=None,
-              constraints=None):
+              constraints=None, user_precond=None):
         lib, op, dtype = self.lib, self.op, self.dtype
         keep = []
         p = F.PrimmeParams()
@@ -217,7 +217,11 @@ class Session:
             if user_matvec is not None:      # an application callback instead of the ready-made one
                 keep.append(user_matvec)
                 p.matrixMatvec = C.cast(user_matvec, C.c_void_p)
-            if precond is not None:
+            if user_precond is not None:     # an application preconditioner callback (same pointer conventions as the matvec)
+                keep.append(user_precond)
+                p.applyPreconditioner = C.cast(user_precond, C.c_void_p)
+                p.correctionParams.precondition = 1
+            elif precond is not None:
                 # "jacobi": per-vector shifts of the solver; ("jacobi", s): fixed K = diag(A) - s
                 if precond == "jacobi": lib.primme_amd_operator_set_jacobi(self.oph, 0, 0.0)
                 else: lib.primme_amd_operator_set_jacobi(self.oph, 1, float(precond[1]))

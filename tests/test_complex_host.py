@@ -221,3 +221,33 @@ def test_native_complex_dynamic_method(built, kw):
     assert np.all(np.linalg.norm(AX - got.evecs * got.evals, axis=0) <= 1.5 * kw["eps"] * aN)
     assert got.params["dynamicMethodSwitch"] in (-1, -2, -3)
     assert got.stats["numMatvecs"] <= 4 * ref.stats["numMatvecs"]      # (the switch follows measured times: the two runs may end on different methods)
+
+
+@pytest.mark.parametrize("name,method", [("jdqmr", "JDQMR"), ("jdqmr_etol", "JDQMR_ETol"), ("gd_olsen", "GD_Olsen_plusK")])
+def test_non_hermitian_preconditioner_counts_equal_the_reference(name, method):
+    """A NON-Hermitian complex diagonal preconditioner K = diag(A)(1 + 0.1 i w_j): x'K^-1 x of the skew projector is a
+    complex number (reference src/eigs/correction.c:969-977, inner_solve.c:737-741).  The product's host solver over
+    the plain-C kernels against the real reference's zprimme (tests/golden/reference_zprecond.json, made by
+    tests/golden/make_zprecond_golden.py): identical outer-iteration / matvec / restart / preconditioner counts."""
+    import ctypes as C
+    import json
+    import os
+    from primme_amd import _ffi as F
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_zprecond.json")))
+    N, fx = g["n"], g["cases"][name]
+    rp, ci, va, d, a = problems.hermitian_tridiag_graded(N)
+    rot = problems.zjacobi_rotation(N, g["gamma"])
+
+    def pc(x, ldx, y, ldy, bs, pp, ierr):
+        nb, lx, ly = bs[0], ldx[0], ldy[0]
+        X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(nb, lx * 2)).view(np.complex128)
+        Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(nb, ly * 2)).view(np.complex128)
+        for c in range(nb):
+            Y[c, :N] = X[c, :N] / (d * rot)
+        ierr[0] = 0
+    r = eigsh(Operator(N, csr=(rp, ci, va)), backend="hostcheck", dtype=np.complex128, numEvals=4, eps=1e-10, aNorm=2001.0,
+              maxMatvecs=20000, v0=problems.rational_complex_start_vector(N), method=method, user_precond=F.BLOCK_OP(pc))
+    assert r.ret == fx["ret"] == 0 and r.initSize == 4
+    assert np.max(np.abs(np.asarray(r.evals) - np.array(fx["evals"]))) <= 1e-10 * 2001.0
+    for k in ("numOuterIterations", "numMatvecs", "numRestarts", "numPreconds"):
+        assert r.stats[k] == fx["stats"][k], (k, r.stats[k], fx["stats"][k])
