@@ -37,8 +37,10 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
       HIPK_CHECK(hipHostGetDevicePointer(&fd, fh, 0));
       ctx->flag_host = (volatile unsigned long long *)fh;
       ctx->flag_dev = (unsigned long long *)fd;
-      HIPK_CHECK(hipMalloc((void **)&ctx->fin_counter, 64));
-      HIPK_CHECK(hipMemsetAsync(ctx->fin_counter, 0, 64, ctx->stream));   /* ordered before every kernel of this context */
+      /* [0, 8): ticket of the separate second-stage launches; [8, 8 + 1 + HIPK_FIN_MAXGROUPS): tickets of the in-kernel form */
+      const size_t cbytes = sizeof(unsigned int) * (8 + 1 + HIPK_FIN_MAXGROUPS + 7);
+      HIPK_CHECK(hipMalloc((void **)&ctx->fin_counter, cbytes));
+      HIPK_CHECK(hipMemsetAsync(ctx->fin_counter, 0, cbytes, ctx->stream));   /* ordered before every kernel of this context */
       HIPK_CHECK(hipStreamSynchronize(ctx->stream));
       ctx->arrive_counter = ctx->fin_counter + 8;
       ctx->seq_issued = 0;
@@ -380,6 +382,14 @@ int hipk_finalize_partials_strided(hipk_ctx *ctx, const double *partials, int nb
       double *out_dev) {
    return launch_finalize<true>(ctx, partials, nblocks, pstride, nout, out_dev);
 }
+
+/* which kernels run their second stage in-kernel (hipk_internal.h: hipk_fin_args) */
+static int g_fin_mask = -1;
+int hipk_inkernel_fin_mask(void) {
+   if (g_fin_mask < 0) { const char *e = getenv("HIPK_INKERNEL_FIN"); g_fin_mask = e ? atoi(e) : 7; }
+   return g_fin_mask;
+}
+extern "C" int hipk_set_inkernel_fin(int mask) { const int old = hipk_inkernel_fin_mask(); g_fin_mask = mask & 7; return old; }
 
 /* ---- cross-rank second stage (see hipk_internal.h: hipk_ctx.xr) ---- */
 extern "C" void hipk_xreduce_arm(hipk_ctx *ctx) { if (ctx->xr) ctx->xr_armed = 1; }

@@ -125,35 +125,49 @@ static inline hipk_fin_flag hipk_next_flag(hipk_ctx *ctx, const double *out_dev)
    else ctx->need_sync = 1;      /* a reduction whose results the flag does not cover */
    return f;
 }
-/* In-kernel second stage: the workgroup that arrives last adds the per-block partials itself (fixed
- * order, so results stay bit-reproducible), stores the results in HBM and in the pinned mirror and
- * publishes the completion flag — no separate finalize launch.  Arguments a kernel needs for it;
- * enabled == 0 (the default, see below): the kernel only writes its partials (o-major:
- * partials[o * nblocks + block]) and a finalize launch follows. */
+/* In-kernel second stage, two levels, no fence (round 4): the workgroups of a launch form GROUPS of `gsize` consecutive
+ * blocks.  Every workgroup stores its partial sums WRITE-THROUGH (agent-scope relaxed atomic stores = `sc1` stores, o-major:
+ * partials[o * nblocks + block]), drains them (s_waitcnt vmcnt(0)) and takes a ticket of its group; the last arriver of
+ * a group adds the group's partials in block order (sc1 loads), stores the group sums write-through and takes a ticket of
+ * the launch; the last group leader adds the group sums in group order, (peer-to-peer transport: exchanges them with the
+ * other ranks,) stores the results in HBM and in the pinned mirror and publishes the completion flag.  Group membership
+ * and both summation orders are fixed by the launch geometry, not by arrival: results are bit-reproducible.
+ * Round 2's form paid an agent-scope RELEASE per workgroup (`buffer_wbl2`: the XCD's whole dirty L2, i.e. the kernel's own
+ * output stream) and lost 2x; write-through stores of the few partial sums need no release at all (MI355X_MICROARCH.md,
+ * "valid forms": sc1 stores and loads on both sides).  What it saves: the separate second-stage launch = its ~2.5 us plus
+ * one more dependent kernel boundary, three times per block-size-1 iteration; the first level overlaps the streaming of
+ * the workgroups that are still running, the serial tail is ngroups <= 256 loads per output. */
 struct hipk_fin_args {
    double *out, *out_host;          /* results (device) and their pinned mirror (device address, may be NULL) */
-   unsigned int *arrive;            /* device counter, zero between launches */
+   unsigned int *arrive;            /* device counters, zero between launches: [0] launch ticket, [1 + g] group tickets */
+   double *group;                   /* device: group sums [nout][ngroups] */
    hipk_fin_flag flag;              /* completion flag record (flag == NULL: none) */
-   int enabled;
+   hipk_xr_dev xr;                  /* tab != NULL: the results are exchanged with the other ranks before they are stored */
+   int enabled, gsize;
 };
-/* OFF by default (HIPK_INKERNEL_FIN=<mask> turns it on per kernel, read once; 7 = everywhere): measured on the MI355X it LOSES — every
- * workgroup pays an agent-scope release (L2 write-back) before its ticket, and with the thousands of
- * workgroups of the streaming kernels that costs far more than the finalize launch it saves
- * (configs[1]: 588 us per outer iteration with it, 258 us without; the fused SpMV 326 us instead of 45).
- * Kept as a correct, tested alternative for kernels with few workgroups. */
+/* HIPK_INKERNEL_FIN=<mask> selects the kernels (read once; default 7 = all three of the block-size-1 iteration, 0 = the
+ * separate second-stage launches) */
 /* bit mask: 1 = fused residual kernel (2 workgroups per CU), 2 = Gram-Schmidt update, 4 = fused SpMV */
 enum { HIPK_FIN_RITZ = 1, HIPK_FIN_PROJECT = 2, HIPK_FIN_SPMV = 4 };
-static inline int hipk_inkernel_fin_mask(void) {
-   static int v = -1;
-   if (v < 0) { const char *e = getenv("HIPK_INKERNEL_FIN"); v = e ? atoi(e) : 0; }
-   return v;
-}
-static inline hipk_fin_args hipk_make_fin(hipk_ctx *ctx, double *out_dev, int kind) {
+#define HIPK_FIN_MAXGROUPS 256
+int hipk_inkernel_fin_mask(void);          /* hipk_core.hip; hipk_set_inkernel_fin(mask) changes it at run time (A/B tests) */
+int hipk_reserve_partials(hipk_ctx *ctx, size_t n);
+/* nblocks workgroups, nout outputs per workgroup; the partials buffer must hold nblocks*nout + nout*HIPK_FIN_MAXGROUPS doubles
+ * (hipk_make_fin reserves it: call it BEFORE taking ctx->partials) */
+static inline hipk_fin_args hipk_make_fin(hipk_ctx *ctx, double *out_dev, int kind, int nblocks, int nout) {
    hipk_fin_args fa;
+   memset(&fa, 0, sizeof(fa));
    fa.out = out_dev; fa.out_host = hipk_mirror_of(ctx, out_dev); fa.arrive = ctx->arrive_counter;
-   fa.enabled = (hipk_inkernel_fin_mask() & kind) && ctx->arrive_counter != NULL;
-   fa.flag.flag = NULL; fa.flag.counter = NULL; fa.flag.seq = 0;
-   if (fa.enabled) fa.flag = hipk_next_flag(ctx, out_dev);
+   fa.enabled = (hipk_inkernel_fin_mask() & kind) && ctx->arrive_counter != NULL && nblocks > 0 && nout > 0;
+   if (fa.enabled) {
+      int g = 8;
+      while ((nblocks + g - 1) / g > HIPK_FIN_MAXGROUPS) g *= 2;
+      fa.gsize = g;
+      if (hipk_reserve_partials(ctx, (size_t)nblocks * nout + (size_t)nout * HIPK_FIN_MAXGROUPS)) { fa.enabled = 0; return fa; }
+      fa.group = ctx->partials + (size_t)nblocks * nout;
+      fa.xr = hipk_xr_take(ctx, out_dev, nout);
+      fa.flag = hipk_next_flag(ctx, out_dev);
+   }
    return fa;
 }
 void hipk_note_turnaround(hipk_ctx *ctx);
@@ -256,40 +270,72 @@ __device__ __forceinline__ void hipk_publish_flag(const hipk_fin_flag &f, unsign
 
 __device__ __forceinline__ double hipk_wave_sum_fwd(double v);
 
+/* write-through store of a partial sum when the launch finalises in-kernel, plain store otherwise */
+__device__ __forceinline__ void hipk_pstore(const hipk_fin_args &fa, double *p, double v) {
+   if (fa.enabled) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   else *p = v;
+}
+__device__ __forceinline__ double hipk_pload(const double *p) {
+   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 /* Called by EVERY thread of EVERY workgroup at the end of a kernel whose partials are o-major
- * (partials[o * nblocks + block]); `s_last` is an int in LDS.  Hand-off as in cdna_hip_programming.md
- * (in-launch split-K reduction): all stores drained, one agent-scope release per workgroup, relaxed
- * ticket, the last arriver takes one agent-scope acquire and reads every slab with plain loads. */
-__device__ __forceinline__ void hipk_inkernel_finalize(const double *__restrict__ partials, int nout, unsigned nblocks,
+ * (partials[o * nblocks + block], stored with hipk_pstore); `s_last` is an int in LDS.  See hipk_fin_args. */
+__device__ __forceinline__ void hipk_inkernel_finalize(double *__restrict__ partials, int nout, unsigned nblocks,
       const hipk_fin_args &fa, int *s_last) {
    if (!fa.enabled) return;
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+   const unsigned G = (unsigned)fa.gsize, g = blockIdx.x / G, ng = (nblocks + G - 1) / G;
+   const unsigned gfirst = g * G, gcount = (gfirst + G <= nblocks) ? G : nblocks - gfirst;
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* this wave's write-through partials have left */
    __syncthreads();
    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned t = __hip_atomic_fetch_add(fa.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_last = (t == nblocks - 1) ? 1 : 0;
-      if (t == nblocks - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const unsigned t = __hip_atomic_fetch_add(fa.arrive + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_last = (t == gcount - 1) ? 1 : 0;
    }
    __syncthreads();
    if (!*s_last) return;
-   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-   for (int o = wv; o < nout; o += nw) {
-      const double *row = partials + (size_t)o * nblocks;
+   /* group leader: the group's partials in block order */
+   for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+      const double *row = partials + (size_t)o * nblocks + gfirst;
       double acc = 0.0;
-      for (unsigned b = lane; b < nblocks; b += 64) acc += row[b];
-      acc = hipk_wave_sum_fwd(acc);
-      if (lane == 0) {
-         fa.out[o] = acc;
-         if (fa.out_host) fa.out_host[o] = acc;
-      }
+      for (unsigned i = 0; i < gcount; i++) acc += hipk_pload(row + i);
+      __hip_atomic_store(fa.group + (size_t)o * ng + g, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    }
-   __threadfence_system();            /* results (device + pinned) visible before the flag */
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();
    if (threadIdx.x == 0) {
-      *fa.arrive = 0;
-      if (fa.flag.flag) *(volatile unsigned long long *)fa.flag.flag = fa.flag.seq;
+      __hip_atomic_store(fa.arrive + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned t = __hip_atomic_fetch_add(fa.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_last = (t == ng - 1) ? 1 : 0;
+   }
+   __syncthreads();
+   if (!*s_last) return;
+   /* the last group leader: the group sums in group order; one 16-lane part of a wave per output */
+   const int lane = threadIdx.x & 63, sub = lane & 15, part = (int)(threadIdx.x >> 4), nparts = (int)(blockDim.x >> 4);
+   for (int o0 = 0; o0 < nout; o0 += nparts) {
+      const int o = o0 + part;
+      const bool live = o < nout;
+      double acc = 0.0;
+      if (live) {
+         const double *row = fa.group + (size_t)o * ng;
+         for (unsigned i = sub; i < ng; i += 16) acc += hipk_pload(row + i);
+      }
+      /* 16 lanes -> 1, fixed order */
+      acc += __shfl_down(acc, 8, 16);
+      acc += __shfl_down(acc, 4, 16);
+      acc += __shfl_down(acc, 2, 16);
+      acc += __shfl_down(acc, 1, 16);
+      acc = __shfl(acc, lane & 48, 64);
+      if (fa.xr.tab) acc = hipk_xr_exchange(fa.xr, (unsigned)(live ? o : 0), acc, live);
+      if (live && sub == 0) {
+         fa.out[o] = acc;
+         if (fa.out_host) __hip_atomic_store(fa.out_host + o, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+   }
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* the mirrored results are out before the flag */
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      __hip_atomic_store(fa.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fa.flag.flag) __hip_atomic_store(fa.flag.flag, fa.flag.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
    }
 }
 

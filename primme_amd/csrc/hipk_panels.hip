@@ -542,8 +542,8 @@ project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *X,
       }
       __syncthreads();
       if (threadIdx.x < nxv)
-         partials[(size_t)(c0 + threadIdx.x) * gridDim.x + blockIdx.x] =
-               (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+         hipk_pstore(fa, partials + (size_t)(c0 + threadIdx.x) * gridDim.x + blockIdx.x,
+               (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]));
       hipk_inkernel_finalize(partials, nx, gridDim.x, fa, &s_last);
    }
 }
@@ -671,12 +671,12 @@ static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
       int ldcoef, T *X, int64_t ldX, T *Xout, int64_t ldXout, int nx, double *nrm2_dev) {
    int gx = hipk_grid_for_rows(ctx, m / VW + 1, HIPK_BLOCK * 2, 4);
    if (nrm2_dev && hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
-   double *part = nrm2_dev ? ctx->partials : NULL;
    dim3 block(HIPK_BLOCK);
    /* one launch covers all columns: its last workgroup finalises the norms itself */
    hipk_fin_args fa;
    memset(&fa, 0, sizeof(fa));
-   if (nrm2_dev && (nx == 1 || nx == 2 || nx == 4 || nx == 8)) fa = hipk_make_fin(ctx, nrm2_dev, HIPK_FIN_PROJECT);
+   if (nrm2_dev && (nx == 1 || nx == 2 || nx == 4 || nx == 8)) fa = hipk_make_fin(ctx, nrm2_dev, HIPK_FIN_PROJECT, gx, nx);
+   double *part = nrm2_dev ? ctx->partials : NULL;      /* after hipk_make_fin: it may have grown the buffer */
    const int pslot = hipk_prof_begin(HIPK_PROF_PROJECT, ctx->stream, (double)m * sizeof(T) * ((double)sa.total * ((nx + 7) / 8) + 2.0 * nx));
    for (int c0 = 0; c0 < nx;) {
       int rem = nx - c0;
@@ -1398,24 +1398,24 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
 #pragma unroll
    for (int jj = 0; jj < CPW; jj++) {
       const double t = hipk_wave_sum(ov[jj]);
-      if (lane == 0 && j0 + jj < k) pcol[(size_t)(j0 + jj) * nb] = t;
+      if (lane == 0 && j0 + jj < k) hipk_pstore(fa, pcol + (size_t)(j0 + jj) * nb, t);
       if (WT) {
          const double u = hipk_wave_sum(ow[WT ? jj : 0]);
-         if (lane == 0 && j0 + jj < k) pcol[(size_t)(k + L + 1 + j0 + jj) * nb] = u;
+         if (lane == 0 && j0 + jj < k) hipk_pstore(fa, pcol + (size_t)(k + L + 1 + j0 + jj) * nb, u);
       }
    }
    if (QPW > 0) {
 #pragma unroll
       for (int qq = 0; qq < QN; qq++) {
          const double t = hipk_wave_sum(oq[qq]);
-         if (lane == 0 && q0 + qq < L) pcol[(size_t)(k + q0 + qq) * nb] = t;
+         if (lane == 0 && q0 + qq < L) hipk_pstore(fa, pcol + (size_t)(k + q0 + qq) * nb, t);
          if (WT) {
             const double u = hipk_wave_sum(og[WT ? qq : 0]);
-            if (lane == 0 && q0 + qq < L) pcol[(size_t)(2 * k + L + 1 + q0 + qq) * nb] = u;
+            if (lane == 0 && q0 + qq < L) hipk_pstore(fa, pcol + (size_t)(2 * k + L + 1 + q0 + qq) * nb, u);
          }
       }
    }
-   { const double t = hipk_wave_sum(n2); if (lane == 0 && wv == 0) pcol[(size_t)(k + L) * nb] = t; }
+   { const double t = hipk_wave_sum(n2); if (lane == 0 && wv == 0) hipk_pstore(fa, pcol + (size_t)(k + L) * nb, t); }
    hipk_inkernel_finalize(partials, nout, gridDim.x, fa, &s_last);
 }
 
@@ -1466,7 +1466,7 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + 1));
    int rc;
-   const hipk_fin_args fa = hipk_make_fin(ctx, out_dev, HIPK_FIN_RITZ);
+   const hipk_fin_args fa = hipk_make_fin(ctx, out_dev, HIPK_FIN_RITZ, gx, nout);
    if (vec) rc = want_wtr ? ritz_cgs_k<T, VWT, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa)
                           : ritz_cgs_k<T, VWT, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
    else rc = want_wtr ? ritz_cgs_k<T, 1, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa)

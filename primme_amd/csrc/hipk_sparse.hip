@@ -191,7 +191,7 @@ csr_stream_kernel(const int4 *__restrict__ tileinfo, int ntiles, const int32_t *
       const double t = hipk_wave_sum(dotp);
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
       __syncthreads();
-      if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (threadIdx.x == 0) hipk_pstore(fa, partials + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]));
       hipk_inkernel_finalize(partials, 1, gridDim.x, fa, &s_last);
    }
 }
@@ -874,7 +874,7 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    const int gx = ((A->ntiles + 7) / 8) * 8;
    if (hipk_reserve_partials(ctx, (size_t)gx)) return -2;
    const double es = A->dt == HIPK_F64 ? 8 : 4;
-   const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV);
+   const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV, gx, 1);
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
 #define LAUNCH_FUSED(TT, C16V, NTV) hipLaunchKernelGGL((csr_stream_kernel<TT, true, C16V, NTV>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr, \
             A->colind, csr16(A), A->row0 - A->c16back, (const TT *)A->values, (const TT *)x, A->nrows, (TT *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo, \
