@@ -317,8 +317,10 @@ int hipk_csr_panels(const hipk_csr *A);
 double hipk_csr_streamed_bytes(const hipk_csr *A);
 /* Second stage of the reductions of the block-size-1 iteration: bit 1 fused residual pass, 2 Gram-Schmidt update, 4 fused
  * SpMV run it inside the producing launch (two-level, write-through partial sums, csrc/hipk_internal.h); 0 = a separate
- * launch each.  Default 7 (environment HIPK_INKERNEL_FIN overrides).  Returns the previous mask.  Both forms give
- * bit-reproducible sums; they differ from each other in the last bits (different, fixed summation orders). */
+ * launch each.  Default 0: the in-kernel form is correct but slower on the MI355X (a workgroup waits ~5 us for its
+ * write-through partial sums and its ticket, csrc/hipk_internal.h); environment HIPK_INKERNEL_FIN overrides.  Returns the
+ * previous mask.  Both forms give bit-reproducible sums; they differ from each other in the last bits (different, fixed
+ * summation orders). */
 int hipk_set_inkernel_fin(int mask);
 /* device copy bandwidth probe: copies `bytes` src->dst `reps` times, returns GB/s (read+write) */
 int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);

@@ -386,7 +386,7 @@ int hipk_finalize_partials_strided(hipk_ctx *ctx, const double *partials, int nb
 /* which kernels run their second stage in-kernel (hipk_internal.h: hipk_fin_args) */
 static int g_fin_mask = -1;
 int hipk_inkernel_fin_mask(void) {
-   if (g_fin_mask < 0) { const char *e = getenv("HIPK_INKERNEL_FIN"); g_fin_mask = e ? atoi(e) : 7; }
+   if (g_fin_mask < 0) { const char *e = getenv("HIPK_INKERNEL_FIN"); g_fin_mask = e ? atoi(e) : 0; }
    return g_fin_mask;
 }
 extern "C" int hipk_set_inkernel_fin(int mask) { const int old = hipk_inkernel_fin_mask(); g_fin_mask = mask & 7; return old; }

@@ -133,10 +133,13 @@ static inline hipk_fin_flag hipk_next_flag(hipk_ctx *ctx, const double *out_dev)
  * other ranks,) stores the results in HBM and in the pinned mirror and publishes the completion flag.  Group membership
  * and both summation orders are fixed by the launch geometry, not by arrival: results are bit-reproducible.
  * Round 2's form paid an agent-scope RELEASE per workgroup (`buffer_wbl2`: the XCD's whole dirty L2, i.e. the kernel's own
- * output stream) and lost 2x; write-through stores of the few partial sums need no release at all (MI355X_MICROARCH.md,
- * "valid forms": sc1 stores and loads on both sides).  What it saves: the separate second-stage launch = its ~2.5 us plus
- * one more dependent kernel boundary, three times per block-size-1 iteration; the first level overlaps the streaming of
- * the workgroups that are still running, the serial tail is ngroups <= 256 loads per output. */
+ * output stream) and lost 2x.  This form needs no release (MI355X_MICROARCH.md, "valid forms": sc1 stores and loads on both
+ * sides) and is correct (the whole GPU suite runs green with it, profiles/r04_inkernel_second_stage_ab.txt) — and it still
+ * LOSES on the MI355X: a workgroup cannot leave before its write-through stores are acknowledged and its ticket has come
+ * back, ~5 us during which its slot streams nothing.  Measured per launch against the separate second-stage launch
+ * (~2.5 us + one kernel boundary): fused residual pass (512 workgroups) +6.6 us, Gram-Schmidt update +5.5 us, fused SpMV
+ * (6 840 workgroups) +37 us; BASELINE configs[1] 205 -> 241 us per outer iteration with all three, 209 with the residual
+ * pass alone.  OFF by default; kept as the tested alternative (HIPK_INKERNEL_FIN=<mask>, hipk_set_inkernel_fin). */
 struct hipk_fin_args {
    double *out, *out_host;          /* results (device) and their pinned mirror (device address, may be NULL) */
    unsigned int *arrive;            /* device counters, zero between launches: [0] launch ticket, [1 + g] group tickets */
@@ -145,8 +148,7 @@ struct hipk_fin_args {
    hipk_xr_dev xr;                  /* tab != NULL: the results are exchanged with the other ranks before they are stored */
    int enabled, gsize;
 };
-/* HIPK_INKERNEL_FIN=<mask> selects the kernels (read once; default 7 = all three of the block-size-1 iteration, 0 = the
- * separate second-stage launches) */
+/* HIPK_INKERNEL_FIN=<mask> selects the kernels (read once; default 0 = the separate second-stage launches) */
 /* bit mask: 1 = fused residual kernel (2 workgroups per CU), 2 = Gram-Schmidt update, 4 = fused SpMV */
 enum { HIPK_FIN_RITZ = 1, HIPK_FIN_PROJECT = 2, HIPK_FIN_SPMV = 4 };
 #define HIPK_FIN_MAXGROUPS 256
