@@ -11,6 +11,7 @@ import pytest
 from primme_amd import _ffi as F
 from primme_amd import problems
 from kernel_harness import Dev, Host, segs_array, NPDT
+import checkers
 
 pytestmark = pytest.mark.gpu
 
@@ -389,6 +390,52 @@ def test_csr_matvec(built, dt, ncols):
         tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
         assert np.max(np.abs(res[0] - res[1])) <= tol * (1 + np.abs(res[1]).max()), name
         assert np.max(np.abs(res[1] - ref)) <= tol * (1 + np.abs(ref).max()), name
+
+
+def test_inkernel_second_stage_agrees_with_separate_launches(built):
+    """The alternative second stage of the three reductions of a block-size-1 iteration (csrc/hipk_internal.h:
+    two-level, inside the producing launch, write-through partial sums; off by default because it is slower): same
+    sums as the separate launches up to the summation order, bit-reproducible from launch to launch (40 launches of the
+    fused residual pass under load), and a whole solve through it converges to the same pairs."""
+    lib = F.load_product()
+    lib.hipk_set_inkernel_fin.argtypes = [C.c_int]
+    m, k, L = 400_003, 14, 6
+    rng = np.random.default_rng(5)
+    ld = m + 3
+    V = rng.standard_normal((k + 1, ld)); W = rng.standard_normal((k + 1, ld)); Q = rng.standard_normal((L, ld))
+    h = np.ascontiguousarray(rng.standard_normal(k) / np.sqrt(k))
+    outs = {}
+    old = lib.hipk_set_inkernel_fin(0)
+    try:
+        for mask in (0, 7):
+            lib.hipk_set_inkernel_fin(mask)
+            side = Dev()
+            v, w, q = side.arr(V), side.arr(W), side.arr(Q)
+            out = side.arr(np.zeros(2 * (k + L) + 1))
+            seen = []
+            for rep in range(40):
+                assert side.lib.hipk_ritz_residual_overlaps(side.ctx, F.HIPK_F64, m, side.ptr(v), side.ptr(w), ld, k, h.ctypes.data_as(C.c_void_p),
+                                                            C.c_double(0.37), side.ptr(v, k * ld), side.ptr(q), ld, L, 1, side.ptr(out)) == 0
+                seen.append(side.get(out).copy())
+            for s_ in seen[1:]:
+                assert np.array_equal(s_, seen[0]), mask          # reproducible bits
+            outs[mask] = seen[0]
+            side.close()
+        scale = np.sqrt(m) * 4
+        assert np.max(np.abs(outs[0] - outs[7])) <= 1e-12 * scale * max(1.0, np.abs(outs[0]).max() / scale)
+        # a whole solve through the in-kernel form
+        dims = (40, 41, 42)
+        rp, ci, va, n = problems.laplacian_csr(dims)
+        kw = dict(numEvals=6, method="GD_plusK", eps=1e-9, aNorm=12.0, v0=problems.start_vector(n))
+        lib.hipk_set_inkernel_fin(0)
+        a = checkers.eigsh(checkers.Operator(n, csr=(rp, ci, va)), backend="hip", **kw)
+        lib.hipk_set_inkernel_fin(7)
+        b = checkers.eigsh(checkers.Operator(n, csr=(rp, ci, va)), backend="hip", **kw)
+        assert a.ret == 0 and b.ret == 0
+        assert np.max(np.abs(a.evals - b.evals)) <= 1e-11 * 12.0
+        assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= max(2, 0.02 * a.stats["numOuterIterations"])
+    finally:
+        lib.hipk_set_inkernel_fin(old)
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
