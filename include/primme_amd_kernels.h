@@ -61,8 +61,13 @@ int  hipk_malloc(hipk_ctx *ctx, size_t bytes, void **dptr);
 int  hipk_free(hipk_ctx *ctx, void *dptr);
 int  hipk_host_alloc(hipk_ctx *ctx, size_t bytes, void **hptr); /* pinned          */
 int  hipk_host_free(hipk_ctx *ctx, void *hptr);
-int  hipk_h2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async  */
-int  hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async  */
+/* Host <-> device copies on the context's stream.  STREAM-ORDERED (asynchronous) when the host side is pinned memory:
+ * a hipk_host_alloc buffer (<= 1 MB of it: a copy kernel through the mapped address, no runtime copy engine) or pinned
+ * memory of the caller's (hipHostMalloc / hipHostRegister, recognised through hipPointerGetAttributes).  For PAGEABLE host
+ * memory (malloc, numpy, stack) the copy goes in chunks through the context's pinned staging buffer (grows on demand up
+ * to 32 MB, kept for the life of the context) and is COMPLETE ON RETURN: the stream is drained per chunk. */
+int  hipk_h2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);
+int  hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);
 int  hipk_d2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async  */
 int  hipk_memset0(hipk_ctx *ctx, void *dst, size_t bytes);
 int  hipk_sync(hipk_ctx *ctx);

@@ -164,6 +164,7 @@ static int solve_host(void *evals, void *evecs, void *resNorms, primme_params *p
    primme->stats = q->stats;
    primme->initSize = q->initSize;
    primme->aNorm = q->aNorm; primme->BNorm = q->BNorm; primme->invBNorm = q->invBNorm;
+   primme->eps = q->eps;            /* the default the solver fills in when eps was 0 (primme_c.c leaves it in the caller's struct) */
    primme->dynamicMethodSwitch = q->dynamicMethodSwitch;
    primme->correctionParams.maxInnerIterations = q->correctionParams.maxInnerIterations;   /* the dynamic method's choice */
    for (int i = 0; i < 4; i++) primme->iseed[i] = q->iseed[i];

@@ -61,6 +61,7 @@ extern "C" int hipk_ctx_destroy(hipk_ctx *ctx) {
    if (ctx->partials) (void)hipFree(ctx->partials);
    if (ctx->jobtab) (void)hipFree(ctx->jobtab);
    if (ctx->fin_counter) (void)hipFree(ctx->fin_counter);
+   if (ctx->stage) (void)hipHostFree(ctx->stage);
    if (ctx->flag_host) (void)hipHostFree((void *)ctx->flag_host);
    (void)hipEventDestroy(ctx->ev0);
    (void)hipEventDestroy(ctx->ev1);
@@ -107,15 +108,22 @@ static void pinned_note(const void *p, size_t bytes, bool add) {
    void *dp = NULL;
    if (add && hipHostGetDevicePointer(&dp, (void *)p, 0) != hipSuccess) { dp = NULL; (void)hipGetLastError(); }
    while (g_pinned_lock.test_and_set(std::memory_order_acquire)) { }
+   bool placed = !add;
    for (int i = 0; i < HIPK_PINNED_MAX; i++) {
       if (add ? g_pinned[i].lo == NULL : g_pinned[i].lo == (const char *)p) {
          g_pinned[i].lo = add ? (const char *)p : NULL;
          g_pinned[i].hi = add ? (const char *)p + bytes : NULL;
          g_pinned[i].dev = add ? (const char *)dp : NULL;
+         placed = true;
          break;
       }
    }
    g_pinned_lock.clear(std::memory_order_release);
+   static bool said = false;
+   if (!placed && !said) {
+      said = true;       /* still correct: such a buffer is recognised through hipPointerGetAttributes, without the copy kernel */
+      fprintf(stderr, "primme_amd: more than %d pinned buffers alive; further ones take the runtime's copy path\n", HIPK_PINNED_MAX);
+   }
 }
 /* is [p, p + bytes) inside one of the library's pinned buffers?  *dev (optional) gets the address a kernel reaches it by */
 static bool pinned_has(const void *p, size_t bytes, const char **dev = NULL) {
@@ -148,37 +156,52 @@ extern "C" int hipk_host_free(hipk_ctx *ctx, void *hptr) {
  * asynchronous copy straight from pageable memory leaves it to the runtime to pin and unpin the caller's pages on the
  * fly — with that variant the GPU suite aborted once inside hipStreamSynchronize and hung once at exit,
  * profiles/r03_gpu_suite_run3_aborted.txt.) */
+static int ctx_stage(hipk_ctx *ctx, size_t bytes, void **stage, size_t *cap) {
+   const size_t want = bytes < ((size_t)32 << 20) ? bytes : ((size_t)32 << 20);
+   if (want > ctx->stage_cap) {
+      if (ctx->stage) { HIPK_CHECK(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->stage); ctx->stage = NULL; ctx->stage_cap = 0; }
+      size_t c = (size_t)1 << 16;
+      while (c < want) c *= 2;
+      HIPK_CHECK(hipHostMalloc(&ctx->stage, c, hipHostMallocDefault));
+      ctx->stage_cap = c;
+   }
+   *stage = ctx->stage; *cap = ctx->stage_cap;
+   return 0;
+}
 int hipk_upload(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
    if (bytes == 0) return 0;
-   const size_t cap = bytes < ((size_t)32 << 20) ? bytes : ((size_t)32 << 20);
    void *stage = NULL;
-   HIPK_CHECK(hipHostMalloc(&stage, cap, hipHostMallocDefault));
-   int rc = 0;
-   for (size_t off = 0; off < bytes && !rc; off += cap) {
+   size_t cap = 0;
+   if (ctx_stage(ctx, bytes, &stage, &cap)) return -1;
+   for (size_t off = 0; off < bytes; off += cap) {
       const size_t n = bytes - off < cap ? bytes - off : cap;
       memcpy(stage, (const char *)src + off, n);
       if (hipMemcpyAsync((char *)dst + off, stage, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) rc = -1;
+            hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;      /* the staging buffer is reused by the next chunk */
    }
-   (void)hipHostFree(stage);
-   return rc;
+   return 0;
 }
 
 /* device -> host array of any kind, complete on return (the counterpart of hipk_upload) */
 int hipk_download(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
    if (bytes == 0) return 0;
-   const size_t cap = bytes < ((size_t)32 << 20) ? bytes : ((size_t)32 << 20);
    void *stage = NULL;
-   HIPK_CHECK(hipHostMalloc(&stage, cap, hipHostMallocDefault));
-   int rc = 0;
-   for (size_t off = 0; off < bytes && !rc; off += cap) {
+   size_t cap = 0;
+   if (ctx_stage(ctx, bytes, &stage, &cap)) return -1;
+   for (size_t off = 0; off < bytes; off += cap) {
       const size_t n = bytes - off < cap ? bytes - off : cap;
       if (hipMemcpyAsync(stage, (const char *)src + off, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) rc = -1;
-      else memcpy((char *)dst + off, stage, n);
+            hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+      memcpy((char *)dst + off, stage, n);
    }
-   (void)hipHostFree(stage);
-   return rc;
+   return 0;
+}
+/* pinned host memory the library did not allocate itself (the caller's hipHostMalloc / hipHostRegister): asynchronous copies
+ * may use it directly */
+static bool foreign_pinned(const void *p) {
+   hipPointerAttribute_t a;
+   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+   return a.type == hipMemoryTypeHost;
 }
 /* Small transfers between the library's pinned (mapped) buffers and HBM go through a copy KERNEL on the context's
  * stream instead of hipMemcpyAsync: the coefficient blocks and Ritz values a solver step uploads are a few KB, and a
@@ -203,7 +226,11 @@ static bool small_copy(hipk_ctx *ctx, void *dst_dev, const void *src_dev, size_t
 extern "C" int hipk_h2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
    if (!bytes) return 0;
    const char *sdev = NULL;
-   if (!pinned_has(src, bytes, &sdev)) return hipk_upload(ctx, dst, src, bytes);
+   if (!pinned_has(src, bytes, &sdev)) {
+      if (!foreign_pinned(src)) return hipk_upload(ctx, dst, src, bytes);
+      HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+      return 0;
+   }
    if (small_copy(ctx, dst, sdev, bytes)) return 0;
    HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
    return 0;
@@ -211,7 +238,11 @@ extern "C" int hipk_h2d(hipk_ctx *ctx, void *dst, const void *src, size_t bytes)
 extern "C" int hipk_d2h(hipk_ctx *ctx, void *dst, const void *src, size_t bytes) {
    if (!bytes) return 0;
    const char *ddev = NULL;
-   if (!pinned_has(dst, bytes, &ddev)) return hipk_download(ctx, dst, src, bytes);
+   if (!pinned_has(dst, bytes, &ddev)) {
+      if (!foreign_pinned(dst)) return hipk_download(ctx, dst, src, bytes);
+      HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      return 0;
+   }
    if (small_copy(ctx, (void *)ddev, src, bytes)) return 0;
    HIPK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
    return 0;

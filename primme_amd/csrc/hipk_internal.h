@@ -47,6 +47,10 @@ struct hipk_ctx {
     * NEXT finalize launch also exchanges its results with every rank through the mailboxes and stores the global
     * sums — local second stage + all-reduce + publication in one launch.  xr_lo/xr_count remember which results
     * are already global so that the solver's reduce step does not reduce them again. */
+   /* pinned staging buffer of hipk_upload / hipk_download (transfers from / to memory the library did not pin itself): grows
+    * on demand up to 32 MB, lives as long as the context */
+   void *stage;
+   size_t stage_cap;
    struct hipk_xreduce *xr;
    int xr_armed;
    const double *xr_lo;

@@ -39,9 +39,14 @@ static int sh_stream(svds_host_side *sd) {
    if (sd->ctx) return 0;
    return hipk_ctx_create(&sd->ctx, sd->q.queue);
 }
+/* the caller's struct as its callbacks may read it during the solve (the reference hands them the live struct) */
 static void sh_mirror(svds_host_side *sd) {
    sd->user->stats = sd->q.stats;
    sd->user->aNorm = sd->q.aNorm;
+   sd->user->initSize = sd->q.initSize;
+   sd->user->primme.stats = sd->q.primme.stats;
+   sd->user->primmeStage2.stats = sd->q.primmeStage2.stats;
+   for (int i = 0; i < 4; i++) sd->user->iseed[i] = sd->q.iseed[i];
 }
 
 /* rows of the input / output block of an operator application (primme_svds.h:140-157; mode of the
@@ -115,7 +120,7 @@ static int scall_c(void *a, void *b, void *c, primme_svds_params *p) { return hi
 static int svds_solve_host(void *svals, void *svecs, void *resNorms, primme_svds_params *ps, svds_dev_solver solver, size_t es) {
    if (!ps) return -4;
    if (!svals && !svecs && !resNorms) return solver(NULL, NULL, NULL, ps);     /* defaults query (primme_svds_c.c:205-209) */
-   if (!svals) return -17;       /* argument checks the device entry cannot make on a host pointer (its own codes) */
+   if (!svals) return -17;       /* the reference's codes for these three (primme_svds_c.c:1085-1090) */
    if (!svecs) return -18;
    if (!resNorms) return -19;
    if (ps->queue) return -21;    /* a device queue belongs to the device entry points (hip_?primme_svds) */
@@ -152,6 +157,7 @@ static int svds_solve_host(void *svals, void *svecs, void *resNorms, primme_svds
    ps->stats = q->stats;
    ps->initSize = q->initSize;
    ps->aNorm = q->aNorm;
+   ps->eps = q->eps;                /* the default filled in when eps was 0 */
    for (int i = 0; i < 4; i++) ps->iseed[i] = q->iseed[i];
    ps->primme.stats = q->primme.stats; ps->primmeStage2.stats = q->primmeStage2.stats;
    {
