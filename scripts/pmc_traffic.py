@@ -19,7 +19,9 @@ alg = None
 if len(sys.argv) > 5:
     try:
         bl = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
-        alg = (bl["roofline"] if workload == "lap3d_2m" else bl["north_star"]["roofline"])["alg_bytes_per_launch"]
+        # round 4: the bench line's main workload is lap2d_10m and configs[1] rides along as `configs1` (round 3: the other way round, `north_star`)
+        if bl.get("config", {}).get("workload", "").startswith(workload): alg = bl["roofline"]["alg_bytes_per_launch"]
+        else: alg = (bl.get("configs1") or bl.get("north_star"))["roofline"]["alg_bytes_per_launch"]
     except Exception:
         alg = None
 lines = [f"# {tag} — HBM traffic from PMC counters ({'BASELINE configs[1]' if workload == 'lap3d_2m' else 'north-star workload lap2d_10m, first outer iterations'}, one solve, separate --pmc passes)", "",
