@@ -119,3 +119,10 @@ def segs_array(side, segs):
         arr[i].ld = ld
         arr[i].ncols = nc
     return arr
+
+
+if __import__("os").environ.get("PRIMME_AMD_HARNESS_HOST_ONLY"):
+    # heap-corruption hunt (round 4): both sides of every kernel test on the plain-C oracle, so that the oracle's code runs
+    # under AddressSanitizer on a box without a GPU (the product-only entry points then fail: expected)
+    class Dev(Host):          # noqa: F811
+        name = "hip"
