@@ -117,6 +117,7 @@ int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) {
 int pa_comm_allreduce_publish(void *ci, struct hipk_ctx *ctx, double *d, int n) { (void)ci; (void)ctx; (void)d; (void)n; return 1; }
 int pa_comm_attach_ctx(void *ci, struct hipk_ctx *ctx) { (void)ci; (void)ctx; return 1; }
 void hipk_xreduce_arm(struct hipk_ctx *ctx) { (void)ctx; }
+int hipk_xreduce_available(struct hipk_ctx *ctx) { (void)ctx; return 0; }
 int hipk_xreduce_covered(struct hipk_ctx *ctx, const double *buf, int count) { (void)ctx; (void)buf; (void)count; return 0; }
 int pa_comm_failed(void *ci) { (void)ci; return 0; }
 

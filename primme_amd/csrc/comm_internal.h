@@ -25,6 +25,8 @@ void pa_ipc_detach(pa_ipc *x);
 int pa_ipc_host_allgather(pa_ipc *x, const void *mine, size_t bytes, void *all);
 /* 1 when every rank sits on its own device (RCCL can be brought up next to the mailboxes) */
 int pa_ipc_distinct_devices(pa_ipc *x);
+/* 0: only the host rendez-vous of this object works (the mailboxes did not come up on every rank) */
+int pa_ipc_gpu_ok(pa_ipc *x);
 /* in place: dbuf[0:count) <- sum over ranks, summed in rank order on every rank (identical bits everywhere).
  * mirror (device address of pinned host memory, may be NULL) receives a copy; `fin` (flag == NULL: none) is
  * published after the results are visible to the host: reduction + publication = ONE launch. */
@@ -55,7 +57,9 @@ struct primme_amd_comm {
    double *dbuf;           /* staging for the host-buffer path */
    double *hbuf;           /* its pinned host twin: the caller's (pageable) buffers never meet an asynchronous copy */
    size_t dbuf_cap;
-   pa_ipc *ipc;            /* IPC and HYBRID */
+   pa_ipc *ipc;            /* IPC and HYBRID: the mailboxes.  RCCL created from a mailbox id whose device side failed: NULL, the
+                              rendez-vous object lives on in `boot` for the host-side exchanges */
+   pa_ipc *boot;
 };
 
 

@@ -63,6 +63,7 @@ struct pa_ipc {
    long long timeout_ticks;
    hipk_xreduce xr;
    int alloc_kind;
+   int gpu_ok;                       /* the mailboxes are up; 0: only the host rendez-vous works (RCCL is then bootstrapped through it) */
 };
 
 static size_t mbox_gran_bytes(int P) { return (size_t)2 * P * IPC_SLOT * 16; }
@@ -367,36 +368,50 @@ int pa_ipc_attach(pa_ipc **out, const void *id128, int rank, int nranks) {
       for (int q = 0; q < p; q++)
          if (!strcmp(bus[p], bus[q])) x->distinct = 0;
 
+   /* from here on a failure is not fatal: every rank learns of it through the rendez-vous, the device side is torn down
+    * everywhere, and the communicator is told to take its collectives elsewhere (pa_ipc_gpu_ok) */
    if (!fail && (hipHostMalloc((void **)&x->err_host, 64, hipHostMallocMapped) != hipSuccess ||
                  hipHostGetDevicePointer((void **)&x->err_dev, x->err_host, 0) != hipSuccess)) fail = 1;
    if (!fail) *x->err_host = 0;
    if (!fail && (hipMalloc((void **)&x->tab_dev, sizeof(void *) * IPC_MAXR * 2) != hipSuccess ||
                  hipMalloc((void **)&x->ticket, 64) != hipSuccess || hipMemset(x->ticket, 0, 64) != hipSuccess)) fail = 1;
    x->bar_dev = x->tab_dev ? x->tab_dev + IPC_MAXR : NULL;
-   if (shm_agree(x, fail)) { pa_ipc_detach(x); return -43; }
-   if (region_open(x, &x->mbox, mbox_bytes(nranks)) || upload_tables(x)) { pa_ipc_detach(x); return -43; }
+   int bad = shm_agree(x, fail);
+   if (bad < 0) { pa_ipc_detach(x); return -43; }           /* the rendez-vous itself broke */
+   if (!bad) bad = region_open(x, &x->mbox, mbox_bytes(nranks)) != 0 || upload_tables(x) != 0;
+   bad = shm_agree(x, bad);
+   if (bad < 0) { pa_ipc_detach(x); return -43; }
 
    x->xr.tab = x->tab_dev; x->xr.nranks = nranks; x->xr.rank = rank; x->xr.slot_doubles = IPC_SLOT;
    x->xr.seq = &x->seq; x->xr.err_dev = x->err_dev; x->xr.timeout_ticks = x->timeout_ticks;
 
    /* self-test: a reduction with known sums and a short time limit, so that a transport that maps but does not
     * deliver (no peer access, an incoherent mapping) is found here and not in the solver */
-   {
+   if (!bad) {
       const long long keep = x->xr.timeout_ticks;
       x->xr.timeout_ticks = (long long)(5.0e8);
       double *d = NULL, h[3] = {1.0 + rank, 0.5 * (rank + 1), -2.0};
-      int bad = hipMalloc((void **)&d, sizeof(h)) != hipSuccess || hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess;
+      int tb = hipMalloc((void **)&d, sizeof(h)) != hipSuccess || hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess;
       hipk_fin_flag nof = {NULL, NULL, 0};
-      if (!bad) bad = pa_ipc_allreduce(x, NULL, d, 3, NULL, nof) != 0 || hipDeviceSynchronize() != hipSuccess ||
-                      hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess;
+      if (!tb) tb = pa_ipc_allreduce(x, NULL, d, 3, NULL, nof) != 0 || hipDeviceSynchronize() != hipSuccess ||
+                    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess;
       const double P = nranks;
-      if (!bad) bad = *x->err_host != 0 || h[0] != P + P * (P - 1) / 2 || h[1] != 0.5 * (P * (P + 1) / 2) || h[2] != -2.0 * P;
+      if (!tb) tb = *x->err_host != 0 || h[0] != P + P * (P - 1) / 2 || h[1] != 0.5 * (P * (P + 1) / 2) || h[2] != -2.0 * P;
       if (d) (void)hipFree(d);
       x->xr.timeout_ticks = keep;
-      if (bad) fprintf(stderr, "primme_amd: rank %d: the peer-to-peer mailbox self-test failed (err word %d)\n", rank, *x->err_host);
-      if (shm_agree(x, bad)) { pa_ipc_detach(x); return -43; }
+      if (getenv("PRIMME_AMD_IPC_FAIL_SELFTEST")) tb = 1;       /* test knob: exercise the fall-back */
+      if (tb) fprintf(stderr, "primme_amd: rank %d: the peer-to-peer mailbox self-test failed (err word %d)\n", rank, x->err_host ? *x->err_host : -1);
+      bad = shm_agree(x, tb);
+      if (bad < 0) { pa_ipc_detach(x); return -43; }
    }
-   if (getenv("PRIMME_AMD_COMM_VERBOSE") && rank == 0)
+   x->gpu_ok = !bad;
+   if (bad) {
+      if (rank == 0) fprintf(stderr, "primme_amd: the peer-to-peer mailboxes did not come up on every rank; the communicator falls back to RCCL\n");
+      (void)hipDeviceSynchronize();
+      region_close(x, &x->mbox);
+      if (x->err_host) *x->err_host = 0;
+   }
+   if (getenv("PRIMME_AMD_COMM_VERBOSE") && rank == 0 && x->gpu_ok)
       fprintf(stderr, "primme_amd: peer-to-peer transport up: %d ranks, %s devices, mailbox memory kind %d\n", nranks,
             x->distinct ? "distinct" : "shared", x->alloc_kind);
    *out = x;
@@ -419,6 +434,7 @@ void pa_ipc_detach(pa_ipc *x) {
 }
 
 int pa_ipc_distinct_devices(pa_ipc *x) { return x->distinct; }
+int pa_ipc_gpu_ok(pa_ipc *x) { return x && x->gpu_ok; }
 int pa_ipc_error(pa_ipc *x) { return x && x->err_host ? *(volatile int *)x->err_host : 0; }
 hipk_xreduce *pa_ipc_xreduce(pa_ipc *x) { return x ? &x->xr : NULL; }
 

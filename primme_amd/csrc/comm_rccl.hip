@@ -71,15 +71,23 @@ extern "C" int primme_amd_comm_create(primme_amd_comm **out, const void *id128, 
       if (pa_ipc_attach(&c->ipc, id128, rank, nranks)) { free(c); return -43; }
       if (pa_ipc_host_allgather(c->ipc, &mode, sizeof(int), modes)) { pa_ipc_detach(c->ipc); free(c); return -43; }
       mode = modes[0] == PA_COMM_RCCL ? PA_COMM_HYBRID : modes[0];
-      c->kind = (mode == PA_COMM_HYBRID && pa_ipc_distinct_devices(c->ipc) && nranks > 1) ? PA_COMM_HYBRID : PA_COMM_IPC;
-      if (c->kind == PA_COMM_HYBRID) {
-         /* RCCL next to the mailboxes: its id travels through the rendez-vous segment */
+      const int gpu_ok = pa_ipc_gpu_ok(c->ipc);
+      if (!gpu_ok && (mode == PA_COMM_IPC || !pa_ipc_distinct_devices(c->ipc))) {
+         /* the mailboxes were asked for explicitly, or ranks share a device (RCCL cannot serve that): no fall-back */
+         pa_ipc_detach(c->ipc); free(c);
+         return -43;
+      }
+      c->kind = !gpu_ok ? PA_COMM_RCCL
+              : (mode == PA_COMM_HYBRID && pa_ipc_distinct_devices(c->ipc) && nranks > 1) ? PA_COMM_HYBRID : PA_COMM_IPC;
+      if (c->kind != PA_COMM_IPC) {
+         /* RCCL next to (or instead of) the mailboxes: its id travels through the rendez-vous segment */
          char all[HIPK_XR_MAXRANKS][128];
          if (rank == 0 && ncclGetUniqueId(&id) != ncclSuccess) memset(&id, 0, sizeof(id));
          if (pa_ipc_host_allgather(c->ipc, &id, 128, all)) { pa_ipc_detach(c->ipc); free(c); return -43; }
          memcpy(&id, all[0], 128);
          NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
       }
+      if (!gpu_ok) { c->boot = c->ipc; c->ipc = NULL; }
    } else {
       c->kind = PA_COMM_RCCL;
       memcpy(&id, id128, sizeof(id) < 128 ? sizeof(id) : 128);
@@ -98,6 +106,7 @@ extern "C" int primme_amd_comm_destroy(primme_amd_comm *c) {
    hipStreamSynchronize(c->stream);
    if (c->kind != PA_COMM_IPC) ncclCommDestroy(c->comm);
    if (c->ipc) pa_ipc_detach(c->ipc);
+   if (c->boot) pa_ipc_detach(c->boot);
    (void)hipFree(c->dbuf);
    if (c->hbuf) (void)hipHostFree(c->hbuf);
    (void)hipStreamDestroy(c->stream);
@@ -284,13 +293,14 @@ extern "C" void primme_amd_svds_global_sum(void *sendBuf, void *recvBuf, int *co
 
 /* small integer exchange at set-up time (neighbour halo sizes) */
 extern "C" int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n, int64_t *all) {
-   if (c->ipc) {
+   if (c->ipc || c->boot) {
+      pa_ipc *hx = c->ipc ? c->ipc : c->boot;
       /* through the rendez-vous segment, PA_IPC_PAYLOAD bytes per rank and round */
       const int per = PA_IPC_PAYLOAD / (int)sizeof(int64_t);
       int64_t tmp[HIPK_XR_MAXRANKS * (PA_IPC_PAYLOAD / sizeof(int64_t))];
       for (int i0 = 0; i0 < n; i0 += per) {
          const int k = n - i0 < per ? n - i0 : per;
-         if (pa_ipc_host_allgather(c->ipc, mine + i0, (size_t)k * sizeof(int64_t), tmp)) return -43;
+         if (pa_ipc_host_allgather(hx, mine + i0, (size_t)k * sizeof(int64_t), tmp)) return -43;
          for (int p = 0; p < c->nranks; p++)
             for (int i = 0; i < k; i++) all[(size_t)p * n + i0 + i] = tmp[(size_t)p * k + i];
       }

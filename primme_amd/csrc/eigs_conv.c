@@ -285,13 +285,18 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
     * launch gathers from it while it writes the normalised vector into V(:,k) */
    const int fuse_tail = speculate2 && wtr && pa_fuse_tail_eligible(s);
    s->spec_fused = 0;
+   /* peer-to-peer transport: every reduction of the tail is exchanged inside the second stage of the launch that
+    * forms it (hipk_xreduce_arm), so the tail keeps its one-rank shape — |t|^2 stays on the device, the operator
+    * launch normalises on the fly, no scaling launches — and costs no reduction launch at all */
+   const int xr = s->parallel && s->dev_comm && hipk_xreduce_available(s->ctx);
+   if (xr) hipk_xreduce_arm(s->ctx);
    CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, rsrc, s->ld,
               fuse_tail ? TCOL(s, 0) : dstc, s->ld, 1, s->d_fov + nfov));
    /* Row-partitioned runs on the library's communicator: |t|^2 and t'At travel in ONE all-reduce.
     * The operator is applied to the un-normalised t (no scaling in the launch), both numbers are
     * reduced together, and V(:,k), W(:,k) are scaled afterwards with the value the host then has:
     * two all-reduces per outer iteration instead of three (each is latency, not bandwidth). */
-   const int merge_red = fuse_tail && s->parallel && s->dev_comm;
+   const int merge_red = fuse_tail && s->parallel && s->dev_comm && !xr;
    if (speculate2 && merge_red) {
       rc = fused_apply(s, TCOL(s, 0), NULL, dstc, WCOL(s, basisSize), s->d_fov + nfov + 1);
       if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
@@ -319,6 +324,7 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
       if (fuse_tail) {
          /* the library's own operator: normalisation, A t and t'At in one launch, reading the
           * un-normalised vector from the scratch column and rebuilding V(:,k) on the way */
+         if (xr) hipk_xreduce_arm(s->ctx);
          rc = fused_apply(s, TCOL(s, 0), s->d_fov + nfov, dstc, WCOL(s, basisSize), s->d_red);
          if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
          s->spec_fused = 1;
@@ -330,7 +336,10 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
          if (ierr) return PRIMME_USER_FAILURE;
       }
       if (wtr) {
-         if (!fuse_tail) CHK(hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red));
+         if (!fuse_tail) {
+            if (xr) hipk_xreduce_arm(s->ctx);
+            CHK(hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red));
+         }
          CHK(pa_reduce(s, s->d_red, 1, 0, 0));                 /* the one synchronisation */
          const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
          const double inv = 1.0 / sqrt(s->h_fov[nfov]);

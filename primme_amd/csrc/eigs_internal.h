@@ -56,6 +56,8 @@ int pa_comm_allreduce_publish(void *commInfo, hipk_ctx *ctx, double *dbuf, int c
 int pa_comm_attach_ctx(void *commInfo, hipk_ctx *ctx);
 /* arm the NEXT second-stage launch on the context as a cross-rank one (only with an attached communicator) */
 void hipk_xreduce_arm(hipk_ctx *ctx);
+/* 1 when a communicator of the peer-to-peer transport is attached to the context (arming has an effect) */
+int hipk_xreduce_available(hipk_ctx *ctx);
 /* 1 when [buf, buf+count) was produced by an armed launch since the last call: the sums are already global and
  * published (the record is consumed) */
 int hipk_xreduce_covered(hipk_ctx *ctx, const double *buf, int count);

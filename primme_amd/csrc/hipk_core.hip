@@ -424,6 +424,7 @@ extern "C" int hipk_set_inkernel_fin(int mask) { const int old = hipk_inkernel_f
 
 /* ---- cross-rank second stage (see hipk_internal.h: hipk_ctx.xr) ---- */
 extern "C" void hipk_xreduce_arm(hipk_ctx *ctx) { if (ctx->xr) ctx->xr_armed = 1; }
+extern "C" int hipk_xreduce_available(hipk_ctx *ctx) { return ctx && ctx->xr ? 1 : 0; }
 extern "C" int hipk_xreduce_covered(hipk_ctx *ctx, const double *buf, int count) {
    const int yes = ctx->xr_lo && buf >= ctx->xr_lo && buf + count <= ctx->xr_lo + ctx->xr_count;
    ctx->xr_lo = NULL; ctx->xr_count = 0;

@@ -66,3 +66,30 @@ def test_solver_through_rccl_reductions(built, kw):
     for k in ("numOuterIterations", "numMatvecs", "numRestarts"):
         assert abs(a.stats[k] - b.stats[k]) <= max(1, 0.02 * a.stats[k]), k
     lib.primme_amd_comm_destroy(comm)
+
+
+def test_mailboxes_that_do_not_come_up_fall_back_to_rccl(built):
+    """`auto`: when the peer-to-peer mailboxes fail their self-test on any rank, every rank learns of it through the
+    rendez-vous and the communicator comes up on RCCL instead (its id travels through the same rendez-vous)."""
+    import torch
+    lib = F.load_product()
+    lib.primme_amd_comm_transport.restype = C.c_char_p
+    lib.primme_amd_comm_transport.argtypes = [C.c_void_p]
+    lib.primme_amd_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    ok = _comm(lib)
+    assert lib.primme_amd_comm_transport(ok).decode() == "ipc"          # one rank: nothing for RCCL to add
+    lib.primme_amd_comm_destroy(ok)
+    os.environ["PRIMME_AMD_IPC_FAIL_SELFTEST"] = "1"
+    try:
+        comm = _comm(lib)
+    finally:
+        del os.environ["PRIMME_AMD_IPC_FAIL_SELFTEST"]
+    assert lib.primme_amd_comm_transport(comm).decode() == "rccl"
+    x = torch.arange(100, dtype=torch.float64, device="cuda")
+    assert lib.primme_amd_comm_allreduce(comm, None, x.data_ptr(), 100) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(100, dtype=torch.float64))
+    mine = (C.c_int64 * 2)(7, 9); allv = (C.c_int64 * 2)()
+    lib.primme_amd_comm_allgather_i64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    assert lib.primme_amd_comm_allgather_i64(comm, mine, 2, allv) == 0 and list(allv) == [7, 9]
+    lib.primme_amd_comm_destroy(comm)
