@@ -59,6 +59,8 @@ def pytest_sessionfinish(session, exitstatus):
 
 @pytest.hookimpl(trylast=True)
 def pytest_unconfigure(config):
+    if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return                      # a pytest-xdist worker reports to its controller on the way out
     if _session["gpu"] and _session["status"] is not None and not os.environ.get("PRIMME_AMD_TEST_NORMAL_EXIT"):
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(_session["status"])
