@@ -140,13 +140,16 @@ int pa_ipc_unique_id(void *id128) {
 
 /* ---- exported allocations --------------------------------------------------------------------------- */
 static int ipc_alloc(pa_ipc *x, void **p, size_t bytes) {
-   static int kind = -1;             /* PRIMME_AMD_IPC_ALLOC = uncached | fine | plain (measurement / bring-up knob) */
+   /* Memory that peers write and this device polls / reads must not sit in this device's L2: uncached, or fine-grained.
+    * Ordinary (coarse-grained) device memory is accepted only on request (PRIMME_AMD_IPC_ALLOC=plain: a bring-up knob for ranks
+    * that share one device) — a remote write over xGMI does not invalidate the owner's L2. */
+   static int kind = -1;             /* PRIMME_AMD_IPC_ALLOC = uncached (default) | fine | plain */
    if (kind < 0) {
       const char *e = getenv("PRIMME_AMD_IPC_ALLOC");
       kind = !e ? 0 : !strcmp(e, "fine") ? 1 : !strcmp(e, "plain") ? 2 : 0;
    }
    *p = NULL;
-   for (int k = kind; k < 3; k++) {
+   for (int k = kind; k < (kind == 2 ? 3 : 2); k++) {
       hipError_t e = k == 0 ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached)
                    : k == 1 ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) : hipMalloc(p, bytes);
       if (e == hipSuccess && *p) { x->alloc_kind = k; break; }
