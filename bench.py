@@ -198,10 +198,12 @@ def main():
         wl = WORKLOADS[name]
         dims = wl["dims"]
         n = int(np.prod(dims))
-        # row partition: contiguous slabs, remainder spread over the first ranks
-        base, rem = divmod(n, world)
-        nloc = base + (1 if rank < rem else 0)
-        row0 = rank * base + min(rank, rem)
+        # row partition: contiguous slabs of a multiple of 16 rows (the last rank takes the remainder): a slab with an odd
+        # number of rows puts every second column of the caller's evecs array (leading dimension nLocal) off the 16-byte
+        # boundary and the panel kernels then fall back to 8-byte loads (profiles/r04_two_ranks_one_device_kernel_stats.md)
+        base = (n // world) // 16 * 16
+        row0 = rank * base
+        nloc = base if rank < world - 1 else n - base * (world - 1)
         if args.operator == "csr":
             rp, ci, va, _ = problems.laplacian_csr(dims, row0=row0, nrows=nloc)
             op = Operator(n, csr=(rp, ci, va), row0=row0, nrows=nloc)
