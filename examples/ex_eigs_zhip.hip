@@ -67,7 +67,7 @@ int main(void) {
    const int ret = hip_zprimme(evals, evecs_dev, rnorms, &primme);
 
    double2 *evecs = (double2 *)malloc(sizeof(double2) * n * nev);
-   hipMemcpy(evecs, evecs_dev, sizeof(double2) * n * nev, hipMemcpyDeviceToHost);
+   (void)hipMemcpy(evecs, evecs_dev, sizeof(double2) * n * nev, hipMemcpyDeviceToHost);
    int bad = (ret != 0 || primme.initSize != nev);
    printf("hip_zprimme returned %d, %d pairs, %lld outer iterations, %lld matvecs\n", ret, primme.initSize,
          (long long)primme.stats.numOuterIterations, (long long)primme.stats.numMatvecs);
@@ -88,7 +88,7 @@ int main(void) {
       if (fabs(evals[k] - exact) > 1e-10 * 4.0 || sqrt(r2) > 1.5e-10 * 4.0 || fabs(sqrt(z2) - 1.0) > 1e-9) bad = 1;
    }
    free(evecs);
-   hipFree(evecs_dev);
+   (void)hipFree(evecs_dev);
    primme_free(&primme);
    return bad;
 }
