@@ -77,7 +77,9 @@ struct hipk_xr_dev {
 };
 static inline unsigned int hipk_xr_next_seq(hipk_xreduce *xr) {
    unsigned int q = ++*xr->seq;
-   if (q == 0) q = ++*xr->seq;      /* 0 is the tag of an empty mailbox */
+   /* wrap-around after 2^32 - 1 reductions: 0 is the tag of an empty mailbox, and the generation (tag & 1) must keep
+    * alternating (0xffffffff was odd), so the sequence continues at 2 */
+   if (q == 0) { *xr->seq = 2; q = 2; }
    return q;
 }
 static inline hipk_xr_dev hipk_xr_make(hipk_xreduce *xr) {

@@ -137,7 +137,8 @@ extern "C" int hipk_pb_build(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int64_t n,
    /* rows per tile: about tile_entries entries per (tile, panel) step, a power of two that the packed word and the LDS hold */
    const double per_row_panel = (double)nnz / (double)m / (double)P;
    int RT = 64;
-   while (RT < 4096 && RT < (1 << (32 - cb)) / 2 && RT * per_row_panel < (double)tile_entries) RT *= 2;
+   /* (2048 rows: the four waves of a workgroup then hold 64 KB of row sums in LDS, the most a launch gets without asking) */
+   while (RT < 2048 && RT < (1 << (32 - cb)) / 2 && RT * per_row_panel < (double)tile_entries) RT *= 2;
    if (RT > (1 << (32 - cb))) return 1;
    const int64_t ntiles = (m + RT - 1) / RT;
    if (ntiles * P + 1 > ((int64_t)1 << 31)) return 1;
