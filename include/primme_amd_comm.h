@@ -42,6 +42,11 @@ int primme_amd_comm_error(const primme_amd_comm *comm);
 /* dbuf[0:count) <- sum over the ranks (doubles, in place, stream-ordered): what primme_amd_global_sum does for
  * host buffers and what the solver does with its device-resident partial sums */
 int primme_amd_comm_allreduce(primme_amd_comm *comm, void *hip_stream, double *dbuf, int count);
+/* Neighbour exchange into caller-owned buffers: my first `send_lo_cnt` rows of every column go to rank-1 (they land in ITS `hi`),
+ * my last `send_hi_cnt` to rank+1 (ITS `lo`); column c of a halo buffer starts at c * count elements.  Stream-ordered on RCCL.
+ * On the peer-to-peer transport the rows land in the communicator's own zones first; this entry point then agrees on the zone
+ * size through the host rendez-vous (it SYNCHRONISES the ranks on the host) and copies out — the ready-made operator
+ * (primme_amd_operator_apply) uses the zones in place and does neither. */
 int primme_amd_comm_halo(primme_amd_comm *c, void *hip_stream, const void *x, int64_t ldx,
       int64_t nrows, int ncols, size_t elem, int64_t send_lo_cnt, int64_t send_hi_cnt, void *lo,
       int64_t recv_lo_cnt, void *hi, int64_t recv_hi_cnt);

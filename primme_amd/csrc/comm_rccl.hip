@@ -85,15 +85,25 @@ extern "C" int primme_amd_comm_create(primme_amd_comm **out, const void *id128, 
          if (rank == 0 && ncclGetUniqueId(&id) != ncclSuccess) memset(&id, 0, sizeof(id));
          if (pa_ipc_host_allgather(c->ipc, &id, 128, all)) { pa_ipc_detach(c->ipc); free(c); return -43; }
          memcpy(&id, all[0], 128);
-         NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
+         const ncclResult_t nr = ncclCommInitRank(&c->comm, nranks, id, rank);
+         if (nr != ncclSuccess) {
+            fprintf(stderr, "primme_amd: ncclCommInitRank failed: %s\n", ncclGetErrorString(nr));
+            pa_ipc_detach(c->ipc); free(c);
+            return -43;
+         }
       }
       if (!gpu_ok) { c->boot = c->ipc; c->ipc = NULL; }
    } else {
       c->kind = PA_COMM_RCCL;
       memcpy(&id, id128, sizeof(id) < 128 ? sizeof(id) : 128);
-      NCCL_CHECK(ncclCommInitRank(&c->comm, nranks, id, rank));
+      const ncclResult_t nr = ncclCommInitRank(&c->comm, nranks, id, rank);
+      if (nr != ncclSuccess) {
+         fprintf(stderr, "primme_amd: ncclCommInitRank failed: %s\n", ncclGetErrorString(nr));
+         free(c);
+         return -43;
+      }
    }
-   if (comm_staging(c)) return -1;
+   if (comm_staging(c)) { primme_amd_comm_destroy(c); return -1; }
    if (getenv("PRIMME_AMD_COMM_VERBOSE") && rank == 0)
       fprintf(stderr, "primme_amd: communicator of %d ranks: %s\n", nranks,
             c->kind == PA_COMM_RCCL ? "rccl" : c->kind == PA_COMM_IPC ? "ipc (peer-to-peer mailboxes)" : "mailboxes + rccl");
