@@ -78,7 +78,7 @@ static double now_s(void) {
 static double host_timeout_s(void) {
    const char *e = getenv("PRIMME_AMD_IPC_TIMEOUT_S");
    const double v = e ? atof(e) : 0.0;
-   return v > 0.0 ? v : 120.0;
+   return v > 0.0 ? v : 300.0;
 }
 static int shm_barrier(pa_ipc *x) {
    ipc_shm *s = x->shm;
