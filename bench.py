@@ -252,7 +252,12 @@ def main():
         ok = last.ret == 0 and last.initSize == args.num_evals and bool(
             np.all(last.resNorms <= args.eps * wl["aNorm"] * (1 + 1e-12)))
         exact = problems.laplacian_eigenvalues(dims, args.num_evals)
-        eval_err = float(np.max(np.abs(np.sort(last.evals) - exact)))
+        eval_err = float(np.max(np.abs(np.sort(last.evals) - exact))) if last.ret == 0 else float("inf")
+        # a solve that did not converge to the analytic spectrum is not a measurement: fail loudly (all ranks see the same result)
+        if not ok or not (eval_err <= 1e-6 * wl["aNorm"]):
+            raise SystemExit(f"bench.py: workload {name} on {world} rank(s) did not converge to the target (ret {last.ret}, "
+                             f"{last.initSize} of {args.num_evals} pairs, largest eigenvalue error {eval_err:.3e}, "
+                             f"largest residual norm {float(np.max(last.resNorms)) if len(last.resNorms) else float('nan'):.3e}); no number is reported")
 
         # ---- roofline of the dominant kernel class (rank 0's launches) ----
         prof = []
