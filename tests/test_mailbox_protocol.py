@@ -28,3 +28,21 @@ def test_rank_ordered_sums_through_two_generations(sim, ranks, reductions, count
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+@pytest.fixture(scope="module")
+def halosim(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("halosim") / "halo_protocol_sim")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-pthread",
+                           os.path.join(HERE, "csrc", "halo_protocol_sim.c"), "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("ranks,exchanges,rows", [(2, 2000, 64), (4, 1500, 257), (8, 800, 33)])
+def test_halo_landing_zones_two_generations(halosim, ranks, exchanges, rows):
+    """The neighbour exchange (xr_halo_kernel): rows pushed into the neighbour's zone of generation seq & 1, one flag per
+    exchange, the consumer reads while faster neighbours already push the next one.  (With ONE generation the same
+    simulation reads a million overwritten words.)"""
+    r = subprocess.run([halosim, str(ranks), str(exchanges), str(rows)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "0 bad words" in r.stdout
