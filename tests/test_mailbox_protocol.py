@@ -46,3 +46,20 @@ def test_halo_landing_zones_two_generations(halosim, ranks, exchanges, rows):
     r = subprocess.run([halosim, str(ranks), str(exchanges), str(rows)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "0 bad words" in r.stdout
+
+
+@pytest.fixture(scope="module")
+def winsim(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("winsim") / "window_protocol_sim")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-D_POSIX_C_SOURCE=200809L", "-pthread",
+                           os.path.join(HERE, "csrc", "window_protocol_sim.c"), "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("ranks,ops,words", [(2, 1500, 100), (4, 1000, 64), (8, 500, 33)])
+def test_bulk_window_one_barrier_two_generations(winsim, ranks, ops, words):
+    """The bulk all-gather / reduce-scatter (push into every rank's window, ONE device-side barrier, local read): two window
+    generations make the single barrier per operation enough."""
+    r = subprocess.run([winsim, str(ranks), str(ops), str(words)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "0 bad words" in r.stdout
