@@ -143,15 +143,35 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = (C.c_char * 128)()
-            assert lib.primme_amd_comm_unique_id(buf) == 0
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        if not shared_devices:
-            uid = uid.cuda()
-        dist.broadcast(uid, 0)
-        raw = bytes(uid.cpu().numpy().tobytes())
+        def make_id():
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                assert lib.primme_amd_comm_unique_id(buf) == 0
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            if not shared_devices:
+                uid = uid.cuda()
+            dist.broadcast(uid, 0)
+            return bytes(uid.cpu().numpy().tobytes())
+
+        raw = make_id()
+        if raw[:6] == b"PAIPC1":
+            # the id of the peer-to-peer transport names a shared-memory segment of THIS node: if some rank cannot see it
+            # (ranks in separate containers / IPC namespaces), every rank switches to RCCL before anybody waits for a rendez-vous
+            seg = "/dev/shm" + raw[8:72].split(b"\0")[0].decode()
+            seen = torch.tensor([1 if os.path.exists(seg) else 0], dtype=torch.int32, device="cpu" if shared_devices else "cuda")
+            dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+            if int(seen.item()) == 0:
+                if shared_devices:
+                    raise SystemExit("bench.py: ranks sharing a device need the peer-to-peer transport, but its rendez-vous segment is not visible to every rank")
+                if rank == 0:
+                    print("bench.py: the rendez-vous segment of the peer-to-peer transport is not visible to every rank; using PRIMME_AMD_COMM=rccl", file=sys.stderr)
+                    try:
+                        os.unlink(seg)
+                    except OSError:
+                        pass
+                os.environ["PRIMME_AMD_COMM"] = "rccl"
+                raw = make_id()
         comm = C.c_void_p()
         assert lib.primme_amd_comm_create(C.byref(comm), raw, rank, world) == 0
         lib.primme_amd_comm_transport.restype = C.c_char_p
