@@ -32,11 +32,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(case, tmp_path):
+def _launch(case, tmp_path, transport="rccl"):
+    """transport: PRIMME_AMD_COMM of the ranks.  This module is about the RCCL transport (the default argument); one case
+    also runs under "auto" (peer-to-peer mailboxes + RCCL when every rank has its own GPU, mailboxes alone with one rank)."""
     world = _world()
     port = _free_port()
-    out = str(tmp_path / f"res_{case}")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = str(tmp_path / f"res_{case}_{transport}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PRIMME_AMD_COMM=transport)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), case, out],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -46,6 +48,7 @@ def _launch(case, tmp_path):
     for r in res:
         assert r["ret"] == 0, r
         assert r["numGlobalSum"] > 0
+        assert r["transport"] == ("rccl" if transport == "rccl" else ("hybrid" if world > 1 else "ipc")), r["transport"]
         # every rank reduced the same panels and solved the same projected problem: identical bits
         assert r["evals"] == res[0]["evals"] and r["its"] == res[0]["its"] and r["resNorms"] == res[0]["resNorms"]
     return world, res
@@ -77,6 +80,15 @@ def test_rccl_bench_workloads_under_the_bench_partition(built, tmp_path, case, d
     assert np.all(np.array(res[0]["resNorms"]) <= 1e-8 * aN * (1 + 1e-6))
     assert abs(sum(r["evecs_norm2"] for r in res) - nev) < 1e-6
     assert res[0]["numGlobalSum"] >= res[0]["its"]          # every outer iteration reduced something across ranks
+
+
+def test_auto_transport_halo_stencil(built, tmp_path):
+    """the same halo case under PRIMME_AMD_COMM=auto: with one GPU per rank this is the mailboxes for reductions and halos
+    next to RCCL for the bulk collectives — the form `bench.py --gpus N` runs by default"""
+    world, res = _launch("halo", tmp_path, transport="auto")
+    ex = problems.laplacian_eigenvalues((24, 25, 26), 6)
+    assert np.max(np.abs(np.sort(res[0]["evals"]) - ex)) <= 1e-10 * 12.0
+    assert abs(sum(r["evecs_norm2"] for r in res) - 6.0) < 1e-8
 
 
 def test_rccl_block_diagonal(built, tmp_path):
