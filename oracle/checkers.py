@@ -202,6 +202,10 @@ class ReferenceBackend:
 
 
 def backend_object(backend):
+    if backend == "hip" and os.environ.get("PRIMME_AMD_TESTS_HIP_IS_HOSTCHECK"):
+        # heap-corruption hunt (round 4, profiles/r04_gpu_suite_exit_crash.md): run the GPU test modules' own Python and the host
+        # solver paths they reach on a box without a GPU, under AddressSanitizer, with the plain-C checker standing in for the device
+        return HostcheckBackend()
     if backend == "hip":
         return _api.HipBackend()
     if backend == "hostcheck":
