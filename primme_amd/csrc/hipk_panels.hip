@@ -1001,9 +1001,10 @@ static int ritz_update_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64
       const size_t shm = (size_t)k * RITZ_BIG_ROWS * sizeof(double);
       if (k > 255 || shm > 64 * 1024) return -1;
       if (!ctx->jobtab) HIPK_CHECK(hipMalloc(&ctx->jobtab, sizeof(tab)));
-      /* the table is tiny and this is the rare path: a blocking copy keeps `tab` safe to reuse */
-      HIPK_CHECK(hipMemcpyAsync(ctx->jobtab, &tab, sizeof(tab), hipMemcpyHostToDevice, ctx->stream));
-      HIPK_CHECK(hipStreamSynchronize(ctx->stream));
+      /* the table is tiny and this is the rare path: staged through the context's pinned buffer and complete on return
+       * (`tab` lives on the stack; since round 3 no runtime copy touches memory the library did not pin itself — this
+       * one had been overlooked until round 4) */
+      if (hipk_upload(ctx, ctx->jobtab, &tab, sizeof(tab))) return -1;
       char *dt_ = (char *)ctx->jobtab;
       jb_.xv_col = (const unsigned char *)dt_;
       jb_.xw_col = (const unsigned char *)(dt_ + RITZ_BIG_MAXOUT);
