@@ -58,7 +58,7 @@ struct pa_ipc {
    unsigned long long **bar_dev;     /* device array of the peers' barrier word arrays */
    unsigned int seq;                 /* tag of the last reduction */
    unsigned long long bseq, hseq, wseq;   /* barriers, halo exchanges, window operations issued */
-   int *err_host, *err_dev;          /* pinned error word */
+   int *err_host, *err_dev;          /* pinned: the error word (first 64 bytes) and 768 bytes of scratch behind it for the set-up copies */
    unsigned int *ticket;             /* device counter of the multi-block halo launch */
    long long timeout_ticks;
    hipk_xreduce xr;
@@ -328,13 +328,17 @@ __global__ void __launch_bounds__(HIPK_BLOCK) xr_sum_kernel(const T *__restrict_
 
 /* ---- set-up ----------------------------------------------------------------------------------------- */
 static int upload_tables(pa_ipc *x) {
-   unsigned long long *tab[IPC_MAXR], *bar[IPC_MAXR];
+   unsigned long long *tab[IPC_MAXR] = {0}, *bar[IPC_MAXR] = {0};
    for (int p = 0; p < x->nranks; p++) {
       tab[p] = (unsigned long long *)x->mbox.peer[p];
       bar[p] = (unsigned long long *)((char *)x->mbox.peer[p] + mbox_gran_bytes(x->nranks));
    }
-   HIPK_CHECK(hipMemcpy(x->tab_dev, tab, sizeof(void *) * x->nranks, hipMemcpyHostToDevice));
-   HIPK_CHECK(hipMemcpy(x->bar_dev, bar, sizeof(void *) * x->nranks, hipMemcpyHostToDevice));
+   /* through pinned scratch (no runtime copy out of pageable memory anywhere in the library) */
+   char *scratch = (char *)x->err_host + 256;
+   memcpy(scratch, tab, sizeof(void *) * IPC_MAXR);
+   memcpy(scratch + sizeof(void *) * IPC_MAXR, bar, sizeof(void *) * IPC_MAXR);
+   HIPK_CHECK(hipMemcpyAsync(x->tab_dev, scratch, sizeof(void *) * IPC_MAXR * 2, hipMemcpyHostToDevice, NULL));
+   HIPK_CHECK(hipStreamSynchronize(NULL));
    return 0;
 }
 
@@ -373,7 +377,7 @@ int pa_ipc_attach(pa_ipc **out, const void *id128, int rank, int nranks) {
 
    /* from here on a failure is not fatal: every rank learns of it through the rendez-vous, the device side is torn down
     * everywhere, and the communicator is told to take its collectives elsewhere (pa_ipc_gpu_ok) */
-   if (!fail && (hipHostMalloc((void **)&x->err_host, 64, hipHostMallocMapped) != hipSuccess ||
+   if (!fail && (hipHostMalloc((void **)&x->err_host, 1024, hipHostMallocMapped) != hipSuccess ||
                  hipHostGetDevicePointer((void **)&x->err_dev, x->err_host, 0) != hipSuccess)) fail = 1;
    if (!fail) *x->err_host = 0;
    if (!fail && (hipMalloc((void **)&x->tab_dev, sizeof(void *) * IPC_MAXR * 2) != hipSuccess ||
@@ -393,11 +397,13 @@ int pa_ipc_attach(pa_ipc **out, const void *id128, int rank, int nranks) {
    if (!bad) {
       const long long keep = x->xr.timeout_ticks;
       x->xr.timeout_ticks = (long long)(5.0e8);
-      double *d = NULL, h[3] = {1.0 + rank, 0.5 * (rank + 1), -2.0};
-      int tb = hipMalloc((void **)&d, sizeof(h)) != hipSuccess || hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess;
+      double *d = NULL, *h = (double *)((char *)x->err_host + 512);     /* pinned scratch */
+      h[0] = 1.0 + rank; h[1] = 0.5 * (rank + 1); h[2] = -2.0;
+      int tb = hipMalloc((void **)&d, 3 * sizeof(double)) != hipSuccess ||
+               hipMemcpyAsync(d, h, 3 * sizeof(double), hipMemcpyHostToDevice, NULL) != hipSuccess || hipStreamSynchronize(NULL) != hipSuccess;
       hipk_fin_flag nof = {NULL, NULL, 0};
       if (!tb) tb = pa_ipc_allreduce(x, NULL, d, 3, NULL, nof) != 0 || hipDeviceSynchronize() != hipSuccess ||
-                    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess;
+                    hipMemcpyAsync(h, d, 3 * sizeof(double), hipMemcpyDeviceToHost, NULL) != hipSuccess || hipStreamSynchronize(NULL) != hipSuccess;
       const double P = nranks;
       if (!tb) tb = *x->err_host != 0 || h[0] != P + P * (P - 1) / 2 || h[1] != 0.5 * (P * (P + 1) / 2) || h[2] != -2.0 * P;
       if (d) (void)hipFree(d);
