@@ -1,4 +1,5 @@
-// Single-vector CSR SpMV probe for round 5 (NOT part of the product, never run yet: written when the round-4 GPU budget was spent).
+// Single-vector CSR SpMV probe (NOT part of the product).  Result on one MI355X (profiles/r04_spmv_pipeline_probe.txt): A 149 us,
+// B 324-326 us, bitwise equal — the in-workgroup pipeline loses 2.2x.
 //
 // Round 4 found the product's csr_stream_kernel unmoved by 70 % fewer matrix bytes (profiles/r04_spmv_value_table_experiment.txt):
 // it is bound by the chain of dependent round trips of a tile (tile record -> value / index batch -> gather -> LDS products ->
