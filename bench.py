@@ -12,10 +12,11 @@ solves), max over ranks.  The operator, start vector and all panels are resident
 Workloads (BASELINE.json north star / configs):
   lap2d_10m  (default) the configuration BASELINE.json's north_star quotes its target on: 2-D 5-pt Laplacian
              3162x3163 (n = 10 001 406), double, blockSize 1, 10 smallest, PRIMME_GD_plusK, eps = 1e-8*|A|, |A| = 8,
-             CSR int32.  One solve takes ~27 s on one MI355X (30 846 outer iterations), so the timed solves are
-             capped to about --budget-s seconds (default 180): steps = min(K, max(1, floor(budget / t_solve))) and
-             warm-up = min(W, 1); `steps` / `warmup` on the JSON line are the numbers actually run, the requested
-             ones are in config.  The timed solves run WITHOUT the per-launch events of the roofline leg.
+             CSR int32.  One solve takes ~25 s on one MI355X (30 846 outer iterations).  --steps K / --warmup W are
+             honoured whenever the whole run fits --budget-s seconds of wall clock (default 1500: the driver gives
+             a bench run 1800 s; `--steps 20 --warmup 5` needs ~900 s); otherwise warm-up drops to 1 solve and the
+             timed solves to what fits.  `steps` / `warmup` on the JSON line are the numbers actually run, the
+             requested ones are in config.  The timed solves run WITHOUT the per-launch events of the roofline leg.
   lap3d_2m   configs[1]: 3-D 7-pt Laplacian 125x126x127 (n = 2 000 250), same settings, |A| = 12; rides along as
              the `configs1` object (3 timed solves) when it is not the main workload.
 N > 1: the SAME problem, rows partitioned over the ranks (strong scaling), the <= 4 KB inner-product panels
@@ -31,6 +32,13 @@ Extra objects on the JSON line (rank 0):
                 HBM bytes per launch / average launch duration, against the 8 TB/s HBM3E peak and against the
                 read / copy bandwidth measured in this process (frac_of_measured_stream).
   configs1      BASELINE configs[1] with its own roofline.
+  configs2      (N == 1) BASELINE configs[2]: Matrix-Market input — tests/golden/reference_driver/LUNDA.mtx read by the
+                library's C reader (primme_amd_mm_read) and tiled block-diagonally 34 014 times by its C tiler
+                (n = 5 000 058, 83.3 M nonzeros), JDQMR, block size 8, 20 eigenvalues closest to 4.4764e8, Jacobi.
+  configs3      (N == 1) BASELINE configs[3] on one GPU: complex Hermitian band n = 4 M, 6 largest, block 4, GD+k.
+  configs4      (N == 1) BASELINE configs[4] on one GPU: 8 M x 2 M CSR, 10 largest singular triplets, normal equations.
+                Each with value / ms_per_step over its own timed solves and a roofline object (dominant kernel class
+                by device time of one more, profiled solve).  --no-extra-configs skips the three.
   cpu_baseline  (N == 1) the real reference (oracle/_ref, PRIMME 3.2 + MKL) on the host cores for a bounded
                 number of outer iterations of the same solve, extrapolated with the iteration count the full
                 solve needs.
@@ -53,7 +61,17 @@ WORKLOADS = {
     "lap3d_small": dict(dims=(60, 61, 62), aNorm=12.0, desc="3-D 7-pt Laplacian 60x61x62 CSR (dev)"),
 }
 KERNEL_CLASSES = ["dots_kernel (TN inner products: CGS overlaps + V'W)", "project_kernel (CGS update + norm)",
-                  "ritz_kernel class = ritz_cgs_kernel + ritz_ov_kernel + ritz_kernel (fused R=Wh-theta Vh with its overlaps; restart X=Vh, Y=Wh)", "csr_stream_kernel (CSR SpMV)"]
+                  "ritz_kernel class = ritz_cgs_kernel + ritz_ov_kernel + ritz_kernel (fused R=Wh-theta Vh with its overlaps; restart X=Vh, Y=Wh)", "csr_stream_kernel (CSR SpMV)",
+                  "vector passes (axpy / copy / norms / QMR recurrences / Jacobi)"]
+# the same five classes of the live profiler (csrc/hipk_internal.h: HIPK_PROF_*), named for any method / scalar type
+GENERIC_CLASSES = ["TN panel products [Q V]'X (dots_kernel / dots_mfma_kernel / zdots_kernel)",
+                   "NN panel updates X -= [Q V]c (project_kernel / project_mul_kernel / zproject_kernel)",
+                   "fused Ritz / residual / restart update (ritz_*_kernel / zritz_kernel)",
+                   "sparse operator (csr_*_block_kernel / zcsr_kernel / pb_matvec_kernel / pat_kernel)",
+                   "vector passes (QMR recurrences, axpy / xpay / copy / gather, norms, Jacobi)"]
+NCLS = 5
+SPMV_FORMATS = {0: "CSR row tiles", 1: "panel-blocked", 2: "row patterns", 3: "stencil"}
+T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0
 
 
@@ -95,12 +113,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="lap2d_10m", choices=sorted(WORKLOADS))
-    ap.add_argument("--budget-s", type=float, default=180.0, help="cap on the seconds of timed solves of the main workload")
+    ap.add_argument("--budget-s", type=float, default=1500.0,
+                    help="wall-clock budget of the whole run: --steps / --warmup are honoured when the run fits, reduced otherwise")
     ap.add_argument("--num-evals", type=int, default=10)
     ap.add_argument("--eps", type=float, default=1e-8)
     ap.add_argument("--operator", default="csr", choices=["csr", "stencil"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs1", action="store_true", help="skip the extra configs[1] solves")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip configs[2] (Matrix-Market), configs[3] (complex), configs[4] (svds)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -211,6 +231,33 @@ def main():
         lib.hipk_ctx_destroy(ctx)
     barrier()
 
+    lib.hipk_prof_get.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+
+    def read_prof():
+        out = []
+        for cls in range(NCLS):
+            ms, launches, nbytes = C.c_double(), C.c_long(), C.c_double()
+            lib.hipk_prof_get(cls, C.byref(ms), C.byref(launches), C.byref(nbytes))
+            out.append((ms.value, launches.value, nbytes.value))
+        return out
+
+    def generic_roofline(prof, note=None):
+        """roofline object of a profiled solve of any method: dominant kernel class by device time (HIP events on the
+        solver's stream around every launch of the class), its algorithmic bytes per launch / its average launch duration"""
+        dom = max(range(NCLS), key=lambda c: prof[c][0])
+        ms, launches, nbytes = prof[dom]
+        ach = (nbytes / max(ms, 1e-12)) / 1e6 if launches else 0.0
+        r = {"kernel": GENERIC_CLASSES[dom], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches,
+             "avg_launch_us": round(1e3 * ms / max(launches, 1), 2), "alg_bytes_per_launch": round(nbytes / max(launches, 1)),
+             "all_kernels": {GENERIC_CLASSES[c].split(" (")[0]: {"ms": round(prof[c][0], 2), "launches": prof[c][1],
+                                                                  "GBps": round((prof[c][2] / max(prof[c][0], 1e-12)) / 1e6, 1)}
+                             for c in range(NCLS) if prof[c][1]},
+             "kernel_ms_per_solve": round(sum(p_[0] for p_ in prof), 1)}
+        if note:
+            r["note"] = note
+        return r
+
     def run_workload(name, steps_req, warmup_req, budget_s):
         """Timed solves of one workload (operator, start vector and panels resident in HBM before the timed
         region), then ONE more solve with HIP events around every launch of the hot kernel classes for the
@@ -237,7 +284,13 @@ def main():
         # the matrix stays resident through a persistent session
         sess = Session(op, comm=comm, dtype=np.float64)
         lib.hipk_csr_index_bytes.argtypes = [C.c_void_p]
-        idx_bytes = lib.hipk_csr_index_bytes(dict(sess.handles)["csr"]) if args.operator == "csr" else 0
+        lib.hipk_csr_format.argtypes = [C.c_void_p]
+        lib.hipk_csr_product_bytes.argtypes = [C.c_void_p, C.c_int]; lib.hipk_csr_product_bytes.restype = C.c_double
+        hcsr = dict(sess.handles)["csr"]
+        idx_bytes = lib.hipk_csr_index_bytes(hcsr) if args.operator == "csr" else 0
+        spmv_format = lib.hipk_csr_format(hcsr)
+        # HBM bytes one fused product (scale + A t + t'At, two outputs) moves in the form that serves it
+        spmv_bytes_fused = lib.hipk_csr_product_bytes(hcsr, 1)
         last = None
         # first warm-up solve, timed on its own: it sizes the cap
         barrier()
@@ -247,11 +300,16 @@ def main():
         t_first = max_over_ranks(time.perf_counter() - t0)
         steps, warmup = steps_req, max(warmup_req, 1)
         cap_note = None
-        if budget_s and t_first * steps_req > budget_s:
-            steps = max(1, min(steps_req, int(budget_s // t_first)))
-            warmup = 1
-            cap_note = (f"one solve takes {t_first:.1f} s: timed solves capped to ~{budget_s:.0f} s "
-                        f"({steps} of the {steps_req} requested steps, {warmup} of the {warmup_req} requested warm-up solves)")
+        if budget_s:
+            # what is left of the run's wall-clock budget after this point: the profiled solve, the other configs,
+            # the CPU baseline sample and the set-up / tear-down around them
+            reserve = t_first + (0.0 if world > 1 else 160.0) + 40.0
+            avail = budget_s - (time.perf_counter() - T_START) - reserve
+            if (warmup - 1 + steps) * t_first > avail:
+                warmup = 1
+                steps = max(1, min(steps_req, int(avail // t_first)))
+                cap_note = (f"one solve takes {t_first:.1f} s and the run has a wall-clock budget of {budget_s:.0f} s: "
+                            f"{steps} of the {steps_req} requested steps, {warmup} of the {warmup_req} requested warm-up solves")
         for _ in range(max(0, warmup - 1)):
             last = sess.solve(**kw)
         barrier()
@@ -280,12 +338,8 @@ def main():
                              f"largest residual norm {float(np.max(last.resNorms)) if len(last.resNorms) else float('nan'):.3e}); no number is reported")
 
         # ---- roofline of the dominant kernel class (rank 0's launches) ----
-        prof = []
-        for cls in range(4):
-            ms, launches, nbytes = C.c_double(), C.c_long(), C.c_double()
-            lib.hipk_prof_get(cls, C.byref(ms), C.byref(launches), C.byref(nbytes))
-            prof.append((ms.value, launches.value, nbytes.value))
-        dom = max(range(4), key=lambda c: prof[c][0])
+        prof = read_prof()
+        dom = max(range(NCLS), key=lambda c: prof[c][0])
         ms, launches, nbytes = prof[dom]
         achieved = (nbytes / max(ms, 1e-12)) / 1e6 if launches else 0.0   # bytes/ms -> GB/s
         # HBM bytes per launch from the PMC counters cannot be collected from inside this process:
@@ -303,18 +357,25 @@ def main():
             pass
         # the inner loop the north star names: CSR SpMV + orthogonalisation (+ the fused residual /
         # projection passes that are part of the same iteration): all four classes together
-        tot_ms = sum(p_[0] for p_ in prof)
-        tot_bytes = sum(p_[2] for p_ in prof)
+        tot_ms = sum(p_[0] for p_ in prof[:4])
+        tot_bytes = sum(p_[2] for p_ in prof[:4])
         so_ms = prof[3][0] + prof[1][0] + prof[0][0]
         so_bytes = prof[3][2] + prof[1][2] + prof[0][2]
-        # the SpMV class on the bytes it really streams: the 16-bit index stream takes 2 of plain CSR's 4 index bytes per nonzero
-        spmv_streamed = prof[3][2] - prof[3][1] * nnz * (4 - idx_bytes) if idx_bytes else prof[3][2]
+        # the SpMV class on the bytes it really moves in the form that serves the one-column products (csrc/hipk_sparse*.hip):
+        # CSR row tiles stream 8 + 2 (16-bit index stream) or 8 + 4 bytes per nonzero, the row-pattern form one byte per row
+        spmv_streamed = prof[3][1] * spmv_bytes_fused if args.operator == "csr" else prof[3][2]
         all_kernels = {KERNEL_CLASSES[c].split(" ")[0]: {
             "ms": round(prof[c][0], 2), "launches": prof[c][1],
-            "GBps": round((prof[c][2] / max(prof[c][0], 1e-12)) / 1e6, 1)} for c in range(4)}
-        all_kernels["csr_stream_kernel"]["accounting"] = "plain CSR: nnz*(8+4) + (m+1)*4 + 3*m*8 bytes per fused launch"
+            "GBps": round((prof[c][2] / max(prof[c][0], 1e-12)) / 1e6, 1)} for c in range(NCLS)}
+        all_kernels["csr_stream_kernel"]["accounting"] = ("plain CSR: nnz*(8+4) + (m+1)*4 + 3*m*8 bytes per fused launch — the ALGORITHMIC bytes of a CSR product; "
+                                                           "a compressed form moves fewer, so this figure may exceed the HBM peak: the roofline fraction of this class is GBps_streamed / peak")
+        all_kernels["csr_stream_kernel"]["format"] = SPMV_FORMATS.get(spmv_format, str(spmv_format))
         all_kernels["csr_stream_kernel"]["GBps_streamed"] = round(spmv_streamed / max(prof[3][0], 1e-12) / 1e6, 1)
-        all_kernels["csr_stream_kernel"]["streamed_accounting"] = f"{8 + idx_bytes} bytes per nonzero ({idx_bytes}-byte index stream) instead of 12"
+        all_kernels["csr_stream_kernel"]["frac_streamed"] = round(spmv_streamed / max(prof[3][0], 1e-12) / 1e6 / HBM_PEAK_GBS, 4)
+        all_kernels["csr_stream_kernel"]["streamed_bytes_per_launch"] = round(spmv_bytes_fused)
+        all_kernels["csr_stream_kernel"]["streamed_accounting"] = (
+            "row-pattern form: m*(1 + 3*8) bytes per fused launch (one pattern byte per row, x once, y and the normalised vector written)"
+            if spmv_format == 2 else f"{8 + idx_bytes} bytes per nonzero ({idx_bytes}-byte index stream) instead of 12")
         so_streamed = so_bytes - (prof[3][2] - spmv_streamed)
         roofline = {
             "kernel": KERNEL_CLASSES[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -365,6 +426,116 @@ def main():
         out["configs1"] = {"metric": "eigenpairs/sec to target resNorm", "value": c1["value"], "unit": "eigenpairs/s",
                            "ms_per_step": c1["ms_per_step"], "steps": c1["steps"], "n_gpus": world,
                            "config": c1["config"], "roofline": c1["roofline"]}
+
+    # ---- the other BASELINE configs on the driver-timed line (one GPU): Matrix-Market input, complex Hermitian, singular values
+    def timed_solves(solve, nsolves):
+        """1 warm-up solve, `nsolves` timed ones (barrier + device synchronisation on both sides), 1 profiled solve"""
+        r = solve()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsolves):
+            r = solve()
+        barrier()
+        el = time.perf_counter() - t0
+        lib.hipk_prof_reset(); lib.hipk_prof_enable(1)
+        barrier()
+        rp_ = solve()
+        barrier()
+        lib.hipk_prof_enable(0)
+        return r, el, read_prof(), rp_
+
+    def config2_lunda():
+        """BASELINE configs[2]: LUNDA.mtx through the library's C Matrix-Market reader and block-diagonal tiler"""
+        from primme_amd import ingest as ingest_c     # ctypes plumbing over primme_amd_mm_read / primme_amd_csr_tile_block_diagonal
+        mtx = os.path.join(ROOT, "tests", "golden", "reference_driver", "LUNDA.mtx")
+        rp0, ci0, va0, n0, _ = ingest_c.mm_read(lib, mtx)
+        T, shift = 34014, 4.4764e8           # shift: DESIGN.md section 5 (SURVEY's 1.0e6 converges nowhere, reference included)
+        rp, ci, va = ingest_c.tile_block_diagonal(lib, rp0, ci0, va0, T, 1.0, 1.0 / T)
+        n = n0 * T
+        A0 = np.zeros((n0, n0)); A0[np.repeat(np.arange(n0), np.diff(rp0)), ci0] = va0
+        w = (np.linalg.eigvalsh(A0)[None, :] * (1.0 + np.arange(T) / T)[:, None]).ravel()
+        aN = float(np.abs(w).max())
+        want = np.sort(w[np.argsort(np.abs(w - shift))][:20])
+        sess = Session(Operator(n, csr=(rp, ci, va)), dtype=np.float64)
+        kw = dict(numEvals=20, target="closest_abs", targetShifts=[shift], method="JDQMR", maxBlockSize=8, eps=1e-8, aNorm=aN,
+                  precond=("jacobi", shift), return_evecs=False)
+        try:
+            r, el, prof, _ = timed_solves(lambda: sess.solve(**kw), 3)
+        finally:
+            sess.close()
+        err = float(np.max(np.abs(np.sort(r.evals) - want))) if r.ret == 0 else float("inf")
+        ok = r.ret == 0 and r.initSize == 20 and err <= 1e-10 * aN and bool(np.all(r.resNorms <= 1e-8 * aN * (1 + 1e-6)))
+        return {"metric": "eigenpairs/sec to target resNorm", "value": round(3 * 20 / el, 4), "unit": "eigenpairs/s", "ms_per_step": round(1e3 * el / 3, 3),
+                "steps": 3, "n_gpus": 1, "dtype": "f64", "data": "Matrix-Market file (reference tests/LUNDA.mtx, committed fixture) tiled",
+                "config": {"workload": f"configs[2]: LUNDA.mtx (147 x 147, 2449 nnz) read by primme_amd_mm_read, tiled block-diagonally {T}x by "
+                                       f"primme_amd_csr_tile_block_diagonal (tile t scaled by 1 + t/T): n={n}, nnz={len(va)}; 20 eigenvalues closest to {shift:.4e}, "
+                                       f"JDQMR, blockSize 8, Jacobi K = diag(A) - shift, eps=1e-8*|A|, |A|={aN:.4e}",
+                           "converged": ok, "max_eval_error_vs_dense_truth": err, "outer_iterations": r.stats["numOuterIterations"],
+                           "matvecs": r.stats["numMatvecs"], "restarts": r.stats["numRestarts"]},
+                "roofline": generic_roofline(prof)}
+
+    def config3_hermitian():
+        """BASELINE configs[3] on ONE GPU (its 8-GPU row partition: tests/test_multigpu_rccl.py)"""
+        n = 4_000_000
+        rp, ci, va = problems.hermitian_banded_csr(n)
+        sess = Session(Operator(n, csr=(rp, ci, va)), dtype=np.complex128)
+        kw = dict(numEvals=6, target="largest", eps=1e-8, maxBlockSize=4, maxBasisSize=20, minRestartSize=8, method="GD_plusK",
+                  iseed=(2, 3, 5, 7), return_evecs=False)
+        try:
+            r, el, prof, _ = timed_solves(lambda: sess.solve(**kw), 3)
+        finally:
+            sess.close()
+        aN = r.params["aNorm"]
+        bound = 3.0 + 2 * (1 / 2 + 1 / 3 + 1 / 4)        # Gershgorin: the largest eigenvalues sit just below it
+        ok = r.ret == 0 and r.initSize == 6 and bool(np.all(r.resNorms <= 1e-8 * aN * (1 + 1e-6))) and bool(np.all(r.evals <= bound)) and r.evals[0] >= bound - 1.5
+        return {"metric": "eigenpairs/sec to target resNorm", "value": round(3 * 6 / el, 4), "unit": "eigenpairs/s", "ms_per_step": round(1e3 * el / 3, 3),
+                "steps": 3, "n_gpus": 1, "dtype": "c128 (f64 complex)", "data": "synthetic",
+                "config": {"workload": f"configs[3] on one GPU: complex Hermitian band, half-bandwidth 3, n={n}, nnz={len(va)}; 6 largest, GD+k, blockSize 4, "
+                                       f"basis 20 / restart 8, eps=1e-8*|A|, |A|={aN:.4f} (estimated by the solver)",
+                           "converged": ok, "outer_iterations": r.stats["numOuterIterations"], "matvecs": r.stats["numMatvecs"],
+                           "restarts": r.stats["numRestarts"], "largest_eigenvalue": float(r.evals[0]), "gershgorin_bound": bound},
+                "roofline": generic_roofline(prof)}
+
+    def config4_svds():
+        """BASELINE configs[4] on ONE GPU"""
+        from primme_amd.svds_api import SvdsSession
+        m_, n_, k = 8_000_000, 2_000_000, 10
+        rp, ci, va = problems.svds_synthetic_csr(m_, n_)
+        sess = SvdsSession(m_, n_, (rp, ci, va))
+        try:
+            r, el, prof, _ = timed_solves(lambda: sess.solve(numSvals=k, eps=1e-8, methodStage1="GD_plusK"), 3)
+        finally:
+            sess.close()
+        tol = 1e-8 * r.params["aNorm"]
+        # power iteration on the host: a lower bound of the largest singular value (same check as tests/test_full_size_configs_gpu.py)
+        x = np.ones(n_)
+        rows = np.repeat(np.arange(m_, dtype=np.int64), np.diff(rp))
+        for _ in range(3):
+            u = np.bincount(rows, weights=va * x[ci], minlength=m_)
+            x = np.bincount(ci, weights=va * u[rows], minlength=n_)
+            x /= np.linalg.norm(x)
+        s1 = float(np.linalg.norm(np.bincount(rows, weights=va * x[ci], minlength=m_)))
+        ok = r.ret == 0 and r.initSize == k and bool(np.all(r.resNorms <= 2 * tol)) and bool(np.all(np.diff(r.svals) <= 1e-12 * r.svals[0])) and r.svals[0] >= s1 * (1 - 1e-10)
+        return {"metric": "singular triplets/sec to target resNorm", "value": round(3 * k / el, 4), "unit": "triplets/s", "ms_per_step": round(1e3 * el / 3, 3),
+                "steps": 3, "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"configs[4] on one GPU: A {m_} x {n_} CSR, 5 nonzeros per row at (i*p_q + q) mod n; {k} largest singular triplets, "
+                                       f"normal equations (GD+k on A'A), eps=1e-8*|A|, |A|={r.params['aNorm']:.4f}",
+                           "converged": ok, "outer_iterations": r.stats["numOuterIterations"], "matvecs": r.stats["numMatvecs"],
+                           "largest_singular_value": float(r.svals[0]), "power_iteration_lower_bound": s1},
+                "roofline": generic_roofline(prof, note="sparse-operator class: algorithmic bytes = nnz*(8+4) + (m+1)*4 + 2*m*8 per product (plain CSR)")}
+
+    if rank == 0 and world == 1 and not args.no_extra_configs:
+        for key, fn in (("configs2", config2_lunda), ("configs3", config3_hermitian), ("configs4", config4_svds)):
+            t0 = time.perf_counter()
+            try:
+                out[key] = fn()
+                out[key]["wall_s_incl_setup"] = round(time.perf_counter() - t0, 1)
+                if not out[key]["config"]["converged"]:
+                    raise SystemExit(f"bench.py: {key} did not converge to its target: {json.dumps(out[key]['config'])}")
+            except SystemExit:
+                raise
+            except Exception as e:      # an extra object never takes the headline line down; the failure is on the line
+                out[key] = {"value": None, "error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -320,6 +320,19 @@ int hipk_csr_index_bytes(const hipk_csr *A);
  * HIPK_PB_KB bytes of x per panel).  Number of panels (0: plain CSR kernels) and the bytes one product streams. */
 int hipk_csr_panels(const hipk_csr *A);
 double hipk_csr_streamed_bytes(const hipk_csr *A);
+/* Matrices whose rows repeat — a row being its sequence of (column - row, value) pairs; constant-coefficient stencils,
+ * lattice operators: at most 256 distinct rows of at most 8 entries in the whole matrix — also get a ROW-PATTERN form
+ * (csrc/hipk_sparse_pat.hip: one byte per row + a pattern table kept in LDS, one lane per row) that serves the
+ * one-column products hipk_csr_matvec / hipk_csr_matvec_scaled with the arithmetic of the CSR tile kernel (y is
+ * bit-identical; the fused form's inner product differs in summation order only).  HIPK_SPMV_PAT=0 in the
+ * environment, or hipk_set_spmv_format(0) at run time, keeps the CSR tile kernels (A/B measurements, tests); returns
+ * the previous setting.  hipk_csr_format: the form that serves one-column products now (0 CSR row tiles, 1
+ * panel-blocked, 2 row patterns, 3 stencil); hipk_csr_product_bytes: the bytes one such product moves through HBM in
+ * that form (fused: with the second output of hipk_csr_matvec_scaled) — what "streamed bytes" means in bench.py. */
+int hipk_set_spmv_format(int use_patterns);
+int hipk_csr_format(const hipk_csr *A);
+int hipk_csr_npatterns(const hipk_csr *A);
+double hipk_csr_product_bytes(const hipk_csr *A, int fused);
 /* Second stage of the reductions of the block-size-1 iteration: bit 1 fused residual pass, 2 Gram-Schmidt update, 4 fused
  * SpMV run it inside the producing launch (two-level, write-through partial sums, csrc/hipk_internal.h); 0 = a separate
  * launch each.  Default 0: the in-kernel form is correct but slower on the MI355X (a workgroup waits ~5 us for its
@@ -333,7 +346,9 @@ int hipk_bandwidth_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);
 int hipk_read_probe(hipk_ctx *ctx, size_t bytes, int reps, double *gbps);
 /* live per-kernel-class timing with HIP events on the launching stream (process-wide,
  * off by default).  cls: 0 = TN inner products, 1 = NN project, 2 = fused Ritz update,
- * 3 = sparse matvec.  alg_bytes = algorithmic HBM bytes of the timed launches. */
+ * 3 = sparse matvec, 4 = element-wise / few-array passes (QMR recurrences of the JDQMR inner solver, axpy / xpay /
+ * scale / copy / gather, column norms and pair products, the Jacobi preconditioner; their second-stage launches are
+ * inside the timed span).  alg_bytes = algorithmic HBM bytes of the timed launches. */
 int hipk_prof_enable(int on);
 int hipk_prof_reset(void);
 int hipk_prof_get(int cls, double *ms, long *launches, double *alg_bytes);

@@ -30,7 +30,8 @@ from primme_amd.api import Operator, Result          # noqa: E402,F401
 from primme_amd.problems import csr_matvec_numpy     # noqa: E402
 from primme_amd.svds_api import transpose_csr        # noqa: E402,F401
 
-HOSTCHECK_LIB = os.path.join(_HERE, "_build", "libprimme_hostcheck.so")
+# PRIMME_AMD_HOSTCHECK_LIB: another build of the checker (the AddressSanitizer build, scripts/build_hostasan.sh)
+HOSTCHECK_LIB = os.environ.get("PRIMME_AMD_HOSTCHECK_LIB") or os.path.join(_HERE, "_build", "libprimme_hostcheck.so")
 REFERENCE_LIB = os.path.join(_HERE, "_ref", "libprimme_ref.so")
 PRODUCT_LIB = F.PRODUCT_LIB
 

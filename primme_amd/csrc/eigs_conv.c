@@ -241,7 +241,7 @@ static int try_speculative_restart(pa_solver *s, int basisSize, int nLk, const i
       return 0;                                  /* the candidate is not what the restart would continue with */
    CHK(hipk_h2d(s->ctx, s->d_coef2, s->h_coef2, (size_t)K * (rs + 1) * sizeof(double)));
    CHK(hipk_h2d(s->ctx, s->d_theta2, s->h_theta2, (size_t)basisSize * sizeof(double)));
-   hipk_job jobs[2 * 16 + 32 + 2];
+   hipk_job jobs[2 * 32 + 32 + 2];                /* rs <= 27 (twice), ncv <= 30, the unit column, the residual */
    int nj = 0;
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, s->V2, s->ld, c), -1};
    for (int c = 0; c < ncv; c++)                                        /* soft locking: converged Ritz vectors out to evecs */

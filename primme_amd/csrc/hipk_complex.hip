@@ -703,6 +703,7 @@ int hipk_z_ritz_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, c
                          : zritz_t<float>(ctx, m, V, W, ld, k, h, ldh, theta, jobs, njobs, nrm2_dev);
 }
 int hipk_z_axpy(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host, const void *X, int64_t ldX, void *Y, int64_t ldY, int nx, int xpay) {
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (dt == HIPK_C64 ? 16.0 : 8.0) * 3.0 * nx);
    for (int c0 = 0; c0 < nx; c0 += 64) {
       const int n = nx - c0 < 64 ? nx - c0 : 64;
       ZFac a;
@@ -720,6 +721,7 @@ int hipk_z_axpy(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_hos
 }
 int hipk_z_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *Y, int64_t ldY, int nx, double *out_dev) {
    if (nx <= 0) return 0;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (dt == HIPK_C64 ? 16.0 : 8.0) * 2.0 * nx);
    const int gx = zgrid(ctx, m, 4);
    if (hipk_reserve_partials(ctx, (size_t)2 * nx * gx)) return -2;
    if (dt == HIPK_C64) hipLaunchKernelGGL(zpair_dots_kernel<double>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const cpx<double> *)X, ldX, (const cpx<double> *)Y, ldY, nx, m, ctx->partials);

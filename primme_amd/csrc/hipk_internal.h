@@ -118,9 +118,19 @@ static inline double *hipk_mirror_of(const hipk_ctx *ctx, const double *out_dev)
 /* ---- live per-kernel-class timing (HIP events on the launching stream) ----------
  * bench.py's roofline leg: average launch duration and algorithmic bytes of each
  * hot kernel class, measured during the timed solves. Off by default. */
-enum { HIPK_PROF_DOTS = 0, HIPK_PROF_PROJECT = 1, HIPK_PROF_RITZ = 2, HIPK_PROF_SPMV = 3, HIPK_PROF_NCLASS = 4 };
+/* VEC: the element-wise / few-array passes (QMR recurrences of the JDQMR inner solver, axpy / xpay / scale / copy / gather,
+ * column norms and pair products, the Jacobi preconditioner) */
+enum { HIPK_PROF_DOTS = 0, HIPK_PROF_PROJECT = 1, HIPK_PROF_RITZ = 2, HIPK_PROF_SPMV = 3, HIPK_PROF_VEC = 4, HIPK_PROF_NCLASS = 5 };
 int hipk_prof_begin(int cls, hipStream_t st, double alg_bytes); /* returns slot or -1 */
 void hipk_prof_end(int slot, hipStream_t st);
+#ifdef __cplusplus
+/* times everything enqueued on `st` between construction and the end of the scope as ONE launch of class `cls` */
+struct hipk_prof_scope {
+   int slot; hipStream_t st;
+   hipk_prof_scope(int cls, hipStream_t s, double alg_bytes) : slot(hipk_prof_begin(cls, s, alg_bytes)), st(s) {}
+   ~hipk_prof_scope() { hipk_prof_end(slot, st); }
+};
+#endif
 
 /* arguments every finalize kernel takes for the completion flag (all NULL / 0: no flag) */
 struct hipk_fin_flag { unsigned long long *flag; unsigned int *counter; unsigned long long seq; };

@@ -1903,6 +1903,7 @@ extern "C" int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X,
       int nx, const double *alpha_host) {
    /* real factors on complex columns: the real kernel on the panel seen as 2m reals */
    if (HIPK_IS_Z(dt)) return hipk_scale_cols(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, nx, alpha_host);
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(2 * nx));
    for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
       int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
       ColScal sc;
@@ -1920,6 +1921,7 @@ extern "C" int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m
       int nx, const double *norm2_dev) {
    if (nx <= 0) return 0;
    if (HIPK_IS_Z(dt)) return hipk_scale_cols_rsqrt_dev(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, nx, norm2_dev);
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(2 * nx));
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 8);
    DISPATCH_RT(dt,
          hipLaunchKernelGGL(scale_rsqrt_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (T *)X, ldX, nx, norm2_dev, m),
@@ -1931,6 +1933,7 @@ extern "C" int hipk_scale_cols_rsqrt_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m
 extern "C" int hipk_axpy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
       const void *X, int64_t ldX, void *Y, int64_t ldY, int nx) {
    if (HIPK_IS_Z(dt)) return hipk_z_axpy(ctx, dt, m, alpha_host, X, ldX, Y, ldY, nx, 0);      /* (re, im) factors */
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(3 * nx));
    for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
       int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
       ColScal sc;
@@ -1974,6 +1977,7 @@ extern "C" int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const voi
       int64_t ldX, void *Y, int64_t ldY, int nx) {
    size_t es = (dt == HIPK_F64) ? 8 : (dt == HIPK_F32) ? 4 : (dt == HIPK_C64) ? 16 : 8;
    if (nx <= 0 || m <= 0) return 0;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(2 * nx));
    const size_t bytes = (size_t)m * es, lx = (size_t)ldX * es, ly = (size_t)ldY * es;
    if (nx > 65535 || bytes < 4096) {
       HIPK_CHECK(hipMemcpy2DAsync(Y, ly, X, lx, bytes, (size_t)nx, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1997,6 +2001,7 @@ extern "C" int hipk_copy_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const voi
 extern "C" int hipk_gather_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
       int64_t ldX, const int *perm_host, int n, void *Y, int64_t ldY) {
    if (HIPK_IS_Z(dt)) return hipk_gather_cols(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, perm_host, n, Y, 2 * ldY);
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(2 * n));
    for (int c0 = 0; c0 < n; c0 += UTIL_MAXCOLS) {
       int nn = n - c0 < UTIL_MAXCOLS ? n - c0 : UTIL_MAXCOLS;
       ColPerm pm;
@@ -2014,6 +2019,7 @@ extern "C" int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const vo
       int64_t ldX, int nx, double *out_dev) {
    if (nx <= 0) return 0;
    if (HIPK_IS_Z(dt)) return hipk_col_norms2(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, nx, out_dev);   /* |z|^2 = re^2 + im^2 */
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(nx));
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
    if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
    DISPATCH_RT(dt,
@@ -2026,6 +2032,7 @@ extern "C" int hipk_col_norms2(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const vo
 extern "C" int hipk_residual_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X,
       int64_t ldX, void *Wr, int64_t ldW, int nx, const double *theta_host, double *nrm2_dev) {
    if (HIPK_IS_Z(dt)) return hipk_residual_cols(ctx, hipk_real_of(dt), 2 * m, X, 2 * ldX, Wr, 2 * ldW, nx, theta_host, nrm2_dev);   /* theta is real */
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(3 * nx));
    const size_t es = (dt == HIPK_F64) ? 8 : 4;
    for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
       const int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
@@ -2049,6 +2056,7 @@ extern "C" int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const voi
       const void *Y, int64_t ldY, int nx, double *out_dev) {
    if (nx <= 0) return 0;
    if (HIPK_IS_Z(dt)) return hipk_z_pair_dots(ctx, dt, m, X, ldX, Y, ldY, nx, out_dev);
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(2 * nx));
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
    if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
    DISPATCH_RT(dt,
@@ -2061,6 +2069,7 @@ extern "C" int hipk_pair_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const voi
 extern "C" int hipk_xpay_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const double *alpha_host,
       const void *X, int64_t ldX, void *Y, int64_t ldY, int nx) {
    if (HIPK_IS_Z(dt)) return hipk_z_axpy(ctx, dt, m, alpha_host, X, ldX, Y, ldY, nx, 1);
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(3 * nx));
    for (int c0 = 0; c0 < nx; c0 += UTIL_MAXCOLS) {
       int n = nx - c0 < UTIL_MAXCOLS ? nx - c0 : UTIL_MAXCOLS;
       ColScal sc;
@@ -2078,6 +2087,7 @@ extern "C" int hipk_axpy_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, co
       const void *X, int64_t ldX, void *Y, int64_t ldY, const void *Z, int64_t ldZ, double *out_dev) {
    if (nx <= 0) return 0;
    if (nx > UTIL_MAXCOLS) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(4 * nx));
    ColScal sc;
    for (int c = 0; c < nx; c++) sc.a[c] = alpha_host[c];
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);   /* same grid as hipk_pair_dots: same sums */
@@ -2094,6 +2104,7 @@ extern "C" int hipk_qmr_update(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, 
       int64_t ldSol, double *dotsol_dev) {
    if (nx <= 0) return 0;
    if (nx > UTIL_MAXCOLS) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(5 * nx));
    ColScal g, e;
    for (int c = 0; c < nx; c++) { g.a[c] = gamma_host[c]; e.a[c] = eta_host[c]; }
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
@@ -2111,6 +2122,7 @@ extern "C" int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, i
       double *out_dev) {
    if (nx <= 0) return 0;
    if (nx > UTIL_MAXCOLS) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(8 * nx + 1));
    if (!(min_den > 0.0)) min_den = 1e-300;
    ColScal g, e, sh;
    for (int c = 0; c < nx; c++) { g.a[c] = gamma_host[c]; e.a[c] = eta_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
@@ -2130,6 +2142,7 @@ extern "C" int hipk_axpy_proj_dot_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m
       double min_den, double *out_dev) {
    if (nx <= 0) return 0;
    if (nx > UTIL_MAXCOLS) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(4 * nx + 1));
    if (!(min_den > 0.0)) min_den = 1e-300;
    ColScal a, r, sh;
    for (int c = 0; c < nx; c++) { a.a[c] = alpha_host[c]; r.a[c] = xr_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
@@ -2149,6 +2162,7 @@ extern "C" int hipk_qmr_update_dir(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int 
       const void *diag, const double *shift_host, double min_den, double *dotsol_dev) {
    if (nx <= 0) return 0;
    if (nx > UTIL_MAXCOLS) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(7 * nx + 1));
    if (!(min_den > 0.0)) min_den = 1e-300;
    ColScal g, e, b, sh;
    for (int c = 0; c < nx; c++) { g.a[c] = gamma_host[c]; e.a[c] = eta_host[c]; b.a[c] = beta_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
@@ -2166,6 +2180,7 @@ extern "C" int hipk_qmr_update_dir(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int 
 extern "C" int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *V, int64_t ldV,
       const void *W, int64_t ldW, int nx, double *out_dev) {
    if (nx <= 0) return 0;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(3 * nx));
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
    if (hipk_reserve_partials(ctx, (size_t)gx * 3 * nx)) return -2;
    DISPATCH_RT(dt,
@@ -2179,6 +2194,7 @@ extern "C" int hipk_axpy_proj_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int n
       const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, double *out_dev) {
    if (nx <= 0) return 0;
    if (nx > UTIL_MAXCOLS) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (double)(HIPK_IS_Z(dt) ? 2 : 1) * (dt == HIPK_F64 || dt == HIPK_C64 ? 8.0 : 4.0) * (double)(4 * nx));
    ColScal a, r;
    for (int c = 0; c < nx; c++) { a.a[c] = alpha_host[c]; r.a[c] = xr_host[c]; }
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);

@@ -46,8 +46,18 @@ struct hipk_csr {
    int64_t ld_lo, ld_hi;       /* their column strides (default: halo_lo / halo_hi, packed) */
    int sx, sy, sz;             /* stencil grid */
    struct hipk_pb *pb;         /* panel-blocked form (hipk_sparse_pb.hip) for scattered column patterns, or NULL */
+   struct hipk_pat *pat;       /* row-pattern dictionary form (hipk_sparse_pat.hip) for matrices whose rows repeat, or NULL */
 };
 struct hipk_pb;
+struct hipk_pat;
+extern "C" int hipk_pat_build(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int64_t row0, const int32_t *rp, const int32_t *ci, const void *val, hipk_pat **out);
+extern "C" int hipk_pat_matvec(const hipk_pat *B, void *hip_stream, int gx, const void *x, void *y, int64_t halo_lo, int64_t halo_hi, const void *xlo,
+      const void *xhi, const double *norm2, void *xout, double *partials, const hipk_fin_args *fa);
+extern "C" void hipk_pat_destroy(hipk_pat *B);
+extern "C" int hipk_pat_grid(const hipk_pat *B, int num_cu);
+extern "C" double hipk_pat_bytes(const hipk_pat *B, int fused);
+extern "C" int hipk_pat_npatterns(const hipk_pat *B);
+extern "C" int hipk_pat_enabled(void);
 extern "C" int hipk_pb_build(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int64_t n, const int32_t *rp, const int32_t *ci, const void *val, hipk_pb **out);
 extern "C" int hipk_pb_matvec(const hipk_pb *B, void *hip_stream, const void *x, int64_t ldx, void *y, int64_t ldy, int ncols);
 extern "C" void hipk_pb_destroy(hipk_pb *B);
@@ -642,6 +652,13 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
       const int rcp = hipk_pb_build(ctx, dt, nrows_local, ncols_global, rowptr_host, colind_host, values_host, &A->pb);
       if (rcp < 0) return rcp;
    }
+   /* rows that repeat (constant-coefficient stencils, lattice operators): one byte per row + a pattern table serves the
+    * one-column products (hipk_sparse_pat.hip); the offsets are taken against the row, so the input entries must be
+    * numbered like the rows (square operators, row slabs with halos) */
+   if (x0 == row0 && (dt == HIPK_F64 || dt == HIPK_F32) && !A->pb) {
+      const int rcp = hipk_pat_build(ctx, dt, nrows_local, row0, rowptr_host, colind_host, values_host, &A->pat);
+      if (rcp < 0) return rcp;
+   }
    *out = A;
    return 0;
 }
@@ -699,6 +716,7 @@ extern "C" int hipk_csr_destroy(hipk_csr *A) {
    if (A->col16) (void)hipFree(A->col16);
    if (A->diag) (void)hipFree(A->diag);
    if (A->pb) hipk_pb_destroy(A->pb);
+   if (A->pat) hipk_pat_destroy(A->pat);
    free(A);
    return 0;
 }
@@ -728,6 +746,26 @@ extern "C" int hipk_csr_index_bytes(const hipk_csr *A) { return (A && A->kind ==
 
 /* number of column panels of the panel-blocked form (0: plain CSR kernels serve this matrix) */
 extern "C" int hipk_csr_panels(const hipk_csr *A) { return A && A->pb ? hipk_pb_panels(A->pb) : 0; }
+/* the form that serves the ONE-column products of this matrix right now: 0 CSR row tiles, 1 panel-blocked, 2 row patterns, 3 stencil */
+extern "C" int hipk_csr_format(const hipk_csr *A) {
+   if (!A) return -1;
+   if (A->kind == 1) return 3;
+   if (A->pat && hipk_pat_enabled()) return 2;
+   return A->pb ? 1 : 0;
+}
+extern "C" int hipk_csr_npatterns(const hipk_csr *A) { return A && A->pat ? hipk_pat_npatterns(A->pat) : 0; }
+/* bytes ONE one-column product (fused = with the second output of hipk_csr_matvec_scaled) moves through HBM in the form in use */
+extern "C" double hipk_csr_product_bytes(const hipk_csr *A, int fused) {
+   if (!A) return 0.0;
+   const double es = (A->dt == HIPK_F64 || A->dt == HIPK_C32) ? 8 : A->dt == HIPK_C64 ? 16 : 4;
+   const double vec = (fused ? 3.0 : 2.0) * (double)A->nrows * es;
+   switch (hipk_csr_format(A)) {
+   case 3: return vec;
+   case 2: return hipk_pat_bytes(A->pat, fused);
+   case 1: return hipk_pb_bytes(A->pb) + (fused ? (double)A->nrows * es : 0.0);
+   default: return (double)A->nnz * (es + hipk_csr_index_bytes(A)) + (A->nrows + 1) * 4.0 + vec;
+   }
+}
 extern "C" double hipk_csr_streamed_bytes(const hipk_csr *A) { return A && A->pb ? hipk_pb_bytes(A->pb) : 0.0; }
 
 /* stream the matrix past the Infinity Cache?  Yes when its (value, index) stream alone is more than about three quarters
@@ -754,6 +792,12 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, stream, alg);
    static int pb_maxcols = -1;       /* HIPK_PB_MAXCOLS: widest block served column by column through the panel-blocked form */
    if (pb_maxcols < 0) { const char *e = getenv("HIPK_PB_MAXCOLS"); pb_maxcols = e ? atoi(e) : 2; }
+   if (A->pat && hipk_pat_enabled() && ncols == 1 && !shift_host) {
+      const int rc = hipk_pat_matvec(A->pat, stream, hipk_pat_grid(A->pat, ctx->num_cu), x, y, A->halo_lo, A->halo_hi, A->xlo, A->xhi, NULL, NULL,
+            NULL, NULL);
+      hipk_prof_end(pslot, stream);
+      return rc;
+   }
    if (A->pb && !shift_host && ncols <= pb_maxcols) {
       const int rc = hipk_pb_matvec(A->pb, stream, x, ldx, y, ldy, ncols);
       hipk_prof_end(pslot, stream);
@@ -871,11 +915,19 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
       ctx->need_sync = 1;
       return 0;
    }
-   const int gx = ((A->ntiles + 7) / 8) * 8;
+   const bool pat = A->pat && hipk_pat_enabled();
+   const int gx = pat ? hipk_pat_grid(A->pat, ctx->num_cu) : ((A->ntiles + 7) / 8) * 8;
    if (hipk_reserve_partials(ctx, (size_t)gx)) return -2;
    const double es = A->dt == HIPK_F64 ? 8 : 4;
    const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV, gx, 1);
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
+   if (pat) {
+      const int rc = hipk_pat_matvec(A->pat, st, gx, x, y, A->halo_lo, A->halo_hi, A->xlo, A->xhi, norm2_dev, xout, ctx->partials, &fa);
+      hipk_prof_end(pslot, st);
+      if (rc) return rc;
+      if (fa.enabled) return 0;
+      return hipk_finalize_partials(ctx, ctx->partials, gx, 1, dot_dev);
+   }
 #define LAUNCH_FUSED(TT, C16V, NTV) hipLaunchKernelGGL((csr_stream_kernel<TT, true, C16V, NTV>), dim3(gx), dim3(HIPK_BLOCK), 0, st, A->tileinfo, A->ntiles, A->rowptr, \
             A->colind, csr16(A), A->row0 - A->c16back, (const TT *)A->values, (const TT *)x, A->nrows, (TT *)y, A->nrows, 1, A->x0, A->xlen, A->halo_lo, \
             A->halo_hi, (const TT *)A->xlo, (const TT *)A->xhi, A->ld_lo, A->ld_hi, norm2_dev, (TT *)xout, ctx->partials, fa)
@@ -903,6 +955,7 @@ extern "C" int hipk_jacobi_apply(void *hip_stream, hipk_dtype dt, int64_t m, con
    if (ncols <= 0) return 0;
    if (!(min_den > 0.0)) min_den = 1e-300;
    if (ncols > 64) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, (hipStream_t)hip_stream, (double)m * (double)elem_size(dt) * (2.0 * ncols) + (double)m * (double)elem_size(hipk_real_of(dt)));
    if (HIPK_IS_Z(dt)) {
       int dev = 0, ncu = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);

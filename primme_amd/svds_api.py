@@ -157,3 +157,65 @@ def svds(m, n, csr, numSvals=1, target="largest", method="normalequations", meth
         if kind == "op": lib.primme_amd_svds_operator_destroy(h)
         elif kind == "ctx": lib.hipk_ctx_destroy(h)
     return res
+
+
+class SvdsSession:
+    """The singular value operator (A and A' resident in HBM, built once) for repeated solves of the same problem:
+    what bench.py times for BASELINE configs[4].  Device library only; real matrices."""
+
+    def __init__(self, m, n, csr, dtype=np.float64, backend="hip"):
+        self.dtype = np.dtype(dtype)
+        if self.dtype.kind == "c":
+            raise ValueError("SvdsSession: real matrices only (complex data: svds())")
+        self.be = _resolve_backend(backend)
+        if not (self.be.native_operator and self.be.device):
+            raise ValueError("SvdsSession needs the device library")
+        self.lib, self.m, self.n = self.be.lib, m, n
+        self.dt = F.HIPK_F64 if self.dtype == np.float64 else F.HIPK_F32
+        rp, ci, va = csr
+        rp = np.ascontiguousarray(rp, dtype=np.int32); ci = np.ascontiguousarray(ci, dtype=np.int32)
+        va = np.ascontiguousarray(va, dtype=self.dtype)
+        self.ctx = C.c_void_p()
+        if self.lib.hipk_ctx_create(C.byref(self.ctx), None):
+            raise RuntimeError("hipk_ctx_create failed: no HIP device (primme_amd has no CPU path)")
+        self.op = C.c_void_p()
+        rc = self.lib.primme_amd_svds_operator_create(C.byref(self.op), self.ctx, self.dt, m, n, rp.ctypes.data_as(C.c_void_p),
+                                                      ci.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p))
+        if rc:
+            self.lib.hipk_ctx_destroy(self.ctx)
+            raise RuntimeError(f"svds operator creation failed: {rc}")
+
+    def solve(self, numSvals=1, target="largest", method="normalequations", methodStage1="DEFAULT_METHOD", eps=1e-8, aNorm=0.0,
+              maxBlockSize=0, maxBasisSize=0, maxMatvecs=0, iseed=None):
+        import torch
+        lib, m, n = self.lib, self.m, self.n
+        ps = F.PrimmeSvdsParams()
+        lib.primme_svds_initialize(C.byref(ps))
+        ps.m, ps.n, ps.numSvals = m, n, numSvals
+        ps.target = F.SVDS_TARGETS[target]
+        ps.eps, ps.aNorm, ps.printLevel, ps.outputFile = eps, aNorm, 0, None
+        if maxBlockSize: ps.maxBlockSize = maxBlockSize
+        if maxBasisSize: ps.maxBasisSize = maxBasisSize
+        if maxMatvecs: ps.maxMatvecs = maxMatvecs
+        if iseed is not None:
+            for i in range(4): ps.iseed[i] = iseed[i]
+        ps.initSize = 0
+        ps.matrix = self.op
+        ps.matrixMatvec = C.cast(lib.primme_amd_svds_matvec, C.c_void_p)
+        mset = getattr(F, "PRIMME_" + methodStage1) if hasattr(F, "PRIMME_" + methodStage1) else F.METHODS.get(methodStage1, 0)
+        lib.primme_svds_set_method(F.SVDS_METHODS[method], mset, 0, C.byref(ps))
+        rdtype = self.dtype
+        svals = np.zeros(numSvals, dtype=rdtype); rnorms = np.zeros(numSvals, dtype=rdtype)
+        tdt = torch.float64 if rdtype == np.float64 else torch.float32
+        sv_t = torch.zeros((m + n) * numSvals, dtype=tdt, device="cuda")
+        torch.cuda.synchronize()
+        ret = self.be.svds_solver(self.dtype.name)(svals.ctypes.data_as(C.c_void_p), C.c_void_p(sv_t.data_ptr()),
+                                                    rnorms.ctypes.data_as(C.c_void_p), C.byref(ps))
+        torch.cuda.synchronize()
+        k = ps.initSize
+        return SvdsResult(ret, svals[:max(k, 0)].copy(), None, None, rnorms[:max(k, 0)].copy(), ps)
+
+    def close(self):
+        if self.op:
+            self.lib.primme_amd_svds_operator_destroy(self.op); self.op = None
+            self.lib.hipk_ctx_destroy(self.ctx); self.ctx = None

@@ -647,6 +647,98 @@ def test_csr_matvec_scaled_fused_tail(built, dt):
         assert abs(res[0][2][0] - float(res[0][0].astype(np.float64) @ res[0][1].astype(np.float64))) <= tol * np.sqrt(n) * (1 + abs(res[0][2][0])), name
 
 
+def _lattice_csr(n, rng):
+    """a 1-D lattice operator with second-neighbour hopping and two site types: 3 x 2 row patterns away from the ends"""
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        for d, v in ((-2, 0.25), (-1, -1.0), (0, 2.0 + 0.5 * (i % 2)), (1, -1.0), (2, 0.25)):
+            if 0 <= i + d < n:
+                rows.append(i); cols.append(i + d); vals.append(v)
+    rp = np.zeros(n + 1, dtype=np.int64); np.add.at(rp, np.array(rows) + 1, 1)
+    return np.cumsum(rp).astype(np.int32), np.array(cols, dtype=np.int32), np.array(vals)
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("case", ["lap1d", "lap2d", "lap2d_big", "lap3d", "lattice", "lap3d_slab", "random"])
+def test_csr_row_pattern_form(built, dt, case):
+    """Matrices whose rows repeat are served by the row-pattern form (csrc/hipk_sparse_pat.hip: one byte per row + a pattern
+    table, one lane per row) for one-column products.  Checked: hipk_csr_create picks it for stencils / lattice operators
+    and not for a random matrix; y is BIT-IDENTICAL to the CSR tile kernel's (same products, same order, no contraction),
+    plain and fused, with and without halo rows; the fused form's normalised vector is bit-identical and its inner product
+    agrees to rounding; both agree with numpy."""
+    npdt = NPDT[dt]
+    rng = np.random.default_rng(11)
+    row0, lo_hi = 0, None
+    if case == "lap1d": rp, ci, va, n = problems.laplacian_csr((70001,))
+    elif case == "lap2d": rp, ci, va, n = problems.laplacian_csr((37, 41))
+    elif case == "lap2d_big": rp, ci, va, n = problems.laplacian_csr((1234, 1111))     # > 2 chunks per workgroup of every XCD
+    elif case == "lap3d": rp, ci, va, n = problems.laplacian_csr((64, 65, 66))
+    elif case == "lattice": n = 40003; rp, ci, va = _lattice_csr(n, rng)
+    elif case == "lap3d_slab":
+        dims = (23, 19, 17); n = int(np.prod(dims)); row0 = 2000
+        rp, ci, va, _ = problems.laplacian_csr(dims, row0=row0, nrows=3003)
+    else:
+        n = 5000
+        counts = rng.integers(1, 7, size=n)
+        rp = np.zeros(n + 1, dtype=np.int64); np.cumsum(counts, out=rp[1:]); rp = rp.astype(np.int32)
+        ci = np.concatenate([np.sort(rng.choice(n, size=c, replace=False)) for c in counts]).astype(np.int32)
+        va = rng.standard_normal(len(ci))
+    nloc = len(rp) - 1
+    side = Dev()
+    lib = side.lib
+    lib.hipk_set_spmv_format.argtypes = [C.c_int]
+    lib.hipk_csr_format.argtypes = [C.c_void_p]; lib.hipk_csr_npatterns.argtypes = [C.c_void_p]
+    lib.hipk_csr_product_bytes.argtypes = [C.c_void_p, C.c_int]; lib.hipk_csr_product_bytes.restype = C.c_double
+    old = lib.hipk_set_spmv_format(1)
+    try:
+        A = C.c_void_p()
+        vv = np.ascontiguousarray(va, dtype=npdt)
+        assert lib.hipk_csr_create(side.ctx, dt, nloc, n, row0, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                   vv.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+        if case == "random":
+            assert lib.hipk_csr_format(A) == 0 and lib.hipk_csr_npatterns(A) == 0
+            lib.hipk_csr_destroy(A)
+            return
+        assert lib.hipk_csr_format(A) == 2
+        want_pat = {"lap1d": 3, "lap2d": 9, "lap2d_big": 9, "lap3d": 27, "lattice": 6}.get(case)
+        if want_pat: assert lib.hipk_csr_npatterns(A) == want_pat
+        es = np.dtype(npdt).itemsize
+        assert lib.hipk_csr_product_bytes(A, 1) == nloc * (1 + 3 * es)
+        Xg = rng.standard_normal(n) * 2.0                                  # the whole vector; this slab owns [row0, row0 + nloc)
+        lo, hi = int(lib.hipk_csr_halo_lo(A)), int(lib.hipk_csr_halo_hi(A))
+        x = side.arr(Xg[row0:row0 + nloc].astype(npdt))
+        xlo = side.arr(Xg[row0 - lo:row0].astype(npdt) if lo else np.zeros(1, npdt))
+        xhi = side.arr(Xg[row0 + nloc:row0 + nloc + hi].astype(npdt) if hi else np.zeros(1, npdt))
+        assert lib.hipk_csr_set_halo_ld(A, side.ptr(xlo), max(lo, 1), side.ptr(xhi), max(hi, 1)) == 0
+        nn = side.arr(np.array([float(np.sum(Xg ** 2))]))
+        got = {}
+        for fmt in (1, 0):
+            lib.hipk_set_spmv_format(fmt)
+            assert lib.hipk_csr_format(A) == (2 if fmt else 0)
+            y = side.arr(np.full(nloc, np.nan, npdt)); yf = side.arr(np.full(nloc, np.nan, npdt)); xo = side.arr(np.full(nloc, np.nan, npdt))
+            dot = side.arr(np.zeros(1))
+            assert lib.hipk_csr_matvec(A, None, side.ptr(x), nloc, side.ptr(y), nloc, 1) == 0
+            assert lib.hipk_csr_matvec_scaled(A, side.ctx, side.ptr(x), side.ptr(nn), side.ptr(xo), side.ptr(yf), side.ptr(dot)) == 0
+            got[fmt] = [side.get(t) for t in (y, yf, xo, dot)]
+        assert lib.hipk_csr_product_bytes(A, 0) > nloc * (1 + 2 * es)      # the tile form streams the nonzeros
+        lib.hipk_csr_destroy(A)
+    finally:
+        lib.hipk_set_spmv_format(old)
+        side.close()
+    for t in range(3):
+        assert not np.any(np.isnan(got[1][t])) and np.array_equal(got[1][t], got[0][t]), (case, t)     # bit for bit
+    tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+    assert abs(got[1][3][0] - got[0][3][0]) <= tol * np.sqrt(nloc) * (1 + abs(got[0][3][0]))
+    # against numpy on the global matrix rows of this slab
+    xin = Xg.astype(npdt).astype(np.float64)
+    ref = np.zeros(nloc)
+    np.add.at(ref, np.repeat(np.arange(nloc), np.diff(rp)), va.astype(npdt).astype(np.float64) * xin[ci])
+    assert np.max(np.abs(got[1][0] - ref)) <= tol * 10 * (1 + np.abs(ref).max())
+    a = 1.0 / np.sqrt(float(np.sum(Xg ** 2)))
+    assert np.max(np.abs(got[1][1] - a * ref)) <= tol * 10 * (1 + np.abs(a * ref).max())
+    assert abs(got[1][3][0] - a * a * float(xin[row0:row0 + nloc] @ ref)) <= tol * 50 * np.sqrt(nloc) * (1 + abs(got[1][3][0]))
+
+
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
 def test_panel_project_out_of_place(built, dt):
     """Xout = X - [segs] coef with X untouched (the form that leaves the projected vector in a scratch column)"""
