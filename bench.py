@@ -92,18 +92,33 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # ranks > 0 print nothing that is needed: their stdout goes nowhere (a pipe nobody drains would block a chatty rank,
+        # e.g. verbose RCCL logging, and with it the whole job); stderr stays the terminal's
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r else None))
+                                      stdout=subprocess.DEVNULL if r else None))
+    # all ranks are watched together: the first one that fails takes the others down at once (not after rank 0's
+    # rendez-vous timeout)
     rc = 0
-    for r, p in enumerate(procs):
-        p.communicate()
-        if p.returncode != 0:
-            rc = rc or p.returncode or 1
+    live = list(procs)
+    while live and not rc:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = code or 1
     if rc:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        raise SystemExit(f"bench.py: a rank failed (exit code {rc})")
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                pass
+        raise SystemExit(f"bench.py: a rank failed (exit code {rc}); the other ranks were stopped")
     sys.exit(0)
 
 
@@ -122,8 +137,12 @@ def main():
     ap.add_argument("--no-configs1", action="store_true", help="skip the extra configs[1] solves")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip configs[2] (Matrix-Market), configs[3] (complex), configs[4] (svds)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--comm", default=None, choices=["auto", "ipc", "rccl"],
+                    help="N > 1: transport of the library's communicator (default: PRIMME_AMD_COMM, else auto = mailboxes + RCCL)")
     args = ap.parse_args()
 
+    if args.comm:
+        os.environ["PRIMME_AMD_COMM"] = args.comm
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)
 
@@ -167,7 +186,9 @@ def main():
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
                 buf = (C.c_char * 128)()
-                assert lib.primme_amd_comm_unique_id(buf) == 0
+                # one node (the launch contract of this benchmark): the library hands out a mailbox id when the mailboxes
+                # can serve `world` ranks and an ncclUniqueId otherwise
+                assert lib.primme_amd_comm_unique_id_for(buf, world, 0) == 0
                 uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
             if not shared_devices:
                 uid = uid.cuda()
@@ -197,6 +218,17 @@ def main():
         lib.primme_amd_comm_transport.restype = C.c_char_p
         lib.primme_amd_comm_transport.argtypes = [C.c_void_p]
         transport = lib.primme_amd_comm_transport(comm).decode()
+        # every collective of the communicator against known data on the transport it came up on, and the latency of a
+        # small all-reduce (a block-size-1 iteration makes three), BEFORE anything is timed: a transport that maps but does
+        # not deliver must end the run here, not inside a solve
+        lib.primme_amd_comm_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        us = C.c_double(-1.0)
+        st_rc = lib.primme_amd_comm_selftest(comm, None, 1000, C.byref(us))
+        if st_rc != 0:
+            raise SystemExit(f"bench.py: rank {rank}: the communicator self-test failed on transport {transport} (code {st_rc}); no number is reported")
+        comm_selftest = {"transport": transport, "allreduce_us": round(us.value, 2),
+                         "checked": "all-reduce of 1..4096 doubles, neighbour halo, all-gather / reduce-scatter of column blocks, integer exchange",
+                         "allreduce_us_is": "wall clock per 8-double all-reduce over 1000 back-to-back reductions on this rank"}
 
     def barrier():
         torch.cuda.synchronize()
@@ -409,6 +441,7 @@ def main():
             "roofline": roofline}
         if dist_path:
             res["config"]["transport"] = transport
+            res["config"]["comm_selftest"] = comm_selftest
             if shared_devices:
                 res["config"]["devices"] = f"{world} ranks on {ndev} device(s): functional run, NOT a scaling number"
         return res, last, dims, wl, n
@@ -464,7 +497,7 @@ def main():
         finally:
             sess.close()
         err = float(np.max(np.abs(np.sort(r.evals) - want))) if r.ret == 0 else float("inf")
-        ok = r.ret == 0 and r.initSize == 20 and err <= 1e-10 * aN and bool(np.all(r.resNorms <= 1e-8 * aN * (1 + 1e-6)))
+        ok = bool(r.ret == 0 and r.initSize == 20 and err <= 1e-10 * aN and np.all(r.resNorms <= 1e-8 * aN * (1 + 1e-6)))
         return {"metric": "eigenpairs/sec to target resNorm", "value": round(3 * 20 / el, 4), "unit": "eigenpairs/s", "ms_per_step": round(1e3 * el / 3, 3),
                 "steps": 3, "n_gpus": 1, "dtype": "f64", "data": "Matrix-Market file (reference tests/LUNDA.mtx, committed fixture) tiled",
                 "config": {"workload": f"configs[2]: LUNDA.mtx (147 x 147, 2449 nnz) read by primme_amd_mm_read, tiled block-diagonally {T}x by "
@@ -487,7 +520,7 @@ def main():
             sess.close()
         aN = r.params["aNorm"]
         bound = 3.0 + 2 * (1 / 2 + 1 / 3 + 1 / 4)        # Gershgorin: the largest eigenvalues sit just below it
-        ok = r.ret == 0 and r.initSize == 6 and bool(np.all(r.resNorms <= 1e-8 * aN * (1 + 1e-6))) and bool(np.all(r.evals <= bound)) and r.evals[0] >= bound - 1.5
+        ok = bool(r.ret == 0 and r.initSize == 6 and np.all(r.resNorms <= 1e-8 * aN * (1 + 1e-6)) and np.all(r.evals <= bound) and r.evals[0] >= bound - 1.5)
         return {"metric": "eigenpairs/sec to target resNorm", "value": round(3 * 6 / el, 4), "unit": "eigenpairs/s", "ms_per_step": round(1e3 * el / 3, 3),
                 "steps": 3, "n_gpus": 1, "dtype": "c128 (f64 complex)", "data": "synthetic",
                 "config": {"workload": f"configs[3] on one GPU: complex Hermitian band, half-bandwidth 3, n={n}, nnz={len(va)}; 6 largest, GD+k, blockSize 4, "
@@ -515,7 +548,7 @@ def main():
             x = np.bincount(ci, weights=va * u[rows], minlength=n_)
             x /= np.linalg.norm(x)
         s1 = float(np.linalg.norm(np.bincount(rows, weights=va * x[ci], minlength=m_)))
-        ok = r.ret == 0 and r.initSize == k and bool(np.all(r.resNorms <= 2 * tol)) and bool(np.all(np.diff(r.svals) <= 1e-12 * r.svals[0])) and r.svals[0] >= s1 * (1 - 1e-10)
+        ok = bool(r.ret == 0 and r.initSize == k and np.all(r.resNorms <= 2 * tol) and np.all(np.diff(r.svals) <= 1e-12 * r.svals[0]) and r.svals[0] >= s1 * (1 - 1e-10))
         return {"metric": "singular triplets/sec to target resNorm", "value": round(3 * k / el, 4), "unit": "triplets/s", "ms_per_step": round(1e3 * el / 3, 3),
                 "steps": 3, "n_gpus": 1, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"configs[4] on one GPU: A {m_} x {n_} CSR, 5 nonzeros per row at (i*p_q + q) mod n; {k} largest singular triplets, "
@@ -561,7 +594,7 @@ def main():
         barrier()
         lib.primme_amd_comm_destroy(comm)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, default=lambda o: o.item() if hasattr(o, "item") else str(o)), flush=True)
     if dist_path:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -31,6 +31,15 @@ typedef struct primme_amd_comm primme_amd_comm;
  *          share a device.
  * Sums are formed in rank order on every rank: all ranks hold identical bits. */
 int primme_amd_comm_unique_id(void *id128);
+/* The same for a launcher that knows the shape of the job: `auto` then hands out a mailbox id only when the mailboxes can
+ * serve it — at most 16 ranks, all on ONE node (one /dev/shm) — and an ncclUniqueId otherwise, so that default settings
+ * keep working for jobs that span nodes or have more ranks.  An explicit PRIMME_AMD_COMM=ipc on a job the mailboxes cannot
+ * serve fails here (-43, with a message) instead of at the rendez-vous. */
+int primme_amd_comm_unique_id_for(void *id128, int nranks, int spans_nodes);
+/* Fails fast (-43 and a message saying what to set), the same way on every rank, when a mailbox id meets more than 16 ranks; a
+ * rank that cannot see the rendez-vous segment (another node / IPC namespace) returns -43 at once and the ranks that can
+ * see it give up after PRIMME_AMD_IPC_ATTACH_TIMEOUT_S seconds (default 60; the later rendez-vous keep
+ * PRIMME_AMD_IPC_TIMEOUT_S, default 300) with the same advice: PRIMME_AMD_COMM=rccl. */
 int primme_amd_comm_create(primme_amd_comm **comm, const void *id128, int rank, int nranks);
 int primme_amd_comm_destroy(primme_amd_comm *comm);
 int primme_amd_comm_rank(const primme_amd_comm *comm);
@@ -62,6 +71,12 @@ int primme_amd_comm_allgather_cols(primme_amd_comm *c, void *hip_stream, const v
 int primme_amd_comm_reduce_scatter_cols(primme_amd_comm *c, void *hip_stream, const void *send, int64_t ld_send,
       void *recv, int64_t ld_recv, size_t count_per_rank, int is_double, int ncols);
 int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *mine, int n, int64_t *all);
+/* Self-test of a communicator on whatever transport it came up on (collective: every rank calls it): all-reduce of
+ * 1 .. 4096 doubles, the neighbour halo, the bulk all-gather / reduce-scatter, the integer exchange — each against known
+ * data — then `reps` back-to-back 8-double all-reduces; *allreduce_us (optional) = wall-clock microseconds per reduction of
+ * that loop.  Returns 0 when every check matched on this rank, the number of failed checks otherwise, negative on a
+ * transport error.  bench.py --gpus N runs it before the timed region and prints transport and latency. */
+int primme_amd_comm_selftest(primme_amd_comm *c, void *hip_stream, int reps, double *allreduce_us);
 
 /* Operator handle for primme->matrix / primme->preconditioner: a local sparse
  * operator plus (optionally) the communicator that feeds its halo. */

@@ -80,7 +80,16 @@ static double host_timeout_s(void) {
    const double v = e ? atof(e) : 0.0;
    return v > 0.0 ? v : 300.0;
 }
-static int shm_barrier(pa_ipc *x) {
+/* the FIRST rendez-vous of a communicator: a rank on another node (or in another IPC namespace) cannot see the segment and
+ * has left with an error already; the ranks that can see it should not sit here for five minutes */
+static double attach_timeout_s(void) {
+   const char *e = getenv("PRIMME_AMD_IPC_ATTACH_TIMEOUT_S");
+   const double v = e ? atof(e) : 0.0;
+   return v > 0.0 ? v : 60.0;
+}
+static int shm_barrier_lim(pa_ipc *x, double lim, const char *advice);
+static int shm_barrier(pa_ipc *x) { return shm_barrier_lim(x, host_timeout_s(), ""); }
+static int shm_barrier_lim(pa_ipc *x, double lim, const char *advice) {
    ipc_shm *s = x->shm;
    const int gen = __atomic_load_n(&s->generation, __ATOMIC_ACQUIRE);
    if (__atomic_add_fetch(&s->arrived, 1, __ATOMIC_ACQ_REL) == x->nranks) {
@@ -88,12 +97,12 @@ static int shm_barrier(pa_ipc *x) {
       __atomic_store_n(&s->generation, gen + 1, __ATOMIC_RELEASE);
       return 0;
    }
-   const double t0 = now_s(), lim = host_timeout_s();
+   const double t0 = now_s();
    for (long spins = 0;; spins++) {
       if (__atomic_load_n(&s->generation, __ATOMIC_ACQUIRE) != gen) return 0;
       if ((spins & 1023) == 1023) {
          if (now_s() - t0 > lim) {
-            fprintf(stderr, "primme_amd: rank %d waited %.0f s for the other ranks at a communicator rendez-vous\n", x->rank, lim);
+            fprintf(stderr, "primme_amd: rank %d waited %.0f s for the other %d rank(s) at a communicator rendez-vous%s\n", x->rank, lim, x->nranks - 1, advice);
             return -43;
          }
          sched_yield();
@@ -342,6 +351,16 @@ static int upload_tables(pa_ipc *x) {
    return 0;
 }
 
+/* the tag sequence of the reductions wraps (hipk_xr_next_seq): every rank gets here at the same reduction.  Drain, meet,
+ * clear this rank's granule area (what the peers wrote in the cycle that ends), meet again. */
+static int ipc_seq_wrap(void *owner) {
+   pa_ipc *x = (pa_ipc *)owner;
+   if (hipDeviceSynchronize() != hipSuccess) return -1;
+   if (shm_barrier(x)) return -43;              /* nobody is inside a reduction of the old cycle any more */
+   if (x->mbox.mine && (hipMemset(x->mbox.mine, 0, mbox_gran_bytes(x->nranks)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) return -1;
+   return shm_barrier(x);                       /* nobody writes a tag of the new cycle into an area that is still being cleared */
+}
+
 int pa_ipc_attach(pa_ipc **out, const void *id128, int rank, int nranks) {
    *out = NULL;
    if (!pa_ipc_is_ipc_id(id128) || nranks < 1 || nranks > IPC_MAXR || rank < 0 || rank >= nranks) {
@@ -353,11 +372,20 @@ int pa_ipc_attach(pa_ipc **out, const void *id128, int rank, int nranks) {
    x->rank = rank; x->nranks = nranks;
    strncpy(x->shm_name, (const char *)id128 + 8, sizeof(x->shm_name) - 1);
    const int fd = shm_open(x->shm_name, O_RDWR, 0600);
-   if (fd < 0) { perror("primme_amd: shm_open (communicator id)"); free(x); return -43; }
+   if (fd < 0) {
+      fprintf(stderr, "primme_amd: rank %d cannot open the rendez-vous segment %s of the peer-to-peer transport (%s): the mailboxes serve the ranks of ONE "
+            "node that share /dev/shm; for a job that spans nodes or containers create the id with PRIMME_AMD_COMM=rccl\n", rank, x->shm_name, strerror(errno));
+      free(x);
+      return -43;
+   }
    x->shm = (ipc_shm *)mmap(NULL, sizeof(ipc_shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
    close(fd);
    if (x->shm == MAP_FAILED) { free(x); return -43; }
-   if (shm_barrier(x)) { munmap(x->shm, sizeof(ipc_shm)); free(x); return -43; }
+   if (shm_barrier_lim(x, attach_timeout_s(), ": a rank on another node or in another IPC namespace cannot see the segment (it has left with an error); "
+         "the mailboxes serve one node — create the id with PRIMME_AMD_COMM=rccl for such a job")) {
+      if (rank == 0) shm_unlink(x->shm_name);
+      munmap(x->shm, sizeof(ipc_shm)); free(x); return -43;
+   }
    if (rank == 0) shm_unlink(x->shm_name);       /* everybody has it mapped: nothing is left behind if a rank dies later */
 
    const char *te = getenv("PRIMME_AMD_IPC_DEVICE_TIMEOUT_S");
@@ -391,6 +419,11 @@ int pa_ipc_attach(pa_ipc **out, const void *id128, int rank, int nranks) {
 
    x->xr.tab = x->tab_dev; x->xr.nranks = nranks; x->xr.rank = rank; x->xr.slot_doubles = IPC_SLOT;
    x->xr.seq = &x->seq; x->xr.err_dev = x->err_dev; x->xr.timeout_ticks = x->timeout_ticks;
+   x->xr.on_wrap = ipc_seq_wrap; x->xr.owner = x;
+   {  /* PRIMME_AMD_IPC_SEQ0: where the tag sequence starts (test knob: a value just below 2^32 exercises the wrap-around) */
+      const char *s0 = getenv("PRIMME_AMD_IPC_SEQ0");
+      if (s0 && *s0) x->seq = (unsigned int)strtoul(s0, NULL, 10) & ~1u;      /* even: the next reduction keeps the generation alternating */
+   }
 
    /* self-test: a reduction with known sums and a short time limit, so that a transport that maps but does not
     * deliver (no peer access, an incoherent mapping) is found here and not in the solver */

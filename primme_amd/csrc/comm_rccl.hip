@@ -43,12 +43,30 @@ static int comm_mode(void) {
    return PA_COMM_HYBRID;
 }
 
-extern "C" int primme_amd_comm_unique_id(void *id128) {
-   if (comm_mode() != PA_COMM_RCCL) return pa_ipc_unique_id(id128);
+static int rccl_unique_id(void *id128) {
    ncclUniqueId id;
    NCCL_CHECK(ncclGetUniqueId(&id));
    memcpy(id128, &id, sizeof(id) < 128 ? sizeof(id) : 128);
    return 0;
+}
+extern "C" int primme_amd_comm_unique_id(void *id128) {
+   if (comm_mode() != PA_COMM_RCCL) return pa_ipc_unique_id(id128);
+   return rccl_unique_id(id128);
+}
+/* for a launcher that knows the job: a mailbox id only when the mailboxes can serve it (<= 16 ranks on one node) */
+extern "C" int primme_amd_comm_unique_id_for(void *id128, int nranks, int spans_nodes) {
+   const int mode = comm_mode();
+   const int servable = nranks >= 1 && nranks <= HIPK_XR_MAXRANKS && !spans_nodes;
+   if (mode == PA_COMM_RCCL) return rccl_unique_id(id128);
+   if (!servable) {
+      if (mode == PA_COMM_IPC) {
+         fprintf(stderr, "primme_amd: PRIMME_AMD_COMM=ipc cannot serve this job (%d ranks%s): the peer-to-peer mailboxes take at most %d ranks "
+               "on one node; unset PRIMME_AMD_COMM or set it to rccl\n", nranks, spans_nodes ? ", several nodes" : "", HIPK_XR_MAXRANKS);
+         return -43;
+      }
+      return rccl_unique_id(id128);      /* auto: RCCL is what serves it */
+   }
+   return pa_ipc_unique_id(id128);
 }
 
 static int comm_staging(primme_amd_comm *c) {
@@ -65,6 +83,13 @@ extern "C" int primme_amd_comm_create(primme_amd_comm **out, const void *id128, 
    c->rank = rank; c->nranks = nranks;
    ncclUniqueId id;
    memset(&id, 0, sizeof(id));
+   if (pa_ipc_is_ipc_id(id128) && nranks > HIPK_XR_MAXRANKS) {
+      /* every rank sees the same id and the same count: all of them leave here, nobody waits at a rendez-vous */
+      fprintf(stderr, "primme_amd: rank %d: the communicator id is one of the peer-to-peer mailbox transport, which serves at most %d ranks (this job has %d); "
+            "create the id with PRIMME_AMD_COMM=rccl (or with primme_amd_comm_unique_id_for, which picks RCCL for such a job)\n", rank, HIPK_XR_MAXRANKS, nranks);
+      free(c);
+      return -43;
+   }
    if (pa_ipc_is_ipc_id(id128)) {
       /* the mode of the rank that made the id decides (a stray PRIMME_AMD_COMM on one rank must not split the job) */
       int mode = comm_mode(), modes[HIPK_XR_MAXRANKS];
@@ -184,6 +209,10 @@ extern "C" void primme_amd_global_sum(void *sendBuf, void *recvBuf, int *count,
       if (hipHostMalloc((void **)&c->hbuf, c->dbuf_cap * sizeof(double), hipHostMallocMapped) != hipSuccess) return;
    }
    /* globalSumReal_type: this callback handles double (the solver always reduces doubles) */
+   /* The mailbox tags are one sequence per communicator and a slot is reused two reductions later: reductions must reach the
+    * device in the order their tags were taken.  The solver's own reductions run on ITS stream and may still be queued
+    * there; this host-buffer path runs on the communicator's stream: drain the device first (this path synchronises anyway). */
+   if (c->ipc && hipDeviceSynchronize() != hipSuccess) return;
    memcpy(c->hbuf, sendBuf, n * sizeof(double));
    if (hipMemcpyAsync(c->dbuf, c->hbuf, n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
    if (c->ipc) {
@@ -329,4 +358,104 @@ extern "C" int primme_amd_comm_allgather_i64(primme_amd_comm *c, const int64_t *
    (void)hipHostFree(h);
    (void)hipFree(d);
    return 0;
+}
+
+/* ---- self-test: what a launcher runs before it trusts a communicator it has never used on this machine ---------------
+ * Every collective of this header with known data on whatever transport the communicator came up on: all-reduce of
+ * 1 .. 4096 doubles (rank-ordered sums on the mailboxes: exact; RCCL: to rounding), the neighbour halo, the bulk
+ * all-gather and reduce-scatter of a block of columns, the integer exchange, then `reps` back-to-back 8-double
+ * all-reduces for the latency a block-size-1 iteration pays per reduction.  Collective: every rank calls it.
+ * Returns 0 when everything matched on this rank, a positive count of mismatching checks otherwise (negative: an error of
+ * the transport); *allreduce_us (optional) = wall-clock microseconds per all-reduce of the timed loop. */
+static double st_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static double st_val(int rank, int i, int salt) { return (double)(rank + 1) + 1e-3 * (double)i + 0.25 * (double)salt; }
+extern "C" int primme_amd_comm_selftest(primme_amd_comm *c, void *hip_stream, int reps, double *allreduce_us) {
+   if (!c) return -43;
+   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+   const int P = c->nranks, me = c->rank, NMAX = 4096, per = 257, nc = 2;
+   const size_t words = (size_t)NMAX + (size_t)per * P * nc * 2 + 64;
+   double *d = NULL, *h = NULL;
+   if (hipMalloc((void **)&d, words * sizeof(double)) != hipSuccess) return -2;
+   if (hipHostMalloc((void **)&h, words * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipFree(d); return -2; }
+   int bad = 0, rc = 0;
+#define ST_UP(n) (hipMemcpyAsync(d, h, (size_t)(n) * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+#define ST_DOWN(n) (hipMemcpyAsync(h, d, (size_t)(n) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+   const int sizes[] = {1, 2, 15, 16, 17, 300, 4096};
+   for (int s = 0; s < 7 && !rc; s++) {
+      const int n = sizes[s];
+      for (int i = 0; i < n; i++) h[i] = st_val(me, i, s);
+      if (ST_UP(n)) { rc = -1; break; }
+      rc = primme_amd_comm_allreduce(c, st, d, n);
+      if (rc || ST_DOWN(n)) { rc = rc ? rc : -1; break; }
+      for (int i = 0; i < n; i++) {
+         double want = 0.0;
+         for (int p = 0; p < P; p++) want += st_val(p, i, s);        /* rank order: what the mailboxes produce bit for bit */
+         if (!(fabs(h[i] - want) <= 1e-12 * fabs(want))) { bad++; break; }
+      }
+   }
+   /* neighbour halo: 3 rows down, 2 rows up, two columns */
+   if (!rc && P > 1) {
+      const int nrows = 40, ld = 48, lo_n = 2, hi_n = 3;          /* I receive 2 rows from below (rank-1's last 2) and 3 from above */
+      for (int col = 0; col < nc; col++) for (int i = 0; i < nrows; i++) h[col * ld + i] = st_val(me, i, 100 + col);
+      double *dx = d, *dlo = d + nc * ld, *dhi = dlo + nc * lo_n;
+      if (hipMemcpyAsync(dx, h, (size_t)nc * ld * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) rc = -1;
+      /* what rank-1 needs from ME is my first hi_n rows (they are ITS rows from above), what rank+1 needs my last lo_n */
+      if (!rc) rc = primme_amd_comm_halo(c, st, dx, ld, nrows, nc, sizeof(double), hi_n, lo_n, dlo, lo_n, dhi, hi_n);
+      if (!rc && (hipMemcpyAsync(h, dlo, (size_t)nc * (lo_n + hi_n) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                  hipStreamSynchronize(st) != hipSuccess)) rc = -1;
+      if (!rc) {
+         const double *glo = h, *ghi = h + nc * lo_n;
+         for (int col = 0; col < nc; col++) {
+            if (me > 0) for (int i = 0; i < lo_n; i++) if (glo[col * lo_n + i] != st_val(me - 1, nrows - lo_n + i, 100 + col)) { bad++; break; }
+            if (me < P - 1) for (int i = 0; i < hi_n; i++) if (ghi[col * hi_n + i] != st_val(me + 1, i, 100 + col)) { bad++; break; }
+         }
+      }
+   }
+   /* bulk window: all-gather and reduce-scatter of a block of columns */
+   if (!rc) {
+      double *dsend = d, *drecv = d + (size_t)per * P * nc;
+      for (int col = 0; col < nc; col++) for (int i = 0; i < per; i++) h[col * per + i] = st_val(me, i, 200 + col);
+      if (hipMemcpyAsync(dsend, h, (size_t)nc * per * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) rc = -1;
+      if (!rc) rc = primme_amd_comm_allgather_cols(c, st, dsend, per, drecv, (int64_t)per * P, (size_t)per * sizeof(double), sizeof(double), nc);
+      if (!rc && (hipMemcpyAsync(h, drecv, (size_t)nc * per * P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                  hipStreamSynchronize(st) != hipSuccess)) rc = -1;
+      if (!rc) for (int col = 0; col < nc && !bad; col++) for (int p = 0; p < P; p++) for (int i = 0; i < per; i++)
+         if (h[(size_t)col * per * P + (size_t)p * per + i] != st_val(p, i, 200 + col)) { bad++; p = P; break; }
+      for (int col = 0; col < nc; col++) for (int i = 0; i < per * P; i++) h[(size_t)col * per * P + i] = st_val(me, i, 300 + col);
+      if (!rc && hipMemcpyAsync(dsend, h, (size_t)nc * per * P * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) rc = -1;
+      if (!rc) rc = primme_amd_comm_reduce_scatter_cols(c, st, dsend, (int64_t)per * P, drecv, per, per, 1, nc);
+      if (!rc && (hipMemcpyAsync(h, drecv, (size_t)nc * per * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                  hipStreamSynchronize(st) != hipSuccess)) rc = -1;
+      if (!rc) for (int col = 0; col < nc; col++) for (int i = 0; i < per; i++) {
+         double want = 0.0;
+         for (int p = 0; p < P; p++) want += st_val(p, me * per + i, 300 + col);
+         if (!(fabs(h[col * per + i] - want) <= 1e-12 * fabs(want))) { bad++; break; }
+      }
+   }
+   if (!rc) {
+      int64_t mine[2] = {7 + me, -(int64_t)me}, all[2 * HIPK_XR_MAXRANKS > 64 ? 2 * HIPK_XR_MAXRANKS : 64];
+      if (P <= 32) {
+         rc = primme_amd_comm_allgather_i64(c, mine, 2, all);
+         if (!rc) for (int p = 0; p < P; p++) if (all[2 * p] != 7 + p || all[2 * p + 1] != -(int64_t)p) { bad++; break; }
+      }
+   }
+   /* latency: back-to-back 8-double all-reduces (a block-size-1 iteration makes three) */
+   if (!rc && reps > 0) {
+      for (int i = 0; i < 8; i++) h[i] = 1.0;
+      if (ST_UP(8) || hipStreamSynchronize(st) != hipSuccess) rc = -1;
+      for (int w = 0; w < 10 && !rc; w++) rc = primme_amd_comm_allreduce(c, st, d, 8);
+      if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = -1;
+      const double t0 = st_now();
+      for (int r = 0; r < reps && !rc; r++) rc = primme_amd_comm_allreduce(c, st, d, 8);
+      if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = -1;
+      if (!rc && allreduce_us) *allreduce_us = 1e6 * (st_now() - t0) / reps;
+   }
+#undef ST_UP
+#undef ST_DOWN
+   if (!rc && primme_amd_comm_error(c)) rc = -43;
+   (void)hipHostFree(h);
+   (void)hipFree(d);
+   if (rc) { fprintf(stderr, "primme_amd: communicator self-test: rank %d: transport error %d\n", me, rc); return rc < 0 ? rc : -43; }
+   if (bad) fprintf(stderr, "primme_amd: communicator self-test: rank %d: %d check(s) did not match (transport %s)\n", me, bad, primme_amd_comm_transport(c));
+   return bad;
 }

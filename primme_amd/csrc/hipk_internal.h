@@ -66,6 +66,10 @@ struct hipk_xreduce {
    unsigned int *seq;            /* HOST counter of the communicator: one tag per reduction, same sequence on every rank */
    int *err_dev;                 /* pinned error word (device address): set when a wait ran into the time limit */
    long long timeout_ticks;      /* of the 100 MHz wall clock */
+   /* called (collectively: every rank reaches it at the same reduction) when the 32-bit tag sequence wraps: the owner drains
+    * its device, meets the other ranks and clears the granule areas, so that no slot keeps a tag of the previous cycle */
+   int (*on_wrap)(void *owner);
+   void *owner;
 };
 /* by-value kernel argument */
 struct hipk_xr_dev {
@@ -78,8 +82,13 @@ struct hipk_xr_dev {
 static inline unsigned int hipk_xr_next_seq(hipk_xreduce *xr) {
    unsigned int q = ++*xr->seq;
    /* wrap-around after 2^32 - 1 reductions: 0 is the tag of an empty mailbox, and the generation (tag & 1) must keep
-    * alternating (0xffffffff was odd), so the sequence continues at 2 */
-   if (q == 0) { *xr->seq = 2; q = 2; }
+    * alternating (0xffffffff was odd), so the sequence continues at 2 — after the granule areas have been cleared on every
+    * rank (a slot that was last written in the previous cycle could otherwise carry exactly the tag a reduction of this
+    * cycle waits for, and stale data would be taken for the peer's contribution) */
+   if (q == 0) {
+      if (xr->on_wrap) (void)xr->on_wrap(xr->owner);
+      *xr->seq = 2; q = 2;
+   }
    return q;
 }
 static inline hipk_xr_dev hipk_xr_make(hipk_xreduce *xr) {

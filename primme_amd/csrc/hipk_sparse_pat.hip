@@ -27,7 +27,15 @@
 
 #define PAT_MAXLEN 8
 #define PAT_MAXPAT 256
-#define PAT_RPL 2                  /* rows per lane and trip */
+/* rows per lane and trip / resident waves per SIMD the kernel is compiled for, by table width (HIPK_PAT_RPL, a build-time
+ * knob for A/B builds: scripts/build_variant.sh) */
+#ifndef HIPK_PAT_RPL
+#define HIPK_PAT_RPL 4
+#endif
+#define PAT_RPL_FOR(ML) ((ML) <= 5 ? HIPK_PAT_RPL : ((HIPK_PAT_RPL) > 2 ? (HIPK_PAT_RPL) / 2 : (HIPK_PAT_RPL)))
+#ifndef HIPK_PAT_WPS
+#define HIPK_PAT_WPS 6
+#endif
 
 struct hipk_pat {
    hipk_ctx *ctx;
@@ -48,11 +56,15 @@ __device__ __forceinline__ double pat_mul_add(double s, double v, double x) {
    return s + p;
 }
 
-/* XCD-aware persistent schedule: workgroups are dealt round-robin to the 8 XCDs; XCD q owns a contiguous eighth of the
+/* XCD-aware PERSISTENT schedule: exactly as many workgroups as the chip holds at once (WPS per SIMD = WPS workgroups of four
+ * waves per CU, enforced through __launch_bounds__; a grid larger than the resident set would run its tail after the
+ * first workgroups have walked ALL their chunks), dealt round-robin to the 8 XCDs; XCD q owns a contiguous eighth of the
  * row chunks and its workgroups walk it with stride (workgroups per XCD), so the rows an XCD has in flight are one
- * contiguous window and the +-nx / +-plane neighbours of a stencil row are found in ITS L2. */
-template <typename T, int ML, bool FUSED, bool HALO>
-__global__ void __launch_bounds__(HIPK_BLOCK)
+ * contiguous window and the +-nx / +-plane neighbours of a stencil row are found in ITS L2.
+ * RPL rows per lane and trip (256 apart: every access of a wave stays unit-stride): all their gathers are issued before
+ * the first product — the bytes a wave keeps in flight are what bounds a kernel whose rows need 9 bytes from HBM. */
+template <typename T, int ML, int RPL, int WPS, bool FUSED, bool HALO>
+__global__ void __launch_bounds__(HIPK_BLOCK, WPS)
 pat_kernel(const uint8_t *__restrict__ pid, const int32_t *__restrict__ toff, const double *__restrict__ tval,
       const int32_t *__restrict__ tlen, int npat, int64_t nrows, const T *__restrict__ x, T *__restrict__ y,
       int64_t halo_lo, const T *__restrict__ xlo, const T *__restrict__ xhi, const double *__restrict__ norm2,
@@ -66,47 +78,44 @@ pat_kernel(const uint8_t *__restrict__ pid, const int32_t *__restrict__ toff, co
    for (int i = threadIdx.x; i < npat; i += HIPK_BLOCK) s_len[i] = tlen[i];
    __syncthreads();
    const double a = (FUSED && norm2) ? 1.0 / sqrt(norm2[0]) : 1.0;
-   const int64_t CH = (int64_t)HIPK_BLOCK * PAT_RPL;
+   const int64_t CH = (int64_t)HIPK_BLOCK * RPL;
    const int64_t nch = (nrows + CH - 1) / CH;
    const int64_t per = (nch + 7) >> 3;
    const int q = blockIdx.x & 7, j = blockIdx.x >> 3, J = gridDim.x >> 3;
    const int64_t c_lo = (int64_t)q * per, c_hi = c_lo + per < nch ? c_lo + per : nch;
    const int64_t last = nrows - 1;
    double dotp = 0.0;
-   int pn[PAT_RPL];
+   int pn[RPL];
    {
       const int64_t c = c_lo + j;
 #pragma unroll
-      for (int u = 0; u < PAT_RPL; u++) {
+      for (int u = 0; u < RPL; u++) {
          const int64_t r = c * CH + threadIdx.x + (int64_t)u * HIPK_BLOCK;
          pn[u] = (c < c_hi) ? (int)__builtin_nontemporal_load(pid + (r < last ? r : last)) : 0;
       }
    }
    for (int64_t c = c_lo + j; c < c_hi; c += J) {
-      int p[PAT_RPL];
-      int64_t r[PAT_RPL];
+      int p[RPL];
+      int64_t r[RPL];
 #pragma unroll
-      for (int u = 0; u < PAT_RPL; u++) { p[u] = pn[u]; r[u] = c * CH + threadIdx.x + (int64_t)u * HIPK_BLOCK; }
+      for (int u = 0; u < RPL; u++) { p[u] = pn[u]; r[u] = c * CH + threadIdx.x + (int64_t)u * HIPK_BLOCK; }
       /* the next trip's patterns are on their way before this trip's gathers go out */
       if (c + J < c_hi) {
 #pragma unroll
-         for (int u = 0; u < PAT_RPL; u++) {
+         for (int u = 0; u < RPL; u++) {
             const int64_t rn = (c + J) * CH + threadIdx.x + (int64_t)u * HIPK_BLOCK;
             pn[u] = (int)__builtin_nontemporal_load(pid + (rn < last ? rn : last));
          }
       }
-      double xg[PAT_RPL][ML], v[PAT_RPL][ML], xo[PAT_RPL];
-      int len[PAT_RPL];
+      double xg[RPL][ML], xo[RPL];
       /* every gather of the trip issued before the first product; a row past the end works on the last row (not stored),
        * an entry past a row's length gathers the row's own x (table: offset 0, value 0) and is not added */
 #pragma unroll
-      for (int u = 0; u < PAT_RPL; u++) {
+      for (int u = 0; u < RPL; u++) {
          const int64_t rc = r[u] < last ? r[u] : last;
-         len[u] = s_len[p[u]];
 #pragma unroll
          for (int e = 0; e < ML; e++) {
             const int64_t l = rc + (int64_t)s_off[p[u] * ML + e];
-            v[u][e] = s_val[p[u] * ML + e];
             if (HALO) {
                const T *src = x + l;
                if (l < 0) src = xlo + (l + halo_lo);
@@ -119,13 +128,14 @@ pat_kernel(const uint8_t *__restrict__ pid, const int32_t *__restrict__ toff, co
          if (FUSED) xo[u] = (double)x[rc];
       }
 #pragma unroll
-      for (int u = 0; u < PAT_RPL; u++) {
+      for (int u = 0; u < RPL; u++) {
+         const int len = s_len[p[u]];
          double s = 0.0;
 #pragma unroll
          for (int e = 0; e < ML; e++) {
             const double xv = FUSED ? (double)(T)(a * xg[u][e]) : xg[u][e];
-            const double t = pat_mul_add(s, v[u][e], xv);
-            s = e < len[u] ? t : s;
+            const double t = pat_mul_add(s, s_val[p[u] * ML + e], xv);
+            s = e < len ? t : s;
          }
          if (r[u] < nrows) {
             const T yt = (T)s;
@@ -232,10 +242,11 @@ extern "C" int hipk_pat_build(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int64_t r
 extern "C" int hipk_pat_npatterns(const hipk_pat *B) { return B ? B->npat : 0; }
 /* workgroups of a launch (a multiple of 8: the XCD schedule); the fused form writes one partial sum per workgroup */
 extern "C" int hipk_pat_grid(const hipk_pat *B, int num_cu) {
-   const int64_t nch = (B->nrows + (int64_t)HIPK_BLOCK * PAT_RPL - 1) / ((int64_t)HIPK_BLOCK * PAT_RPL);
-   int64_t g = (int64_t)num_cu * 8;
+   const int rpl = PAT_RPL_FOR(B->ml);
+   const int64_t nch = (B->nrows + (int64_t)HIPK_BLOCK * rpl - 1) / ((int64_t)HIPK_BLOCK * rpl);
+   int64_t g = (int64_t)num_cu * HIPK_PAT_WPS;        /* the resident set: HIPK_PAT_WPS workgroups per CU (__launch_bounds__) */
    if (g > nch) g = nch;
-   g = (g + 7) / 8 * 8;
+   g = g / 8 * 8;                                     /* a multiple of 8 that does not exceed it: the XCD schedule */
    return (int)(g < 8 ? 8 : g);
 }
 /* bytes one product moves through HBM: the pattern bytes, x once, y (and the second output of the fused form) */
@@ -248,7 +259,7 @@ template <typename T, bool FUSED, bool HALO>
 static void pat_launch_ml(const hipk_pat *B, hipStream_t st, int gx, const T *x, T *y, int64_t halo_lo, const T *xlo, const T *xhi,
       const double *norm2, T *xout, double *partials, const hipk_fin_args &fa) {
    const size_t shm = (size_t)B->npat * B->ml * 12 + (size_t)B->npat * 4 + 8;
-#define PATL(MLV) hipLaunchKernelGGL((pat_kernel<T, MLV, FUSED, HALO>), dim3(gx), dim3(HIPK_BLOCK), shm, st, B->pid, B->toff, B->tval, B->tlen, B->npat, \
+#define PATL(MLV) hipLaunchKernelGGL((pat_kernel<T, MLV, PAT_RPL_FOR(MLV), HIPK_PAT_WPS, FUSED, HALO>), dim3(gx), dim3(HIPK_BLOCK), shm, st, B->pid, B->toff, B->tval, B->tlen, B->npat, \
          B->nrows, x, y, halo_lo, xlo, xhi, norm2, xout, partials, fa)
    switch (B->ml) {
    case 3: PATL(3); break;

@@ -38,16 +38,12 @@ def pytest_collection_modifyitems(config, items):
 
 
 # ---- leaving a GPU session --------------------------------------------------------------------------------------
-# Round 4 (profiles/r04_gpu_suite_exit_crash.md): of the three full `-m gpu` runs that included the multi-rank module
-# (tests/test_multirank_ipc_gpu.py: two dozen rank processes spawned on the same device), two ended in SIGSEGV / SIGABRT
-# during interpreter exit — AFTER pytest had printed `532 passed` — and one aborted mid-run in glibc's heap check
-# (`realloc(): invalid next size`, inside pytest's own bookkeeping, before any multi-rank test had run).  Three runs
-# without that module, every test module on its own, the CPU suite under AddressSanitizer, the panel-blocked builder
-# under AddressSanitizer at full size, and component loops under MALLOC_CHECK_=3 were all clean: the cause was not
-# found.  What this hook does about the exit-time form only: nothing of the library is alive when the session ends
-# (every context, communicator and buffer is destroyed by its test), so a GPU session leaves with the status pytest
-# computed, without running the teardown of the HIP runtime / torch / RCCL.  PRIMME_AMD_TEST_NORMAL_EXIT=1 restores the
-# normal exit.
+# Round 4 (profiles/r04_gpu_suite_exit_crash.md): two of three full `-m gpu` runs that included the multi-rank module ended
+# in SIGSEGV / SIGABRT during interpreter exit, one aborted mid-run in glibc's heap check, and round 4 left every GPU
+# session through os._exit.  Round 5 (profiles/r05_gpu_suite_*.txt): the whole suite ran on the
+# device with the host code of the product library under AddressSanitizer (no report) and under glibc's heap checks with
+# the NORMAL interpreter exit, and every full run of the round left normally.  The normal exit is the default again;
+# PRIMME_AMD_TEST_FAST_EXIT=1 brings the os._exit shortcut back (a debugging aid, nothing relies on it).
 _session = {"status": None, "gpu": False}
 
 
@@ -61,6 +57,6 @@ def pytest_sessionfinish(session, exitstatus):
 def pytest_unconfigure(config):
     if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
         return                      # a pytest-xdist worker reports to its controller on the way out
-    if _session["gpu"] and _session["status"] is not None and not os.environ.get("PRIMME_AMD_TEST_NORMAL_EXIT"):
+    if _session["gpu"] and _session["status"] is not None and os.environ.get("PRIMME_AMD_TEST_FAST_EXIT"):
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(_session["status"])

@@ -15,6 +15,10 @@ subprocess.check_call(["make", "ref", "-j8"], cwd=os.path.join(ROOT, "oracle"))
 subprocess.check_call(["make", "kernel-fixture"], cwd=os.path.join(ROOT, "oracle"))
 out = subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_kernel_harness")], text=True)
 data = json.loads(out)
+# round 5: the same four routines at large shapes (inputs are closed forms the test regenerates; m-sized outputs as sums + samples)
+WIDE = [(4099, 15, 8, 9), (4099, 41, 1, 0), (100003, 15, 1, 9), (100003, 41, 8, 9)]
+data["wide"] = [json.loads(subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_kernel_harness"), "wide", *map(str, w)], text=True))
+                for w in WIDE]
 data["generated_by"] = "tests/golden/make_kernel_golden.py -> oracle/ref_kernel_harness.c (reference PRIMME, double, MKL BLAS)"
 path = os.path.join(ROOT, "tests", "golden", "reference_kernels.json")
 json.dump(data, open(path, "w"))

@@ -104,6 +104,12 @@ def comm_ops(lib, comm, rank, world, res):
     res["allreduce8_chain_us"] = 1e6 * (time.perf_counter() - t0) / 5
     ok &= bool(np.all(x.cpu().numpy() == (1.0 / 1024) * float(world) ** 5))
     ok &= lib.primme_amd_comm_error(comm) == 0
+    # the library's own self-test (what bench.py --gpus N runs before its timed region)
+    lib.primme_amd_comm_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    us = C.c_double(-1.0)
+    res["selftest"] = lib.primme_amd_comm_selftest(comm, None, 200, C.byref(us))
+    res["selftest_allreduce_us"] = us.value
+    ok &= res["selftest"] == 0 and us.value > 0
     res.update(ret=0 if ok else 1, evals=[], resNorms=[], its=0, numGlobalSum=1, evecs_norm2=0.0, aNorm=0.0)
     return None
 

@@ -68,6 +68,26 @@ def test_solver_through_rccl_reductions(built, kw):
     lib.primme_amd_comm_destroy(comm)
 
 
+@pytest.mark.parametrize("transport", ["auto", "rccl"])
+def test_communicator_selftest_one_rank(built, transport, monkeypatch):
+    """primme_amd_comm_selftest on the one GPU of the box (one rank: mailboxes under `auto`, RCCL when asked for): every
+    collective against known data, and a latency figure"""
+    lib = F.load_product()
+    monkeypatch.setenv("PRIMME_AMD_COMM", transport)
+    lib.primme_amd_comm_transport.restype = C.c_char_p
+    lib.primme_amd_comm_transport.argtypes = [C.c_void_p]
+    lib.primme_amd_comm_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    buf = (C.c_char * 128)()
+    assert lib.primme_amd_comm_unique_id_for(buf, 1, 0) == 0
+    comm = C.c_void_p()
+    assert lib.primme_amd_comm_create(C.byref(comm), bytes(buf.raw), 0, 1) == 0
+    assert lib.primme_amd_comm_transport(comm).decode() == ("rccl" if transport == "rccl" else "ipc")
+    us = C.c_double(-1.0)
+    assert lib.primme_amd_comm_selftest(comm, None, 100, C.byref(us)) == 0
+    assert 0.0 < us.value < 1e4
+    lib.primme_amd_comm_destroy(comm)
+
+
 def test_mailboxes_that_do_not_come_up_fall_back_to_rccl(built):
     """`auto`: when the peer-to-peer mailboxes fail their self-test on any rank, every rank learns of it through the
     rendez-vous and the communicator comes up on RCCL instead (its id travels through the same rendez-vous)."""

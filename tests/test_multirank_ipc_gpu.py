@@ -60,13 +60,23 @@ def test_ipc_collectives(built, tmp_path, world):
     integer exchange: against numpy; the reduction results are bitwise the same on every rank."""
     res = _launch("comm_ops", world, tmp_path)
     for r in res:
-        assert r["digest"] == res[0]["digest"]
-    lat = {"world": world, "allreduce8_sync_us": [round(r["allreduce8_sync_us"], 1) for r in res],
+        assert r["digest"] == res[0]["digest"] and r["selftest"] == 0
+    lat = {"world": world, "selftest_allreduce_us": [round(r["selftest_allreduce_us"], 1) for r in res], "allreduce8_sync_us": [round(r["allreduce8_sync_us"], 1) for r in res],
            "allreduce8_chain_us": [round(r["allreduce8_chain_us"], 1) for r in res]}
     print("IPC_LATENCY", json.dumps(lat))
     os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(HERE), "gpurun_out", "ipc_allreduce_latency.jsonl"), "a") as f:
         f.write(json.dumps(lat) + "\n")
+
+
+def test_ipc_tag_sequence_wraps_around(built, tmp_path):
+    """The 32-bit tag sequence of the mailbox reductions started 60 reductions below 2^32 (PRIMME_AMD_IPC_SEQ0): the
+    collectives cross the wrap-around — every rank drains, meets the others and clears its granule area there
+    (csrc/comm_ipc.hip: ipc_seq_wrap), the sequence continues at 2 with the generations alternating — and every sum
+    is still the rank-ordered one on every rank, the library's self-test included."""
+    res = _launch("comm_ops", 2, tmp_path, extra_env={"PRIMME_AMD_IPC_SEQ0": str(2 ** 32 - 60)})
+    for r in res:
+        assert r["digest"] == res[0]["digest"] and r["selftest"] == 0
 
 
 @pytest.mark.parametrize("world", WORLDS)

@@ -19,3 +19,19 @@ def test_hip_kernels_against_reference_routines(built, case):
     side = Dev()
     getattr(RK, "check_" + case)(side)
     side.close()
+
+
+# round 5: the same routines of the reference at m = 4 099 and 100 003, k = 15 and 41, blocks of 1 and 8, 0 and 9 locked vectors
+@pytest.mark.parametrize("idx", range(len(RK.GOLD["wide"])))
+def test_oracle_kernels_against_reference_routines_large_shapes(built, idx):
+    side = Host()
+    RK.check_wide(side, idx)
+    side.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", range(len(RK.GOLD["wide"])))
+def test_hip_kernels_against_reference_routines_large_shapes(built, idx):
+    side = Dev()
+    RK.check_wide(side, idx)
+    side.close()
