@@ -36,6 +36,8 @@ int primme_amd_comm_unique_id(void *id128);
  * keep working for jobs that span nodes or have more ranks.  An explicit PRIMME_AMD_COMM=ipc on a job the mailboxes cannot
  * serve fails here (-43, with a message) instead of at the rendez-vous. */
 int primme_amd_comm_unique_id_for(void *id128, int nranks, int spans_nodes);
+/* the decision alone, without creating anything: 1 = a mailbox id, 0 = an ncclUniqueId, -43 = refused */
+int primme_amd_comm_id_kind_for(int nranks, int spans_nodes);
 /* Fails fast (-43 and a message saying what to set), the same way on every rank, when a mailbox id meets more than 16 ranks; a
  * rank that cannot see the rendez-vous segment (another node / IPC namespace) returns -43 at once and the ranks that can
  * see it give up after PRIMME_AMD_IPC_ATTACH_TIMEOUT_S seconds (default 60; the later rendez-vous keep

@@ -172,6 +172,38 @@ int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
       const void *W, int64_t ldVW, int k, const double *hcol_host, double theta, void *dst,
       const void *Q, int64_t ldQ, int L, int want_wtr, double *out_dev);
 
+/* ---- the NEXT block-size-1 iteration enqueued before the host has seen this one ----
+ * Between the last reduction of an outer iteration and the first kernel of the next the device used to wait for the host:
+ * completion flag over PCIe, the small eigenproblem, a launch — 20-26 us per iteration.  With these two entry points the host
+ * enqueues the next iteration's launches right behind the current ones; the ONE thing they need from the host, the Ritz pair
+ * the next residual is formed with, is computed by a one-wave kernel from what is already in HBM:
+ *   hipk_rr_arrow: the host passes the Rayleigh-Ritz decomposition it holds for the CURRENT basis (k Ritz values theta,
+ *     coefficient vectors Y, the kept rows of G = W'Q) by value; the kernel reads this iteration's reductions
+ *     fov = [V'r (k) | Q'r (L) | r'r | W'r (k) | W(:,k-1)'Q (L)], |t|^2 at fov[nfov] and t'At at alpha_dev[0], forms the new
+ *     column of the projected matrix in the Ritz basis, z = Y'(W'r - H V'r - G Q'r)/|t| (H = Y diag(theta) Y'), and solves the
+ *     (k+1) x (k+1) ARROWHEAD eigenproblem [diag(theta) z; z' alpha] for its `cand`-th eigenpair (ascending; descending with
+ *     largest != 0) through the secular equation (one pole-shifted root, safeguarded Newton on 16 lanes) — O(k) per step
+ *     instead of the O(k^3) dense solve, which the host still runs, off the critical path, for its own bookkeeping.
+ *     out_dev[0 .. k] = the coefficient vector in the basis [V t], out_dev[32] = the Ritz value, out_dev[33] = status
+ *     (0 ok; anything else: no valid pair, the residual launch that reads it leaves at once).  k <= 16, L <= 10.
+ *   hipk_ritz_residual_overlaps_dev: hipk_ritz_residual_overlaps with the coefficient vector and the Ritz value read
+ *     from DEVICE memory (hth_dev = out_dev of hipk_rr_arrow).
+ * The host adopts the result when its own Rayleigh-Ritz solve arrives at the same pair (to rounding) and throws it away
+ * otherwise; hipk_seq_issued / hipk_wait_seq let it wait for one particular flagged reduction while later ones are queued. */
+typedef struct hipk_rr_in {
+   int k, L, cand, largest, grow_row;      /* grow_row != 0: row k-1 of G is this pass' W(:,k-1)'Q (fov[2k+L+1 ..)), not G[k-1][:] */
+   int pad;
+   double theta[16];                       /* Ritz values of the current basis, in the host's order */
+   double Y[16 * 16];                      /* their coefficient vectors, column i = Y[i*k .. i*k + k) */
+   double G[16 * 10];                      /* G[j + l*k] = W(:,j)' Q(:,l) */
+} hipk_rr_in;
+int hipk_rr_arrow(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov_dev, int nfov, const double *alpha_dev, double *out_dev);
+int hipk_ritz_residual_overlaps_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W, int64_t ldVW, int k,
+      const double *hth_dev, void *dst, const void *Q, int64_t ldQ, int L, int want_wtr, double *out_dev);
+/* sequence number of the last flagged reduction enqueued on the context, and a wait for a particular one */
+unsigned long long hipk_seq_issued(hipk_ctx *ctx);
+int hipk_wait_seq(hipk_ctx *ctx, unsigned long long seq);
+
 /* ---- column utilities ---------------------------------------------------------
  * Num_scal (cublas_wrapper.c:678), Num_axpy (:616), Num_copy_matrix (:739),
  * permute_vecs / Num_compact_vecs on device columns (auxiliary.c:716, :897). */

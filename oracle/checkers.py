@@ -51,6 +51,12 @@ def load_hostcheck():
 def load_reference():
     """The real reference built by oracle/Makefile from /root/reference."""
     if "reference" not in _cache:
+        # The reference is linked with the image's MKL (libmkl_rt), whose default threading layer brings Intel's OpenMP
+        # runtime; a process that has imported torch (primme_amd._ffi does, for the one HIP runtime) already runs GNU's.
+        # Two OpenMP runtimes under MKL make the reference return garbage or hang — whether it happened depended on which
+        # test module touched MKL first (round 5: a new module moved the order and three reference runs went wrong).
+        # One runtime for everybody; must be in the environment before MKL's first call.
+        os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
         lib = C.CDLL(REFERENCE_LIB)
         F.declare_solver(lib, "")
         _cache["reference"] = lib

@@ -275,6 +275,88 @@ int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
    return 0;
 }
 
+/* the residual pass with the coefficient vector / Ritz value / status left in "device" memory by hipk_rr_arrow */
+int hipk_ritz_residual_overlaps_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W, int64_t ld, int k,
+      const double *hth, void *dst, const void *Q, int64_t ldQ, int L, int want_wtr, double *out) {
+   if (!hth) return -1;
+   if (hth[33] != 0.0) return 0;                 /* no valid pair: the launch leaves at once */
+   return hipk_ritz_residual_overlaps(ctx, dt, m, V, W, ld, k, hth, hth[32], dst, Q, ldQ, L, want_wtr, out);
+}
+unsigned long long hipk_seq_issued(hipk_ctx *ctx) { (void)ctx; return 0; }
+int hipk_wait_seq(hipk_ctx *ctx, unsigned long long seq) { (void)ctx; (void)seq; return 0; }
+
+/* One eigenpair of the arrowhead matrix [diag(theta) z; z' alpha] through the secular equation: the plain-C restatement of
+ * rr_arrow_kernel (csrc/hipk_panels.hip; include/primme_amd_kernels.h: hipk_rr_arrow).  Same formulas, sequential sums. */
+int hipk_rr_arrow(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov, int nfov, const double *alpha_dev, double *out) {
+   (void)ctx;
+   if (!in || in->k < 1 || in->k > 16 || in->L < 0 || in->L > 10) return -1;
+   const int k = in->k, L = in->L, c = in->cand;
+   const double sgn = in->largest ? -1.0 : 1.0;
+   const double n2 = fov[nfov], nt = sqrt(n2), alpha = alpha_dev[0];
+   double v1[16], v2[16], th[16], z[16], y[17], h[17];
+   int status = (c < 0 || c > k || !(n2 > 0.0)) ? 1 : 0;
+   for (int j = 0; j < k; j++) {
+      double gq = 0.0;
+      for (int l = 0; l < L; l++) gq += ((in->grow_row && j == k - 1) ? fov[2 * k + L + 1 + l] : in->G[j + l * k]) * fov[k + l];
+      v1[j] = fov[k + L + 1 + j] - gq;
+      v2[j] = fov[j];
+   }
+   double zn2 = 0.0;
+   for (int i = 0; i < k; i++) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int r = 0; r < k; r++) { a1 += in->Y[r + i * k] * v1[r]; a2 += in->Y[r + i * k] * v2[r]; }
+      z[i] = sgn * (a1 - in->theta[i] * a2) / nt;
+      th[i] = sgn * in->theta[i];
+      zn2 += z[i] * z[i];
+      if (!isfinite(th[i]) || !isfinite(z[i]) || (i > 0 && !(th[i - 1] < th[i]))) status = status ? status : 2;
+   }
+   const double al = sgn * alpha, zn = sqrt(zn2);
+   if (!isfinite(al)) status = status ? status : 2;
+   double lam = 0.0, ynorm2 = 1.0;
+   for (int j = 0; j <= 16; j++) y[j] = 0.0;
+   if (status == 0) {
+      int o;
+      double lo, hi;
+      if (c == 0) { o = 0; lo = fmin(0.0, al - th[0]) - zn - 1e-300; lo -= 4e-16 * fabs(lo); hi = 0.0; }
+      else if (c == k) { o = k - 1; lo = 0.0; hi = fmax(0.0, al - th[k - 1]) + zn + 1e-300; hi += 4e-16 * fabs(hi); }
+      else {
+         const double gap = th[c] - th[c - 1], mid = 0.5 * gap;
+         double sm = 0.0;
+         for (int j = 0; j < k; j++) sm += z[j] * z[j] / ((th[j] - th[c - 1]) - mid);
+         const double gm = (al - th[c - 1]) - mid - sm;
+         if (gm > 0.0) { o = c; lo = -mid; hi = 0.0; }
+         else { o = c - 1; lo = 0.0; hi = mid; }
+      }
+      const double a0 = al - th[o];
+      double mu = 0.5 * (lo + hi);
+      int it = 0;
+      for (; it < 100; it++) {
+         double sm = 0.0, sp = 0.0;
+         for (int j = 0; j < k; j++) { const double r = 1.0 / ((th[j] - th[o]) - mu), t = z[j] * z[j] * r; sm += t; sp += t * r; }
+         const double g = a0 - mu - sm, gp = -1.0 - sp;
+         if (!(g == g)) { status = 3; break; }
+         if (g > 0.0) lo = mu; else if (g < 0.0) hi = mu; else break;
+         double mn = mu - g / gp;
+         if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
+         const double step = fabs(mn - mu);
+         const int done = step <= 4.4e-16 * fabs(mn) || mn == lo || mn == hi;
+         mu = mn;
+         if (done) break;
+      }
+      if (it >= 100) status = 4;
+      lam = sgn * (th[o] + mu);
+      for (int j = 0; j < k; j++) { y[j] = z[j] / (mu - (th[j] - th[o])); ynorm2 += y[j] * y[j]; }
+      if (!isfinite(lam) || !isfinite(ynorm2)) status = 5;
+   }
+   const double inv = 1.0 / sqrt(ynorm2);
+   for (int j = 0; j < k; j++) { double hv = 0.0; for (int i = 0; i < k; i++) hv += in->Y[j + i * k] * y[i]; h[j] = hv * inv; }
+   h[k] = inv;
+   for (int j = 0; j <= k; j++) out[j] = h[j];
+   out[32] = lam; out[33] = (double)status;
+   mirror(out, 34);
+   return 0;
+}
+
 int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx, const double *a) {
    (void)ctx;
    if (IS_Z(dt)) return hipk_z_scale_cols(dt, m, X, ldX, nx, a);

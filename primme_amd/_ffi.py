@@ -152,6 +152,12 @@ class HipkJob(C.Structure):
     _fields_ = [("kind", C.c_int), ("col", C.c_int), ("dst", C.c_void_p), ("slot", C.c_int)]
 
 
+class HipkRrIn(C.Structure):
+    """include/primme_amd_kernels.h: hipk_rr_in (what the host passes to the one-wave Rayleigh-Ritz kernel by value)"""
+    _fields_ = [("k", C.c_int), ("L", C.c_int), ("cand", C.c_int), ("largest", C.c_int), ("grow_row", C.c_int), ("pad", C.c_int),
+                ("theta", C.c_double * 16), ("Y", C.c_double * 256), ("G", C.c_double * 160)]
+
+
 # PRIMME_AMD_LIB: another build of the product library (measurement only: the build-time variants of scripts/build_variant.sh)
 PRODUCT_LIB = os.environ.get("PRIMME_AMD_LIB") or os.path.join(_HERE, "libprimme_amd.so")
 
@@ -192,6 +198,8 @@ def declare_kernels(lib):
         "hipk_panel_project": [_vp, _i, _i64, P(HipkSeg), _i, _vp, _i, _vp, _i64, _i, _vp],
         "hipk_ritz_update": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, P(HipkJob), _i, _vp],
         "hipk_ritz_residual_overlaps": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, C.c_double, _vp, _vp, _i64, _i, _i, _vp],
+        "hipk_ritz_residual_overlaps_dev": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
+        "hipk_rr_arrow": [_vp, P(HipkRrIn), _vp, _i, _vp, _vp],
         "hipk_ritz_update_overlaps": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, P(HipkJob), _i, _vp, _i, _vp, _i64, _i, _vp],
         "hipk_pair_dots": [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i, _vp],
         "hipk_sym_eig": [_vp, _i, _vp, _i, _vp, _vp, _i],

@@ -53,20 +53,23 @@ extern "C" int primme_amd_comm_unique_id(void *id128) {
    if (comm_mode() != PA_COMM_RCCL) return pa_ipc_unique_id(id128);
    return rccl_unique_id(id128);
 }
-/* for a launcher that knows the job: a mailbox id only when the mailboxes can serve it (<= 16 ranks on one node) */
-extern "C" int primme_amd_comm_unique_id_for(void *id128, int nranks, int spans_nodes) {
+/* for a launcher that knows the job: a mailbox id only when the mailboxes can serve it (<= 16 ranks on one node).
+ * primme_amd_comm_id_kind_for: the decision alone, without side effects — 1 mailbox id, 0 ncclUniqueId, -43 refused */
+extern "C" int primme_amd_comm_id_kind_for(int nranks, int spans_nodes) {
    const int mode = comm_mode();
    const int servable = nranks >= 1 && nranks <= HIPK_XR_MAXRANKS && !spans_nodes;
-   if (mode == PA_COMM_RCCL) return rccl_unique_id(id128);
-   if (!servable) {
-      if (mode == PA_COMM_IPC) {
-         fprintf(stderr, "primme_amd: PRIMME_AMD_COMM=ipc cannot serve this job (%d ranks%s): the peer-to-peer mailboxes take at most %d ranks "
-               "on one node; unset PRIMME_AMD_COMM or set it to rccl\n", nranks, spans_nodes ? ", several nodes" : "", HIPK_XR_MAXRANKS);
-         return -43;
-      }
-      return rccl_unique_id(id128);      /* auto: RCCL is what serves it */
+   if (mode == PA_COMM_RCCL) return 0;
+   if (!servable) return mode == PA_COMM_IPC ? -43 : 0;      /* auto: RCCL is what serves it; ipc asked for explicitly: refused */
+   return 1;
+}
+extern "C" int primme_amd_comm_unique_id_for(void *id128, int nranks, int spans_nodes) {
+   const int kind = primme_amd_comm_id_kind_for(nranks, spans_nodes);
+   if (kind < 0) {
+      fprintf(stderr, "primme_amd: PRIMME_AMD_COMM=ipc cannot serve this job (%d ranks%s): the peer-to-peer mailboxes take at most %d ranks "
+            "on one node; unset PRIMME_AMD_COMM or set it to rccl\n", nranks, spans_nodes ? ", several nodes" : "", HIPK_XR_MAXRANKS);
+      return kind;
    }
-   return pa_ipc_unique_id(id128);
+   return kind == 1 ? pa_ipc_unique_id(id128) : rccl_unique_id(id128);
 }
 
 static int comm_staging(primme_amd_comm *c) {

@@ -269,13 +269,102 @@ static int try_speculative_restart(pa_solver *s, int basisSize, int nLk, const i
    return 1;
 }
 
+/* ---- the NEXT iteration enqueued before the host has seen this one -----------------------------
+ * Where t'At of the fused tail goes: a slot at the end of the overlap buffer the pass belongs to (the pre-enqueued
+ * iteration must not write where the host is still reading this iteration's). */
+#define PA_ALPHA_OFF(s) ((s)->red_cap - 2)
+
+/* The host-side arithmetic after the one wait of the fused tail: the new column of H from W'r. */
+static void tail_finish(pa_solver *s, int basisSize, int nLk, int nfov, const double *h_fov, double alpha) {
+   const int nov = basisSize + nLk;
+   const double *cV = h_fov, *cQ = h_fov + basisSize, *wr = h_fov + nov + 1;
+   const double inv = 1.0 / sqrt(h_fov[nfov]);
+   if (nLk > 0 && s->wtq_rows == basisSize - 1) {
+      for (int l = 0; l < nLk; l++) s->wtq[(basisSize - 1) + (size_t)l * s->K] = wr[basisSize + l];
+      s->wtq_rows = basisSize;
+   }
+   for (int j = 0; j < basisSize; j++) {
+      double hc = 0.0;
+      for (int i = 0; i < basisSize; i++)
+         hc += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * cV[i];
+      for (int l = 0; l < nLk; l++) hc += s->wtq[j + (size_t)l * s->K] * cQ[l];
+      s->spec_hcol[j] = (wr[j] - hc) * inv;
+   }
+   s->spec_hcol[basisSize] = alpha;
+}
+
+/* Enqueue iteration basisSize + 1 behind the launches of iteration basisSize, whose results the host has NOT seen yet:
+ * the Ritz pair of its residual comes from hipk_rr_arrow (one wave: the arrowhead eigenproblem in the Ritz basis the host
+ * holds for the current size), then the same three launches as any iteration — residual + overlaps, Gram-Schmidt update,
+ * scale + A t + t'At — on the other overlap buffer / scratch column.  Nothing here synchronises.  Returns 0 when enqueued
+ * (s->pre_valid set) or when the case is not covered (s->pre_valid clear). */
+static int pa_prelaunch_next(pa_solver *s, int basisSize, int nLk, int col, int nfov) {
+   primme_params *p = s->p;
+   const int k = basisSize, k1 = basisSize + 1;
+   s->pre_valid = 0;
+   if (!s->pre_enabled || s->parallel || s->phase_timing || s->Q || s->VtBV || !s->wtr_enabled) return 0;
+   if (p->target != primme_smallest && p->target != primme_largest) return 0;
+   if (k1 > 16 || nLk > 10 || k1 + 1 > p->maxBasisSize || col < 0 || col > k) return 0;
+   if (p->maxMatvecs > 0 && p->stats.numMatvecs + 3 >= p->maxMatvecs) return 0;
+   if (p->maxOuterIterations > 0 && p->stats.numOuterIterations + 2 >= p->maxOuterIterations) return 0;
+   if (nLk > 0 && !(s->wtq_L == nLk && s->wtq_rows >= k - 1)) return 0;
+   const int nov1 = k1 + nLk, nfov1 = 2 * nov1 + 1;
+   if (nfov1 + 8 > PA_ALPHA_OFF(s)) return 0;
+   hipk_rr_in in;
+   memset(&in, 0, sizeof(in));
+   in.k = k; in.L = nLk; in.cand = col; in.largest = (p->target == primme_largest);
+   in.grow_row = (nLk > 0 && s->wtq_rows == k - 1);
+   for (int i = 0; i < k; i++) {
+      in.theta[i] = s->hVals[i];
+      for (int r = 0; r < k; r++) in.Y[r + i * k] = s->hVecs[r + (size_t)i * k];
+   }
+   for (int l = 0; l < nLk; l++)
+      for (int j = 0; j < k; j++) in.G[j + l * k] = s->wtq[j + (size_t)l * s->K];
+   const int tcol = 1 - s->spec_tcol;
+   if (tcol >= s->nT) return 0;
+   char *dst1 = VCOL(s, k1);
+   CHK(hipk_rr_arrow(s->ctx, &in, s->d_fov, nfov, s->d_fov + PA_ALPHA_OFF(s), s->d_hnext));
+   s->pre_seq_rr = hipk_seq_issued(s->ctx);
+   CHK(hipk_ritz_residual_overlaps_dev(s->ctx, s->dt, s->m, s->V, s->W, s->ld, k1, s->d_hnext, dst1, s->evecs, s->ldevecs, nLk, 1, s->d_fov_alt));
+   hipk_seg segs[2] = {{s->V, s->ld, k1}, {s->evecs, s->ldevecs, nLk}};
+   CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov_alt, nov1, dst1, s->ld, TCOL(s, tcol), s->ld, 1, s->d_fov_alt + nfov1));
+   {
+      int rc = (p->matrixMatvec == primme_amd_matvec)
+             ? primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, tcol), s->d_fov_alt + nfov1, dst1, WCOL(s, k1), s->d_fov_alt + PA_ALPHA_OFF(s))
+             : pa_svds_apply_scaled(p, s->ctx, TCOL(s, tcol), s->d_fov_alt + nfov1, dst1, WCOL(s, k1), s->d_fov_alt + PA_ALPHA_OFF(s));
+      if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
+   }
+   s->pre_seq_end = hipk_seq_issued(s->ctx);
+   s->pre_valid = 1; s->pre_k = k1; s->pre_L = nLk; s->pre_cand = col; s->pre_nfov = nfov1; s->pre_tcol = tcol;
+   s->pre_launched++;
+   return 0;
+}
+
+/* Is the pair the pre-enqueued pass was formed with the one the host's own Rayleigh-Ritz solve arrived at?  It must be an
+ * eigenpair of the projected matrix to rounding (its residual IN the projected problem), with the host's Ritz value.  The
+ * vectors themselves may differ by eps |H| / gap (two backward-stable solvers); the residual A V h - theta V h they produce
+ * then differs by eps |A| (the difference lies along Ritz vectors whose values are as close as the gap). */
+static int pre_pair_matches(const pa_solver *s, int k1, int col) {
+   const double *h = s->h_hnext;
+   if (h[33] != 0.0) return 0;
+   double scale = 0.0, nh = 0.0, res = 0.0;
+   for (int i = 0; i < k1; i++) { scale = PA_MAX(scale, fabs(s->hVals[i])); nh += h[i] * h[i]; }
+   if (!(scale > 0.0) || !(fabs(nh - 1.0) <= 1e-12) || !(fabs(h[32] - s->hVals[col]) <= 1e-12 * scale)) return 0;
+   for (int i = 0; i < k1; i++) {
+      double t = -h[32] * h[i];
+      for (int j = 0; j < k1; j++) t += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * h[j];
+      res = PA_MAX(res, fabs(t));
+   }
+   return res <= 1e-13 * scale;
+}
+
 /* The speculative tail of a block-size-1 GD iteration, enqueued right after the fused residual pass: the
  * first Gram-Schmidt update with the device-resident overlaps, then (speculate2) normalisation, operator
  * application and the new column of H, so that the host synchronises once.  `rsrc` holds the residual
  * (the basis slot `dstc` itself, or a scratch column after a restart: the update is out of place either
  * way); d_fov / h_fov hold [V'r | Q'r | r'r | W'r | ..] in `nfov` entries. */
 int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, char *dstc, int nfov, int wtr,
-      int speculate2, int parallel_host) {
+      int speculate2, int parallel_host, int col, int adopted) {
    primme_params *p = s->p;
    const int nov = basisSize + nLk;
    int rc = 0;
@@ -285,6 +374,22 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
     * launch gathers from it while it writes the normalised vector into V(:,k) */
    const int fuse_tail = speculate2 && wtr && pa_fuse_tail_eligible(s);
    s->spec_fused = 0;
+   if (adopted) {
+      /* this iteration was enqueued ahead of time (pa_prelaunch_next) and its pair is the host's: nothing to launch.  The
+       * NEXT one goes in behind it now, then the one wait for ITS last reduction, then the usual host arithmetic. */
+      const unsigned long long seq_end = s->pre_seq_end;
+      s->spec_tcol = s->pre_tcol;
+      s->spec_fused = 1;
+      s->pre_valid = 0;
+      s->pre_adopted++;
+      CHK(pa_prelaunch_next(s, basisSize, nLk, col, nfov));
+      CHK(hipk_wait_seq(s->ctx, seq_end));
+      tail_finish(s, basisSize, nLk, nfov, s->h_fov, s->h_fov[PA_ALPHA_OFF(s)]);
+      s->spec2_valid = 1; s->spec2_k = basisSize;
+      s->fov_projected = 1;
+      return 0;
+   }
+   s->spec_tcol = 0;
    /* peer-to-peer transport: every reduction of the tail is exchanged inside the second stage of the launch that
     * forms it (hipk_xreduce_arm), so the tail keeps its one-rank shape — |t|^2 stays on the device, the operator
     * launch normalises on the fly, no scaling launches — and costs no reduction launch at all */
@@ -321,7 +426,23 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
       s->spec2_valid = 1; s->spec2_k = basisSize;
    } else if (speculate2) {
       CHK(pa_reduce(s, s->d_fov + nfov, 1, 1, 1));
-      if (fuse_tail) {
+      if (fuse_tail && !xr) {
+         /* the library's own operator, one rank: normalisation, A t and t'At in one launch, reading the un-normalised vector
+          * from the scratch column and rebuilding V(:,k) on the way; t'At goes to the alpha slot of the overlap buffer.
+          * Before the one wait the NEXT iteration is enqueued behind this one (pa_prelaunch_next), so the wait is for this
+          * tail's own completion flag, not for the last launch of the stream. */
+         rc = fused_apply(s, TCOL(s, 0), s->d_fov + nfov, dstc, WCOL(s, basisSize), s->d_fov + PA_ALPHA_OFF(s));
+         if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
+         s->spec_fused = 1;
+         const unsigned long long seq_end = hipk_seq_issued(s->ctx);
+         CHK(pa_prelaunch_next(s, basisSize, nLk, col, nfov));
+         if (s->pre_valid) CHK(hipk_wait_seq(s->ctx, seq_end));
+         else CHK(pa_reduce(s, s->d_fov + PA_ALPHA_OFF(s), 1, 0, 0));                 /* the one synchronisation */
+         tail_finish(s, basisSize, nLk, nfov, s->h_fov, s->h_fov[PA_ALPHA_OFF(s)]);
+         s->spec2_valid = 1; s->spec2_k = basisSize;
+         s->fov_projected = 1;
+         return 0;
+      } else if (fuse_tail) {
          /* the library's own operator: normalisation, A t and t'At in one launch, reading the
           * un-normalised vector from the scratch column and rebuilding V(:,k) on the way */
          if (xr) hipk_xreduce_arm(s->ctx);
@@ -515,12 +636,28 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
          const int nfov = nov + 1 + (wtr ? basisSize + nLk : 0);      /* [V'r | Q'r | r'r | W'r | W(:,k-1)'Q] */
          /* row-partitioned, peer-to-peer transport: the second stage of this pass exchanges the overlaps with the
           * other ranks itself (ortho.c:249's all-reduce inside the launch that forms the local sums) */
-         if (s->parallel && s->dev_comm) hipk_xreduce_arm(s->ctx);
-         if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
-                    s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, wtr, s->d_fov))) goto out;
+         /* Was this very iteration enqueued ahead of time, behind the previous one (pa_prelaunch_next)?  Its pair came from
+          * the one-wave kernel; it is adopted when the host's own solve arrived at the same pair, thrown away otherwise
+          * (the launches below then run behind it in the stream and overwrite what it wrote). */
+         int adopted = 0;
+         if (s->pre_valid && s->pre_k == basisSize && s->pre_L == nLk && s->pre_cand == col && speculate && speculate2 && wtr &&
+               s->pre_nfov == nfov && pa_fuse_tail_eligible(s) && !(s->parallel && s->dev_comm)) {
+            if ((rc = hipk_wait_seq(s->ctx, s->pre_seq_rr))) goto out;
+            if (pre_pair_matches(s, basisSize, col)) {
+               double *td = s->d_fov, *th = s->h_fov;
+               s->d_fov = s->d_fov_alt; s->h_fov = s->h_fov_alt; s->d_fov_alt = td; s->h_fov_alt = th;
+               adopted = 1;
+            }
+         }
+         if (!adopted) {
+            s->pre_valid = 0;
+            if (s->parallel && s->dev_comm) hipk_xreduce_arm(s->ctx);
+            if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
+                       s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, wtr, s->d_fov))) goto out;
+         }
          if (speculate) {
-            if ((rc = pa_reduce(s, s->d_fov, nfov, 1, parallel_host ? 0 : 1))) goto out;
-            if ((rc = pa_speculative_tail(s, basisSize, nLk, dstc, dstc, nfov, wtr, speculate2, parallel_host))) goto out;
+            if (!adopted && (rc = pa_reduce(s, s->d_fov, nfov, 1, parallel_host ? 0 : 1))) goto out;
+            if ((rc = pa_speculative_tail(s, basisSize, nLk, dstc, dstc, nfov, wtr, speculate2, parallel_host, col, adopted))) goto out;
          } else {
             if ((rc = pa_reduce(s, s->d_fov, nfov, 1, 0))) goto out;
          }

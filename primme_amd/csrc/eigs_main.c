@@ -936,11 +936,11 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    rc = hipk_malloc(s->ctx, colBytes * K, (void **)&s->V) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W) ||
         hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
         ((p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) && hipk_malloc(s->ctx, colBytes * 6 * b, (void **)&s->Jw)) ||
-        hipk_malloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->d_red) ||
+        hipk_malloc(s->ctx, ((size_t)s->red_cap * 3 + 64) * 8, (void **)&s->d_red) ||
         (harmonic && hipk_malloc(s->ctx, colBytes * K, (void **)&s->Q)) ||
         (need_hat && hipk_malloc(s->ctx, (size_t)(s->ldevecs > 0 ? s->ldevecs : 1) * s->es * maxEvecs, (void **)&s->evecsHat)) ||
         hipk_malloc(s->ctx, s->coef_cap * sizeof(HS), (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
-        hipk_host_alloc(s->ctx, (size_t)s->red_cap * 16, (void **)&s->h_red) ||
+        hipk_host_alloc(s->ctx, ((size_t)s->red_cap * 3 + 64) * 8, (void **)&s->h_red) ||
         hipk_host_alloc(s->ctx, s->coef_cap * sizeof(HS), (void **)&s->h_coef) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta);
    s->H = (HS *)calloc((size_t)K * K, sizeof(HS)); s->hVecs = (HS *)calloc((size_t)K * K, sizeof(HS));
    s->prevhVecs = (HS *)calloc((size_t)K * K, sizeof(HS)); s->hVals = (double *)calloc((size_t)K, 8);
@@ -972,8 +972,15 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
       s->fVtBV = (HS *)calloc((size_t)s->maxRank * s->maxRank, sizeof(HS));
       if (!s->VtBV || !s->fVtBV) rc = 1;
    }
-   if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap * 2);
-   if (!rc) { s->d_fov = s->d_red + s->red_cap; s->h_fov = s->h_red + s->red_cap; }
+   if (!rc) rc = hipk_ctx_set_mirror(s->ctx, s->d_red, s->h_red, (size_t)s->red_cap * 3 + 64);
+   if (!rc) {
+      /* [reductions | overlaps of the fused pass | the other overlap buffer (pre-enqueued iteration) | its Ritz pair] */
+      s->d_fov = s->d_red + s->red_cap; s->h_fov = s->h_red + s->red_cap;
+      s->d_fov_alt = s->d_red + 2 * (size_t)s->red_cap; s->h_fov_alt = s->h_red + 2 * (size_t)s->red_cap;
+      s->d_hnext = s->d_red + 3 * (size_t)s->red_cap; s->h_hnext = s->h_red + 3 * (size_t)s->red_cap;
+      rc = hipk_memset0(s->ctx, s->d_red, ((size_t)s->red_cap * 3 + 64) * 8);
+   }
+   s->pre_enabled = getenv("PRIMME_AMD_NO_PRELAUNCH") == NULL;
    if (!rc && s->fused_restart && s->fuse_gd && b == 1 && !harmonic && K <= 32 && s->nT >= 4 &&
          s->red_cap >= 64 + 2 * HIPK_WTR_MAX_K && getenv("PRIMME_AMD_NO_SPEC_RESTART") == NULL) {
       /* alternate panels of the speculative restart (eigs_solver.h); without them the restart runs in place */
@@ -1005,6 +1012,9 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    }
    free(evals);
    free(resNorms);
+   if (getenv("PRIMME_AMD_PRELAUNCH_STATS"))
+      fprintf(stderr, "primme_amd: iterations enqueued ahead of the host: %ld launched, %ld adopted (of %lld outer iterations)\n", s->pre_launched,
+            s->pre_adopted, (long long)p->stats.numOuterIterations);
    if (p->convTestFun == pa_conv_test_absolute) { /* leave the struct as the reference does: default installed */ }
    free_solver(s);
    p->queue = user_queue;

@@ -38,7 +38,7 @@ int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sy
    primme_params *p = s->p;
    if (count <= 0) return 0;
    /* d_buf lies in [d_red, d_red + 2*red_cap): the second half holds the fused kernel's overlaps */
-   if (d_buf < s->d_red || (size_t)(d_buf - s->d_red) + (size_t)count > 2 * (size_t)s->red_cap) return PRIMME_UNEXPECTED_FAILURE;
+   if (d_buf < s->d_red || (size_t)(d_buf - s->d_red) + (size_t)count > 3 * (size_t)s->red_cap + 64) return PRIMME_UNEXPECTED_FAILURE;
    const int parallel = s->parallel;
    double t0 = parallel ? pa_wtime() : 0.0;
    if (parallel && s->dev_comm) {
@@ -171,6 +171,7 @@ int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc)
  * consecutive numbers of the stream, (re, im), as zlarnv does) */
 int pa_random_col(pa_solver *s, char *col) {
    s->fov_valid = 0;
+   s->pre_valid = 0;
    /* generated on the device (hipk_larnv_uniform11): the same stream, nothing crosses PCIe */
    int64_t seed[4] = {s->p->iseed[0], s->p->iseed[1], s->p->iseed[2], s->p->iseed[3]};
    CHK(hipk_larnv_uniform11(s->ctx, s->dt, seed, s->m * SD, col));
@@ -207,6 +208,7 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
    if (b2_out) *b2_out = b1;
    /* overlaps left by the fused residual pass (or carried over a restart) belong to ONE column */
    if (s->fov_valid && !(b1 == b2 && b1 == s->fov_k && Vp == s->V)) { s->fov_valid = 0; s->spec2_valid = 0; }
+   if (!(b1 == b2 && s->fov_valid)) s->pre_valid = 0;      /* an iteration enqueued ahead assumed the tail of THIS column stands */
    s->fov_carry = 0;
 
    for (int i = b1; i <= b2; i++) {
@@ -256,7 +258,7 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
          /* the speculative tail (normalise on device, operator, projection) stands only if THIS
           * first pass is the last one */
          const int tail_done = speculated && s->spec2_valid && s->spec2_k == i && b1 == b2;
-         if (!tail_done) s->spec2_valid = 0;
+         if (!tail_done) { s->spec2_valid = 0; s->pre_valid = 0; }
          /* fused tail (eigs_conv.c): v holds the NORMALISED vector, the projected un-normalised one is in
           * T(:,0); whenever the tail is not accepted as it stands it goes back into v first */
          const int fused_pending = speculated && s->spec_fused;
@@ -272,12 +274,12 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
             nOrth = maxNumOrthos;             /* lost all significant digits: randomise */
          } else if (s1 <= tol * s0) {
             s0 = s1; s02 = s12;               /* another pass */
-            if (fused_pending) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, v, ldV, 1));
+            if (fused_pending) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, s->spec_tcol), s->ld, v, ldV, 1));
          } else {
             double inv = 1.0 / s1;
             if (isfinite(inv)) {
                if (!tail_done) {
-                  if (fused_pending) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, 0), s->ld, v, ldV, 1));
+                  if (fused_pending) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, TCOL(s, s->spec_tcol), s->ld, v, ldV, 1));
                   CHK(hipk_scale_cols(s->ctx, s->dt, s->m, v, ldV, 1, &inv));
                }
                break;

@@ -35,7 +35,7 @@ void pa_monitor(pa_solver *s, double *basisEvals, int basisSize, int *basisFlags
 
 int pa_reduce(pa_solver *s, double *d_buf, int count, int keep_dev, int defer_sync);
 int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, char *dstc, int nfov, int wtr,
-      int speculate2, int parallel_host);
+      int speculate2, int parallel_host, int col, int adopted);
 int pa_restart_harmonic(pa_solver *s, int ldh, int restartSize, int basisSize, int numConverged);
 int pa_restart_refined(pa_solver *s, int ldh, int restartSize, int basisSize, int numConverged, int numPrevRetained,
       int indexOfPreviousVecs, int indexOfPreviousVecsBeforeRestart, const int *restartPerm, const int *hVecsPerm,
@@ -683,6 +683,7 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       s->fov_valid = 0;
       s->fov_carry = 0;
       s->rst_ready = 0;
+      s->pre_valid = 0;        /* an iteration enqueued ahead of the host belongs to the basis that is being replaced */
    }
 
    for (i = 0, *numConverged = *numLocked; i < basisSize; i++) {
@@ -811,8 +812,10 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       const int rs = restartSize, nLk = p->numOrthoConst + *numLocked, nov = rs + nLk, nfov = 2 * nov + 1;
       memcpy(s->h_fov, s->rst_c, (size_t)(2 * rs + nLk + 1) * sizeof(double));
       for (i = 2 * rs + nLk + 1; i < nfov; i++) s->h_fov[i] = 0.0;
-      CHK(hipk_h2d(s->ctx, s->d_fov, s->h_fov, (size_t)(nov + 1) * sizeof(double)));
-      CHK(pa_speculative_tail(s, rs, nLk, TCOL(s, 2), VCOL(s, rs), nfov, 1, 1, 0));
+      /* (all of them: the Gram-Schmidt update reads the first nov + 1, the one-wave Rayleigh-Ritz kernel of the iteration
+       * that is enqueued behind this tail reads W'r as well) */
+      CHK(hipk_h2d(s->ctx, s->d_fov, s->h_fov, (size_t)nfov * sizeof(double)));
+      CHK(pa_speculative_tail(s, rs, nLk, TCOL(s, 2), VCOL(s, rs), nfov, 1, 1, 0, iev[0], 0));
       s->fov_valid = 1; s->fov_k = rs; s->fov_L = nLk; s->fov_col = VCOL(s, rs); s->fov_s1_off = nfov;
       s->fov_carry = 1;
    } else if (s->rst_ready) {

@@ -113,6 +113,17 @@ typedef struct pa_solver {
    int pl_cand, pl_nc;     /* coefficient column of the candidate; converged pairs copied out by the pass (soft locking) */
    int pl_launched;        /* the pass ran with it: rst_c holds the overlaps with the new basis, rst_grow W(:,k-1)'Q */
    double *rst_grow;
+   /* The NEXT block-size-1 iteration enqueued before the host has seen this one (eigs_conv.c:
+    * pa_prelaunch_next).  The pre-enqueued pass writes its overlaps into the OTHER overlap buffer (d_fov_alt / h_fov_alt:
+    * the host is still reading this iteration's), its projected vector into the other scratch column, its t'At into the
+    * alpha slot of that buffer; adopting it swaps the buffers. */
+   int pre_enabled;        /* off with PRIMME_AMD_NO_PRELAUNCH=1 (A/B knob, read once per solve) */
+   double *d_fov_alt, *h_fov_alt;
+   double *d_hnext, *h_hnext;     /* hipk_rr_arrow's output: coefficient vector [0..k], Ritz value [32], status [33] */
+   int pre_valid, pre_k, pre_L, pre_cand, pre_nfov, pre_tcol;
+   unsigned long long pre_seq_rr, pre_seq_end;   /* flags to wait for: the small kernel's, the pass' last reduction's */
+   int spec_tcol;          /* scratch column holding the projected, un-normalised vector of the tail that is pending */
+   long pre_launched, pre_adopted;
    int parallel;           /* reductions cross ranks (numProcs > 1 and a globalSumReal installed) */
    int fuse_gd;            /* GD without preconditioner/Olsen: residual written straight into V */
    int coef_valid_k;       /* d_coef/d_theta currently hold hVecs/hVals of this size, or -1 */

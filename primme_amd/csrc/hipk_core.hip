@@ -304,6 +304,21 @@ static int wait_results_impl(hipk_ctx *ctx) {
    ctx->need_sync = 0;
    return 0;
 }
+/* sequence number of the last flagged reduction enqueued on the context; wait for a PARTICULAR one while later ones are
+ * already queued behind it (the iteration enqueued ahead of the host, eigs_conv.c).  Falls back to draining the stream. */
+extern "C" unsigned long long hipk_seq_issued(hipk_ctx *ctx) { return ctx->seq_issued; }
+extern "C" int hipk_wait_seq(hipk_ctx *ctx, unsigned long long want) {
+   if (ctx->spin_wait && ctx->flag_host && want > 0 && want <= ctx->seq_issued) {
+      for (long spins = 0; spins < 200000000L; spins++) {
+         if (*ctx->flag_host >= want) { if (want > ctx->seq_waited) ctx->seq_waited = want; return 0; }
+         __builtin_ia32_pause();
+      }
+   }
+   HIPK_CHECK(hipStreamSynchronize(ctx->stream));
+   ctx->seq_waited = ctx->seq_issued;
+   ctx->need_sync = 0;
+   return 0;
+}
 extern "C" int hipk_is_device_ptr(const void *p) {
    hipPointerAttribute_t attr;
    if (!p) return 0;

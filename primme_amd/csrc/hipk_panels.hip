@@ -1236,7 +1236,7 @@ struct HCol { double h[32]; };   /* the coefficient vector travels in the kernel
 template <typename T, int CPW, int QPW, int VW, bool WT>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, int k,
-      HCol hcol, double theta, T *__restrict__ dst, const T *__restrict__ Q,
+      HCol hcol, double theta, const double *__restrict__ hdev, T *__restrict__ dst, const T *__restrict__ Q,
       int64_t ldQ, int L, int64_t m, double *__restrict__ partials, int blocked, hipk_fin_args fa) {
    typedef lanevec<T, VW> LV;
    constexpr int QN = QPW > 0 ? QPW : 1;
@@ -1245,12 +1245,18 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
    const int lane = threadIdx.x & 63;
    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const int j0 = wv * CPW, q0 = wv * QPW;
+   /* hdev != NULL: the coefficient vector and the Ritz value were left in HBM by hipk_rr_arrow (the iteration that was
+    * enqueued before the host had seen the previous one); a status other than 0 means there is no valid pair: nothing to do */
+   if (hdev) {
+      if (hdev[33] != 0.0) return;
+      theta = hdev[32];
+   }
    double hj[CPW];
    const T *vp[CPW], *wp[CPW], *qp[QN];
 #pragma unroll
    for (int jj = 0; jj < CPW; jj++) {
       const int j = j0 + jj;
-      hj[jj] = (j < k) ? hcol.h[j < 32 ? j : 0] : 0.0;
+      hj[jj] = (j < k) ? (hdev ? hdev[j < 32 ? j : 0] : hcol.h[j < 32 ? j : 0]) : 0.0;
       vp[jj] = V + (size_t)(j < k ? j : 0) * ld;
       wp[jj] = W + (size_t)(j < k ? j : 0) * ld;
    }
@@ -1428,9 +1434,9 @@ static int rcgs_blocked(void) {               /* HIPK_RCGS_BLOCKED: measurement 
 
 template <typename T, int CPW, int VW, bool WT>
 static int ritz_cgs_q(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
-      double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m, const hipk_fin_args &fa) {
+      double theta, const double *hdev, T *dst, const T *Q, int64_t ldQ, int L, int64_t m, const hipk_fin_args &fa) {
    dim3 g(gx), b(HIPK_BLOCK);
-#define RCGS(QPWV) hipLaunchKernelGGL((ritz_cgs_kernel<T, CPW, QPWV, VW, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, ctx->partials, rcgs_blocked(), fa)
+#define RCGS(QPWV) hipLaunchKernelGGL((ritz_cgs_kernel<T, CPW, QPWV, VW, WT>), g, b, 0, ctx->stream, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, ctx->partials, rcgs_blocked(), fa)
    if (L == 0) RCGS(0);
    else if (L <= 8) RCGS(2);
    else if (L <= 16) RCGS(4);
@@ -1443,19 +1449,19 @@ static int ritz_cgs_q(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld,
 
 template <typename T, int VW, bool WT>
 static int ritz_cgs_k(hipk_ctx *ctx, int gx, const T *V, const T *W, int64_t ld, int k, const HCol &hcol,
-      double theta, T *dst, const T *Q, int64_t ldQ, int L, int64_t m, const hipk_fin_args &fa) {
-   if (k <= 8) return ritz_cgs_q<T, 2, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
-   if (k <= 16) return ritz_cgs_q<T, 4, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
-   if (k <= 24) return ritz_cgs_q<T, 6, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
-   return ritz_cgs_q<T, 8, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
+      double theta, const double *hdev, T *dst, const T *Q, int64_t ldQ, int L, int64_t m, const hipk_fin_args &fa) {
+   if (k <= 8) return ritz_cgs_q<T, 2, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, fa);
+   if (k <= 16) return ritz_cgs_q<T, 4, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, fa);
+   if (k <= 24) return ritz_cgs_q<T, 6, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, fa);
+   return ritz_cgs_q<T, 8, VW, WT>(ctx, gx, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, fa);
 }
 
 template <typename T>
 static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t ld, int k,
-      const double *hcol_host, double theta, T *dst, const T *Q, int64_t ldQ, int L, int want_wtr, double *out_dev) {
+      const double *hcol_host, double theta, const double *hdev, T *dst, const T *Q, int64_t ldQ, int L, int want_wtr, double *out_dev) {
    if (k <= 0 || k > 32 || L < 0 || L > 32) return -1;
    HCol hcol;
-   for (int j = 0; j < 32; j++) hcol.h[j] = (j < k) ? hcol_host[j] : 0.0;
+   for (int j = 0; j < 32; j++) hcol.h[j] = (j < k && hcol_host) ? hcol_host[j] : 0.0;
    constexpr int VWT = 2;   /* two rows per lane: 16-byte loads in double, 8-byte in float (register budget) */
    const bool vec = aligned16(V, ld, sizeof(T)) && aligned16(W, ld, sizeof(T)) && aligned16(dst, ld, sizeof(T)) &&
                     (L == 0 || aligned16(Q, ldQ, sizeof(T)));
@@ -1468,10 +1474,10 @@ static int ritz_cgs_t(hipk_ctx *ctx, int64_t m, const T *V, const T *W, int64_t 
    const int pslot = hipk_prof_begin(HIPK_PROF_RITZ, ctx->stream, (double)m * sizeof(T) * (2.0 * k + L + 1));
    int rc;
    const hipk_fin_args fa = hipk_make_fin(ctx, out_dev, HIPK_FIN_RITZ, gx, nout);
-   if (vec) rc = want_wtr ? ritz_cgs_k<T, VWT, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa)
-                          : ritz_cgs_k<T, VWT, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
-   else rc = want_wtr ? ritz_cgs_k<T, 1, true>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa)
-                      : ritz_cgs_k<T, 1, false>(ctx, gx, V, W, ld, k, hcol, theta, dst, Q, ldQ, L, m, fa);
+   if (vec) rc = want_wtr ? ritz_cgs_k<T, VWT, true>(ctx, gx, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, fa)
+                          : ritz_cgs_k<T, VWT, false>(ctx, gx, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, fa);
+   else rc = want_wtr ? ritz_cgs_k<T, 1, true>(ctx, gx, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, fa)
+                      : ritz_cgs_k<T, 1, false>(ctx, gx, V, W, ld, k, hcol, theta, hdev, dst, Q, ldQ, L, m, fa);
    hipk_prof_end(pslot, ctx->stream);
    if (rc) return rc;
    if (fa.enabled) return 0;                    /* the last workgroup finalised */
@@ -1483,10 +1489,137 @@ extern "C" int hipk_ritz_residual_overlaps(hipk_ctx *ctx, hipk_dtype dt, int64_t
       const void *Q, int64_t ldQ, int L, int want_wtr, double *out_dev) {
    hipk_note_turnaround(ctx);
    switch (dt) {
-   case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, hcol_host, theta, (double *)dst, (const double *)Q, ldQ, L, want_wtr, out_dev);
-   case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, hcol_host, theta, (float *)dst, (const float *)Q, ldQ, L, want_wtr, out_dev);
+   case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, hcol_host, theta, NULL, (double *)dst, (const double *)Q, ldQ, L, want_wtr, out_dev);
+   case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, hcol_host, theta, NULL, (float *)dst, (const float *)Q, ldQ, L, want_wtr, out_dev);
    default: return -44;
    }
+}
+/* the same with the coefficient vector (hth_dev[0 .. k)), the Ritz value (hth_dev[32]) and a status word (hth_dev[33]) in HBM:
+ * the residual pass of an iteration enqueued before the host has seen the previous one (hipk_rr_arrow) */
+extern "C" int hipk_ritz_residual_overlaps_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *V, const void *W, int64_t ldVW, int k,
+      const double *hth_dev, void *dst, const void *Q, int64_t ldQ, int L, int want_wtr, double *out_dev) {
+   if (!hth_dev) return -1;
+   switch (dt) {
+   case HIPK_F64: return ritz_cgs_t<double>(ctx, m, (const double *)V, (const double *)W, ldVW, k, NULL, 0.0, hth_dev, (double *)dst, (const double *)Q, ldQ, L, want_wtr, out_dev);
+   case HIPK_F32: return ritz_cgs_t<float>(ctx, m, (const float *)V, (const float *)W, ldVW, k, NULL, 0.0, hth_dev, (float *)dst, (const float *)Q, ldQ, L, want_wtr, out_dev);
+   default: return -44;
+   }
+}
+
+/* ---- Rayleigh-Ritz step of the pre-enqueued iteration: one eigenpair of the arrowhead matrix (primme_amd_kernels.h) ----
+ * One wave; lane j (< k) of every group of 16 lanes owns Ritz value j (all four groups compute the same, so every lane
+ * holds the sums).  Secular equation in the coordinate mu = lambda - theta_o of the nearer pole o:
+ *    g(mu) = (alpha - theta_o) - mu - sum_j z_j^2 / ((theta_j - theta_o) - mu),   strictly decreasing between two poles,
+ * safeguarded Newton (a step that leaves the bracket is replaced by its midpoint), until the step is below two ulps of mu. */
+__device__ __forceinline__ double rr_sum16(double v) {
+   v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+   return v;
+}
+__global__ void __launch_bounds__(64)
+rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const double *__restrict__ alpha_dev,
+      double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
+   __shared__ double s_v[16], s_y[17];
+   const int lane = threadIdx.x, j = lane & 15, k = in.k, L = in.L;
+   const bool on = j < k;
+   const double sgn = in.largest ? -1.0 : 1.0;
+   /* this iteration's reductions */
+   const double n2 = fov[nfov], nt = sqrt(n2), alpha = alpha_dev[0];
+   const double cv = on ? fov[j] : 0.0;                       /* V'r */
+   const double wr = on ? fov[k + L + 1 + j] : 0.0;           /* W'r */
+   double gq = 0.0;                                           /* (G Q'r)_j */
+   for (int l = 0; l < L; l++) {
+      const double g = (in.grow_row && j == k - 1) ? fov[2 * k + L + 1 + l] : in.G[j + l * k];
+      gq = on ? fma(g, fov[k + l], gq) : 0.0;
+   }
+   /* z_i = (Y(:,i)'(W'r - G Q'r) - theta_i Y(:,i)'(V'r)) / |t| */
+   if (lane < 16) s_v[lane] = on ? wr - gq : 0.0;
+   __syncthreads();
+   double a1 = 0.0;
+   for (int r = 0; r < k; r++) a1 = on ? fma(in.Y[r + j * k], s_v[r], a1) : 0.0;
+   __syncthreads();
+   if (lane < 16) s_v[lane] = cv;
+   __syncthreads();
+   double a2 = 0.0;
+   for (int r = 0; r < k; r++) a2 = on ? fma(in.Y[r + j * k], s_v[r], a2) : 0.0;
+   const double thj = on ? in.theta[j] : 0.0;
+   const double z = on ? sgn * (a1 - thj * a2) / nt : 0.0;     /* the negated problem for `largest`: -M = [-Theta -z; -z' -alpha] */
+   const double th = sgn * thj, al = sgn * alpha;               /* ascending in j for both targets */
+   const double z2 = z * z;
+   const int c = in.cand;
+   int status = (k < 1 || k > 16 || L < 0 || L > 10 || c < 0 || c > k || !(n2 > 0.0)) ? 1 : 0;
+   /* poles strictly increasing, everything finite */
+   {
+      const double thn = __shfl(th, (lane & 48) + (j + 1 < k ? j + 1 : j), 64);
+      const int bad = on && (!(isfinite(th) && isfinite(z)) || (j + 1 < k && !(th < thn)));
+      if (__any(bad) || !isfinite(al)) status = 2;
+   }
+   const double zn = sqrt(rr_sum16(z2));
+   double lam = 0.0, yj = 0.0, ynorm2 = 1.0;
+   if (status == 0) {
+      const double th0 = __shfl(th, lane & 48, 64), thl = __shfl(th, (lane & 48) + k - 1, 64);
+      const double thc = __shfl(th, (lane & 48) + (c < k ? c : k - 1), 64), thcm = __shfl(th, (lane & 48) + (c > 0 ? c - 1 : 0), 64);
+      int o;
+      double lo, hi;
+      if (c == 0) { o = 0; lo = fmin(0.0, al - th0) - zn - 1e-300; lo -= 4e-16 * fabs(lo); hi = 0.0; }
+      else if (c == k) { o = k - 1; lo = 0.0; hi = fmax(0.0, al - thl) + zn + 1e-300; hi += 4e-16 * fabs(hi); }
+      else {
+         /* the sign of g at the middle of the interval says which pole the root is closer to */
+         const double gap = thc - thcm, mid = 0.5 * gap;
+         const double d = (th - thcm) - mid;
+         const double sm = rr_sum16(on ? z2 / d : 0.0);
+         const double gm = (al - thcm) - mid - sm;
+         if (gm > 0.0) { o = c; lo = -mid; hi = 0.0; }
+         else { o = c - 1; lo = 0.0; hi = mid; }
+      }
+      const double tho = __shfl(th, (lane & 48) + o, 64);
+      const double dj = th - tho, a0 = al - tho;
+      double mu = 0.5 * (lo + hi);
+      int it = 0;
+      for (; it < 100; it++) {
+         const double d = dj - mu;
+         const double r = 1.0 / d;
+         const double t = on ? z2 * r : 0.0;
+         const double sm = rr_sum16(t), sp = rr_sum16(on ? t * r : 0.0);
+         const double g = a0 - mu - sm, gp = -1.0 - sp;
+         if (!(g == g)) { status = 3; break; }                      /* a lane sat on its pole: give up */
+         if (g > 0.0) lo = mu; else if (g < 0.0) hi = mu; else break;
+         double mn = mu - g / gp;
+         if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
+         const double step = fabs(mn - mu);
+         const bool done = step <= 4.4e-16 * fabs(mn) || mn == lo || mn == hi;
+         mu = mn;
+         if (done) break;
+      }
+      if (it >= 100) status = 4;
+      lam = sgn * (tho + mu);
+      yj = on ? z / (mu - dj) : 0.0;                              /* eigenvector [y; 1] of the (possibly negated) arrowhead */
+      ynorm2 = 1.0 + rr_sum16(yj * yj);
+      if (!isfinite(lam) || !isfinite(ynorm2)) status = 5;
+   }
+   /* back to the basis [V t]: h = [Y y; 1] / |[y; 1]| */
+   const double inv = 1.0 / sqrt(ynorm2);
+   __syncthreads();
+   if (lane < 16) s_y[lane] = yj;
+   __syncthreads();
+   double hv = 0.0;
+   for (int i = 0; i < k; i++) hv = on ? fma(in.Y[j + i * k], s_y[i], hv) : 0.0;
+   hv *= inv;
+   if (lane < 16) {
+      if (on) { out[j] = hv; if (out_host) out_host[j] = hv; }
+      if (lane == 0) {
+         out[k] = inv; out[32] = lam; out[33] = (double)status;
+         if (out_host) { out_host[k] = inv; out_host[32] = lam; out_host[33] = (double)status; }
+      }
+   }
+   __syncthreads();
+   if (lane == 0) hipk_publish_flag(fin, 1);
+}
+extern "C" int hipk_rr_arrow(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov_dev, int nfov, const double *alpha_dev, double *out_dev) {
+   if (!in || in->k < 1 || in->k > 16 || in->L < 0 || in->L > 10) return -1;
+   hipLaunchKernelGGL(rr_arrow_kernel, dim3(1), dim3(64), 0, ctx->stream, *in, fov_dev, nfov, alpha_dev, out_dev, hipk_mirror_of(ctx, out_dev),
+         hipk_next_flag(ctx, out_dev));
+   HIPK_CHECK(hipGetLastError());
+   return 0;
 }
 
 /* ============================ column utilities ================================ */

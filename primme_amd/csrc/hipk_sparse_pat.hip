@@ -56,6 +56,15 @@ __device__ __forceinline__ double pat_mul_add(double s, double v, double x) {
    return s + p;
 }
 
+/* the outputs: plain stores by default; HIPK_PAT_NT_STORES=1 (build-time, A/B builds) marks them non-temporal */
+#ifndef HIPK_PAT_NT_STORES
+#define HIPK_PAT_NT_STORES 0
+#endif
+template <typename T> __device__ __forceinline__ void pat_store(T *p, T v) {
+   if (HIPK_PAT_NT_STORES) __builtin_nontemporal_store(v, p);
+   else *p = v;
+}
+
 /* XCD-aware PERSISTENT schedule: exactly as many workgroups as the chip holds at once (WPS per SIMD = WPS workgroups of four
  * waves per CU, enforced through __launch_bounds__; a grid larger than the resident set would run its tail after the
  * first workgroups have walked ALL their chunks), dealt round-robin to the 8 XCDs; XCD q owns a contiguous eighth of the
@@ -139,10 +148,10 @@ pat_kernel(const uint8_t *__restrict__ pid, const int32_t *__restrict__ toff, co
          }
          if (r[u] < nrows) {
             const T yt = (T)s;
-            y[r[u]] = yt;
+            pat_store(y + r[u], yt);
             if (FUSED) {
                const double xown = (double)(T)(a * xo[u]);
-               xout[r[u]] = (T)xown;
+               pat_store(xout + r[u], (T)xown);
                dotp = fma(xown, (double)yt, dotp);
             }
          }

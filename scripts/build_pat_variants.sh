@@ -6,8 +6,8 @@ cd "$(dirname "$0")/../primme_amd/csrc"
 make -s all
 mkdir -p ../variants
 for v in "$@"; do
-  set -- $v; R=$1; W=$2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -DHIPK_PAT_RPL=$R -DHIPK_PAT_WPS=$W -c hipk_sparse_pat.hip -o /tmp/pat_r${R}_w${W}.o
+  set -- $v; R=$1; W=$2; X=${3:-}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -DHIPK_PAT_RPL=$R -DHIPK_PAT_WPS=$W $X -c hipk_sparse_pat.hip -o /tmp/pat_r${R}_w${W}.o
   OBJS=$(ls *.o | grep -v '^hipk_sparse_pat.o$')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -Wl,--version-script=exports.map -o ../variants/libprimme_amd_pat_r${R}_w${W}.so \
      $OBJS /tmp/pat_r${R}_w${W}.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -lm

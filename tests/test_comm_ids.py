@@ -22,17 +22,21 @@ def lib(built, monkeypatch):
 
 
 def test_auto_hands_out_what_can_serve_the_job(lib, monkeypatch):
-    buf = (C.c_char * 128)()
-    assert lib.primme_amd_comm_unique_id_for(buf, 8, 0) == 0 and buf.raw[:6] == b"PAIPC1"      # one node, <= 16 ranks: mailboxes
-    os.unlink(_seg(buf))
-    assert lib.primme_amd_comm_unique_id_for(buf, 17, 0) == 0 and buf.raw[:6] != b"PAIPC1"     # more ranks: an ncclUniqueId
-    assert lib.primme_amd_comm_unique_id_for(buf, 8, 1) == 0 and buf.raw[:6] != b"PAIPC1"      # several nodes: an ncclUniqueId
+    """(the decision is checked through primme_amd_comm_id_kind_for: making an ncclUniqueId starts RCCL's bootstrap threads, which a
+    box without a GPU does not need — tests/test_comm_gpu.py brings the RCCL transport up on the device)"""
+    kind = lib.primme_amd_comm_id_kind_for
+    assert kind(8, 0) == 1 and kind(16, 0) == 1 and kind(1, 0) == 1      # one node, <= 16 ranks: mailboxes
+    assert kind(17, 0) == 0 and kind(8, 1) == 0                           # more ranks / several nodes: RCCL, with default settings
     monkeypatch.setenv("PRIMME_AMD_COMM", "rccl")
-    assert lib.primme_amd_comm_unique_id_for(buf, 2, 0) == 0 and buf.raw[:6] != b"PAIPC1"
+    assert kind(2, 0) == 0
     monkeypatch.setenv("PRIMME_AMD_COMM", "ipc")
-    assert lib.primme_amd_comm_unique_id_for(buf, 17, 0) == -43                                # asked for explicitly, cannot be served
-    assert lib.primme_amd_comm_unique_id_for(buf, 4, 1) == -43
+    assert kind(17, 0) == -43 and kind(4, 1) == -43 and kind(4, 0) == 1   # asked for explicitly and cannot be served: refused
+    buf = (C.c_char * 128)()
+    assert lib.primme_amd_comm_unique_id_for(buf, 17, 0) == -43
     assert lib.primme_amd_comm_unique_id_for(buf, 4, 0) == 0 and buf.raw[:6] == b"PAIPC1"
+    os.unlink(_seg(buf))
+    monkeypatch.delenv("PRIMME_AMD_COMM")
+    assert lib.primme_amd_comm_unique_id_for(buf, 8, 0) == 0 and buf.raw[:6] == b"PAIPC1"
     os.unlink(_seg(buf))
 
 

@@ -647,6 +647,87 @@ def test_csr_matvec_scaled_fused_tail(built, dt):
         assert abs(res[0][2][0] - float(res[0][0].astype(np.float64) @ res[0][1].astype(np.float64))) <= tol * np.sqrt(n) * (1 + abs(res[0][2][0])), name
 
 
+def _rr_arrow_case(side, k, L, cand, largest, grow_row, seed):
+    """hipk_rr_arrow against numpy: the pair the kernel returns must be the cand-th eigenpair of the arrowhead matrix its
+    inputs define, mapped back to the basis [V t]; then the residual pass that reads the pair from device memory
+    (hipk_ritz_residual_overlaps_dev) must equal the one that gets it by value."""
+    rng = np.random.default_rng(seed)
+    Hk = rng.standard_normal((k, k)); Hk = (Hk + Hk.T) / 2 + np.diag(np.linspace(-2.0, 3.0, k))
+    th, Y = np.linalg.eigh(Hk)
+    if largest:
+        th, Y = th[::-1].copy(), Y[:, ::-1].copy()
+    G = rng.standard_normal((k, L)) * 0.1
+    cV, cQ, wr, grow = rng.standard_normal(k) * 1e-3, rng.standard_normal(L) * 0.1, rng.standard_normal(k), rng.standard_normal(L) * 0.1
+    n2, alpha = 0.7 + rng.random(), float(rng.standard_normal())
+    nfov = 2 * (k + L) + 1
+    fov = np.concatenate([cV, cQ, [0.3], wr, grow, [n2]])
+    Guse = G.copy()
+    if grow_row and L > 0:
+        Guse[k - 1] = grow
+    hc = (wr - Y @ (th * (Y.T @ cV)) - Guse @ cQ) / np.sqrt(n2)
+    z = Y.T @ hc
+    M = np.zeros((k + 1, k + 1)); M[:k, :k] = np.diag(th); M[:k, k] = z; M[k, :k] = z; M[k, k] = alpha
+    w, U = np.linalg.eigh(M)
+    idx = (k - cand) if largest else cand
+    lam, y = w[idx], U[:, idx]
+    hwant = np.concatenate([Y @ y[:k], [y[k]]])
+    inp = F.HipkRrIn()
+    inp.k, inp.L, inp.cand, inp.largest, inp.grow_row = k, L, cand, int(largest), int(grow_row)
+    for i in range(k):
+        inp.theta[i] = th[i]
+        for r in range(k):
+            inp.Y[r + i * k] = Y[r, i]
+    for l in range(L):
+        for j in range(k):
+            inp.G[j + l * k] = G[j, l]
+    fd, ad, out = side.arr(fov), side.arr(np.array([alpha])), side.arr(np.zeros(64))
+    assert side.lib.hipk_rr_arrow(side.ctx, C.byref(inp), side.ptr(fd), nfov, side.ptr(ad), side.ptr(out)) == 0
+    got = side.get(out)
+    assert got[33] == 0.0, (k, L, cand, largest, got[33])
+    scale = max(1.0, np.abs(w).max())
+    assert abs(got[32] - lam) <= 1e-13 * scale, (k, cand, got[32], lam)
+    h = got[:k + 1]
+    gaps = np.abs(w - lam); gaps[idx] = np.inf
+    tol = 1e-13 * scale / min(1.0, gaps.min())            # an eigenvector is determined to eps |M| / gap
+    assert min(np.max(np.abs(h - hwant)), np.max(np.abs(h + hwant))) <= 10 * tol, (k, L, cand, largest)
+    Hfull = np.zeros((k + 1, k + 1)); Hfull[:k, :k] = Y @ np.diag(th) @ Y.T; Hfull[:k, k] = hc; Hfull[k, :k] = hc; Hfull[k, k] = alpha
+    assert np.max(np.abs(Hfull @ h - got[32] * h)) <= 2e-13 * scale and abs(h @ h - 1.0) <= 1e-13
+    return out, h, got[32]
+
+
+@pytest.mark.parametrize("largest", [0, 1])
+def test_rr_arrow_pair_of_the_next_iteration(built, largest):
+    """The one-wave Rayleigh-Ritz kernel of the iteration that is enqueued before the host has seen the previous one
+    (include/primme_amd_kernels.h: hipk_rr_arrow): every root index, both targets, with and without locked vectors, and the
+    residual pass that takes its pair from device memory."""
+    for side in (Dev(), Host()):
+        seed = 0
+        for k, L in ((1, 0), (2, 0), (5, 3), (9, 0), (15, 10), (16, 4)):
+            for cand in sorted({0, 1, k // 2, k - 1, k} & set(range(k + 1))):
+                seed += 1
+                out, h, lam = _rr_arrow_case(side, k, L, cand, largest, grow_row=(L > 0 and cand % 2 == 0), seed=seed)
+        # the residual pass reading (h, theta) from device memory == the one that gets them by value
+        k, L, m = 15, 10, 70001
+        out, h, lam = _rr_arrow_case(side, k, L, 0, largest, True, 99)
+        rng = np.random.default_rng(5)
+        ld = m + 1
+        V = rng.standard_normal((k + 1, ld)); W = rng.standard_normal((k + 1, ld)); Q = rng.standard_normal((L, ld))
+        v, w, q = side.arr(V), side.arr(W), side.arr(Q)
+        res = []
+        for dev in (0, 1):
+            dst = side.arr(np.zeros((1, ld))); o = side.arr(np.zeros(4 * (k + 1 + L) + 4))
+            if dev:
+                assert side.lib.hipk_ritz_residual_overlaps_dev(side.ctx, F.HIPK_F64, m, side.ptr(v), side.ptr(w), ld, k + 1, side.ptr(out), side.ptr(dst),
+                                                                side.ptr(q), ld, L, 1, side.ptr(o)) == 0
+            else:
+                hh = np.zeros(32); hh[:k + 1] = h
+                assert side.lib.hipk_ritz_residual_overlaps(side.ctx, F.HIPK_F64, m, side.ptr(v), side.ptr(w), ld, k + 1, hh.ctypes.data_as(C.c_void_p),
+                                                            C.c_double(lam), side.ptr(dst), side.ptr(q), ld, L, 1, side.ptr(o)) == 0
+            res.append((side.get(dst), side.get(o)))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        side.close()
+
+
 def _lattice_csr(n, rng):
     """a 1-D lattice operator with second-neighbour hopping and two site types: 3 x 2 row patterns away from the ends"""
     rows, cols, vals = [], [], []

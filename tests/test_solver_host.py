@@ -190,6 +190,12 @@ def test_launch_structure_block_size_one(built, mode, monkeypatch):
     its, rst = r.stats["numOuterIterations"], r.stats["numRestarts"]
     dots, project, ritz_upd, ritz_cgs, fused_tail, ritz_ov = cnt[0], cnt[1], cnt[2], cnt[3], cnt[5], cnt[6]
     assert r.ret == 0 and its == 490 and rst == 69 and r.stats["numMatvecs"] == 490
+    # Round 5: the next iteration is enqueued before the host has seen the current one (eigs_conv.c: pa_prelaunch_next) and thrown
+    # away when the host then decides otherwise — the candidate converged, a pair gets locked: a handful per solve (one per
+    # wanted pair here).  Those launches are counted by the checker but are no iterations: `ahead` is their allowance.
+    ahead = 12
+    fused_tail -= min(ahead, max(0, fused_tail - its)); ritz_cgs -= min(ahead, max(0, ritz_cgs - (its - rst if mode == "default" else its)))
+    project -= min(ahead, max(0, project - its))
     if mode == "default":
         # every iteration but the ones around a locked pair: one-launch tail, fused pass; the check at the full
         # basis IS the restart pass (speculative, out of place; with locked pairs plus one panel product for
