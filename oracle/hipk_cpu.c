@@ -327,23 +327,33 @@ int hipk_rr_arrow(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov, int nf
          if (gm > 0.0) { o = c; lo = -mid; hi = 0.0; }
          else { o = c - 1; lo = 0.0; hi = mid; }
       }
-      const double a0 = al - th[o];
+      const double a0 = al - th[o], B = z[o] * z[o];
+      const int neg = hi == 0.0;
       double mu = 0.5 * (lo + hi);
       int it = 0;
+      /* the pole at the origin exact, the rest of the sum by its tangent: a quadratic per step (csrc/hipk_panels.hip) */
       for (; it < 100; it++) {
-         double sm = 0.0, sp = 0.0;
-         for (int j = 0; j < k; j++) { const double r = 1.0 / ((th[j] - th[o]) - mu), t = z[j] * z[j] * r; sm += t; sp += t * r; }
-         const double g = a0 - mu - sm, gp = -1.0 - sp;
+         double S = 0.0, Sp = 0.0;
+         for (int j = 0; j < k; j++) if (j != o) { const double r = 1.0 / ((th[j] - th[o]) - mu), t = z[j] * z[j] * r; S += t; Sp += t * r; }
+         const double pole = B / mu, g = a0 - mu - S + pole;
          if (!(g == g)) { status = 3; break; }
-         if (g > 0.0) lo = mu; else if (g < 0.0) hi = mu; else break;
-         double mn = mu - g / gp;
-         if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
+         /* converged: g is zero to the rounding of its own terms (going on from here only moves mu by an ulp — or throws the
+          * next point an ulp outside the bracket, whose far end was never tightened, and the midpoint fall-back then crawls) */
+         if (fabs(g) <= 2.3e-16 * (fabs(a0) + fabs(mu) + fabs(S) + fabs(pole))) break;
+         if (g > 0.0) lo = mu; else hi = mu;
+         const double A = 1.0 + Sp, Cc = a0 - S + Sp * mu, disc = sqrt(Cc * Cc + 4.0 * A * B);
+         double mn;
+         if (neg) mn = (Cc > 0.0) ? -2.0 * B / (Cc + disc) : (Cc - disc) / (2.0 * A);
+         else mn = (Cc < 0.0) ? 2.0 * B / (disc - Cc) : (Cc + disc) / (2.0 * A);
+         if (!(mn > lo && mn < hi)) { if (fabs(mn - mu) <= 1e-14 * fabs(mu)) break; mn = 0.5 * (lo + hi); }
          const double step = fabs(mn - mu);
          const int done = step <= 4.4e-16 * fabs(mn) || mn == lo || mn == hi;
+         if (getenv("HIPK_RR_DEBUG")) fprintf(stderr, "  rr k=%d c=%d it=%d mu=%.17g mn=%.17g g=%.3e lo=%.17g hi=%.17g\n", k, c, it, mu, mn, g, lo, hi);
          mu = mn;
          if (done) break;
       }
       if (it >= 100) status = 4;
+      g_cnt[7] += it + 1;                        /* steps of the secular iteration (hipk_cpu_counts: diagnostics) */
       lam = sgn * (th[o] + mu);
       for (int j = 0; j < k; j++) { y[j] = z[j] / (mu - (th[j] - th[o])); ynorm2 += y[j] * y[j]; }
       if (!isfinite(lam) || !isfinite(ynorm2)) status = 5;

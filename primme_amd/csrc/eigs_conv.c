@@ -324,8 +324,10 @@ static int pa_prelaunch_next(pa_solver *s, int basisSize, int nLk, int col, int 
    if (tcol >= s->nT) return 0;
    char *dst1 = VCOL(s, k1);
    CHK(hipk_rr_arrow(s->ctx, &in, s->d_fov, nfov, s->d_fov + PA_ALPHA_OFF(s), s->d_hnext));
-   s->pre_seq_rr = hipk_seq_issued(s->ctx);
    CHK(hipk_ritz_residual_overlaps_dev(s->ctx, s->dt, s->m, s->V, s->W, s->ld, k1, s->d_hnext, dst1, s->evecs, s->ldevecs, nLk, 1, s->d_fov_alt));
+   /* the pair's pinned copy is looked at once the flagged second stage of this pass is through (the small kernel publishes
+    * no flag of its own: a system-scope fence and a PCIe write on the one chain of the iteration that has no slack) */
+   s->pre_seq_rr = hipk_seq_issued(s->ctx);
    hipk_seg segs[2] = {{s->V, s->ld, k1}, {s->evecs, s->ldevecs, nLk}};
    CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov_alt, nov1, dst1, s->ld, TCOL(s, tcol), s->ld, 1, s->d_fov_alt + nfov1));
    {

@@ -1511,80 +1511,123 @@ extern "C" int hipk_ritz_residual_overlaps_dev(hipk_ctx *ctx, hipk_dtype dt, int
  * holds the sums).  Secular equation in the coordinate mu = lambda - theta_o of the nearer pole o:
  *    g(mu) = (alpha - theta_o) - mu - sum_j z_j^2 / ((theta_j - theta_o) - mu),   strictly decreasing between two poles,
  * safeguarded Newton (a step that leaves the bracket is replaced by its midpoint), until the step is below two ulps of mu. */
-__device__ __forceinline__ double rr_sum16(double v) {
-   v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-   return v;
+/* sum over the 16 values a wave left in LDS (every lane gets the same bits: a fixed order) — no cross-lane traffic beyond
+ * two LDS round trips per Newton step */
+__device__ __forceinline__ double rr_sum16(const double *s) {
+   double a = 0.0;
+#pragma unroll
+   for (int i = 0; i < 16; i++) a += s[i];
+   return a;
 }
 __global__ void __launch_bounds__(64)
 rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const double *__restrict__ alpha_dev,
-      double *__restrict__ out, double *__restrict__ out_host, hipk_fin_flag fin) {
-   __shared__ double s_v[16], s_y[17];
+      double *__restrict__ out, double *__restrict__ out_host) {
+   /* The kernel arguments live in host-visible memory on this stack: indexed, per-lane reads of `in` would each be a trip over
+    * PCIe (the first version of this kernel did that in its loops and took longer than the host round trip it replaces).
+    * Everything is brought into LDS with ONE batch of loads — the arguments and this iteration's reductions together. */
+   __shared__ double sY[256], sG[160], sTh[16], sF[128], s_v[16], s_w[16], s_y[16];
    const int lane = threadIdx.x, j = lane & 15, k = in.k, L = in.L;
-   const bool on = j < k;
+   const bool on = lane < 16 && j < k;
+   {
+      double ty[4], tg[3], tf[2];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ty[u] = in.Y[lane + 64 * u];
+#pragma unroll
+      for (int u = 0; u < 3; u++) tg[u] = (lane + 64 * u < 160) ? in.G[lane + 64 * u] : 0.0;
+      const double tt = in.theta[j];
+#pragma unroll
+      for (int u = 0; u < 2; u++) tf[u] = (lane + 64 * u <= nfov) ? fov[lane + 64 * u] : 0.0;
+      const double ta = alpha_dev[0];
+#pragma unroll
+      for (int u = 0; u < 4; u++) sY[lane + 64 * u] = ty[u];
+#pragma unroll
+      for (int u = 0; u < 3; u++) if (lane + 64 * u < 160) sG[lane + 64 * u] = tg[u];
+      if (lane < 16) sTh[lane] = tt;
+#pragma unroll
+      for (int u = 0; u < 2; u++) sF[lane + 64 * u] = tf[u];
+      if (lane == 0) s_y[0] = ta;              /* (s_y is reused below) */
+   }
+   __syncthreads();
    const double sgn = in.largest ? -1.0 : 1.0;
-   /* this iteration's reductions */
-   const double n2 = fov[nfov], nt = sqrt(n2), alpha = alpha_dev[0];
-   const double cv = on ? fov[j] : 0.0;                       /* V'r */
-   const double wr = on ? fov[k + L + 1 + j] : 0.0;           /* W'r */
+   const double n2 = sF[nfov], nt = sqrt(n2), alpha = s_y[0];
+   const double cv = on ? sF[j] : 0.0;                        /* V'r */
+   const double wr = on ? sF[k + L + 1 + j] : 0.0;            /* W'r */
    double gq = 0.0;                                           /* (G Q'r)_j */
    for (int l = 0; l < L; l++) {
-      const double g = (in.grow_row && j == k - 1) ? fov[2 * k + L + 1 + l] : in.G[j + l * k];
-      gq = on ? fma(g, fov[k + l], gq) : 0.0;
+      const double g = (in.grow_row && j == k - 1) ? sF[2 * k + L + 1 + l] : sG[j + l * k];
+      gq = on ? fma(g, sF[k + l], gq) : 0.0;
    }
    /* z_i = (Y(:,i)'(W'r - G Q'r) - theta_i Y(:,i)'(V'r)) / |t| */
-   if (lane < 16) s_v[lane] = on ? wr - gq : 0.0;
    __syncthreads();
-   double a1 = 0.0;
-   for (int r = 0; r < k; r++) a1 = on ? fma(in.Y[r + j * k], s_v[r], a1) : 0.0;
+   if (lane < 16) { s_v[lane] = on ? wr - gq : 0.0; s_w[lane] = cv; }
    __syncthreads();
-   if (lane < 16) s_v[lane] = cv;
-   __syncthreads();
-   double a2 = 0.0;
-   for (int r = 0; r < k; r++) a2 = on ? fma(in.Y[r + j * k], s_v[r], a2) : 0.0;
-   const double thj = on ? in.theta[j] : 0.0;
+   double a1 = 0.0, a2 = 0.0;
+   for (int r = 0; r < k; r++) { const double yv = sY[r + j * k]; a1 = fma(yv, s_v[r], a1); a2 = fma(yv, s_w[r], a2); }
+   const double thj = on ? sTh[j] : 0.0;
    const double z = on ? sgn * (a1 - thj * a2) / nt : 0.0;     /* the negated problem for `largest`: -M = [-Theta -z; -z' -alpha] */
    const double th = sgn * thj, al = sgn * alpha;               /* ascending in j for both targets */
    const double z2 = z * z;
    const int c = in.cand;
-   int status = (k < 1 || k > 16 || L < 0 || L > 10 || c < 0 || c > k || !(n2 > 0.0)) ? 1 : 0;
-   /* poles strictly increasing, everything finite */
-   {
-      const double thn = __shfl(th, (lane & 48) + (j + 1 < k ? j + 1 : j), 64);
-      const int bad = on && (!(isfinite(th) && isfinite(z)) || (j + 1 < k && !(th < thn)));
-      if (__any(bad) || !isfinite(al)) status = 2;
+   int status = (k < 1 || k > 16 || L < 0 || L > 10 || c < 0 || c > k || nfov > 126 || !(n2 > 0.0)) ? 1 : 0;
+   __syncthreads();
+   if (lane < 16) { s_v[lane] = on ? th : 0.0; s_w[lane] = z2; }
+   __syncthreads();
+   /* poles strictly increasing, everything finite (every lane looks at all of them: uniform control flow) */
+   double zn2 = 0.0;
+   for (int i = 0; i < k; i++) {
+      const double ti = s_v[i], zi = s_w[i];
+      if (!(isfinite(ti) && isfinite(zi)) || (i + 1 < k && !(ti < s_v[i + 1]))) status = status ? status : 2;
+      zn2 += zi;
    }
-   const double zn = sqrt(rr_sum16(z2));
+   if (!isfinite(al)) status = status ? status : 2;
+   const double zn = sqrt(zn2);
    double lam = 0.0, yj = 0.0, ynorm2 = 1.0;
    if (status == 0) {
-      const double th0 = __shfl(th, lane & 48, 64), thl = __shfl(th, (lane & 48) + k - 1, 64);
-      const double thc = __shfl(th, (lane & 48) + (c < k ? c : k - 1), 64), thcm = __shfl(th, (lane & 48) + (c > 0 ? c - 1 : 0), 64);
+      const double th0 = s_v[0], thl = s_v[k - 1];
+      const double thc = s_v[c < k ? c : k - 1], thcm = s_v[c > 0 ? c - 1 : 0];
       int o;
       double lo, hi;
       if (c == 0) { o = 0; lo = fmin(0.0, al - th0) - zn - 1e-300; lo -= 4e-16 * fabs(lo); hi = 0.0; }
       else if (c == k) { o = k - 1; lo = 0.0; hi = fmax(0.0, al - thl) + zn + 1e-300; hi += 4e-16 * fabs(hi); }
       else {
          /* the sign of g at the middle of the interval says which pole the root is closer to */
-         const double gap = thc - thcm, mid = 0.5 * gap;
-         const double d = (th - thcm) - mid;
-         const double sm = rr_sum16(on ? z2 / d : 0.0);
+         const double mid = 0.5 * (thc - thcm);
+         double sm = 0.0;
+         for (int i = 0; i < k; i++) sm += s_w[i] / ((s_v[i] - thcm) - mid);
          const double gm = (al - thcm) - mid - sm;
          if (gm > 0.0) { o = c; lo = -mid; hi = 0.0; }
          else { o = c - 1; lo = 0.0; hi = mid; }
       }
-      const double tho = __shfl(th, (lane & 48) + o, 64);
+      const double tho = s_v[o];
       const double dj = th - tho, a0 = al - tho;
+      const bool neg = hi == 0.0;                               /* the root lies below its pole (mu < 0) or above it (mu > 0) */
+      const double B = s_w[o];                                  /* z_o^2: the pole's weight */
+      const bool mine = on && j != o;
       double mu = 0.5 * (lo + hi);
       int it = 0;
+      /* The pole at the origin is kept EXACT and the rest of the sum is replaced by its tangent at the current point
+       * (what LAPACK's dlaed4 does with two poles): g(mu) ~ (a0 - S + S' mu_i) - (1 + S') mu + z_o^2 / mu, a quadratic in mu
+       * whose root on the bracket's side of the pole is the next point.  Converges in 3-5 steps where Newton on g itself
+       * crawls (the root of the wanted pair sits within 1e-8 of its pole: the first version of this loop averaged 55 steps,
+       * 19 us per launch).  Safeguard: a point outside the bracket is replaced by its midpoint. */
       for (; it < 100; it++) {
-         const double d = dj - mu;
-         const double r = 1.0 / d;
-         const double t = on ? z2 * r : 0.0;
-         const double sm = rr_sum16(t), sp = rr_sum16(on ? t * r : 0.0);
-         const double g = a0 - mu - sm, gp = -1.0 - sp;
-         if (!(g == g)) { status = 3; break; }                      /* a lane sat on its pole: give up */
-         if (g > 0.0) lo = mu; else if (g < 0.0) hi = mu; else break;
-         double mn = mu - g / gp;
-         if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
+         const double r = 1.0 / (dj - mu);
+         const double t = mine ? z2 * r : 0.0;
+         __syncthreads();
+         if (lane < 16) { s_y[lane] = t; sF[lane] = mine ? t * r : 0.0; }
+         __syncthreads();
+         const double S = rr_sum16(s_y), Sp = rr_sum16(sF);
+         const double pole = B / mu, g = a0 - mu - S + pole;
+         if (!(g == g)) { status = 3; break; }
+         /* converged: g is zero to the rounding of its own terms (going on from here only moves mu by an ulp — or throws the
+          * next point an ulp outside the bracket, whose far end was never tightened, and the midpoint fall-back then crawls) */
+         if (fabs(g) <= 2.3e-16 * (fabs(a0) + fabs(mu) + fabs(S) + fabs(pole))) break;
+         if (g > 0.0) lo = mu; else hi = mu;
+         const double A = 1.0 + Sp, Cc = a0 - S + Sp * mu, disc = sqrt(Cc * Cc + 4.0 * A * B);
+         double mn;
+         if (neg) mn = (Cc > 0.0) ? -2.0 * B / (Cc + disc) : (Cc - disc) / (2.0 * A);
+         else mn = (Cc < 0.0) ? 2.0 * B / (disc - Cc) : (Cc + disc) / (2.0 * A);
+         if (!(mn > lo && mn < hi)) { if (fabs(mn - mu) <= 1e-14 * fabs(mu)) break; mn = 0.5 * (lo + hi); }
          const double step = fabs(mn - mu);
          const bool done = step <= 4.4e-16 * fabs(mn) || mn == lo || mn == hi;
          mu = mn;
@@ -1593,7 +1636,10 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
       if (it >= 100) status = 4;
       lam = sgn * (tho + mu);
       yj = on ? z / (mu - dj) : 0.0;                              /* eigenvector [y; 1] of the (possibly negated) arrowhead */
-      ynorm2 = 1.0 + rr_sum16(yj * yj);
+      __syncthreads();
+      if (lane < 16) s_y[lane] = yj * yj;
+      __syncthreads();
+      ynorm2 = 1.0 + rr_sum16(s_y);
       if (!isfinite(lam) || !isfinite(ynorm2)) status = 5;
    }
    /* back to the basis [V t]: h = [Y y; 1] / |[y; 1]| */
@@ -1602,7 +1648,7 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
    if (lane < 16) s_y[lane] = yj;
    __syncthreads();
    double hv = 0.0;
-   for (int i = 0; i < k; i++) hv = on ? fma(in.Y[j + i * k], s_y[i], hv) : 0.0;
+   for (int i = 0; i < k; i++) hv = fma(sY[j + i * k], s_y[i], hv);
    hv *= inv;
    if (lane < 16) {
       if (on) { out[j] = hv; if (out_host) out_host[j] = hv; }
@@ -1611,13 +1657,13 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
          if (out_host) { out_host[k] = inv; out_host[32] = lam; out_host[33] = (double)status; }
       }
    }
-   __syncthreads();
-   if (lane == 0) hipk_publish_flag(fin, 1);
+   /* no completion flag of its own: the host looks at the pinned copy after the flagged second stage of the residual pass that
+    * follows in the stream (a kernel boundary on the queue lies in between) */
 }
 extern "C" int hipk_rr_arrow(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov_dev, int nfov, const double *alpha_dev, double *out_dev) {
    if (!in || in->k < 1 || in->k > 16 || in->L < 0 || in->L > 10) return -1;
-   hipLaunchKernelGGL(rr_arrow_kernel, dim3(1), dim3(64), 0, ctx->stream, *in, fov_dev, nfov, alpha_dev, out_dev, hipk_mirror_of(ctx, out_dev),
-         hipk_next_flag(ctx, out_dev));
+   if (nfov > 126) return -1;
+   hipLaunchKernelGGL(rr_arrow_kernel, dim3(1), dim3(64), 0, ctx->stream, *in, fov_dev, nfov, alpha_dev, out_dev, hipk_mirror_of(ctx, out_dev));
    HIPK_CHECK(hipGetLastError());
    return 0;
 }

@@ -2,7 +2,9 @@
 REFERENCE's own panel routines — update_projection_dprimme, Num_update_VWXR_dprimme, Bortho_gen_dprimme,
 Bortho_block_dprimme — called by oracle/ref_kernel_harness.c, which is compiled against the reference's
 headers where they lie and linked with oracle/_ref/libprimme_ref.so.  Run in the build container
-(needs /root/reference); the JSON travels, the reference does not.
+(needs /root/reference: the harness is compiled against the reference's headers where they lie); the JSON is what the tests
+read, here and on the GPU box.  (The reference's SOURCES never travel; the prebuilt oracle/_ref/libprimme_ref.so does — it is
+git-ignored, not gpurun-ignored — and on the GPU box only bench.py's cpu_baseline leg loads it, in a process of its own.)
 
     python tests/golden/make_kernel_golden.py
 """
