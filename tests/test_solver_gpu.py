@@ -107,7 +107,19 @@ def test_most_fixtures_reproduce_the_reference_history(built):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     json.dump({"exact_history": sorted(EXACT_HISTORY), "fixtures": len(GOLD)}, open(os.path.join(root, "gpurun_out", "exact_history_gpu.json"), "w"))
-    assert len(EXACT_HISTORY) >= 25, sorted(EXACT_HISTORY)
+    # Round 5, measured on the MI355X (gpurun_out/exact_history_gpu.json, twice, with the row-pattern SpMV and the iteration
+    # enqueued ahead of the host both on): these 32 of the 50 fixtures reproduce the reference's outer-iteration AND matvec
+    # counts exactly, and then its residual norms to 1e-10 |A| (1e-4 |A| in single precision) — every extremal-target
+    # fixture (GD, GD+k, Olsen, LOBPCG-like, JDQMR at block size 1, blocks of 2 / 4 / 8 of the Davidson family, locking and
+    # soft locking, both precisions).  The other 18 are the ones the tolerances above exist for: interior targets, harmonic /
+    # refined extraction, block JDQMR, the wall-clock-driven dynamic method.
+    known_exact = {"blk1_explicit", "blk2_implicit", "blk2_jacobi", "blk2_lock", "blk2_soft", "blk4_largest", "blk4_lock", "blk8_K40", "float_bs1",
+                   "float_bs2", "jdqmr_bs1", "jdqmr_etol_bs1", "jdqmr_etol_jacobi", "jdqmr_etol_largest_3d", "jdqmr_float", "jdqmr_jacobi",
+                   "jdqmr_largest_3d", "jdqmr_soft", "lap1d_ex_dseq", "lap2d_gd", "lap2d_gd_olsen", "lap2d_gdk_lock", "lap2d_gdk_soft",
+                   "lap2d_gdk_soft_K20", "lap2d_jacobi", "lap2d_krylov_rng", "lap2d_largest", "lap3d_gdk", "lap3d_lobpcg", "lap3d_medium",
+                   "lap3d_noanorm", "lobpcg_default"}
+    missing = sorted(known_exact - set(EXACT_HISTORY))
+    assert len(EXACT_HISTORY) >= 30 and len(missing) <= 2, (sorted(EXACT_HISTORY), missing)
 
 
 @pytest.mark.parametrize("dims,kw", [
