@@ -441,6 +441,13 @@ def main():
                        "steps_requested": steps_req, "warmup_requested": warmup_req, "steps_cap": cap_note,
                        "profiled_solve_outer_iterations": lastp.stats["numOuterIterations"]},
             "roofline": roofline}
+        try:   # iterations enqueued before the host had seen the previous one / adopted, of the last solve
+            pre = (C.c_long * 2)()
+            lib.primme_amd_prelaunch_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+            lib.primme_amd_prelaunch_stats(C.cast(pre, C.POINTER(C.c_long)), C.cast(C.byref(pre, C.sizeof(C.c_long)), C.POINTER(C.c_long)))
+            res["config"]["iterations_enqueued_ahead"] = {"launched": int(pre[0]), "adopted": int(pre[1])}
+        except AttributeError:
+            pass
         if dist_path:
             res["config"]["transport"] = transport
             res["config"]["comm_selftest"] = comm_selftest

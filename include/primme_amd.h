@@ -240,6 +240,11 @@ void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ld
 void primme_amd_global_sum(void *sendBuf, void *recvBuf, int *count,
       struct primme_params *primme, int *ierr);
 
+/* Diagnostics of the LAST solve of this process (block size 1, GD+k family): how many outer iterations were enqueued before
+ * the host had seen the previous one and how many of those the host then adopted.  No reference
+ * counterpart (the reference has no device queue to run ahead of). */
+void primme_amd_prelaunch_stats(long *launched, long *adopted);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,7 +87,11 @@ int hipk_sync(hipk_ctx *c) { (void)c; return 0; }
 static double *g_mirror_dev, *g_mirror_host; static size_t g_mirror_n;
 int hipk_ctx_set_mirror(hipk_ctx *c, double *d, double *h, size_t n) { (void)c; g_mirror_dev = d; g_mirror_host = h; g_mirror_n = n; return 0; }
 void hipk_cpu_mirror(const double *out, size_t cnt);
-static void mirror(const double *out, size_t cnt) { hipk_cpu_mirror(out, cnt); }
+/* the checker's stand-in for the cross-rank second stage of the product's reductions (hipk_finalize_kernel<., XR>): when the stand-in
+ * communicator of oracle/hostcheck_glue.c installs this hook, the results of a reduction pass through it (it sums them over the ranks
+ * if the pass was armed, hipk_xreduce_arm) before they are mirrored */
+void (*hipk_cpu_xr_hook)(double *out, size_t cnt);
+static void mirror(const double *out, size_t cnt) { if (hipk_cpu_xr_hook) hipk_cpu_xr_hook((double *)out, cnt); hipk_cpu_mirror(out, cnt); }
 void hipk_cpu_mirror(const double *out, size_t cnt) {   /* keep the zero-copy contract on the host build */
    if (g_mirror_dev && out >= g_mirror_dev && out < g_mirror_dev + g_mirror_n && g_mirror_host != g_mirror_dev)
       memmove(g_mirror_host + (out - g_mirror_dev), out, cnt * sizeof(double));

@@ -11,7 +11,7 @@
 #include <math.h>
 
 typedef void (*hostcheck_allreduce_fn)(double *buf, int count);
-struct primme_amd_comm { hostcheck_allreduce_fn cb; int rank, size; long calls; };
+struct primme_amd_comm { hostcheck_allreduce_fn cb; int rank, size; long calls; int xr; long xr_calls; };
 /* comm / xfull: a row slab that references rows of other ranks (halo) gathers the whole vector through the stand-in
  * communicator's all-reduce (every rank contributes its slab to a zero-padded copy) and hands the kernels the two
  * halo windows inside it, like the all-gather mode of the real operator (amd_operator.hip) */
@@ -86,6 +86,9 @@ void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ld
  * place to the "device" buffer, which is host memory here.  With it installed the solver runs the SAME code path as
  * on several GPUs -- reductions inside the stream of launches, |t|^2 and t'At in one all-reduce, the fused /
  * speculative restart with reduced overlaps -- in the world_size-2 CPU tests (tests/test_multirank_gloo.py). */
+/* (the stand-in of the cross-rank second stage, below) */
+extern void (*hipk_cpu_xr_hook)(double *out, size_t cnt);
+static primme_amd_comm *g_xr_comm; static int g_xr_armed; static const double *g_xr_lo; static size_t g_xr_count;
 int primme_amd_hostcheck_comm_create(primme_amd_comm **out, hostcheck_allreduce_fn cb, int rank, int size) {
    primme_amd_comm *c = calloc(1, sizeof(*c));
    if (!c) return -2;
@@ -93,7 +96,7 @@ int primme_amd_hostcheck_comm_create(primme_amd_comm **out, hostcheck_allreduce_
    *out = c;
    return 0;
 }
-int primme_amd_comm_destroy(primme_amd_comm *c) { free(c); return 0; }
+int primme_amd_comm_destroy(primme_amd_comm *c) { if (c == g_xr_comm) { g_xr_comm = NULL; hipk_cpu_xr_hook = NULL; } free(c); return 0; }
 int primme_amd_comm_rank(const primme_amd_comm *c) { return c ? c->rank : 0; }
 int primme_amd_comm_size(const primme_amd_comm *c) { return c ? c->size : 1; }
 long primme_amd_hostcheck_comm_calls(const primme_amd_comm *c) { return c ? c->calls : 0; }
@@ -112,13 +115,36 @@ int pa_comm_allreduce_device(void *ci, double *d, int n, void *st) {
    return 0;
 }
 
-/* the peer-to-peer transport and its fused second stage exist on the device only: the checker always takes the
- * separate all-reduce above */
+/* The peer-to-peer transport exists on the device only: the checker takes the separate all-reduce above.  Its FUSED SECOND STAGE
+ * (hipk_xreduce_arm: the launch that forms the local sums exchanges them with the other ranks itself) has a stand-in, switched on
+ * per communicator with primme_amd_hostcheck_comm_set_xr: an armed reduction of oracle/hipk_cpu.c passes its results through the
+ * all-reduce callback before it mirrors them (hipk_cpu_xr_hook), and hipk_xreduce_covered answers as on the device.  With it the
+ * world_size-2 CPU tests run the host logic of the row-partitioned run on the mailboxes, including the iteration that is enqueued
+ * before the host has seen the current one. */
 int pa_comm_allreduce_publish(void *ci, struct hipk_ctx *ctx, double *d, int n) { (void)ci; (void)ctx; (void)d; (void)n; return 1; }
-int pa_comm_attach_ctx(void *ci, struct hipk_ctx *ctx) { (void)ci; (void)ctx; return 1; }
-void hipk_xreduce_arm(struct hipk_ctx *ctx) { (void)ctx; }
-int hipk_xreduce_available(struct hipk_ctx *ctx) { (void)ctx; return 0; }
-int hipk_xreduce_covered(struct hipk_ctx *ctx, const double *buf, int count) { (void)ctx; (void)buf; (void)count; return 0; }
+static void xr_hook(double *out, size_t cnt) {
+   if (!g_xr_armed || !g_xr_comm) return;
+   g_xr_armed = 0;
+   g_xr_comm->cb(out, (int)cnt); g_xr_comm->calls++; g_xr_comm->xr_calls++;
+   g_xr_lo = out; g_xr_count = cnt;
+}
+int primme_amd_hostcheck_comm_set_xr(primme_amd_comm *c, int on) { if (!c) return -1; c->xr = on ? 1 : 0; return 0; }
+long primme_amd_hostcheck_comm_xr_calls(const primme_amd_comm *c) { return c ? c->xr_calls : 0; }
+int pa_comm_attach_ctx(void *ci, struct hipk_ctx *ctx) {
+   primme_amd_comm *c = (primme_amd_comm *)ci;
+   (void)ctx;
+   g_xr_comm = (c && c->xr) ? c : NULL; g_xr_armed = 0; g_xr_lo = NULL; g_xr_count = 0;
+   hipk_cpu_xr_hook = g_xr_comm ? xr_hook : NULL;
+   return g_xr_comm ? 0 : 1;
+}
+void hipk_xreduce_arm(struct hipk_ctx *ctx) { (void)ctx; if (g_xr_comm) g_xr_armed = 1; }
+int hipk_xreduce_available(struct hipk_ctx *ctx) { (void)ctx; return g_xr_comm ? 1 : 0; }
+int hipk_xreduce_covered(struct hipk_ctx *ctx, const double *buf, int count) {
+   (void)ctx;
+   const int yes = g_xr_lo && buf >= g_xr_lo && buf + count <= g_xr_lo + g_xr_count;
+   g_xr_lo = NULL; g_xr_count = 0; g_xr_armed = 0;
+   return yes;
+}
 int pa_comm_failed(void *ci) { (void)ci; return 0; }
 
 /* singular value operator on host memory */

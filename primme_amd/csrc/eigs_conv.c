@@ -274,6 +274,13 @@ static int try_speculative_restart(pa_solver *s, int basisSize, int nLk, const i
  * iteration must not write where the host is still reading this iteration's). */
 #define PA_ALPHA_OFF(s) ((s)->red_cap - 2)
 
+/* diagnostics of the last solve of this process: iterations enqueued ahead of the host / adopted (include/primme_amd.h) */
+long pa_last_pre[2];
+void primme_amd_prelaunch_stats(long *launched, long *adopted) {
+   if (launched) *launched = pa_last_pre[0];
+   if (adopted) *adopted = pa_last_pre[1];
+}
+
 /* The host-side arithmetic after the one wait of the fused tail: the new column of H from W'r. */
 static void tail_finish(pa_solver *s, int basisSize, int nLk, int nfov, const double *h_fov, double alpha) {
    const int nov = basisSize + nLk;
@@ -302,7 +309,11 @@ static int pa_prelaunch_next(pa_solver *s, int basisSize, int nLk, int col, int 
    primme_params *p = s->p;
    const int k = basisSize, k1 = basisSize + 1;
    s->pre_valid = 0;
-   if (!s->pre_enabled || s->parallel || s->phase_timing || s->Q || s->VtBV || !s->wtr_enabled) return 0;
+   /* row-partitioned runs: only where every reduction of the pass is exchanged inside the second stage of the launch that forms
+    * it (peer-to-peer transport, hipk_xreduce_arm) — the global sums are then in HBM for the next launch without the host; every
+    * rank takes the same decisions from the same bits, so the ranks enqueue (and throw away) the same launches */
+   const int xr = s->parallel && s->dev_comm && hipk_xreduce_available(s->ctx);
+   if (!s->pre_enabled || (s->parallel && !xr) || s->phase_timing || s->Q || s->VtBV || !s->wtr_enabled) return 0;
    if (p->target != primme_smallest && p->target != primme_largest) return 0;
    if (k1 > 16 || nLk > 10 || k1 + 1 > p->maxBasisSize || col < 0 || col > k) return 0;
    if (p->maxMatvecs > 0 && p->stats.numMatvecs + 3 >= p->maxMatvecs) return 0;
@@ -324,19 +335,27 @@ static int pa_prelaunch_next(pa_solver *s, int basisSize, int nLk, int col, int 
    if (tcol >= s->nT) return 0;
    char *dst1 = VCOL(s, k1);
    CHK(hipk_rr_arrow(s->ctx, &in, s->d_fov, nfov, s->d_fov + PA_ALPHA_OFF(s), s->d_hnext));
+   if (xr) hipk_xreduce_arm(s->ctx);
    CHK(hipk_ritz_residual_overlaps_dev(s->ctx, s->dt, s->m, s->V, s->W, s->ld, k1, s->d_hnext, dst1, s->evecs, s->ldevecs, nLk, 1, s->d_fov_alt));
    /* the pair's pinned copy is looked at once the flagged second stage of this pass is through (the small kernel publishes
     * no flag of its own: a system-scope fence and a PCIe write on the one chain of the iteration that has no slack) */
    s->pre_seq_rr = hipk_seq_issued(s->ctx);
+   /* (a second stage that did not take the arm — sums that are not global — means this pass cannot be used: it is left to be
+    * overwritten, on every rank alike) */
+   if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt, nfov1)) return 0;
    hipk_seg segs[2] = {{s->V, s->ld, k1}, {s->evecs, s->ldevecs, nLk}};
+   if (xr) hipk_xreduce_arm(s->ctx);
    CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov_alt, nov1, dst1, s->ld, TCOL(s, tcol), s->ld, 1, s->d_fov_alt + nfov1));
+   if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt + nfov1, 1)) return 0;
    {
+      if (xr) hipk_xreduce_arm(s->ctx);
       int rc = (p->matrixMatvec == primme_amd_matvec)
              ? primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, tcol), s->d_fov_alt + nfov1, dst1, WCOL(s, k1), s->d_fov_alt + PA_ALPHA_OFF(s))
              : pa_svds_apply_scaled(p, s->ctx, TCOL(s, tcol), s->d_fov_alt + nfov1, dst1, WCOL(s, k1), s->d_fov_alt + PA_ALPHA_OFF(s));
       if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
    }
    s->pre_seq_end = hipk_seq_issued(s->ctx);
+   if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt + PA_ALPHA_OFF(s), 1)) return 0;
    s->pre_valid = 1; s->pre_k = k1; s->pre_L = nLk; s->pre_cand = col; s->pre_nfov = nfov1; s->pre_tcol = tcol;
    s->pre_launched++;
    return 0;
@@ -386,6 +405,11 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
       s->pre_adopted++;
       CHK(pa_prelaunch_next(s, basisSize, nLk, col, nfov));
       CHK(hipk_wait_seq(s->ctx, seq_end));
+      if (s->parallel) {                             /* the three exchanges of the adopted pass (residual overlaps, |t|^2, t'At) */
+         if (s->dev_comm && pa_comm_failed(p->commInfo)) return PRIMME_PARALLEL_FAILURE;
+         p->stats.numGlobalSum += 3;
+         p->stats.volumeGlobalSum += nfov + 2;
+      }
       tail_finish(s, basisSize, nLk, nfov, s->h_fov, s->h_fov[PA_ALPHA_OFF(s)]);
       s->spec2_valid = 1; s->spec2_k = basisSize;
       s->fov_projected = 1;
@@ -428,29 +452,30 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
       s->spec2_valid = 1; s->spec2_k = basisSize;
    } else if (speculate2) {
       CHK(pa_reduce(s, s->d_fov + nfov, 1, 1, 1));
-      if (fuse_tail && !xr) {
-         /* the library's own operator, one rank: normalisation, A t and t'At in one launch, reading the un-normalised vector
+      if (fuse_tail) {
+         /* the library's own operator (one rank, or the peer-to-peer transport: the second stage of the launch exchanges t'At with
+          * the other ranks): normalisation, A t and t'At in one launch, reading the un-normalised vector
           * from the scratch column and rebuilding V(:,k) on the way; t'At goes to the alpha slot of the overlap buffer.
           * Before the one wait the NEXT iteration is enqueued behind this one (pa_prelaunch_next), so the wait is for this
           * tail's own completion flag, not for the last launch of the stream. */
+         if (xr) hipk_xreduce_arm(s->ctx);
          rc = fused_apply(s, TCOL(s, 0), s->d_fov + nfov, dstc, WCOL(s, basisSize), s->d_fov + PA_ALPHA_OFF(s));
          if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
          s->spec_fused = 1;
          const unsigned long long seq_end = hipk_seq_issued(s->ctx);
          CHK(pa_prelaunch_next(s, basisSize, nLk, col, nfov));
-         if (s->pre_valid) CHK(hipk_wait_seq(s->ctx, seq_end));
-         else CHK(pa_reduce(s, s->d_fov + PA_ALPHA_OFF(s), 1, 0, 0));                 /* the one synchronisation */
+         if (s->pre_valid) {
+            CHK(hipk_wait_seq(s->ctx, seq_end));
+            if (xr) {
+               if (pa_comm_failed(p->commInfo)) return PRIMME_PARALLEL_FAILURE;
+               p->stats.numGlobalSum++;
+               p->stats.volumeGlobalSum++;
+            }
+         } else CHK(pa_reduce(s, s->d_fov + PA_ALPHA_OFF(s), 1, 0, 0));                 /* the one synchronisation */
          tail_finish(s, basisSize, nLk, nfov, s->h_fov, s->h_fov[PA_ALPHA_OFF(s)]);
          s->spec2_valid = 1; s->spec2_k = basisSize;
          s->fov_projected = 1;
          return 0;
-      } else if (fuse_tail) {
-         /* the library's own operator: normalisation, A t and t'At in one launch, reading the
-          * un-normalised vector from the scratch column and rebuilding V(:,k) on the way */
-         if (xr) hipk_xreduce_arm(s->ctx);
-         rc = fused_apply(s, TCOL(s, 0), s->d_fov + nfov, dstc, WCOL(s, basisSize), s->d_red);
-         if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
-         s->spec_fused = 1;
       } else {
          CHK(hipk_scale_cols_rsqrt_dev(s->ctx, s->dt, s->m, dstc, s->ld, 1, s->d_fov + nfov));
          int one = 1, ierr = 0;
@@ -459,10 +484,8 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
          if (ierr) return PRIMME_USER_FAILURE;
       }
       if (wtr) {
-         if (!fuse_tail) {
-            if (xr) hipk_xreduce_arm(s->ctx);
-            CHK(hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red));
-         }
+         if (xr) hipk_xreduce_arm(s->ctx);
+         CHK(hipk_pair_dots(s->ctx, s->dt, s->m, dstc, s->ld, WCOL(s, basisSize), s->ld, 1, s->d_red));
          CHK(pa_reduce(s, s->d_red, 1, 0, 0));                 /* the one synchronisation */
          const double *cV = s->h_fov, *cQ = s->h_fov + basisSize, *wr = s->h_fov + nov + 1;
          const double inv = 1.0 / sqrt(s->h_fov[nfov]);
@@ -643,7 +666,8 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
           * (the launches below then run behind it in the stream and overwrite what it wrote). */
          int adopted = 0;
          if (s->pre_valid && s->pre_k == basisSize && s->pre_L == nLk && s->pre_cand == col && speculate && speculate2 && wtr &&
-               s->pre_nfov == nfov && pa_fuse_tail_eligible(s) && !(s->parallel && s->dev_comm)) {
+               s->pre_nfov == nfov && pa_fuse_tail_eligible(s) &&
+               (!s->parallel || (s->dev_comm && hipk_xreduce_available(s->ctx)))) {
             if ((rc = hipk_wait_seq(s->ctx, s->pre_seq_rr))) goto out;
             if (pre_pair_matches(s, basisSize, col)) {
                double *td = s->d_fov, *th = s->h_fov;

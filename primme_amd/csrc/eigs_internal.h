@@ -63,6 +63,7 @@ int hipk_xreduce_available(hipk_ctx *ctx);
 int hipk_xreduce_covered(hipk_ctx *ctx, const double *buf, int count);
 /* non-zero after a device-side wait of the transport ran into its time limit (a rank left the collective sequence) */
 int pa_comm_failed(void *commInfo);
+extern long pa_last_pre[2];   /* eigs_conv.c: pre-enqueued iterations of the last solve (launched, adopted) */
 
 /* the matvec handle understands the communicator for halo exchange */
 #endif

@@ -1012,6 +1012,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    }
    free(evals);
    free(resNorms);
+   pa_last_pre[0] = s->pre_launched; pa_last_pre[1] = s->pre_adopted;
    if (getenv("PRIMME_AMD_PRELAUNCH_STATS"))
       fprintf(stderr, "primme_amd: iterations enqueued ahead of the host: %ld launched, %ld adopted (of %lld outer iterations)\n", s->pre_launched,
             s->pre_adopted, (long long)p->stats.numOuterIterations);

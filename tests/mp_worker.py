@@ -44,6 +44,8 @@ def run(rank, world, port, case, out_path):
         r = s.solve(numEvals=6, eps=1e-10, aNorm=8.0 * 1.37, v0=v0, numProcs=world, procID=rank, global_sum=global_sum)
         s.close()
     elif case.startswith("devcomm"):
+        xr = case.endswith("_xr")
+        case = case[:-3] if xr else case
         # The path the GPUs take: the library's own operator and communicator (reductions inside the stream of
         # launches, |t|^2 and t'At in one all-reduce, fused / speculative restart on reduced overlaps).  The
         # all-reduce of the stand-in communicator (oracle/hostcheck_glue.c) is gloo; block-diagonal matrix, so
@@ -71,6 +73,11 @@ def run(rank, world, port, case, out_path):
         comm = C.c_void_p()
         lib.primme_amd_hostcheck_comm_create.argtypes = [C.POINTER(C.c_void_p), AR, C.c_int, C.c_int]
         assert lib.primme_amd_hostcheck_comm_create(C.byref(comm), arcb, rank, world) == 0
+        if xr:
+            # stand-in of the peer-to-peer transport's fused second stage: armed reductions are summed over the ranks inside the
+            # "launch" that forms them (oracle/hostcheck_glue.c), the host logic is the one of ranks on the mailboxes
+            lib.primme_amd_hostcheck_comm_set_xr.argtypes = [C.c_void_p, C.c_int]
+            assert lib.primme_amd_hostcheck_comm_set_xr(comm, 1) == 0
         op = Operator(n, csr=(rpt, cit, vat), row0=rank * n0, nrows=n0)
         v0 = problems.start_vector(n, row0=rank * n0, nrows=n0)
         s = Session(op, comm=comm, backend="hostcheck")
@@ -81,8 +88,14 @@ def run(rank, world, port, case, out_path):
         lib.hipk_cpu_counts(counts, 1)
         lib.primme_amd_hostcheck_comm_calls.restype = C.c_long
         lib.primme_amd_hostcheck_comm_calls.argtypes = [C.c_void_p]
+        lib.primme_amd_hostcheck_comm_xr_calls.restype = C.c_long
+        lib.primme_amd_hostcheck_comm_xr_calls.argtypes = [C.c_void_p]
+        pre = (C.c_long * 2)()
+        lib.primme_amd_prelaunch_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        lib.primme_amd_prelaunch_stats(C.cast(pre, C.POINTER(C.c_long)), C.cast(C.byref(pre, C.sizeof(C.c_long)), C.POINTER(C.c_long)))
         extra = dict(allreduces=int(lib.primme_amd_hostcheck_comm_calls(comm)), fused_tail=int(counts[5]), ritz_cgs=int(counts[3]),
-                     ritz_ov=int(counts[6]), dots=int(counts[0]), locking=int(r.params["locking"]))
+                     ritz_ov=int(counts[6]), dots=int(counts[0]), locking=int(r.params["locking"]),
+                     fused_exchanges=int(lib.primme_amd_hostcheck_comm_xr_calls(comm)), ahead=int(pre[0]), adopted=int(pre[1]))
         s.close()
     elif case == "halo":
         # one 2-D Laplacian split by rows; the callback matvec exchanges one grid line with the neighbour

@@ -261,6 +261,10 @@ def run(rank, world, port, case, out_path):
         res.update(ret=r.ret, evals=r.evals.tolist(), resNorms=r.resNorms.tolist(), its=r.stats["numOuterIterations"],
                    matvecs=r.stats["numMatvecs"], numGlobalSum=r.stats["numGlobalSum"], evecs_norm2=float(np.sum(np.abs(r.evecs) ** 2)),
                    aNorm=r.params["aNorm"])
+        pre = (C.c_long * 2)()
+        lib.primme_amd_prelaunch_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        lib.primme_amd_prelaunch_stats(C.cast(pre, C.POINTER(C.c_long)), C.cast(C.byref(pre, C.sizeof(C.c_long)), C.POINTER(C.c_long)))
+        res.update(ahead=int(pre[0]), adopted=int(pre[1]))      # iterations enqueued before the host had seen the previous one / adopted
     json.dump(res, open(f"{out_path}.{rank}", "w"))
     dist.barrier()
     lib.primme_amd_comm_destroy(comm)

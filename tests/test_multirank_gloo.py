@@ -168,3 +168,27 @@ def test_device_communicator_path_with_halo_two_ranks(built, tmp_path):
     assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]
     assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - 6) < 1e-8
     assert abs(res[0]["its"] - single.stats["numOuterIterations"]) <= max(3, 0.05 * single.stats["numOuterIterations"])
+
+
+@pytest.mark.parametrize("case,nev", [("devcomm_lock_xr", 10), ("devcomm_soft_xr", 4), ("devcomm_halo_xr", 6)])
+def test_peer_to_peer_second_stage_and_iterations_enqueued_ahead_two_ranks(built, tmp_path, case, nev):
+    """Round 5.  The host logic of ranks on the MAILBOX transport (comm_ipc.hip), world_size 2 on CPU: every reduction of the
+    block-size-1 iteration is exchanged inside the second stage of the launch that forms it (hipk_xreduce_arm; stand-in:
+    oracle/hostcheck_glue.c), so the global sums are in "HBM" without the host and the NEXT iteration is enqueued before the host
+    has seen the current one (eigs_conv.c: pa_prelaunch_next), on both ranks alike.  Same iteration / matvec / restart counts as
+    the same solve with separate all-reduces (the RCCL form), identical bits on both ranks, most iterations adopted."""
+    res = _launch(case, tmp_path)
+    plain = _launch(case[:-3], tmp_path)
+    for r, q in zip(res, plain):
+        assert r["ret"] == 0 and q["ret"] == 0
+        assert (r["its"], r["matvecs"], r["restarts"]) == (q["its"], q["matvecs"], q["restarts"])
+        assert np.max(np.abs(np.array(r["evals"]) - np.array(q["evals"]))) <= 1e-12 * 8 * 1.37
+        assert np.all(np.array(r["resNorms"]) <= 1e-10 * 8 * 1.37 * 1.001)
+        # three exchanges per iteration, each inside the launch that forms the sums; iterations enqueued ahead: all but the ones
+        # around restarts and converged pairs, and nearly all of them adopted
+        assert r["fused_exchanges"] >= 3 * (r["its"] - r["restarts"]) - 60 and q["fused_exchanges"] == 0
+        assert r["ahead"] >= r["its"] - r["restarts"] - 40 and r["adopted"] >= r["ahead"] - 12 and q["ahead"] == 0
+        assert r["fused_tail"] >= r["its"] - 20
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]
+    assert res[0]["adopted"] == res[1]["adopted"] and res[0]["ahead"] == res[1]["ahead"] and res[0]["allreduces"] == res[1]["allreduces"]
+    assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - nev) < 1e-8

@@ -96,6 +96,10 @@ def test_ipc_configs1_small(built, tmp_path, world):
     assert abs(sum(r["evecs_norm2"] for r in res) - 10.0) < 1e-8
     assert abs(res[0]["its"] - one.stats["numOuterIterations"]) <= max(3, 0.05 * one.stats["numOuterIterations"])
     assert res[0]["numGlobalSum"] >= res[0]["its"]
+    # round 5: on the mailboxes the global sums are in HBM without the host, so the next iteration is enqueued before the host has
+    # seen the current one on every rank alike (eigs_conv.c: pa_prelaunch_next) — most iterations, same decisions on all ranks
+    assert res[0]["adopted"] >= 0.6 * res[0]["its"] and res[0]["ahead"] - res[0]["adopted"] <= 40
+    assert all(r["adopted"] == res[0]["adopted"] and r["ahead"] == res[0]["ahead"] for r in res)
 
 
 @pytest.mark.parametrize("world,case", [(2, "halo"), (4, "halo"), (8, "halo"), (4, "halo_block")])
@@ -111,6 +115,7 @@ def test_ipc_halo_laplacian(built, tmp_path, world, case):
         one = eigsh(Operator(n, csr=(rp, ci, va)), backend="hip", numEvals=6, eps=1e-10, aNorm=12.0, v0=problems.start_vector(n))
         assert np.max(np.abs(np.array(res[0]["evals"]) - one.evals)) <= 1e-10 * 12.0
         assert abs(res[0]["its"] - one.stats["numOuterIterations"]) <= max(2, 0.03 * one.stats["numOuterIterations"])
+        assert res[0]["adopted"] >= 0.6 * res[0]["its"] and all(r["adopted"] == res[0]["adopted"] for r in res)
 
 
 @pytest.mark.parametrize("world", WORLDS)
@@ -156,3 +161,16 @@ def test_ipc_transport_agrees_with_separate_launches(built, tmp_path):
     b = _launch("lap3d_small", 2, tmp_path, extra_env={"PRIMME_AMD_NO_XREDUCE": "1"})
     assert a[0]["its"] == b[0]["its"] and a[0]["matvecs"] == b[0]["matvecs"]
     assert np.max(np.abs(np.array(a[0]["evals"]) - np.array(b[0]["evals"]))) <= 1e-12 * 12.0
+
+
+def test_ipc_iterations_enqueued_ahead_agree_with_the_plain_sequence(built, tmp_path):
+    """Round 5: the row-partitioned run with the next iteration enqueued before the host has seen the current one (default on the
+    mailboxes) against the same run with every iteration launched after the host's own Rayleigh-Ritz solve
+    (PRIMME_AMD_NO_PRELAUNCH=1): same history, same pairs."""
+    for case in ("lap3d_small", "halo"):
+        a = _launch(case, 2, tmp_path)
+        b = _launch(case, 2, tmp_path, extra_env={"PRIMME_AMD_NO_PRELAUNCH": "1"})
+        assert a[0]["adopted"] > 0 and b[0]["ahead"] == 0
+        assert a[0]["its"] == b[0]["its"] and a[0]["matvecs"] == b[0]["matvecs"]
+        assert np.max(np.abs(np.array(a[0]["evals"]) - np.array(b[0]["evals"]))) <= 1e-12 * 12.0
+        assert np.max(np.abs(np.array(a[0]["resNorms"]) - np.array(b[0]["resNorms"]))) <= 1e-10 * 12.0
