@@ -1,5 +1,6 @@
-/* svds_complex.c — hip_zprimme_svds / hip_cprimme_svds: singular triplets of a complex matrix through its
- * real-equivalent form.
+/* svds_complex.c — hip_zprimme_svds / hip_cprimme_svds: the entry points, and the REAL-EQUIVALENT form of the complex singular
+ * value problem (the default until round 4; since round 5 the native complex front end of svds_main.c is the default and this
+ * form is the A/B alternative behind PRIMME_AMD_COMPLEX_REAL_FORM=1).
  *
  * Boundary: reference include/primme_svds.h:242-243, :268-271 (zprimme_svds / cprimme_svds and their GPU
  * flavours), front end src/svds/primme_svds_c.c:103-108 with SCALAR = complex.  Same construction as
@@ -12,7 +13,7 @@
  * residual norms of what is returned are recomputed.
  *
  * Cost: twice the triplets; the operator-application counts are NOT those of zprimme_svds (the values, vectors and
- * residual norms are, to the tolerance).  Native complex kernels are the follow-up.
+ * residual norms are, to the tolerance).
  */
 #include <math.h>
 #include <stddef.h>
@@ -74,10 +75,20 @@ static int sum_svds(void *who, double *buf, int count) { return pa_svds_call_glo
 
 #define CX(call) do { int rc__ = (call); if (rc__) { ret = rc__ < 0 ? rc__ : PRIMME_UNEXPECTED_FAILURE; goto done; } } while (0)
 
+int pa_svds_solve_native_complex(void *svals, void *svecs, void *resNorms, primme_svds_params *ps, int single);
+
 static int solve_svds_complex(void *svals_out, void *svecs_, void *resNorms_out, primme_svds_params *ps, hipk_dtype dtr) {
    if (!ps) return -4;
    if (!svals_out && !svecs_ && !resNorms_out)       /* defaults query: the same for every precision */
       return hip_dprimme_svds(NULL, NULL, NULL, ps);
+   /* Round 5: the NATIVE complex front end is the default — svds_main.c instantiated for complex panels over the native complex
+    * eigensolver, like the reference's primme_svds_c.c for SCALAR = complex: numSvals triplets, the reference's operator counts.
+    * The real-equivalent form below (twice the triplets, twice the bytes per application) stays behind PRIMME_AMD_COMPLEX_REAL_FORM=1
+    * (A/B measurements, tests of both). */
+   if (!getenv("PRIMME_AMD_COMPLEX_REAL_FORM")) {
+      if (svecs_ && !hipk_is_device_ptr(svecs_)) return -18;
+      return pa_svds_solve_native_complex(svals_out, svecs_, resNorms_out, ps, dtr == HIPK_F32);
+   }
    if (ps->numProcs <= 1) { ps->mLocal = ps->m; ps->nLocal = ps->n; ps->procID = 0; ps->numProcs = 1; }
    primme_svds_set_defaults(ps);
    if (ps->n < 0 || ps->m < 0 || ps->nLocal < 0 || ps->mLocal < 0 || ps->nLocal > ps->n || ps->mLocal > ps->m) return -5;

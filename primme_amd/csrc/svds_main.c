@@ -44,7 +44,18 @@ static svds_side *side_new(primme_svds_params *ps) {
    return NULL;
 }
 
-static size_t es_of(hipk_dtype dt) { return dt == HIPK_F64 ? 8 : 4; }
+/* Complex panels (hip_zprimme_svds / hip_cprimme_svds, reference primme_svds_c.c instantiated for SCALAR = complex): every
+ * n-length operation of THIS file has real coefficients — copies, scalings by real factors, squared norms, Re(u'A v), an
+ * axpy with a real factor — so it runs on the complex vectors viewed as real ones of twice the length (RDT / RF below); the
+ * complex arithmetic is the eigensolver's (pa_eigs_solve_z: native complex panels) and the user's operator's.  Leading
+ * dimensions handed to the callbacks count complex elements, as in the reference. */
+static int is_cplx(hipk_dtype dt) { return dt == HIPK_C64 || dt == HIPK_C32; }
+static int is_single(hipk_dtype dt) { return dt == HIPK_F32 || dt == HIPK_C32; }
+static hipk_dtype rdt_of(hipk_dtype dt) { return dt == HIPK_C64 ? HIPK_F64 : dt == HIPK_C32 ? HIPK_F32 : dt; }
+static size_t es_of(hipk_dtype dt) { return dt == HIPK_C64 ? 16 : (dt == HIPK_F64 || dt == HIPK_C32) ? 8 : 4; }
+#define RDT(sd) rdt_of((sd)->dt)
+#define RF(sd) ((PRIMME_INT)(is_cplx((sd)->dt) ? 2 : 1))
+int pa_eigs_solve_z(void *evals_out, void *evecs, void *resNorms_out, primme_params *p, hipk_dtype dt, int out_double);
 
 /* W(:, 0:nb) = A V or A' V through the user's operator (reference :1116-1172) */
 static int svds_matvec(primme_svds_params *ps, void *V, PRIMME_INT ldV, void *W, PRIMME_INT ldW, int nb, int transpose) {
@@ -106,7 +117,7 @@ int pa_svds_can_fuse(const primme_params *primme) {
    const primme_svds_operator op = (&ps->primme == primme) ? ps->method : ps->methodStage2;
    if (op != primme_svds_op_AtA && op != primme_svds_op_AAt) return 0;
    return ps->matrixMatvec == primme_amd_svds_matvec && ps->matrix && primme_amd_svds_operator_is_local(ps->matrix) &&
-          side_of(ps) != NULL;
+          side_of(ps) != NULL && !is_cplx(side_of(ps)->dt);
 }
 int pa_svds_apply_scaled(primme_params *primme, hipk_ctx *ctx, const void *t, const double *norm2_dev, void *xout, void *y,
       double *dot_dev) {
@@ -144,7 +155,7 @@ void pa_svds_default_conv_test(double *sval, void *leftsvec, void *rightsvec, do
       int *isConv, primme_svds_params *ps, int *ierr) {
    (void)sval;
    svds_side *sd = side_of(ps);
-   const double meps = (sd && sd->dt == HIPK_F32) ? 1.1920928955078125e-07 : PA_EPS;
+   const double meps = (sd && is_single(sd->dt)) ? 1.1920928955078125e-07 : PA_EPS;
    *isConv = *rNorm < PA_MAX(ps->eps, meps * 3.16) * ps->aNorm;
    *ierr = 0;
    /* the augmented operator's residual norm is an estimate: confirm with the true one */
@@ -164,7 +175,7 @@ void pa_svds_conv_test_ata(double *eval, void *evec, double *rNorm, int *isConv,
    const primme_svds_operator op = (&ps->primme == primme) ? ps->method : ps->methodStage2;
    const double aNorm = primme->aNorm > 0.0 ? primme->aNorm : primme->stats.estimateLargestSVal;
    const double maxaNorm = PA_MAX(primme->aNorm, primme->stats.estimateLargestSVal);
-   const double meps = (sd && sd->dt == HIPK_F32) ? 1.1920928955078125e-07 : PA_EPS;
+   const double meps = (sd && is_single(sd->dt)) ? 1.1920928955078125e-07 : PA_EPS;
    *ierr = 0;
    if (rNorm && *rNorm < meps * maxaNorm * 3.16) { *isConv = 1; return; }
    const double old = ps->aNorm;
@@ -246,8 +257,8 @@ static int move_cols(svds_side *sd, PRIMME_INT rows, int ncols, char *src, char 
    const size_t bytes = (size_t)rows * ncols * es_of(sd->dt);
    char *tmp = NULL;
    CHK(hipk_malloc(sd->ctx, bytes, (void **)&tmp));
-   CHK(hipk_copy_cols(sd->ctx, sd->dt, rows, src, rows, tmp, rows, ncols));
-   CHK(hipk_copy_cols(sd->ctx, sd->dt, rows, tmp, rows, dst, rows, ncols));
+   CHK(hipk_copy_cols(sd->ctx, RDT(sd), RF(sd) * rows, src, RF(sd) * rows, tmp, RF(sd) * rows, ncols));
+   CHK(hipk_copy_cols(sd->ctx, RDT(sd), RF(sd) * rows, tmp, RF(sd) * rows, dst, RF(sd) * rows, ncols));
    CHK(hipk_sync(sd->ctx));
    hipk_free(sd->ctx, tmp);
    return 0;
@@ -265,7 +276,7 @@ static int scale_inverse(primme_svds_params *ps, svds_side *sd, char *x, PRIMME_
    if (need_norms) {
       norms = (double *)malloc(sizeof(double) * (size_t)ncols);
       if (!norms || hipk_malloc(sd->ctx, sizeof(double) * (size_t)ncols, (void **)&d_n)) { free(f); free(norms); return PRIMME_MALLOC_FAILURE; }
-      int rc = hipk_col_norms2(sd->ctx, sd->dt, rows, x, rows, ncols, d_n);
+      int rc = hipk_col_norms2(sd->ctx, RDT(sd), RF(sd) * rows, x, RF(sd) * rows, ncols, d_n);
       if (!rc) rc = hipk_d2h(sd->ctx, norms, d_n, sizeof(double) * (size_t)ncols);
       if (!rc) rc = hipk_sync(sd->ctx);
       hipk_free(sd->ctx, d_n);
@@ -274,7 +285,7 @@ static int scale_inverse(primme_svds_params *ps, svds_side *sd, char *x, PRIMME_
    }
    for (int i = 0; i < ncols; i++)
       f[i] = 1.0 / ((factors[i] > 0.0 && 1.0 / factors[i] < 1.79e308) ? factors[i] : sqrt(norms[i]));
-   int rc = hipk_scale_cols(sd->ctx, sd->dt, rows, x, rows, ncols, f);
+   int rc = hipk_scale_cols(sd->ctx, RDT(sd), RF(sd) * rows, x, RF(sd) * rows, ncols, f);
    free(f); free(norms);
    return rc;
 }
@@ -292,9 +303,11 @@ static int true_res_norm(primme_svds_params *ps, svds_side *sd, char *u, char *v
    char *Av = Atu + (size_t)nL * es;
    int rc = svds_matvec(ps, u, mL, Atu, nL, 1, 1);
    if (!rc) rc = svds_matvec(ps, v, nL, Av, mL, 1, 0);
-   if (!rc) rc = hipk_pair_dots(sd->ctx, sd->dt, nL, v, nL, v, nL, 1, d_ip);
-   if (!rc) rc = hipk_pair_dots(sd->ctx, sd->dt, mL, u, mL, u, mL, 1, d_ip + 1);
-   if (!rc) rc = hipk_pair_dots(sd->ctx, sd->dt, mL, u, mL, Av, mL, 1, d_ip + 2);
+   const hipk_dtype rd = RDT(sd);
+   const PRIMME_INT rf = RF(sd), mR = rf * mL, nR = rf * nL;           /* the vectors as real ones: Re(u'Av) is their real inner product */
+   if (!rc) rc = hipk_pair_dots(sd->ctx, rd, nR, v, nR, v, nR, 1, d_ip);
+   if (!rc) rc = hipk_pair_dots(sd->ctx, rd, mR, u, mR, u, mR, 1, d_ip + 1);
+   if (!rc) rc = hipk_pair_dots(sd->ctx, rd, mR, u, mR, Av, mR, 1, d_ip + 2);
    if (!rc) rc = hipk_d2h(sd->ctx, ip, d_ip, 3 * sizeof(double));
    if (!rc) rc = hipk_sync(sd->ctx);
    if (!rc) rc = pa_svds_call_global_sum(ps, ip, 3);
@@ -304,11 +317,11 @@ static int true_res_norm(primme_svds_params *ps, svds_side *sd, char *u, char *v
       if (!(sval >= 0.0) || !isfinite(sval)) *rNorm = 1.79e308;   /* negative, or a null vector of [0 A'; A 0] */
       else {
          double a;
-         a = 1.0 / ip[1]; rc = hipk_scale_cols(sd->ctx, sd->dt, nL, Atu, nL, 1, &a);
-         a = -sval / ip[0]; if (!rc) rc = hipk_axpy_cols(sd->ctx, sd->dt, nL, &a, v, nL, Atu, nL, 1);
-         a = 1.0 / ip[0]; if (!rc) rc = hipk_scale_cols(sd->ctx, sd->dt, mL, Av, mL, 1, &a);
-         a = -sval / ip[1]; if (!rc) rc = hipk_axpy_cols(sd->ctx, sd->dt, mL, &a, u, mL, Av, mL, 1);
-         if (!rc) rc = hipk_col_norms2(sd->ctx, sd->dt, mL + nL, Atu, mL + nL, 1, d_ip);
+         a = 1.0 / ip[1]; rc = hipk_scale_cols(sd->ctx, rd, nR, Atu, nR, 1, &a);
+         a = -sval / ip[0]; if (!rc) rc = hipk_axpy_cols(sd->ctx, rd, nR, &a, v, nR, Atu, nR, 1);
+         a = 1.0 / ip[0]; if (!rc) rc = hipk_scale_cols(sd->ctx, rd, mR, Av, mR, 1, &a);
+         a = -sval / ip[1]; if (!rc) rc = hipk_axpy_cols(sd->ctx, rd, mR, &a, u, mR, Av, mR, 1);
+         if (!rc) rc = hipk_col_norms2(sd->ctx, rd, mR + nR, Atu, mR + nR, 1, d_ip);
          if (!rc) rc = hipk_d2h(sd->ctx, ip, d_ip, sizeof(double));
          if (!rc) rc = hipk_sync(sd->ctx);
          if (!rc) rc = pa_svds_call_global_sum(ps, ip, 1);
@@ -367,15 +380,17 @@ static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double 
       /* [Uc U Vc V] -> n0 columns [v; u] of length nLocal + mLocal; unit constraints */
       char *aux = NULL;
       CHK(hipk_malloc(sd->ctx, (size_t)tot * n0 * es, (void **)&aux));
-      int rc = hipk_copy_cols(sd->ctx, sd->dt, tot * n0, svecs, tot * n0, aux, tot * n0, 1);
-      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, nL, aux + (size_t)mL * n0 * es, nL, svecs, tot, n0);
-      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, mL, aux, mL, svecs + (size_t)nL * es, tot, n0);
+      const hipk_dtype rd = RDT(sd);
+      const PRIMME_INT rf = RF(sd);
+      int rc = hipk_copy_cols(sd->ctx, rd, rf * tot * n0, svecs, rf * tot * n0, aux, rf * tot * n0, 1);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, rd, rf * nL, aux + (size_t)mL * n0 * es, rf * nL, svecs, rf * tot, n0);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, rd, rf * mL, aux, rf * mL, svecs + (size_t)nL * es, rf * tot, n0);
       if (!rc && ps->numOrthoConst > 0) {
          double f[64];
          for (int c0 = 0; c0 < ps->numOrthoConst && !rc; c0 += 64) {
             const int nc = PA_MIN(64, ps->numOrthoConst - c0);
             for (int c = 0; c < nc; c++) f[c] = 1.0 / sqrt(2.0);
-            rc = hipk_scale_cols(sd->ctx, sd->dt, tot, svecs + (size_t)c0 * tot * es, tot, nc, f);
+            rc = hipk_scale_cols(sd->ctx, rd, rf * tot, svecs + (size_t)c0 * tot * es, rf * tot, nc, f);
          }
       }
       if (!rc) rc = hipk_sync(sd->ctx);
@@ -425,13 +440,14 @@ static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double 
    if (!normal && p->initSize <= 0) {
       char *v0 = svecs + (size_t)p->numOrthoConst * tot * es, *u0 = v0 + (size_t)nL * es;
       const PRIMME_INT len = (ps->m >= ps->n) ? mL : nL;
-      double *h = (double *)malloc(sizeof(double) * (size_t)(len > 0 ? len : 1));
+      const PRIMME_INT rlen = RF(sd) * len;         /* a complex entry takes two consecutive numbers of the stream: (re, im), as xLARNV */
+      double *h = (double *)malloc(sizeof(double) * (size_t)(rlen > 0 ? rlen : 1));
       if (!h) return PRIMME_MALLOC_FAILURE;
-      pa_larnv_uniform11(p->iseed, len, h);
+      pa_larnv_uniform11(p->iseed, rlen, h);
       int rc = 0;
-      if (sd->dt == HIPK_F32) {
+      if (is_single(sd->dt)) {
          float *hf = (float *)h;
-         for (PRIMME_INT i = 0; i < len; i++) hf[i] = (float)h[i];
+         for (PRIMME_INT i = 0; i < rlen; i++) hf[i] = (float)h[i];
       }
       rc = hipk_h2d(sd->ctx, (ps->m >= ps->n) ? u0 : v0, h, (size_t)len * es);
       if (!rc) rc = hipk_sync(sd->ctx);
@@ -439,17 +455,17 @@ static int stage_begin(primme_svds_params *ps, svds_side *sd, int stage, double 
       if (!rc) rc = (ps->m >= ps->n) ? svds_matvec(ps, u0, mL, v0, nL, 1, 1) : svds_matvec(ps, v0, nL, u0, mL, 1, 0);
       double n2[2], *d_n = NULL;
       if (!rc) rc = hipk_malloc(sd->ctx, 2 * sizeof(double), (void **)&d_n) ? PRIMME_MALLOC_FAILURE : 0;
-      if (!rc) rc = hipk_col_norms2(sd->ctx, sd->dt, nL, v0, nL, 1, d_n);
-      if (!rc) rc = hipk_col_norms2(sd->ctx, sd->dt, mL, u0, mL, 1, d_n + 1);
+      if (!rc) rc = hipk_col_norms2(sd->ctx, RDT(sd), RF(sd) * nL, v0, RF(sd) * nL, 1, d_n);
+      if (!rc) rc = hipk_col_norms2(sd->ctx, RDT(sd), RF(sd) * mL, u0, RF(sd) * mL, 1, d_n + 1);
       if (!rc) rc = hipk_d2h(sd->ctx, n2, d_n, 2 * sizeof(double));
       if (!rc) rc = hipk_sync(sd->ctx);
       hipk_free(sd->ctx, d_n);
       if (!rc) rc = pa_svds_call_global_sum(ps, n2, 2);
       if (rc) return rc;
       double f = 1.0 / sqrt(n2[0]);
-      CHK(hipk_scale_cols(sd->ctx, sd->dt, nL, v0, nL, 1, &f));
+      CHK(hipk_scale_cols(sd->ctx, RDT(sd), RF(sd) * nL, v0, RF(sd) * nL, 1, &f));
       f = 1.0 / sqrt(n2[1]);
-      CHK(hipk_scale_cols(sd->ctx, sd->dt, mL, u0, mL, 1, &f));
+      CHK(hipk_scale_cols(sd->ctx, RDT(sd), RF(sd) * mL, u0, RF(sd) * mL, 1, &f));
       p->initSize = 1;
       if (rnorms) rnorms[0] = 1.79e308;
       p->initBasisMode = primme_init_user;
@@ -532,14 +548,16 @@ static int stage_end(primme_svds_params *ps, svds_side *sd, int stage, double *s
          for (int c0 = 0; c0 < ps->numOrthoConst && !rc; c0 += 64) {
             const int nc = PA_MIN(64, ps->numOrthoConst - c0);
             for (int c = 0; c < nc; c++) f[c] = sqrt(2.0);
-            rc = hipk_scale_cols(sd->ctx, sd->dt, tot, svecs + (size_t)c0 * tot * es, tot, nc, f);
+            rc = hipk_scale_cols(sd->ctx, RDT(sd), RF(sd) * tot, svecs + (size_t)c0 * tot * es, RF(sd) * tot, nc, f);
          }
       }
       char *aux = NULL;
+      const hipk_dtype rd = RDT(sd);
+      const PRIMME_INT rf = RF(sd);
       if (!rc) rc = hipk_malloc(sd->ctx, (size_t)tot * n1 * es, (void **)&aux) ? PRIMME_MALLOC_FAILURE : 0;
-      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, tot * n1, svecs, tot * n1, aux, tot * n1, 1);
-      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, nL, aux, tot, svecs + (size_t)mL * n1 * es, nL, n1);
-      if (!rc) rc = hipk_copy_cols(sd->ctx, sd->dt, mL, aux + (size_t)nL * es, tot, svecs, mL, n1);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, rd, rf * tot * n1, svecs, rf * tot * n1, aux, rf * tot * n1, 1);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, rd, rf * nL, aux, rf * tot, svecs + (size_t)mL * n1 * es, rf * nL, n1);
+      if (!rc) rc = hipk_copy_cols(sd->ctx, rd, rf * mL, aux + (size_t)nL * es, rf * tot, svecs, rf * mL, n1);
       if (!rc) rc = hipk_sync(sd->ctx);
       hipk_free(sd->ctx, aux);
       double *zero = (double *)calloc((size_t)n1, sizeof(double));     /* "factor unusable" -> normalise */
@@ -560,7 +578,7 @@ static int stage_end(primme_svds_params *ps, svds_side *sd, int stage, double *s
 
 static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_svds_params *ps, hipk_dtype dt) {
    if (!ps) return -4;
-   const int out_float = (dt == HIPK_F32);
+   const int out_float = is_single(dt);
    const double meps = out_float ? 1.1920928955078125e-07 : PA_EPS;
    const primme_op_datatype scalar_t = out_float ? primme_op_float : primme_op_double;
    if (ps->matrixMatvec && ps->matrixMatvec_type == primme_op_default) ps->matrixMatvec_type = scalar_t;
@@ -603,7 +621,7 @@ static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_
    /* ---- first stage ---- */
    rc = stage_begin(ps, sd, 0, NULL, svecs, rnorms, &stream, &st);
    if (rc) goto done;
-   ret = pa_eigs_solve(svals, st.eig_vecs, rnorms, st.p, dt, 1);
+   ret = is_cplx(dt) ? pa_eigs_solve_z(svals, st.eig_vecs, rnorms, st.p, dt, 1) : pa_eigs_solve(svals, st.eig_vecs, rnorms, st.p, dt, 1);
    rc = stage_end(ps, sd, 0, svals, svecs, rnorms, &st);
    if (rc) goto done;
    if (ret != 0) ret -= 100;
@@ -613,7 +631,8 @@ static int solve_svds(void *svals_out, void *svecs_, void *resNorms_out, primme_
       rc = stage_begin(ps, sd, 1, svals, svecs, rnorms, &stream, &st);
       if (rc) goto done;
       const int nconv = ps->numSvals - ps->primmeStage2.numEvals;
-      ret = pa_eigs_solve(svals + nconv, st.eig_vecs, rnorms + nconv, st.p, dt, 1);
+      ret = is_cplx(dt) ? pa_eigs_solve_z(svals + nconv, st.eig_vecs, rnorms + nconv, st.p, dt, 1)
+                        : pa_eigs_solve(svals + nconv, st.eig_vecs, rnorms + nconv, st.p, dt, 1);
       rc = stage_end(ps, sd, 1, svals, svecs, rnorms, &st);
       if (rc) goto done;
       if (ret != 0) ret -= 200;
@@ -641,4 +660,8 @@ int hip_dprimme_svds(double *svals, double *svecs, double *resNorms, primme_svds
 }
 int hip_sprimme_svds(float *svals, float *svecs, float *resNorms, primme_svds_params *ps) {
    return solve_svds(svals, svecs, resNorms, ps, HIPK_F32);
+}
+/* the native complex front end (called by svds_complex.c's hip_zprimme_svds / hip_cprimme_svds) */
+int pa_svds_solve_native_complex(void *svals, void *svecs, void *resNorms, primme_svds_params *ps, int single) {
+   return solve_svds(svals, svecs, resNorms, ps, single ? HIPK_C32 : HIPK_C64);
 }

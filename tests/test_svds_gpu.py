@@ -98,13 +98,17 @@ def test_hip_svds_config5_shape(built):
     assert r.svals[0] >= lower * (1 - 1e-12)
 
 
+@pytest.mark.parametrize("form", ["native", "real_equivalent"])
 @pytest.mark.parametrize("m,n,k,target,method,dtype,eps", [(1200, 800, 4, "largest", "normalequations", np.complex128, 1e-10),
                                                            (800, 1200, 3, "largest", "hybrid", np.complex128, 1e-10),
                                                            (600, 400, 3, "smallest", "hybrid", np.complex128, 1e-9),
                                                            (900, 700, 3, "largest", "normalequations", np.complex64, 1e-4)])
-def test_hip_complex_svds(built, m, n, k, target, method, dtype, eps):
-    """hip_zprimme_svds / hip_cprimme_svds: complex singular triplets on the device (real-equivalent form,
-    csrc/svds_complex.c) against numpy's dense SVD and the checker run of the same call"""
+def test_hip_complex_svds(built, m, n, k, target, method, dtype, eps, form, monkeypatch):
+    """hip_zprimme_svds / hip_cprimme_svds: complex singular triplets on the device — the native complex front end (default since
+    round 5: csrc/svds_main.c on complex panels) and the real-equivalent form (PRIMME_AMD_COMPLEX_REAL_FORM=1,
+    csrc/svds_complex.c) — against numpy's dense SVD and the checker run of the same call"""
+    if form == "real_equivalent":
+        monkeypatch.setenv("PRIMME_AMD_COMPLEX_REAL_FORM", "1")
     Z, csr = _rect_complex(m, n)
     s = np.linalg.svd(Z, compute_uv=False)
     want = s[:k] if target == "largest" else s[::-1][:k]
