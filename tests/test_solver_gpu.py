@@ -112,7 +112,9 @@ def test_most_fixtures_reproduce_the_reference_history(built):
     # counts exactly, and then its residual norms to 1e-10 |A| (1e-4 |A| in single precision) — every extremal-target
     # fixture (GD, GD+k, Olsen, LOBPCG-like, JDQMR at block size 1, blocks of 2 / 4 / 8 of the Davidson family, locking and
     # soft locking, both precisions).  The other 18 are the ones the tolerances above exist for: interior targets, harmonic /
-    # refined extraction, block JDQMR, the wall-clock-driven dynamic method.
+    # refined extraction, block JDQMR, the wall-clock-driven dynamic method.  (lap3d_gdk sits on an edge: 465 iterations in the
+    # reference, 464 or 465 here depending on the order in which the fused product sums t'At — with the row-pattern kernel in pairs
+    # of rows it is 464: the two misses the assertion allows are for such cases.)
     known_exact = {"blk1_explicit", "blk2_implicit", "blk2_jacobi", "blk2_lock", "blk2_soft", "blk4_largest", "blk4_lock", "blk8_K40", "float_bs1",
                    "float_bs2", "jdqmr_bs1", "jdqmr_etol_bs1", "jdqmr_etol_jacobi", "jdqmr_etol_largest_3d", "jdqmr_float", "jdqmr_jacobi",
                    "jdqmr_largest_3d", "jdqmr_soft", "lap1d_ex_dseq", "lap2d_gd", "lap2d_gd_olsen", "lap2d_gdk_lock", "lap2d_gdk_soft",
