@@ -280,6 +280,21 @@ int hipk_qmr_update_dir(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const d
       const double *beta_host, void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G,
       int64_t ldG, const void *diag, const double *shift_host, double min_denominator, double *dotsol_dev);
 
+/* The block-QMR step with ONE host synchronisation (csrc/eigs_jd.c): the two launches above with the step's scalar recurrences
+ * (inner_solve.c:376-409: alpha = rho_prev / sigma, Theta, c, gamma, eta, beta) evaluated ON THE DEVICE, in the prologue of the
+ * launch that applies them, from reduction results still in HBM — tri_dev = [x'w | v'w | v'x] (hipk_triple_dots), ggr_dev =
+ * [g'g | g'K^-1 g] (the first of the two) — and the previous step's rho, tau, Theta passed by value.  The host evaluates the same
+ * expressions on the mirrored results after its one wait (same roundings: no contraction on either side).  A column whose alpha
+ * is unusable (sigma = 0 or not finite, |alpha| outside [eps, 1/eps]) gets alpha = 0 and is left alone by the second launch,
+ * as the host drops it from the block.  nx <= 8. */
+int hipk_axpy_proj_dot_jacobi_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *tri_dev, const double *rho_prev_host,
+      double mach_eps, const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, const void *diag,
+      const double *shift_host, double min_denominator, double *out_dev);
+int hipk_qmr_update_dir_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *tri_dev, const double *ggr_dev,
+      const double *rho_prev_host, const double *tau_prev_host, const double *theta_prev_host, double mach_eps, void *D, int64_t ldD,
+      void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G, int64_t ldG, const void *diag, const double *shift_host,
+      double min_denominator, double *dotsol_dev);
+
 /* ---- sparse operator: the user matvec ------------------------------------------
  * Replaces the hipsparseSpMM-based callback of examples/ex_eigs_dhipblas.c:239-264
  * and the SPARSKIT amux of tests/COMMON/mat.c:64-90.

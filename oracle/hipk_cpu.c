@@ -653,6 +653,62 @@ int hipk_csr_matvec_shifted(hipk_csr *A, void *stream, const void *x, int64_t ld
          st_(A->dt, (void *)colp(A->dt, y, ldy, c), i, ld_(A->dt, colp(A->dt, y, ldy, c), i) - shift[c] * ld_(A->dt, colp(A->dt, x, ldx, c), i));
    return rc;
 }
+/* The scalar recurrences of one block-QMR step (csrc/hipk_panels.hip: qmr_alpha_dev / qmr_coeffs_dev; csrc/eigs_jd.c evaluates the
+ * same expressions on the host).  ISO C: every operation rounded on its own. */
+static void qmr_alpha_cpu(const double *tri, int nx, int col, double rho_prev, double eps, double *alpha, double *xr) {
+   *xr = tri[col];
+   const double t = *xr * tri[2 * nx + col];
+   const double sigma = tri[nx + col] - t;
+   int bad = !isfinite(sigma) || sigma == 0.0;
+   double a = 0.0;
+   if (!bad) {
+      a = rho_prev / sigma;
+      bad = !isfinite(a) || fabs(a) < eps || fabs(a) > 1.0 / eps;
+   }
+   *alpha = bad ? 0.0 : a;
+}
+int hipk_axpy_proj_dot_jacobi_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *tri_dev, const double *rho_prev_host,
+      double mach_eps, const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, const void *diag, const double *shift_host,
+      double min_den, double *out_dev) {
+   if (nx <= 0) return 0;
+   if (nx > 8 || !tri_dev) return -1;
+   double al[8], xr[8];
+   for (int c = 0; c < nx; c++) qmr_alpha_cpu(tri_dev, nx, c, rho_prev_host[c], mach_eps, &al[c], &xr[c]);
+   return hipk_axpy_proj_dot_jacobi(ctx, dt, m, nx, al, xr, W, ldW, X, ldX, G, ldG, diag, shift_host, min_den, out_dev);
+}
+int hipk_qmr_update_dir_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *tri_dev, const double *ggr_dev,
+      const double *rho_prev_host, const double *tau_prev_host, const double *theta_prev_host, double mach_eps, void *D, int64_t ldD,
+      void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G, int64_t ldG, const void *diag, const double *shift_host,
+      double min_den, double *dotsol_dev) {
+   if (nx <= 0) return 0;
+   if (nx > 8 || !tri_dev || !ggr_dev) return -1;
+   double out[8];
+   for (int c = 0; c < nx; c++) {
+      double a, xr;
+      qmr_alpha_cpu(tri_dev, nx, c, rho_prev_host[c], mach_eps, &a, &xr);
+      out[c] = 0.0;
+      if (a == 0.0) continue;                   /* the column leaves the block at this step: left alone */
+      const double theta = sqrt(ggr_dev[c]) / tau_prev_host[c];
+      const double t2 = theta * theta;
+      const double cs = 1.0 / sqrt(1 + t2);
+      const double cc = cs * cs;
+      const double g1 = cc * theta_prev_host[c];
+      const double gam = g1 * theta_prev_host[c];
+      const double e1 = a * cs;
+      const double eta = e1 * cs;
+      const double bet = ggr_dev[nx + c] / rho_prev_host[c];
+      const double sh = shift_host ? shift_host[c] : 0.0;
+      double o1 = 0.0;
+      int rc = hipk_qmr_update_dir(ctx, dt, m, 1, &gam, &eta, &bet, (void *)colp(dt, D, ldD, c), ldD, (void *)colp(dt, Delta, ldDelta, c), ldDelta,
+            (void *)colp(dt, Sol, ldSol, c), ldSol, colp(dt, G, ldG, c), ldG, diag, &sh, min_den, &o1);
+      if (rc) return rc;
+      out[c] = o1;
+   }
+   for (int c = 0; c < nx; c++) dotsol_dev[c] = out[c];
+   mirror(dotsol_dev, (size_t)nx);
+   return 0;
+}
+
 int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *gam, const double *eta,
       const void *D, int64_t ldD, void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G, int64_t ldG,
       const void *diag, const double *shift, double min_den, void *W, int64_t ldW, double *out) {

@@ -223,6 +223,9 @@ def declare_kernels(lib):
         "hipk_csr_matvec_shifted": [_vp, _vp, _vp, _i64, _vp, _i64, _i, _dp],
         "hipk_axpy_proj_dot_jacobi": [_vp, _i, _i64, _i, _dp, _dp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _dp, C.c_double, _vp],
         "hipk_qmr_update_dir": [_vp, _i, _i64, _i, _dp, _dp, _dp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _dp, C.c_double, _vp],
+        "hipk_axpy_proj_dot_jacobi_dev": [_vp, _i, _i64, _i, _vp, _dp, C.c_double, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _dp, C.c_double, _vp],
+        "hipk_qmr_update_dir_dev": [_vp, _i, _i64, _i, _vp, _vp, _dp, _dp, _dp, C.c_double, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _dp,
+                                    C.c_double, _vp],
         "hipk_qmr_update_jacobi": [_vp, _i, _i64, _i, _dp, _dp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _dp, C.c_double, _vp, _i64, _vp],
         "hipk_csr_matvec_scaled": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
         "hipk_panel_project_mul": [_vp, _i, _i64, P(HipkSeg), _i, _vp, _i, _vp, _vp, _i64, _i],

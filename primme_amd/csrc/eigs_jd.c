@@ -231,8 +231,10 @@ static int skew_project_Q(pa_solver *s, const jd_proj *P, char *v, int64_t ldv, 
 /* xr_out != NULL (blocks): the projection against x is NOT applied to `result`; xr_out[c] = x_c' result_c and
  * vdot[c] = v'(I - x x') result = v'result - (x'result)(v'x) come from one pass of three inner products
  * (hipk_triple_dots), and the caller folds the projection into its update of g (hipk_axpy_proj_dot). */
+/* nowait (with xr_out): the three inner products stay in HBM (s->d_red[0 .. 3 nb), mirrored), nothing is waited for and
+ * vdot / xr_out are NOT set: the launches of the one-synchronisation step read them on the device (inner_solve) */
 static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const double *shift, const jd_proj *P,
-      int nb, char *result, int64_t ldres, double *vdot, double *xr_out) {
+      int nb, char *result, int64_t ldres, double *vdot, double *xr_out, int nowait) {
    /* result = A v - shift v: in ONE launch when the operator is the library's own CSR matrix (the shift is
     * applied in the SpMM epilogue), otherwise the callback followed by an axpy */
    int shifted = 0;
@@ -275,6 +277,12 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
          if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
          if (P->nLQ > 0) CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
          CHK(hipk_triple_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, v, ldv, result, ldres, nb, s->d_red));
+         if (nowait) {
+            CHK(pa_reduce(s, s->d_red, 3 * nb, 1, 1));
+            s->p->stats.numOrthoInnerProds += 3 * nb;
+            s->p->stats.timeOrtho += pa_wtime() - t0;
+            return 0;
+         }
          CHK(pa_reduce(s, s->d_red, 3 * nb, 0, 0));
          for (int i = 0; i < nb; i++) {
             xr_out[i] = s->h_red[i];
@@ -408,7 +416,46 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
        * synchronisation fewer per step); block size 1 keeps the reference's operation order */
       const int fold_x = (!PA_IS_COMPLEX && b0 > 1 && P->nLX > 0);
       double xr[64];
-      CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld, tmp, fold_x ? xr : NULL));
+      /* ONE host synchronisation per step (round 5): with the library's Jacobi preconditioner and the folded x-projection the
+       * step is three launches — (A - shift) d with its three inner products, the update of g (+ g'g, g'K^-1 g), the QMR
+       * update that also writes the next direction (+ |sol|^2) — whose coefficients alpha, gamma, eta, beta are functions of the
+       * reductions of the launches before them and of the previous step's rho, tau, Theta.  They are evaluated ON THE DEVICE,
+       * in the prologue of the launch that applies them (hipk_axpy_proj_dot_jacobi_dev, hipk_qmr_update_dir_dev), the host
+       * enqueues all three, waits ONCE and then evaluates the same expressions on the mirrored reductions (the code below,
+       * unchanged) for its own bookkeeping: the stopping tests, the columns that leave the block, the next step's state.
+       * Same roundings on both sides (hipk_panels.hip: qmr_alpha_dev), so the history is the three-wait sequence's, bit for bit.
+       * PRIMME_AMD_QMR_THREE_WAITS=1 keeps that sequence (A/B knob).  Needs reductions that stay on the device. */
+      const int three_waits = getenv("PRIMME_AMD_QMR_THREE_WAITS") != NULL;      /* (read per step: tests switch it within a process) */
+      const int onewait = !three_waits && early_rho && fold_x && numIts + 1 < maxIterations && blockSize <= 8 &&
+                          !(s->parallel && !s->dev_comm) && 3 * 64 + 3 * 8 < s->red_cap;
+      double gg_all[8], rho_all[8], dot_all[8];
+      if (onewait) {
+#if !PA_IS_COMPLEX
+         double rp[8], tp[8], thp[8], jsh[8];
+         double *d_tri = s->d_red, *d_ggr = s->d_red + 3 * 64, *d_dot = s->d_red + 3 * 64 + 16;
+         for (i = 0; i < blockSize; i++) {
+            const int q = pm[i];
+            rp[i] = rho_prev[q]; tp[i] = tau_prev[q]; thp[i] = Theta_prev[q];
+            jsh[i] = jac_fixed ? jac_shift : (p->ShiftsForPreconditioner ? p->ShiftsForPreconditioner[i] : 0.0);
+         }
+         const double md = 1e-14 * (p->aNorm >= 0.0 ? p->aNorm : 1.0);
+         CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld, tmp, xr, 1));
+         CHK(hipk_axpy_proj_dot_jacobi_dev(s->ctx, s->dt, s->m, blockSize, d_tri, rp, s->mach_eps, w, ld, P->LX, P->ldLX, g, ld, jac_diag, jsh, md, d_ggr));
+         CHK(pa_reduce(s, d_ggr, 2 * blockSize, 1, 1));
+         double t0 = pa_wtime();
+         CHK(hipk_qmr_update_dir_dev(s->ctx, s->dt, s->m, blockSize, d_tri, d_ggr, rp, tp, thp, s->mach_eps, d, ld, delta, ld, sol, ld, g, ld,
+               jac_diag, jsh, md, d_dot));
+         CHK(pa_reduce(s, d_dot, blockSize, 0, 0));                    /* the one synchronisation of the step */
+         p->stats.timePrecond += pa_wtime() - t0;
+         const double *h3 = s->h_red, *hg = s->h_red + 3 * 64, *hd = s->h_red + 3 * 64 + 16;
+         for (i = 0; i < blockSize; i++) {
+            xr[i] = h3[i];
+            tmp[i] = h3[blockSize + i] - h3[i] * h3[2 * blockSize + i];
+            gg_all[i] = hg[i]; rho_all[i] = hg[blockSize + i]; dot_all[i] = hd[i];
+         }
+#endif
+      } else
+      CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld, tmp, fold_x ? xr : NULL, 0));
       for (i = 0; i < blockSize; i++) sigma_prev[pm[i]] = tmp[i];
 
       int conv = 0;
@@ -430,7 +477,10 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
       }
       /* g -= alpha w (0 for dropped columns) and g'g in the same pass */
       const int early = early_rho && fold_x && numIts + 1 < maxIterations;
-      if (early) {
+      if (onewait) {
+         /* the update of g ran on the device with the same alpha (0 for the columns dropped above) */
+         for (i = 0; i < blockSize; i++) { gg[i] = gg_all[i]; rho_new[i] = rho_all[i]; }
+      } else if (early) {
          double al[64], jsh[64];
          for (i = 0; i < blockSize; i++) {
             al[i] = -malpha[i];
@@ -471,6 +521,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          if (P->nRX) P->nRX -= conv;                                                               \
       } while (0)
       if (early && conv > 0) pa_permute_reals(rho_new, 1, blockSize, 1, p0);
+      if (onewait && conv > 0) pa_permute_reals(dot_all, 1, blockSize, 1, p0);
       SHRINK();
       if (blockSize <= 0) break;
 
@@ -486,7 +537,13 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
       }
       /* delta = gamma delta + eta d; sol += delta; |sol|^2 */
       int have_w = 0, have_d = 0;
-      if (early) {
+      if (onewait) {
+         /* the QMR update and the next direction ran on the device with the same gamma, eta, beta (evaluated there from the
+          * same reductions); the columns dropped above were left alone */
+         for (i = 0; i < blockSize; i++) dot_sol[i] = dot_all[i];
+         p->stats.numPreconds += blockSize;
+         have_d = 1;
+      } else if (early) {
          /* rho of the next step is known: the update writes the next direction straight into d */
          double jsh[64], beta_c[64];
          for (i = 0; i < blockSize; i++) {

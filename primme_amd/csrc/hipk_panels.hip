@@ -1984,17 +1984,57 @@ axpy_proj_dot_kernel(ColScal alpha, ColScal xr, const T *__restrict__ Wv, int64_
  * beta = rho / rho_prev is known before the QMR update runs, and that pass can write the new direction
  * d = K^-1 g + beta d in place (qmr_update_dir_kernel) instead of storing w = K^-1 g and adding beta d in a further pass.
  * Rows outside, (up to 8) columns inside: the diagonal is read once per row. */
-template <typename T>
+/* ---- the scalar recurrences of one block-QMR step, evaluated ON THE DEVICE (eigs_jd.c: the step with one host synchronisation).
+ * The launches that apply a step's coefficients compute them in their prologue, every lane for itself, from the reduction
+ * results of the launches before them — still in HBM — and from the previous step's state, passed by value.  The host evaluates
+ * the same expressions on the mirrored results after its one wait; both sides round every operation separately (no
+ * contraction here, ISO C on the host), division and square root are correctly rounded on both: the same bits.
+ *   tri = [x'w | v'w | v'x] (hipk_triple_dots), ggr = [g'g | g'K^-1 g] (hipk_axpy_proj_dot_jacobi_dev) */
+struct QmrPrev { double rho_prev[8], tau_prev[8], theta_prev[8]; double eps; };
+__device__ __forceinline__ void qmr_alpha_dev(const double *__restrict__ tri, int nx, int col, double rho_prev, double eps, double &alpha, double &xr) {
+#pragma clang fp contract(off)
+   xr = tri[col];
+   const double t = xr * tri[2 * nx + col];
+   const double sigma = tri[nx + col] - t;
+   bool bad = !isfinite(sigma) || sigma == 0.0;
+   double a = 0.0;
+   if (!bad) {
+      a = rho_prev / sigma;
+      bad = !isfinite(a) || fabs(a) < eps || fabs(a) > 1.0 / eps;
+   }
+   alpha = bad ? 0.0 : a;                        /* 0: the column leaves the block at this step (the host sees the same) */
+}
+__device__ __forceinline__ void qmr_coeffs_dev(const double *__restrict__ ggr, int nx, int col, double alpha, double rho_prev, double tau_prev,
+      double theta_prev, double &gam, double &eta, double &bet) {
+#pragma clang fp contract(off)
+   const double theta = sqrt(ggr[col]) / tau_prev;
+   const double t2 = theta * theta;
+   const double c = 1.0 / sqrt(1 + t2);
+   const double cc = c * c;
+   const double g1 = cc * theta_prev;
+   gam = g1 * theta_prev;
+   const double e1 = alpha * c;
+   eta = e1 * c;
+   bet = ggr[nx + col] / rho_prev;
+}
+
+template <typename T, bool DEV>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 axpy_proj_dot_jacobi_kernel(ColScal alpha, ColScal xr, ColScal shf, double min_den, const T *__restrict__ Wv, int64_t ldW,
       const T *__restrict__ X, int64_t ldX, T *__restrict__ G, int64_t ldG, const T *__restrict__ diag, int nx, int c0, int64_t m,
-      double *__restrict__ partials) {
+      double *__restrict__ partials, const double *__restrict__ tri, QmrPrev pv) {
    constexpr int NXC = 8;
    __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][2 * NXC];
    const int nc = min(NXC, nx - c0);
-   double s1[NXC], s2[NXC];
+   double s1[NXC], s2[NXC], al[NXC], xq[NXC];
 #pragma unroll
-   for (int c = 0; c < NXC; c++) { s1[c] = 0.0; s2[c] = 0.0; }
+   for (int c = 0; c < NXC; c++) {
+      s1[c] = 0.0; s2[c] = 0.0; al[c] = 0.0; xq[c] = 0.0;
+      if (c < nc) {
+         if (DEV) qmr_alpha_dev(tri, nx, c0 + c, pv.rho_prev[c], pv.eps, al[c], xq[c]);
+         else { al[c] = alpha.a[c0 + c]; xq[c] = xr.a[c0 + c]; }
+      }
+   }
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
    for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
       const double dg = (double)diag[i];
@@ -2002,8 +2042,8 @@ axpy_proj_dot_jacobi_kernel(ColScal alpha, ColScal xr, ColScal shf, double min_d
       for (int c = 0; c < NXC; c++)
          if (c < nc) {
             const size_t cc = (size_t)(c0 + c);
-            const T wp = (T)fma(-xr.a[c0 + c], (double)X[i + cc * ldX], (double)Wv[i + cc * ldW]);   /* rounded like the stored projected w */
-            const T ng = (T)fma(-alpha.a[c0 + c], (double)wp, (double)G[i + cc * ldG]);
+            const T wp = (T)fma(-xq[c], (double)X[i + cc * ldX], (double)Wv[i + cc * ldW]);   /* rounded like the stored projected w */
+            const T ng = (T)fma(-al[c], (double)wp, (double)G[i + cc * ldG]);
             G[i + cc * ldG] = ng;
             s1[c] = fma((double)ng, (double)ng, s1[c]);
             double den = dg - shf.a[c0 + c];
@@ -2030,26 +2070,38 @@ axpy_proj_dot_jacobi_kernel(ColScal alpha, ColScal xr, ColScal shf, double min_d
 /* delta = gamma delta + eta d;  sol += delta;  out[c] = |sol(:,c)|^2;  d = g ./ (diag - shift[c]) + beta d (in place):
  * the QMR step and the next search direction in one pass over d, delta, sol, g (seven array passes per column; the
  * sequence qmr_update_jacobi + axpy it replaces makes eleven) */
-template <typename T>
+template <typename T, bool DEV>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 qmr_update_dir_kernel(ColScal gam, ColScal eta, ColScal bet, ColScal shf, double min_den, T *__restrict__ D, int64_t ldD,
       T *__restrict__ Delta, int64_t ldDelta, T *__restrict__ Sol, int64_t ldSol, const T *__restrict__ G, int64_t ldG,
-      const T *__restrict__ diag, int nx, int c0, int64_t m, double *__restrict__ partials) {
+      const T *__restrict__ diag, int nx, int c0, int64_t m, double *__restrict__ partials, const double *__restrict__ tri,
+      const double *__restrict__ ggr, QmrPrev pv) {
    constexpr int NXC = 8;
    __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][NXC];
    const int nc = min(NXC, nx - c0);
-   double s1[NXC];
+   double s1[NXC], ga[NXC], et[NXC], be[NXC];
+   bool live[NXC];                  /* DEV: a column whose alpha was unusable leaves the block before this update (its sol stays) */
 #pragma unroll
-   for (int c = 0; c < NXC; c++) s1[c] = 0.0;
+   for (int c = 0; c < NXC; c++) {
+      s1[c] = 0.0; ga[c] = 0.0; et[c] = 0.0; be[c] = 0.0; live[c] = c < nc;
+      if (c < nc) {
+         if (DEV) {
+            double a, x_;
+            qmr_alpha_dev(tri, nx, c0 + c, pv.rho_prev[c], pv.eps, a, x_);
+            live[c] = a != 0.0;
+            if (live[c]) qmr_coeffs_dev(ggr, nx, c0 + c, a, pv.rho_prev[c], pv.tau_prev[c], pv.theta_prev[c], ga[c], et[c], be[c]);
+         } else { ga[c] = gam.a[c0 + c]; et[c] = eta.a[c0 + c]; be[c] = bet.a[c0 + c]; }
+      }
+   }
    const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
    for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
       const double dg = (double)diag[i];
 #pragma unroll
       for (int c = 0; c < NXC; c++)
-         if (c < nc) {
+         if (live[c]) {
             const size_t cc = (size_t)(c0 + c);
             const double di = (double)D[i + cc * ldD];
-            const T nd = (T)fma((double)Delta[i + cc * ldDelta], gam.a[c0 + c], di * eta.a[c0 + c]);
+            const T nd = (T)fma((double)Delta[i + cc * ldDelta], ga[c], di * et[c]);
             Delta[i + cc * ldDelta] = nd;
             const T ns = (T)((double)nd + (double)Sol[i + cc * ldSol]);
             Sol[i + cc * ldSol] = ns;
@@ -2057,7 +2109,7 @@ qmr_update_dir_kernel(ColScal gam, ColScal eta, ColScal bet, ColScal shf, double
             double den = dg - shf.a[c0 + c];
             if (!(fabs(den) > min_den)) den = copysign(min_den, den);
             const T wi = (T)((double)G[i + cc * ldG] / den);
-            D[i + cc * ldD] = (T)fma(bet.a[c0 + c], di, (double)wi);    /* w += beta d, as the axpy pass rounds it */
+            D[i + cc * ldD] = (T)fma(be[c], di, (double)wi);    /* w += beta d, as the axpy pass rounds it */
          }
    }
    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2327,12 +2379,36 @@ extern "C" int hipk_axpy_proj_dot_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m
    for (int c = 0; c < nx; c++) { a.a[c] = alpha_host[c]; r.a[c] = xr_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
    if (hipk_reserve_partials(ctx, (size_t)gx * 2 * nx)) return -2;
+   QmrPrev pv;
+   memset(&pv, 0, sizeof(pv));
    for (int c0 = 0; c0 < nx; c0 += 8) {
       DISPATCH_RT(dt,
-            hipLaunchKernelGGL(axpy_proj_dot_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, a, r, sh, min_den, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials),
-            hipLaunchKernelGGL(axpy_proj_dot_jacobi_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, a, r, sh, min_den, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials));
+            hipLaunchKernelGGL((axpy_proj_dot_jacobi_kernel<T, false>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, a, r, sh, min_den, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials, (const double *)NULL, pv),
+            hipLaunchKernelGGL((axpy_proj_dot_jacobi_kernel<T, false>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, a, r, sh, min_den, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials, (const double *)NULL, pv));
       HIPK_CHECK(hipGetLastError());
    }
+   return hipk_finalize_partials(ctx, ctx->partials, gx, 2 * nx, out_dev);
+}
+/* the same with alpha_c = rho_prev_c / (v'w - (x'w)(v'x)) and xr_c = x'w taken from tri_dev = [x'w | v'w | v'x] in HBM (the
+ * results of hipk_triple_dots, which the host has NOT seen yet); nx <= 8 */
+extern "C" int hipk_axpy_proj_dot_jacobi_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *tri_dev, const double *rho_prev_host,
+      double mach_eps, const void *W, int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, const void *diag, const double *shift_host,
+      double min_den, double *out_dev) {
+   if (nx <= 0) return 0;
+   if (nx > 8 || !tri_dev) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (dt == HIPK_F64 ? 8.0 : 4.0) * (double)(4 * nx + 1));
+   if (!(min_den > 0.0)) min_den = 1e-300;
+   ColScal z, sh;
+   QmrPrev pv;
+   memset(&pv, 0, sizeof(pv)); memset(&z, 0, sizeof(z));
+   pv.eps = mach_eps;
+   for (int c = 0; c < nx; c++) { pv.rho_prev[c] = rho_prev_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * 2 * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL((axpy_proj_dot_jacobi_kernel<T, true>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, z, z, sh, min_den, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, (const T *)diag, nx, 0, m, ctx->partials, tri_dev, pv),
+         hipLaunchKernelGGL((axpy_proj_dot_jacobi_kernel<T, true>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, z, z, sh, min_den, (const T *)W, ldW, (const T *)X, ldX, (T *)G, ldG, (const T *)diag, nx, 0, m, ctx->partials, tri_dev, pv));
+   HIPK_CHECK(hipGetLastError());
    return hipk_finalize_partials(ctx, ctx->partials, gx, 2 * nx, out_dev);
 }
 
@@ -2347,12 +2423,41 @@ extern "C" int hipk_qmr_update_dir(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int 
    for (int c = 0; c < nx; c++) { g.a[c] = gamma_host[c]; e.a[c] = eta_host[c]; b.a[c] = beta_host[c]; sh.a[c] = shift_host ? shift_host[c] : 0.0; }
    int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
    if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   QmrPrev pv;
+   memset(&pv, 0, sizeof(pv));
    for (int c0 = 0; c0 < nx; c0 += 8) {
       DISPATCH_RT(dt,
-            hipLaunchKernelGGL(qmr_update_dir_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, b, sh, min_den, (T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials),
-            hipLaunchKernelGGL(qmr_update_dir_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, b, sh, min_den, (T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials));
+            hipLaunchKernelGGL((qmr_update_dir_kernel<T, false>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, b, sh, min_den, (T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials, (const double *)NULL, (const double *)NULL, pv),
+            hipLaunchKernelGGL((qmr_update_dir_kernel<T, false>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, g, e, b, sh, min_den, (T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, nx, c0, m, ctx->partials, (const double *)NULL, (const double *)NULL, pv));
       HIPK_CHECK(hipGetLastError());
    }
+   return hipk_finalize_partials(ctx, ctx->partials, gx, nx, dotsol_dev);
+}
+/* the same with gamma, eta, beta of the step formed in the launch from tri_dev (as above), ggr_dev = [g'g | g'K^-1 g] (the results of
+ * hipk_axpy_proj_dot_jacobi_dev) and the previous step's rho, tau, Theta; a column whose alpha was unusable is left alone; nx <= 8.
+ * dotsol_dev[c] = |sol(:,c)|^2 of the columns that were updated (0 for the others) */
+extern "C" int hipk_qmr_update_dir_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *tri_dev, const double *ggr_dev,
+      const double *rho_prev_host, const double *tau_prev_host, const double *theta_prev_host, double mach_eps, void *D, int64_t ldD,
+      void *Delta, int64_t ldDelta, void *Sol, int64_t ldSol, const void *G, int64_t ldG, const void *diag, const double *shift_host,
+      double min_den, double *dotsol_dev) {
+   if (nx <= 0) return 0;
+   if (nx > 8 || !tri_dev || !ggr_dev) return -1;
+   hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * (dt == HIPK_F64 ? 8.0 : 4.0) * (double)(7 * nx + 1));
+   if (!(min_den > 0.0)) min_den = 1e-300;
+   ColScal z, sh;
+   QmrPrev pv;
+   memset(&pv, 0, sizeof(pv)); memset(&z, 0, sizeof(z));
+   pv.eps = mach_eps;
+   for (int c = 0; c < nx; c++) {
+      pv.rho_prev[c] = rho_prev_host[c]; pv.tau_prev[c] = tau_prev_host[c]; pv.theta_prev[c] = theta_prev_host[c];
+      sh.a[c] = shift_host ? shift_host[c] : 0.0;
+   }
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);
+   if (hipk_reserve_partials(ctx, (size_t)gx * nx)) return -2;
+   DISPATCH_RT(dt,
+         hipLaunchKernelGGL((qmr_update_dir_kernel<T, true>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, z, z, z, sh, min_den, (T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, nx, 0, m, ctx->partials, tri_dev, ggr_dev, pv),
+         hipLaunchKernelGGL((qmr_update_dir_kernel<T, true>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, z, z, z, sh, min_den, (T *)D, ldD, (T *)Delta, ldDelta, (T *)Sol, ldSol, (const T *)G, ldG, (const T *)diag, nx, 0, m, ctx->partials, tri_dev, ggr_dev, pv));
+   HIPK_CHECK(hipGetLastError());
    return hipk_finalize_partials(ctx, ctx->partials, gx, nx, dotsol_dev);
 }
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--precond", default="fixed", choices=["fixed", "davidson", "none"])
     ap.add_argument("--scale-range", type=float, default=1.0)
     ap.add_argument("--max-matvecs", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=1, help="solves; the fastest is reported")
     args = ap.parse_args()
     from primme_amd import problems, _ffi as F
     from checkers import Operator, Session
@@ -46,9 +47,11 @@ def main():
     if args.max_matvecs: kw["maxMatvecs"] = args.max_matvecs
     if args.prof and args.backend == "hip":
         sess.lib.hipk_prof_reset(); sess.lib.hipk_prof_enable(1)
-    t0 = time.time()
-    r = sess.solve(**kw)
-    el = time.time() - t0
+    el = None
+    for _ in range(max(1, args.reps)):
+        t0 = time.time()
+        r = sess.solve(**kw)
+        el = min(el, time.time() - t0) if el is not None else time.time() - t0
     out = dict(n=n, tiles=T, ret=r.ret, seconds=round(el, 3), eigenpairs_per_s=round(args.num_evals / el, 4),
                outer=r.stats["numOuterIterations"], matvecs=r.stats["numMatvecs"], restarts=r.stats["numRestarts"],
                preconds=r.stats["numPreconds"], maxBasisSize=r.params["maxBasisSize"],

@@ -1003,3 +1003,70 @@ def test_larnv_stream_on_the_device(built, dt):
             side.close()
         assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
         assert np.all(np.abs(outs[0][0]) < 1.0) and outs[0][1] != [1, 2, 3, 5]
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("nx", [1, 5, 8])
+def test_qmr_step_scalars_on_the_device(built, dt, nx):
+    """Round 5: the block QMR step with one host synchronisation.  hipk_axpy_proj_dot_jacobi_dev / hipk_qmr_update_dir_dev evaluate
+    alpha = rho_prev / (v'w - (x'w)(v'x)), Theta, c, gamma, eta, beta in the launch, from reductions that are in device memory;
+    the host solver evaluates the same expressions on the mirrored values.  Checked: the panels they leave are EXACTLY the ones the
+    host-coefficient launches leave when the coefficients are computed here in numpy with every operation rounded on its own
+    (device == host arithmetic for the scalars), a column with an unusable alpha is left alone, device == oracle."""
+    rng = np.random.default_rng(177 + nx)
+    npdt = NPDT[dt]
+    m, ld = 50021, 50024
+    X, W, G, D, De, So = (rng.standard_normal((nx, ld)).astype(npdt) for _ in range(6))
+    diag = (2.0 + rng.random(m)).astype(npdt)
+    sh = np.resize(np.array([1.0, 0.3, -2.0, 0.0, 1.5]), nx)
+    tri = rng.standard_normal(3 * nx) * 3.0
+    if nx >= 5:
+        tri[nx + 2] = tri[2] * tri[2 * nx + 2]              # sigma == 0 exactly: column 2 leaves the block
+    rho_prev, tau_prev, th_prev = np.abs(rng.standard_normal(nx)) + 0.1, np.abs(rng.standard_normal(nx)) + 0.1, np.abs(rng.standard_normal(nx))
+    eps = 2.220446049250313e-16
+    a = lambda v: (C.c_double * nx)(*v)
+    out = []
+    for side in (Dev(), Host()):
+        x, w, g, d, de, so, dg = (side.arr(t) for t in (X, W, G, D, De, So, diag))
+        t3, o2, o1 = side.arr(tri), side.arr(np.zeros(2 * nx)), side.arr(np.zeros(nx))
+        assert side.lib.hipk_axpy_proj_dot_jacobi_dev(side.ctx, dt, m, nx, side.ptr(t3), a(rho_prev), C.c_double(eps), side.ptr(w), ld, side.ptr(x), ld,
+                                                      side.ptr(g), ld, side.ptr(dg), a(sh), C.c_double(1e-10), side.ptr(o2)) == 0
+        assert side.lib.hipk_qmr_update_dir_dev(side.ctx, dt, m, nx, side.ptr(t3), side.ptr(o2), a(rho_prev), a(tau_prev), a(th_prev), C.c_double(eps),
+                                                side.ptr(d), ld, side.ptr(de), ld, side.ptr(so), ld, side.ptr(g), ld, side.ptr(dg), a(sh),
+                                                C.c_double(1e-10), side.ptr(o1)) == 0
+        dev = [side.get(t).copy() for t in (g, d, de, so, o2, o1)]
+        # the same step with the coefficients formed on the host (numpy float64: one rounding per operation), from the reductions
+        # the first launch left
+        ggr = dev[4]
+        sigma = tri[nx:2 * nx] - tri[:nx] * tri[2 * nx:]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            alpha = rho_prev / sigma
+        bad = ~np.isfinite(sigma) | (sigma == 0.0) | ~np.isfinite(alpha) | (np.abs(alpha) < eps) | (np.abs(alpha) > 1.0 / eps)
+        alpha = np.where(bad, 0.0, alpha)
+        g2, d2, de2, so2 = (side.arr(t) for t in (G, D, De, So))
+        p2, p1 = side.arr(np.zeros(2 * nx)), side.arr(np.zeros(nx))
+        assert side.lib.hipk_axpy_proj_dot_jacobi(side.ctx, dt, m, nx, a(alpha), a(tri[:nx]), side.ptr(w), ld, side.ptr(x), ld, side.ptr(g2), ld,
+                                                  side.ptr(dg), a(sh), C.c_double(1e-10), side.ptr(p2)) == 0
+        assert np.array_equal(side.get(p2), ggr) and np.array_equal(side.get(g2), dev[0])
+        theta = np.sqrt(ggr[:nx]) / tau_prev
+        c = 1.0 / np.sqrt(1 + theta * theta)
+        gam, eta, beta = ((c * c) * th_prev) * th_prev, (alpha * c) * c, ggr[nx:] / rho_prev
+        live = np.nonzero(~bad)[0]
+        for col in live:                                    # column by column: the dropped ones are not touched
+            one = lambda v: (C.c_double * 1)(v[col])
+            off = lambda t: side.ptr(t, int(col) * ld)
+            q1 = side.arr(np.zeros(1))
+            assert side.lib.hipk_qmr_update_dir(side.ctx, dt, m, 1, one(gam), one(eta), one(beta), off(d2), ld, off(de2), ld, off(so2), ld, off(g2), ld,
+                                                side.ptr(dg), one(sh), C.c_double(1e-10), side.ptr(q1)) == 0
+        host = [side.get(t).copy() for t in (g2, d2, de2, so2)]
+        for t in range(4):
+            assert np.array_equal(dev[t], host[t]), t
+        if nx >= 5:
+            assert bad[2] and np.array_equal(dev[1][2], D[2]) and np.array_equal(dev[3][2], So[2]) and dev[5][2] == 0.0
+        out.append(dev)
+        side.close()
+    tol = 1e-12 if dt == F.HIPK_F64 else 2e-4
+    for t in range(4):                                      # device == oracle
+        assert np.max(np.abs(out[0][t][:, :m] - out[1][t][:, :m]) / (1 + np.abs(out[1][t][:, :m]))) <= tol * 10
+    for t in (4, 5):
+        assert np.max(np.abs(out[0][t] - out[1][t]) / (1 + np.abs(out[1][t]))) <= tol * np.sqrt(m)

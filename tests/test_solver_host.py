@@ -550,3 +550,28 @@ def test_host_pointer_entry_points(built):
               method="GD_plusK", v0=problems.start_vector(n))
     assert g.ret == 0 and g.stats["numOuterIterations"] == p.stats.numOuterIterations and g.stats["numMatvecs"] == p.stats.numMatvecs
     assert np.max(np.abs(g.evals - evals)) <= 1e-13
+
+
+@pytest.mark.parametrize("kw", [dict(numEvals=10, maxBlockSize=8), dict(numEvals=6, target="largest", maxBlockSize=8), dict(numEvals=9, maxBlockSize=3),
+                                dict(numEvals=8, maxBlockSize=8, locking=1)])
+def test_block_qmr_step_with_one_synchronisation_keeps_the_history(built, kw, monkeypatch):
+    """Round 5: block JDQMR with the library's Jacobi preconditioner runs every inner step as three launches and ONE host wait — the
+    step's alpha, gamma, eta, beta are evaluated on the device, in the prologue of the launch that applies them
+    (hipk_axpy_proj_dot_jacobi_dev, hipk_qmr_update_dir_dev; oracle/hipk_cpu.c restates them), the host evaluates the same
+    expressions afterwards for its stopping tests.  Same roundings on both sides: the history is the three-wait sequence's
+    (PRIMME_AMD_QMR_THREE_WAITS=1) bit for bit — iterations, operator and preconditioner applications, eigenvalues, residual norms."""
+    import ctypes as C
+    rp, ci, va, n = problems.laplacian_csr((22, 23, 13))
+    v0 = np.random.default_rng(7).standard_normal((n, kw["maxBlockSize"]))
+    lib = checkers.load_hostcheck()
+    runs = []
+    for three in (False, True):
+        if three: monkeypatch.setenv("PRIMME_AMD_QMR_THREE_WAITS", "1")
+        else: monkeypatch.delenv("PRIMME_AMD_QMR_THREE_WAITS", raising=False)
+        r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", method="JDQMR", eps=1e-9, aNorm=12.0, v0=v0, precond=("jacobi", 0.0), **kw)
+        assert r.ret == 0
+        runs.append((r.stats["numOuterIterations"], r.stats["numMatvecs"], r.stats["numPreconds"], r.evals.tobytes(), r.resNorms.tobytes()))
+    assert runs[0] == runs[1]
+    ex = problems.laplacian_eigenvalues((22, 23, 13), kw["numEvals"])
+    want = ex if kw.get("target") != "largest" else 12.0 - ex        # the spectrum of the 3-D stencil is symmetric about 6
+    assert np.max(np.abs(np.sort(np.frombuffer(runs[0][3])) - np.sort(want))) <= 1e-8 * 12.0
