@@ -244,6 +244,9 @@ void primme_amd_global_sum(void *sendBuf, void *recvBuf, int *count,
  * the host had seen the previous one and how many of those the host then adopted.  No reference
  * counterpart (the reference has no device queue to run ahead of). */
 void primme_amd_prelaunch_stats(long *launched, long *adopted);
+/* Diagnostics of this process (JDQMR): inner QMR steps taken since the last call, and how many of them ran with ONE host
+ * synchronisation (block sizes 2 .. 8 with the library's Jacobi preconditioner: DESIGN.md section 4b); the call resets both. */
+void primme_amd_qmr_step_stats(long *steps, long *one_synchronisation);
 
 #ifdef __cplusplus
 }

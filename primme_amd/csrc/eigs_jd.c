@@ -343,6 +343,16 @@ static int apply_projected_preconditioner(pa_solver *s, char *v, int64_t ldv, co
    return 0;
 }
 
+#if !PA_IS_COMPLEX
+/* diagnostics of this process (include/primme_amd.h): inner QMR steps taken / taken with one host synchronisation since the last call */
+static long g_qmr_steps[2];
+void primme_amd_qmr_step_stats(long *steps, long *one_synchronisation) {
+   if (steps) *steps = g_qmr_steps[0];
+   if (one_synchronisation) *one_synchronisation = g_qmr_steps[1];
+   g_qmr_steps[0] = g_qmr_steps[1] = 0;
+}
+#endif
+
 /* Block QMR.  x, r: the block's Ritz vectors and residuals (V / W slots at basisSize);
  * sol receives the corrections.  eval[i], shift[i], rnorm[i] per block vector. */
 static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const double *rnorm, jd_proj *P,
@@ -429,8 +439,12 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
       const int onewait = !three_waits && early_rho && fold_x && numIts + 1 < maxIterations && blockSize <= 8 &&
                           !(s->parallel && !s->dev_comm) && 3 * 64 + 3 * 8 < s->red_cap;
       double gg_all[8], rho_all[8], dot_all[8];
+#if !PA_IS_COMPLEX
+      g_qmr_steps[0]++;
+#endif
       if (onewait) {
 #if !PA_IS_COMPLEX
+         g_qmr_steps[1]++;
          double rp[8], tp[8], thp[8], jsh[8];
          double *d_tri = s->d_red, *d_ggr = s->d_red + 3 * 64, *d_dot = s->d_red + 3 * 64 + 16;
          for (i = 0; i < blockSize; i++) {

@@ -81,10 +81,19 @@ def run(rank, world, port, case, out_path):
         op = Operator(n, csr=(rpt, cit, vat), row0=rank * n0, nrows=n0)
         v0 = problems.start_vector(n, row0=rank * n0, nrows=n0)
         s = Session(op, comm=comm, backend="hostcheck")
-        nev = 10 if case == "devcomm_lock" else (6 if case == "devcomm_halo" else 4)
+        nev = 10 if case == "devcomm_lock" else (6 if case in ("devcomm_halo", "devcomm_jdqmr", "devcomm_jdqmr3") else 4)
         counts = (C.c_long * 8)()
         lib.hipk_cpu_counts(counts, 1)
-        r = s.solve(numEvals=nev, eps=1e-10, aNorm=8.0 * (1.0 if case == "devcomm_halo" else 1.37), v0=v0, numProcs=world, procID=rank)
+        if case in ("devcomm_jdqmr", "devcomm_jdqmr3"):
+            # block JDQMR with the library's Jacobi preconditioner, rows over two ranks: the inner step with ONE synchronisation
+            # (scalar recurrences evaluated next to the launches, from all-reduced sums) — or, "3", the three-wait sequence
+            if case == "devcomm_jdqmr3":
+                os.environ["PRIMME_AMD_QMR_THREE_WAITS"] = "1"
+            v0b = np.random.default_rng(7).standard_normal((n, 4))[rank * n0:(rank + 1) * n0]
+            r = s.solve(numEvals=nev, eps=1e-9, aNorm=8.0 * 1.37, v0=v0b, numProcs=world, procID=rank, method="JDQMR", maxBlockSize=4,
+                        precond=("jacobi", 0.0))
+        else:
+            r = s.solve(numEvals=nev, eps=1e-10, aNorm=8.0 * (1.0 if case == "devcomm_halo" else 1.37), v0=v0, numProcs=world, procID=rank)
         lib.hipk_cpu_counts(counts, 1)
         lib.primme_amd_hostcheck_comm_calls.restype = C.c_long
         lib.primme_amd_hostcheck_comm_calls.argtypes = [C.c_void_p]
@@ -93,7 +102,11 @@ def run(rank, world, port, case, out_path):
         pre = (C.c_long * 2)()
         lib.primme_amd_prelaunch_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
         lib.primme_amd_prelaunch_stats(C.cast(pre, C.POINTER(C.c_long)), C.cast(C.byref(pre, C.sizeof(C.c_long)), C.POINTER(C.c_long)))
-        extra = dict(allreduces=int(lib.primme_amd_hostcheck_comm_calls(comm)), fused_tail=int(counts[5]), ritz_cgs=int(counts[3]),
+        qs = (C.c_long * 2)()
+        lib.primme_amd_qmr_step_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        lib.primme_amd_qmr_step_stats(C.cast(qs, C.POINTER(C.c_long)), C.cast(C.byref(qs, C.sizeof(C.c_long)), C.POINTER(C.c_long)))
+        extra = dict(qmr_steps=int(qs[0]), qmr_steps_one_wait=int(qs[1]),
+                     allreduces=int(lib.primme_amd_hostcheck_comm_calls(comm)), fused_tail=int(counts[5]), ritz_cgs=int(counts[3]),
                      ritz_ov=int(counts[6]), dots=int(counts[0]), locking=int(r.params["locking"]),
                      fused_exchanges=int(lib.primme_amd_hostcheck_comm_xr_calls(comm)), ahead=int(pre[0]), adopted=int(pre[1]))
         s.close()

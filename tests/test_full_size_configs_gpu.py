@@ -38,11 +38,19 @@ def test_config3_full_size_lunda_tiles_jdqmr_block8(built):
     aN = float(np.abs(w).max())
     want = np.sort(w[np.argsort(np.abs(w - CONFIG3_SHIFT))][:20])
     s = Session(Operator(n, csr=(rp, ci, va)), backend="hip")
+    import ctypes as C
+    qs = (C.c_long * 2)()
+    lib.primme_amd_qmr_step_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.primme_amd_qmr_step_stats(None, None)
     try:
         r = s.solve(numEvals=20, target="closest_abs", targetShifts=[CONFIG3_SHIFT], method="JDQMR", maxBlockSize=8,
                     eps=1e-8, aNorm=aN, precond=("jacobi", CONFIG3_SHIFT))
     finally:
         s.close()
+    lib.primme_amd_qmr_step_stats(C.cast(qs, C.POINTER(C.c_long)), C.cast(C.byref(qs, C.sizeof(C.c_long)), C.POINTER(C.c_long)))
+    # round 5: the inner steps run with one host synchronisation (scalar recurrences on the device): all but
+    # the last step of every inner solve
+    assert qs[0] > 1000 and qs[1] >= 0.9 * qs[0], (qs[0], qs[1])
     assert r.ret == 0 and r.initSize == 20 and r.params["maxBlockSize"] == 8 and r.params["maxBasisSize"] == 41
     assert np.max(np.abs(np.sort(r.evals) - want)) <= 1e-10 * aN
     assert np.all(r.resNorms <= 1e-8 * aN * (1 + 1e-6))

@@ -192,3 +192,21 @@ def test_peer_to_peer_second_stage_and_iterations_enqueued_ahead_two_ranks(built
     assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]
     assert res[0]["adopted"] == res[1]["adopted"] and res[0]["ahead"] == res[1]["ahead"] and res[0]["allreduces"] == res[1]["allreduces"]
     assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - nev) < 1e-8
+
+
+def test_block_qmr_one_synchronisation_two_ranks(built, tmp_path):
+    """Round 5: the block QMR step with one host synchronisation (eigs_jd.c) on the device-communicator path, world_size 2 on CPU:
+    the three inner products / the two reductions of the step are all-reduced inside the stream of launches and the step's scalar
+    recurrences are evaluated from the GLOBAL sums, next to the launches that apply them and — afterwards — on every host.  Same
+    history as the three-wait sequence bit for bit, identical bits on both ranks, the one-rank solve's eigenvalues."""
+    res = _launch("devcomm_jdqmr", tmp_path)
+    old = _launch("devcomm_jdqmr3", tmp_path)
+    dims = (15, 16)
+    ex = np.sort(np.concatenate([problems.laplacian_eigenvalues(dims, 6), 1.37 * problems.laplacian_eigenvalues(dims, 6)]))[:6]
+    for r, q in zip(res, old):
+        assert r["ret"] == 0 and q["ret"] == 0
+        assert (r["its"], r["matvecs"], r["evals"], r["resNorms"]) == (q["its"], q["matvecs"], q["evals"], q["resNorms"])
+        assert np.max(np.abs(np.sort(r["evals"]) - ex)) <= 1e-9 * 8 * 1.37
+        assert r["allreduces"] > 0
+        assert r["qmr_steps"] == q["qmr_steps"] > 50 and r["qmr_steps_one_wait"] >= 0.8 * r["qmr_steps"] and q["qmr_steps_one_wait"] == 0
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]

@@ -564,12 +564,17 @@ def test_block_qmr_step_with_one_synchronisation_keeps_the_history(built, kw, mo
     rp, ci, va, n = problems.laplacian_csr((22, 23, 13))
     v0 = np.random.default_rng(7).standard_normal((n, kw["maxBlockSize"]))
     lib = checkers.load_hostcheck()
+    lib.primme_amd_qmr_step_stats(None, None)
     runs = []
     for three in (False, True):
         if three: monkeypatch.setenv("PRIMME_AMD_QMR_THREE_WAITS", "1")
         else: monkeypatch.delenv("PRIMME_AMD_QMR_THREE_WAITS", raising=False)
         r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hostcheck", method="JDQMR", eps=1e-9, aNorm=12.0, v0=v0, precond=("jacobi", 0.0), **kw)
         assert r.ret == 0
+        qs = (C.c_long * 2)()
+        lib.primme_amd_qmr_step_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        lib.primme_amd_qmr_step_stats(C.cast(qs, C.POINTER(C.c_long)), C.cast(C.byref(qs, C.sizeof(C.c_long)), C.POINTER(C.c_long)))
+        assert qs[0] > 20 and (qs[1] == 0 if three else qs[1] >= 0.8 * qs[0]), (three, qs[0], qs[1])     # (the last step of an inner solve keeps the old form)
         runs.append((r.stats["numOuterIterations"], r.stats["numMatvecs"], r.stats["numPreconds"], r.evals.tobytes(), r.resNorms.tobytes()))
     assert runs[0] == runs[1]
     ex = problems.laplacian_eigenvalues((22, 23, 13), kw["numEvals"])
