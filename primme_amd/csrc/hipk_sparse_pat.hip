@@ -157,7 +157,7 @@ template <typename T> __device__ __forceinline__ void pat_bstore2(__amdgpu_buffe
  *   u-th pair within the chunk */
 template <typename T, int ML, int RPL, bool FUSED>
 __device__ __forceinline__ void pat_trip_inner(const int (&p)[2 * RPL], const double *s_val, const int32_t *s_off, const int32_t *s_len,
-      __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ry, __amdgpu_buffer_rsrc_t ro, int32_t minoff,
+      __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ry, __amdgpu_buffer_rsrc_t ro, int32_t minoff, bool near,
       const uint32_t (&rowb)[RPL], double a, double &dotp) {
    constexpr int SH = sizeof(T) == 8 ? 3 : 2;
    const uint32_t ownb = (uint32_t)(-minoff) << SH;
@@ -171,11 +171,20 @@ __device__ __forceinline__ void pat_trip_inner(const int (&p)[2 * RPL], const do
       for (int e = 0; e < ML; e++)
          pat_bload2<T>(rx, rowb[u] + ((uint32_t)(s_off[pa * ML + e] - minoff) << SH), 0, xa[u][e], xb[u][e]);
       if (FUSED) pat_bload2<T>(rx, rowb[u] + ownb, 0, oa[u], ob[u]);
-      /* ... and where the second row has a pattern of its own (the few lanes whose pair straddles a change) its entries again */
+      /* ... and where the second row has a pattern of its own (the few lanes whose pair straddles a change) its entries again.
+       * With the first row's offsets the second element of such a pair's access can lie one past the end of x (the first row
+       * references the last column), and what a partially out-of-range access returns for its in-range half is not something
+       * to build on: within reach of the end of x (`near`, a handful of chunks) the first row is loaded again as well, entry by
+       * entry.  (Two rows with the SAME pattern never overrun: the second row's reference is a column of the matrix.) */
       if (pa != pb) {
 #pragma unroll
          for (int e = 0; e < ML; e++)
             xb[u][e] = pat_bload<T>(rx, rowb[u] + (uint32_t)sizeof(T) + ((uint32_t)(s_off[pb * ML + e] - minoff) << SH), 0);
+         if (near) {
+#pragma unroll
+            for (int e = 0; e < ML; e++)
+               xa[u][e] = pat_bload<T>(rx, rowb[u] + ((uint32_t)(s_off[pa * ML + e] - minoff) << SH), 0);
+         }
       }
    }
 #pragma unroll
@@ -272,7 +281,8 @@ pat_kernel(const uint8_t *__restrict__ pid, const int32_t *__restrict__ toff, co
          const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(x + r0 + minoff), 0, (int)(xbytes < 0x7fffffff ? xbytes : 0x7fffffff), 0x00020000);
          const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(y + r0), 0, (int)(ybytes < 0x7fffffff ? ybytes : 0x7fffffff), 0x00020000);
          const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)((FUSED ? xout : y) + r0), 0, (int)(ybytes < 0x7fffffff ? ybytes : 0x7fffffff), 0x00020000);
-         pat_trip_inner<T, ML, RPL, FUSED>(p, s_val, s_off, s_len, rx, ry, ro, minoff, rowb, a, dotp);
+         const bool near = r0 + CH + maxoff >= nrows;               /* some row of the chunk may reference the last column */
+         pat_trip_inner<T, ML, RPL, FUSED>(p, s_val, s_off, s_len, rx, ry, ro, minoff, near, rowb, a, dotp);
       } else {
          int64_t r[NR];
 #pragma unroll

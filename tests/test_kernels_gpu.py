@@ -740,7 +740,7 @@ def _lattice_csr(n, rng):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
-@pytest.mark.parametrize("case", ["lap1d", "lap2d", "lap2d_big", "lap3d", "lattice", "lap3d_slab", "random"])
+@pytest.mark.parametrize("case", ["lap1d", "lap1d_full_chunks", "lap2d", "lap2d_full_chunks", "lap2d_big", "lap3d", "lattice", "lap3d_slab", "random"])
 def test_csr_row_pattern_form(built, dt, case):
     """Matrices whose rows repeat are served by the row-pattern form (csrc/hipk_sparse_pat.hip: one byte per row + a pattern
     table, one lane per row) for one-column products.  Checked: hipk_csr_create picks it for stencils / lattice operators
@@ -751,7 +751,9 @@ def test_csr_row_pattern_form(built, dt, case):
     rng = np.random.default_rng(11)
     row0, lo_hi = 0, None
     if case == "lap1d": rp, ci, va, n = problems.laplacian_csr((70001,))
+    elif case == "lap1d_full_chunks": rp, ci, va, n = problems.laplacian_csr((8192,))   # no ragged chunk: the last pair (interior row, last row) is in the fast form and its first row references the LAST column
     elif case == "lap2d": rp, ci, va, n = problems.laplacian_csr((37, 41))
+    elif case == "lap2d_full_chunks": rp, ci, va, n = problems.laplacian_csr((33, 512))   # n = 33 * 512: full chunks only; row n - 1 - 33 is even and its +33 entry is the last column
     elif case == "lap2d_big": rp, ci, va, n = problems.laplacian_csr((1234, 1111))     # > 2 chunks per workgroup of every XCD
     elif case == "lap3d": rp, ci, va, n = problems.laplacian_csr((64, 65, 66))
     elif case == "lattice": n = 40003; rp, ci, va = _lattice_csr(n, rng)
@@ -781,7 +783,7 @@ def test_csr_row_pattern_form(built, dt, case):
             lib.hipk_csr_destroy(A)
             return
         assert lib.hipk_csr_format(A) == 2
-        want_pat = {"lap1d": 3, "lap2d": 9, "lap2d_big": 9, "lap3d": 27, "lattice": 6}.get(case)
+        want_pat = {"lap1d": 3, "lap1d_full_chunks": 3, "lap2d": 9, "lap2d_full_chunks": 9, "lap2d_big": 9, "lap3d": 27, "lattice": 6}.get(case)
         if want_pat: assert lib.hipk_csr_npatterns(A) == want_pat
         es = np.dtype(npdt).itemsize
         assert lib.hipk_csr_product_bytes(A, 1) == nloc * (1 + 3 * es)
