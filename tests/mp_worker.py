@@ -205,31 +205,44 @@ def run(rank, world, port, case, out_path):
         r = s.solve(numProcs=world, procID=rank, global_sum=global_sum, iseed=(5 + rank, 1, 2, 3), **kw)
         s.close()
         r.evecs = np.concatenate([r.evecs.real, r.evecs.imag])
-    elif case == "svds":
+    elif case in ("svds", "svds_z"):
         # A (m x n) split by rows, n-vectors split in equal slabs: y = A x needs an all-gather of x,
-        # y = A' x a reduce-scatter of the local products (BASELINE configs[4] in small)
+        # y = A' x a reduce-scatter of the local products (BASELINE configs[4] in small).  svds_z: the same pattern with complex
+        # phases through hip_zprimme_svds — the native complex front end (round 5) on two ranks
         from primme_amd.svds_api import transpose_csr
+        cz = case == "svds_z"
         m, n, k = 600, 200, 4
         rp, ci, va = problems.svds_synthetic_csr(m, n)
+        if cz:
+            va = va.astype(np.complex128) * np.exp(1j * np.random.default_rng(5).uniform(0, 2 * np.pi, size=len(va)))
         mloc, nloc = m // world, n // world
         r0 = rank * mloc
         lrp = (rp[r0:r0 + mloc + 1] - rp[r0]).astype(np.int32)
         lci, lva = ci[rp[r0]:rp[r0 + mloc]], va[rp[r0]:rp[r0 + mloc]]
-        trp, tci, tva = transpose_csr(mloc, n, lrp, lci, lva)
+        if cz:
+            import scipy.sparse as sp
+            Al = sp.csr_matrix((lva, lci, lrp), shape=(mloc, n))
+            AlH = Al.conj().T.tocsr()
+        else:
+            trp, tci, tva = transpose_csr(mloc, n, lrp, lci, lva)
         lib = checkers.load_hostcheck()
+        sdt = np.complex128 if cz else np.float64
+        tdt = torch.complex128 if cz else torch.float64
 
         def mv(x, ldx, y, ldy, bs, tr, pp, ierr):
             nb, lx, ly = bs[0], ldx[0], ldy[0]
-            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(nb, lx))
-            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(nb, ly))
+            f = 2 if cz else 1                                 # leading dimensions count (complex) elements
+            X = np.ctypeslib.as_array(C.cast(x, C.POINTER(C.c_double)), shape=(nb, f * lx)).view(sdt)
+            Y = np.ctypeslib.as_array(C.cast(y, C.POINTER(C.c_double)), shape=(nb, f * ly)).view(sdt)
             for c in range(nb):
                 if not tr[0]:
-                    parts = [torch.zeros(nloc, dtype=torch.float64) for _ in range(world)]
+                    parts = [torch.zeros(nloc, dtype=tdt) for _ in range(world)]
                     dist.all_gather(parts, torch.from_numpy(X[c, :nloc].copy()))
                     xf = torch.cat(parts).numpy()
-                    Y[c, :mloc] = problems.csr_matvec_numpy(lrp, lci, lva, xf.reshape(-1, 1)).ravel()
+                    Y[c, :mloc] = (Al @ xf) if cz else problems.csr_matvec_numpy(lrp, lci, lva, xf.reshape(-1, 1)).ravel()
                 else:
-                    z = torch.from_numpy(problems.csr_matvec_numpy(trp, tci, tva, X[c, :mloc].reshape(-1, 1)).ravel().copy())
+                    zz = (AlH @ X[c, :mloc]) if cz else problems.csr_matvec_numpy(trp, tci, tva, X[c, :mloc].reshape(-1, 1)).ravel()
+                    z = torch.from_numpy(np.ascontiguousarray(zz).copy())
                     dist.all_reduce(z)
                     Y[c, :nloc] = z.numpy()[rank * nloc:(rank + 1) * nloc]
             ierr[0] = 0
@@ -250,14 +263,14 @@ def run(rank, world, port, case, out_path):
         ps.globalSumReal = C.cast(gcb, C.c_void_p)
         lib.primme_svds_set_method(F.SVDS_METHODS["normalequations"], F.METHODS["GD_plusK"], 0, C.byref(ps))
         svals, rn = np.zeros(k), np.zeros(k)
-        sv = np.zeros((mloc + nloc) * k)
-        ret = lib.hip_dprimme_svds(svals.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p),
-                                   rn.ctypes.data_as(C.c_void_p), C.byref(ps))
+        sv = np.zeros((mloc + nloc) * k, dtype=sdt)
+        ret = (lib.hip_zprimme_svds if cz else lib.hip_dprimme_svds)(svals.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p),
+                                                                     rn.ctypes.data_as(C.c_void_p), C.byref(ps))
         U = sv[:mloc * k].reshape(k, mloc)
         V = sv[mloc * k:].reshape(k, nloc)
         res = dict(rank=rank, ret=ret, evals=svals.tolist(), resNorms=rn.tolist(), its=int(ps.stats.numOuterIterations),
-                   numGlobalSum=int(ps.stats.numGlobalSum), evecs_norm2=float(np.sum(V ** 2)), u_norm2=float(np.sum(U ** 2)),
-                   aNorm=float(ps.aNorm))
+                   numGlobalSum=int(ps.stats.numGlobalSum), evecs_norm2=float(np.sum(np.abs(V) ** 2)), u_norm2=float(np.sum(np.abs(U) ** 2)),
+                   aNorm=float(ps.aNorm), matvecs=int(ps.stats.numMatvecs))
         json.dump(res, open(f"{out_path}.{rank}", "w"))
         dist.barrier()
         dist.destroy_process_group()

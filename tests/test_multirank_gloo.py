@@ -210,3 +210,24 @@ def test_block_qmr_one_synchronisation_two_ranks(built, tmp_path):
         assert r["allreduces"] > 0
         assert r["qmr_steps"] == q["qmr_steps"] > 50 and r["qmr_steps_one_wait"] >= 0.8 * r["qmr_steps"] and q["qmr_steps_one_wait"] == 0
     assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]
+
+
+def test_complex_svds_native_two_ranks(built, tmp_path):
+    """Round 5: hip_zprimme_svds on two ranks — the native complex singular value front end (csrc/svds_main.c on complex panels over
+    the native complex eigensolver) with A split by rows and all-gather / reduce-scatter callbacks on complex blocks: the dense
+    truth's triplets, identical on both ranks, unit-norm complex vectors."""
+    res = _launch("svds_z", tmp_path)
+    m, n, k = 600, 200, 4
+    rp, ci, va = problems.svds_synthetic_csr(m, n)
+    vz = va.astype(np.complex128) * np.exp(1j * np.random.default_rng(5).uniform(0, 2 * np.pi, size=len(va)))
+    A = np.zeros((m, n), dtype=np.complex128)
+    A[np.repeat(np.arange(m), np.diff(rp)), ci] = vz
+    s = np.linalg.svd(A, compute_uv=False)
+    for r in res:
+        assert r["ret"] == 0
+        assert np.max(np.abs(np.array(r["evals"]) - s[:k])) <= 1e-10 * s[0]
+        assert np.all(np.array(r["resNorms"]) <= 1e-10 * r["aNorm"] * (1 + 1e-6))
+        assert r["numGlobalSum"] > 0
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"] and res[0]["matvecs"] == res[1]["matvecs"]
+    assert abs(res[0]["evecs_norm2"] + res[1]["evecs_norm2"] - k) < 1e-8
+    assert abs(res[0]["u_norm2"] + res[1]["u_norm2"] - k) < 1e-8
