@@ -204,6 +204,33 @@ int hipk_ritz_residual_overlaps_dev(hipk_ctx *ctx, hipk_dtype dt, int64_t m, con
 unsigned long long hipk_seq_issued(hipk_ctx *ctx);
 int hipk_wait_seq(hipk_ctx *ctx, unsigned long long seq);
 
+/* ---- the tail of a block-size-1 iteration without its own second-stage launches (round 6) ----
+ * The tail is: Gram-Schmidt update + |t|^2 (hipk_panel_project_to, ortho.c:262-291), then scale + A t + t'At
+ * (hipk_csr_matvec_scaled; matrixMatvec + update_projection.c:99-122).  Each of the two used to end in a second-stage launch of
+ * its own (globalSumReal's place in the reference, ortho.c:290 and update_projection.c:136), and the pre-enqueued next
+ * iteration started with the one-wave launch hipk_rr_arrow: ~16 us and four kernel boundaries per outer iteration that stream
+ * nothing.  hipk_tail_defer(ctx, want) arms, for the NEXT hipk_panel_project_to with one column and the NEXT
+ * hipk_csr_matvec_scaled on this context:
+ *   HIPK_TAIL_NORM  the partial sums of |t|^2 stay in HBM; every workgroup of the operator launch adds them itself (a few KB
+ *                   out of L2, one fixed order) before it scales — only honoured by the row-pattern form of the operator,
+ *                   whose grid is the resident set (a tile kernel with tens of thousands of workgroups would re-read them
+ *                   more often than the launch it saves is worth); not for row-partitioned runs (|t|^2 must be global);
+ *   HIPK_TAIL_DOT   the second stage of t'At is left to hipk_tail_finish.
+ * It returns the flags it accepted (0: the sequence of separate launches, e.g. HIPK_NO_TAIL_DEFER=1 or the CPU checker).
+ * hipk_tail_finish(ctx, in, fov_dev, nfov, alpha_dev, hnext_out) is then ONE small launch: both sums in the order the operator
+ * launch used, into HBM and the pinned mirror (+ the exchange with the other ranks when hipk_xreduce_arm was called before it),
+ * and — in != NULL — hipk_rr_arrow's step for the next iteration in the same launch (same arithmetic, same outputs), the
+ * completion flag last.  The caller may enqueue it LATER than the tail itself (eigs_conv.c does: at the point where it knows
+ * the Rayleigh-Ritz decomposition the next iteration's step needs) as long as nothing else used the context's reduction
+ * scratch in between.  With nothing deferred it finishes what is pending the separate way and runs hipk_rr_arrow for in != NULL.
+ * hipk_tail_abandon forgets an armed / pending tail (a pre-enqueued iteration that is thrown away). */
+#define HIPK_TAIL_NORM 1
+#define HIPK_TAIL_DOT 2
+int hipk_tail_defer(hipk_ctx *ctx, int want);
+int hipk_tail_finish(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov_dev, int nfov, const double *alpha_dev, double *hnext_out);
+void hipk_tail_abandon(hipk_ctx *ctx);
+int hipk_tail_pending(hipk_ctx *ctx);
+
 /* ---- column utilities ---------------------------------------------------------
  * Num_scal (cublas_wrapper.c:678), Num_axpy (:616), Num_copy_matrix (:739),
  * permute_vecs / Num_compact_vecs on device columns (auxiliary.c:716, :897). */

@@ -371,6 +371,17 @@ int hipk_rr_arrow(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov, int nf
    return 0;
 }
 
+/* the tail without its own second-stage launches (include/primme_amd_kernels.h: hipk_tail_defer): on the CPU every
+ * reduction is complete when its call returns, so nothing is ever deferred (0 flags accepted) and hipk_tail_finish is the
+ * Rayleigh-Ritz step alone — the host solver takes the same decisions in the same order either way */
+int hipk_tail_defer(hipk_ctx *ctx, int want) { (void)ctx; (void)want; return 0; }
+void hipk_tail_abandon(hipk_ctx *ctx) { (void)ctx; }
+int hipk_tail_pending(hipk_ctx *ctx) { (void)ctx; return 0; }
+int hipk_tail_finish(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov, int nfov, const double *alpha_dev, double *hnext_out) {
+   if (in) return hipk_rr_arrow(ctx, in, fov, nfov, alpha_dev, hnext_out);
+   return 0;
+}
+
 int hipk_scale_cols(hipk_ctx *ctx, hipk_dtype dt, int64_t m, void *X, int64_t ldX, int nx, const double *a) {
    (void)ctx;
    if (IS_Z(dt)) return hipk_z_scale_cols(dt, m, X, ldX, nx, a);

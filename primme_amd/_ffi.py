@@ -200,6 +200,8 @@ def declare_kernels(lib):
         "hipk_ritz_residual_overlaps": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, C.c_double, _vp, _vp, _i64, _i, _i, _vp],
         "hipk_ritz_residual_overlaps_dev": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
         "hipk_rr_arrow": [_vp, P(HipkRrIn), _vp, _i, _vp, _vp],
+        "hipk_tail_defer": [_vp, _i], "hipk_tail_pending": [_vp],
+        "hipk_tail_finish": [_vp, P(HipkRrIn), _vp, _i, _vp, _vp],
         "hipk_ritz_update_overlaps": [_vp, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, P(HipkJob), _i, _vp, _i, _vp, _i64, _i, _vp],
         "hipk_pair_dots": [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i, _vp],
         "hipk_sym_eig": [_vp, _i, _vp, _i, _vp, _vp, _i],

@@ -300,15 +300,21 @@ static void tail_finish(pa_solver *s, int basisSize, int nLk, int nfov, const do
    s->spec_hcol[basisSize] = alpha;
 }
 
-/* Enqueue iteration basisSize + 1 behind the launches of iteration basisSize, whose results the host has NOT seen yet:
- * the Ritz pair of its residual comes from hipk_rr_arrow (one wave: the arrowhead eigenproblem in the Ritz basis the host
- * holds for the current size), then the same three launches as any iteration — residual + overlaps, Gram-Schmidt update,
- * scale + A t + t'At — on the other overlap buffer / scratch column.  Nothing here synchronises.  Returns 0 when enqueued
- * (s->pre_valid set) or when the case is not covered (s->pre_valid clear). */
-static int pa_prelaunch_next(pa_solver *s, int basisSize, int nLk, int col, int nfov) {
+/* Iteration basisSize + 1 enqueued behind the launches of iteration basisSize, whose results the host has NOT seen yet: the
+ * Ritz pair of its residual comes from the one-wave Rayleigh-Ritz step (hipk_rr_arrow's arithmetic: the arrowhead eigenproblem in
+ * the Ritz basis the host holds for the current size), then the same launches as any iteration — residual + overlaps,
+ * Gram-Schmidt update, scale + A t + t'At — on the other overlap buffer / scratch column.  Nothing here synchronises.
+ *
+ * Round 6: two halves.  pa_prelaunch_prepare decides whether the case is covered and fills the step's input; the caller hands
+ * it to hipk_tail_finish, the ONE small launch that ends the CURRENT iteration's tail (second stages of |t|^2 and t'At,
+ * publication, and the step for the next iteration — until round 5 three second-stage launches and a launch for the step);
+ * pa_prelaunch_enqueue then puts the next iteration's streaming launches behind it and leaves ITS tail unfinished
+ * (s->pre_tail_deferred): whoever adopts that iteration finishes it, at the point where the decomposition of the iteration
+ * after it is known. */
+static int pa_prelaunch_prepare(pa_solver *s, int basisSize, int nLk, int col, int nfov, hipk_rr_in *in) {
    primme_params *p = s->p;
    const int k = basisSize, k1 = basisSize + 1;
-   s->pre_valid = 0;
+   (void)nfov;
    /* row-partitioned runs: only where every reduction of the pass is exchanged inside the second stage of the launch that forms
     * it (peer-to-peer transport, hipk_xreduce_arm) — the global sums are then in HBM for the next launch without the host; every
     * rank takes the same decisions from the same bits, so the ranks enqueue (and throw away) the same launches */
@@ -321,41 +327,55 @@ static int pa_prelaunch_next(pa_solver *s, int basisSize, int nLk, int col, int 
    if (nLk > 0 && !(s->wtq_L == nLk && s->wtq_rows >= k - 1)) return 0;
    const int nov1 = k1 + nLk, nfov1 = 2 * nov1 + 1;
    if (nfov1 + 8 > PA_ALPHA_OFF(s)) return 0;
-   hipk_rr_in in;
-   memset(&in, 0, sizeof(in));
-   in.k = k; in.L = nLk; in.cand = col; in.largest = (p->target == primme_largest);
-   in.grow_row = (nLk > 0 && s->wtq_rows == k - 1);
+   if (1 - s->spec_tcol >= s->nT) return 0;
+   memset(in, 0, sizeof(*in));
+   in->k = k; in->L = nLk; in->cand = col; in->largest = (p->target == primme_largest);
+   in->grow_row = (nLk > 0 && s->wtq_rows == k - 1);
    for (int i = 0; i < k; i++) {
-      in.theta[i] = s->hVals[i];
-      for (int r = 0; r < k; r++) in.Y[r + i * k] = s->hVecs[r + (size_t)i * k];
+      in->theta[i] = s->hVals[i];
+      for (int r = 0; r < k; r++) in->Y[r + i * k] = s->hVecs[r + (size_t)i * k];
    }
    for (int l = 0; l < nLk; l++)
-      for (int j = 0; j < k; j++) in.G[j + l * k] = s->wtq[j + (size_t)l * s->K];
+      for (int j = 0; j < k; j++) in->G[j + l * k] = s->wtq[j + (size_t)l * s->K];
+   return 1;
+}
+
+/* the streaming launches of iteration basisSize + 1; the Rayleigh-Ritz step has been enqueued (its pair will be in d_hnext).
+ * Returns 0 when enqueued (s->pre_valid set) or when a row-partitioned pass turned out unusable (s->pre_valid clear). */
+static int pa_prelaunch_enqueue(pa_solver *s, int basisSize, int nLk, int col, int rr_flagged) {
+   primme_params *p = s->p;
+   const int k1 = basisSize + 1;
+   s->pre_valid = 0;
+   const int xr = s->parallel && s->dev_comm && hipk_xreduce_available(s->ctx);
+   const int nov1 = k1 + nLk, nfov1 = 2 * nov1 + 1;
    const int tcol = 1 - s->spec_tcol;
-   if (tcol >= s->nT) return 0;
    char *dst1 = VCOL(s, k1);
-   CHK(hipk_rr_arrow(s->ctx, &in, s->d_fov, nfov, s->d_fov + PA_ALPHA_OFF(s), s->d_hnext));
    if (xr) hipk_xreduce_arm(s->ctx);
    CHK(hipk_ritz_residual_overlaps_dev(s->ctx, s->dt, s->m, s->V, s->W, s->ld, k1, s->d_hnext, dst1, s->evecs, s->ldevecs, nLk, 1, s->d_fov_alt));
-   /* the pair's pinned copy is looked at once the flagged second stage of this pass is through (the small kernel publishes
-    * no flag of its own: a system-scope fence and a PCIe write on the one chain of the iteration that has no slack) */
-   s->pre_seq_rr = hipk_seq_issued(s->ctx);
+   /* the pair's pinned copy may be looked at once a flagged launch behind the Rayleigh-Ritz step is through: the small launch
+    * that carried the step itself (rr_flagged: the caller has its sequence number), else the second stage of this pass */
+   if (!rr_flagged) s->pre_seq_rr = hipk_seq_issued(s->ctx);
    /* (a second stage that did not take the arm — sums that are not global — means this pass cannot be used: it is left to be
     * overwritten, on every rank alike) */
    if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt, nfov1)) return 0;
    hipk_seg segs[2] = {{s->V, s->ld, k1}, {s->evecs, s->ldevecs, nLk}};
+   /* the tail without second-stage launches of its own (hipk_tail_defer): with the library's own operator, whose one-launch
+    * form adds the partial sums of |t|^2 itself (one rank: row-partitioned runs need the global |t|^2 first) and leaves the
+    * second stage of t'At to hipk_tail_finish */
+   const int acc = (p->matrixMatvec == primme_amd_matvec) ? hipk_tail_defer(s->ctx, xr ? HIPK_TAIL_DOT : (HIPK_TAIL_NORM | HIPK_TAIL_DOT)) : 0;
    if (xr) hipk_xreduce_arm(s->ctx);
    CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov_alt, nov1, dst1, s->ld, TCOL(s, tcol), s->ld, 1, s->d_fov_alt + nfov1));
-   if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt + nfov1, 1)) return 0;
+   if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt + nfov1, 1)) { hipk_tail_abandon(s->ctx); return 0; }
    {
-      if (xr) hipk_xreduce_arm(s->ctx);
+      if (xr && !(acc & HIPK_TAIL_DOT)) hipk_xreduce_arm(s->ctx);
       int rc = (p->matrixMatvec == primme_amd_matvec)
              ? primme_amd_operator_apply_scaled((primme_amd_operator *)p->matrix, s->ctx, TCOL(s, tcol), s->d_fov_alt + nfov1, dst1, WCOL(s, k1), s->d_fov_alt + PA_ALPHA_OFF(s))
              : pa_svds_apply_scaled(p, s->ctx, TCOL(s, tcol), s->d_fov_alt + nfov1, dst1, WCOL(s, k1), s->d_fov_alt + PA_ALPHA_OFF(s));
-      if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
+      if (rc) { hipk_tail_abandon(s->ctx); return rc < 0 ? rc : PRIMME_USER_FAILURE; }
    }
-   s->pre_seq_end = hipk_seq_issued(s->ctx);
-   if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt + PA_ALPHA_OFF(s), 1)) return 0;
+   s->pre_tail_deferred = (hipk_tail_pending(s->ctx) & HIPK_TAIL_DOT) != 0;
+   s->pre_seq_end = hipk_seq_issued(s->ctx);       /* (tail not deferred: the flag of its last second stage) */
+   if (!s->pre_tail_deferred && xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt + PA_ALPHA_OFF(s), 1)) return 0;
    s->pre_valid = 1; s->pre_k = k1; s->pre_L = nLk; s->pre_cand = col; s->pre_nfov = nfov1; s->pre_tcol = tcol;
    s->pre_launched++;
    return 0;
@@ -396,14 +416,29 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
    const int fuse_tail = speculate2 && wtr && pa_fuse_tail_eligible(s);
    s->spec_fused = 0;
    if (adopted) {
-      /* this iteration was enqueued ahead of time (pa_prelaunch_next) and its pair is the host's: nothing to launch.  The
-       * NEXT one goes in behind it now, then the one wait for ITS last reduction, then the usual host arithmetic. */
-      const unsigned long long seq_end = s->pre_seq_end;
+      /* this iteration was enqueued ahead of time (pa_prelaunch_enqueue) and its pair is the host's: its streaming launches are
+       * in the stream.  What goes in behind them NOW: the one small launch that finishes its tail — with the Rayleigh-Ritz step
+       * of the NEXT iteration when that one can be enqueued too —, the next iteration's streaming launches, then the one wait
+       * for this tail's completion flag and the usual host arithmetic. */
+      const int xr = s->parallel && s->dev_comm && hipk_xreduce_available(s->ctx);
+      unsigned long long seq_end = s->pre_seq_end;
+      const int deferred = s->pre_tail_deferred;
       s->spec_tcol = s->pre_tcol;
       s->spec_fused = 1;
-      s->pre_valid = 0;
+      s->pre_valid = 0; s->pre_tail_deferred = 0;
       s->pre_adopted++;
-      CHK(pa_prelaunch_next(s, basisSize, nLk, col, nfov));
+      hipk_rr_in in;
+      const int go = pa_prelaunch_prepare(s, basisSize, nLk, col, nfov, &in);
+      if (deferred || go) {
+         if (xr && deferred) hipk_xreduce_arm(s->ctx);
+         CHK(hipk_tail_finish(s->ctx, go ? &in : NULL, s->d_fov, nfov, s->d_fov + PA_ALPHA_OFF(s), s->d_hnext));
+         if (deferred) {
+            seq_end = hipk_seq_issued(s->ctx);
+            if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov + PA_ALPHA_OFF(s), 1)) return PRIMME_PARALLEL_FAILURE;
+         }
+      }
+      s->pre_seq_rr = seq_end;
+      if (go) CHK(pa_prelaunch_enqueue(s, basisSize, nLk, col, deferred));
       CHK(hipk_wait_seq(s->ctx, seq_end));
       if (s->parallel) {                             /* the three exchanges of the adopted pass (residual overlaps, |t|^2, t'At) */
          if (s->dev_comm && pa_comm_failed(p->commInfo)) return PRIMME_PARALLEL_FAILURE;
@@ -420,6 +455,11 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
     * forms it (hipk_xreduce_arm), so the tail keeps its one-rank shape — |t|^2 stays on the device, the operator
     * launch normalises on the fly, no scaling launches — and costs no reduction launch at all */
    const int xr = s->parallel && s->dev_comm && hipk_xreduce_available(s->ctx);
+   /* Row-partitioned runs on the library's communicator: |t|^2 and t'At travel in ONE all-reduce (see below) */
+   const int merge_red = fuse_tail && s->parallel && s->dev_comm && !xr;
+   /* the one-launch tail of the library's own operator without second-stage launches of its own (hipk_tail_defer) */
+   const int acc = (fuse_tail && speculate2 && !merge_red && p->matrixMatvec == primme_amd_matvec)
+                 ? hipk_tail_defer(s->ctx, xr ? HIPK_TAIL_DOT : (HIPK_TAIL_NORM | HIPK_TAIL_DOT)) : 0;
    if (xr) hipk_xreduce_arm(s->ctx);
    CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, rsrc, s->ld,
               fuse_tail ? TCOL(s, 0) : dstc, s->ld, 1, s->d_fov + nfov));
@@ -427,7 +467,6 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
     * The operator is applied to the un-normalised t (no scaling in the launch), both numbers are
     * reduced together, and V(:,k), W(:,k) are scaled afterwards with the value the host then has:
     * two all-reduces per outer iteration instead of three (each is latency, not bandwidth). */
-   const int merge_red = fuse_tail && s->parallel && s->dev_comm && !xr;
    if (speculate2 && merge_red) {
       rc = fused_apply(s, TCOL(s, 0), NULL, dstc, WCOL(s, basisSize), s->d_fov + nfov + 1);
       if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
@@ -458,15 +497,27 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
           * from the scratch column and rebuilding V(:,k) on the way; t'At goes to the alpha slot of the overlap buffer.
           * Before the one wait the NEXT iteration is enqueued behind this one (pa_prelaunch_next), so the wait is for this
           * tail's own completion flag, not for the last launch of the stream. */
-         if (xr) hipk_xreduce_arm(s->ctx);
+         if (xr && !(acc & HIPK_TAIL_DOT)) hipk_xreduce_arm(s->ctx);
          rc = fused_apply(s, TCOL(s, 0), s->d_fov + nfov, dstc, WCOL(s, basisSize), s->d_fov + PA_ALPHA_OFF(s));
-         if (rc) return rc < 0 ? rc : PRIMME_USER_FAILURE;
+         if (rc) { hipk_tail_abandon(s->ctx); return rc < 0 ? rc : PRIMME_USER_FAILURE; }
          s->spec_fused = 1;
+         /* the one small launch that finishes this tail (+ the Rayleigh-Ritz step of the next iteration when that one is
+          * enqueued behind it), or — nothing deferred — that step as a launch of its own behind the usual second stages */
+         const int deferred = (hipk_tail_pending(s->ctx) & HIPK_TAIL_DOT) != 0;
+         hipk_rr_in in;
+         const int go = pa_prelaunch_prepare(s, basisSize, nLk, col, nfov, &in);
+         if (deferred || go) {
+            if (xr && deferred) hipk_xreduce_arm(s->ctx);
+            CHK(hipk_tail_finish(s->ctx, go ? &in : NULL, s->d_fov, nfov, s->d_fov + PA_ALPHA_OFF(s), s->d_hnext));
+         }
          const unsigned long long seq_end = hipk_seq_issued(s->ctx);
-         CHK(pa_prelaunch_next(s, basisSize, nLk, col, nfov));
-         if (s->pre_valid) {
+         s->pre_seq_rr = seq_end;
+         s->pre_valid = 0; s->pre_tail_deferred = 0;
+         if (go) CHK(pa_prelaunch_enqueue(s, basisSize, nLk, col, deferred));
+         if (go) {                                   /* launches are queued behind the one whose flag is wanted */
             CHK(hipk_wait_seq(s->ctx, seq_end));
             if (xr) {
+               (void)hipk_xreduce_covered(s->ctx, s->d_fov + PA_ALPHA_OFF(s), 1);
                if (pa_comm_failed(p->commInfo)) return PRIMME_PARALLEL_FAILURE;
                p->stats.numGlobalSum++;
                p->stats.volumeGlobalSum++;
@@ -676,7 +727,7 @@ int pa_prepare_candidates(pa_solver *s, int basisSize, char *X, char *R, int com
             }
          }
          if (!adopted) {
-            s->pre_valid = 0;
+            pa_pre_discard(s);
             if (s->parallel && s->dev_comm) hipk_xreduce_arm(s->ctx);
             if ((rc = hipk_ritz_residual_overlaps(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize,
                        s->hVecs + (size_t)col * ldh, s->hVals[col], dstc, s->evecs, s->ldevecs, nLk, wtr, s->d_fov))) goto out;

@@ -171,7 +171,7 @@ int pa_precond(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc)
  * consecutive numbers of the stream, (re, im), as zlarnv does) */
 int pa_random_col(pa_solver *s, char *col) {
    s->fov_valid = 0;
-   s->pre_valid = 0;
+   pa_pre_discard(s);
    /* generated on the device (hipk_larnv_uniform11): the same stream, nothing crosses PCIe */
    int64_t seed[4] = {s->p->iseed[0], s->p->iseed[1], s->p->iseed[2], s->p->iseed[3]};
    CHK(hipk_larnv_uniform11(s->ctx, s->dt, seed, s->m * SD, col));
@@ -208,7 +208,7 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
    if (b2_out) *b2_out = b1;
    /* overlaps left by the fused residual pass (or carried over a restart) belong to ONE column */
    if (s->fov_valid && !(b1 == b2 && b1 == s->fov_k && Vp == s->V)) { s->fov_valid = 0; s->spec2_valid = 0; }
-   if (!(b1 == b2 && s->fov_valid)) s->pre_valid = 0;      /* an iteration enqueued ahead assumed the tail of THIS column stands */
+   if (!(b1 == b2 && s->fov_valid)) pa_pre_discard(s);      /* an iteration enqueued ahead assumed the tail of THIS column stands */
    s->fov_carry = 0;
 
    for (int i = b1; i <= b2; i++) {
@@ -258,7 +258,7 @@ int pa_ortho_cgs(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, char *lock
          /* the speculative tail (normalise on device, operator, projection) stands only if THIS
           * first pass is the last one */
          const int tail_done = speculated && s->spec2_valid && s->spec2_k == i && b1 == b2;
-         if (!tail_done) { s->spec2_valid = 0; s->pre_valid = 0; }
+         if (!tail_done) { s->spec2_valid = 0; pa_pre_discard(s); }
          /* fused tail (eigs_conv.c): v holds the NORMALISED vector, the projected un-normalised one is in
           * T(:,0); whenever the tail is not accepted as it stands it goes back into v first */
          const int fused_pending = speculated && s->spec_fused;

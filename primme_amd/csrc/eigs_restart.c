@@ -683,7 +683,7 @@ int pa_restart(pa_solver *s, int basisSize, int *flags, int *iev, int *ievSize, 
       s->fov_valid = 0;
       s->fov_carry = 0;
       s->rst_ready = 0;
-      s->pre_valid = 0;        /* an iteration enqueued ahead of the host belongs to the basis that is being replaced */
+      pa_pre_discard(s);        /* an iteration enqueued ahead of the host belongs to the basis that is being replaced */
    }
 
    for (i = 0, *numConverged = *numLocked; i < basisSize; i++) {

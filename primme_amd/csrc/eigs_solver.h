@@ -121,6 +121,7 @@ typedef struct pa_solver {
    double *d_fov_alt, *h_fov_alt;
    double *d_hnext, *h_hnext;     /* hipk_rr_arrow's output: coefficient vector [0..k], Ritz value [32], status [33] */
    int pre_valid, pre_k, pre_L, pre_cand, pre_nfov, pre_tcol;
+   int pre_tail_deferred;  /* the pre-enqueued iteration left its tail to hipk_tail_finish (whoever adopts it launches that) */
    unsigned long long pre_seq_rr, pre_seq_end;   /* flags to wait for: the small kernel's, the pass' last reduction's */
    int spec_tcol;          /* scratch column holding the projected, un-normalised vector of the tail that is pending */
    long pre_launched, pre_adopted;
@@ -138,6 +139,11 @@ typedef struct pa_solver {
 
 /* error propagation; with PRIMME_AMD_TRACE_ERRORS set the failing call chain is printed, the
  * counterpart of the reference's CHKERR trace (src/include/common.h:437-470) */
+/* an iteration enqueued ahead of the host is not going to be used: forget it and the tail it left unfinished (eigs_conv.c) */
+static inline void pa_pre_discard(pa_solver *s) {
+   if (s->pre_valid && s->pre_tail_deferred) hipk_tail_abandon(s->ctx);
+   s->pre_valid = 0; s->pre_tail_deferred = 0;
+}
 int pa_trace_errors(void);
 #define CHK(call) do { int rc_ = (call); if (rc_) { \
       if (pa_trace_errors()) fprintf(stderr, "primme_amd: error %d at %s:%d: %s\n", rc_, __FILE__, __LINE__, #call); \

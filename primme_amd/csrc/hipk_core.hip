@@ -43,6 +43,7 @@ extern "C" int hipk_ctx_create(hipk_ctx **out, void *stream_or_null) {
       HIPK_CHECK(hipMemsetAsync(ctx->fin_counter, 0, cbytes, ctx->stream));   /* ordered before every kernel of this context */
       HIPK_CHECK(hipStreamSynchronize(ctx->stream));
       ctx->arrive_counter = ctx->fin_counter + 8;
+      HIPK_CHECK(hipMalloc((void **)&ctx->tailp, sizeof(double) * HIPK_TAIL_MAXPART));
       ctx->seq_issued = 0;
       ctx->spin_wait = getenv("HIPK_NO_SPINWAIT") == NULL;
       ctx->host_timing = getenv("HIPK_HOST_TIMING") != NULL;
@@ -61,6 +62,7 @@ extern "C" int hipk_ctx_destroy(hipk_ctx *ctx) {
    if (ctx->partials) (void)hipFree(ctx->partials);
    if (ctx->jobtab) (void)hipFree(ctx->jobtab);
    if (ctx->fin_counter) (void)hipFree(ctx->fin_counter);
+   if (ctx->tailp) (void)hipFree(ctx->tailp);
    if (ctx->stage) (void)hipHostFree(ctx->stage);
    if (ctx->flag_host) (void)hipHostFree((void *)ctx->flag_host);
    (void)hipEventDestroy(ctx->ev0);
@@ -436,6 +438,20 @@ int hipk_inkernel_fin_mask(void) {
    return g_fin_mask;
 }
 extern "C" int hipk_set_inkernel_fin(int mask) { const int old = hipk_inkernel_fin_mask(); g_fin_mask = mask & 7; return old; }
+
+/* ---- the iteration tail without its own second-stage launches (primme_amd_kernels.h: hipk_tail_defer) ---- */
+static int g_tail_off = -1;
+extern "C" int hipk_tail_defer(hipk_ctx *ctx, int want) {
+   if (g_tail_off < 0) g_tail_off = getenv("HIPK_NO_TAIL_DEFER") != NULL;      /* A/B knob: the round-5 sequence of launches */
+   ctx->tail_want = 0; ctx->tail_np2 = 0; ctx->tail_np3 = 0; ctx->tail_norm2_out = NULL; ctx->tail_dot_out = NULL;
+   if (g_tail_off || !ctx->tailp || hipk_inkernel_fin_mask()) return 0;
+   ctx->tail_want = want & (HIPK_TAIL_NORM | HIPK_TAIL_DOT);
+   return ctx->tail_want;
+}
+extern "C" void hipk_tail_abandon(hipk_ctx *ctx) {
+   ctx->tail_want = 0; ctx->tail_np2 = 0; ctx->tail_np3 = 0; ctx->tail_norm2_out = NULL; ctx->tail_dot_out = NULL;
+}
+extern "C" int hipk_tail_pending(hipk_ctx *ctx) { return (ctx->tail_np2 > 0 ? HIPK_TAIL_NORM : 0) | (ctx->tail_np3 > 0 ? HIPK_TAIL_DOT : 0); }
 
 /* ---- cross-rank second stage (see hipk_internal.h: hipk_ctx.xr) ---- */
 extern "C" void hipk_xreduce_arm(hipk_ctx *ctx) { if (ctx->xr) ctx->xr_armed = 1; }

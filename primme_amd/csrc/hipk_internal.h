@@ -55,7 +55,16 @@ struct hipk_ctx {
    int xr_armed;
    const double *xr_lo;
    int xr_count;
+   /* the tail of a block-size-1 iteration without its own second-stage launches (round 6, hipk_tail_defer / hipk_tail_finish in
+    * include/primme_amd_kernels.h): the partial sums of |t|^2 stay in `tailp` (the operator launch adds them itself), those of
+    * t'At in `partials`, and ONE small launch later adds both, publishes them and runs the Rayleigh-Ritz step of the next
+    * iteration */
+   double *tailp;                            /* device, HIPK_TAIL_MAXPART doubles */
+   int tail_want;                            /* flags of the armed deferral (one-shot), 0: none */
+   int tail_np2, tail_np3;                   /* partial sums waiting in tailp / partials (0: none) */
+   double *tail_norm2_out, *tail_dot_out;    /* where the sums belong */
 };
+#define HIPK_TAIL_MAXPART 4096
 
 /* what a kernel needs to take part in a mailbox reduction; filled by pa_ipc_xreduce_args */
 #define HIPK_XR_MAXRANKS 16
@@ -372,6 +381,26 @@ __device__ __forceinline__ double hipk_wave_sum(double v) {
    return v;
 }
 __device__ __forceinline__ double hipk_wave_sum_fwd(double v) { return hipk_wave_sum(v); }
+
+/* Sum of n partial sums another launch left in HBM, by the first 256 threads of a workgroup, in an order that depends on n
+ * only: thread t adds p[t], p[t + 256], ... , the four waves add their lanes (hipk_wave_sum) and leave their sums in sm4;
+ * after a barrier hipk_block_sum256_get gives every thread the same bits.  Every workgroup of the operator launch that
+ * normalises with |t|^2 and the one-workgroup launch that publishes |t|^2 to the host use THIS order, so the number the host
+ * sees is the number the vector was scaled with.  Threads >= 256 (a wider finishing launch) pass through. */
+__device__ __forceinline__ void hipk_block_sum256_put(const double *__restrict__ p, int n, double *sm4) {
+   if (threadIdx.x < 256) {
+      double s = 0.0;
+      int i = (int)threadIdx.x;
+      for (; i + 768 < n; i += 1024) {
+         const double a0 = p[i], a1 = p[i + 256], a2 = p[i + 512], a3 = p[i + 768];
+         s += a0; s += a1; s += a2; s += a3;
+      }
+      for (; i < n; i += 256) s += p[i];
+      s = hipk_wave_sum(s);
+      if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = s;
+   }
+}
+__device__ __forceinline__ double hipk_block_sum256_get(const double *sm4) { return (sm4[0] + sm4[1]) + (sm4[2] + sm4[3]); }
 #endif
 
 #endif

@@ -448,6 +448,7 @@ extern "C" int hipk_panel_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hi
 
 /* ===================== NN-accumulate: project + norms ========================= */
 #define PROJ_MAXCOLS 192
+#define FIN_TAIL_MAXBLOCK 1024
 template <typename T, int NX, int VW>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 project_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *X,
@@ -675,8 +676,11 @@ static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
    /* one launch covers all columns: its last workgroup finalises the norms itself */
    hipk_fin_args fa;
    memset(&fa, 0, sizeof(fa));
-   if (nrm2_dev && (nx == 1 || nx == 2 || nx == 4 || nx == 8)) fa = hipk_make_fin(ctx, nrm2_dev, HIPK_FIN_PROJECT, gx, nx);
-   double *part = nrm2_dev ? ctx->partials : NULL;      /* after hipk_make_fin: it may have grown the buffer */
+   /* the tail of a block-size-1 iteration (hipk_tail_defer): the partial sums of |t|^2 stay where the operator launch and
+    * hipk_tail_finish add them up themselves — no second-stage launch here */
+   const bool defer = nrm2_dev && nx == 1 && (ctx->tail_want & HIPK_TAIL_NORM) && ctx->tail_np2 == 0 && gx <= HIPK_TAIL_MAXPART;
+   if (!defer && nrm2_dev && (nx == 1 || nx == 2 || nx == 4 || nx == 8)) fa = hipk_make_fin(ctx, nrm2_dev, HIPK_FIN_PROJECT, gx, nx);
+   double *part = defer ? ctx->tailp : (nrm2_dev ? ctx->partials : NULL);      /* after hipk_make_fin: it may have grown the buffer */
    const int pslot = hipk_prof_begin(HIPK_PROF_PROJECT, ctx->stream, (double)m * sizeof(T) * ((double)sa.total * ((nx + 7) / 8) + 2.0 * nx));
    for (int c0 = 0; c0 < nx;) {
       int rem = nx - c0;
@@ -689,6 +693,7 @@ static int panel_project_v(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const do
       c0 += step;
    }
    hipk_prof_end(pslot, ctx->stream);
+   if (defer) { ctx->tail_np2 = gx; ctx->tail_norm2_out = nrm2_dev; return 0; }
    if (nrm2_dev && !fa.enabled) return hipk_finalize_partials_t(ctx, ctx->partials, gx, nx, nrm2_dev);
    return 0;
 }
@@ -1519,14 +1524,28 @@ __device__ __forceinline__ double rr_sum16(const double *s) {
    for (int i = 0; i < 16; i++) a += s[i];
    return a;
 }
-__global__ void __launch_bounds__(64)
-rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const double *__restrict__ alpha_dev,
-      double *__restrict__ out, double *__restrict__ out_host) {
+/* what the Rayleigh-Ritz step keeps in LDS */
+struct RrShared { double sY[256], sG[160], sTh[16], sF[128], s_v[16], s_w[16], s_y[16]; };
+/* the step is run by ONE wave: as a launch of its own (a 64-thread workgroup: __syncthreads) or as the last part of the
+ * one-workgroup launch that finishes an iteration's tail (wave 0 of a wider workgroup: the LDS traffic of a single wave is
+ * ordered by itself, the fences keep the compiler from moving an access across the point) */
+struct RrSyncBlock { __device__ static __forceinline__ void sync() { __syncthreads(); } };
+struct RrSyncWave {
+   __device__ static __forceinline__ void sync() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+   }
+};
+/* lane = 0..63 of the one wave; n2 = |t|^2 and alpha = t'At of the iteration whose reductions are in fov[0 .. nfov) */
+template <class SY>
+__device__ __forceinline__ void rr_arrow_body(const hipk_rr_in &in, const double *__restrict__ fov, int nfov, double n2, double alpha,
+      RrShared &S, double *__restrict__ out, double *__restrict__ out_host, const int lane) {
    /* The kernel arguments live in host-visible memory on this stack: indexed, per-lane reads of `in` would each be a trip over
     * PCIe (the first version of this kernel did that in its loops and took longer than the host round trip it replaces).
     * Everything is brought into LDS with ONE batch of loads — the arguments and this iteration's reductions together. */
-   __shared__ double sY[256], sG[160], sTh[16], sF[128], s_v[16], s_w[16], s_y[16];
-   const int lane = threadIdx.x, j = lane & 15, k = in.k, L = in.L;
+   double *sY = S.sY, *sG = S.sG, *sTh = S.sTh, *sF = S.sF, *s_v = S.s_v, *s_w = S.s_w, *s_y = S.s_y;
+   const int j = lane & 15, k = in.k, L = in.L;
    const bool on = lane < 16 && j < k;
    {
       double ty[4], tg[3], tf[2];
@@ -1536,8 +1555,7 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
       for (int u = 0; u < 3; u++) tg[u] = (lane + 64 * u < 160) ? in.G[lane + 64 * u] : 0.0;
       const double tt = in.theta[j];
 #pragma unroll
-      for (int u = 0; u < 2; u++) tf[u] = (lane + 64 * u <= nfov) ? fov[lane + 64 * u] : 0.0;
-      const double ta = alpha_dev[0];
+      for (int u = 0; u < 2; u++) tf[u] = (lane + 64 * u < nfov) ? fov[lane + 64 * u] : 0.0;
 #pragma unroll
       for (int u = 0; u < 4; u++) sY[lane + 64 * u] = ty[u];
 #pragma unroll
@@ -1545,11 +1563,10 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
       if (lane < 16) sTh[lane] = tt;
 #pragma unroll
       for (int u = 0; u < 2; u++) sF[lane + 64 * u] = tf[u];
-      if (lane == 0) s_y[0] = ta;              /* (s_y is reused below) */
    }
-   __syncthreads();
+   SY::sync();
    const double sgn = in.largest ? -1.0 : 1.0;
-   const double n2 = sF[nfov], nt = sqrt(n2), alpha = s_y[0];
+   const double nt = sqrt(n2);
    const double cv = on ? sF[j] : 0.0;                        /* V'r */
    const double wr = on ? sF[k + L + 1 + j] : 0.0;            /* W'r */
    double gq = 0.0;                                           /* (G Q'r)_j */
@@ -1558,9 +1575,9 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
       gq = on ? fma(g, sF[k + l], gq) : 0.0;
    }
    /* z_i = (Y(:,i)'(W'r - G Q'r) - theta_i Y(:,i)'(V'r)) / |t| */
-   __syncthreads();
+   SY::sync();
    if (lane < 16) { s_v[lane] = on ? wr - gq : 0.0; s_w[lane] = cv; }
-   __syncthreads();
+   SY::sync();
    double a1 = 0.0, a2 = 0.0;
    for (int r = 0; r < k; r++) { const double yv = sY[r + j * k]; a1 = fma(yv, s_v[r], a1); a2 = fma(yv, s_w[r], a2); }
    const double thj = on ? sTh[j] : 0.0;
@@ -1569,9 +1586,9 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
    const double z2 = z * z;
    const int c = in.cand;
    int status = (k < 1 || k > 16 || L < 0 || L > 10 || c < 0 || c > k || nfov > 126 || !(n2 > 0.0)) ? 1 : 0;
-   __syncthreads();
+   SY::sync();
    if (lane < 16) { s_v[lane] = on ? th : 0.0; s_w[lane] = z2; }
-   __syncthreads();
+   SY::sync();
    /* poles strictly increasing, everything finite (every lane looks at all of them: uniform control flow) */
    double zn2 = 0.0;
    for (int i = 0; i < k; i++) {
@@ -1613,9 +1630,9 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
       for (; it < 100; it++) {
          const double r = 1.0 / (dj - mu);
          const double t = mine ? z2 * r : 0.0;
-         __syncthreads();
+         SY::sync();
          if (lane < 16) { s_y[lane] = t; sF[lane] = mine ? t * r : 0.0; }
-         __syncthreads();
+         SY::sync();
          const double S = rr_sum16(s_y), Sp = rr_sum16(sF);
          const double pole = B / mu, g = a0 - mu - S + pole;
          if (!(g == g)) { status = 3; break; }
@@ -1636,17 +1653,17 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
       if (it >= 100) status = 4;
       lam = sgn * (tho + mu);
       yj = on ? z / (mu - dj) : 0.0;                              /* eigenvector [y; 1] of the (possibly negated) arrowhead */
-      __syncthreads();
+      SY::sync();
       if (lane < 16) s_y[lane] = yj * yj;
-      __syncthreads();
+      SY::sync();
       ynorm2 = 1.0 + rr_sum16(s_y);
       if (!isfinite(lam) || !isfinite(ynorm2)) status = 5;
    }
    /* back to the basis [V t]: h = [Y y; 1] / |[y; 1]| */
    const double inv = 1.0 / sqrt(ynorm2);
-   __syncthreads();
+   SY::sync();
    if (lane < 16) s_y[lane] = yj;
-   __syncthreads();
+   SY::sync();
    double hv = 0.0;
    for (int i = 0; i < k; i++) hv = fma(sY[j + i * k], s_y[i], hv);
    hv *= inv;
@@ -1657,6 +1674,14 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
          if (out_host) { out_host[k] = inv; out_host[32] = lam; out_host[33] = (double)status; }
       }
    }
+}
+
+__global__ void __launch_bounds__(64)
+rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const double *__restrict__ alpha_dev,
+      double *__restrict__ out, double *__restrict__ out_host) {
+   __shared__ RrShared S;
+   const double n2 = fov[nfov], alpha = alpha_dev[0];
+   rr_arrow_body<RrSyncBlock>(in, fov, nfov, n2, alpha, S, out, out_host, (int)threadIdx.x);
    /* no completion flag of its own: the host looks at the pinned copy after the flagged second stage of the residual pass that
     * follows in the stream (a kernel boundary on the queue lies in between) */
 }
@@ -1664,6 +1689,85 @@ extern "C" int hipk_rr_arrow(hipk_ctx *ctx, const hipk_rr_in *in, const double *
    if (!in || in->k < 1 || in->k > 16 || in->L < 0 || in->L > 10) return -1;
    if (nfov > 126) return -1;
    hipLaunchKernelGGL(rr_arrow_kernel, dim3(1), dim3(64), 0, ctx->stream, *in, fov_dev, nfov, alpha_dev, out_dev, hipk_mirror_of(ctx, out_dev));
+   HIPK_CHECK(hipGetLastError());
+   return 0;
+}
+
+/* ---- the ONE small launch that finishes the tail of a block-size-1 iteration (hipk_tail_defer / hipk_tail_finish) ----
+ * np2 partial sums of |t|^2 (left by the Gram-Schmidt update; already added up, in the same order, by every workgroup of the
+ * operator launch that normalised with them) and np3 partial sums of t'At (left by that operator launch) -> their sums in HBM
+ * and in the pinned mirror; row-partitioned runs on the peer-to-peer transport exchange t'At with the other ranks here; then —
+ * when the next iteration is enqueued behind this one — the Rayleigh-Ritz step of that iteration (rr_arrow_body: what
+ * rr_arrow_kernel does as a launch of its own), and the completion flag last.  Replaces two second-stage launches and the
+ * one-wave launch: three kernel boundaries and ~10 us less per outer iteration. */
+template <bool XR>
+__global__ void __launch_bounds__(FIN_TAIL_MAXBLOCK)
+tail_finish_kernel(const double *__restrict__ p2, int np2, const double *__restrict__ p3, int np3, double *__restrict__ norm2_out,
+      double *__restrict__ norm2_host, double *__restrict__ dot_out, double *__restrict__ dot_host, hipk_fin_flag fin, hipk_xr_dev xr,
+      int do_rr, hipk_rr_in in, const double *__restrict__ fov, int nfov, double *__restrict__ rr_out, double *__restrict__ rr_host) {
+   __shared__ double sm2[4], sm3[FIN_TAIL_MAXBLOCK / HIPK_WAVE];
+   __shared__ RrShared S;
+   if (np2 > 0) hipk_block_sum256_put(p2, np2, sm2);
+   {  /* t'At: the order of hipk_finalize_kernel (one output) at the same workgroup size — the bits of the separate launch */
+      const int nt = blockDim.x;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int b = threadIdx.x;
+      for (; b + 3 * nt < np3; b += 4 * nt) {
+         const double a0 = p3[b], a1 = p3[b + nt], a2 = p3[b + 2 * nt], a3 = p3[b + 3 * nt];
+         s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      }
+      {
+         const int last = np3 - 1;
+         const int b0 = b, b1 = b + nt, b2 = b + 2 * nt;
+         const double a0 = p3[b0 < last ? b0 : last], a1 = p3[b1 < last ? b1 : last], a2 = p3[b2 < last ? b2 : last];
+         s0 += b0 < np3 ? a0 : 0.0; s1 += b1 < np3 ? a1 : 0.0; s2 += b2 < np3 ? a2 : 0.0;
+      }
+      const double s = hipk_wave_sum((s0 + s1) + (s2 + s3));
+      if ((threadIdx.x & 63) == 0) sm3[threadIdx.x >> 6] = s;
+   }
+   __syncthreads();
+   if (threadIdx.x >= 64) return;
+   double v3 = 0.0;
+   {
+      const int nw = blockDim.x >> 6;
+      for (int w = 0; w < nw; w++) v3 += sm3[w];
+   }
+   const double v2 = np2 > 0 ? hipk_block_sum256_get(sm2) : 0.0;
+   if (XR) v3 = hipk_xr_exchange(xr, 0u, v3, threadIdx.x < 16);
+   if (threadIdx.x == 0) {
+      dot_out[0] = v3;
+      if (dot_host) dot_host[0] = v3;
+      if (np2 > 0) { norm2_out[0] = v2; if (norm2_host) norm2_host[0] = v2; }
+   }
+   if (do_rr) rr_arrow_body<RrSyncWave>(in, fov, nfov, np2 > 0 ? v2 : fov[nfov], v3, S, rr_out, rr_host, (int)threadIdx.x);
+   if (threadIdx.x == 0) hipk_publish_flag(fin, 1u);
+}
+
+extern "C" int hipk_tail_finish(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov_dev, int nfov, const double *alpha_dev, double *hnext_out) {
+   const int np2 = ctx->tail_np2, np3 = ctx->tail_np3;
+   double *n2o = ctx->tail_norm2_out, *doto = ctx->tail_dot_out;
+   hipk_tail_abandon(ctx);
+   if (in && (in->k < 1 || in->k > 16 || in->L < 0 || in->L > 10 || nfov > 126 || !hnext_out)) return -1;
+   if (np3 <= 0) {
+      /* t'At was not deferred (another operator path, the CPU checker): finish |t|^2 if it is still waiting, then the
+       * Rayleigh-Ritz step as a launch of its own */
+      if (np2 > 0) { const int rc = hipk_finalize_partials_t(ctx, ctx->tailp, np2, 1, n2o); if (rc) return rc; }
+      if (in) return hipk_rr_arrow(ctx, in, fov_dev, nfov, alpha_dev, hnext_out);
+      return 0;
+   }
+   if (in && (alpha_dev != doto || (np2 > 0 && fov_dev + nfov != n2o))) return -1;
+   const hipk_xr_dev xr = hipk_xr_take(ctx, doto, 1);
+   if (xr.tab && np2 > 0) return -1;            /* |t|^2 of a row-partitioned run must be global before the operator launch */
+   const hipk_fin_flag ff = hipk_next_flag(ctx, doto);
+   const int nt = np3 <= 1024 ? HIPK_BLOCK : (np3 <= 2048 ? 512 : FIN_TAIL_MAXBLOCK);      /* = fin_block_for (hipk_core.hip) */
+   hipk_rr_in none;
+   if (!in) memset(&none, 0, sizeof(none));
+   if (xr.tab)
+      hipLaunchKernelGGL((tail_finish_kernel<true>), dim3(1), dim3(nt), 0, ctx->stream, ctx->tailp, np2, ctx->partials, np3, n2o, np2 > 0 ? hipk_mirror_of(ctx, n2o) : NULL,
+            doto, hipk_mirror_of(ctx, doto), ff, xr, in ? 1 : 0, in ? *in : none, fov_dev, nfov, hnext_out, in ? hipk_mirror_of(ctx, hnext_out) : NULL);
+   else
+      hipLaunchKernelGGL((tail_finish_kernel<false>), dim3(1), dim3(nt), 0, ctx->stream, ctx->tailp, np2, ctx->partials, np3, n2o, np2 > 0 ? hipk_mirror_of(ctx, n2o) : NULL,
+            doto, hipk_mirror_of(ctx, doto), ff, xr, in ? 1 : 0, in ? *in : none, fov_dev, nfov, hnext_out, in ? hipk_mirror_of(ctx, hnext_out) : NULL);
    HIPK_CHECK(hipGetLastError());
    return 0;
 }

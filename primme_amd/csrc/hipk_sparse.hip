@@ -52,7 +52,7 @@ struct hipk_pb;
 struct hipk_pat;
 extern "C" int hipk_pat_build(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int64_t row0, const int32_t *rp, const int32_t *ci, const void *val, hipk_pat **out);
 extern "C" int hipk_pat_matvec(const hipk_pat *B, void *hip_stream, int gx, const void *x, void *y, int64_t halo_lo, int64_t halo_hi, const void *xlo,
-      const void *xhi, const double *norm2, void *xout, double *partials, const hipk_fin_args *fa);
+      const void *xhi, const double *norm2, int np2, void *xout, double *partials, const hipk_fin_args *fa);
 extern "C" void hipk_pat_destroy(hipk_pat *B);
 extern "C" int hipk_pat_grid(const hipk_pat *B, int num_cu);
 extern "C" double hipk_pat_bytes(const hipk_pat *B, int fused);
@@ -654,8 +654,11 @@ static int csr_create_impl(hipk_ctx *ctx, hipk_dtype dt, int64_t nrows_local,
    }
    /* rows that repeat (constant-coefficient stencils, lattice operators): one byte per row + a pattern table serves the
     * one-column products (hipk_sparse_pat.hip); the offsets are taken against the row, so the input entries must be
-    * numbered like the rows (square operators, row slabs with halos) */
-   if (x0 == row0 && (dt == HIPK_F64 || dt == HIPK_F32) && !A->pb) {
+    * numbered like the rows AND be as many as the rows (square operators, row slabs with halos): pat_kernel sizes its x
+    * descriptor, its end-of-vector test and the own-row reads of its padded table entries from nrows, so a rectangular
+    * operator (hipk_csr_create_rect: x0 == row0 == 0 but xlen != nrows — A and A' of the singular value problem when the
+    * panel-blocked builder declines) must stay on the row tiles */
+   if (x0 == row0 && xlen == nrows_local && (dt == HIPK_F64 || dt == HIPK_F32) && !A->pb) {
       const int rcp = hipk_pat_build(ctx, dt, nrows_local, row0, rowptr_host, colind_host, values_host, &A->pat);
       if (rcp < 0) return rcp;
    }
@@ -793,7 +796,7 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
    static int pb_maxcols = -1;       /* HIPK_PB_MAXCOLS: widest block served column by column through the panel-blocked form */
    if (pb_maxcols < 0) { const char *e = getenv("HIPK_PB_MAXCOLS"); pb_maxcols = e ? atoi(e) : 2; }
    if (A->pat && hipk_pat_enabled() && ncols == 1 && !shift_host) {
-      const int rc = hipk_pat_matvec(A->pat, stream, hipk_pat_grid(A->pat, ctx->num_cu), x, y, A->halo_lo, A->halo_hi, A->xlo, A->xhi, NULL, NULL,
+      const int rc = hipk_pat_matvec(A->pat, stream, hipk_pat_grid(A->pat, ctx->num_cu), x, y, A->halo_lo, A->halo_hi, A->xlo, A->xhi, NULL, 0, NULL,
             NULL, NULL);
       hipk_prof_end(pslot, stream);
       return rc;
@@ -909,6 +912,8 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    hipStream_t st = ctx->stream;
    if ((A->halo_lo > 0 && !A->xlo) || (A->halo_hi > 0 && !A->xhi)) return -1;
    if (A->nrows == 0) {      /* an empty slab: the result is 0; no flagged launch, so the next wait drains the stream */
+      ctx->tail_want = 0;
+      if (ctx->tail_np2 > 0) { const int np = ctx->tail_np2; ctx->tail_np2 = 0; if (hipk_finalize_partials_t(ctx, ctx->tailp, np, 1, ctx->tail_norm2_out)) return -1; }
       HIPK_CHECK(hipMemsetAsync(dot_dev, 0, sizeof(double), st));
       double *mh = hipk_mirror_of(ctx, dot_dev);
       if (mh) { HIPK_CHECK(hipStreamSynchronize(st)); *mh = 0.0; }
@@ -919,12 +924,29 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    const int gx = pat ? hipk_pat_grid(A->pat, ctx->num_cu) : ((A->ntiles + 7) / 8) * 8;
    if (hipk_reserve_partials(ctx, (size_t)gx)) return -2;
    const double es = A->dt == HIPK_F64 ? 8 : 4;
-   const hipk_fin_args fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV, gx, 1);
+   /* the tail of a block-size-1 iteration without second-stage launches (hipk_tail_defer): |t|^2 may still be np2 partial sums
+    * (only the row-pattern kernel adds them itself; any other form gets them finished the separate way first), and the second
+    * stage of t'At may be left to hipk_tail_finish */
+   int np2 = 0;
+   if (ctx->tail_np2 > 0) {
+      if (pat && norm2_dev == ctx->tail_norm2_out) np2 = ctx->tail_np2;
+      else {
+         const int np = ctx->tail_np2;
+         ctx->tail_np2 = 0;
+         const int rc = hipk_finalize_partials_t(ctx, ctx->tailp, np, 1, ctx->tail_norm2_out);
+         if (rc) return rc;
+      }
+   }
+   const bool defer_dot = (ctx->tail_want & HIPK_TAIL_DOT) && ctx->tail_np3 == 0 && !hipk_inkernel_fin_mask();
+   ctx->tail_want = 0;                                           /* one-shot */
+   hipk_fin_args fa;
+   if (defer_dot) memset(&fa, 0, sizeof(fa)); else fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV, gx, 1);
    const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
    if (pat) {
-      const int rc = hipk_pat_matvec(A->pat, st, gx, x, y, A->halo_lo, A->halo_hi, A->xlo, A->xhi, norm2_dev, xout, ctx->partials, &fa);
+      const int rc = hipk_pat_matvec(A->pat, st, gx, x, y, A->halo_lo, A->halo_hi, A->xlo, A->xhi, np2 > 0 ? ctx->tailp : norm2_dev, np2, xout, ctx->partials, &fa);
       hipk_prof_end(pslot, st);
       if (rc) return rc;
+      if (defer_dot) { ctx->tail_np3 = gx; ctx->tail_dot_out = dot_dev; return 0; }
       if (fa.enabled) return 0;
       return hipk_finalize_partials(ctx, ctx->partials, gx, 1, dot_dev);
    }
@@ -941,6 +963,7 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
 #undef LAUNCH_FUSED
    hipk_prof_end(pslot, st);
    HIPK_CHECK(hipGetLastError());
+   if (defer_dot) { ctx->tail_np3 = gx; ctx->tail_dot_out = dot_dev; return 0; }
    if (fa.enabled) return 0;
    return hipk_finalize_partials(ctx, ctx->partials, gx, 1, dot_dev);
 }

@@ -238,17 +238,21 @@ template <typename T, int ML, int RPL, int WPS, bool FUSED, bool HALO>
 __global__ void __launch_bounds__(HIPK_BLOCK, WPS)
 pat_kernel(const uint8_t *__restrict__ pid, const int32_t *__restrict__ toff, const double *__restrict__ tval,
       const int32_t *__restrict__ tlen, int npat, int64_t nrows, const T *__restrict__ x, T *__restrict__ y,
-      int64_t halo_lo, const T *__restrict__ xlo, const T *__restrict__ xhi, const double *__restrict__ norm2,
+      int64_t halo_lo, const T *__restrict__ xlo, const T *__restrict__ xhi, const double *__restrict__ norm2, int np2,
       T *__restrict__ xout, double *__restrict__ partials, hipk_fin_args fa, int32_t minoff, int32_t maxoff) {
    extern __shared__ double pat_sh[];
    __shared__ int s_last;
+   __shared__ double s_n2[4];
    double *s_val = pat_sh;                                     /* [npat * ML] */
    int32_t *s_off = (int32_t *)(pat_sh + (size_t)npat * ML);   /* [npat * ML] */
    int32_t *s_len = s_off + (size_t)npat * ML;                 /* [npat] */
    for (int i = threadIdx.x; i < npat * ML; i += HIPK_BLOCK) { s_val[i] = tval[i]; s_off[i] = toff[i]; }
    for (int i = threadIdx.x; i < npat; i += HIPK_BLOCK) s_len[i] = tlen[i];
+   /* np2 > 0: norm2 points at the np2 partial sums of |t|^2 the Gram-Schmidt update left (hipk_tail_defer): this workgroup
+    * adds them itself, in the order every other workgroup and hipk_tail_finish use — no second-stage launch in between */
+   if (FUSED && np2 > 0) hipk_block_sum256_put(norm2, np2, s_n2);
    __syncthreads();
-   const double a = (FUSED && norm2) ? 1.0 / sqrt(norm2[0]) : 1.0;
+   const double a = (FUSED && norm2) ? 1.0 / sqrt(np2 > 0 ? hipk_block_sum256_get(s_n2) : norm2[0]) : 1.0;
    constexpr int NR = 2 * RPL;                                /* rows of a lane per trip: RPL pairs of consecutive rows */
    const int64_t CH = (int64_t)HIPK_BLOCK * NR;
    const int64_t nch = (nrows + CH - 1) / CH;
@@ -404,10 +408,10 @@ extern "C" double hipk_pat_bytes(const hipk_pat *B, int fused) {
 
 template <typename T, bool FUSED, bool HALO>
 static void pat_launch_ml(const hipk_pat *B, hipStream_t st, int gx, const T *x, T *y, int64_t halo_lo, const T *xlo, const T *xhi,
-      const double *norm2, T *xout, double *partials, const hipk_fin_args &fa) {
+      const double *norm2, int np2, T *xout, double *partials, const hipk_fin_args &fa) {
    const size_t shm = (size_t)B->npat * B->ml * 12 + (size_t)B->npat * 4 + 8;
 #define PATL(MLV) hipLaunchKernelGGL((pat_kernel<T, MLV, PAT_RPL_FOR(MLV), HIPK_PAT_WPS, FUSED, HALO>), dim3(gx), dim3(HIPK_BLOCK), shm, st, B->pid, B->toff, B->tval, B->tlen, B->npat, \
-         B->nrows, x, y, halo_lo, xlo, xhi, norm2, xout, partials, fa, B->minoff, B->maxoff)
+         B->nrows, x, y, halo_lo, xlo, xhi, norm2, np2, xout, partials, fa, B->minoff, B->maxoff)
    switch (B->ml) {
    case 3: PATL(3); break;
    case 5: PATL(5); break;
@@ -418,19 +422,20 @@ static void pat_launch_ml(const hipk_pat *B, hipStream_t st, int gx, const T *x,
 }
 
 /* y = A x (xout == NULL) or the fused form y = A (a x), xout = a x, partials[workgroup] = its part of xout'y
- * (a = 1/sqrt(norm2[0]), norm2 == NULL: a = 1).  gx = hipk_pat_grid().  xlo / xhi: halo rows below / above the slab. */
+ * (a = 1/sqrt(norm2[0]), or of the sum of the np2 partial sums norm2[0 .. np2) when np2 > 0; norm2 == NULL: a = 1).
+ * gx = hipk_pat_grid().  xlo / xhi: halo rows below / above the slab. */
 extern "C" int hipk_pat_matvec(const hipk_pat *B, void *hip_stream, int gx, const void *x, void *y, int64_t halo_lo, int64_t halo_hi,
-      const void *xlo, const void *xhi, const double *norm2, void *xout, double *partials, const hipk_fin_args *fa_in) {
+      const void *xlo, const void *xhi, const double *norm2, int np2, void *xout, double *partials, const hipk_fin_args *fa_in) {
    hipStream_t st = (hipStream_t)hip_stream;
    const bool halo = halo_lo > 0 || halo_hi > 0;
    const bool fused = xout != NULL;
    hipk_fin_args fa;
    if (fa_in) fa = *fa_in; else memset(&fa, 0, sizeof(fa));
 #define PATD(TT) do { \
-      if (fused) { if (halo) pat_launch_ml<TT, true, true>(B, st, gx, (const TT *)x, (TT *)y, halo_lo, (const TT *)xlo, (const TT *)xhi, norm2, (TT *)xout, partials, fa); \
-                   else pat_launch_ml<TT, true, false>(B, st, gx, (const TT *)x, (TT *)y, halo_lo, (const TT *)xlo, (const TT *)xhi, norm2, (TT *)xout, partials, fa); } \
-      else { if (halo) pat_launch_ml<TT, false, true>(B, st, gx, (const TT *)x, (TT *)y, halo_lo, (const TT *)xlo, (const TT *)xhi, norm2, (TT *)xout, partials, fa); \
-             else pat_launch_ml<TT, false, false>(B, st, gx, (const TT *)x, (TT *)y, halo_lo, (const TT *)xlo, (const TT *)xhi, norm2, (TT *)xout, partials, fa); } } while (0)
+      if (fused) { if (halo) pat_launch_ml<TT, true, true>(B, st, gx, (const TT *)x, (TT *)y, halo_lo, (const TT *)xlo, (const TT *)xhi, norm2, np2, (TT *)xout, partials, fa); \
+                   else pat_launch_ml<TT, true, false>(B, st, gx, (const TT *)x, (TT *)y, halo_lo, (const TT *)xlo, (const TT *)xhi, norm2, np2, (TT *)xout, partials, fa); } \
+      else { if (halo) pat_launch_ml<TT, false, true>(B, st, gx, (const TT *)x, (TT *)y, halo_lo, (const TT *)xlo, (const TT *)xhi, norm2, np2, (TT *)xout, partials, fa); \
+             else pat_launch_ml<TT, false, false>(B, st, gx, (const TT *)x, (TT *)y, halo_lo, (const TT *)xlo, (const TT *)xhi, norm2, np2, (TT *)xout, partials, fa); } } while (0)
    if (B->dt == HIPK_F64) PATD(double); else PATD(float);
 #undef PATD
    HIPK_CHECK(hipGetLastError());

@@ -728,6 +728,90 @@ def test_rr_arrow_pair_of_the_next_iteration(built, largest):
         side.close()
 
 
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("case", ["lap3d", "lap2d", "random"])
+def test_tail_without_second_stage_launches(built, dt, case):
+    """Round 6 (include/primme_amd_kernels.h: hipk_tail_defer / hipk_tail_finish): the tail of a block-size-1 iteration —
+    Gram-Schmidt update + |t|^2, then scale + A t + t'At — with ONE small launch at its end instead of two second-stage
+    launches and the one-wave Rayleigh-Ritz launch.  Checked against the sequence of separate launches on the same data:
+    the published |t|^2 is EXACTLY the number the operator launch scaled with (the normalised vector is a x with
+    a = 1 / sqrt(|t|^2) of the published value, bit for bit), t'At is the sum over the vectors actually written, both agree
+    with the separate sequence to rounding, the Rayleigh-Ritz step inside the launch returns the bits of hipk_rr_arrow on the
+    same reductions; the row-pattern operator takes both deferrals, the tile kernel only that of t'At."""
+    npdt = NPDT[dt]
+    rng = np.random.default_rng(21)
+    if case == "lap3d": rp, ci, va, n = problems.laplacian_csr((61, 62, 63))
+    elif case == "lap2d": rp, ci, va, n = problems.laplacian_csr((700, 701))
+    else:
+        n = 300_007
+        counts = rng.integers(1, 9, size=n)
+        rp = np.zeros(n + 1, dtype=np.int64); np.cumsum(counts, out=rp[1:]); rp = rp.astype(np.int32)
+        ci = np.concatenate([np.sort(rng.choice(np.arange(max(0, i - 40), min(n, i + 40)), size=c, replace=False)) for i, c in enumerate(counts)]).astype(np.int32)
+        va = rng.standard_normal(len(ci))
+    k, L = 9, 4
+    side = Dev()
+    lib = side.lib
+    lib.hipk_csr_format.argtypes = [C.c_void_p]
+    lib.hipk_tail_abandon.argtypes = [C.c_void_p]; lib.hipk_tail_abandon.restype = None
+    A = C.c_void_p()
+    vv = np.ascontiguousarray(va, dtype=npdt)
+    assert lib.hipk_csr_create(side.ctx, dt, n, n, 0, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+    is_pat = lib.hipk_csr_format(A) == 2
+    assert is_pat == (case != "random")
+    ld = n + 2
+    V = rng.standard_normal((k, ld)).astype(npdt); Q = rng.standard_normal((L, ld)).astype(npdt)
+    r = rng.standard_normal((1, ld)).astype(npdt)
+    v, q, rr = side.arr(V), side.arr(Q), side.arr(r)
+    segs = segs_array(side, [(v, 0, ld, k), (q, 0, ld, L)])
+    nov = k + L; nfov = 2 * nov + 1; ALPHA = 100
+    fov0 = np.zeros(128); fov0[:nov] = rng.standard_normal(nov) * 1e-2; fov0[nov] = 0.4; fov0[nov + 1:nfov] = rng.standard_normal(nov)
+    # a Rayleigh-Ritz decomposition for the step that rides on the last launch
+    Hk = rng.standard_normal((k, k)); Hk = (Hk + Hk.T) / 2 + np.diag(np.linspace(-2.0, 3.0, k))
+    th, Y = np.linalg.eigh(Hk)
+    inp = F.HipkRrIn()
+    inp.k, inp.L, inp.cand, inp.largest, inp.grow_row = k, L, 0, 0, 1
+    for i in range(k):
+        inp.theta[i] = th[i]
+        for rw in range(k): inp.Y[rw + i * k] = Y[rw, i]
+    G = rng.standard_normal((k, L)) * 0.1
+    for l in range(L):
+        for j in range(k): inp.G[j + l * k] = G[j, l]
+    res = {}
+    for mode in ("separate", "deferred"):
+        fov = side.arr(fov0); t = side.arr(np.zeros((1, ld), npdt)); xo = side.arr(np.full((1, ld), np.nan, npdt))
+        y = side.arr(np.full((1, ld), np.nan, npdt)); hn = side.arr(np.zeros(64)); hn2 = side.arr(np.zeros(64))
+        if mode == "deferred":
+            assert lib.hipk_tail_defer(side.ctx, 3) == 3
+        assert lib.hipk_panel_project_to(side.ctx, dt, n, segs, 2, side.ptr(fov), nov, side.ptr(rr), ld, side.ptr(t), ld, 1, side.ptr(fov, nfov)) == 0
+        if mode == "deferred": assert lib.hipk_tail_pending(side.ctx) == 1
+        assert lib.hipk_csr_matvec_scaled(A, side.ctx, side.ptr(t), side.ptr(fov, nfov), side.ptr(xo), side.ptr(y), side.ptr(fov, ALPHA)) == 0
+        if mode == "deferred": assert lib.hipk_tail_pending(side.ctx) == (3 if is_pat else 2)
+        assert lib.hipk_tail_finish(side.ctx, C.byref(inp), side.ptr(fov), nfov, side.ptr(fov, ALPHA), side.ptr(hn)) == 0
+        assert lib.hipk_tail_pending(side.ctx) == 0
+        # the step as a launch of its own on what is in HBM now
+        assert lib.hipk_rr_arrow(side.ctx, C.byref(inp), side.ptr(fov), nfov, side.ptr(fov, ALPHA), side.ptr(hn2)) == 0
+        f = side.get(fov)
+        res[mode] = dict(n2=f[nfov], dot=f[ALPHA], t=side.get(t)[0, :n].astype(np.float64), xo=side.get(xo)[0, :n], y=side.get(y)[0, :n], hn=side.get(hn), hn2=side.get(hn2))
+    lib.hipk_csr_destroy(A)
+    side.close()
+    eps = 2.3e-16 if dt == F.HIPK_F64 else 1.2e-7
+    for mode, d in res.items():
+        assert np.array_equal(d["hn"][:34], d["hn2"][:34]), mode                     # the step: same bits either way
+        assert d["hn"][33] == 0.0
+        a = 1.0 / np.sqrt(d["n2"])
+        assert np.array_equal(d["xo"], (a * d["t"]).astype(npdt)), mode              # scaled with the PUBLISHED |t|^2
+        assert abs(d["n2"] - float(d["t"] @ d["t"])) <= 50 * eps * d["n2"], mode
+        assert abs(d["dot"] - float(d["xo"].astype(np.float64) @ d["y"].astype(np.float64))) <= 200 * eps * np.sqrt(n) * max(1.0, abs(d["dot"])), mode
+    s_, d_ = res["separate"], res["deferred"]
+    assert np.array_equal(s_["t"], d_["t"])
+    assert abs(s_["n2"] - d_["n2"]) <= 4 * 2.3e-16 * s_["n2"]
+    if not is_pat:
+        assert s_["n2"] == d_["n2"] and np.array_equal(s_["y"], d_["y"]) and s_["dot"] == d_["dot"]      # only the launch count differs
+    else:
+        assert np.max(np.abs(s_["y"].astype(np.float64) - d_["y"].astype(np.float64))) <= 8 * eps * np.abs(s_["y"]).max()
+        assert abs(s_["dot"] - d_["dot"]) <= 100 * eps * np.sqrt(n) * max(1.0, abs(s_["dot"]))
+
+
 def _lattice_csr(n, rng):
     """a 1-D lattice operator with second-neighbour hopping and two site types: 3 x 2 row patterns away from the ends"""
     rows, cols, vals = [], [], []
@@ -820,6 +904,65 @@ def test_csr_row_pattern_form(built, dt, case):
     a = 1.0 / np.sqrt(float(np.sum(Xg ** 2)))
     assert np.max(np.abs(got[1][1] - a * ref)) <= tol * 10 * (1 + np.abs(a * ref).max())
     assert abs(got[1][3][0] - a * a * float(xin[row0:row0 + nloc] @ ref)) <= tol * 50 * np.sqrt(nloc) * (1 + abs(got[1][3][0]))
+
+
+def _rect_structured_csr(kind, m):
+    """rectangular operators whose rows REPEAT (so the pattern scan would accept them): wide [D D] (m x 2m), m x (m+1)
+    bidiagonal, tall [D; D] (2m x m) and a tall bidiagonal (m+1) x m — every row of the wide ones references a column
+    >= nrows, the tall ones have fewer columns than rows"""
+    rows, cols, vals = [], [], []
+    if kind == "wide_DD":
+        nr, nc = m, 2 * m
+        for i in range(m): rows += [i, i]; cols += [i, i + m]; vals += [2.0, -0.5]
+    elif kind == "wide_bidiag":
+        nr, nc = m, m + 1
+        for i in range(m): rows += [i, i]; cols += [i, i + 1]; vals += [1.0, -1.0]
+    elif kind == "tall_DD":
+        nr, nc = 2 * m, m
+        for i in range(2 * m): rows.append(i); cols.append(i % m); vals.append(1.5 if i < m else -0.25)
+    else:
+        nr, nc = m + 1, m
+        for i in range(m + 1):
+            if i < m: rows.append(i); cols.append(i); vals.append(1.0)
+            if i > 0: rows.append(i); cols.append(i - 1); vals.append(-1.0)
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = np.array(rows)[order], np.array(cols)[order], np.array(vals)[order]
+    rp = np.zeros(nr + 1, dtype=np.int64); np.add.at(rp, rows + 1, 1)
+    return np.cumsum(rp).astype(np.int32), cols.astype(np.int32), vals, nr, nc
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("kind", ["wide_DD", "wide_bidiag", "tall_DD", "tall_bidiag"])
+def test_csr_rect_structured_operator(built, dt, kind):
+    """Advisor finding of round 5: hipk_csr_create_rect hands the pattern builder x0 == row0 == 0, and pat_kernel sizes its x
+    descriptor from nrows — a wide structured operator (A' of a tall structured matrix in the singular value problem) read
+    zeros for every column >= nrows in full chunks, a tall one could read past the end of x.  The pattern form is now built
+    for square operators / row slabs only; rectangular structured operators with >= 1024 rows (full 512-row chunks) must give
+    the numpy product, one column and a block."""
+    npdt = NPDT[dt]
+    for m in (1024, 4096 + 512, 20000):
+        rp, ci, va, nr, nc = _rect_structured_csr(kind, m)
+        rng = np.random.default_rng(m)
+        for ncols in (1, 3):
+            X = (rng.standard_normal((ncols, nc)) + 3.0).astype(npdt)          # no zeros: a read of 0 cannot pass
+            res = []
+            for side in (Dev(), Host()):
+                A = C.c_void_p()
+                vv = np.ascontiguousarray(va, dtype=npdt)
+                assert side.lib.hipk_csr_create_rect(side.ctx, dt, nr, nc, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                                     vv.ctypes.data_as(C.c_void_p), C.byref(A)) == 0
+                if side.name == "hip":
+                    side.lib.hipk_csr_format.argtypes = [C.c_void_p]
+                    assert side.lib.hipk_csr_format(A) != 2, (kind, m)        # never the row-pattern form
+                x = side.arr(X); y = side.arr(np.full((ncols, nr), np.nan, dtype=npdt))
+                assert side.lib.hipk_csr_matvec(A, None, side.ptr(x), nc, side.ptr(y), nr, ncols) == 0
+                res.append(side.get(y).copy())
+                side.lib.hipk_csr_destroy(A)
+                side.close()
+            ref = problems.csr_matvec_numpy(rp, ci, np.asarray(va).astype(npdt).astype(np.float64), X.T.astype(np.float64)).T
+            tol = 1e-13 if dt == F.HIPK_F64 else 1e-5
+            assert np.max(np.abs(res[0] - ref)) <= tol * (1 + np.abs(ref).max()), (kind, m, ncols)
+            assert np.max(np.abs(res[1] - ref)) <= tol * (1 + np.abs(ref).max()), (kind, m, ncols)
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
