@@ -230,6 +230,10 @@ int hipk_tail_defer(hipk_ctx *ctx, int want);
 int hipk_tail_finish(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov_dev, int nfov, const double *alpha_dev, double *hnext_out);
 void hipk_tail_abandon(hipk_ctx *ctx);
 int hipk_tail_pending(hipk_ctx *ctx);
+/* the NEXT mirrored reduction on the context publishes no completion flag (one-shot): its second stage then has no
+ * system-scope fence and no ticket.  For a reduction whose results the host reads only after a LATER flagged launch
+ * (the overlaps of a pre-enqueued residual pass: the host waits for the flag of hipk_tail_finish behind it). */
+void hipk_skip_next_flag(hipk_ctx *ctx);
 
 /* ---- column utilities ---------------------------------------------------------
  * Num_scal (cublas_wrapper.c:678), Num_axpy (:616), Num_copy_matrix (:739),
@@ -291,6 +295,12 @@ int hipk_qmr_update_jacobi(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, cons
  * sigma = v'(I - x x')w = v'w - (x'w)(v'x) is known before the projected w is formed */
 int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int64_t ldX, const void *V, int64_t ldV,
       const void *W, int64_t ldW, int nx, double *out_dev);
+/* W <- W - [segs] coef (coefficients in HBM, column c at coef_dev + c*ldcoef), then out_dev = [x'w | v'w | v'x] (3 nx) for
+ * the updated W: hipk_panel_project + hipk_triple_dots in one pass with the arithmetic and summation order of that pair
+ * (reference apply_projected_matrix, inner_solve.c:853-880: Num_gemm_dhd + three Num_dist_dots).  Returns 1 when the shape
+ * is not covered (complex, nx > 8, no columns): the caller runs the two launches. */
+int hipk_project_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg, const double *coef_dev,
+      int ldcoef, void *W, int64_t ldW, int nx, const void *X, int64_t ldX, const void *V, int64_t ldV, double *out_dev);
 /* g_c -= alpha_c (w_c - xr_c x_c), out_dev[c] = |g_c|^2: projection of w against x and the residual update of the
  * QMR step in one pass, the projected w is never stored (inner_solve.c:853-880 followed by :371-377) */
 int hipk_axpy_proj_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha_host, const double *xr_host,

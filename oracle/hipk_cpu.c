@@ -376,6 +376,7 @@ int hipk_rr_arrow(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov, int nf
  * Rayleigh-Ritz step alone — the host solver takes the same decisions in the same order either way */
 int hipk_tail_defer(hipk_ctx *ctx, int want) { (void)ctx; (void)want; return 0; }
 void hipk_tail_abandon(hipk_ctx *ctx) { (void)ctx; }
+void hipk_skip_next_flag(hipk_ctx *ctx) { (void)ctx; }
 int hipk_tail_pending(hipk_ctx *ctx) { (void)ctx; return 0; }
 int hipk_tail_finish(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov, int nfov, const double *alpha_dev, double *hnext_out) {
    if (in) return hipk_rr_arrow(ctx, in, fov, nfov, alpha_dev, hnext_out);
@@ -634,6 +635,21 @@ int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const void *X, int
    }
    mirror(out, (size_t)3 * nx);
    return 0;
+}
+/* W <- W - [segs] coef, then [x'w | v'w | v'x]: the pair of launches it fuses on the device, called one after the other */
+int hipk_project_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg, const double *coef,
+      int ldcoef, void *W, int64_t ldW, int nx, const void *X, int64_t ldX, const void *V, int64_t ldV, double *out) {
+   if (dt == HIPK_C64 || dt == HIPK_C32 || nx > 8 || nx <= 0) return nx <= 0 ? 0 : 1;
+   int tot = 0;
+   for (int q = 0; q < nseg; q++) tot += segs[q].ncols > 0 ? segs[q].ncols : 0;
+   if (tot <= 0) return 1;
+   /* (the coefficients live where the results go: keep a copy, as the device kernel reads them before its second stage writes) */
+   double cf[192 * 8];
+   if (tot > 192) return 1;
+   for (int c = 0; c < nx; c++) for (int j = 0; j < tot; j++) cf[j + c * tot] = coef[j + (size_t)c * ldcoef];
+   int rc = hipk_panel_project(ctx, dt, m, segs, nseg, cf, tot, W, ldW, nx, NULL);
+   if (rc) return rc;
+   return hipk_triple_dots(ctx, dt, m, X, ldX, V, ldV, W, ldW, nx, out);
 }
 int hipk_axpy_proj_dot(hipk_ctx *ctx, hipk_dtype dt, int64_t m, int nx, const double *alpha, const double *xr, const void *W,
       int64_t ldW, const void *X, int64_t ldX, void *G, int64_t ldG, double *out) {

@@ -221,6 +221,7 @@ def declare_kernels(lib):
         "hipk_csr_set_halo": [_vp, _vp, _vp],
         "hipk_csr_set_halo_ld": [_vp, _vp, _i64, _vp, _i64],
         "hipk_triple_dots": [_vp, _i, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp],
+        "hipk_project_triple_dots": [_vp, _i, _i64, P(HipkSeg), _i, _vp, _i, _vp, _i64, _i, _vp, _i64, _vp, _i64, _vp],
         "hipk_axpy_proj_dot": [_vp, _i, _i64, _i, _dp, _dp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
         "hipk_csr_matvec_shifted": [_vp, _vp, _vp, _i64, _vp, _i64, _i, _dp],
         "hipk_axpy_proj_dot_jacobi": [_vp, _i, _i64, _i, _dp, _dp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _dp, C.c_double, _vp],

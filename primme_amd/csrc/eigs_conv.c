@@ -351,6 +351,9 @@ static int pa_prelaunch_enqueue(pa_solver *s, int basisSize, int nLk, int col, i
    const int tcol = 1 - s->spec_tcol;
    char *dst1 = VCOL(s, k1);
    if (xr) hipk_xreduce_arm(s->ctx);
+   /* (rr_flagged: the host looks at these overlaps only after the flag of the hipk_tail_finish that ends this iteration, so
+    * the second stage of the pass need not publish one of its own) */
+   if (rr_flagged && s->pre_quiet_fin) hipk_skip_next_flag(s->ctx);
    CHK(hipk_ritz_residual_overlaps_dev(s->ctx, s->dt, s->m, s->V, s->W, s->ld, k1, s->d_hnext, dst1, s->evecs, s->ldevecs, nLk, 1, s->d_fov_alt));
    /* the pair's pinned copy may be looked at once a flagged launch behind the Rayleigh-Ritz step is through: the small launch
     * that carried the step itself (rr_flagged: the caller has its sequence number), else the second stage of this pass */

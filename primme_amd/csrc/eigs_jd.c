@@ -225,6 +225,12 @@ static int skew_project_Q(pa_solver *s, const jd_proj *P, char *v, int64_t ldv, 
    return 0;
 }
 
+static int jd_no_project_triple(void) {           /* A/B knob, read once */
+   static int v = -1;
+   if (v < 0) v = getenv("PRIMME_AMD_NO_PROJECT_TRIPLE") != NULL;
+   return v;
+}
+
 /* result = (I - Q Q')(I - x x')... (A - shift) v, and vdot[c] = v_c' result_c.  The axpy of every
  * step is fused with the dot product that follows it (hipk_axpy_dot): same arithmetic as the
  * reference's separate Num_axpy / Num_dist_dots calls, two passes over the panels fewer. */
@@ -275,8 +281,22 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
 #else
       if (xr_out) {
          if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
-         if (P->nLQ > 0) CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
-         CHK(hipk_triple_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, v, ldv, result, ldres, nb, s->d_red));
+         /* the projection against the locked vectors and the three inner products of the step in ONE pass over the panel
+          * (hipk_project_triple_dots: the arithmetic of the two launches, bit for bit; PRIMME_AMD_NO_PROJECT_TRIPLE=1 keeps them) */
+         int fused_pt = 0;
+         if (P->nLQ > 0 && !jd_no_project_triple()) {
+            double tq = pa_wtime();
+            hipk_seg sq = {P->LQ, P->ldLQ, P->nLQ};
+            CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, result, ldres, nb, s->d_red + 3 * 64, P->nLQ));
+            CHK(pa_reduce(s, s->d_red + 3 * 64, P->nLQ * nb, 1, 1));
+            const int rcp = hipk_project_triple_dots(s->ctx, s->dt, s->m, &sq, 1, s->d_red + 3 * 64, P->nLQ, result, ldres, nb, P->LX, P->ldLX, v, ldv, s->d_red);
+            if (rcp < 0) return rcp;
+            if (rcp == 0) { fused_pt = 1; s->p->stats.numOrthoInnerProds += (double)P->nLQ * nb; }
+            else CHK(hipk_panel_project(s->ctx, s->dt, s->m, &sq, 1, s->d_red + 3 * 64, P->nLQ, result, ldres, nb, NULL));
+            s->p->stats.timeOrtho += pa_wtime() - tq;
+            if (rcp != 0) { s->p->stats.numOrthoInnerProds += (double)P->nLQ * nb; }
+         } else if (P->nLQ > 0) CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+         if (!fused_pt) CHK(hipk_triple_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, v, ldv, result, ldres, nb, s->d_red));
          if (nowait) {
             CHK(pa_reduce(s, s->d_red, 3 * nb, 1, 1));
             s->p->stats.numOrthoInnerProds += 3 * nb;
@@ -372,7 +392,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    const void *jac_diag = NULL;
    int jac_fixed = 0;
    double jac_shift = 0.0, rho_new[64];
-   const int fuse_pk = (!PA_IS_COMPLEX && b0 > 1 && !plain_K && p->correctionParams.precondition && p->applyPreconditioner == primme_amd_jacobi_precond &&
+   const int fuse_pk = (!PA_IS_COMPLEX && b0 > 1 && !plain_K && getenv("PRIMME_AMD_JDQMR_REF_INDEXING") == NULL && p->correctionParams.precondition && p->applyPreconditioner == primme_amd_jacobi_precond &&
                         p->preconditioner && P->nRQ == 0 && P->nRX == 0 && !P->skewQ &&
                         primme_amd_operator_jacobi_data((primme_amd_operator *)p->preconditioner, &jac_diag, &jac_fixed, &jac_shift) == 0);
    /* ... and with the x-projection folded into the update of g (fold_x) the inner product rho = g'K^-1 g of the NEXT step
@@ -382,7 +402,14 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
     * PRIMME_AMD_NO_EARLY_RHO=1 keeps the round-2 sequence (A/B knob). */
    static int no_early = -1;
    if (no_early < 0) no_early = getenv("PRIMME_AMD_NO_EARLY_RHO") != NULL;
-   const int early_rho = fuse_pk && P->nLX > 0 && !no_early;
+   /* PRIMME_AMD_JDQMR_REF_INDEXING=1 (blocks): restate the reference's own indexing of the block recurrences, quirks included —
+    * sigma_prev, Theta and rho are WRITTEN by block position (Num_dist_dots_real fills [0, blockSize)) but READ by original
+    * column (inner_solve.c:317, :329-337, :373-377, :616-620), and x is permuted once more for every projector it doubles as
+    * (:352-357, :600-603) — in the reference's operation order (no folded x-projection, no early rho, three waits).  As long as
+    * no column has left the block both indexings coincide; afterwards this mode follows the reference's history where the
+    * default keeps every recurrence with its own column.  A parity instrument, not a fast path. */
+   const int ref_ix = (b0 > 1 && getenv("PRIMME_AMD_JDQMR_REF_INDEXING") != NULL);
+   const int early_rho = fuse_pk && P->nLX > 0 && !no_early && !ref_ix;
    int pm[64], p0[64];
    const int adaptive = (p->correctionParams.convTest == primme_adaptive ||
                          p->correctionParams.convTest == primme_adaptive_ETolerance);
@@ -424,7 +451,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    for (int64_t numIts = 0; numIts < maxIterations && blockSize > 0; numIts++) {
       /* blocks: the x-projection of w is folded into the update of g below (one pass and one
        * synchronisation fewer per step); block size 1 keeps the reference's operation order */
-      const int fold_x = (!PA_IS_COMPLEX && b0 > 1 && P->nLX > 0);
+      const int fold_x = (!PA_IS_COMPLEX && b0 > 1 && P->nLX > 0 && !ref_ix);
       double xr[64];
       /* ONE host synchronisation per step (round 5): with the library's Jacobi preconditioner and the folded x-projection the
        * step is three launches — (A - shift) d with its three inner products, the update of g (+ g'g, g'K^-1 g), the QMR
@@ -470,7 +497,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
 #endif
       } else
       CHK(apply_projected_matrix(s, d, ld, shift, P, blockSize, w, ld, tmp, fold_x ? xr : NULL, 0));
-      for (i = 0; i < blockSize; i++) sigma_prev[pm[i]] = tmp[i];
+      for (i = 0; i < blockSize; i++) sigma_prev[ref_ix ? i : pm[i]] = tmp[i];
 
       int conv = 0;
       double malpha[64];
@@ -525,6 +552,10 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          CHK(permute_panel(s, delta, ld, blockSize, p0));                                          \
          CHK(permute_panel(s, r, ld, blockSize, p0));                                              \
          CHK(permute_panel(s, x, ld, blockSize, p0));    /* LX / RX alias x */                     \
+         if (ref_ix) {   /* the reference permutes the aliases too: once more per projector x doubles as */ \
+            if (P->nLX > 0 && P->LX == x) CHK(permute_panel(s, x, ld, blockSize, p0));             \
+            if (P->nRX > 0 && P->RX == x) CHK(permute_panel(s, x, ld, blockSize, p0));             \
+         }                                                                                         \
          if (P->skewX && P->nRX) {                                                                 \
             CHK(permute_panel(s, P->RX, P->ldRX, blockSize, p0));                                  \
             pa_permute_cols(P->xKx, 1, blockSize, 1, p0);                                          \
@@ -540,9 +571,10 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
       if (blockSize <= 0) break;
 
       double gam_c[64], eta_c[64];
+      if (ref_ix) for (i = 0; i < blockSize; i++) Theta[i] = gg[i];      /* written by position ... */
       for (i = 0; i < blockSize; i++) {
          const int q = pm[i];
-         Theta[q] = sqrt(gg[i]) / tau_prev[q];
+         Theta[q] = sqrt(ref_ix ? Theta[q] : gg[i]) / tau_prev[q];       /* ... read by original column */
          const double c = 1.0 / sqrt(1 + Theta[q] * Theta[q]);
          tau[q] = tau_prev[q] * Theta[q] * c;
          gamma[q] = c * c * Theta_prev[q] * Theta_prev[q];
@@ -659,9 +691,10 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
             }
          }
          double beta[64];
+         if (ref_ix) for (i = 0; i < blockSize; i++) rho[i] = plain_K ? gg[i] : tmp[i];
          for (i = 0; i < blockSize; i++) {
             const int q = pm[i];
-            rho[q] = plain_K ? gg[i] : tmp[i];
+            if (!ref_ix) rho[q] = plain_K ? gg[i] : tmp[i];
             beta[i] = rho[q] / rho_prev[q];
             rho_prev[q] = rho[q]; tau_prev[q] = tau[q]; Theta_prev[q] = Theta[q];
          }

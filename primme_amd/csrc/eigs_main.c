@@ -981,6 +981,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
       rc = hipk_memset0(s->ctx, s->d_red, ((size_t)s->red_cap * 3 + 64) * 8);
    }
    s->pre_enabled = getenv("PRIMME_AMD_NO_PRELAUNCH") == NULL;
+   s->pre_quiet_fin = getenv("PRIMME_AMD_LOUD_FIN") == NULL;
    if (!rc && s->fused_restart && s->fuse_gd && b == 1 && !harmonic && K <= 32 && s->nT >= 4 &&
          s->red_cap >= 64 + 2 * HIPK_WTR_MAX_K && getenv("PRIMME_AMD_NO_SPEC_RESTART") == NULL) {
       /* alternate panels of the speculative restart (eigs_solver.h); without them the restart runs in place */

@@ -121,6 +121,7 @@ typedef struct pa_solver {
    double *d_fov_alt, *h_fov_alt;
    double *d_hnext, *h_hnext;     /* hipk_rr_arrow's output: coefficient vector [0..k], Ritz value [32], status [33] */
    int pre_valid, pre_k, pre_L, pre_cand, pre_nfov, pre_tcol;
+   int pre_quiet_fin;      /* the residual pass of a pre-enqueued iteration publishes no flag of its own (PRIMME_AMD_LOUD_FIN=1: it does) */
    int pre_tail_deferred;  /* the pre-enqueued iteration left its tail to hipk_tail_finish (whoever adopts it launches that) */
    unsigned long long pre_seq_rr, pre_seq_end;   /* flags to wait for: the small kernel's, the pass' last reduction's */
    int spec_tcol;          /* scratch column holding the projected, un-normalised vector of the tail that is pending */

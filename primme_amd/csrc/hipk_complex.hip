@@ -140,15 +140,140 @@ zdots_kernel(ZSegs sa, const cpx<R> *__restrict__ X, int64_t ldX, int nx, int c0
       }
 }
 
+/* ---- the same product on the MATRIX CORES (round 6; the real panels' dots_mfma_kernel, hipk_panels.hip) ----------------
+ * A complex m x k panel IS a real 2m x k panel V_r (rows re, im interleaved), and with X = p + i q
+ *    Re([V]^H X) = V_r' X_r,        Im([V]^H X) = V_r' (J X_r),   J (p, q) = (q, -p)  pair by pair,
+ * so the conjugated TN product is ONE real TN product with twice the right-hand columns: [X_r | J X_r].  Tiles of 64
+ * complex rows (128 real rows of v_mfma_f64_16x16x4_f64's k dimension) of up to 16 NT basis columns and 8 complex
+ * right-hand columns are staged in LDS with one 16-byte load per lane and column (1 KB per wave instruction, every load
+ * of a tile issued before the first LDS store; a right-hand element is stored twice, as (p, q) and as (q, -p)); operands
+ * are read back with a column stride of 130 doubles (bank-conflict free for the 32-lane halves of ds_read_b64); each wave
+ * multiplies a quarter of the tile's rows, accumulators in the C/D layout (column = lane & 15, row = (lane >> 4) + 4 reg),
+ * the four waves' tiles are added in a fixed order.  16 real accumulators per 16 basis columns and lane instead of
+ * 2 CPW NX doubles: the register budget no longer sets the occupancy.  blockIdx.y: group of 16 NT basis columns,
+ * blockIdx.z: group of 8 right-hand columns.  Partials as zdots_kernel's: o = 2 (j + c tot) + {re, im}, o-major. */
+#define ZMF_ROWS 128                 /* real rows per tile = 64 complex rows */
+#define ZMF_STRIDE (ZMF_ROWS + 2)
+typedef double zmf_acc __attribute__((ext_vector_type(4)));
+template <typename R, int NT>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+zdots_mfma_kernel(ZSegs sa, const cpx<R> *__restrict__ X, int64_t ldX, int nx, int64_t m, int tot, double *__restrict__ partials) {
+   extern __shared__ double zmf_lds[];           /* [(16 NT + 16) columns][ZMF_STRIDE] */
+   const int lane = threadIdx.x & 63;
+   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const int j0 = blockIdx.y * 16 * NT;
+   const int ncv = min(16 * NT, tot - j0);
+   const int c0 = blockIdx.z * 8;
+   const int nxv = min(8, nx - c0);
+   double *sV = zmf_lds, *sX = zmf_lds + (size_t)16 * NT * ZMF_STRIDE;
+   zmf_acc acc[NT];
+#pragma unroll
+   for (int t = 0; t < NT; t++) acc[t] = (zmf_acc){0.0, 0.0, 0.0, 0.0};
+   const int ci = lane & 15, kg = lane >> 4;
+   constexpr int NVW = 4 * NT;                    /* basis columns a wave stages per tile */
+   const cpx<R> *vcol[NVW], *xcol[2];
+#pragma unroll
+   for (int q = 0; q < NVW; q++) { const int c = wv + 4 * q; vcol[q] = zseg_col<R>(sa, j0 + (c < ncv ? c : 0)); }
+#pragma unroll
+   for (int q = 0; q < 2; q++) { const int c = wv + 4 * q; xcol[q] = X + (size_t)(c0 + (c < nxv ? c : 0)) * ldX; }
+   const int64_t ntile = (m + 63) / 64;
+   for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+      const int64_t i = tile * 64 + lane;
+      const bool live = i < m;
+      const int64_t ic = live ? i : m - 1;
+      zacc tv[NVW], tx[2];
+#pragma unroll
+      for (int q = 0; q < NVW; q++) tv[q] = zload_s(vcol[q] + ic);
+#pragma unroll
+      for (int q = 0; q < 2; q++) tx[q] = zload(xcol[q] + ic);
+#pragma unroll
+      for (int q = 0; q < NVW; q++) {
+         const int c = wv + 4 * q;
+         const bool have = live && c < ncv;
+         double *dst = sV + (size_t)c * ZMF_STRIDE + 2 * lane;
+         dst[0] = have ? tv[q].re : 0.0;
+         dst[1] = have ? tv[q].im : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+         const int c = wv + 4 * q;
+         const bool have = live && c < nxv;
+         double *d0 = sX + (size_t)c * ZMF_STRIDE + 2 * lane, *d1 = sX + (size_t)(8 + c) * ZMF_STRIDE + 2 * lane;
+         d0[0] = have ? tx[q].re : 0.0;  d0[1] = have ? tx[q].im : 0.0;
+         d1[0] = have ? tx[q].im : 0.0;  d1[1] = have ? -tx[q].re : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < ZMF_ROWS / 16; st++) {
+         const int row = wv * (ZMF_ROWS / 4) + 4 * st + kg;
+         const double b = sX[(size_t)ci * ZMF_STRIDE + row];
+#pragma unroll
+         for (int t = 0; t < NT; t++) {
+            const double a = sV[(size_t)(16 * t + ci) * ZMF_STRIDE + row];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+         }
+      }
+      __syncthreads();
+   }
+   double *red = zmf_lds;
+#pragma unroll
+   for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[(((size_t)wv * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+   __syncthreads();
+   if (wv == 0) {
+      const unsigned nb = gridDim.x;
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+         for (int r = 0; r < 4; r++) {
+            const size_t o = ((size_t)t * 4 + r) * 64 + lane;
+            const double v = (red[o] + red[(size_t)NT * 256 + o]) + (red[(size_t)2 * NT * 256 + o] + red[(size_t)3 * NT * 256 + o]);
+            const int iv = 16 * t + kg + 4 * r, jc = ci & 7, part = ci >> 3;     /* C/D layout: row = basis column, column = right-hand column */
+            if (iv < ncv && jc < nxv) {
+               const size_t oo = 2 * ((size_t)(j0 + iv) + (size_t)(c0 + jc) * tot) + (size_t)part;
+               partials[oo * nb + blockIdx.x] = v;
+            }
+         }
+   }
+}
+static int g_zmfma = -1;                         /* HIPK_ZMFMA=1 / hipk_set_zdots_mfma(1): the matrix-core form (measured: no faster) */
+static int zdots_mfma_enabled(void) {
+   if (g_zmfma < 0) { const char *e = getenv("HIPK_ZMFMA"); g_zmfma = (e && atoi(e) != 0 && getenv("HIPK_NO_MFMA") == NULL) ? 1 : 0; }
+   return g_zmfma;
+}
+extern "C" int hipk_set_zdots_mfma(int on) { const int old = zdots_mfma_enabled(); g_zmfma = on != 0; return old; }
+
 template <typename R>
 static int zpanel_dots_t(hipk_ctx *ctx, int64_t m, const ZSegs &sa, const void *X, int64_t ldX, int nx, double *out_dev, int ldout) {
    const int tot = sa.total;
    int64_t need = (m + 63) / 64;
    if (need < 1) need = 1;
-   const int gx = (int)(need < (int64_t)ctx->num_cu * 4 ? need : (int64_t)ctx->num_cu * 4);     /* a workgroup walks 64 rows per step */
+   static int bpc = -1, mbpc = -1;                 /* HIPK_ZDOTS_BPC / HIPK_ZMFMA_BPC: workgroups per CU (measurement knobs, read once) */
+   if (bpc < 0) { const char *e = getenv("HIPK_ZDOTS_BPC"); bpc = e ? atoi(e) : 4; if (bpc < 1) bpc = 4; }
+   if (mbpc < 0) { const char *e = getenv("HIPK_ZMFMA_BPC"); mbpc = e ? atoi(e) : 2; if (mbpc < 1) mbpc = 2; }
+   const int gx = (int)(need < (int64_t)ctx->num_cu * bpc ? need : (int64_t)ctx->num_cu * bpc);     /* a workgroup walks 64 rows per step */
    const size_t nout = 2 * (size_t)tot * nx;
    if (hipk_reserve_partials(ctx, nout * gx)) return -2;
    const int pslot = hipk_prof_begin(HIPK_PROF_DOTS, ctx->stream, (double)(tot + nx) * (double)m * 2.0 * sizeof(R));
+   /* blocks of >= 4 right-hand columns: the matrix cores (zdots_mfma_kernel) */
+   if (nx >= 4 && zdots_mfma_enabled()) {
+      const int nt = tot <= 16 ? 1 : 2;
+      const int gy = (tot + 16 * nt - 1) / (16 * nt), gz = (nx + 7) / 8;
+      int gm = (int)(need < (int64_t)ctx->num_cu * mbpc ? need : (int64_t)ctx->num_cu * mbpc);
+      while (gm > 1 && (int64_t)gm * gy * gz > (int64_t)ctx->num_cu * 2 * mbpc) gm = (gm + 1) / 2;
+      const size_t shm = (size_t)(16 * nt + 16) * ZMF_STRIDE * sizeof(double);
+      if (nt == 1) hipLaunchKernelGGL((zdots_mfma_kernel<R, 1>), dim3(gm, gy, gz), dim3(HIPK_BLOCK), shm, ctx->stream, sa, (const cpx<R> *)X, ldX, nx, m, tot, ctx->partials);
+      else hipLaunchKernelGGL((zdots_mfma_kernel<R, 2>), dim3(gm, gy, gz), dim3(HIPK_BLOCK), shm, ctx->stream, sa, (const cpx<R> *)X, ldX, nx, m, tot, ctx->partials);
+      hipk_prof_end(pslot, ctx->stream);
+      HIPK_CHECK(hipGetLastError());
+      if (ldout == tot) return hipk_finalize_partials_t(ctx, ctx->partials, gm, (int)nout, out_dev);
+      for (int c = 0; c < nx; c++) {
+         int rc = hipk_finalize_partials_t(ctx, ctx->partials + (size_t)2 * tot * c * gm, gm, 2 * tot, out_dev + (size_t)2 * ldout * c);
+         if (rc) return rc;
+      }
+      return 0;
+   }
    for (int c0 = 0; c0 < nx; c0 += 8) {
       const int nc = nx - c0;
       /* columns per wave: as many as the accumulators allow (CPW * NX <= 32 complex = 64 doubles), no more than needed */

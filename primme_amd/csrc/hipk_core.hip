@@ -448,6 +448,10 @@ extern "C" int hipk_tail_defer(hipk_ctx *ctx, int want) {
    ctx->tail_want = want & (HIPK_TAIL_NORM | HIPK_TAIL_DOT);
    return ctx->tail_want;
 }
+/* the NEXT mirrored second stage on this context stores its results (HBM + pinned mirror) but publishes no completion flag:
+ * no system-scope fences, no ticket — for a reduction the host only looks at after a LATER flagged launch of the same stream
+ * (the kernel boundary in between has made its mirrored stores visible).  One-shot. */
+extern "C" void hipk_skip_next_flag(hipk_ctx *ctx) { ctx->skip_flag_once = 1; }
 extern "C" void hipk_tail_abandon(hipk_ctx *ctx) {
    ctx->tail_want = 0; ctx->tail_np2 = 0; ctx->tail_np3 = 0; ctx->tail_norm2_out = NULL; ctx->tail_dot_out = NULL;
 }
@@ -607,7 +611,7 @@ static struct {
    hipEvent_t e0[PROF_RING], e1[PROF_RING];
    int cls[PROF_RING];
    int head, tail;                  /* slots [tail, head) are in flight */
-   double ms[HIPK_PROF_NCLASS], bytes[HIPK_PROF_NCLASS];
+   double ms[HIPK_PROF_NCLASS], bytes[HIPK_PROF_NCLASS], streamed[HIPK_PROF_NCLASS];   /* streamed: what the format in use moves (<= bytes for a compressed operator) */
    long launches[HIPK_PROF_NCLASS];
 } g_prof;
 
@@ -625,13 +629,15 @@ static void prof_drain(int all) {
    }
 }
 
-int hipk_prof_begin(int cls, hipStream_t st, double alg_bytes) {
+int hipk_prof_begin(int cls, hipStream_t st, double alg_bytes) { return hipk_prof_begin_s(cls, st, alg_bytes, alg_bytes); }
+int hipk_prof_begin_s(int cls, hipStream_t st, double alg_bytes, double streamed_bytes) {
    if (!g_prof.enabled) return -1;
    if (g_prof.head - g_prof.tail >= PROF_RING - 1) prof_drain(0);
    if (g_prof.head - g_prof.tail >= PROF_RING - 1) prof_drain(1);
    const int s = g_prof.head % PROF_RING;
    g_prof.cls[s] = cls;
    g_prof.bytes[cls] += alg_bytes;
+   g_prof.streamed[cls] += streamed_bytes;
    (void)hipEventRecord(g_prof.e0[s], st);
    return s;
 }
@@ -654,7 +660,7 @@ extern "C" int hipk_prof_enable(int on) {
 }
 extern "C" int hipk_prof_reset(void) {
    if (g_prof.inited) prof_drain(1);
-   for (int c = 0; c < HIPK_PROF_NCLASS; c++) { g_prof.ms[c] = 0; g_prof.bytes[c] = 0; g_prof.launches[c] = 0; }
+   for (int c = 0; c < HIPK_PROF_NCLASS; c++) { g_prof.ms[c] = 0; g_prof.bytes[c] = 0; g_prof.streamed[c] = 0; g_prof.launches[c] = 0; }
    return 0;
 }
 /* cls: 0 dots (TN panel), 1 project (NN accumulate), 2 ritz (fused update), 3 spmv */
@@ -663,6 +669,13 @@ extern "C" int hipk_prof_get(int cls, double *ms, long *launches, double *alg_by
    if (g_prof.inited) prof_drain(1);
    *ms = g_prof.ms[cls]; *launches = g_prof.launches[cls]; *alg_bytes = g_prof.bytes[cls];
    return 0;
+}
+/* the bytes the launches of the class really moved through HBM in the form they ran in (the sparse operator in a compressed
+ * form moves fewer than the CSR-algorithmic count above; equal for every other class) */
+extern "C" double hipk_prof_streamed(int cls) {
+   if (cls < 0 || cls >= HIPK_PROF_NCLASS) return 0.0;
+   if (g_prof.inited) prof_drain(1);
+   return g_prof.streamed[cls];
 }
 
 

@@ -63,6 +63,7 @@ struct hipk_ctx {
    int tail_want;                            /* flags of the armed deferral (one-shot), 0: none */
    int tail_np2, tail_np3;                   /* partial sums waiting in tailp / partials (0: none) */
    double *tail_norm2_out, *tail_dot_out;    /* where the sums belong */
+   int skip_flag_once;                       /* the next mirrored second stage publishes no completion flag (hipk_skip_next_flag) */
 };
 #define HIPK_TAIL_MAXPART 4096
 
@@ -140,6 +141,7 @@ static inline double *hipk_mirror_of(const hipk_ctx *ctx, const double *out_dev)
  * column norms and pair products, the Jacobi preconditioner) */
 enum { HIPK_PROF_DOTS = 0, HIPK_PROF_PROJECT = 1, HIPK_PROF_RITZ = 2, HIPK_PROF_SPMV = 3, HIPK_PROF_VEC = 4, HIPK_PROF_NCLASS = 5 };
 int hipk_prof_begin(int cls, hipStream_t st, double alg_bytes); /* returns slot or -1 */
+int hipk_prof_begin_s(int cls, hipStream_t st, double alg_bytes, double streamed_bytes);   /* the same, with the bytes the format in use really moves */
 void hipk_prof_end(int slot, hipStream_t st);
 #ifdef __cplusplus
 /* times everything enqueued on `st` between construction and the end of the scope as ONE launch of class `cls` */
@@ -155,6 +157,7 @@ struct hipk_fin_flag { unsigned long long *flag; unsigned int *counter; unsigned
 /* next sequence number for a finalize launch whose output lies in the mirror (else an empty record) */
 static inline hipk_fin_flag hipk_next_flag(hipk_ctx *ctx, const double *out_dev) {
    hipk_fin_flag f = {NULL, NULL, 0};
+   if (ctx->skip_flag_once) { ctx->skip_flag_once = 0; ctx->need_sync = 1; return f; }
    if (ctx->flag_dev && hipk_mirror_of(ctx, out_dev)) { f.flag = ctx->flag_dev; f.counter = ctx->fin_counter; f.seq = ++ctx->seq_issued; ctx->need_sync = 0; }
    else ctx->need_sync = 1;      /* a reduction whose results the flag does not cover */
    return f;

@@ -1537,33 +1537,36 @@ struct RrSyncWave {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
    }
 };
-/* lane = 0..63 of the one wave; n2 = |t|^2 and alpha = t'At of the iteration whose reductions are in fov[0 .. nfov) */
-template <class SY>
-__device__ __forceinline__ void rr_arrow_body(const hipk_rr_in &in, const double *__restrict__ fov, int nfov, double n2, double alpha,
-      RrShared &S, double *__restrict__ out, double *__restrict__ out_host, const int lane) {
+/* lane = 0..63 of the one wave.  rr_arrow_stage: the step's inputs into LDS — independent of |t|^2 and t'At, so the launch that
+ * first has to add those up issues these loads before it does; rr_arrow_solve: the step itself, n2 = |t|^2 and alpha = t'At of
+ * the iteration whose reductions are in fov[0 .. nfov) */
+__device__ __forceinline__ void rr_arrow_stage(const hipk_rr_in &in, const double *__restrict__ fov, int nfov, RrShared &S, const int lane) {
    /* The kernel arguments live in host-visible memory on this stack: indexed, per-lane reads of `in` would each be a trip over
     * PCIe (the first version of this kernel did that in its loops and took longer than the host round trip it replaces).
     * Everything is brought into LDS with ONE batch of loads — the arguments and this iteration's reductions together. */
+   const int j = lane & 15;
+   double ty[4], tg[3], tf[2];
+#pragma unroll
+   for (int u = 0; u < 4; u++) ty[u] = in.Y[lane + 64 * u];
+#pragma unroll
+   for (int u = 0; u < 3; u++) tg[u] = (lane + 64 * u < 160) ? in.G[lane + 64 * u] : 0.0;
+   const double tt = in.theta[j];
+#pragma unroll
+   for (int u = 0; u < 2; u++) tf[u] = (lane + 64 * u < nfov) ? fov[lane + 64 * u] : 0.0;
+#pragma unroll
+   for (int u = 0; u < 4; u++) S.sY[lane + 64 * u] = ty[u];
+#pragma unroll
+   for (int u = 0; u < 3; u++) if (lane + 64 * u < 160) S.sG[lane + 64 * u] = tg[u];
+   if (lane < 16) S.sTh[lane] = tt;
+#pragma unroll
+   for (int u = 0; u < 2; u++) S.sF[lane + 64 * u] = tf[u];
+}
+template <class SY>
+__device__ __forceinline__ void rr_arrow_solve(const hipk_rr_in &in, int nfov, double n2, double alpha,
+      RrShared &S, double *__restrict__ out, double *__restrict__ out_host, const int lane) {
    double *sY = S.sY, *sG = S.sG, *sTh = S.sTh, *sF = S.sF, *s_v = S.s_v, *s_w = S.s_w, *s_y = S.s_y;
    const int j = lane & 15, k = in.k, L = in.L;
    const bool on = lane < 16 && j < k;
-   {
-      double ty[4], tg[3], tf[2];
-#pragma unroll
-      for (int u = 0; u < 4; u++) ty[u] = in.Y[lane + 64 * u];
-#pragma unroll
-      for (int u = 0; u < 3; u++) tg[u] = (lane + 64 * u < 160) ? in.G[lane + 64 * u] : 0.0;
-      const double tt = in.theta[j];
-#pragma unroll
-      for (int u = 0; u < 2; u++) tf[u] = (lane + 64 * u < nfov) ? fov[lane + 64 * u] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 4; u++) sY[lane + 64 * u] = ty[u];
-#pragma unroll
-      for (int u = 0; u < 3; u++) if (lane + 64 * u < 160) sG[lane + 64 * u] = tg[u];
-      if (lane < 16) sTh[lane] = tt;
-#pragma unroll
-      for (int u = 0; u < 2; u++) sF[lane + 64 * u] = tf[u];
-   }
    SY::sync();
    const double sgn = in.largest ? -1.0 : 1.0;
    const double nt = sqrt(n2);
@@ -1681,7 +1684,8 @@ rr_arrow_kernel(hipk_rr_in in, const double *__restrict__ fov, int nfov, const d
       double *__restrict__ out, double *__restrict__ out_host) {
    __shared__ RrShared S;
    const double n2 = fov[nfov], alpha = alpha_dev[0];
-   rr_arrow_body<RrSyncBlock>(in, fov, nfov, n2, alpha, S, out, out_host, (int)threadIdx.x);
+   rr_arrow_stage(in, fov, nfov, S, (int)threadIdx.x);
+   rr_arrow_solve<RrSyncBlock>(in, nfov, n2, alpha, S, out, out_host, (int)threadIdx.x);
    /* no completion flag of its own: the host looks at the pinned copy after the flagged second stage of the residual pass that
     * follows in the stream (a kernel boundary on the queue lies in between) */
 }
@@ -1707,6 +1711,9 @@ tail_finish_kernel(const double *__restrict__ p2, int np2, const double *__restr
       int do_rr, hipk_rr_in in, const double *__restrict__ fov, int nfov, double *__restrict__ rr_out, double *__restrict__ rr_host) {
    __shared__ double sm2[4], sm3[FIN_TAIL_MAXBLOCK / HIPK_WAVE];
    __shared__ RrShared S;
+   /* the Rayleigh-Ritz step's inputs (3.4 KB of kernel arguments + this iteration's overlaps) do not depend on the two sums:
+    * wave 0 has them on their way before anybody adds anything */
+   if (do_rr && threadIdx.x < 64) rr_arrow_stage(in, fov, nfov, S, (int)threadIdx.x);
    if (np2 > 0) hipk_block_sum256_put(p2, np2, sm2);
    {  /* t'At: the order of hipk_finalize_kernel (one output) at the same workgroup size — the bits of the separate launch */
       const int nt = blockDim.x;
@@ -1739,8 +1746,12 @@ tail_finish_kernel(const double *__restrict__ p2, int np2, const double *__restr
       if (dot_host) dot_host[0] = v3;
       if (np2 > 0) { norm2_out[0] = v2; if (norm2_host) norm2_host[0] = v2; }
    }
-   if (do_rr) rr_arrow_body<RrSyncWave>(in, fov, nfov, np2 > 0 ? v2 : fov[nfov], v3, S, rr_out, rr_host, (int)threadIdx.x);
-   if (threadIdx.x == 0) hipk_publish_flag(fin, 1u);
+   if (do_rr) rr_arrow_solve<RrSyncWave>(in, nfov, np2 > 0 ? v2 : fov[nfov], v3, S, rr_out, rr_host, (int)threadIdx.x);
+   /* one workgroup: no ticket — the mirrored results are out (system scope) before the flag */
+   if (threadIdx.x == 0 && fin.flag) {
+      __threadfence_system();
+      *(volatile unsigned long long *)fin.flag = fin.seq;
+   }
 }
 
 extern "C" int hipk_tail_finish(hipk_ctx *ctx, const hipk_rr_in *in, const double *fov_dev, int nfov, const double *alpha_dev, double *hnext_out) {
@@ -2575,6 +2586,96 @@ extern "C" int hipk_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const v
          hipLaunchKernelGGL(triple_dots_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (const T *)V, ldV, (const T *)W, ldW, nx, m, ctx->partials),
          hipLaunchKernelGGL(triple_dots_kernel<T>, dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, (const T *)X, ldX, (const T *)V, ldV, (const T *)W, ldW, nx, m, ctx->partials));
    HIPK_CHECK(hipGetLastError());
+   return hipk_finalize_partials(ctx, ctx->partials, gx, 3 * nx, out_dev);
+}
+
+/* W <- W - [segs] coef, then out = [x'w | v'w | v'x] for the updated W: the projection of (A - shift) d against the locked
+ * vectors (the reference's apply_projected_matrix, inner_solve.c:853-880, Num_gemm + Num_dist_dots) and the three inner
+ * products of the block QMR step in ONE pass — the projected panel used to be written by project_kernel and read back by
+ * triple_dots_kernel.  Same arithmetic as that pair of launches in the same order (coefficients applied with one fma each in
+ * column order; a thread walks the rows triple_dots_kernel gives it, so every partial sum is that kernel's): identical bits,
+ * one read of nx columns and one launch less per inner step (round 6). */
+template <typename T, int NX>
+__global__ void __launch_bounds__(HIPK_BLOCK)
+project_triple_kernel(SegArgs segs, const double *__restrict__ coef, int ldcoef, T *__restrict__ Wv, int64_t ldW,
+      const T *__restrict__ X, int64_t ldX, const T *__restrict__ Vv, int64_t ldV, int nx, int64_t m, double *__restrict__ partials) {
+   __shared__ double scoef[PROJ_MAXCOLS * NX];
+   __shared__ const T *sptr[PROJ_MAXCOLS];
+   __shared__ double sm[HIPK_BLOCK / HIPK_WAVE][3][NX];
+   const int total = segs.total;
+   for (int t = threadIdx.x; t < total * NX; t += HIPK_BLOCK) {
+      const int j = t / NX, c = t % NX;
+      scoef[t] = (c < nx) ? coef[j + (size_t)c * ldcoef] : 0.0;
+   }
+   for (int j = threadIdx.x; j < total; j += HIPK_BLOCK) sptr[j] = seg_col<T>(segs, j);
+   __syncthreads();
+   double a[NX], b[NX], d[NX];
+#pragma unroll
+   for (int c = 0; c < NX; c++) { a[c] = 0.0; b[c] = 0.0; d[c] = 0.0; }
+   const int64_t stride = (int64_t)gridDim.x * HIPK_BLOCK;
+   for (int64_t i = (int64_t)blockIdx.x * HIPK_BLOCK + threadIdx.x; i < m; i += stride) {
+      double wv[NX], xv[NX], vv[NX];
+#pragma unroll
+      for (int c = 0; c < NX; c++) {
+         const int cc = c < nx ? c : 0;
+         wv[c] = (double)Wv[i + (size_t)cc * ldW];
+         xv[c] = (double)X[i + (size_t)cc * ldX];
+         vv[c] = (double)Vv[i + (size_t)cc * ldV];
+      }
+      int j = 0;
+      for (; j + 8 <= total; j += 8) {
+         double q[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) q[u] = (double)__builtin_nontemporal_load(sptr[j + u] + i);
+#pragma unroll
+         for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int c = 0; c < NX; c++) wv[c] = fma(-q[u], scoef[(j + u) * NX + c], wv[c]);
+      }
+      for (; j < total; j++) {
+         const double q = (double)sptr[j][i];
+#pragma unroll
+         for (int c = 0; c < NX; c++) wv[c] = fma(-q, scoef[j * NX + c], wv[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < NX; c++)
+         if (c < nx) {
+            const T o = (T)wv[c];
+            Wv[i + (size_t)c * ldW] = o;
+            const double wi = (double)o;
+            a[c] = fma(xv[c], wi, a[c]); b[c] = fma(vv[c], wi, b[c]); d[c] = fma(vv[c], xv[c], d[c]);
+         }
+   }
+   const int lane = threadIdx.x & 63, wvn = threadIdx.x >> 6;
+#pragma unroll
+   for (int c = 0; c < NX; c++) {
+      const double ta = hipk_wave_sum(a[c]), tb = hipk_wave_sum(b[c]), td = hipk_wave_sum(d[c]);
+      if (lane == 0) { sm[wvn][0][c] = ta; sm[wvn][1][c] = tb; sm[wvn][2][c] = td; }
+   }
+   __syncthreads();
+   for (int t = threadIdx.x; t < 3 * nx; t += HIPK_BLOCK) {
+      const int w = t / nx, c = t % nx;
+      partials[(size_t)blockIdx.x * 3 * nx + w * nx + c] = (sm[0][w][c] + sm[1][w][c]) + (sm[2][w][c] + sm[3][w][c]);
+   }
+}
+
+extern "C" int hipk_project_triple_dots(hipk_ctx *ctx, hipk_dtype dt, int64_t m, const hipk_seg *segs, int nseg, const double *coef_dev,
+      int ldcoef, void *W, int64_t ldW, int nx, const void *X, int64_t ldX, const void *V, int64_t ldV, double *out_dev) {
+   if (nx <= 0) return 0;
+   SegArgs sa;
+   if (HIPK_IS_Z(dt) || pack_segs(segs, nseg, &sa) || nx > 8 || sa.total > PROJ_MAXCOLS || sa.total <= 0) return 1;   /* not covered: the caller runs the two launches */
+   const double es = dt == HIPK_F64 ? 8.0 : 4.0;
+   int gx = hipk_grid_for_rows(ctx, m, HIPK_BLOCK * 4, 4);        /* = hipk_triple_dots: the same partial sums */
+   if (hipk_reserve_partials(ctx, (size_t)gx * 3 * nx)) return -2;
+   {
+      hipk_prof_scope ps_(HIPK_PROF_VEC, ctx->stream, (double)m * es * ((double)sa.total + 4.0 * nx));
+#define PTK(NXV) DISPATCH_RT(dt, \
+         hipLaunchKernelGGL((project_triple_kernel<T, NXV>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sa, coef_dev, ldcoef, (T *)W, ldW, (const T *)X, ldX, (const T *)V, ldV, nx, m, ctx->partials), \
+         hipLaunchKernelGGL((project_triple_kernel<T, NXV>), dim3(gx), dim3(HIPK_BLOCK), 0, ctx->stream, sa, coef_dev, ldcoef, (T *)W, ldW, (const T *)X, ldX, (const T *)V, ldV, nx, m, ctx->partials))
+      if (nx <= 2) { PTK(2); } else if (nx <= 4) { PTK(4); } else { PTK(8); }
+#undef PTK
+      HIPK_CHECK(hipGetLastError());
+   }
    return hipk_finalize_partials(ctx, ctx->partials, gx, 3 * nx, out_dev);
 }
 

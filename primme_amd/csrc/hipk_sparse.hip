@@ -792,9 +792,21 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
    const double es = sizeof(T);
    const double alg = (A->kind == 1) ? 2.0 * A->nrows * es * ncols
                                      : (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 2.0 * A->nrows * es * ncols;
-   const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, stream, alg);
    static int pb_maxcols = -1;       /* HIPK_PB_MAXCOLS: widest block served column by column through the panel-blocked form */
    if (pb_maxcols < 0) { const char *e = getenv("HIPK_PB_MAXCOLS"); pb_maxcols = e ? atoi(e) : 2; }
+   /* what the form that serves THIS product streams (the class' roofline fraction is taken on these bytes): one pattern byte
+    * per row; the panel-blocked entries; the tile kernels' 2- or 4-byte index stream (the windowed and the one-column kernel
+    * read the 2-byte one when the matrix has it, the plain row-block kernel the 4-byte one) */
+   double streamed = alg;
+   if (A->kind == 0) {
+      const bool one_pat = A->pat && hipk_pat_enabled() && ncols == 1 && !shift_host;
+      const bool one_pb = A->pb && !shift_host && ncols <= pb_maxcols;
+      const bool win = A->halo_lo == 0 && A->halo_hi == 0 && ncols <= 64 && ((A->windowed && ncols >= 2) || shift_host);
+      if (one_pat) streamed = hipk_pat_bytes(A->pat, 0);
+      else if (one_pb) streamed = hipk_pb_bytes(A->pb) * ncols;
+      else streamed = (double)A->nnz * (es + ((win || ncols == 1) && csr16(A) ? 2 : 4)) + (A->nrows + 1) * 4.0 + 2.0 * A->nrows * es * ncols;
+   }
+   const int pslot = hipk_prof_begin_s(HIPK_PROF_SPMV, stream, alg, streamed);
    if (A->pat && hipk_pat_enabled() && ncols == 1 && !shift_host) {
       const int rc = hipk_pat_matvec(A->pat, stream, hipk_pat_grid(A->pat, ctx->num_cu), x, y, A->halo_lo, A->halo_hi, A->xlo, A->xhi, NULL, 0, NULL,
             NULL, NULL);
@@ -941,7 +953,7 @@ extern "C" int hipk_csr_matvec_scaled(hipk_csr *A, hipk_ctx *ctx, const void *x,
    ctx->tail_want = 0;                                           /* one-shot */
    hipk_fin_args fa;
    if (defer_dot) memset(&fa, 0, sizeof(fa)); else fa = hipk_make_fin(ctx, dot_dev, HIPK_FIN_SPMV, gx, 1);
-   const int pslot = hipk_prof_begin(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es);
+   const int pslot = hipk_prof_begin_s(HIPK_PROF_SPMV, st, (double)A->nnz * (es + 4) + (A->nrows + 1) * 4.0 + 3.0 * A->nrows * es, hipk_csr_product_bytes(A, 1));
    if (pat) {
       const int rc = hipk_pat_matvec(A->pat, st, gx, x, y, A->halo_lo, A->halo_hi, A->xlo, A->xhi, np2 > 0 ? ctx->tailp : norm2_dev, np2, xout, ctx->partials, &fa);
       hipk_prof_end(pslot, st);

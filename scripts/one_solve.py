@@ -16,5 +16,17 @@ if kind == "csr":
 else:
     op = Operator(n, stencil=dims)
 v0 = problems.start_vector(n)
-r = eigsh(op, numEvals=10, eps=1e-8, aNorm=aNorm, v0=v0, backend="hip", return_evecs=False, maxOuterIterations=max_outer)
-print(kind, wl, "ret", r.ret, "its", r.stats["numOuterIterations"], "t", r.stats["elapsedTime"])
+reps = int(os.environ.get("REPS", "1"))      # REPS=n: n solves through one session (matrix and panels stay resident), every solver time printed
+if reps > 1:
+    from checkers import Session
+    sess = Session(op, backend="hip")
+    ts = []
+    for _ in range(reps):
+        r = sess.solve(numEvals=10, eps=1e-8, aNorm=aNorm, v0=v0, return_evecs=False, maxOuterIterations=max_outer)
+        ts.append(r.stats["elapsedTime"])
+    sess.close()
+    its = r.stats["numOuterIterations"]
+    print(kind, wl, "ret", r.ret, "its", its, "t", " ".join(f"{t:.4f}" for t in ts), "us/iteration (fastest)", round(1e6 * min(ts) / its, 2))
+else:
+    r = eigsh(op, numEvals=10, eps=1e-8, aNorm=aNorm, v0=v0, backend="hip", return_evecs=False, maxOuterIterations=max_outer)
+    print(kind, wl, "ret", r.ret, "its", r.stats["numOuterIterations"], "t", r.stats["elapsedTime"])

@@ -506,6 +506,42 @@ def test_csr_matvec_shifted(built, dt, ncols):
 
 
 @pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
+@pytest.mark.parametrize("nx,L", [(8, 19), (5, 3), (2, 9), (1, 1), (8, 40)])
+def test_project_and_triple_dots_in_one_pass(built, dt, nx, L):
+    """hipk_project_triple_dots (round 6): W -= Q c and [x'w | v'w | v'x] of the updated W in one pass — the projection of
+    (A - shift) d against the locked vectors and the three inner products of a block QMR step.  Must be the pair of launches
+    it replaces BIT FOR BIT on the device (same fma order per element, same partial sums): the history of a JDQMR solve does
+    not move; and agree with the plain-C restatement and numpy."""
+    rng = np.random.default_rng(100 * nx + L)
+    npdt = NPDT[dt]
+    m, ld = 90001, 90004
+    Q = rng.standard_normal((L, ld)).astype(npdt); X, Vv, W = (rng.standard_normal((nx, ld)).astype(npdt) for _ in range(3))
+    coef = rng.standard_normal((nx, L + 3))          # ldcoef = L + 3
+    res = {}
+    for side in (Dev(), Host()):
+        q, x, v = side.arr(Q), side.arr(X), side.arr(Vv)
+        segs = segs_array(side, [(q, 0, ld, L)])
+        for mode in ("fused", "pair"):
+            w = side.arr(W); cf = side.arr(coef); o3 = side.arr(np.zeros(3 * nx))
+            if mode == "fused":
+                assert side.lib.hipk_project_triple_dots(side.ctx, dt, m, segs, 1, side.ptr(cf), L + 3, side.ptr(w), ld, nx, side.ptr(x), ld, side.ptr(v), ld, side.ptr(o3)) == 0
+            else:
+                assert side.lib.hipk_panel_project(side.ctx, dt, m, segs, 1, side.ptr(cf), L + 3, side.ptr(w), ld, nx, None) == 0
+                assert side.lib.hipk_triple_dots(side.ctx, dt, m, side.ptr(x), ld, side.ptr(v), ld, side.ptr(w), ld, nx, side.ptr(o3)) == 0
+            res[(side.name, mode)] = (side.get(w)[:, :m].copy(), side.get(o3).copy())
+        side.close()
+    assert np.array_equal(res[("hip", "fused")][0], res[("hip", "pair")][0])
+    assert np.array_equal(res[("hip", "fused")][1], res[("hip", "pair")][1])
+    Wref = W[:, :m].astype(np.float64) - coef[:, :L] @ Q[:, :m].astype(np.float64)
+    X64, V64 = X[:, :m].astype(np.float64), Vv[:, :m].astype(np.float64)
+    ref3 = np.concatenate([np.sum(X64 * Wref, axis=1), np.sum(V64 * Wref, axis=1), np.sum(V64 * X64, axis=1)])
+    tol = 1e-12 if dt == F.HIPK_F64 else 3e-4
+    for key, (wg, d3) in res.items():
+        assert np.max(np.abs(wg - Wref)) <= tol * (1 + np.abs(Wref).max()) * max(1, L) ** 0.5, key
+        assert np.max(np.abs(d3 - ref3)) <= tol * np.sqrt(m) * 4 * max(1, L) ** 0.5, key
+
+
+@pytest.mark.parametrize("dt", [F.HIPK_F64, F.HIPK_F32])
 def test_qmr_projection_folded_into_residual_update(built, dt):
     """sigma = v'(I - x x')w from one pass of three inner products, then g -= alpha (w - (x'w) x), |g|^2 in one pass:
     equal to projecting w first and updating g afterwards (the two passes and the extra synchronisation it replaces)"""

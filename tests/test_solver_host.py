@@ -91,6 +91,49 @@ def test_against_reference_fixture(built, name, projection_column, monkeypatch):
         assert np.max(np.abs(np.array(r.resNorms, dtype=np.float64) - np.array(g["resNorms"]))) <= rel * aN
 
 
+def test_block_jdqmr_with_the_references_own_indexing(built, monkeypatch):
+    """PRIMME_AMD_JDQMR_REF_INDEXING=1 (csrc/eigs_jd.c): the block QMR recurrences indexed the way the reference indexes them —
+    sigma_prev, Theta and rho written by block position, read by original column, x permuted once more per projector it doubles
+    as (reference inner_solve.c:317, :329-337, :352-357, :373-377, :600-603, :616-620), in the reference's operation order.
+    With it the block fixture reproduces dprimme's outer-iteration, matvec and restart counts EXACTLY and then its residual
+    norms; without it (the default: every recurrence stays with its own column) the same problem takes a different, equally
+    valid history — the reason the fixture tests carry a 15 % / 30 % tolerance for block JDQMR."""
+    r0, g = _run("jdqmr_blk4", "hostcheck")
+    monkeypatch.setenv("PRIMME_AMD_JDQMR_REF_INDEXING", "1")
+    r, g = _run("jdqmr_blk4", "hostcheck")
+    got = (r.stats["numOuterIterations"], r.stats["numMatvecs"], r.stats["numRestarts"])
+    want = (g["stats"]["numOuterIterations"], g["stats"]["numMatvecs"], g["stats"]["numRestarts"])
+    assert r.ret == 0 and got == want, (got, want)
+    assert np.max(np.abs(np.array(r.evals) - np.array(g["evals"]))) <= 1e-10 * 8.0
+    assert np.max(np.abs(np.array(r.resNorms) - np.array(g["resNorms"]))) <= 1e-10 * 8.0
+    assert (r0.stats["numOuterIterations"], r0.stats["numMatvecs"]) != want[:2]      # the default is the other iteration
+    # the preconditioned block-8 fixture comes closer with it, not exact (near-degenerate 3-D spectrum: the histories part at rounding level)
+    r8, g8 = _run("jdqmr_etol_blk8_jacobi", "hostcheck")
+    assert abs(r8.stats["numMatvecs"] - g8["stats"]["numMatvecs"]) <= 0.02 * g8["stats"]["numMatvecs"]
+    assert abs(r8.stats["numOuterIterations"] - g8["stats"]["numOuterIterations"]) <= 3
+
+
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("dims,method,b,pc", [((20, 21, 22), "JDQMR", 2, "jacobi"), ((20, 21, 22), "JDQMR", 4, None), ((20, 21, 22), "JDQMR_ETol", 4, "jacobi"),
+                                              ((30, 31), "JDQMR", 8, None), ((30, 31), "JDQMR_ETol", 8, "jacobi"), ((30, 31), "JDQMR_ETol", 2, None)])
+def test_block_jdqmr_reference_indexing_against_live_reference(built, monkeypatch, dims, method, b, pc):
+    """The same knob against the LIVE reference at block sizes 2, 4 and 8, with and without the Jacobi preconditioner: identical
+    outer-iteration / matvec / restart counts (20 of 24 configurations of the sweep in profiles/r06_jdqmr_reference_indexing.txt
+    are exact; the four that are not are block size 8 on the near-degenerate 3-D spectrum, within 3 %)."""
+    monkeypatch.setenv("PRIMME_AMD_JDQMR_REF_INDEXING", "1")
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    op = Operator(n, csr=(rp, ci, va))
+    kw = dict(numEvals=10 if len(dims) == 3 else 6, method=method, eps=1e-9, aNorm=12.0 if len(dims) == 3 else 8.0, maxBlockSize=b, v0=problems.start_vector(n))
+    if pc:
+        kw["precond"] = pc
+    a = eigsh(op, backend="reference", **kw)
+    c = eigsh(op, backend="hostcheck", **kw)
+    f = lambda r: (r.stats["numOuterIterations"], r.stats["numMatvecs"], r.stats["numRestarts"])
+    assert a.ret == c.ret == 0 and f(a) == f(c), (f(a), f(c))
+    assert np.max(np.abs(a.evals - c.evals)) <= 1e-10 * kw["aNorm"]
+    assert np.max(np.abs(a.resNorms - c.resNorms)) <= 1e-10 * kw["aNorm"]
+
+
 @pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_block_and_guesses_against_live_reference(built, seed):
