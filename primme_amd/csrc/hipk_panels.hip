@@ -409,8 +409,10 @@ static int panel_dots_t(hipk_ctx *ctx, int64_t m, const SegArgs &sa, const T *X,
       nt = sa.total <= 16 ? 1 : 2;                 /* 2 tiles: 48 staged columns = 50 KB of LDS */
       gy = (sa.total + 16 * nt - 1) / (16 * nt);
       gz = (nx + 15) / 16;
-      gx = hipk_grid_for_rows(ctx, m, MF_ROWS, 2);
-      while (gx > 1 && (int64_t)gx * gy * gz > (int64_t)ctx->num_cu * 4) gx = (gx + 1) / 2;
+      static int mbpc = -1;                         /* HIPK_MFMA_BPC: workgroups per CU (measurement knob, read once) */
+      if (mbpc < 0) { const char *e = getenv("HIPK_MFMA_BPC"); mbpc = e ? atoi(e) : 3; if (mbpc < 1) mbpc = 3; }      /* 3: 0.50 / 0.71 / 0.66 of HBM at 8 / 16 / 24 basis columns, 2: 0.44 / 0.67 / 0.63 (profiles/r06_zpanel_perf.txt) */
+      gx = hipk_grid_for_rows(ctx, m, MF_ROWS, mbpc);
+      while (gx > 1 && (int64_t)gx * gy * gz > (int64_t)ctx->num_cu * 2 * mbpc) gx = (gx + 1) / 2;
    }
    if (hipk_reserve_partials(ctx, (size_t)gx * nout)) return -2;
    dim3 grid(gx, gy, gz);

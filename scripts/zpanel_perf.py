@@ -15,7 +15,7 @@ m = int(os.environ.get("KP_M", "4000000"))
 V = torch.randn((28, m), dtype=torch.complex128, device="cuda")
 red = torch.zeros(8192, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize()
-tag = " ".join(f"{k}={os.environ[k]}" for k in ("HIPK_ZMFMA", "HIPK_ZDOTS_BPC", "HIPK_ZMFMA_BPC") if k in os.environ) or "default"
+tag = " ".join(f"{k}={os.environ[k]}" for k in ("HIPK_ZMFMA", "HIPK_ZDOTS_BPC", "HIPK_ZMFMA_BPC", "HIPK_MFMA_BPC", "HIPK_NO_MFMA") if k in os.environ) or "default"
 def timeit(fn, nbytes, label):
     for _ in range(3): fn()
     lib.hipk_sync(ctx)

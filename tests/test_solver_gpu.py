@@ -122,6 +122,61 @@ def test_most_fixtures_reproduce_the_reference_history(built):
     assert len(EXACT_HISTORY) >= 30 and len(missing) <= 2, (sorted(EXACT_HISTORY), missing)
 
 
+EVECS = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_evecs.npz"))
+EVEC_NAMES = sorted({k.split("/")[0] for k in EVECS.files})
+
+
+def subspace_check(name, r, g):
+    """Angle between the invariant subspace a solve returned and the one the REAL reference returned for the same fixture
+    (tests/golden/reference_evecs.npz, generated by tests/golden/make_evec_golden.py): a parity check that needs neither an
+    identical history nor residual norms.  Both bases are accurate to |r| / gap, gap = distance of the wanted eigenvalues to
+    the rest of the (analytic) spectrum, so sin(largest principal angle) <= 2 eps |A| / gap + rounding."""
+    dims = tuple(g["dims"])
+    aN = g["params"]["aNorm"] if g["params"]["aNorm"] > 0 else max(abs(np.array(g["evals"])))
+    Xr = EVECS[name + "/evecs"]
+    X = np.asarray(r.evecs, dtype=np.float64)
+    assert X.shape == Xr.shape, (name, X.shape, Xr.shape)
+    Qr, _ = np.linalg.qr(Xr)
+    Q, _ = np.linalg.qr(X)
+    sin_max = float(np.linalg.norm(Q - Qr @ (Qr.T @ Q), 2))
+    n = int(np.prod(dims))
+    spec = problems.laplacian_eigenvalues(dims, n)                    # the whole analytic spectrum, ascending
+    wanted = np.sort(np.array(g["evals"], dtype=np.float64))
+    idx = [int(np.argmin(np.abs(spec - w))) for w in wanted]
+    taken = np.zeros(n, dtype=bool)
+    for i, w in zip(idx, wanted):                                     # (a repeated eigenvalue: take the next free copy)
+        j = i
+        while taken[j] and j + 1 < n and abs(spec[j + 1] - w) <= 1e-9 * aN: j += 1
+        taken[j] = True
+    rest = spec[~taken]
+    gap = float(np.min(np.abs(rest[None, :] - wanted[:, None])))
+    eps = g["kwargs"].get("eps") or 1e-12
+    assert gap > 1e-6 * aN, (name, gap)                               # the fixtures' wanted sets are separated from the rest
+    tol = 2.0 * eps * aN / gap + 1e-12
+    assert sin_max <= tol, (name, sin_max, tol, gap)
+    # the eigenvalues themselves against the ANALYTIC spectrum with the bound the residual norms imply (Kato-Temple:
+    # |theta - lambda| <= |r|^2 / gap_i, gap_i = distance to the nearest OTHER eigenvalue) — much tighter than the 1e-10 |A| of the
+    # fixture comparison, and stated relative to the eigenvalue too (every other tolerance in this file is relative to |A|)
+    lam = np.sort(np.asarray(r.evals, dtype=np.float64))
+    for li, ji in zip(lam, sorted(np.flatnonzero(taken))):
+        others = np.delete(spec, ji)
+        gap_i = float(np.min(np.abs(others - spec[ji])))
+        bound = (eps * aN) ** 2 / gap_i + 200 * np.finfo(np.float64).eps * aN if gap_i > 1e-6 * aN else eps * aN
+        assert abs(li - spec[ji]) <= bound, (name, li, spec[ji], bound)
+        assert abs(li - spec[ji]) / max(abs(spec[ji]), 1e-300) <= bound / max(abs(spec[ji]), 1e-300)
+    return sin_max, tol
+
+
+@pytest.mark.parametrize("name", EVEC_NAMES)
+def test_hip_invariant_subspace_against_the_references_eigenvectors(built, name):
+    """The 17 fixtures whose history is not reproduced count for count (interior targets, harmonic / refined extraction, block
+    JDQMR, the dynamic method): the returned invariant subspace is the reference's to 2 eps |A| / gap."""
+    op, kw, g = _case(name)
+    r = eigsh(op, backend="hip", **kw)
+    assert r.ret == 0 and r.initSize == g["initSize"]
+    subspace_check(name, r, g)
+
+
 def test_block_jdqmr_with_the_references_own_indexing_on_the_device(built, monkeypatch):
     """PRIMME_AMD_JDQMR_REF_INDEXING=1 (csrc/eigs_jd.c; tests/test_solver_host.py has the CPU-checker and live-reference legs):
     the block QMR recurrences indexed the way the reference indexes them.  On the HIP path the block fixture then follows

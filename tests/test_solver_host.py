@@ -91,6 +91,17 @@ def test_against_reference_fixture(built, name, projection_column, monkeypatch):
         assert np.max(np.abs(np.array(r.resNorms, dtype=np.float64) - np.array(g["resNorms"]))) <= rel * aN
 
 
+@pytest.mark.parametrize("name", ["lap2d_closest_abs", "ref_closest_geq", "harm_two_shifts", "jdqmr_blk4", "jdqmr_closest_abs", "lap2d_dynamic_few_soft"])
+def test_invariant_subspace_against_the_references_eigenvectors(built, name):
+    """CPU-checker leg of tests/test_solver_gpu.py::test_hip_invariant_subspace_against_the_references_eigenvectors (a sample of
+    the 17 fixtures; the GPU suite runs all of them): the subspace returned for a fixture whose history is not the reference's
+    count for count is the reference's own (tests/golden/reference_evecs.npz) to 2 eps |A| / gap."""
+    from test_solver_gpu import subspace_check
+    r, g = _run(name, "hostcheck")
+    assert r.ret == 0 and r.initSize == g["initSize"]
+    subspace_check(name, r, g)
+
+
 def test_block_jdqmr_with_the_references_own_indexing(built, monkeypatch):
     """PRIMME_AMD_JDQMR_REF_INDEXING=1 (csrc/eigs_jd.c): the block QMR recurrences indexed the way the reference indexes them —
     sigma_prev, Theta and rho written by block position, read by original column, x permuted once more per projector it doubles
