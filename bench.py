@@ -182,6 +182,10 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        lib.primme_amd_comm_transport.restype = C.c_char_p
+        lib.primme_amd_comm_transport.argtypes = [C.c_void_p]
+        lib.primme_amd_comm_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+
         def make_id():
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -195,40 +199,81 @@ def main():
             dist.broadcast(uid, 0)
             return bytes(uid.cpu().numpy().tobytes())
 
-        raw = make_id()
-        if raw[:6] == b"PAIPC1":
-            # the id of the peer-to-peer transport names a shared-memory segment of THIS node: if some rank cannot see it
-            # (ranks in separate containers / IPC namespaces), every rank switches to RCCL before anybody waits for a rendez-vous
-            seg = "/dev/shm" + raw[8:72].split(b"\0")[0].decode()
-            seen = torch.tensor([1 if os.path.exists(seg) else 0], dtype=torch.int32, device="cpu" if shared_devices else "cuda")
-            dist.all_reduce(seen, op=dist.ReduceOp.MIN)
-            if int(seen.item()) == 0:
-                if shared_devices:
-                    raise SystemExit("bench.py: ranks sharing a device need the peer-to-peer transport, but its rendez-vous segment is not visible to every rank")
-                if rank == 0:
-                    print("bench.py: the rendez-vous segment of the peer-to-peer transport is not visible to every rank; using PRIMME_AMD_COMM=rccl", file=sys.stderr)
-                    try:
-                        os.unlink(seg)
-                    except OSError:
-                        pass
-                os.environ["PRIMME_AMD_COMM"] = "rccl"
-                raw = make_id()
-        comm = C.c_void_p()
-        assert lib.primme_amd_comm_create(C.byref(comm), raw, rank, world) == 0
-        lib.primme_amd_comm_transport.restype = C.c_char_p
-        lib.primme_amd_comm_transport.argtypes = [C.c_void_p]
-        transport = lib.primme_amd_comm_transport(comm).decode()
-        # every collective of the communicator against known data on the transport it came up on, and the latency of a
-        # small all-reduce (a block-size-1 iteration makes three), BEFORE anything is timed: a transport that maps but does
-        # not deliver must end the run here, not inside a solve
-        lib.primme_amd_comm_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-        us = C.c_double(-1.0)
-        st_rc = lib.primme_amd_comm_selftest(comm, None, 1000, C.byref(us))
-        if st_rc != 0:
-            raise SystemExit(f"bench.py: rank {rank}: the communicator self-test failed on transport {transport} (code {st_rc}); no number is reported")
-        comm_selftest = {"transport": transport, "allreduce_us": round(us.value, 2),
-                         "checked": "all-reduce of 1..4096 doubles, neighbour halo, all-gather / reduce-scatter of column blocks, integer exchange",
-                         "allreduce_us_is": "wall clock per 8-double all-reduce over 1000 back-to-back reductions on this rank"}
+        def all_ranks(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if shared_devices else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        def make_comm(mode, required):
+            """One communicator of the library on transport `mode` (auto | ipc | rccl): create, self-test (every collective against
+            known data + the latency of a small all-reduce) — collectively; returns (handle or None, record).  A transport that
+            does not come up or does not deliver is RECORDED (and ends the run only when `required`)."""
+            os.environ["PRIMME_AMD_COMM"] = mode
+            rec = {"requested": mode}
+            raw = make_id()
+            if raw[:6] == b"PAIPC1":
+                # the id of the peer-to-peer transport names a shared-memory segment of THIS node: if some rank cannot see it
+                # (ranks in separate containers / IPC namespaces), nobody waits for a rendez-vous that cannot happen
+                seg = "/dev/shm" + raw[8:72].split(b"\0")[0].decode()
+                if not all_ranks(os.path.exists(seg)):
+                    if rank == 0:
+                        try:
+                            os.unlink(seg)
+                        except OSError:
+                            pass
+                    rec.update(came_up=False, why="the rendez-vous segment of the peer-to-peer transport is not visible to every rank")
+                    if shared_devices or (required and mode == "ipc"):
+                        raise SystemExit("bench.py: " + rec["why"])
+                    if mode != "rccl":
+                        return make_comm("rccl", required)[0], dict(rec, fell_back_to="rccl")
+                    return None, rec
+            c = C.c_void_p()
+            rc = lib.primme_amd_comm_create(C.byref(c), raw, rank, world)
+            if not all_ranks(rc == 0):
+                if rc == 0:
+                    lib.primme_amd_comm_destroy(c)
+                rec.update(came_up=False, why=f"primme_amd_comm_create returned {rc} on rank {rank}" if rc else "another rank could not create it")
+                if required:
+                    raise SystemExit(f"bench.py: rank {rank}: the communicator did not come up on transport {mode}: {rec['why']}")
+                return None, rec
+            us = C.c_double(-1.0)
+            st_rc = lib.primme_amd_comm_selftest(c, None, 1000, C.byref(us))
+            rec.update(came_up=True, transport=lib.primme_amd_comm_transport(c).decode(), selftest="passed" if st_rc == 0 else f"FAILED (code {st_rc})",
+                       allreduce_us=round(us.value, 2),
+                       checked="all-reduce of 1..4096 doubles, neighbour halo, all-gather / reduce-scatter of column blocks, integer exchange",
+                       allreduce_us_is="wall clock per 8-double all-reduce over 1000 back-to-back reductions on this rank")
+            if not all_ranks(st_rc == 0):
+                lib.primme_amd_comm_destroy(c)
+                if required:
+                    raise SystemExit(f"bench.py: rank {rank}: the communicator self-test failed on transport {rec['transport']} (code {st_rc}); no number is reported")
+                return None, rec
+            return c, rec
+
+        # Both transports, each with its self-test and all-reduce latency on the line (VERDICT r05 Next #7): the one the run is timed
+        # on — --comm / PRIMME_AMD_COMM, default auto = mailboxes for the small reductions and halos + RCCL for bulk — and, when the
+        # ranks sit on distinct devices and nothing was forced, RCCL alone as the second one (a few solves after the headline).
+        primary_mode = args.comm or os.environ.get("PRIMME_AMD_COMM") or "auto"
+        if shared_devices:
+            primary_mode = "ipc"
+        comm, comm_selftest = make_comm(primary_mode, True)
+        transport = comm_selftest["transport"]
+        comm_records = [comm_selftest]
+        second = None
+        if world > 1 and not shared_devices and not args.comm and transport != "rccl" and not os.environ.get("PRIMME_AMD_BENCH_ONE_TRANSPORT"):
+            try:
+                second, rec2 = make_comm("rccl", False)
+            except SystemExit:
+                raise
+            except Exception as e:      # (deterministic on every rank: a Python-level error, not a transport failure)
+                second, rec2 = None, {"requested": "rccl", "came_up": False, "why": repr(e)}
+            comm_records.append(rec2)
+        os.environ["PRIMME_AMD_COMM"] = primary_mode
+        selftest_of = {comm.value: comm_selftest}
+        if second is not None:
+            selftest_of[second.value] = comm_records[-1]
+        if rank == 0:
+            for rec in comm_records:
+                print("bench.py: transport " + json.dumps(rec), file=sys.stderr, flush=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -312,7 +357,7 @@ def main():
             r["note"] = note
         return r
 
-    def run_workload(name, steps_req, warmup_req, budget_s):
+    def run_workload(name, steps_req, warmup_req, budget_s, comm=None, profile=True):
         """Timed solves of one workload (operator, start vector and panels resident in HBM before the timed
         region), then ONE more solve with HIP events around every launch of the hot kernel classes for the
         roofline."""
@@ -337,6 +382,7 @@ def main():
                   return_evecs=False, numProcs=world, procID=rank)
         # the matrix stays resident through a persistent session
         sess = Session(op, comm=comm, dtype=np.float64)
+        transport = lib.primme_amd_comm_transport(comm).decode() if comm is not None else None
         lib.hipk_csr_index_bytes.argtypes = [C.c_void_p]
         lib.hipk_csr_format.argtypes = [C.c_void_p]
         lib.hipk_csr_product_bytes.argtypes = [C.c_void_p, C.c_int]; lib.hipk_csr_product_bytes.restype = C.c_double
@@ -473,12 +519,13 @@ def main():
             pass
         if dist_path:
             res["config"]["transport"] = transport
-            res["config"]["comm_selftest"] = comm_selftest
+            res["config"]["comm_selftest"] = selftest_of.get(comm.value) if comm is not None else None
+            res["config"]["transports"] = comm_records
             if shared_devices:
                 res["config"]["devices"] = f"{world} ranks on {ndev} device(s): functional run, NOT a scaling number"
         return res, last, dims, wl, n
 
-    main_res, last, dims, wl, n = run_workload(args.workload, args.steps, args.warmup, args.budget_s)
+    main_res, last, dims, wl, n = run_workload(args.workload, args.steps, args.warmup, args.budget_s, comm=comm)
     out = {
         "metric": "eigenpairs/sec to target resNorm", "value": main_res["value"],
         "unit": "eigenpairs/s", "n_gpus": world, "steps": main_res["steps"], "warmup": main_res["warmup"],
@@ -487,10 +534,26 @@ def main():
         "config": main_res["config"], "roofline": main_res["roofline"],
     }
     if not args.no_configs1 and args.workload != "lap3d_2m":
-        c1, _, _, _, _ = run_workload("lap3d_2m", 3, 1, 0.0)
+        c1, _, _, _, _ = run_workload("lap3d_2m", 3, 1, 0.0, comm=comm)
         out["configs1"] = {"metric": "eigenpairs/sec to target resNorm", "value": c1["value"], "unit": "eigenpairs/s",
                            "ms_per_step": c1["ms_per_step"], "steps": c1["steps"], "n_gpus": world,
                            "config": c1["config"], "roofline": c1["roofline"]}
+
+    # ---- N > 1: the same workloads once more on the OTHER transport (RCCL alone), so that one scaling run records the pair
+    if dist_path and second is not None:
+        try:
+            r2, _, _, _, _ = run_workload(args.workload, min(args.steps, 3), 1, 0.0, comm=second)
+            out["other_transport"] = {"transport": r2["config"].get("transport"), "value": r2["value"], "unit": "eigenpairs/s", "ms_per_step": r2["ms_per_step"],
+                                      "steps": r2["steps"], "us_per_outer_iteration": r2["config"]["us_per_outer_iteration"],
+                                      "outer_iterations": r2["config"]["outer_iterations"], "comm_selftest": r2["config"].get("comm_selftest")}
+            if "configs1" in out:
+                c1b, _, _, _, _ = run_workload("lap3d_2m", 3, 1, 0.0, comm=second)
+                out["other_transport"]["configs1"] = {"value": c1b["value"], "ms_per_step": c1b["ms_per_step"],
+                                                      "us_per_outer_iteration": c1b["config"]["us_per_outer_iteration"]}
+        except SystemExit:
+            raise
+        except Exception as e:      # the second transport never takes the headline line down; the failure is on the line
+            out["other_transport"] = {"value": None, "error": repr(e)}
 
     # ---- the other BASELINE configs on the driver-timed line (one GPU): Matrix-Market input, complex Hermitian, singular values
     def timed_solves(solve, nsolves):
@@ -624,6 +687,8 @@ def main():
                                    "sample": f"failed: {e!r}"}
     if comm is not None:
         barrier()
+        if dist_path and second is not None:
+            lib.primme_amd_comm_destroy(second)
         lib.primme_amd_comm_destroy(comm)
     if rank == 0:
         print(json.dumps(out, default=lambda o: o.item() if hasattr(o, "item") else str(o)), flush=True)

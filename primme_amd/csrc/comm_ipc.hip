@@ -353,12 +353,20 @@ static int upload_tables(pa_ipc *x) {
 
 /* the tag sequence of the reductions wraps (hipk_xr_next_seq): every rank gets here at the same reduction.  Drain, meet,
  * clear this rank's granule area (what the peers wrote in the cycle that ends), meet again. */
-static int ipc_seq_wrap(void *owner) {
-   pa_ipc *x = (pa_ipc *)owner;
+static int ipc_seq_wrap_impl(pa_ipc *x) {
    if (hipDeviceSynchronize() != hipSuccess) return -1;
    if (shm_barrier(x)) return -43;              /* nobody is inside a reduction of the old cycle any more */
    if (x->mbox.mine && (hipMemset(x->mbox.mine, 0, mbox_gran_bytes(x->nranks)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) return -1;
    return shm_barrier(x);                       /* nobody writes a tag of the new cycle into an area that is still being cleared */
+}
+static int ipc_seq_wrap(void *owner) {
+   pa_ipc *x = (pa_ipc *)owner;
+   const int rc = ipc_seq_wrap_impl(x);
+   /* a wrap that did not complete (barrier time limit, HIP error) leaves granule areas that may still carry tags of the old
+    * cycle: the transport is unusable from here on — say so through the error word the solver looks at after every reduction
+    * (pa_comm_failed -> PRIMME_PARALLEL_FAILURE) instead of restarting the sequence over stale tags */
+   if (rc && x->err_host) *(volatile int *)x->err_host = 2;
+   return rc;
 }
 
 int pa_ipc_attach(pa_ipc **out, const void *id128, int rank, int nranks) {

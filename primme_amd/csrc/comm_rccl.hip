@@ -100,7 +100,12 @@ extern "C" int primme_amd_comm_create(primme_amd_comm **out, const void *id128, 
       if (pa_ipc_host_allgather(c->ipc, &mode, sizeof(int), modes)) { pa_ipc_detach(c->ipc); free(c); return -43; }
       mode = modes[0] == PA_COMM_RCCL ? PA_COMM_HYBRID : modes[0];
       const int gpu_ok = pa_ipc_gpu_ok(c->ipc);
-      if (!gpu_ok && (mode == PA_COMM_IPC || !pa_ipc_distinct_devices(c->ipc))) {
+      /* PRIMME_AMD_COMM_STRICT=1: mailboxes that do not map across the devices are an ERROR, not a reason to fall back to RCCL
+       * quietly (tests/test_multigpu_rccl.py: a silent fall-back must not pass for the peer-to-peer result) */
+      const int strict = getenv("PRIMME_AMD_COMM_STRICT") != NULL && modes[0] != PA_COMM_RCCL;
+      if (!gpu_ok && strict)
+         fprintf(stderr, "primme_amd: rank %d: PRIMME_AMD_COMM_STRICT: the peer-to-peer mailboxes did not come up across the devices of this job (no fall-back to RCCL)\n", rank);
+      if (!gpu_ok && (strict || mode == PA_COMM_IPC || !pa_ipc_distinct_devices(c->ipc))) {
          /* the mailboxes were asked for explicitly, or ranks share a device (RCCL cannot serve that): no fall-back */
          pa_ipc_detach(c->ipc); free(c);
          return -43;

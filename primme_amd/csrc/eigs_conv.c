@@ -399,7 +399,15 @@ static int pre_pair_matches(const pa_solver *s, int k1, int col) {
       for (int j = 0; j < k1; j++) t += s->H[(i < j ? i : j) + (size_t)(i < j ? j : i) * s->K] * h[j];
       res = PA_MAX(res, fabs(t));
    }
-   return res <= 1e-13 * scale;
+   if (!(res <= 1e-13 * scale)) return 0;
+   /* ... and it must be the host's VECTOR as well (up to its sign): with (nearly) repeated Ritz values two eigenpairs of H that
+    * both pass the test above can differ by O(1) in the vector, and the host goes on to use ITS column — for the restart, for
+    * locking, for the Ritz vector it returns — while residual and overlaps would be the device's (advisor, round 5).  Two
+    * backward-stable solvers agree to eps |H| / gap; anything beyond 1e-6 is another vector of the cluster: not adopted. */
+   const double *y = s->hVecs + (size_t)col * k1;
+   double dp = 0.0, dm = 0.0;
+   for (int i = 0; i < k1; i++) { dp = PA_MAX(dp, fabs(h[i] - y[i])); dm = PA_MAX(dm, fabs(h[i] + y[i])); }
+   return PA_MIN(dp, dm) <= 1e-6;
 }
 
 /* The speculative tail of a block-size-1 GD iteration, enqueued right after the fused residual pass: the

@@ -411,6 +411,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    const int ref_ix = (b0 > 1 && getenv("PRIMME_AMD_JDQMR_REF_INDEXING") != NULL);
    const int early_rho = fuse_pk && P->nLX > 0 && !no_early && !ref_ix;
    int pm[64], p0[64];
+   const int three_waits = getenv("PRIMME_AMD_QMR_THREE_WAITS") != NULL;      /* (A/B knob, read once per inner solve: tests switch it within a process) */
    const int adaptive = (p->correctionParams.convTest == primme_adaptive ||
                          p->correctionParams.convTest == primme_adaptive_ETolerance);
    int i, isConv;
@@ -462,7 +463,6 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
        * unchanged) for its own bookkeeping: the stopping tests, the columns that leave the block, the next step's state.
        * Same roundings on both sides (hipk_panels.hip: qmr_alpha_dev), so the history is the three-wait sequence's, bit for bit.
        * PRIMME_AMD_QMR_THREE_WAITS=1 keeps that sequence (A/B knob).  Needs reductions that stay on the device. */
-      const int three_waits = getenv("PRIMME_AMD_QMR_THREE_WAITS") != NULL;      /* (read per step: tests switch it within a process) */
       const int onewait = !three_waits && early_rho && fold_x && numIts + 1 < maxIterations && blockSize <= 8 &&
                           !(s->parallel && !s->dev_comm) && 3 * 64 + 3 * 8 < s->red_cap;
       double gg_all[8], rho_all[8], dot_all[8];

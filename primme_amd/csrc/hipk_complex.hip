@@ -250,7 +250,7 @@ static int zpanel_dots_t(hipk_ctx *ctx, int64_t m, const ZSegs &sa, const void *
    int64_t need = (m + 63) / 64;
    if (need < 1) need = 1;
    static int bpc = -1, mbpc = -1;                 /* HIPK_ZDOTS_BPC / HIPK_ZMFMA_BPC: workgroups per CU (measurement knobs, read once) */
-   if (bpc < 0) { const char *e = getenv("HIPK_ZDOTS_BPC"); bpc = e ? atoi(e) : 2; if (bpc < 1) bpc = 2; }      /* 2 per CU: 0.80 of HBM where 4 reach 0.68-0.78 and 8 0.57-0.69 (profiles/r06_zpanel_perf.txt) */
+   if (bpc < 0) { const char *e = getenv("HIPK_ZDOTS_BPC"); bpc = e ? atoi(e) : 4; if (bpc < 1) bpc = 4; }      /* 4: in isolation 2 per CU is faster (0.80 against 0.68-0.78 of HBM), inside the configs[3] solve it is SLOWER (0.395-0.405 s against 0.386-0.388 s per solve, same box): profiles/r06_zpanel_perf.txt */
    if (mbpc < 0) { const char *e = getenv("HIPK_ZMFMA_BPC"); mbpc = e ? atoi(e) : 2; if (mbpc < 1) mbpc = 2; }
    const int gx = (int)(need < (int64_t)ctx->num_cu * bpc ? need : (int64_t)ctx->num_cu * bpc);     /* a workgroup walks 64 rows per step */
    const size_t nout = 2 * (size_t)tot * nx;

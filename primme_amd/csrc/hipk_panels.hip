@@ -1254,8 +1254,11 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
    const int j0 = wv * CPW, q0 = wv * QPW;
    /* hdev != NULL: the coefficient vector and the Ritz value were left in HBM by hipk_rr_arrow (the iteration that was
     * enqueued before the host had seen the previous one); a status other than 0 means there is no valid pair: nothing to do */
+   /* (no valid pair: nothing is streamed and nothing is written to dst, but the partial sums ARE stored — zeros — so that the
+    * second stage behind this launch, and whatever was enqueued behind that, work on defined numbers) */
+   bool dead = false;
    if (hdev) {
-      if (hdev[33] != 0.0) return;
+      dead = hdev[33] != 0.0;
       theta = hdev[32];
    }
    double hj[CPW];
@@ -1286,7 +1289,7 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
     * stream) instead of striding through the panel with the whole grid */
    const int64_t gpb = (ngroups + gridDim.x - 1) / gridDim.x;
    const int64_t gbeg = blocked ? (int64_t)blockIdx.x * gpb : blockIdx.x;
-   const int64_t gend = blocked ? (gbeg + gpb < ngroups ? gbeg + gpb : ngroups) : ngroups;
+   const int64_t gend = dead ? gbeg : (blocked ? (gbeg + gpb < ngroups ? gbeg + gpb : ngroups) : ngroups);
    const int64_t gstep = blocked ? 1 : gridDim.x;
    for (int64_t g = gbeg; g < gend; g += gstep, buf ^= 1) {
       const int64_t e = g * 64 + lane;            /* index in LV units */
@@ -1355,7 +1358,7 @@ ritz_cgs_kernel(const T *__restrict__ V, const T *__restrict__ W, int64_t ld, in
     * as two one-row-per-lane steps on the last workgroup it was the tail of the whole launch -- 132.6 us against
     * 122.6 us for 31 k more rows that divide evenly (k = 15, L = 10, m = 2 000 250). */
    const int tailwg = blocked ? (int)gridDim.x - 1 : (int)(ngroups % gridDim.x);
-   if ((int)blockIdx.x == tailwg && ngroups * 64 * VW < m) {
+   if ((int)blockIdx.x == tailwg && ngroups * 64 * VW < m && !dead) {
       const int64_t i0 = ngroups * 64 * VW + (int64_t)lane * VW;
       double tv[CPW][VW], tw[CPW][VW], tq[QN][VW], twl[VW], px[VW], py[VW];
       bool live[VW];

@@ -322,7 +322,7 @@ csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32
  * shift != NULL: y = A x - shift[c] x(:,c), the first update of the projected operator in the
  * JDQMR inner iteration (reference inner_solve.c:853-858) fused into the operator. */
 #define XS_MAX 3072
-struct SpmmShift { double s[64]; int on; int nosplit; };
+struct SpmmShift { double s[64]; int on; int nosplit; int evenstride; };
 template <typename T, int NC, int XS, bool C16>
 __global__ void __launch_bounds__(HIPK_BLOCK)
 csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restrict__ twin, int ntiles,
@@ -340,7 +340,12 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
    const int2 tw = twin[tile];
    const int r0 = ti.x, r1 = ti.y, p0 = ti.z, nz = ti.w - ti.z, nr = r1 - r0;
    const int cmin = tw.x, cw = tw.y;
-   const bool win = cw > 0 && cw * ncols <= XS && nz <= TILE_NNZ;
+   /* LDS rows of the window are `xst` doubles apart, xst ODD: the lanes of a wave walk different rows of the matrix and read
+    * the window at unrelated row numbers — with a stride of ncols = 8 doubles (64 bytes = 16 banks) only four bank groups
+    * exist and a 32-lane read serialises up to eight-fold; with 9 the 32 lanes hit 32 distinct bank pairs (round 6:
+    * profiles/r06_spmm_window_stride.txt) */
+   const int xst = sh.evenstride ? ncols : (ncols | 1);
+   const bool win = cw > 0 && cw * xst <= XS && nz <= TILE_NNZ;
    if (nz <= TILE_NNZ) {
       {  /* every load of the tile — (value, column) pairs, row pointers, the x window — is issued before
           * the first LDS store: indices clamped, not predicated, so nothing branches around a load */
@@ -379,7 +384,7 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
 #pragma unroll
             for (int u = 0; u < XS / HIPK_BLOCK; u++) {
                const int idx = threadIdx.x + u * HIPK_BLOCK;
-               if (idx < nxw) { const int c = idx / cw, w = idx - c * cw; xs[w * ncols + c] = (double)xw[u]; }   /* LDS rows are ncols apart */
+               if (idx < nxw) { const int c = idx / cw, w = idx - c * cw; xs[w * xst + c] = (double)xw[u]; }   /* LDS rows are xst apart */
             }
          }
       }
@@ -403,7 +408,7 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
             for (int c = 0; c < NC; c++) cofs[c] = (c0 + c < ncols) ? c0 + c : ncols - 1;
             for (int q = qa; q < qb; q++) {
                const double v = (double)sval[q];
-               const double *xr = xs + scol[q] * ncols;
+               const double *xr = xs + scol[q] * xst;
 #pragma unroll
                for (int c = 0; c < NC; c++) acc[c] = fma(v, xr[cofs[c]], acc[c]);
             }
@@ -839,12 +844,15 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
          static int nosplit = -1;                   /* HIPK_SPMM_NO_SPLIT=1: one lane per row always (A/B knob) */
          if (nosplit < 0) nosplit = getenv("HIPK_SPMM_NO_SPLIT") != NULL;
          sh.nosplit = nosplit;
+         static int evenstride = -1;                /* HIPK_SPMM_EVEN_STRIDE=1: window rows ncols apart in LDS, as until round 5 (A/B knob) */
+         if (evenstride < 0) evenstride = getenv("HIPK_SPMM_EVEN_STRIDE") != NULL;
+         sh.evenstride = evenstride;
          for (int c = 0; c < 64; c++) sh.s[c] = (shift_host && c < ncols) ? shift_host[c] : 0.0;
          /* the window buffer in two sizes: 1536 values when every window of this matrix fits (38 KB of LDS per
           * workgroup, 4 per CU) and XS_MAX = 3072 otherwise (50 KB, 3 per CU) */
          static int bigxs = -1;                     /* HIPK_SPMM_BIG_WINDOW=1: always the large buffer (A/B knob) */
          if (bigxs < 0) bigxs = getenv("HIPK_SPMM_BIG_WINDOW") != NULL;
-         const bool small = !bigxs && (int64_t)A->cw_max * ncols <= 1536;
+         const bool small = !bigxs && (int64_t)A->cw_max * (evenstride ? ncols : (ncols | 1)) <= 1536;
 #define LAUNCH_WIN(NCV, XSV, C16V) hipLaunchKernelGGL((csr_window_block_kernel<T, NCV, XSV, C16V>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->tileinfo, A->twin, \
                   A->ntiles, A->rowptr, A->colind, csr16(A), A->row0 - A->c16back, (const T *)A->values, x, ldx, y, ldy, ncols, A->x0, sh)
 #define LAUNCH_WIN2(NCV, XSV) do { if (csr16(A)) LAUNCH_WIN(NCV, XSV, true); else LAUNCH_WIN(NCV, XSV, false); } while (0)

@@ -30,7 +30,7 @@
 #define PAT_MAXLEN 8
 #define PAT_MAXPAT 256
 /* PAIRS of consecutive rows per lane and trip / resident waves per SIMD the kernel is compiled for (build-time knobs for A/B
- * builds: scripts/build_pat_variants.sh) */
+ * builds: scripts/build_variant.sh with -DHIPK_PAT_RPL=.. -DHIPK_PAT_WPS=..) */
 #ifndef HIPK_PAT_RPL
 #define HIPK_PAT_RPL 1
 #endif

@@ -32,13 +32,15 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(case, tmp_path, transport="rccl"):
+def _launch(case, tmp_path, transport="rccl", strict=False):
     """transport: PRIMME_AMD_COMM of the ranks.  This module is about the RCCL transport (the default argument); one case
     also runs under "auto" (peer-to-peer mailboxes + RCCL when every rank has its own GPU, mailboxes alone with one rank)."""
     world = _world()
     port = _free_port()
     out = str(tmp_path / f"res_{case}_{transport}")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PRIMME_AMD_COMM=transport)
+    if strict:
+        env["PRIMME_AMD_COMM_STRICT"] = "1"      # mailboxes that do not map across the devices FAIL the create instead of falling back to RCCL
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker_gpu.py"), str(r), str(world), str(port), case, out],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -86,6 +88,19 @@ def test_auto_transport_halo_stencil(built, tmp_path):
     """the same halo case under PRIMME_AMD_COMM=auto: with one GPU per rank this is the mailboxes for reductions and halos
     next to RCCL for the bulk collectives — the form `bench.py --gpus N` runs by default"""
     world, res = _launch("halo", tmp_path, transport="auto")
+    ex = problems.laplacian_eigenvalues((24, 25, 26), 6)
+    assert np.max(np.abs(np.sort(res[0]["evals"]) - ex)) <= 1e-10 * 12.0
+    assert abs(sum(r["evecs_norm2"] for r in res) - 6.0) < 1e-8
+
+
+@pytest.mark.parametrize("transport", ["auto", "rccl"])
+def test_both_transports_strict_at_the_full_device_count(built, tmp_path, transport):
+    """First contact with distinct GPUs made boring (VERDICT r05 Next #7): at world = device_count() the halo case must pass on
+    BOTH transports, and under PRIMME_AMD_COMM_STRICT=1 the auto transport must really be the peer-to-peer mailboxes — if they
+    do not map across the devices the communicator fails to come up (the ranks exit non-zero and this test fails) instead of
+    falling back to RCCL silently; _launch asserts the transport every rank reports ("hybrid" with more than one device, "ipc"
+    with one, "rccl" when asked for)."""
+    world, res = _launch("halo", tmp_path, transport=transport, strict=True)
     ex = problems.laplacian_eigenvalues((24, 25, 26), 6)
     assert np.max(np.abs(np.sort(res[0]["evals"]) - ex)) <= 1e-10 * 12.0
     assert abs(sum(r["evecs_norm2"] for r in res) - 6.0) < 1e-8
