@@ -860,8 +860,12 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 #endif
    const int refined = (p->projectionParams.projection == primme_proj_refined);
    const int harmonic = (p->projectionParams.projection == primme_proj_harmonic) || refined;
-   if (p->massMatrixMatvec ||
-         (harmonic && (p->target == primme_smallest || p->target == primme_largest || p->target == primme_largest_abs))) {
+   /* harmonic extraction with an extremal target: the reference's own solve_H_Harm has no case for it (solve_projection.c:469-482,
+    * `default: assert(0)`), so there is nothing to be at parity with.  Refined extraction with an extremal target is defined
+    * as soon as the caller gives the shift of the factorisation (targetShifts[0]; without one the reference dereferences a
+    * NULL pointer, main_iter.c:465): round 6 lets it through */
+   const int extremal = (p->target == primme_smallest || p->target == primme_largest || p->target == primme_largest_abs);
+   if (p->massMatrixMatvec || (harmonic && extremal && !(refined && p->numTargetShifts > 0 && p->targetShifts))) {
       if (p->printLevel > 0 && p->outputFile)
          fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / harmonic or refined "
                "projection with an extremal target) is not on the device path\n");

@@ -322,6 +322,7 @@ csr_rows_block_kernel(const int32_t *__restrict__ tiles, int ntiles, const int32
  * shift != NULL: y = A x - shift[c] x(:,c), the first update of the projected operator in the
  * JDQMR inner iteration (reference inner_solve.c:853-858) fused into the operator. */
 #define XS_MAX 3072
+#define XS_SMALL 1728      /* 192 window rows of 8 columns on the odd stride of 9: 39 KB of LDS per workgroup, still 4 per CU (1536 until round 6) */
 struct SpmmShift { double s[64]; int on; int nosplit; int evenstride; };
 template <typename T, int NC, int XS, bool C16>
 __global__ void __launch_bounds__(HIPK_BLOCK)
@@ -351,7 +352,7 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
           * the first LDS store: indices clamped, not predicated, so nothing branches around a load */
          T tv[TILE_PER_LANE];
          int32_t tc[TILE_PER_LANE];
-         T xw[XS / HIPK_BLOCK];
+         T xw[(XS + HIPK_BLOCK - 1) / HIPK_BLOCK];
 #pragma unroll
          for (int u = 0; u < TILE_PER_LANE; u++) {
             const int q = threadIdx.x + u * HIPK_BLOCK;
@@ -365,7 +366,7 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
          const int nxw = win ? cw * ncols : 0;
          if (win) {
 #pragma unroll
-            for (int u = 0; u < XS / HIPK_BLOCK; u++) {
+            for (int u = 0; u < (XS + HIPK_BLOCK - 1) / HIPK_BLOCK; u++) {
                const int idx = threadIdx.x + u * HIPK_BLOCK;
                const int ic = idx < nxw ? idx : nxw - 1;
                const int c = ic / cw, w = ic - c * cw;          /* coalesced along the window for each column */
@@ -382,7 +383,7 @@ csr_window_block_kernel(const int4 *__restrict__ tileinfo, const int2 *__restric
          if (threadIdx.x == 0 && nr == TILE_ROWS) rp[TILE_ROWS] = rowptr[r0 + TILE_ROWS] - p0;
          if (win) {
 #pragma unroll
-            for (int u = 0; u < XS / HIPK_BLOCK; u++) {
+            for (int u = 0; u < (XS + HIPK_BLOCK - 1) / HIPK_BLOCK; u++) {
                const int idx = threadIdx.x + u * HIPK_BLOCK;
                if (idx < nxw) { const int c = idx / cw, w = idx - c * cw; xs[w * xst + c] = (double)xw[u]; }   /* LDS rows are xst apart */
             }
@@ -852,12 +853,12 @@ static int csr_matvec_t(hipk_csr *A, hipStream_t stream, const T *x, int64_t ldx
           * workgroup, 4 per CU) and XS_MAX = 3072 otherwise (50 KB, 3 per CU) */
          static int bigxs = -1;                     /* HIPK_SPMM_BIG_WINDOW=1: always the large buffer (A/B knob) */
          if (bigxs < 0) bigxs = getenv("HIPK_SPMM_BIG_WINDOW") != NULL;
-         const bool small = !bigxs && (int64_t)A->cw_max * (evenstride ? ncols : (ncols | 1)) <= 1536;
+         const bool small = !bigxs && (int64_t)A->cw_max * (evenstride ? ncols : (ncols | 1)) <= XS_SMALL;
 #define LAUNCH_WIN(NCV, XSV, C16V) hipLaunchKernelGGL((csr_window_block_kernel<T, NCV, XSV, C16V>), dim3(gx), dim3(HIPK_BLOCK), 0, stream, A->tileinfo, A->twin, \
                   A->ntiles, A->rowptr, A->colind, csr16(A), A->row0 - A->c16back, (const T *)A->values, x, ldx, y, ldy, ncols, A->x0, sh)
 #define LAUNCH_WIN2(NCV, XSV) do { if (csr16(A)) LAUNCH_WIN(NCV, XSV, true); else LAUNCH_WIN(NCV, XSV, false); } while (0)
-         if (ncols <= 2) { if (small) LAUNCH_WIN2(2, 1536); else LAUNCH_WIN2(2, XS_MAX); }
-         else { if (small) LAUNCH_WIN2(4, 1536); else LAUNCH_WIN2(4, XS_MAX); }
+         if (ncols <= 2) { if (small) LAUNCH_WIN2(2, XS_SMALL); else LAUNCH_WIN2(2, XS_MAX); }
+         else { if (small) LAUNCH_WIN2(4, XS_SMALL); else LAUNCH_WIN2(4, XS_MAX); }
 #undef LAUNCH_WIN2
 #undef LAUNCH_WIN
       } else if (ncols == 1 && force == 0) {

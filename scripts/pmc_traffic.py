@@ -24,8 +24,8 @@ if len(sys.argv) > 5:
         else: alg = (bl.get("configs1") or bl.get("north_star"))["roofline"]["alg_bytes_per_launch"]
     except Exception:
         alg = None
-lines = [f"# {tag} — HBM traffic from PMC counters ({'BASELINE configs[1]' if workload == 'lap3d_2m' else 'north-star workload lap2d_10m, first outer iterations'}, one solve, separate --pmc passes)", "",
-         "Collected by `scripts/profile_round.sh` with `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `rocprofv3 --pmc WRITE_SIZE --kernel-trace`",
+lines = [f"# {tag} — HBM traffic from PMC counters ({'BASELINE configs[1]' if workload == 'lap3d_2m' else 'north-star workload lap2d_10m'}, one solve, separate --pmc passes)", "",
+         "Collected (scripts/r06_step6.sh) with `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `rocprofv3 --pmc WRITE_SIZE --kernel-trace`",
          f"on `python scripts/one_solve.py csr {workload}` (gpurun, 1xMI355X).  The counters report KiB.  Correction as `MI355X_MICROARCH.md` §HBM prescribes for gfx950:",
          "FETCH_SIZE counts half of the bytes of a wide coalesced streaming read, so fetched bytes = FETCH_SIZE x 1024 x 2; WRITE_SIZE x 1024 is used as reported.", "",
          "| kernel | launches | avg us | FETCH_SIZE KiB (avg) | fetched MB (x2) | WRITE_SIZE KiB (avg) | written MB | HBM MB / launch |", "|---|---|---|---|---|---|---|---|"]

@@ -102,6 +102,29 @@ def test_invariant_subspace_against_the_references_eigenvectors(built, name):
     subspace_check(name, r, g)
 
 
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("dims,tgt,sh", [((20, 21), "smallest", 0.0), ((20, 21), "largest", 8.0), ((9, 10, 11), "largest", 12.0), ((20, 21), "largest_abs", 8.0)])
+def test_refined_extraction_with_an_extremal_target_against_live_reference(built, dims, tgt, sh):
+    """Refined extraction with an EXTREMAL target (round 6; returned -44 before): the reference lets it through
+    (primme_c.c:512-520) and runs the refined procedure around targetShifts[0] — the pairs it converges to are the ones whose
+    refined residual the target ordering prefers, not the ones the name of the target suggests (smallest + shift 0 ends at the
+    top of the spectrum).  Whatever one thinks of that, a drop-in does the same: the same set of eigenvalues as the live
+    reference, iteration counts within 8 %.  (Harmonic extraction with an extremal target stays refused: the reference's own
+    solve_H_Harm has no case for it, solve_projection.c:469-482 `default: assert(0)`.)"""
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    op = Operator(n, csr=(rp, ci, va))
+    aN = 8.0 if len(dims) == 2 else 12.0
+    kw = dict(numEvals=4, target=tgt, targetShifts=[sh], eps=1e-9, aNorm=aN, projection="refined", v0=problems.start_vector(n))
+    a = eigsh(op, backend="reference", **kw)
+    b = eigsh(op, backend="hostcheck", **kw)
+    assert a.ret == b.ret == 0 and a.initSize == b.initSize == 4
+    assert np.max(np.abs(np.sort(a.evals) - np.sort(b.evals))) <= 1e-10 * aN
+    assert np.all(b.resNorms <= 1e-9 * aN * (1 + 1e-6))
+    assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= max(3, 0.08 * a.stats["numOuterIterations"])
+    h = eigsh(op, backend="hostcheck", **dict(kw, projection="harmonic"))
+    assert h.ret == -44
+
+
 def test_block_jdqmr_with_the_references_own_indexing(built, monkeypatch):
     """PRIMME_AMD_JDQMR_REF_INDEXING=1 (csrc/eigs_jd.c): the block QMR recurrences indexed the way the reference indexes them —
     sigma_prev, Theta and rho written by block position, read by original column, x permuted once more per projector it doubles
