@@ -873,9 +873,12 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    }
 
    /* the basis never grows beyond the space itself, whatever maxBasisSize says */
-   if (PA_MIN((int64_t)p->maxBasisSize, p->n - p->numOrthoConst) > 255) {
+   /* (real panels: the wide-basis restart kernel takes 1 023 columns since round 6, hipk_panels.hip:ritz_big_kernel; the complex
+    * one still 255; the reference has no limit, primme_c.c:470-487) */
+   const int max_basis = PA_IS_COMPLEX ? 255 : 1023;
+   if (PA_MIN((int64_t)p->maxBasisSize, p->n - p->numOrthoConst) > max_basis) {
       if (p->printLevel > 0 && p->outputFile)
-         fprintf(p->outputFile, "primme_amd: maxBasisSize > 255 is not on the device path\n");
+         fprintf(p->outputFile, "primme_amd: maxBasisSize > %d is not on the device path\n", max_basis);
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 

@@ -125,6 +125,24 @@ def test_refined_extraction_with_an_extremal_target_against_live_reference(built
     assert h.ret == -44
 
 
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+def test_wide_basis_against_live_reference(built):
+    """maxBasisSize beyond 255 (round 6: up to 1 023 on real panels; the reference has no limit, primme_c.c:470-487): basis 260,
+    restart 60 on a 50 x 60 Laplacian, two restarts through the wide-basis update — the reference's eigenvalues, its restart
+    count, its iteration count to 3 % (the histories of two bases this wide separate at rounding level)."""
+    dims = (50, 60)
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    op = Operator(n, csr=(rp, ci, va))
+    kw = dict(numEvals=8, eps=1e-11, aNorm=8.0, maxBasisSize=260, minRestartSize=60, v0=problems.start_vector(n), maxBlockSize=1)
+    a = eigsh(op, backend="reference", **kw)
+    b = eigsh(op, backend="hostcheck", **kw)
+    assert a.ret == b.ret == 0 and b.initSize == 8 and b.params["maxBasisSize"] == 260
+    assert np.max(np.abs(a.evals - b.evals)) <= 1e-10 * 8.0
+    assert np.max(np.abs(b.evals - problems.laplacian_eigenvalues(dims, 8))) <= 1e-10 * 8.0
+    assert b.stats["numRestarts"] == a.stats["numRestarts"] >= 2
+    assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= 0.03 * a.stats["numOuterIterations"]
+
+
 def test_block_jdqmr_with_the_references_own_indexing(built, monkeypatch):
     """PRIMME_AMD_JDQMR_REF_INDEXING=1 (csrc/eigs_jd.c): the block QMR recurrences indexed the way the reference indexes them —
     sigma_prev, Theta and rho written by block position, read by original column, x permuted once more per projector it doubles
@@ -221,8 +239,9 @@ def test_edge_cases(built):
     op = Operator(n, csr=(rp, ci, va))
     r = eigsh(op, backend="hostcheck", numEvals=5, eps=1e-12, aNorm=8.0, v0=problems.start_vector(n), maxMatvecs=40)
     assert r.ret == -3 and r.stats["numMatvecs"] <= 41
-    # configurations that are not on the device path fail loudly with -44
-    r = eigsh(op, backend="hostcheck", numEvals=2, maxBasisSize=300, aNorm=8.0, v0=problems.start_vector(n))
+    # configurations that are not on the device path fail loudly with -44 (a basis beyond 1 023 columns; 255 until round 6)
+    rpw, ciw, vaw, nw = problems.laplacian_csr((40, 41))
+    r = eigsh(Operator(nw, csr=(rpw, ciw, vaw)), backend="hostcheck", numEvals=2, maxBasisSize=1100, aNorm=8.0, v0=problems.start_vector(nw))
     assert r.ret == -44
 
 
