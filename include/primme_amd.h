@@ -226,6 +226,10 @@ int cprimme(float *evals, void *evecs, float *resNorms, primme_params *primme);
  * (primme_amd_comm.h, primme_amd_kernels.h). */
 void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       struct primme_params *primme, int *ierr);
+/* massMatrixMatvec for a device CSR mass matrix B of a generalised problem A x = lambda B x (round 6; reference
+ * primme_eigs.h:182-185, auxiliary_eigs.c:250-290): set primme->massMatrix = another operator handle. */
+void primme_amd_mass_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
+      struct primme_params *primme, int *ierr);
 /* Jacobi (diagonal) preconditioner y = (diag(A) - shift)^-1 x with the shifts the
  * solver publishes in primme->ShiftsForPreconditioner; primme->preconditioner =
  * the same operator handle, flavour chosen with

@@ -108,6 +108,17 @@ class ReferenceBackend:
         cb = F.BLOCK_OP(mv)
         keep.append(cb)
         p.matrixMatvec = C.cast(cb, C.c_void_p)
+        if sess.mass is not None:      # generalised problem: the mass matrix as a numpy callback
+
+            def bmv(x, ldx, y, ldy, bs, pp, ierr):
+                nb, lx, ly = bs[0], ldx[0], ldy[0]
+                X = view(x, nb, lx)
+                Y = view(y, nb, ly)
+                Y[:, :nLocal] = sess.mass.apply_numpy(X[:, :nLocal].T.astype(np.float64)).T
+                ierr[0] = 0
+            bcb = F.BLOCK_OP(bmv)
+            keep.append(bcb)
+            p.massMatrixMatvec = C.cast(bcb, C.c_void_p)
         if precond is not None:
             dg = np.real(op.diagonal())        # Hermitian: the diagonal is real (divide by a real number, as the device kernel does)
             zrot = None
@@ -225,12 +236,12 @@ def backend_object(backend):
 
 
 class Session(_api.Session):
-    def __init__(self, op, comm=None, dtype=np.float64, backend="hip", complex_form="native"):
-        super().__init__(op, comm=comm, dtype=dtype, backend=backend_object(backend), complex_form=complex_form)
+    def __init__(self, op, comm=None, dtype=np.float64, backend="hip", complex_form="native", mass=None):
+        super().__init__(op, comm=comm, dtype=dtype, backend=backend_object(backend), complex_form=complex_form, mass=mass)
 
 
-def eigsh(op, backend="hip", comm=None, dtype=np.float64, complex_form="native", **kw):
-    s = Session(op, comm=comm, dtype=dtype, backend=backend, complex_form=complex_form)
+def eigsh(op, backend="hip", comm=None, dtype=np.float64, complex_form="native", mass=None, **kw):
+    s = Session(op, comm=comm, dtype=dtype, backend=backend, complex_form=complex_form, mass=mass)
     try:
         return s.solve(**kw)
     finally:

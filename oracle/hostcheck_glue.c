@@ -74,6 +74,10 @@ void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *
    primme_amd_operator *op = (primme_amd_operator *)p->matrix;
    *ierr = primme_amd_operator_apply(op, NULL, x, *ldx * op->ldscale, y, *ldy * op->ldscale, *bs);
 }
+void primme_amd_mass_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
+   primme_amd_operator *op = (primme_amd_operator *)p->massMatrix;
+   *ierr = op ? primme_amd_operator_apply(op, NULL, x, *ldx * op->ldscale, y, *ldy * op->ldscale, *bs) : 1;
+}
 void primme_amd_jacobi_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, struct primme_params *p, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)p->preconditioner;
    double fixed[64];

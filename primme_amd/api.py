@@ -85,8 +85,10 @@ def _resolve_backend(backend):
 
 
 class Session:
-    def __init__(self, op, comm=None, dtype=np.float64, backend="hip", complex_form="native"):
+    def __init__(self, op, comm=None, dtype=np.float64, backend="hip", complex_form="native", mass=None):
         self.op, self.comm = op, comm
+        self.mass = mass         # Operator of the mass matrix B of a generalised problem A x = lambda B x (real, CSR), or None
+        self.mass_oph = None
         self.be = _resolve_backend(backend)
         self.backend = self.be.name
         self.dtype = np.dtype(dtype)
@@ -146,6 +148,22 @@ class Session:
         self.handles.append(("op", oph))
         if self.cplx and self.real_form: lib.primme_amd_operator_set_complex(oph, 1)
         self.oph = oph
+        if mass is not None:
+            if self.cplx or mass.csr is None:
+                raise ValueError("mass matrix: real CSR operators")
+            rpb, cib, vab = mass.csr
+            rpb = np.ascontiguousarray(rpb, dtype=np.int32); cib = np.ascontiguousarray(cib, dtype=np.int32)
+            vab = np.ascontiguousarray(vab, dtype=self.dtype)
+            Bh = C.c_void_p()
+            if lib.hipk_csr_create(ctx, self.dt, mass.nrows, mass.n, mass.row0, rpb.ctypes.data_as(C.c_void_p),
+                                   cib.ctypes.data_as(C.c_void_p), vab.ctypes.data_as(C.c_void_p), C.byref(Bh)):
+                raise RuntimeError("mass matrix creation failed")
+            self.handles.append(("csr", Bh))
+            ophB = C.c_void_p()
+            if lib.primme_amd_operator_create(C.byref(ophB), Bh, comm):
+                raise RuntimeError("mass operator handle creation failed")
+            self.handles.append(("op", ophB))
+            self.mass_oph = ophB
 
     def close(self):
         for kind, h in reversed(self.handles):
@@ -214,6 +232,9 @@ class Session:
         else:
             p.matrix = self.oph
             p.matrixMatvec = C.cast(lib.primme_amd_matvec, C.c_void_p)
+            if self.mass_oph is not None:    # generalised problem: B through the ready-made callback over a second operator handle
+                p.massMatrix = self.mass_oph
+                p.massMatrixMatvec = C.cast(lib.primme_amd_mass_matvec, C.c_void_p)
             if user_matvec is not None:      # an application callback instead of the ready-made one
                 keep.append(user_matvec)
                 p.matrixMatvec = C.cast(user_matvec, C.c_void_p)
@@ -287,14 +308,14 @@ class Session:
         return Result(ret, evals, None if evecs is None else evecs[nOC:nOC + numEvals].T.copy(), resNorms, p)
 
 
-def eigsh(op, backend="hip", comm=None, dtype=np.float64, complex_form="native", **kw):
+def eigsh(op, backend="hip", comm=None, dtype=np.float64, complex_form="native", mass=None, **kw):
     """One-shot: compute a few eigenpairs of the symmetric operator `op` (see Session.solve).
 
     v0: optional (nLocal x initSize) initial guesses -> initBasisMode defaults to
     primme_init_user so that no random numbers enter (parity runs).
     precond: None | "jacobi" (Davidson: per-vector shifts) | ("jacobi", shift) (fixed shift).
     """
-    s = Session(op, comm=comm, dtype=dtype, backend=backend, complex_form=complex_form)
+    s = Session(op, comm=comm, dtype=dtype, backend=backend, complex_form=complex_form, mass=mass)
     try:
         return s.solve(**kw)
     finally:

@@ -166,6 +166,12 @@ extern "C" int primme_amd_operator_jacobi_data(primme_amd_operator *op, const vo
 }
 
 /* ---- the callbacks ---------------------------------------------------------- */
+extern "C" void primme_amd_mass_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
+      struct primme_params *primme, int *ierr) {
+   primme_amd_operator *op = (primme_amd_operator *)primme->massMatrix;
+   void *stream = primme->queue ? (void *)*(hipStream_t *)primme->queue : NULL;
+   *ierr = op ? primme_amd_operator_apply(op, stream, x, *ldx * op->ldscale, y, *ldy * op->ldscale, *blockSize) : 1;
+}
 extern "C" void primme_amd_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *blockSize,
       struct primme_params *primme, int *ierr) {
    primme_amd_operator *op = (primme_amd_operator *)primme->matrix;

@@ -171,8 +171,16 @@ int pa_ortho_block_gram(pa_solver *s, char *Vp, int64_t ldV, int b1, int b2, cha
             CHK(right_multiply(s, X, ldV, nX, M));
          }
       }
-      /* A = [Q V(0:b2)]' X */
-      CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segsA, 2, X, ldV, nX, s->d_red, nrowsA));
+      /* A = [Q V(0:b2)]' B X: with a mass matrix B X is formed through the callback first (the reference does the same in every
+       * sweep, ortho.c:621-629), into the scratch panel */
+      const char *Xrhs = X;
+      int64_t ldrhs = ldV;
+      if (s->B) {
+         if (nX > s->nBT) { rc = PRIMME_FUNCTION_UNAVAILABLE; break; }
+         if ((rc = pa_apply_B(s, X, ldV, s->BT, s->ld, nX))) break;
+         Xrhs = s->BT; ldrhs = s->ld;
+      }
+      CHK(hipk_panel_dots(s->ctx, s->dt, s->m, segsA, 2, Xrhs, ldrhs, nX, s->d_red, nrowsA));
       CHK(pa_reduce(s, s->d_red, SD * nrowsA * nX, 0, 0));
       for (int c = 0; c < nX; c++)
          for (int i = 0; i < nrowsA; i++) A[i + (size_t)c * ldG] = ((const HS *)s->h_red)[i + (size_t)c * nrowsA];

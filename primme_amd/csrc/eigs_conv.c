@@ -25,7 +25,7 @@ void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv,
    (void)eval; (void)evec;
    /* machine epsilon of the working precision is kept in convtest when we install it */
    double meps = p->convtest ? *(double *)p->convtest : PA_EPS;
-   *isConv = *rNorm < PA_MAX(p->eps, meps * 2) * pa_problem_norm(0, p);
+   *isConv = *rNorm < PA_MAX(p->eps, meps * (p->massMatrixMatvec ? 1 : 2)) * pa_problem_norm(0, p);
    *ierr = 0;
 }
 
@@ -36,7 +36,7 @@ void pa_conv_test_absolute(double *eval, void *evec, double *rNorm, int *isConv,
 static int call_conv_test(pa_solver *s, double eval, void *evec, double rnorm, int *isconv) {
    primme_params *p = s->p;
    if (p->convTestFun == pa_conv_test_absolute) {
-      *isconv = rnorm < PA_MAX(p->eps, s->mach_eps * 2) * pa_problem_norm(0, p);
+      *isconv = rnorm < PA_MAX(p->eps, s->mach_eps * (p->massMatrixMatvec ? 1 : 2)) * pa_problem_norm(0, p);      /* (primme_c.c:555-570) */
       return 0;
    }
    return pa_call_conv_test(p, eval, evec, rnorm, isconv);
@@ -92,7 +92,7 @@ int pa_check_convergence(pa_solver *s, char *X, int64_t ldX, int givenX, char *R
       } else if (bn <= p->stats.estimateResidualError && reset) {
          flags[i] = SKIP_RESTART;
          *reset = 1;
-      } else if (p->locking && numLocked > 0 && practConvCheck >= 0) {
+      } else if (p->locking && numLocked > 0 && practConvCheck >= 0 && !s->B) {      /* (the projector of the practical test would need B Q: not taken with a mass matrix) */
          if (givenR && bn < attainableTol) toProject[numToProject++] = i - left;
          else if (flags[i] != PRACT_CONV) flags[i] = UNCONV;
       } else {

@@ -77,6 +77,9 @@ static void bridge_block_op(void (*fn)(void *, PRIMME_INT *, void *, PRIMME_INT 
 static void bridge_matvec(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, primme_params *qp, int *ierr) {
    bridge_block_op(HSIDE(qp)->user->matrixMatvec, x, ldx, y, ldy, bs, qp, ierr);
 }
+static void bridge_mass(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, primme_params *qp, int *ierr) {
+   bridge_block_op(HSIDE(qp)->user->massMatrixMatvec, x, ldx, y, ldy, bs, qp, ierr);      /* generalised problems (round 6) */
+}
 static void bridge_precond(void *x, PRIMME_INT *ldx, void *y, PRIMME_INT *ldy, int *bs, primme_params *qp, int *ierr) {
    bridge_block_op(HSIDE(qp)->user->applyPreconditioner, x, ldx, y, ldy, bs, qp, ierr);
 }
@@ -140,6 +143,7 @@ static int solve_host(void *evals, void *evecs, void *resNorms, primme_params *p
    q->ldevecs = m; q->ldOPs = m;
    if (primme->matrixMatvec) q->matrixMatvec = bridge_matvec;
    if (primme->applyPreconditioner) q->applyPreconditioner = bridge_precond;
+   if (primme->massMatrixMatvec) q->massMatrixMatvec = bridge_mass;
    if (primme->convTestFun) q->convTestFun = bridge_conv_test;
    if (primme->monitorFun) q->monitorFun = bridge_monitor;
    if (primme->globalSumReal) q->globalSumReal = bridge_global_sum;

@@ -265,7 +265,13 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
             ((p->correctionParams.precondition && p->applyPreconditioner) ||
                   (p->locking && p->orth == primme_orth_implicit_I))) {
          for (int b = 0; b < blockSize; b++) colsen[b] = -olsen[b];
-         rc = hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)colsen, x, s->ld, r, s->ld, blockSize);
+         const char *xm = x;                       /* r -= eps B x for a generalised problem (correction.c:340-352) */
+         if (s->B) {
+            if (blockSize > s->nBT) rc = PRIMME_FUNCTION_UNAVAILABLE;
+            if (!rc) rc = pa_apply_B(s, x, s->ld, s->BT, s->ld, blockSize);
+            xm = s->BT;
+         }
+         if (!rc) rc = hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)colsen, xm, s->ld, r, s->ld, blockSize);
       }
       if (!rc && !s->fuse_gd) rc = pa_precond(s, r, s->ld, x, s->ld, blockSize);
    }
@@ -281,7 +287,13 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
  * just after a restart: V holds Ritz vectors, W = A V) */
 static int verify_norms(pa_solver *s, int nb, double *resNorms, int *flags, int *numConverged) {
    if (nb > 0) {
-      CHK(hipk_residual_cols(s->ctx, s->dt, s->m, s->V, s->ld, s->W, s->ld, nb, s->hVals, s->d_red));
+      const char *Vm = s->V;      /* generalised problem: the residual is W - theta B V */
+      if (s->B) {
+         if (nb > s->nBT) return PRIMME_FUNCTION_UNAVAILABLE;
+         CHK(pa_apply_B(s, s->V, s->ld, s->BT, s->ld, nb));
+         Vm = s->BT;
+      }
+      CHK(hipk_residual_cols(s->ctx, s->dt, s->m, Vm, s->ld, s->W, s->ld, nb, s->hVals, s->d_red));
       CHK(pa_reduce(s, s->d_red, nb, 0, 0));
       for (int i = 0; i < nb; i++) resNorms[i] = sqrt(s->h_red[i]);
       CHK(pa_check_convergence(s, s->V, s->ld, 1, s->W, s->ld, 1, 0, 0, nb, flags, resNorms, s->hVals, NULL, 0));
@@ -397,8 +409,8 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
    p->stats.estimateMinEVal = HUGE_VAL;
    p->stats.estimateMaxEVal = -HUGE_VAL;
    p->stats.estimateLargestSVal = -HUGE_VAL;
-   p->stats.estimateBNorm = 1.0;
-   p->stats.estimateInvBNorm = 1.0;
+   p->stats.estimateBNorm = p->massMatrixMatvec ? -HUGE_VAL : 1.0;        /* (main_iter.c:387-388) */
+   p->stats.estimateInvBNorm = p->massMatrixMatvec ? -HUGE_VAL : 1.0;
    for (i = 0; i < p->numEvals; i++) perm[i] = i;
    for (i = 0; i < p->maxBasisSize; i++) { map[i] = i; s->basisNorms[i] = 0.0; }
    s->targetShiftIndex = 0;
@@ -782,7 +794,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
    }
 
 clean:
-   if (p->aNorm <= 0.0) p->aNorm = p->stats.estimateLargestSVal;
+   if (p->aNorm <= 0.0) p->aNorm = p->massMatrixMatvec ? p->stats.estimateLargestSVal / p->stats.estimateInvBNorm : p->stats.estimateLargestSVal;      /* (main_iter.c:1344-1347) */
    /* locked vectors are stored in convergence order: sort them like evals */
    CHK(permute_dev_cols(s, ECOL(s, p->numOrthoConst), s->ldevecs, p->initSize, perm));
    CHK(hipk_sync(s->ctx));
@@ -797,7 +809,7 @@ static void free_solver(pa_solver *s) {
       hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T); hipk_free(s->ctx, s->Jw);
       hipk_free(s->ctx, s->V2); hipk_free(s->ctx, s->W2); hipk_free(s->ctx, s->d_coef2); hipk_free(s->ctx, s->d_theta2);
       hipk_host_free(s->ctx, s->h_coef2); hipk_host_free(s->ctx, s->h_theta2);
-      hipk_free(s->ctx, s->evecsHat); hipk_free(s->ctx, s->Q);
+      hipk_free(s->ctx, s->evecsHat); hipk_free(s->ctx, s->Q); hipk_free(s->ctx, s->BT);
       hipk_free(s->ctx, s->d_red); hipk_free(s->ctx, s->d_coef); hipk_free(s->ctx, s->d_theta);
       hipk_host_free(s->ctx, s->h_red); hipk_host_free(s->ctx, s->h_coef); hipk_host_free(s->ctx, s->h_theta);
       hipk_ctx_destroy(s->ctx);
@@ -824,6 +836,9 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    primme_set_defaults(p);
    if (p->orth == primme_orth_default)
       p->orth = (work_is_float || p->maxBlockSize > 1) ? primme_orth_explicit_I : primme_orth_implicit_I;
+   /* generalised problems run on the tracked-Gram path whatever was asked for (the reference would take Bortho_gen with
+    * orth = implicit_I; same subspaces, another orthonormalisation of them) */
+   if (p->massMatrixMatvec) p->orth = primme_orth_explicit_I;
    if (p->ldOPs == -1) p->ldOPs = p->nLocal;
    if (!evals_out && !evecs && !resNorms_out) return 0;
    if (p->iseed[0] < 0 || p->iseed[0] > 4095) p->iseed[0] = p->procID % 4096;
@@ -865,9 +880,15 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
     * as soon as the caller gives the shift of the factorisation (targetShifts[0]; without one the reference dereferences a
     * NULL pointer, main_iter.c:465): round 6 lets it through */
    const int extremal = (p->target == primme_smallest || p->target == primme_largest || p->target == primme_largest_abs);
-   if (p->massMatrixMatvec || (harmonic && extremal && !(refined && p->numTargetShifts > 0 && p->targetShifts))) {
+   /* mass matrix (round 6): real panels, Rayleigh-Ritz (check_input: -39 otherwise, like the reference), the Generalized-Davidson
+    * family — the JDQMR inner solver with B (projectors on B Q, B x: inner_solve.c:283-300, correction.c:862-997) and the
+    * dynamic switch into it are not restated: -44 */
+   const int mass_unavailable = p->massMatrixMatvec &&
+         (PA_IS_COMPLEX || p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0 ||
+          (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX));
+   if (mass_unavailable || (harmonic && extremal && !(refined && p->numTargetShifts > 0 && p->targetShifts))) {
       if (p->printLevel > 0 && p->outputFile)
-         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix / harmonic or refined "
+         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix with an inner solver / harmonic "
                "projection with an extremal target) is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
@@ -913,6 +934,8 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
                  !p->correctionParams.projectors.RightX &&
                  (p->convTestFun == pa_conv_test_absolute || pa_svds_conv_test_is_vector_free(p)));
    s->maxRank = p->numOrthoConst + (p->locking ? p->numEvals : 0) + p->maxBasisSize;
+   s->B = p->massMatrixMatvec != NULL;
+   if (s->B) s->fuse_gd = 0;
    if (hipk_ctx_create(&s->ctx, p->queue)) { free(s); return PRIMME_UNEXPECTED_FAILURE; }
    /* peer-to-peer transport: the second stage of a reduction may exchange with the other ranks itself */
    if (s->dev_comm) (void)pa_comm_attach_ctx(p->commInfo, s->ctx);
@@ -945,6 +968,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
         ((p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) && hipk_malloc(s->ctx, colBytes * 6 * b, (void **)&s->Jw)) ||
         hipk_malloc(s->ctx, ((size_t)s->red_cap * 3 + 64) * 8, (void **)&s->d_red) ||
         (harmonic && hipk_malloc(s->ctx, colBytes * K, (void **)&s->Q)) ||
+        (s->B && hipk_malloc(s->ctx, colBytes * (s->nBT = PA_MAX(3 * (K + b), PA_MAX(p->numOrthoConst, 3 * (b + nev)))), (void **)&s->BT)) ||
         (need_hat && hipk_malloc(s->ctx, (size_t)(s->ldevecs > 0 ? s->ldevecs : 1) * s->es * maxEvecs, (void **)&s->evecsHat)) ||
         hipk_malloc(s->ctx, s->coef_cap * sizeof(HS), (void **)&s->d_coef) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta) ||
         hipk_host_alloc(s->ctx, ((size_t)s->red_cap * 3 + 64) * 8, (void **)&s->h_red) ||

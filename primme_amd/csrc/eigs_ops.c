@@ -23,6 +23,11 @@ double pa_wtime(void) {
 
 /* ---- problem norm / machine epsilons (reference auxiliary_eigs.c:498-591) ------ */
 double pa_problem_norm(int overrideUser, const primme_params *p) {
+   if (p->massMatrixMatvec) {      /* an estimate of |B^-1 A| (auxiliary_eigs.c:567-591) */
+      const double user = (p->aNorm > 0.0 && p->invBNorm > 0.0) ? p->aNorm * p->invBNorm : 0.0;
+      if (!overrideUser) return user > 0.0 ? user : p->stats.estimateLargestSVal;
+      return PA_MAX(user, p->stats.estimateLargestSVal);
+   }
    if (!overrideUser) return p->aNorm > 0.0 ? p->aNorm : p->stats.estimateLargestSVal;
    return PA_MAX(p->aNorm > 0.0 ? p->aNorm : 0.0, p->stats.estimateLargestSVal);
 }
@@ -144,6 +149,22 @@ int pa_matvec(pa_solver *s, char *Vp, int64_t ldV, char *Wp, int64_t ldW, int c0
    if (s->phase_timing) CHK(hipk_sync(s->ctx));
    p->stats.timeMatvec += pa_wtime() - t0;
    p->stats.numMatvecs += nc;
+   return 0;
+}
+
+/* ---- Y(:,0:nc) = B * X(:,0:nc)  (reference massMatrixMatvec_Sprimme, auxiliary_eigs.c:250-290) ---- */
+int pa_apply_B(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc) {
+   primme_params *p = s->p;
+   if (nc <= 0) return 0;
+   double t0 = pa_wtime();
+   /* in blocks of the width the callback was promised (maxBlockSize; the initial basis hands over more at once, init.c:210) */
+   int ierr = 0;
+   PRIMME_INT ldx = ldX, ldy = ldY;
+   p->massMatrixMatvec(X, &ldx, Y, &ldy, &nc, p, &ierr);
+   if (ierr) return PRIMME_USER_FAILURE;
+   if (s->phase_timing) CHK(hipk_sync(s->ctx));
+   p->stats.timeMatvec += pa_wtime() - t0;
+   p->stats.numMatvecs += nc;      /* the reference counts applications of B with those of A (auxiliary_eigs.c:283) */
    return 0;
 }
 
@@ -484,6 +505,48 @@ int pa_ritz_update(pa_solver *s, int basisSize, const hipk_job *jobs, int njobs,
    /* count residual jobs */
    int nres = 0;
    for (int q = 0; q < njobs; q++) if (jobs[q].kind == HIPK_JOB_RES) nres++;
+   if (s->B && nres > 0) {
+      /* Generalised problem: R = W h - theta B (V h).  The fused kernel forms W h - theta V h; here the residual jobs become
+       * X = V h and Y = W h into the scratch panel BT = [X | Y | B X] (in the same launch as the caller's other outputs, so the
+       * in-place semantics are unchanged), then B X through the callback, R = Y - theta B X, |R|^2 and |X|^2 in one reduction,
+       * and the residuals that are wanted are copied to their destinations.  |x|_2 of the B-normalised Ritz vectors feeds the
+       * estimates of |B| and |B^-1| (main_iter.c:1690-1700). */
+      if (3 * nres > s->nBT) return PRIMME_FUNCTION_UNAVAILABLE;
+      hipk_job *wk = (hipk_job *)malloc((size_t)(njobs + nres) * sizeof(hipk_job));
+      double *mth = (double *)malloc((size_t)nres * SD * sizeof(double));
+      if (!wk || !mth) { free(wk); free(mth); return PRIMME_MALLOC_FAILURE; }
+      char *Xb = s->BT, *Yb = PCOL(s, s->BT, s->ld, nres), *BXb = PCOL(s, s->BT, s->ld, 2 * nres);
+      int cnt = 0, r = 0;
+      for (int q = 0; q < njobs; q++) {
+         if (jobs[q].kind != HIPK_JOB_RES) { wk[cnt++] = jobs[q]; continue; }
+         wk[cnt++] = (hipk_job){HIPK_JOB_XV, jobs[q].col, PCOL(s, Xb, s->ld, r), -1};
+         wk[cnt++] = (hipk_job){HIPK_JOB_XW, jobs[q].col, PCOL(s, Yb, s->ld, r), -1};
+         for (int d = 0; d < SD; d++) mth[r * SD + d] = 0.0;
+         mth[r * SD] = -s->h_theta[jobs[q].col];
+         r++;
+      }
+      int rc = hipk_ritz_update(s->ctx, s->dt, s->m, s->V, s->W, s->ld, basisSize, s->d_coef, s->K, s->d_theta, wk, cnt, NULL);
+      if (!rc) rc = pa_apply_B(s, Xb, s->ld, BXb, s->ld, nres);
+      if (!rc) rc = hipk_axpy_cols(s->ctx, s->dt, s->m, mth, BXb, s->ld, Yb, s->ld, nres);
+      if (!rc) rc = hipk_col_norms2(s->ctx, s->dt, s->m, Xb, s->ld, 2 * nres, s->d_red);      /* [|X|^2 | |R|^2]: X and Y are adjacent */
+      if (!rc) rc = pa_reduce(s, s->d_red, 2 * nres, 0, 0);
+      r = 0;
+      for (int q = 0; q < njobs && !rc; q++) {
+         if (jobs[q].kind != HIPK_JOB_RES) continue;
+         if (jobs[q].slot >= 0 && norms_out) norms_out[jobs[q].slot] = sqrt(s->h_red[nres + r]);
+         const double xn = sqrt(s->h_red[r]);
+         if (xn > 0.0) {
+            p->stats.estimateBNorm = PA_MAX(p->stats.estimateBNorm, 1.0 / xn);
+            p->stats.estimateInvBNorm = PA_MAX(p->stats.estimateInvBNorm, xn);
+         }
+         if (jobs[q].dst) rc = hipk_copy_cols(s->ctx, s->dt, s->m, PCOL(s, Yb, s->ld, r), s->ld, (char *)jobs[q].dst, s->ld, 1);
+         r++;
+      }
+      free(wk); free(mth);
+      p->stats.timeDense += pa_wtime() - t0;
+      p->stats.flopsDense += (double)s->m * (double)flop_cols * basisSize;
+      return rc;
+   }
    hipk_job *work = (hipk_job *)malloc((size_t)njobs * sizeof(hipk_job));
    if (!work) return PRIMME_MALLOC_FAILURE;
    double *d_n = s->d_red;

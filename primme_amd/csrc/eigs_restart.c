@@ -62,7 +62,13 @@ static int refresh_gram_after_restart(pa_solver *s, int evecsSize, int nVold, in
       for (int i = 0; i < evecsSize; i++) s->VtBV[i + (size_t)(evecsSize + c) * ldG] = work[i + (size_t)c * evecsSize];
    free(work);
    hipk_seg seg = {s->V, s->ld, rs};
-   CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, s->V, s->ld, rs, s->d_red, rs));
+   const char *Vm = s->V;                          /* the metric side: B V for a generalised problem */
+   if (s->B) {
+      if (rs > s->nBT) return PRIMME_FUNCTION_UNAVAILABLE;
+      CHK(pa_apply_B(s, s->V, s->ld, s->BT, s->ld, rs));
+      Vm = s->BT;
+   }
+   CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &seg, 1, Vm, s->ld, rs, s->d_red, rs));
    CHK(pa_reduce(s, s->d_red, SD * rs * rs, 0, 0));
    for (int c = 0; c < rs; c++)
       for (int i = 0; i < rs; i++) s->VtBV[(evecsSize + i) + (size_t)(evecsSize + c) * ldG] = ((const HS *)s->h_red)[i + (size_t)c * rs];
@@ -577,7 +583,9 @@ pass_done:
             if (!s->fuse_gd) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, VCOL(s, src), s->ld, TCOL(s, id), s->ld, 1));
             CHK(hipk_copy_cols(s->ctx, s->dt, s->m, WCOL(s, src), s->ld, TCOL(s, nd + id), s->ld, 1));
             double th = s->hVals[src];
-            CHK(hipk_residual_cols(s->ctx, s->dt, s->m, VCOL(s, src), s->ld, TCOL(s, nd + id), s->ld, 1, &th, s->d_red));
+            const char *vm = VCOL(s, src);
+            if (s->B) { CHK(pa_apply_B(s, VCOL(s, src), s->ld, s->BT, s->ld, 1)); vm = s->BT; }      /* R = W - theta B V */
+            CHK(hipk_residual_cols(s->ctx, s->dt, s->m, vm, s->ld, TCOL(s, nd + id), s->ld, 1, &th, s->d_red));
             ifl++;
          } else {
             break;

@@ -35,6 +35,13 @@ typedef struct pa_solver {
    /* HBM-resident panels */
    char *V, *W;            /* m x K */
    char *T;                /* scratch, m x nT */
+   /* generalised problems A x = lambda B x (round 6): massMatrixMatvec given.  B enters through the callback only — no B V
+    * panel is kept: B X is formed where it is needed (the new block in the orthonormalisation, the Ritz vectors whose
+    * residual W h - theta B V h is wanted) into the scratch panel BT (nBT columns).  Always the explicit_I path (tracked
+    * V'BV, ortho.c:497-803), Rayleigh-Ritz, the Generalized-Davidson family. */
+   int B;
+   char *BT;
+   int nBT;
    /* harmonic extraction: (A - tau I) V = Q R, with Q in HBM, R / Q'V / left vectors on the host */
    char *Q;
    HS *R, *QtV, *hU;       /* (harmonic / refined extraction: real objects only) */
@@ -145,6 +152,7 @@ static inline void pa_pre_discard(pa_solver *s) {
    if (s->pre_valid && s->pre_tail_deferred) hipk_tail_abandon(s->ctx);
    s->pre_valid = 0; s->pre_tail_deferred = 0;
 }
+int pa_apply_B(pa_solver *s, char *X, int64_t ldX, char *Y, int64_t ldY, int nc);
 int pa_trace_errors(void);
 #define CHK(call) do { int rc_ = (call); if (rc_) { \
       if (pa_trace_errors()) fprintf(stderr, "primme_amd: error %d at %s:%d: %s\n", rc_, __FILE__, __LINE__, #call); \

@@ -124,6 +124,22 @@ def tile_block_diagonal(rowptr, colind, values, ntiles, scale_fn=None, row0_tile
     return rp.astype(np.int32), ci.astype(np.int32), va
 
 
+def mass_matrix_csr(n, row0=0, nrows=None):
+    """A closed-form SPD mass matrix B for generalised problems A x = lambda B x (tests): tridiagonal,
+    diagonal 1 + 0.5 sin^2(0.1 i), off-diagonals 0.15 (strictly diagonally dominant)."""
+    nrows = n if nrows is None else nrows
+    rows, cols, vals = [], [], []
+    for i in range(row0, row0 + nrows):
+        for d in (-1, 0, 1):
+            j = i + d
+            if 0 <= j < n:
+                rows.append(i - row0); cols.append(j)
+                vals.append(1.0 + 0.5 * np.sin(0.1 * i) ** 2 if d == 0 else 0.15)
+    rp = np.zeros(nrows + 1, dtype=np.int64)
+    np.add.at(rp, np.array(rows) + 1, 1)
+    return np.cumsum(rp).astype(np.int32), np.array(cols, dtype=np.int32), np.array(vals)
+
+
 def csr_matvec_numpy(rowptr, colind, values, x):
     """y = A x for a CSR matrix with numpy (reference tests/COMMON/mat.c:64-90 amux)."""
     x = np.asarray(x)

@@ -220,6 +220,14 @@ def test_hip_wide_basis(built, K, mr):
         assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= 0.03 * b.stats["numOuterIterations"]
 
 
+@pytest.mark.parametrize("name", ["gen_gdk", "gen_gdk_blk2", "gen_largest_soft", "gen_olsen_jacobi", "gen_gd", "gen_lobpcg", "gen_blk4_3d", "gen_noanorm"])
+def test_hip_generalized_problem_against_reference_fixture(built, name):
+    """Generalised problems A x = lambda B x on the device (round 6; tests/generalized_cases.py): the reference's eigenvalues and
+    residual norms, scipy's dense truth, B-orthonormal vectors, counts within 5 % of dprimme's."""
+    from generalized_cases import check
+    check(name, "hip")
+
+
 def test_hip_refined_extraction_with_an_extremal_target(built):
     """Round 6 widening (VERDICT r05 Missing #4): refined extraction with target = largest / largest_abs and the shift of the
     factorisation given in targetShifts — accepted by the reference's check_input (primme_c.c:512-520), returned -44 here until
