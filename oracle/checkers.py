@@ -114,7 +114,7 @@ class ReferenceBackend:
                 nb, lx, ly = bs[0], ldx[0], ldy[0]
                 X = view(x, nb, lx)
                 Y = view(y, nb, ly)
-                Y[:, :nLocal] = sess.mass.apply_numpy(X[:, :nLocal].T.astype(np.float64)).T
+                Y[:, :nLocal] = sess.mass.apply_numpy(X[:, :nLocal].T.astype(np.complex128 if cplx else np.float64)).T
                 ierr[0] = 0
             bcb = F.BLOCK_OP(bmv)
             keep.append(bcb)

@@ -149,13 +149,14 @@ class Session:
         if self.cplx and self.real_form: lib.primme_amd_operator_set_complex(oph, 1)
         self.oph = oph
         if mass is not None:
-            if self.cplx or mass.csr is None:
-                raise ValueError("mass matrix: real CSR operators")
+            if (self.cplx and self.real_form) or mass.csr is None:
+                raise ValueError("mass matrix: CSR operators, complex ones on the native complex panels")
             rpb, cib, vab = mass.csr
             rpb = np.ascontiguousarray(rpb, dtype=np.int32); cib = np.ascontiguousarray(cib, dtype=np.int32)
             vab = np.ascontiguousarray(vab, dtype=self.dtype)
             Bh = C.c_void_p()
-            if lib.hipk_csr_create(ctx, self.dt, mass.nrows, mass.n, mass.row0, rpb.ctypes.data_as(C.c_void_p),
+            bdt = self.dt if not self.cplx else (F.HIPK_C64 if self.dtype == np.complex128 else F.HIPK_C32)
+            if lib.hipk_csr_create(ctx, bdt, mass.nrows, mass.n, mass.row0, rpb.ctypes.data_as(C.c_void_p),
                                    cib.ctypes.data_as(C.c_void_p), vab.ctypes.data_as(C.c_void_p), C.byref(Bh)):
                 raise RuntimeError("mass matrix creation failed")
             self.handles.append(("csr", Bh))

@@ -163,7 +163,8 @@ static int solve_complex(void *evals_out, void *evecs, void *resNorms_out, primm
       primme_set_defaults(primme);
       return 0;
    }
-   if (primme->massMatrixMatvec) return PRIMME_FUNCTION_UNAVAILABLE;
+   /* generalised Hermitian problems (round 6): on the native complex panels only */
+   if (primme->massMatrixMatvec && !native_complex_ok(primme)) return PRIMME_FUNCTION_UNAVAILABLE;
    if (!evals_out) return -30;
    if (!evecs || !hipk_is_device_ptr(evecs)) return -31;
    if (!resNorms_out) return -32;

@@ -880,11 +880,18 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
     * as soon as the caller gives the shift of the factorisation (targetShifts[0]; without one the reference dereferences a
     * NULL pointer, main_iter.c:465): round 6 lets it through */
    const int extremal = (p->target == primme_smallest || p->target == primme_largest || p->target == primme_largest_abs);
-   /* mass matrix (round 6): real panels, Rayleigh-Ritz (check_input: -39 otherwise, like the reference), the Generalized-Davidson
+   /* mass matrix (round 6): real and complex Hermitian panels, Rayleigh-Ritz (check_input: -39 otherwise, like the reference), the Generalized-Davidson
     * family — the JDQMR inner solver with B (projectors on B Q, B x: inner_solve.c:283-300, correction.c:862-997) and the
     * dynamic switch into it are not restated: -44 */
+   if (p->massMatrixMatvec && p->dynamicMethodSwitch > 0) {
+      /* PRIMME_DYNAMIC (the default method) with a mass matrix: the inner solver it would switch to is not restated, so the run
+       * stays in its GD+k mode — what the reference's own switch does when it leaves JDQMR (maxInnerIterations = 0,
+       * main_iter.c:2330-2345) — and reports the state "GD+k" (-2) like a finished dynamic run (main_iter.c:1221-1228) */
+      p->dynamicMethodSwitch = -2;
+      p->correctionParams.maxInnerIterations = 0;
+   }
    const int mass_unavailable = p->massMatrixMatvec &&
-         (PA_IS_COMPLEX || p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0 ||
+         (p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0 ||
           (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX));
    if (mass_unavailable || (harmonic && extremal && !(refined && p->numTargetShifts > 0 && p->targetShifts))) {
       if (p->printLevel > 0 && p->outputFile)

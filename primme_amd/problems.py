@@ -140,6 +140,17 @@ def mass_matrix_csr(n, row0=0, nrows=None):
     return np.cumsum(rp).astype(np.int32), np.array(cols, dtype=np.int32), np.array(vals)
 
 
+def hermitian_mass_matrix_csr(n):
+    """Hermitian positive definite mass matrix for complex generalised problems (tests): tridiagonal, real diagonal
+    1 + 0.5 sin^2(0.1 i), off-diagonals 0.15 exp(+-0.3 i)."""
+    rp, ci, va = mass_matrix_csr(n)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v = va.astype(np.complex128)
+    v[ci > rows] = 0.15 * np.exp(0.3j)
+    v[ci < rows] = 0.15 * np.exp(-0.3j)
+    return rp, ci, v
+
+
 def csr_matvec_numpy(rowptr, colind, values, x):
     """y = A x for a CSR matrix with numpy (reference tests/COMMON/mat.c:64-90 amux)."""
     x = np.asarray(x)

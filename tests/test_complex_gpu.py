@@ -128,3 +128,21 @@ def test_hip_native_complex_dynamic_method(built):
     assert np.max(np.abs(r.evals - w[:6])) <= 1e-9 * aN
     AX = A @ r.evecs
     assert np.all(np.linalg.norm(AX - r.evecs * r.evals, axis=0) <= 1.5e-10 * aN)
+
+
+@pytest.mark.parametrize("kw", [dict(numEvals=4, eps=1e-9, target="largest", method="GD_plusK"), dict(numEvals=4, eps=1e-9, target="largest", maxBlockSize=2)])
+def test_hip_generalized_hermitian(built, kw):
+    """Generalised Hermitian problems on the device (round 6; the live-reference leg is tests/test_complex_host.py): scipy's dense
+    truth, B-orthonormal vectors, true residuals, the CPU checker's counts to 5 %."""
+    from test_complex_host import _generalized_hermitian
+    kw = dict(kw, iseed=(2, 3, 5, 7))
+    a, A, B, truth = _generalized_hermitian("hip", kw)
+    b, _, _, _ = _generalized_hermitian("hostcheck", kw)
+    assert a.ret == b.ret == 0
+    aN = a.params["aNorm"]
+    assert np.max(np.abs(np.sort(a.evals) - np.sort(truth))) <= 1e-10 * aN
+    X = a.evecs
+    assert np.max(np.abs(X.conj().T @ B @ X - np.eye(X.shape[1]))) <= 1e-9
+    assert np.max(np.abs(np.linalg.norm(A @ X - (B @ X) * a.evals, axis=0) - a.resNorms)) <= 1e-9 * aN
+    assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= max(2, 0.05 * b.stats["numOuterIterations"])
+

@@ -156,6 +156,40 @@ def test_reference_driver_complex_case_pins_the_checker(built, name):
     assert np.max(np.abs(np.sort(h.evals) - np.sort(r.evals))) <= 1e-10 * r.params["aNorm"]
 
 
+def _generalized_hermitian(backend, kw, n=600):
+    import scipy.linalg as sl
+    import scipy.sparse as sp
+    rp, ci, va = problems.hermitian_banded_csr(n)
+    brp, bci, bva = problems.hermitian_mass_matrix_csr(n)
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend=backend, mass=Operator(n, csr=(brp, bci, bva)), dtype=np.complex128, **kw)
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n)).toarray()
+    B = sp.csr_matrix((bva, bci, brp), shape=(n, n)).toarray()
+    w = sl.eigh(A, B, eigvals_only=True)
+    k = kw["numEvals"]
+    truth = w[::-1][:k] if kw.get("target") == "largest" else w[:k]
+    return r, A, B, truth
+
+
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("kw", [dict(numEvals=4, eps=1e-9, target="largest", method="GD_plusK"), dict(numEvals=4, eps=1e-9, target="largest", maxBlockSize=2),
+                                dict(numEvals=3, eps=1e-9, target="smallest", locking=0)])
+def test_generalized_hermitian_against_live_reference(built, kw):
+    """Generalised HERMITIAN problems A x = lambda B x (round 6): zprimme with massMatrixMatvec against the native complex path —
+    the same eigenvalues (and scipy's dense truth), B-orthonormal vectors, true residuals, the reference's outer-iteration
+    and restart counts."""
+    kw = dict(kw, iseed=(2, 3, 5, 7))
+    a, A, B, truth = _generalized_hermitian("reference", kw)
+    b, _, _, _ = _generalized_hermitian("hostcheck", kw)
+    assert a.ret == b.ret == 0 and b.initSize == kw["numEvals"]
+    aN = b.params["aNorm"]
+    assert np.max(np.abs(np.sort(b.evals) - np.sort(truth))) <= 1e-10 * aN and np.max(np.abs(np.sort(a.evals) - np.sort(b.evals))) <= 1e-10 * aN
+    X = b.evecs
+    assert np.max(np.abs(X.conj().T @ B @ X - np.eye(X.shape[1]))) <= 1e-9
+    res = np.linalg.norm(A @ X - (B @ X) * b.evals, axis=0)
+    assert np.max(np.abs(res - b.resNorms)) <= 1e-9 * aN
+    assert (a.stats["numOuterIterations"], a.stats["numRestarts"]) == (b.stats["numOuterIterations"], b.stats["numRestarts"])
+
+
 def test_complex_unsupported_and_argument_errors(built):
     import ctypes as C
     lib = checkers.load_hostcheck()

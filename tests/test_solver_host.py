@@ -161,7 +161,11 @@ def test_generalized_problem_unsupported_corners(built):
     op, bop = Operator(n, csr=(rp, ci, va)), Operator(n, csr=(brp, bci, bva))
     kw = dict(numEvals=2, eps=1e-8, aNorm=8.0, v0=problems.start_vector(n))
     assert eigsh(op, backend="hostcheck", mass=bop, method="JDQMR", **kw).ret == -44
-    assert eigsh(op, backend="hostcheck", mass=bop, method="DYNAMIC", **kw).ret == -44
+    d = eigsh(op, backend="hostcheck", mass=bop, method="DYNAMIC", **kw)       # the default method: runs in its GD+k mode and says so
+    assert d.ret == 0 and d.params["dynamicMethodSwitch"] == -2
+    import scipy.linalg as sl, scipy.sparse as sp
+    w = sl.eigh(sp.csr_matrix((va, ci, rp), shape=(n, n)).toarray(), sp.csr_matrix((bva, bci, brp), shape=(n, n)).toarray(), eigvals_only=True)[:2]
+    assert np.max(np.abs(d.evals - w)) <= 1e-9 * 8.0
     assert eigsh(op, backend="hostcheck", mass=bop, projection="refined", target="closest_abs", targetShifts=[1.0], **kw).ret == -39
 
 
