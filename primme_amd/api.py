@@ -178,7 +178,7 @@ class Session:
               maxMatvecs=0, maxOuterIterations=0, targetShifts=None, precond=None, printLevel=0,
               initBasisMode=None, global_sum=None, numProcs=1, procID=0, orth=None, iseed=None,
               profile=False, return_evecs=True, monitor=None, user_matvec=None, projection=None,
-              constraints=None, user_precond=None):
+              constraints=None, user_precond=None, tweak=None):
         lib, op, dtype = self.lib, self.op, self.dtype
         keep = []
         p = F.PrimmeParams()
@@ -299,6 +299,8 @@ class Session:
 
         if lib.primme_set_method(m, C.byref(p)):
             raise ValueError("unknown method")
+        if tweak is not None:            # last word on the parameter structure (e.g. the correction equation's projectors)
+            tweak(p)
         evals = np.zeros(numEvals, dtype=self.rdtype)
         resNorms = np.zeros(numEvals, dtype=self.rdtype)
         ret = solver(evals.ctypes.data_as(C.c_void_p), evecs_ptr, resNorms.ctypes.data_as(C.c_void_p), C.byref(p))

@@ -104,3 +104,22 @@ int pa_call_monitor(primme_params *p, double *basisEvals, int basisSize, int *ba
    }
    return err ? PRIMME_USER_FAILURE : 0;
 }
+
+/* the report of one inner (QMR) step: primme_event_inner_iteration with the arguments the reference passes
+ * (inner_solve.c:550-558 adaptive tests, :581-588 otherwise; auxiliary_eigs_normal.c:446-490) */
+int pa_call_monitor_inner(primme_params *p, double eval, double resNorm, int counts, int innerIts, double lsRes) {
+   int err = 0, one = 1, zero = 0, unconv = 0 /* UNCONVERGED */, nconv = counts, nlock = counts;
+   double time = 0.0;
+   primme_event event = primme_event_inner_iteration;
+   if (!p->monitorFun) return 0;
+   if (!type_ok(p->monitorFun_type)) return PRIMME_FUNCTION_UNAVAILABLE;
+   if (p->monitorFun_type == primme_op_float) {
+      float e = (float)eval, r = (float)resNorm, t = (float)lsRes;
+      p->monitorFun(&e, &one, &unconv, &zero, &one, &r, &nconv, NULL, &nlock, NULL, NULL, &innerIts, lsRes >= 0 ? &t : NULL, NULL,
+            &time, &event, p, &err);
+   } else {
+      p->monitorFun(&eval, &one, &unconv, &zero, &one, &resNorm, &nconv, NULL, &nlock, NULL, NULL, &innerIts,
+            lsRes >= 0 ? &lsRes : NULL, NULL, &time, &event, p, &err);
+   }
+   return err ? PRIMME_USER_FAILURE : 0;
+}

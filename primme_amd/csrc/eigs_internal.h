@@ -34,6 +34,7 @@ int pa_call_conv_test(primme_params *p, double eval, void *evec, double rnorm, i
 int pa_call_monitor(primme_params *p, double *basisEvals, int basisSize, int *basisFlags, int *iblock, int blockSize,
       double *basisNorms, int numConverged, double *lockedEvals, int numLocked, int *lockedFlags, double *lockedNorms,
       primme_event event);
+int pa_call_monitor_inner(primme_params *p, double eval, double resNorm, int counts, int innerIts, double lsRes);
 int pa_svds_call_global_sum(struct primme_svds_params *ps, double *buf, int count);
 int pa_svds_call_conv_test(struct primme_svds_params *ps, double sval, void *leftsvec, void *rightsvec, double rnorm,
       int *method, int *isconv);

@@ -125,7 +125,10 @@ static void perm_set_value_on_pos(int *p, int val, int pos, int n) {
 }
 
 typedef struct {
-   char *LQ, *LX; int64_t ldLQ, ldLX; int nLQ, nLX;   /* left projectors  (B = I: BQ = Q, BX = X) */
+   char *LQ, *LX; int64_t ldLQ, ldLX; int nLQ, nLX;   /* left projectors I - LBQ LQ', I - LBX_i LX_i' ... */
+   char *LBQ, *LBX; int64_t ldLBQ, ldLBX;             /* ... with LBQ = B Q, LBX = B x (B = I: the same panels) */
+   char *Bx;               /* B x of a generalised problem (NULL otherwise): permuted with x when columns leave the block */
+   char *Bv;               /* scratch panel for B v (generalised problems) */
    char *RQ, *RX; int64_t ldRQ, ldRX; int nRQ, nRX;   /* right projectors: I - RQ M^-1 Q', I - RX_i x_i'/xKx_i */
    int skewQ, skewX;       /* RQ = K^-1 Q with M = Q'K^-1 Q factorised; RX = K^-1 x with xKx = x'K^-1 x */
    char *x;                /* the Ritz vectors (dotted against in the X projector) */
@@ -160,8 +163,16 @@ static void lu_solve(const HS *LU, const int *piv, int n, HS *b) {
  * the orthogonality constraints. */
 static int extend_evecs_hat(pa_solver *s, int c0, int count) {
    if (count <= 0) return 0;
+   char *src = ECOL(s, c0);
+   if (s->Bevecs && !s->ref_soft_alias) {
+      /* generalised problem: evecsHat = K^-1 B evecs (init.c:162-164, restart.c:1511-1515); B evecs itself is the left projector's */
+      src = s->Bevecs + (size_t)c0 * s->ldevecs * s->es;
+      CHK(pa_apply_B(s, ECOL(s, c0), s->ldevecs, src, s->ldevecs, count));
+      s->nBevecs = c0 + count;
+   }
+   if (!s->evecsHat) return 0;
    char *hat = s->evecsHat + (size_t)c0 * s->ldevecs * s->es;
-   CHK(pa_precond(s, ECOL(s, c0), s->ldevecs, hat, s->ldevecs, count));
+   CHK(pa_precond(s, src, s->ldevecs, hat, s->ldevecs, count));
    const int nM = c0 + count;
    for (int j0 = 0; j0 < count; j0 += 8) {
       const int nj = PA_MIN(8, count - j0);
@@ -172,14 +183,23 @@ static int extend_evecs_hat(pa_solver *s, int c0, int count) {
          for (int i = 0; i < nM; i++) {
             const HS mij = ((const HS *)s->h_red)[i + (size_t)j * nM];
             s->Mq[i + (size_t)(c0 + j0 + j) * s->ldM] = mij;
-            if (i < c0) s->Mq[(c0 + j0 + j) + (size_t)i * s->ldM] = HS_CONJ(mij);   /* K Hermitian */
+            if (i < c0 && !s->B) s->Mq[(c0 + j0 + j) + (size_t)i * s->ldM] = HS_CONJ(mij);   /* K Hermitian */
          }
+   }
+   /* M = evecs' K^-1 B evecs is not Hermitian (factorize.c:190-195): the rows of the new vectors against the old K^-1 B evecs */
+   if (s->B) for (int i0 = 0; i0 < c0; i0 += 8) {
+      const int ni = PA_MIN(8, c0 - i0);
+      hipk_seg sq = {ECOL(s, c0), s->ldevecs, count};
+      CHK(hipk_panel_dots(s->ctx, s->dt, s->m, &sq, 1, s->evecsHat + (size_t)i0 * s->ldevecs * s->es, s->ldevecs, ni, s->d_red, count));
+      CHK(pa_reduce(s, s->d_red, SD * count * ni, 0, 0));
+      for (int i = 0; i < ni; i++)
+         for (int j = 0; j < count; j++) s->Mq[(c0 + j) + (size_t)(i0 + i) * s->ldM] = ((const HS *)s->h_red)[j + (size_t)i * count];
    }
    return lu_factor(s->Mq, s->ldM, nM, s->Mlu, s->Mpiv);
 }
 
 int pa_evecs_hat_init(pa_solver *s) {
-   if (!s->evecsHat) return 0;
+   if (!s->evecsHat && !s->Bevecs) return 0;
    s->p->ShiftsForPreconditioner = NULL;
    return extend_evecs_hat(s, 0, s->p->numOrthoConst);
 }
@@ -244,7 +264,7 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
    /* result = A v - shift v: in ONE launch when the operator is the library's own CSR matrix (the shift is
     * applied in the SpMM epilogue), otherwise the callback followed by an axpy */
    int shifted = 0;
-   if (nb > 1 && s->p->matrixMatvec == primme_amd_matvec && s->p->matrix) {
+   if (nb > 1 && !s->B && s->p->matrixMatvec == primme_amd_matvec && s->p->matrix) {
       double t0 = pa_wtime();
       const int rcs = primme_amd_operator_apply_shifted((primme_amd_operator *)s->p->matrix, hipk_ctx_stream(s->ctx), v, ldv,
             result, ldres, nb, shift);
@@ -257,6 +277,14 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
       }
    }
    if (!shifted) CHK(pa_matvec(s, v, ldv, result, ldres, 0, nb));
+   /* generalised problem: result = A v - shift B v, left projectors I - (B Q) Q' and I - (B x) x' (inner_solve.c:838-890) */
+   char *av = v;
+   int64_t ldav = ldv;
+   if (s->B) {
+      if (xr_out) return PRIMME_UNEXPECTED_FAILURE;      /* the folded x-projection is the standard problem's */
+      CHK(pa_apply_B(s, v, ldv, P->Bv, s->ld, nb));
+      av = P->Bv; ldav = s->ld;
+   }
    double ms[64];
    for (int i = 0; i < nb; i++) ms[i] = -shift[i];
    if (P->nLX > 0) {
@@ -265,14 +293,14 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
       /* the reference's operation order with complex projector coefficients: result -= shift v (real), (I - Q Q^H),
        * c = x^H result (complex), result -= c x, vdot = Re(v^H result) */
       (void)xr_out;
-      if (!shifted) CHK(hipk_axpy_cols(s->ctx, RDT(s), RM(s), ms, v, R2(ldv), result, R2(ldres), nb));
-      if (P->nLQ > 0) CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+      if (!shifted) CHK(hipk_axpy_cols(s->ctx, RDT(s), RM(s), ms, av, R2(ldav), result, R2(ldres), nb));
+      if (P->nLQ > 0) CHK(project_panel(s, P->LQ, P->ldLQ, P->LBQ, P->ldLBQ, P->nLQ, result, ldres, nb));
       CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, result, ldres, nb, s->d_red));
       CHK(pa_reduce(s, s->d_red, SD * nb, 0, 0));
       {
          HS mc[64];
          for (int i = 0; i < nb; i++) mc[i] = -((const HS *)s->h_red)[i];
-         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)mc, P->LX, P->ldLX, result, ldres, nb));
+         CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, (const double *)mc, P->LBX, P->ldLBX, result, ldres, nb));
       }
       CHK(pair_dots_host(s, v, ldv, result, ldres, nb, vdot));
       s->p->stats.numOrthoInnerProds += nb;
@@ -313,28 +341,28 @@ static int apply_projected_matrix(pa_solver *s, char *v, int64_t ldv, const doub
          return 0;
       }
       if (P->nLQ > 0) {
-         if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, v, ldv, result, ldres, nb));
-         CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+         if (!shifted) CHK(hipk_axpy_cols(s->ctx, s->dt, s->m, ms, av, ldav, result, ldres, nb));
+         CHK(project_panel(s, P->LQ, P->ldLQ, P->LBQ, P->ldLBQ, P->nLQ, result, ldres, nb));
          CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, result, ldres, nb, s->d_red));
       } else if (shifted) {
          CHK(hipk_pair_dots(s->ctx, s->dt, s->m, P->LX, P->ldLX, result, ldres, nb, s->d_red));
       } else {
          /* result -= shift v  and  x' result */
-         CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, nb, ms, v, ldv, result, ldres, P->LX, P->ldLX, s->d_red));
+         CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, nb, ms, av, ldav, result, ldres, P->LX, P->ldLX, s->d_red));
       }
       CHK(pa_reduce(s, s->d_red, nb, 0, 0));
       double ma[64];
       for (int i = 0; i < nb; i++) ma[i] = -s->h_red[i];
-      /* result -= (x' result) x  and  v' result */
-      CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, nb, ma, P->LX, P->ldLX, result, ldres, v, ldv, s->d_red));
+      /* result -= (x' result) B x  and  v' result */
+      CHK(hipk_axpy_dot(s->ctx, s->dt, s->m, nb, ma, P->LBX, P->ldLBX, result, ldres, v, ldv, s->d_red));
       CHK(pa_reduce(s, s->d_red, nb, 0, 0));
       for (int i = 0; i < nb; i++) vdot[i] = s->h_red[i];
       s->p->stats.numOrthoInnerProds += nb;
       s->p->stats.timeOrtho += pa_wtime() - t0;
 #endif
    } else {
-      if (!shifted) CHK(hipk_axpy_cols(s->ctx, RDT(s), RM(s), ms, v, R2(ldv), result, R2(ldres), nb));
-      CHK(project_panel(s, P->LQ, P->ldLQ, P->LQ, P->ldLQ, P->nLQ, result, ldres, nb));
+      if (!shifted) CHK(hipk_axpy_cols(s->ctx, RDT(s), RM(s), ms, av, R2(ldav), result, R2(ldres), nb));
+      CHK(project_panel(s, P->LQ, P->ldLQ, P->LBQ, P->ldLBQ, P->nLQ, result, ldres, nb));
       CHK(pair_dots_host(s, v, ldv, result, ldres, nb, vdot));
    }
    return 0;
@@ -357,7 +385,7 @@ static int apply_projected_preconditioner(pa_solver *s, char *v, int64_t ldv, co
          s->p->stats.numOrthoInnerProds += nb;
          s->p->stats.timeOrtho += pa_wtime() - t0;
       } else {
-         CHK(project_each(s, P->RX, P->ldRX, P->RX, P->ldRX, result, ldres, nb));
+         CHK(project_each(s, P->x, s->ld, P->RX, P->ldRX, result, ldres, nb));      /* (I - (B x) x'): RX = B x, = x for B = I */
       }
    }
    return 0;
@@ -392,7 +420,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    const void *jac_diag = NULL;
    int jac_fixed = 0;
    double jac_shift = 0.0, rho_new[64];
-   const int fuse_pk = (!PA_IS_COMPLEX && b0 > 1 && !plain_K && getenv("PRIMME_AMD_JDQMR_REF_INDEXING") == NULL && p->correctionParams.precondition && p->applyPreconditioner == primme_amd_jacobi_precond &&
+   const int fuse_pk = (!PA_IS_COMPLEX && b0 > 1 && !plain_K && !s->B && getenv("PRIMME_AMD_JDQMR_REF_INDEXING") == NULL && p->correctionParams.precondition && p->applyPreconditioner == primme_amd_jacobi_precond &&
                         p->preconditioner && P->nRQ == 0 && P->nRX == 0 && !P->skewQ &&
                         primme_amd_operator_jacobi_data((primme_amd_operator *)p->preconditioner, &jac_diag, &jac_fixed, &jac_shift) == 0);
    /* ... and with the x-projection folded into the update of g (fold_x) the inner product rho = g'K^-1 g of the NEXT step
@@ -448,11 +476,15 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
    CHK(hipk_memset0(s->ctx, delta, (size_t)ld * s->es * blockSize));
    CHK(hipk_memset0(s->ctx, sol, (size_t)ld * s->es * blockSize));
    for (i = 0; i < blockSize; i++) pm[i] = i;
+   /* generalised problem with the adaptive tests: |B x|^2 enters the estimate of the eigen-residual (inner_solve.c:296-303) */
+   double normBx[64];
+   for (i = 0; i < blockSize; i++) normBx[i] = 1.0;
+   if (adaptive && s->B) CHK(pair_dots_host(s, P->Bx, ld, P->Bx, ld, blockSize, normBx));
 
    for (int64_t numIts = 0; numIts < maxIterations && blockSize > 0; numIts++) {
       /* blocks: the x-projection of w is folded into the update of g below (one pass and one
        * synchronisation fewer per step); block size 1 keeps the reference's operation order */
-      const int fold_x = (!PA_IS_COMPLEX && b0 > 1 && P->nLX > 0 && !ref_ix);
+      const int fold_x = (!PA_IS_COMPLEX && b0 > 1 && P->nLX > 0 && !ref_ix && !s->B);
       double xr[64];
       /* ONE host synchronisation per step (round 5): with the library's Jacobi preconditioner and the folded x-projection the
        * step is three launches — (A - shift) d with its three inner products, the update of g (+ g'g, g'K^-1 g), the QMR
@@ -560,6 +592,9 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
             CHK(permute_panel(s, P->RX, P->ldRX, blockSize, p0));                                  \
             pa_permute_cols(P->xKx, 1, blockSize, 1, p0);                                          \
          }                                                                                         \
+         /* LBX / RX alias B x.  (The reference permutes B x only where it doubles as the right projector,            \
+          * inner_solve.c:352-357: its left projector pairs x_i with the B x of another column once one has left) */  \
+         if (P->Bx && (!ref_ix || (P->nRX > 0 && P->RX == P->Bx))) CHK(permute_panel(s, P->Bx, ld, blockSize, p0)); \
          CHK(permute_panel(s, sol, ld, blockSize, p0));                                            \
          blockSize -= conv;                                                                        \
          if (P->nLX) P->nLX -= conv;                                                               \
@@ -620,6 +655,11 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
          if (adaptive) {
             CHK(pa_reduce(s, s->d_red, blockSize, 0, 0));
             for (i = 0; i < blockSize; i++) dot_sol[i] = s->h_red[i];
+            /* generalised problem: the B-norm of the correction, sol' B sol (inner_solve.c:416-422) */
+            if (s->B) {
+               CHK(pa_apply_B(s, sol, ld, P->Bv, ld, blockSize));
+               CHK(pair_dots_host(s, sol, ld, P->Bv, ld, blockSize, dot_sol));
+            }
          }
       }
 
@@ -638,7 +678,7 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
             const double Gamma = Gamma_prev[q] + 2.0 * Psi + Phi;
             const double nrm = 1.0 + dot_sol[i];
             const double eval_updated = shift[i] + (eval[q] - shift[i] + 2 * Beta + Gamma) / nrm;
-            const double eres2 = (tau[q] * tau[q]) / nrm + ((eval[q] - shift[i] + Beta) * (eval[q] - shift[i] + Beta)) / nrm -
+            const double eres2 = (tau[q] * tau[q]) / nrm + (normBx[q] * (eval[q] - shift[i] + Beta) * (eval[q] - shift[i] + Beta)) / nrm -
                                  (eval_updated - shift[i]) * (eval_updated - shift[i]);
             const double eres_prev = eres_updated[q];
             eres_updated[q] = (eres2 < 0) ? sqrt((tau[q] * tau[q]) / nrm) : sqrt(eres2);
@@ -662,9 +702,17 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
                perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue;
             }
             eval_prev[q] = eval_updated;
+            if (p->monitorFun) {      /* report of the inner step (inner_solve.c:550-558) */
+               p->stats.elapsedTime = pa_wtime() - s->startTime;
+               CHK(pa_call_monitor_inner(p, eval_updated, eres_updated[q], -1, (int)numIts, tau[q]));
+            }
          } else {
             CHK(conv_test(s, eval[q], tau[q] / LTolerance_factor * sqrt((double)numIts), &isConv));
             if (numIts > 0 && isConv) { perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue; }
+            if (p->monitorFun) {      /* (inner_solve.c:581-588) */
+               p->stats.elapsedTime = pa_wtime() - s->startTime;
+               CHK(pa_call_monitor_inner(p, eval[q], rnorm[q], 0, (int)numIts, tau[q]));
+            }
          }
       }
       if (have_w && conv > 0) {
@@ -720,15 +768,34 @@ int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double
    const int sizeEvecs = p->numOrthoConst + (p->locking ? numLocked : numConvergedStored);
    jd_proj P;
    memset(&P, 0, sizeof(P));
+   char *Bx = x, *Bq = s->evecs;          /* B x and B evecs: the vectors themselves for a standard problem */
+   if (s->B) {
+      if (!s->Bevecs) return PRIMME_UNEXPECTED_FAILURE;
+      /* the reference reads B x off its B V panel (correction.c:399) and keeps B evecs up to date at every restart; here B comes
+       * through the callback: the block's B x now, B evecs for the columns locked since the last call */
+      P.Bx = Bx = PCOL(s, s->Jw, s->ld, 6 * p->maxBlockSize);
+      P.Bv = PCOL(s, s->Jw, s->ld, 7 * p->maxBlockSize);
+      CHK(pa_apply_B(s, x, s->ld, Bx, s->ld, blockSize));
+      if (s->ref_soft_alias) Bq = s->evecs;
+      else {
+         if (s->nBevecs < sizeEvecs) {
+            CHK(pa_apply_B(s, ECOL(s, s->nBevecs), s->ldevecs, s->Bevecs + (size_t)s->nBevecs * s->ldevecs * s->es, s->ldevecs, sizeEvecs - s->nBevecs));
+            s->nBevecs = sizeEvecs;
+         }
+         Bq = s->Bevecs;
+      }
+   }
    if (jp->LeftQ) {
       P.LQ = s->evecs; P.ldLQ = s->ldevecs; P.nLQ = sizeEvecs;
+      P.LBQ = Bq; P.ldLBQ = s->ldevecs;
       if (jp->LeftX) {
-         if (blockSize <= 1) {   /* keep x next to Q: one projector panel */
+         if (blockSize <= 1) {   /* keep x next to Q (and B x next to B Q): one projector panel */
             CHK(hipk_copy_cols(s->ctx, s->dt, s->m, x, s->ld, ECOL(s, sizeEvecs), s->ldevecs, blockSize));
+            if (s->B) CHK(hipk_copy_cols(s->ctx, s->dt, s->m, Bx, s->ld, Bq + (size_t)sizeEvecs * s->ldevecs * s->es, s->ldevecs, blockSize));
             P.nLQ += blockSize;
-         } else { P.LX = x; P.ldLX = s->ld; P.nLX = blockSize; }
+         } else { P.LX = x; P.ldLX = s->ld; P.nLX = blockSize; P.LBX = Bx; P.ldLBX = s->ld; }
       }
-   } else if (jp->LeftX) { P.LX = x; P.ldLX = s->ld; P.nLX = blockSize; }
+   } else if (jp->LeftX) { P.LX = x; P.ldLX = s->ld; P.nLX = blockSize; P.LBX = Bx; P.ldLBX = s->ld; }
    P.x = x;
    p->ShiftsForPreconditioner = shifts;
    if (jp->RightQ) {
@@ -736,20 +803,20 @@ int pa_correction_jdqmr(pa_solver *s, int basisSize, int blockSize, const double
       if (p->correctionParams.precondition && jp->SkewQ) {
          if (!s->evecsHat) return PRIMME_UNEXPECTED_FAILURE;
          P.RQ = s->evecsHat; P.ldRQ = s->ldevecs; P.skewQ = 1;
-      } else { P.RQ = s->evecs; P.ldRQ = s->ldevecs; }
+      } else { P.RQ = Bq; P.ldRQ = s->ldevecs; }
    }
    if (jp->RightX) {
       P.nRX = blockSize;
       if (p->correctionParams.precondition && jp->SkewX) {
-         /* K^-1 x and x'K^-1 x (reference correction.c:969-977) */
+         /* K^-1 B x and x'K^-1 B x (reference correction.c:969-977) */
          char *Kx = PCOL(s, s->Jw, s->ld, 5 * p->maxBlockSize);
-         CHK(pa_precond(s, x, s->ld, Kx, s->ld, blockSize));
+         CHK(pa_precond(s, Bx, s->ld, Kx, s->ld, blockSize));
          CHK(hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kx, s->ld, blockSize, s->d_red));
          CHK(pa_reduce(s, s->d_red, SD * blockSize, 0, 0));
          for (int i = 0; i < blockSize; i++) P.xKx[i] = ((const HS *)s->h_red)[i];
          P.RX = Kx; P.ldRX = s->ld; P.skewX = 1;
       } else {
-         P.RX = x; P.ldRX = s->ld;
+         P.RX = Bx; P.ldRX = s->ld;
          for (int i = 0; i < blockSize; i++) P.xKx[i] = 1.0;
       }
    }

@@ -248,7 +248,13 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
        * K^-1 [x r] live in the scratch panel */
       if (2 * blockSize > s->nT) rc = PRIMME_UNEXPECTED_FAILURE;
       char *Kx = s->T, *Kr = TCOL(s, blockSize);
-      if (!rc) rc = pa_precond(s, x, s->ld, Kx, s->ld, blockSize);
+      char *xm = x;                                /* K^-1 B x for a generalised problem (correction.c:738-741) */
+      if (s->B) {
+         if (blockSize > s->nBT) rc = PRIMME_FUNCTION_UNAVAILABLE;
+         if (!rc) rc = pa_apply_B(s, x, s->ld, s->BT, s->ld, blockSize);
+         xm = s->BT;
+      }
+      if (!rc) rc = pa_precond(s, xm, s->ld, Kx, s->ld, blockSize);
       if (!rc) rc = pa_precond(s, r, s->ld, Kr, s->ld, blockSize);
       if (!rc) rc = hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kx, s->ld, blockSize, s->d_red);
       if (!rc) rc = hipk_pair_dots(s->ctx, s->dt, s->m, x, s->ld, Kr, s->ld, blockSize, s->d_red + SD * blockSize);
@@ -262,7 +268,7 @@ static int solve_correction_gd(pa_solver *s, const double *lockedEvals, int numL
       }
    } else {
       if (p->correctionParams.projectors.RightX &&
-            ((p->correctionParams.precondition && p->applyPreconditioner) ||
+            ((p->correctionParams.precondition && p->applyPreconditioner) || s->B ||      /* (`Bx != x`, correction.c:359) */
                   (p->locking && p->orth == primme_orth_implicit_I))) {
          for (int b = 0; b < blockSize; b++) colsen[b] = -olsen[b];
          const char *xm = x;                       /* r -= eps B x for a generalised problem (correction.c:340-352) */
@@ -435,6 +441,7 @@ static int main_iter(pa_solver *s, double *evals, double *resNorms, int *ret, in
 
    while (OUTER_LIMITS_OK()) {
       p->initSize = numConverged = numConvergedStored = numLocked;
+      if (s->nBevecs > p->numOrthoConst) s->nBevecs = p->numOrthoConst;     /* B evecs of the locked columns: formed again on demand */
       reset = 0;
       for (i = 0; i < p->maxBasisSize; i++) flags[i] = UNCONV;
       s->targetShiftIndex = 0;
@@ -809,7 +816,7 @@ static void free_solver(pa_solver *s) {
       hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T); hipk_free(s->ctx, s->Jw);
       hipk_free(s->ctx, s->V2); hipk_free(s->ctx, s->W2); hipk_free(s->ctx, s->d_coef2); hipk_free(s->ctx, s->d_theta2);
       hipk_host_free(s->ctx, s->h_coef2); hipk_host_free(s->ctx, s->h_theta2);
-      hipk_free(s->ctx, s->evecsHat); hipk_free(s->ctx, s->Q); hipk_free(s->ctx, s->BT);
+      hipk_free(s->ctx, s->evecsHat); hipk_free(s->ctx, s->Q); hipk_free(s->ctx, s->BT); hipk_free(s->ctx, s->Bevecs);
       hipk_free(s->ctx, s->d_red); hipk_free(s->ctx, s->d_coef); hipk_free(s->ctx, s->d_theta);
       hipk_host_free(s->ctx, s->h_red); hipk_host_free(s->ctx, s->h_coef); hipk_host_free(s->ctx, s->h_theta);
       hipk_ctx_destroy(s->ctx);
@@ -880,23 +887,17 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
     * as soon as the caller gives the shift of the factorisation (targetShifts[0]; without one the reference dereferences a
     * NULL pointer, main_iter.c:465): round 6 lets it through */
    const int extremal = (p->target == primme_smallest || p->target == primme_largest || p->target == primme_largest_abs);
-   /* mass matrix (round 6): real and complex Hermitian panels, Rayleigh-Ritz (check_input: -39 otherwise, like the reference), the Generalized-Davidson
-    * family — the JDQMR inner solver with B (projectors on B Q, B x: inner_solve.c:283-300, correction.c:862-997) and the
-    * dynamic switch into it are not restated: -44 */
-   if (p->massMatrixMatvec && p->dynamicMethodSwitch > 0) {
-      /* PRIMME_DYNAMIC (the default method) with a mass matrix: the inner solver it would switch to is not restated, so the run
-       * stays in its GD+k mode — what the reference's own switch does when it leaves JDQMR (maxInnerIterations = 0,
-       * main_iter.c:2330-2345) — and reports the state "GD+k" (-2) like a finished dynamic run (main_iter.c:1221-1228) */
+   /* mass matrix (round 6): real and complex Hermitian panels, Rayleigh-Ritz (check_input: -39 otherwise, like the reference), the
+    * Generalized-Davidson family, the JDQMR inner solver (projectors on B Q and B x, eigs_jd.c) and the dynamic switch between them.
+    * PRIMME_AMD_MASS_NO_DYNAMIC=1 keeps a PRIMME_DYNAMIC run in its GD+k mode (what the reference's own switch does when it
+    * leaves JDQMR: maxInnerIterations = 0, state -2 on return, main_iter.c:2330-2345, :1221-1228): an A/B knob. */
+   if (p->massMatrixMatvec && p->dynamicMethodSwitch > 0 && getenv("PRIMME_AMD_MASS_NO_DYNAMIC") != NULL) {
       p->dynamicMethodSwitch = -2;
       p->correctionParams.maxInnerIterations = 0;
    }
-   const int mass_unavailable = p->massMatrixMatvec &&
-         (p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0 ||
-          (p->correctionParams.projectors.RightX && p->correctionParams.projectors.SkewX));
-   if (mass_unavailable || (harmonic && extremal && !(refined && p->numTargetShifts > 0 && p->targetShifts))) {
+   if (harmonic && extremal && !(refined && p->numTargetShifts > 0 && p->targetShifts)) {
       if (p->printLevel > 0 && p->outputFile)
-         fprintf(p->outputFile, "primme_amd: requested configuration (mass matrix with an inner solver / harmonic "
-               "projection with an extremal target) is not on the device path\n");
+         fprintf(p->outputFile, "primme_amd: requested configuration (harmonic projection with an extremal target) is not on the device path\n");
       return PRIMME_FUNCTION_UNAVAILABLE;
    }
 
@@ -943,6 +944,7 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    s->maxRank = p->numOrthoConst + (p->locking ? p->numEvals : 0) + p->maxBasisSize;
    s->B = p->massMatrixMatvec != NULL;
    if (s->B) s->fuse_gd = 0;
+   s->ref_soft_alias = s->B && !p->locking && getenv("PRIMME_AMD_JDQMR_REF_SOFT_LOCKING") != NULL;
    if (hipk_ctx_create(&s->ctx, p->queue)) { free(s); return PRIMME_UNEXPECTED_FAILURE; }
    /* peer-to-peer transport: the second stage of a reduction may exchange with the other ranks itself */
    if (s->dev_comm) (void)pa_comm_attach_ctx(p->commInfo, s->ctx);
@@ -972,7 +974,9 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
    }
    rc = hipk_malloc(s->ctx, colBytes * K, (void **)&s->V) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W) ||
         hipk_malloc(s->ctx, colBytes * s->nT, (void **)&s->T) ||
-        ((p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) && hipk_malloc(s->ctx, colBytes * 6 * b, (void **)&s->Jw)) ||
+        ((p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) && hipk_malloc(s->ctx, colBytes * (s->B ? 8 : 6) * b, (void **)&s->Jw)) ||
+        (s->B && (p->correctionParams.maxInnerIterations != 0 || p->dynamicMethodSwitch > 0) &&
+         hipk_malloc(s->ctx, (size_t)(s->ldevecs > 0 ? s->ldevecs : 1) * s->es * (maxEvecs + 1), (void **)&s->Bevecs)) ||
         hipk_malloc(s->ctx, ((size_t)s->red_cap * 3 + 64) * 8, (void **)&s->d_red) ||
         (harmonic && hipk_malloc(s->ctx, colBytes * K, (void **)&s->Q)) ||
         (s->B && hipk_malloc(s->ctx, colBytes * (s->nBT = PA_MAX(3 * (K + b), PA_MAX(p->numOrthoConst, 3 * (b + nev)))), (void **)&s->BT)) ||

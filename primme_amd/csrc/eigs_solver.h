@@ -42,6 +42,14 @@ typedef struct pa_solver {
    int B;
    char *BT;
    int nBT;
+   /* ... and an inner solver (JDQMR): B evecs of the constraints and locked vectors, the left projector I - (B Q) Q' and the
+    * right one (correction.c:862-997); columns [0, nBevecs) are current */
+   char *Bevecs;
+   int nBevecs;
+   /* PRIMME_AMD_JDQMR_REF_SOFT_LOCKING=1: without locking the reference allocates no B evecs and hands evecs over in its place
+    * (main_iter.c:334-336, :659-661), so its projectors read Q where B Q is meant and, for block size 1, B x where x is
+    * (correction.c:911-917 copies x, then B x, into the same column).  A parity instrument like the indexing knob. */
+   int ref_soft_alias;
    /* harmonic extraction: (A - tau I) V = Q R, with Q in HBM, R / Q'V / left vectors on the host */
    char *Q;
    HS *R, *QtV, *hU;       /* (harmonic / refined extraction: real objects only) */

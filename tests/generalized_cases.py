@@ -13,16 +13,31 @@ GEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "referenc
 # eigenvalues, outer iterations and restarts are the reference's exactly on the CPU checker for these; the matvec count (the
 # reference counts the applications of B with those of A) differs: B enters here through the callback on demand — B X of the new
 # block in every orthonormalisation sweep, B (V h) of the Ritz vectors whose residual is wanted — where the reference keeps a B V panel
-EXACT = {"gen_gdk", "gen_gdk_blk2", "gen_largest_soft", "gen_olsen_jacobi", "gen_gd"}
+EXACT = {"gen_gdk", "gen_gdk_blk2", "gen_largest_soft", "gen_olsen_jacobi", "gen_gd",
+         # the JDQMR inner solver with B (locking on, block size 1): outer iterations, restarts AND preconditioner applications
+         "gen_jdqmr", "gen_jdqmr_jacobi", "gen_jdqmr_etol_3d", "gen_jdqmr_largest", "gen_jd_olsen"}
+JDQMR = ["gen_jdqmr", "gen_jdqmr_jacobi", "gen_jdqmr_etol_3d", "gen_jdqmr_largest", "gen_jdqmr_blk3", "gen_jd_olsen", "gen_jdqmr_soft", "gen_lund_jdqmr"]
+# "gen_lund_*": LUNDA.mtx x = lambda lund_b.mtx x, the pair among the reference's own data files (condition 1e7: the histories agree to
+# six digits for 190 outer iterations and then separate at rounding level — 545 vs 535, 35 vs 34, 303 vs 302 outer iterations)
+LUND = ["gen_lund_gdk", "gen_lund_jdqmr", "gen_lund_blk2"]
+# "gen_jdqmr_blk3": blocks — exact with PRIMME_AMD_JDQMR_REF_INDEXING=1 (the reference's own indexing of the block recurrences, and its
+# B x panel left unpermuted when a column leaves the block), a different equally valid history without (15 %).
+# "gen_jdqmr_soft": without locking the reference passes evecs where B evecs is meant (main_iter.c:334-336, :659-661: its projector
+# for block size 1 is I - (B x)(B x)' and its inner solves stagnate); the default here keeps B evecs and needs a fraction of the
+# reference's matrix-vector products — only the eigenpairs are compared, and the work must not exceed the reference's.
 
 
 def check(name, backend):
     import scipy.linalg as sl
     import scipy.sparse as sp
     g = GEN[name]
-    dims = tuple(g["dims"])
-    rp, ci, va, n = problems.laplacian_csr(dims)
-    brp, bci, bva = problems.mass_matrix_csr(n)
+    if g["dims"] == "lund":      # LUNDA.mtx x = lambda lund_b.mtx x, the reference's own data files
+        data = os.path.join(os.path.dirname(__file__), "golden", "reference_driver")
+        rp, ci, va, n, _ = problems.read_matrix_market(os.path.join(data, "LUNDA.mtx"))
+        brp, bci, bva, _, _ = problems.read_matrix_market(os.path.join(data, "lund_b.mtx"))
+    else:
+        rp, ci, va, n = problems.laplacian_csr(tuple(g["dims"]))
+        brp, bci, bva = problems.mass_matrix_csr(n)
     kw = dict(g["kwargs"])
     r = eigsh(Operator(n, csr=(rp, ci, va)), backend=backend, mass=Operator(n, csr=(brp, bci, bva)), v0=problems.start_vector(n), **kw)
     assert r.ret == g["ret"] == 0 and r.initSize == g["initSize"], (name, r.ret)
@@ -43,9 +58,14 @@ def check(name, backend):
     assert np.all(res <= 1.5 * max(np.max(g["resNorms"]), np.max(r.resNorms)) + 1e-12), (name, res, g["resNorms"])
     assert np.max(np.abs(res - r.resNorms)) <= 1e-9 * aN, name                        # the reported norms are the true ones
     its, itsg = r.stats["numOuterIterations"], g["stats"]["numOuterIterations"]
-    if backend == "hostcheck" and name in EXACT:
+    if backend == "hostcheck" and (name in EXACT or (name == "gen_jdqmr_blk3" and os.environ.get("PRIMME_AMD_JDQMR_REF_INDEXING"))):
         assert (its, r.stats["numRestarts"]) == (itsg, g["stats"]["numRestarts"]), (name, its, itsg)
+        assert r.stats["numPreconds"] == g["stats"]["numPreconds"], name
         assert np.max(np.abs(np.array(r.resNorms) - np.array(g["resNorms"]))) <= 1e-10 * aN, name
+    elif name == "gen_jdqmr_soft":
+        assert its <= itsg and r.stats["numMatvecs"] <= g["stats"]["numMatvecs"], (name, its, itsg)
+    elif name == "gen_jdqmr_blk3" or (name in JDQMR and backend != "hostcheck"):
+        assert abs(its - itsg) <= max(2, 0.15 * itsg), (name, its, itsg)
     else:
         assert abs(its - itsg) <= max(2, 0.05 * itsg), (name, its, itsg)
     assert r.stats["numMatvecs"] >= its                                              # A at least once per outer iteration, B counted too

@@ -24,16 +24,39 @@ CASES = {
     "gen_lobpcg": ((9, 10, 11), dict(numEvals=3, eps=1e-7, aNorm=12.0, method="LOBPCG_OrthoBasis")),
     "gen_blk4_3d": ((12, 13, 14), dict(numEvals=8, eps=1e-9, aNorm=12.0, maxBlockSize=4)),
     "gen_noanorm": ((20, 21), dict(numEvals=3, eps=1e-8)),
+    # the JDQMR inner solver with B (projectors on B Q and B x); locking on: without it the reference hands evecs over where
+    # B evecs is meant (main_iter.c:334-336, :659-661) — "gen_jdqmr_soft" records that history too
+    "gen_jdqmr": ((20, 21), dict(numEvals=5, eps=1e-9, aNorm=8.0, method="JDQMR", locking=1)),
+    "gen_jdqmr_jacobi": ((20, 21), dict(numEvals=5, eps=1e-9, aNorm=8.0, method="JDQMR", precond="jacobi", locking=1)),
+    "gen_jdqmr_etol_3d": ((9, 10, 11), dict(numEvals=4, eps=1e-9, aNorm=12.0, method="JDQMR_ETol", precond="jacobi", locking=1)),
+    "gen_jdqmr_largest": ((20, 21), dict(numEvals=4, eps=1e-9, aNorm=8.0, method="JDQMR", target="largest", locking=1)),
+    "gen_jdqmr_blk3": ((12, 13, 14), dict(numEvals=6, eps=1e-9, aNorm=12.0, method="JDQMR_ETol", maxBlockSize=3, precond="jacobi", locking=1)),
+    "gen_jd_olsen": ((20, 21), dict(numEvals=4, eps=1e-9, aNorm=8.0, method="JD_Olsen_plusK", precond="jacobi")),
+    "gen_jdqmr_soft": ((20, 21), dict(numEvals=5, eps=1e-9, aNorm=8.0, method="JDQMR", precond="jacobi", locking=0)),
+    # the classic pair of the reference's own data files: LUNDA.mtx x = lambda lund_b.mtx x (n = 147, both s.p.d.; reference_driver/)
+    "gen_lund_gdk": ("lund", dict(numEvals=5, eps=1e-10, method="GD_Olsen_plusK", precond="jacobi")),
+    "gen_lund_jdqmr": ("lund", dict(numEvals=5, eps=1e-10, method="JDQMR", precond="jacobi", locking=1)),
+    "gen_lund_blk2": ("lund", dict(numEvals=4, eps=1e-10, maxBlockSize=2, precond="jacobi", locking=1)),
 }
+
+
+def operators(dims):
+    if dims == "lund":
+        data = os.path.join(HERE, "reference_driver")
+        rp, ci, va, n, _ = problems.read_matrix_market(os.path.join(data, "LUNDA.mtx"))
+        brp, bci, bva, nb, _ = problems.read_matrix_market(os.path.join(data, "lund_b.mtx"))
+        assert n == nb
+        return (rp, ci, va), (brp, bci, bva), n
+    rp, ci, va, n = problems.laplacian_csr(tuple(dims))
+    return (rp, ci, va), problems.mass_matrix_csr(n), n
 
 
 def main():
     out = {}
     for name, (dims, kw) in CASES.items():
-        rp, ci, va, n = problems.laplacian_csr(dims)
-        brp, bci, bva = problems.mass_matrix_csr(n)
+        (rp, ci, va), (brp, bci, bva), n = operators(dims)
         r = eigsh(Operator(n, csr=(rp, ci, va)), backend="reference", mass=Operator(n, csr=(brp, bci, bva)), v0=problems.start_vector(n), **kw)
-        out[name] = dict(dims=list(dims), kwargs=kw, ret=r.ret, initSize=r.initSize, evals=r.evals.tolist(), resNorms=r.resNorms.tolist(),
+        out[name] = dict(dims=dims if isinstance(dims, str) else list(dims), kwargs=kw, ret=r.ret, initSize=r.initSize, evals=r.evals.tolist(), resNorms=r.resNorms.tolist(),
                          params=r.params, stats={k: r.stats[k] for k in ("numOuterIterations", "numMatvecs", "numRestarts", "numPreconds")})
         print(name, r.ret, out[name]["stats"])
     json.dump(out, open(os.path.join(HERE, "reference_generalized.json"), "w"), indent=1)

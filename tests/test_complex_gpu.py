@@ -130,7 +130,10 @@ def test_hip_native_complex_dynamic_method(built):
     assert np.all(np.linalg.norm(AX - r.evecs * r.evals, axis=0) <= 1.5e-10 * aN)
 
 
-@pytest.mark.parametrize("kw", [dict(numEvals=4, eps=1e-9, target="largest", method="GD_plusK"), dict(numEvals=4, eps=1e-9, target="largest", maxBlockSize=2)])
+@pytest.mark.parametrize("kw", [dict(numEvals=4, eps=1e-9, target="largest", method="GD_plusK"), dict(numEvals=4, eps=1e-9, target="largest", maxBlockSize=2),
+                                dict(numEvals=4, eps=1e-9, target="largest", method="JDQMR", locking=1),
+                                dict(numEvals=4, eps=1e-9, target="largest", method="JDQMR_ETol", locking=1, precond="jacobi"),
+                                dict(numEvals=3, eps=1e-9, target="smallest", method="JDQMR", locking=1, maxBlockSize=2)])
 def test_hip_generalized_hermitian(built, kw):
     """Generalised Hermitian problems on the device (round 6; the live-reference leg is tests/test_complex_host.py): scipy's dense
     truth, B-orthonormal vectors, true residuals, the CPU checker's counts to 5 %."""
@@ -144,5 +147,6 @@ def test_hip_generalized_hermitian(built, kw):
     X = a.evecs
     assert np.max(np.abs(X.conj().T @ B @ X - np.eye(X.shape[1]))) <= 1e-9
     assert np.max(np.abs(np.linalg.norm(A @ X - (B @ X) * a.evals, axis=0) - a.resNorms)) <= 1e-9 * aN
-    assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= max(2, 0.05 * b.stats["numOuterIterations"])
+    tol = 0.15 if "JDQMR" in kw.get("method", "") else 0.05
+    assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= max(2, tol * b.stats["numOuterIterations"])
 

@@ -172,7 +172,12 @@ def _generalized_hermitian(backend, kw, n=600):
 
 @pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
 @pytest.mark.parametrize("kw", [dict(numEvals=4, eps=1e-9, target="largest", method="GD_plusK"), dict(numEvals=4, eps=1e-9, target="largest", maxBlockSize=2),
-                                dict(numEvals=3, eps=1e-9, target="smallest", locking=0)])
+                                dict(numEvals=3, eps=1e-9, target="smallest", locking=0),
+                                # the JDQMR inner solver with B on complex panels (complex projector coefficients, real QMR recurrences)
+                                dict(numEvals=4, eps=1e-9, target="largest", method="JDQMR", locking=1),
+                                dict(numEvals=4, eps=1e-9, target="largest", method="JDQMR_ETol", locking=1, precond="jacobi"),
+                                dict(numEvals=3, eps=1e-9, target="smallest", method="JDQMR", locking=1, maxBlockSize=2),
+                                dict(numEvals=3, eps=1e-9, target="smallest", method="JDQMR", locking=0)])
 def test_generalized_hermitian_against_live_reference(built, kw):
     """Generalised HERMITIAN problems A x = lambda B x (round 6): zprimme with massMatrixMatvec against the native complex path —
     the same eigenvalues (and scipy's dense truth), B-orthonormal vectors, true residuals, the reference's outer-iteration
@@ -188,6 +193,7 @@ def test_generalized_hermitian_against_live_reference(built, kw):
     res = np.linalg.norm(A @ X - (B @ X) * b.evals, axis=0)
     assert np.max(np.abs(res - b.resNorms)) <= 1e-9 * aN
     assert (a.stats["numOuterIterations"], a.stats["numRestarts"]) == (b.stats["numOuterIterations"], b.stats["numRestarts"])
+    assert a.stats["numPreconds"] == b.stats["numPreconds"]
 
 
 def test_complex_unsupported_and_argument_errors(built):

@@ -220,12 +220,33 @@ def test_hip_wide_basis(built, K, mr):
         assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= 0.03 * b.stats["numOuterIterations"]
 
 
-@pytest.mark.parametrize("name", ["gen_gdk", "gen_gdk_blk2", "gen_largest_soft", "gen_olsen_jacobi", "gen_gd", "gen_lobpcg", "gen_blk4_3d", "gen_noanorm"])
+@pytest.mark.parametrize("name", ["gen_gdk", "gen_gdk_blk2", "gen_largest_soft", "gen_olsen_jacobi", "gen_gd", "gen_lobpcg", "gen_blk4_3d", "gen_noanorm",
+                                  "gen_lund_gdk", "gen_lund_jdqmr", "gen_lund_blk2"])
 def test_hip_generalized_problem_against_reference_fixture(built, name):
     """Generalised problems A x = lambda B x on the device (round 6; tests/generalized_cases.py): the reference's eigenvalues and
     residual norms, scipy's dense truth, B-orthonormal vectors, counts within 5 % of dprimme's."""
     from generalized_cases import check
     check(name, "hip")
+
+
+@pytest.mark.parametrize("name", ["gen_jdqmr", "gen_jdqmr_jacobi", "gen_jdqmr_etol_3d", "gen_jdqmr_largest", "gen_jdqmr_blk3", "gen_jd_olsen", "gen_jdqmr_soft"])
+def test_hip_generalized_jdqmr_against_reference_fixture(built, name):
+    """The JDQMR inner solver with a mass matrix on the device (round 6; csrc/eigs_jd.c, the CPU-checker leg with the exact counts is
+    tests/test_solver_host.py): the reference's eigenvalues, scipy's dense truth, B-orthonormal vectors with true residuals, outer
+    iterations within 15 % of dprimme's (inner-outer histories separate at rounding level between two arithmetic orders)."""
+    from generalized_cases import check
+    check(name, "hip")
+
+
+def test_hip_generalized_dynamic_method(built):
+    """PRIMME_DYNAMIC (the default method) with a mass matrix on the device: both modes of the switch run with B."""
+    import scipy.linalg as sl, scipy.sparse as sp
+    rp, ci, va, n = problems.laplacian_csr((20, 21))
+    brp, bci, bva = problems.mass_matrix_csr(n)
+    r = eigsh(Operator(n, csr=(rp, ci, va)), backend="hip", mass=Operator(n, csr=(brp, bci, bva)), numEvals=5, eps=1e-9, aNorm=8.0,
+              v0=problems.start_vector(n), method="DYNAMIC")
+    w = sl.eigh(sp.csr_matrix((va, ci, rp), shape=(n, n)).toarray(), sp.csr_matrix((bva, bci, brp), shape=(n, n)).toarray(), eigvals_only=True)[:5]
+    assert r.ret == 0 and np.max(np.abs(r.evals - w)) <= 1e-9 * 8.0
 
 
 def test_hip_refined_extraction_with_an_extremal_target(built):
