@@ -903,8 +903,9 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
 
    /* the basis never grows beyond the space itself, whatever maxBasisSize says */
    /* (real panels: the wide-basis restart kernel takes 1 023 columns since round 6, hipk_panels.hip:ritz_big_kernel; the complex
-    * one still 255; the reference has no limit, primme_c.c:470-487) */
-   const int max_basis = PA_IS_COMPLEX ? 255 : 1023;
+    * update stages its coefficient block in slices of 64 basis columns and its outputs in groups of 16, hipk_complex.hip:zritz_t,
+    * so it takes the same width; the reference has no limit, primme_c.c:470-487) */
+   const int max_basis = 1023;
    if (PA_MIN((int64_t)p->maxBasisSize, p->n - p->numOrthoConst) > max_basis) {
       if (p->printLevel > 0 && p->outputFile)
          fprintf(p->outputFile, "primme_amd: maxBasisSize > %d is not on the device path\n", max_basis);

@@ -130,6 +130,26 @@ def test_hip_native_complex_dynamic_method(built):
     assert np.all(np.linalg.norm(AX - r.evecs * r.evals, axis=0) <= 1.5e-10 * aN)
 
 
+@pytest.mark.parametrize("K,mr", [(260, 60), (520, 100)])
+def test_hip_complex_wide_basis(built, K, mr):
+    """maxBasisSize beyond 255 on complex panels on the device (round 6): the restart through the sliced complex update, against
+    numpy's dense spectrum and — at 260 — the CPU checker's history (tied to live zprimme in tests/test_complex_host.py)."""
+    n = 3000
+    A, csr = hermitian_band(n, seed=1)
+    kw = dict(numEvals=6, eps=1e-10, iseed=(1, 2, 3, 5), maxBasisSize=K, minRestartSize=mr, maxBlockSize=1, dtype=np.complex128)
+    a = eigsh(Operator(n, csr=csr), backend="hip", **kw)
+    assert a.ret == 0 and a.params["maxBasisSize"] == K and a.stats["numRestarts"] >= 1
+    aN = a.params["aNorm"]
+    assert np.max(np.abs(a.evals - np.linalg.eigvalsh(A)[:6])) <= 1e-9 * aN
+    X = a.evecs
+    assert np.max(np.abs(X.conj().T @ X - np.eye(6))) <= 1e-9
+    assert np.all(np.linalg.norm(A @ X - X * a.evals, axis=0) <= 1.5e-10 * aN)
+    if K == 260:
+        b = eigsh(Operator(n, csr=csr), backend="hostcheck", **kw)
+        assert a.stats["numRestarts"] == b.stats["numRestarts"]
+        assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= 0.03 * b.stats["numOuterIterations"]
+
+
 @pytest.mark.parametrize("kw", [dict(numEvals=4, eps=1e-9, target="largest", method="GD_plusK"), dict(numEvals=4, eps=1e-9, target="largest", maxBlockSize=2),
                                 dict(numEvals=4, eps=1e-9, target="largest", method="JDQMR", locking=1),
                                 dict(numEvals=4, eps=1e-9, target="largest", method="JDQMR_ETol", locking=1, precond="jacobi"),

@@ -196,6 +196,22 @@ def test_generalized_hermitian_against_live_reference(built, kw):
     assert a.stats["numPreconds"] == b.stats["numPreconds"]
 
 
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+def test_complex_wide_basis_against_live_reference(built):
+    """maxBasisSize beyond 255 on complex panels (round 6: up to 1 023 like the real ones; the complex Ritz / restart update
+    stages its coefficients in slices of 64 basis columns and its outputs in groups of 16): basis 260, restart 60 on a Hermitian
+    band matrix — zprimme's outer-iteration, restart and matvec counts exactly."""
+    n = 2000
+    A, csr = hermitian_band(n, seed=1)
+    kw = dict(numEvals=6, eps=1e-10, iseed=(1, 2, 3, 5), maxBasisSize=260, minRestartSize=60, maxBlockSize=1, dtype=np.complex128)
+    a = eigsh(Operator(n, csr=csr), backend="reference", **kw)
+    b = eigsh(Operator(n, csr=csr), backend="hostcheck", **kw)
+    assert a.ret == b.ret == 0 and b.params["maxBasisSize"] == 260 and b.stats["numRestarts"] >= 2
+    assert (a.stats["numOuterIterations"], a.stats["numRestarts"], a.stats["numMatvecs"]) == (b.stats["numOuterIterations"], b.stats["numRestarts"], b.stats["numMatvecs"])
+    assert np.max(np.abs(a.evals - b.evals)) <= 1e-10 * b.params["aNorm"]
+    assert np.max(np.abs(b.evals - np.linalg.eigvalsh(A)[:6])) <= 1e-9 * b.params["aNorm"]
+
+
 def test_complex_unsupported_and_argument_errors(built):
     import ctypes as C
     lib = checkers.load_hostcheck()
