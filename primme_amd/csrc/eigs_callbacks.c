@@ -9,6 +9,7 @@
  * MPI_Allreduce(MPI_FLOAT) therefore keeps working: these helpers do the same conversions.
  * Only primme_op_float and primme_op_double are accepted (half / quad: PRIMME_FUNCTION_UNAVAILABLE).
  */
+#include <stdio.h>
 #include "eigs_internal.h"
 #include "primme_amd_svds.h"
 #include <stdlib.h>
@@ -111,7 +112,13 @@ int pa_call_monitor_inner(primme_params *p, double eval, double resNorm, int cou
    int err = 0, one = 1, zero = 0, unconv = 0 /* UNCONVERGED */, nconv = counts, nlock = counts;
    double time = 0.0;
    primme_event event = primme_event_inner_iteration;
-   if (!p->monitorFun) return 0;
+   if (!p->monitorFun) {
+      /* the reference's default report of an inner step (primme_c.c:653-666), same line so that logs stay comparable */
+      if (p->outputFile && p->procID == 0 && p->printLevel >= 4)
+         fprintf(p->outputFile, "INN MV %lld Sec %e Eval %13E Lin|r| %.3e EV|r| %.3e\n", (long long)p->stats.numMatvecs,
+               p->stats.elapsedTime, eval, lsRes, resNorm);
+      return 0;
+   }
    if (!type_ok(p->monitorFun_type)) return PRIMME_FUNCTION_UNAVAILABLE;
    if (p->monitorFun_type == primme_op_float) {
       float e = (float)eval, r = (float)resNorm, t = (float)lsRes;

@@ -702,14 +702,14 @@ static int inner_solve(pa_solver *s, int blockSize, char *x, char *r, const doub
                perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue;
             }
             eval_prev[q] = eval_updated;
-            if (p->monitorFun) {      /* report of the inner step (inner_solve.c:550-558) */
+            if (p->monitorFun || p->printLevel >= 4) {      /* report of the inner step (inner_solve.c:550-558) */
                p->stats.elapsedTime = pa_wtime() - s->startTime;
                CHK(pa_call_monitor_inner(p, eval_updated, eres_updated[q], -1, (int)numIts, tau[q]));
             }
          } else {
             CHK(conv_test(s, eval[q], tau[q] / LTolerance_factor * sqrt((double)numIts), &isConv));
             if (numIts > 0 && isConv) { perm_set_value_on_pos(p0, i, blockSize - ++conv, blockSize); continue; }
-            if (p->monitorFun) {      /* (inner_solve.c:581-588) */
+            if (p->monitorFun || p->printLevel >= 4) {      /* (inner_solve.c:581-588) */
                p->stats.elapsedTime = pa_wtime() - s->startTime;
                CHK(pa_call_monitor_inner(p, eval[q], rnorm[q], 0, (int)numIts, tau[q]));
             }

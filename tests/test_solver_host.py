@@ -165,6 +165,41 @@ def test_generalized_jdqmr_against_reference_fixture(built, name):
     check(name, "hostcheck")
 
 
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("method,mass", [("JDQMR", False), ("JDQMR_ETol", False), ("JDQMR/full_LTolerance", False), ("JDQMR", True)])
+def test_inner_iteration_events_follow_the_live_reference(built, method, mass):
+    """monitorFun receives primme_event_inner_iteration for every QMR step (reference inner_solve.c:550-558 with the adaptive
+    tests, :581-588 otherwise): the same number of reports as dprimme, each with its outer-iteration count, inner step, eigenvalue
+    estimate, residual estimate and QMR residual (1e-7 relative, 1e-4 with a mass matrix: the steps themselves are the reference's)."""
+    import ctypes as C
+    rp, ci, va, n = problems.laplacian_csr((20, 21))
+    brp, bci, bva = problems.mass_matrix_csr(n)
+    op, bop = Operator(n, csr=(rp, ci, va)), Operator(n, csr=(brp, bci, bva))
+
+    def run(be):
+        log = []
+
+        def mon(bev, bs, bf, iblock, blockSize, bnorms, numConv, lev, numLocked, lflags, lnorms, inner, lsres, msg, time, event, pp, ierr):
+            if event[0] == 1:        # primme_event_inner_iteration
+                assert bs[0] == 1 and blockSize[0] == 1 and iblock[0] == 0 and bf[0] == 0
+                val = [C.cast(q, C.POINTER(C.c_double))[0] for q in (bev, bnorms, lsres)]
+                log.append((pp[0].stats.numOuterIterations, inner[0], numConv[0], numLocked[0], *val))
+            ierr[0] = 0
+        def tw(p):       # the non-adaptive branch of the inner stopping tests (inner_solve.c:563-588): at most 12 steps to a full tolerance
+            if "/" in method:
+                p.correctionParams.convTest = 0          # primme_full_LTolerance
+                p.correctionParams.maxInnerIterations = 12
+        r = eigsh(op, backend=be, mass=bop if mass else None, v0=problems.start_vector(n), numEvals=4, eps=1e-9, aNorm=8.0, method=method.split("/")[0],
+                  precond="jacobi", locking=1, monitor=mon, tweak=tw)
+        assert r.ret == 0
+        return r, log
+    (a, la), (b, lb) = run("reference"), run("hostcheck")
+    assert len(la) == len(lb) > 50 and [e[:4] for e in la] == [e[:4] for e in lb]
+    # (with B the residual estimate of a step carries the rounding of two more operator applications)
+    assert max(abs(x - y) / max(abs(x), 1e-300) for ea, eb in zip(la, lb) for x, y in zip(ea[4:], eb[4:])) <= (1e-4 if mass else 1e-7)
+    assert a.stats["numOuterIterations"] == b.stats["numOuterIterations"] and a.stats["numPreconds"] == b.stats["numPreconds"]
+
+
 def test_generalized_block_jdqmr_with_the_references_own_indexing(built, monkeypatch):
     """PRIMME_AMD_JDQMR_REF_INDEXING=1 on a generalised problem: besides its indexing of the block recurrences the reference leaves
     the B x panel unpermuted when a column leaves the block (inner_solve.c:352-357 permutes x and the right projector only);
