@@ -238,6 +238,20 @@ def test_hip_generalized_jdqmr_against_reference_fixture(built, name):
     check(name, "hip")
 
 
+@pytest.mark.parametrize("kw", [dict(method="GD_plusK"), dict(method="JDQMR", locking=1, precond="jacobi"), dict(method="GD_plusK", maxBlockSize=2)])
+def test_hip_generalized_single_precision(built, kw):
+    """hip_sprimme with a mass matrix on the device against scipy's dense truth and the CPU checker's counts (the checker is tied
+    to live sprimme in tests/test_solver_host.py)."""
+    import scipy.linalg as sl, scipy.sparse as sp
+    from test_solver_host import _single_generalized
+    a, b = _single_generalized("hip", kw), _single_generalized("hostcheck", kw)
+    rp, ci, va, n = problems.laplacian_csr((20, 21))
+    brp, bci, bva = problems.mass_matrix_csr(n)
+    w = sl.eigh(sp.csr_matrix((va, ci, rp), shape=(n, n)).toarray(), sp.csr_matrix((bva, bci, brp), shape=(n, n)).toarray(), eigvals_only=True)[:4]
+    assert a.ret == b.ret == 0 and np.max(np.abs(a.evals - w)) <= 1e-4 * 8.0
+    assert abs(a.stats["numOuterIterations"] - b.stats["numOuterIterations"]) <= max(2, 0.15 * b.stats["numOuterIterations"])
+
+
 def test_hip_generalized_dynamic_method(built):
     """PRIMME_DYNAMIC (the default method) with a mass matrix on the device: both modes of the switch run with B."""
     import scipy.linalg as sl, scipy.sparse as sp

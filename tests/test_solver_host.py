@@ -246,6 +246,27 @@ def test_generalized_jdqmr_without_locking_the_references_way(built, monkeypatch
     assert plain.stats["numMatvecs"] < 0.5 * ref.stats["numMatvecs"]
 
 
+SINGLE_GEN = [dict(method="GD_plusK"), dict(method="JDQMR", locking=1, precond="jacobi"), dict(method="GD_plusK", maxBlockSize=2)]
+
+
+def _single_generalized(backend, kw):
+    rp, ci, va, n = problems.laplacian_csr((20, 21))
+    brp, bci, bva = problems.mass_matrix_csr(n)
+    return eigsh(Operator(n, csr=(rp, ci, va.astype(np.float32))), backend=backend, mass=Operator(n, csr=(brp, bci, bva.astype(np.float32))),
+                 v0=problems.start_vector(n).astype(np.float32), dtype=np.float32, numEvals=4, eps=1e-4, aNorm=8.0, **kw)
+
+
+@pytest.mark.skipif(not os.path.exists(checkers.REFERENCE_LIB), reason="oracle/_ref not built")
+@pytest.mark.parametrize("kw", SINGLE_GEN)
+def test_generalized_single_precision_against_live_reference(built, kw):
+    """sprimme with a mass matrix (single-precision panels take the tracked-Gram block path anyway): the live reference's outer
+    iterations and restarts exactly, its eigenvalues to single-precision rounding."""
+    a, b = _single_generalized("reference", kw), _single_generalized("hostcheck", kw)
+    assert a.ret == b.ret == 0 and b.initSize == 4
+    assert (a.stats["numOuterIterations"], a.stats["numRestarts"]) == (b.stats["numOuterIterations"], b.stats["numRestarts"])
+    assert np.max(np.abs(a.evals - b.evals)) <= 2e-6 * 8.0
+
+
 def test_generalized_problem_corners(built, monkeypatch):
     """The corners of the mass-matrix path: the dynamic method switches between GD+k and JDQMR with B like on a standard problem
     (PRIMME_AMD_MASS_NO_DYNAMIC=1 keeps it in GD+k and says so), exact Olsen and skew projectors work on K^-1 B x, and a
