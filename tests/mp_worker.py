@@ -43,6 +43,23 @@ def run(rank, world, port, case, out_path):
         s = Session(op, backend="hostcheck")
         r = s.solve(numEvals=6, eps=1e-10, aNorm=8.0 * 1.37, v0=v0, numProcs=world, procID=rank, global_sum=global_sum)
         s.close()
+    elif case.startswith("blockdiag_mass"):
+        # generalised problem A x = lambda B x with the rows over two ranks (round 6): A and the mass matrix B block-diagonal,
+        # one tile per rank, so neither callback communicates; every inner product of the tracked-Gram path, of the
+        # residuals W h - theta B(V h) and (…_jdqmr) of the inner solver's projectors on B Q / B x goes through globalSumReal
+        dims = (15, 16)
+        rp, ci, va, n0 = problems.laplacian_csr(dims)
+        rpt, cit, vat = problems.tile_block_diagonal(rp, ci, va, 1, scale_fn=lambda t: 1.0 + 0.37 * t, row0_tile=rank)
+        brp, bci, bva = problems.mass_matrix_csr(n0)
+        brpt, bcit, bvat = problems.tile_block_diagonal(brp, bci, bva, 1, scale_fn=lambda t: 1.0 + 0.11 * t, row0_tile=rank)
+        n = n0 * world
+        op = Operator(n, csr=(rpt, cit, vat), row0=rank * n0, nrows=n0)
+        bop = Operator(n, csr=(brpt, bcit, bvat), row0=rank * n0, nrows=n0)
+        v0 = problems.start_vector(n, row0=rank * n0, nrows=n0)
+        s = Session(op, backend="hostcheck", mass=bop)
+        kw = dict(method="JDQMR", precond="jacobi", locking=1) if case.endswith("_jdqmr") else dict(method="GD_plusK")
+        r = s.solve(numEvals=5, eps=1e-9, aNorm=8.0 * 1.37, v0=v0, numProcs=world, procID=rank, global_sum=global_sum, **kw)
+        s.close()
     elif case.startswith("devcomm"):
         xr = case.endswith("_xr")
         case = case[:-3] if xr else case

@@ -51,6 +51,33 @@ def test_block_diagonal_two_ranks(built, tmp_path):
     assert abs(res[0]["its"] - single.stats["numOuterIterations"]) <= 0.05 * single.stats["numOuterIterations"]
 
 
+@pytest.mark.parametrize("case", ["blockdiag_mass", "blockdiag_mass_jdqmr"])
+def test_generalized_problem_two_ranks(built, tmp_path, case):
+    """A x = lambda B x with the rows over two ranks (round 6): GD+k through the tracked-Gram path and JDQMR with its projectors on
+    B Q / B x, every inner product through globalSumReal — scipy's dense truth, the one-rank solve of the same problem, identical
+    bits on both ranks, B-orthonormal slabs."""
+    import scipy.linalg as sl
+    import scipy.sparse as sp
+    res = _launch(case, tmp_path)
+    dims = (15, 16)
+    rp, ci, va, n0 = problems.laplacian_csr(dims)
+    rpt, cit, vat = problems.tile_block_diagonal(rp, ci, va, 2, scale_fn=lambda t: 1.0 + 0.37 * t)
+    brp, bci, bva = problems.mass_matrix_csr(n0)
+    brpt, bcit, bvat = problems.tile_block_diagonal(brp, bci, bva, 2, scale_fn=lambda t: 1.0 + 0.11 * t)
+    n = 2 * n0
+    kw = dict(method="JDQMR", precond="jacobi", locking=1) if case.endswith("_jdqmr") else dict(method="GD_plusK")
+    single = eigsh(Operator(n, csr=(rpt, cit, vat)), backend="hostcheck", mass=Operator(n, csr=(brpt, bcit, bvat)), numEvals=5, eps=1e-9,
+                   aNorm=8.0 * 1.37, v0=problems.start_vector(n), **kw)
+    w = sl.eigh(sp.csr_matrix((vat, cit, rpt), shape=(n, n)).toarray(), sp.csr_matrix((bvat, bcit, brpt), shape=(n, n)).toarray(), eigvals_only=True)[:5]
+    assert single.ret == 0
+    for r in res:
+        assert r["ret"] == 0 and r["numGlobalSum"] > 0
+        assert np.max(np.abs(np.sort(r["evals"]) - w)) <= 1e-9 * 8 * 1.37
+        assert np.max(np.abs(np.sort(r["evals"]) - np.sort(single.evals))) <= 1e-9 * 8 * 1.37
+    assert res[0]["evals"] == res[1]["evals"] and res[0]["its"] == res[1]["its"]
+    assert abs(res[0]["its"] - single.stats["numOuterIterations"]) <= max(2, 0.1 * single.stats["numOuterIterations"])
+
+
 def test_halo_exchange_two_ranks(built, tmp_path):
     res = _launch("halo", tmp_path)
     dims = (20, 22)
