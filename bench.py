@@ -145,6 +145,11 @@ def main():
         os.environ["PRIMME_AMD_COMM"] = args.comm
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)
+    # The contract is ONE JSON line on stdout.  Libraries underneath write banners to file descriptor 1 (RCCL's version block,
+    # gloo's "connected to N peer ranks"): from here on fd 1 is stderr, and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -691,7 +696,9 @@ def main():
             lib.primme_amd_comm_destroy(second)
         lib.primme_amd_comm_destroy(comm)
     if rank == 0:
-        print(json.dumps(out, default=lambda o: o.item() if hasattr(o, "item") else str(o)), flush=True)
+        line = (json.dumps(out, default=lambda o: o.item() if hasattr(o, "item") else str(o)) + "\n").encode()
+        while line:
+            line = line[os.write(real_stdout, line):]
     if dist_path:
         import torch.distributed as dist
         dist.destroy_process_group()
