@@ -604,7 +604,9 @@ def main():
                                        f"primme_amd_csr_tile_block_diagonal (tile t scaled by 1 + t/T): n={n}, nnz={len(va)}; 20 eigenvalues closest to {shift:.4e}, "
                                        f"JDQMR, blockSize 8, Jacobi K = diag(A) - shift, eps=1e-8*|A|, |A|={aN:.4e}",
                            "converged": ok, "max_eval_error_vs_dense_truth": err, "outer_iterations": r.stats["numOuterIterations"],
-                           "matvecs": r.stats["numMatvecs"], "restarts": r.stats["numRestarts"]},
+                           "matvecs": r.stats["numMatvecs"], "restarts": r.stats["numRestarts"],
+                           "shift_note": "SURVEY 8(d) suggests the shift 1.0e6; at that shift the live reference does not converge either "
+                                         "(profiles/r04_config3_reference_shift_1e6.log), BASELINE.json names none: 4.4764e8 is this build's choice"},
                 "roofline": dict(generic_roofline(prof), mfma=mfma_evidence("configs2"))}
 
     def config3_hermitian():
