@@ -2,7 +2,8 @@
 the plain-C kernel layer (tests' checker).  Catches device-layer limits the checker does not have
 (jobs per launch, columns per launch, basis sizes).
    python scripts/fuzz_hip_vs_host.py N seed host FILE    # checker leg (CPU, slow): results -> FILE
-   python scripts/fuzz_hip_vs_host.py N seed hip FILE     # HIP leg on the GPU box, compared with FILE"""
+   python scripts/fuzz_hip_vs_host.py N seed hip FILE     # HIP leg on the GPU box, compared with FILE
+FUZZ_MASS=1 (both legs): every case is a generalised problem A x = lambda B x with B = problems.mass_matrix_csr, randomly scaled."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,6 +61,14 @@ for it in range(N):
     if rng.random() < 0.15:
         kw["constraints"] = np.linalg.qr(rng.standard_normal((n, int(rng.integers(1, 4)))))[0]
     kw["maxMatvecs"] = 15000
+    B = None
+    if os.environ.get("FUZZ_MASS"):
+        brp, bci, bva = problems.mass_matrix_csr(n)
+        bva = bva * float(rng.choice([1.0, 0.25, 7.0]))
+        B = (brp, bci, bva.astype(dtype))
+        kw.pop("projection", None)
+        kw["mass"] = Operator(n, csr=B)
+        kw["maxMatvecs"] = 40000
     try:
         if leg == "hip":
             if str(it) not in saved: continue
@@ -91,11 +100,11 @@ for it in range(N):
                 continue
         g = eigsh(Operator(n, csr=(rp, ci, va)), backend="hip", dtype=dtype, **kw)
     except Exception as e:
-        bad.append(dict(it=it, err=repr(e)[:200], kw={k: (v if not isinstance(v, np.ndarray) else "array") for k, v in kw.items()}))
+        bad.append(dict(it=it, err=repr(e)[:200], kw={k: (v if not isinstance(v, np.ndarray) else "array") for k, v in kw.items() if k != "mass"}))
         continue
     ran += 1
     if os.environ.get("FUZZ_TRACE"): print(it, round(time.time() - t0, 1), dims, kw.get("method"), h.ret, g.ret, flush=True)
-    desc = dict(it=it, dims=dims, dtype=np.dtype(dtype).name, kw={k: (v if not isinstance(v, np.ndarray) else f"array{v.shape}") for k, v in kw.items()},
+    desc = dict(it=it, dims=dims, dtype=np.dtype(dtype).name, kw={k: (v if not isinstance(v, np.ndarray) else f"array{v.shape}") for k, v in kw.items() if k != "mass"},
                 host=(h.ret, h.initSize, h.stats["numOuterIterations"]), hip=(g.ret, g.initSize, g.stats["numOuterIterations"]))
     if h.ret != g.ret and not (h.ret in (0, -3) and g.ret in (0, -3)):
         bad.append(dict(kind="ret", **desc)); continue
@@ -107,7 +116,8 @@ for it in range(N):
     if h.initSize != g.initSize or (k and np.max(np.abs(np.sort(h.evals[:k]) - np.sort(g.evals[:k]))) > tol * aN):
         # interior targets may legitimately pick different members of a cluster: check residuals instead
         X = g.evecs[:, :g.initSize].astype(np.float64)
-        R = problems.csr_matvec_numpy(rp, ci, va, X) - X * g.evals[:g.initSize].astype(np.float64)
+        BX = X if B is None else problems.csr_matvec_numpy(B[0], B[1], B[2].astype(np.float64), X)
+        R = problems.csr_matvec_numpy(rp, ci, va, X) - BX * g.evals[:g.initSize].astype(np.float64)
         rn = np.linalg.norm(R, axis=0)
         if g.initSize != kw["numEvals"] or np.any(rn > 10 * max(kw["eps"], np.finfo(dtype).eps * 50) * aN):
             bad.append(dict(kind="values", maxres=float(rn.max()) if len(rn) else None, **desc))
