@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("prog", ["ex_eigs_dhip", "ex_svds_dhip", "ex_svds_zhip", "ex_eigs_zhip", "ex_eigs_dseq_host", "ex_svds_dseq_host", "test_hip_wrapper"])
+@pytest.mark.parametrize("prog", ["ex_eigs_dhip", "ex_eigs_dhip_mass", "ex_svds_dhip", "ex_svds_zhip", "ex_eigs_zhip", "ex_eigs_dseq_host", "ex_svds_dseq_host", "test_hip_wrapper"])
 def test_c_example(built, prog):
     exe = os.path.join(ROOT, "examples", prog)
     if not os.path.exists(exe):
