@@ -173,6 +173,18 @@ def run(rank, world, port, case, out_path):
             v0 = np.random.default_rng(7).standard_normal((n, 4))[row0:row0 + nloc]
             r = s.solve(v0=v0, maxBlockSize=4, method="JDQMR", **kw)
         s.close()
+    elif case in ("halo_mass", "halo_mass_jdqmr"):
+        # generalised problem (round 6): the 3-D Laplacian and a tridiagonal mass matrix, both split by rows — two ready-made
+        # operators with their own neighbour exchanges, B X / B (V h) / B d through primme_amd_mass_matvec on every rank
+        dims = (24, 25, 26)
+        n = int(np.prod(dims))
+        row0, nloc = split(n, world, rank)
+        rp, ci, va, _ = problems.laplacian_csr(dims, row0=row0, nrows=nloc)
+        brp, bci, bva = problems.mass_matrix_csr(n, row0=row0, nrows=nloc)
+        s = Session(Operator(n, csr=(rp, ci, va), row0=row0, nrows=nloc), comm=comm, mass=Operator(n, csr=(brp, bci, bva), row0=row0, nrows=nloc))
+        kw = dict(method="JDQMR", precond="jacobi", locking=1) if case.endswith("_jdqmr") else dict(method="GD_plusK")
+        r = s.solve(numEvals=5, eps=1e-9, aNorm=12.0, numProcs=world, procID=rank, v0=problems.start_vector(n, row0=row0, nrows=nloc), **kw)
+        s.close()
     elif case in ("config2_full", "lap2d_10m"):
         # the bench workloads under the bench's own row partition (bench.py --gpus N): BASELINE configs[1] at full
         # size, and the north-star 10 M-row 5-point Laplacian (2 pairs: the partition is what is under test)

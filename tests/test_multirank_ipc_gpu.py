@@ -118,6 +118,30 @@ def test_ipc_halo_laplacian(built, tmp_path, world, case):
         assert res[0]["adopted"] >= 0.6 * res[0]["its"] and all(r["adopted"] == res[0]["adopted"] for r in res)
 
 
+@pytest.mark.parametrize("world,case", [(2, "halo_mass"), (4, "halo_mass"), (2, "halo_mass_jdqmr"), (4, "halo_mass_jdqmr")])
+def test_ipc_generalized_problem(built, tmp_path, world, case):
+    """A x = lambda B x with the rows over `world` processes on the mailboxes (round 6): A and B are two ready-made operators with
+    their own halo exchanges; GD+k through the tracked-Gram path and JDQMR with its projectors on B Q / B x.  Against the one-rank
+    solve on the device: the same eigenvalues to 1e-10 |A|, the same iteration count to 5 % (15 % for the inner-outer method),
+    identical bits on all ranks."""
+    res = _launch(case, world, tmp_path)
+    dims = (24, 25, 26)
+    rp, ci, va, n = problems.laplacian_csr(dims)
+    brp, bci, bva = problems.mass_matrix_csr(n)
+    kw = dict(method="JDQMR", precond="jacobi", locking=1) if case.endswith("_jdqmr") else dict(method="GD_plusK")
+    one = eigsh(Operator(n, csr=(rp, ci, va)), backend="hip", mass=Operator(n, csr=(brp, bci, bva)), numEvals=5, eps=1e-9, aNorm=12.0,
+                v0=problems.start_vector(n), **kw)
+    assert one.ret == 0
+    for r in res:
+        assert r["ret"] == 0 and r["evals"] == res[0]["evals"] and r["its"] == res[0]["its"]
+    assert np.max(np.abs(np.sort(res[0]["evals"]) - np.sort(one.evals))) <= 1e-10 * 12.0
+    tol = 0.15 if case.endswith("_jdqmr") else 0.05
+    assert abs(res[0]["its"] - one.stats["numOuterIterations"]) <= max(2, tol * one.stats["numOuterIterations"])
+    # B-orthonormal Ritz vectors: the Euclidean norms of the slabs add up to x'x = 1 / (x'Bx / x'x) per vector, between 1/|B| and |B^-1|
+    tot = sum(r["evecs_norm2"] for r in res)
+    assert 5.0 / 1.8 < tot < 5.0 / 0.7
+
+
 @pytest.mark.parametrize("world", WORLDS)
 def test_ipc_configs3_small(built, tmp_path, world):
     """BASELINE configs[3] in small: complex Hermitian banded, block size 4, 6 largest, rows split."""
