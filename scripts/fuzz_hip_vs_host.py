@@ -3,7 +3,9 @@ the plain-C kernel layer (tests' checker).  Catches device-layer limits the chec
 (jobs per launch, columns per launch, basis sizes).
    python scripts/fuzz_hip_vs_host.py N seed host FILE    # checker leg (CPU, slow): results -> FILE
    python scripts/fuzz_hip_vs_host.py N seed hip FILE     # HIP leg on the GPU box, compared with FILE
-FUZZ_MASS=1 (both legs): every case is a generalised problem A x = lambda B x with B = problems.mass_matrix_csr, randomly scaled."""
+FUZZ_MASS=1 (both legs): every case is a generalised problem A x = lambda B x with B = problems.mass_matrix_csr, randomly scaled.
+FUZZ_COMPLEX=1 (both legs): Hermitian problems on the native complex panels (problems.hermitian_banded_csr with a random diagonal
+scaling, complex128 / complex64; with FUZZ_MASS the Hermitian mass matrix)."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,6 +46,16 @@ for it in range(N):
               iseed=tuple(int(x) for x in rng.integers(0, 4000, 4)))
     dtype = np.float32 if rng.random() < 0.2 else np.float64
     if dtype == np.float32: kw["eps"] = 1e-4
+    CPLX = bool(os.environ.get("FUZZ_COMPLEX"))
+    if CPLX:
+        n = int(rng.integers(60, 500))
+        rp, ci, va = problems.hermitian_banded_csr(n, hbw=int(rng.integers(1, 5)))
+        dsc = 1.0 + 0.5 * rng.random(n)
+        rows_ = np.repeat(np.arange(n), np.diff(rp))
+        va = va * dsc[rows_] * dsc[ci]
+        kw["numEvals"] = int(min(kw["numEvals"], max(1, n // 8)))
+        dtype = np.complex64 if dtype == np.float32 else np.complex128
+        va = va.astype(dtype)
     target = str(rng.choice(["smallest", "largest", "closest_abs", "closest_geq", "closest_leq", "largest_abs"], p=[.35, .25, .15, .1, .1, .05]))
     kw["target"] = target
     if target.startswith("closest") or target == "largest_abs":
@@ -59,11 +71,12 @@ for it in range(N):
     if rng.random() < 0.15 and dtype == np.float64 and kw.get("maxBlockSize", 1) == 1 and target.startswith("closest"):
         kw["projection"] = str(rng.choice(["harmonic", "refined"]))
     if rng.random() < 0.15:
-        kw["constraints"] = np.linalg.qr(rng.standard_normal((n, int(rng.integers(1, 4)))))[0]
+        nc_ = int(rng.integers(1, 4))
+        kw["constraints"] = np.linalg.qr(rng.standard_normal((n, nc_)) + (1j * rng.standard_normal((n, nc_)) if CPLX else 0.0))[0]
     kw["maxMatvecs"] = 15000
     B = None
     if os.environ.get("FUZZ_MASS"):
-        brp, bci, bva = problems.mass_matrix_csr(n)
+        brp, bci, bva = problems.hermitian_mass_matrix_csr(n) if CPLX else problems.mass_matrix_csr(n)
         bva = bva * float(rng.choice([1.0, 0.25, 7.0]))
         B = (brp, bci, bva.astype(dtype))
         kw.pop("projection", None)
@@ -111,15 +124,17 @@ for it in range(N):
     if h.ret != 0 or g.ret != 0:
         skipped += 1; continue
     aN = max(h.params["aNorm"], 1e-300)
-    tol = 2e-4 if dtype == np.float32 else 1e-8
+    single = dtype in (np.float32, np.complex64)
+    tol = 2e-4 if single else 1e-8
     k = min(h.initSize, g.initSize)
     if h.initSize != g.initSize or (k and np.max(np.abs(np.sort(h.evals[:k]) - np.sort(g.evals[:k]))) > tol * aN):
         # interior targets may legitimately pick different members of a cluster: check residuals instead
-        X = g.evecs[:, :g.initSize].astype(np.float64)
-        BX = X if B is None else problems.csr_matvec_numpy(B[0], B[1], B[2].astype(np.float64), X)
-        R = problems.csr_matvec_numpy(rp, ci, va, X) - BX * g.evals[:g.initSize].astype(np.float64)
+        wide = np.complex128 if CPLX else np.float64
+        X = g.evecs[:, :g.initSize].astype(wide)
+        BX = X if B is None else problems.csr_matvec_numpy(B[0], B[1], B[2].astype(wide), X)
+        R = problems.csr_matvec_numpy(rp, ci, va.astype(wide), X) - BX * g.evals[:g.initSize].astype(np.float64)
         rn = np.linalg.norm(R, axis=0)
-        if g.initSize != kw["numEvals"] or np.any(rn > 10 * max(kw["eps"], np.finfo(dtype).eps * 50) * aN):
+        if g.initSize != kw["numEvals"] or np.any(rn > 10 * max(kw["eps"], np.finfo(np.float32 if single else np.float64).eps * 50) * aN):
             bad.append(dict(kind="values", maxres=float(rn.max()) if len(rn) else None, **desc))
 if leg == "host":
     json.dump(out_host, open(ref_file, "w"))
