@@ -365,7 +365,10 @@ static int pa_prelaunch_enqueue(pa_solver *s, int basisSize, int nLk, int col, i
    /* the tail without second-stage launches of its own (hipk_tail_defer): with the library's own operator, whose one-launch
     * form adds the partial sums of |t|^2 itself (one rank: row-partitioned runs need the global |t|^2 first) and leaves the
     * second stage of t'At to hipk_tail_finish */
-   const int acc = (p->matrixMatvec == primme_amd_matvec) ? hipk_tail_defer(s->ctx, xr ? HIPK_TAIL_DOT : (HIPK_TAIL_NORM | HIPK_TAIL_DOT)) : 0;
+   /* (one rank only: on the mailboxes the deferred second stage would also defer its exchange to a launch the host issues late —
+    * measured with the rows over 2 / 4 processes: 221 / 233 us per iteration against 198 / 211 with the second stages where
+    * they were, profiles/r06_ranks_sharing_one_gpu.txt) */
+   const int acc = (p->matrixMatvec == primme_amd_matvec && !xr) ? hipk_tail_defer(s->ctx, HIPK_TAIL_NORM | HIPK_TAIL_DOT) : 0;
    if (xr) hipk_xreduce_arm(s->ctx);
    CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov_alt, nov1, dst1, s->ld, TCOL(s, tcol), s->ld, 1, s->d_fov_alt + nfov1));
    if (xr && !hipk_xreduce_covered(s->ctx, s->d_fov_alt + nfov1, 1)) { hipk_tail_abandon(s->ctx); return 0; }
@@ -469,8 +472,8 @@ int pa_speculative_tail(pa_solver *s, int basisSize, int nLk, const char *rsrc, 
    /* Row-partitioned runs on the library's communicator: |t|^2 and t'At travel in ONE all-reduce (see below) */
    const int merge_red = fuse_tail && s->parallel && s->dev_comm && !xr;
    /* the one-launch tail of the library's own operator without second-stage launches of its own (hipk_tail_defer) */
-   const int acc = (fuse_tail && speculate2 && !merge_red && p->matrixMatvec == primme_amd_matvec)
-                 ? hipk_tail_defer(s->ctx, xr ? HIPK_TAIL_DOT : (HIPK_TAIL_NORM | HIPK_TAIL_DOT)) : 0;
+   const int acc = (fuse_tail && speculate2 && !merge_red && !xr && p->matrixMatvec == primme_amd_matvec)
+                 ? hipk_tail_defer(s->ctx, HIPK_TAIL_NORM | HIPK_TAIL_DOT) : 0;
    if (xr) hipk_xreduce_arm(s->ctx);
    CHK(hipk_panel_project_to(s->ctx, s->dt, s->m, segs, 2, s->d_fov, nov > 0 ? nov : 1, rsrc, s->ld,
               fuse_tail ? TCOL(s, 0) : dstc, s->ld, 1, s->d_fov + nfov));
