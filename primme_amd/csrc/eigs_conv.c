@@ -239,8 +239,14 @@ static int try_speculative_restart(pa_solver *s, int basisSize, int nLk, const i
    if (s->pl_L != nLk || rs < 1 || 8 + 2 * rs + 1 > 64 || ncv > 30 || s->h_theta2[cc] != s->hVals[col] ||
          memcmp(s->h_coef2 + (size_t)cc * K, s->hVecs + (size_t)col * ldh, (size_t)basisSize * sizeof(double)))
       return 0;                                  /* the candidate is not what the restart would continue with */
-   CHK(hipk_h2d(s->ctx, s->d_coef2, s->h_coef2, (size_t)K * (rs + 1) * sizeof(double)));
-   CHK(hipk_h2d(s->ctx, s->d_theta2, s->h_theta2, (size_t)basisSize * sizeof(double)));
+   /* one copy launch for the coefficient block and the Ritz values behind it (at most K*K + K doubles: K <= 32 here);
+    * PRIMME_AMD_RESTART_TWO_COPIES=1: the two launches of round 5 (A/B knob) */
+   static int two_copies = -1;
+   if (two_copies < 0) two_copies = getenv("PRIMME_AMD_RESTART_TWO_COPIES") != NULL;
+   if (two_copies) {
+      CHK(hipk_h2d(s->ctx, s->d_coef2, s->h_coef2, (size_t)K * (rs + 1) * sizeof(double)));
+      CHK(hipk_h2d(s->ctx, s->d_theta2, s->h_theta2, (size_t)basisSize * sizeof(double)));
+   } else CHK(hipk_h2d(s->ctx, s->d_coef2, s->h_coef2, ((size_t)K * K + basisSize) * sizeof(double)));
    hipk_job jobs[2 * 32 + 32 + 2];                /* rs <= 27 (twice), ncv <= 30, the unit column, the residual */
    int nj = 0;
    for (int c = 0; c < rs; c++) jobs[nj++] = (hipk_job){HIPK_JOB_XV, c, PCOL(s, s->V2, s->ld, c), -1};

@@ -814,8 +814,8 @@ static void free_solver(pa_solver *s) {
    if (s->ctx) {
       hipk_sync(s->ctx);
       hipk_free(s->ctx, s->V); hipk_free(s->ctx, s->W); hipk_free(s->ctx, s->T); hipk_free(s->ctx, s->Jw);
-      hipk_free(s->ctx, s->V2); hipk_free(s->ctx, s->W2); hipk_free(s->ctx, s->d_coef2); hipk_free(s->ctx, s->d_theta2);
-      hipk_host_free(s->ctx, s->h_coef2); hipk_host_free(s->ctx, s->h_theta2);
+      hipk_free(s->ctx, s->V2); hipk_free(s->ctx, s->W2); hipk_free(s->ctx, s->d_coef2);      /* (d_theta2 / h_theta2 live inside) */
+      hipk_host_free(s->ctx, s->h_coef2);
       hipk_free(s->ctx, s->evecsHat); hipk_free(s->ctx, s->Q); hipk_free(s->ctx, s->BT); hipk_free(s->ctx, s->Bevecs);
       hipk_free(s->ctx, s->d_red); hipk_free(s->ctx, s->d_coef); hipk_free(s->ctx, s->d_theta);
       hipk_host_free(s->ctx, s->h_red); hipk_host_free(s->ctx, s->h_coef); hipk_host_free(s->ctx, s->h_theta);
@@ -1029,12 +1029,16 @@ static int solve(void *evals_out, void *evecs, void *resNorms_out, primme_params
          s->red_cap >= 64 + 2 * HIPK_WTR_MAX_K && getenv("PRIMME_AMD_NO_SPEC_RESTART") == NULL) {
       /* alternate panels of the speculative restart (eigs_solver.h); without them the restart runs in place */
       if (hipk_malloc(s->ctx, colBytes * K, (void **)&s->V2) || hipk_malloc(s->ctx, colBytes * K, (void **)&s->W2) ||
-            hipk_malloc(s->ctx, (size_t)K * K * 8, (void **)&s->d_coef2) || hipk_malloc(s->ctx, (size_t)K * 8, (void **)&s->d_theta2) ||
-            hipk_host_alloc(s->ctx, (size_t)K * K * 8, (void **)&s->h_coef2) || hipk_host_alloc(s->ctx, (size_t)K * 8, (void **)&s->h_theta2)) {
-         hipk_free(s->ctx, s->V2); hipk_free(s->ctx, s->W2); hipk_free(s->ctx, s->d_coef2); hipk_free(s->ctx, s->d_theta2);
-         hipk_host_free(s->ctx, s->h_coef2); hipk_host_free(s->ctx, s->h_theta2);
-         s->V2 = s->W2 = NULL; s->d_coef2 = s->d_theta2 = s->h_coef2 = s->h_theta2 = NULL;
+            /* coefficient block and Ritz values of the planned restart in ONE buffer (values behind the K x K block), on the device
+             * and in the pinned mirror: they travel in one copy launch instead of two (eigs_conv.c:try_speculative_restart) */
+            hipk_malloc(s->ctx, (size_t)(K * K + K) * 8, (void **)&s->d_coef2) ||
+            hipk_host_alloc(s->ctx, (size_t)(K * K + K) * 8, (void **)&s->h_coef2)) {
+         hipk_free(s->ctx, s->V2); hipk_free(s->ctx, s->W2); hipk_free(s->ctx, s->d_coef2);
+         hipk_host_free(s->ctx, s->h_coef2);
+         s->V2 = s->W2 = NULL; s->d_coef2 = s->h_coef2 = NULL;
       }
+      s->d_theta2 = s->d_coef2 ? s->d_coef2 + (size_t)K * K : NULL;
+      s->h_theta2 = s->h_coef2 ? s->h_coef2 + (size_t)K * K : NULL;
    }
    if (rc || !s->H || !s->hVecs || !s->prevhVecs || !s->hVals || !s->prevRitzVals || !s->blockNorms ||
          !s->basisNorms || !s->flags || !s->map || !s->iev || !s->perm || !s->lockedFlags) {
