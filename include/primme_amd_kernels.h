@@ -223,6 +223,8 @@ int hipk_wait_seq(hipk_ctx *ctx, unsigned long long seq);
  * completion flag last.  The caller may enqueue it LATER than the tail itself (eigs_conv.c does: at the point where it knows
  * the Rayleigh-Ritz decomposition the next iteration's step needs) as long as nothing else used the context's reduction
  * scratch in between.  With nothing deferred it finishes what is pending the separate way and runs hipk_rr_arrow for in != NULL.
+ * (The solver arms a deferral on ONE rank only: with the rows over several ranks a deferred second stage also defers its
+ * exchange to a launch that comes late, measured 10 % slower per iteration than the separate launches — DESIGN.md section 4g.)
  * hipk_tail_abandon forgets an armed / pending tail (a pre-enqueued iteration that is thrown away). */
 #define HIPK_TAIL_NORM 1
 #define HIPK_TAIL_DOT 2
